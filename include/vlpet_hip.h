@@ -1,0 +1,126 @@
+/* vlpet_hip.h -- C ABI of the MI355X-native VL-PET hot path (libvlpet_hip.so).
+ *
+ * The reference (HenryHZY/VL-PET) has no FFI: its boundary for this path is the Python module
+ * contract between the forked transformer blocks and the PET operator packages.  Each entry
+ * point below names the reference op chain it replaces (paths relative to /root/reference/src);
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator in the
+ *     shipped host code); the library allocates nothing and keeps no state between calls;
+ *   - activations are row-major [M, d], contiguous, 16-byte aligned; d % 64 == 0;
+ *   - io_dtype: VLPET_BF16 (performance mode) or VLPET_F32 (parity mode: bf16 hi/lo split
+ *     products, fp32 accumulate); gradients of parameters are always fp32;
+ *   - work is enqueued on `stream` (a hipStream_t); no call synchronises;
+ *   - return value: 0 on success, a negative VLPET_E_* code for argument errors, or a positive
+ *     hipError_t; nothing is thrown across the boundary.
+ */
+#ifndef VLPET_HIP_H
+#define VLPET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLPET_F32 0
+#define VLPET_BF16 1
+
+#define VLPET_E_SHAPE (-1)      /* d % 64 != 0, M <= 0, r <= 0 ... */
+#define VLPET_E_RANK (-2)       /* bottleneck larger than 192 */
+#define VLPET_E_ALIGN (-3)      /* pointer not 16-byte aligned */
+#define VLPET_E_WORKSPACE (-4)  /* workspace too small */
+#define VLPET_E_NULL (-5)       /* required pointer is NULL */
+#define VLPET_E_DTYPE (-6)
+
+/* gate modes (config flags of the reference) */
+#define VLPET_GATE_NONE 0       /* adapter only                                              */
+#define VLPET_GATE_MUL 1        /* use_encoder_adapter_gating_large_x_lowrank:  h * sigmoid  */
+#define VLPET_GATE_ADD 2        /* ... + use_encoder_adapter_gating_add:         h + sigmoid */
+
+typedef void* vlpet_stream_t;   /* hipStream_t */
+
+int vlpet_version(void);
+const char* vlpet_error_string(int code);
+
+/* Number of 32-wide bottleneck tiles the kernels are instantiated for: 1 (r<=32), 3 (r<=96),
+ * 6 (r<=192); -2 (VLPET_E_RANK) above.  Ranks are zero-padded to 32*tiles inside the pack. */
+int vlpet_rank_tiles(int r);
+
+/* ---- weight packing -----------------------------------------------------------------------
+ * Re-pack one (down, up) projection pair into MFMA fragment order (+ cast / hi-lo split).  Call
+ * once per optimizer step per pair; forward and backward share the result.
+ *   wd_heads[n_heads]: blocks [r/n_heads, d] of the down weight -- the reference keeps the
+ *       multi-head down projection as a ModuleList of N_h Linears
+ *       (my_transformers/modeling_bart.py:1044-1051); adapters / LoRA pass n_heads = 1;
+ *   bd_heads[n_heads]: bias blocks or NULL (LoRA);  wu [d, r];  bu [d] or NULL;
+ *   param_dtype: dtype of the parameter tensors (VLPET_F32 / VLPET_BF16).
+ * `tiles` may exceed vlpet_rank_tiles(r) (e.g. to give adapter and gate the same tile count). */
+size_t vlpet_packed_bytes(int tiles, int d, int io_dtype);
+int vlpet_pack_pair(const void* const* wd_heads, const void* const* bd_heads, int n_heads,
+                    const void* wu, const void* bu, int r, int d, int tiles,
+                    int param_dtype, int io_dtype, void* packed, vlpet_stream_t stream);
+
+/* ---- K1: encoder granularity-controlled adapter + gate ------------------------------------
+ * out = ( x2_scale*x2 + delta_scale*up(gelu_new(down(x2))) ) (*|+) sigmoid(up_g(gelu_new(down_g(x1)))) * gate_scale
+ * replaces my_transformers/modeling_bart.py:1147-1155,1195-1209,1256-1257 (attention sublayer),
+ * :1270-1278,1317-1325,1372-1373 (FFN sublayer); my_transformers/modeling_t5.py:366-379,385-390,
+ * 405-406 and :782-795,801-806,821-822.  gate_mode VLPET_GATE_NONE ignores x1 / packed_g. */
+int vlpet_adapter_gate_fwd(const void* x1, const void* x2, const void* packed_a, const void* packed_g,
+                           void* out, int64_t M, int d, int tiles, int gate_mode,
+                           float delta_scale, float x2_scale, float gate_scale,
+                           int io_dtype, vlpet_stream_t stream);
+
+size_t vlpet_bwd_workspace_bytes(int64_t M, int d, int tiles, int has_gate, int io_dtype);
+
+/* Backward of the above (torch.autograd through the same lines in the reference).  Recomputes
+ * the forward intermediates from (x1, x2).  dx2 includes the residual path (x2_scale*dh); the
+ * parameter gradients are fp32, OVERWRITTEN (not accumulated):
+ *   dwd [r, d] (head blocks stacked), dbd [r], dwu [d, r], dbu [d]; same four for the gate with rg. */
+int vlpet_adapter_gate_bwd(const void* dy, const void* x1, const void* x2,
+                           const void* packed_a, const void* packed_g,
+                           void* dx1, void* dx2,
+                           float* dwd, float* dbd, float* dwu, float* dbu,
+                           float* dwgd, float* dbgd, float* dwgu, float* dbgu,
+                           int r, int rg, void* workspace, size_t workspace_bytes,
+                           int64_t M, int d, int tiles, int gate_mode,
+                           float delta_scale, float x2_scale, float gate_scale,
+                           int io_dtype, vlpet_stream_t stream);
+
+/* ---- K2: parallel adapter (decoder cross-attention value path) ----------------------------
+ * out = y + scale * up(gelu_new(down(x)))
+ * replaces adapters/adapter_modeling.py:55-61 + adapters/adapter_controller.py:149-162 as called at
+ * my_transformers/modeling_bart.py:427-430 and my_transformers/modeling_t5.py:600-603. */
+int vlpet_parallel_adapter_fwd(const void* x, const void* y, const void* packed, void* out,
+                               int64_t M, int d, int tiles, float scale,
+                               int io_dtype, vlpet_stream_t stream);
+/* dx is the adapter-branch gradient only; d/dy is dy itself and is not materialised. */
+int vlpet_parallel_adapter_bwd(const void* dy, const void* x, const void* packed, void* dx,
+                               float* dwd, float* dbd, float* dwu, float* dbu, int r,
+                               void* workspace, size_t workspace_bytes,
+                               int64_t M, int d, int tiles, float scale,
+                               int io_dtype, vlpet_stream_t stream);
+
+/* ---- K3: LoRA low-rank update on top of the frozen linear ---------------------------------
+ * out = base + scaling * ((dropout(x) @ A^T) @ B^T),  base = F.linear(x, W, b) computed by the caller
+ * replaces lora/controller.py:61-68 (the base GEMM at :59 stays a library GEMM).
+ * Square projections only (in_features == out_features == d: q_proj / v_proj,
+ * my_transformers/modeling_bart.py:767-768).  keep_mask: uint8 [M, d], 1 = keep, or NULL
+ * (eval / p = 0); keep_scale = 1/(1-p).  A = lora_As[task] [r, d], B = lora_Bs[task] [d, r]. */
+int vlpet_lora_delta_fwd(const void* x, const void* base, const void* packed,
+                         const uint8_t* keep_mask, float keep_scale, void* out,
+                         int64_t M, int d, int tiles, float scaling,
+                         int io_dtype, vlpet_stream_t stream);
+/* dx is the LoRA share of the input gradient (the caller adds dy @ W). */
+int vlpet_lora_delta_bwd(const void* dy, const void* x, const void* packed,
+                         const uint8_t* keep_mask, float keep_scale, void* dx,
+                         float* da, float* db, int r,
+                         void* workspace, size_t workspace_bytes,
+                         int64_t M, int d, int tiles, float scaling,
+                         int io_dtype, vlpet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLPET_HIP_H */

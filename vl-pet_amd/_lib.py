@@ -1,0 +1,66 @@
+"""ctypes binding of libvlpet_hip.so (the C ABI in include/vlpet_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails, a
+RuntimeError is raised."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvlpet_hip.so")
+
+VLPET_F32 = 0
+VLPET_BF16 = 1
+GATE_NONE, GATE_MUL, GATE_ADD = 0, 1, 2
+
+_lib = None
+
+# name -> (restype, argtypes); one row per declaration in include/vlpet_hip.h
+SIGNATURES = {
+    "vlpet_version": (c_int, []),
+    "vlpet_error_string": (c_char_p, [c_int]),
+    "vlpet_rank_tiles": (c_int, [c_int]),
+    "vlpet_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vlpet_pack_pair": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                c_void_p, c_void_p]),
+    "vlpet_adapter_gate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                       c_int, c_float, c_float, c_float, c_int, c_void_p]),
+    "vlpet_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
+    "vlpet_adapter_gate_bwd": (c_int, [c_void_p] * 7 + [c_void_p] * 8 + [c_int, c_int, c_void_p, c_size_t, c_int64,
+                                                                         c_int, c_int, c_int, c_float, c_float,
+                                                                         c_float, c_int, c_void_p]),
+    "vlpet_parallel_adapter_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float,
+                                           c_int, c_void_p]),
+    "vlpet_parallel_adapter_bwd": (c_int, [c_void_p] * 4 + [c_void_p] * 4 + [c_int, c_void_p, c_size_t, c_int64,
+                                                                             c_int, c_int, c_float, c_int, c_void_p]),
+    "vlpet_lora_delta_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int,
+                                     c_int, c_float, c_int, c_void_p]),
+    "vlpet_lora_delta_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_void_p, c_size_t, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
+}
+
+
+def load():
+    """Load the shared library (built in-tree by ``__graft_entry__.build()`` / ``make -C csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"vl-pet_amd: HIP library not found at {LIB_PATH}; run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (there is no CPU fallback for the PET hot path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().vlpet_error_string(code)
+        raise RuntimeError(f"vl-pet_amd: {what} failed: {msg.decode() if msg else code} (code {code})")

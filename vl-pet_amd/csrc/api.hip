@@ -1,0 +1,246 @@
+// C ABI of libvlpet_hip.so (declared in include/vlpet_hip.h): argument checking + launch plumbing.
+#include "../../include/vlpet_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+#define VLPET_VERSION 100
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+static inline int herr(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+extern "C" int vlpet_version(void) { return VLPET_VERSION; }
+
+extern "C" const char* vlpet_error_string(int code) {
+    switch (code) {
+        case 0: return "success";
+        case VLPET_E_SHAPE: return "bad shape (need M > 0, d % 64 == 0, r > 0)";
+        case VLPET_E_RANK: return "unsupported bottleneck rank (max 192) or tile count";
+        case VLPET_E_ALIGN: return "pointer not 16-byte aligned";
+        case VLPET_E_WORKSPACE: return "workspace too small";
+        case VLPET_E_NULL: return "required pointer is NULL";
+        case VLPET_E_DTYPE: return "unsupported dtype";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+extern "C" int vlpet_rank_tiles(int r) {
+    if (r <= 0) return VLPET_E_SHAPE;
+    if (r <= 32) return 1;
+    if (r <= 96) return 3;
+    if (r <= 192) return 6;
+    return VLPET_E_RANK;
+}
+
+static inline bool tiles_ok(int t) { return t == 1 || t == 3 || t == 6; }
+static inline bool dtype_ok(int t) { return t == VLPET_F32 || t == VLPET_BF16; }
+
+extern "C" size_t vlpet_packed_bytes(int tiles, int d, int io_dtype) {
+    return (size_t)pack_geom(tiles, d, io_dtype == VLPET_F32 ? 2 : 1).total_bytes;
+}
+
+extern "C" int vlpet_pack_pair(const void* const* wd_heads, const void* const* bd_heads, int n_heads,
+                               const void* wu, const void* bu, int r, int d, int tiles,
+                               int param_dtype, int io_dtype, void* packed, vlpet_stream_t stream) {
+    if (!wd_heads || !wu || !packed) return VLPET_E_NULL;
+    if (r <= 0 || d <= 0 || d % 64 != 0 || n_heads <= 0 || n_heads > VLPET_MAX_HEADS || r % n_heads != 0)
+        return VLPET_E_SHAPE;
+    if (!tiles_ok(tiles) || r > 32 * tiles) return VLPET_E_RANK;
+    if (!dtype_ok(param_dtype) || !dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    if (!aligned16(packed)) return VLPET_E_ALIGN;
+    PackArgs a;
+    for (int i = 0; i < VLPET_MAX_HEADS; ++i) {
+        a.wd[i] = i < n_heads ? wd_heads[i] : nullptr;
+        a.bd[i] = (bd_heads && i < n_heads) ? bd_heads[i] : nullptr;
+        if (i < n_heads && a.wd[i] == nullptr) return VLPET_E_NULL;
+    }
+    a.wu = wu; a.bu = bu;
+    a.n_heads = n_heads; a.rows_per_head = r / n_heads;
+    a.r = r; a.d = d; a.RT = tiles; a.src_bf16 = param_dtype == VLPET_BF16;
+    a.out = reinterpret_cast<uint8_t*>(packed);
+    return herr(launch_pack_pair(a, io_dtype == VLPET_F32 ? 2 : 1, (hipStream_t)stream));
+}
+
+static int check_common(int64_t M, int d, int tiles, int io_dtype) {
+    if (M <= 0 || d <= 0 || d % 64 != 0) return VLPET_E_SHAPE;
+    if (!tiles_ok(tiles)) return VLPET_E_RANK;
+    if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    return 0;
+}
+
+static int run_fwd(const void* xa, const void* res, const void* xg, const void* pk_a, const void* pk_g,
+                   const uint8_t* keep, float keep_scale, void* out, int64_t M, int d, int tiles,
+                   float s2, float sd, float gs, int flags, int io_dtype, vlpet_stream_t stream) {
+    int rc = check_common(M, d, tiles, io_dtype);
+    if (rc) return rc;
+    if (!xa || !res || !pk_a || !out) return VLPET_E_NULL;
+    if ((flags & PET_GATE) && (!xg || !pk_g)) return VLPET_E_NULL;
+    if (!aligned16(xa) || !aligned16(res) || !aligned16(out) || !aligned16(pk_a) ||
+        ((flags & PET_GATE) && (!aligned16(xg) || !aligned16(pk_g))) || (keep && !aligned16(keep)))
+        return VLPET_E_ALIGN;
+    PetFwdArgs a;
+    a.xa = xa; a.res = res; a.xg = xg; a.out = out;
+    a.pk_a = reinterpret_cast<const uint8_t*>(pk_a);
+    a.pk_g = reinterpret_cast<const uint8_t*>(pk_g);
+    a.keep = keep; a.keep_scale = keep_scale;
+    a.M = M; a.d = d; a.RT = tiles;
+    a.s2 = s2; a.sd = sd; a.gs = gs; a.flags = flags;
+    return herr(launch_pet_fwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_adapter_gate_fwd(const void* x1, const void* x2, const void* packed_a,
+                                      const void* packed_g, void* out, int64_t M, int d, int tiles,
+                                      int gate_mode, float delta_scale, float x2_scale, float gate_scale,
+                                      int io_dtype, vlpet_stream_t stream) {
+    int flags = 0;
+    if (gate_mode == VLPET_GATE_MUL) flags = PET_GATE;
+    else if (gate_mode == VLPET_GATE_ADD) flags = PET_GATE | PET_GATE_ADD;
+    else if (gate_mode != VLPET_GATE_NONE) return VLPET_E_SHAPE;
+    return run_fwd(x2, x2, x1, packed_a, packed_g, nullptr, 1.f, out, M, d, tiles, x2_scale, delta_scale,
+                   flags ? gate_scale : 1.f, flags, io_dtype, stream);
+}
+
+extern "C" int vlpet_parallel_adapter_fwd(const void* x, const void* y, const void* packed, void* out,
+                                          int64_t M, int d, int tiles, float scale, int io_dtype,
+                                          vlpet_stream_t stream) {
+    return run_fwd(x, y, nullptr, packed, nullptr, nullptr, 1.f, out, M, d, tiles, 1.f, scale, 1.f, 0, io_dtype, stream);
+}
+
+extern "C" int vlpet_lora_delta_fwd(const void* x, const void* base, const void* packed,
+                                    const uint8_t* keep_mask, float keep_scale, void* out, int64_t M, int d,
+                                    int tiles, float scaling, int io_dtype, vlpet_stream_t stream) {
+    return run_fwd(x, base, nullptr, packed, nullptr, keep_mask, keep_scale, out, M, d, tiles, 1.f, scaling, 1.f,
+                   PET_ACT_IDENTITY, io_dtype, stream);
+}
+
+// ------------------------------------------------------------------ backward workspace
+struct BwdWs {
+    size_t z_a, dp_a, z_g, dp_g, dh, dq, partial, total;
+    int row_chunks;
+    int64_t rows_per_chunk;
+};
+static BwdWs bwd_ws(int64_t M, int d, int tiles, bool gate, int io_dtype) {
+    BwdWs w{};
+    const size_t esz = io_dtype == VLPET_F32 ? 4 : 2;
+    const size_t side = align256((size_t)M * 32 * tiles * esz);
+    const size_t wide = align256((size_t)M * d * esz);
+    size_t o = 0;
+    w.z_a = o; o += side;
+    w.dp_a = o; o += side;
+    if (gate) {
+        w.z_g = o; o += side;
+        w.dp_g = o; o += side;
+        w.dh = o; o += wide;
+        w.dq = o; o += wide;
+    }
+    const int njobs = gate ? 4 : 2;
+    wgrad_plan(M, njobs, d, &w.row_chunks, &w.rows_per_chunk);
+    w.partial = o;
+    o += align256(wgrad_workspace_bytes(njobs, tiles, d, w.row_chunks));
+    w.total = o;
+    return w;
+}
+
+extern "C" size_t vlpet_bwd_workspace_bytes(int64_t M, int d, int tiles, int has_gate, int io_dtype) {
+    if (M <= 0 || d <= 0 || !tiles_ok(tiles)) return 0;
+    return bwd_ws(M, d, tiles, has_gate != 0, io_dtype).total;
+}
+
+static int run_bwd(const void* dy, const void* xa, const void* res, const void* xg,
+                   const void* pk_a, const void* pk_g, const uint8_t* keep, float keep_scale,
+                   void* dxa, void* dxg,
+                   float* dwd, float* dbd, float* dwu, float* dbu,
+                   float* dwgd, float* dbgd, float* dwgu, float* dbgu, int r, int rg,
+                   void* workspace, size_t workspace_bytes, int64_t M, int d, int tiles,
+                   float s2, float sd, float gs, int flags, int io_dtype, vlpet_stream_t stream) {
+    int rc = check_common(M, d, tiles, io_dtype);
+    if (rc) return rc;
+    const bool gate = flags & PET_GATE;
+    if (!dy || !xa || !pk_a || !dxa || !dwd || !dwu || !workspace) return VLPET_E_NULL;
+    if (gate && (!res || !xg || !pk_g || !dxg || !dwgd || !dwgu || !dbgd || !dbgu)) return VLPET_E_NULL;
+    if (r <= 0 || r > 32 * tiles || (gate && (rg <= 0 || rg > 32 * tiles))) return VLPET_E_RANK;
+    if (!aligned16(dy) || !aligned16(xa) || !aligned16(dxa) || !aligned16(workspace) || !aligned16(pk_a) ||
+        (gate && (!aligned16(xg) || !aligned16(res) || !aligned16(dxg) || !aligned16(pk_g))) ||
+        (keep && !aligned16(keep)))
+        return VLPET_E_ALIGN;
+    const BwdWs w = bwd_ws(M, d, tiles, gate, io_dtype);
+    if (workspace_bytes < w.total) return VLPET_E_WORKSPACE;
+    uint8_t* ws = reinterpret_cast<uint8_t*>(workspace);
+
+    PetBwdArgs b;
+    b.dy = dy; b.xa = xa; b.res = res; b.xg = xg;
+    b.dxa = dxa; b.dxg = dxg;
+    b.z_a = ws + w.z_a; b.dp_a = ws + w.dp_a;
+    b.z_g = gate ? ws + w.z_g : nullptr; b.dp_g = gate ? ws + w.dp_g : nullptr;
+    b.dh = gate ? ws + w.dh : nullptr; b.dq = gate ? ws + w.dq : nullptr;
+    b.pk_a = reinterpret_cast<const uint8_t*>(pk_a);
+    b.pk_g = reinterpret_cast<const uint8_t*>(pk_g);
+    b.keep = keep; b.keep_scale = keep_scale;
+    b.M = M; b.d = d; b.RT = tiles;
+    b.s2 = s2; b.sd = sd; b.gs = gs; b.flags = flags;
+    hipError_t e = launch_pet_bwd(b, io_dtype == VLPET_F32, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+
+    WgradArgs g{};
+    g.M = M; g.RT = tiles; g.row_chunks = w.row_chunks; g.rows_per_chunk = w.rows_per_chunk;
+    g.partial = reinterpret_cast<float*>(ws + w.partial);
+    const int ldp = 32 * tiles;
+    auto job = [&](int i, const void* P, const void* X, const uint8_t* kp, float scale, float* out, int ldo,
+                   int transposed, int out_rows, float* csx, float* csp) {
+        WgradJob& J = g.job[i];
+        J.P = P; J.ldp = ldp; J.pcols = ldp;
+        J.X = X; J.ldx = d; J.xcols = d;
+        J.keep = kp; J.keep_scale = keep_scale;
+        J.scale = scale; J.out = out; J.ldo = ldo; J.transposed = transposed; J.out_rows = out_rows;
+        J.colsum_x = csx; J.colsum_p = csp;
+    };
+    // down weight:  dWd[c,k] = sum_m dpre[m,c] * xa[m,k];  bias = column sums of dpre
+    job(0, b.dp_a, xa, keep, 1.f, dwd, d, 0, r, nullptr, dbd);
+    // up weight:    dWu[f,c] = sd * sum_m dh[m,f] * z[m,c]  (X = dh, or dy itself without a gate)
+    job(1, b.z_a, gate ? b.dh : dy, nullptr, sd, dwu, r, 1, r, dbu, nullptr);
+    g.njobs = 2;
+    if (gate) {
+        job(2, b.dp_g, xg, nullptr, 1.f, dwgd, d, 0, rg, nullptr, dbgd);
+        job(3, b.z_g, b.dq, nullptr, 1.f, dwgu, rg, 1, rg, dbgu, nullptr);
+        g.njobs = 4;
+    }
+    return herr(launch_wgrad(g, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_adapter_gate_bwd(const void* dy, const void* x1, const void* x2,
+                                      const void* packed_a, const void* packed_g, void* dx1, void* dx2,
+                                      float* dwd, float* dbd, float* dwu, float* dbu,
+                                      float* dwgd, float* dbgd, float* dwgu, float* dbgu, int r, int rg,
+                                      void* workspace, size_t workspace_bytes, int64_t M, int d, int tiles,
+                                      int gate_mode, float delta_scale, float x2_scale, float gate_scale,
+                                      int io_dtype, vlpet_stream_t stream) {
+    int flags = 0;
+    if (gate_mode == VLPET_GATE_MUL) flags = PET_GATE;
+    else if (gate_mode == VLPET_GATE_ADD) flags = PET_GATE | PET_GATE_ADD;
+    else if (gate_mode != VLPET_GATE_NONE) return VLPET_E_SHAPE;
+    if (!dbd || !dbu) return VLPET_E_NULL;
+    return run_bwd(dy, x2, x2, x1, packed_a, packed_g, nullptr, 1.f, dx2, dx1, dwd, dbd, dwu, dbu,
+                   dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
+                   x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream);
+}
+
+extern "C" int vlpet_parallel_adapter_bwd(const void* dy, const void* x, const void* packed, void* dx,
+                                          float* dwd, float* dbd, float* dwu, float* dbu, int r,
+                                          void* workspace, size_t workspace_bytes, int64_t M, int d,
+                                          int tiles, float scale, int io_dtype, vlpet_stream_t stream) {
+    if (!dbd || !dbu) return VLPET_E_NULL;
+    return run_bwd(dy, x, nullptr, nullptr, packed, nullptr, nullptr, 1.f, dx, nullptr, dwd, dbd, dwu, dbu,
+                   nullptr, nullptr, nullptr, nullptr, r, 0, workspace, workspace_bytes, M, d, tiles,
+                   1.f, scale, 1.f, 0, io_dtype, stream);
+}
+
+extern "C" int vlpet_lora_delta_bwd(const void* dy, const void* x, const void* packed,
+                                    const uint8_t* keep_mask, float keep_scale, void* dx,
+                                    float* da, float* db, int r, void* workspace, size_t workspace_bytes,
+                                    int64_t M, int d, int tiles, float scaling, int io_dtype,
+                                    vlpet_stream_t stream) {
+    return run_bwd(dy, x, nullptr, nullptr, packed, nullptr, keep_mask, keep_scale, dx, nullptr,
+                   da, nullptr, db, nullptr, nullptr, nullptr, nullptr, nullptr, r, 0,
+                   workspace, workspace_bytes, M, d, tiles, 1.f, scaling, 1.f, PET_ACT_IDENTITY,
+                   io_dtype, stream);
+}

@@ -1,0 +1,86 @@
+// Internal kernel argument blocks and launchers (the public C ABI is include/vlpet_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VLPET_MAX_HEADS 16
+
+struct PackArgs {
+    const void* wd[VLPET_MAX_HEADS];   // N_h blocks of the down weight, each [r/N_h, d]
+    const void* bd[VLPET_MAX_HEADS];   // N_h bias blocks (bd[0] == nullptr -> no bias)
+    const void* wu;                    // up weight [d, r]
+    const void* bu;                    // up bias [d] or nullptr
+    int n_heads, rows_per_head;
+    int r, d, RT;                      // true rank, width, padded rank / 32
+    int src_bf16;                      // parameter dtype: 0 fp32, 1 bf16
+    uint8_t* out;                      // packed pair (see pack_geom)
+};
+hipError_t launch_pack_pair(const PackArgs& a, int NS, hipStream_t stream);
+
+// flags
+#define PET_GATE 1        // chain G present: out = (res*s2 + sd*delta) (*|+) sigmoid(gate) * gs
+#define PET_GATE_ADD 2    // additive gate (use_encoder_adapter_gating_add)
+#define PET_ACT_IDENTITY 4  // LoRA: no nonlinearity between down and up
+
+struct PetFwdArgs {
+    const void* xa;     // chain-A input   [M,d]  (K1: x2, K2/K3: x)
+    const void* res;    // residual        [M,d]  (K1: x2, K2: y = v_proj(x), K3: base linear output)
+    const void* xg;     // gate input x1   [M,d]  (K1) or nullptr
+    void* out;          // [M,d]
+    const uint8_t* pk_a;   // packed pair, chain A
+    const uint8_t* pk_g;   // packed pair, chain G (gate) or nullptr
+    const uint8_t* keep;   // optional LoRA-dropout keep mask [M,d] uint8 (1 keep) or nullptr
+    float keep_scale;      // 1/(1-p)
+    int64_t M;
+    int d, RT;
+    float s2, sd, gs;      // x2 scale, delta scale, gate scale
+    int flags;
+};
+hipError_t launch_pet_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream);
+
+struct PetBwdArgs {
+    const void* dy;     // [M,d]
+    const void* xa;     // chain-A input
+    const void* res;    // residual (only read when PET_GATE: needed for h)
+    const void* xg;     // gate input
+    void* dxa;          // K1: d/dx2 (includes the residual path); K2/K3: d/dx of the adapter branch only
+    void* dxg;          // K1: d/dx1 of the gate branch
+    // row-major side products consumed by the weight-gradient kernel (IO dtype)
+    void* z_a; void* dp_a;      // [M, 32*RT] each
+    void* z_g; void* dp_g;      // [M, 32*RT] each (gate)
+    void* dh; void* dq;         // [M, d] each (gate only; without gate the wgrad reads dy itself)
+    const uint8_t* pk_a;
+    const uint8_t* pk_g;
+    const uint8_t* keep;
+    float keep_scale;
+    int64_t M;
+    int d, RT;
+    float s2, sd, gs;
+    int flags;
+};
+hipError_t launch_pet_bwd(const PetBwdArgs& a, int io_fp32, hipStream_t stream);
+
+// Weight gradients:  Out[c, n] = scale * sum_m P[m, c] * X[m, n]   (P skinny, X wide), plus the
+// column sums of X (bias of the "up" side) and of P (bias of the "down" side).
+struct WgradJob {
+    const void* P; int ldp; int pcols;     // P [M, ldp], columns [0, pcols) used, pcols = 32*RT
+    const void* X; int ldx; int xcols;     // X [M, ldx], xcols multiple of 64
+    const uint8_t* keep; float keep_scale; // optional dropout mask applied to X (LoRA down grad)
+    float scale;
+    float* out; int ldo; int transposed;   // transposed: out[n*ldo + c] else out[c*ldo + n]
+    int out_rows;                          // true rank r (rows c >= r are dropped)
+    float* colsum_x;                       // [xcols] or nullptr   (scale applied)
+    float* colsum_p;                       // [out_rows] or nullptr (no scale)
+};
+struct WgradArgs {
+    WgradJob job[4];
+    int njobs;
+    int64_t M;
+    int RT;
+    int row_chunks;        // RC
+    int64_t rows_per_chunk;  // multiple of 128
+    float* partial;        // workspace, see wgrad_workspace_bytes
+};
+size_t wgrad_workspace_bytes(int njobs, int RT, int xcols_max, int row_chunks);
+void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* rows_per_chunk);
+hipError_t launch_wgrad(const WgradArgs& a, int io_fp32, hipStream_t stream);

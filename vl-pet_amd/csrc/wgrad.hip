@@ -1,0 +1,285 @@
+// Column-parallel weight gradients for the PET hot path:
+//     Out[c, n] = scale * sum_m P[m, c] * X[m, n]        P: [M, 32*RT] (z or dpre), X: [M, xcols]
+// plus column sums of X and P (the bias gradients).  Grid = (64-column slice of X, row chunk, job);
+// up to four jobs per launch (dWd, dWu, dWgd, dWgu of one K1 call).
+//
+// Both operands arrive row-major, but the contraction index is the row m, so each wave loads its
+// 32 rows naturally (lane = row, 16/32 contiguous bytes) as an MFMA *A* fragment and multiplies it
+// by an identity B fragment: the product comes back in the C/D layout, i.e. transposed
+// (lane = column, registers = rows) -- exactly the A / B operand shape of the m-contraction.
+// No LDS transpose, no strided global access.  Row-chunk partials are written to a workspace
+// and summed by wgrad_finalize (deterministic: no atomics).
+#include "common.h"
+#include "kernels.h"
+
+struct WgradLayout {
+    int64_t off[4];      // float offset of each job's partial block
+    int64_t total;       // floats
+};
+__host__ __device__ inline WgradLayout wgrad_layout(const WgradArgs& a) {
+    WgradLayout L;
+    int64_t o = 0;
+    const int PR = 32 * a.RT;
+    for (int j = 0; j < 4; ++j) {
+        L.off[j] = o;
+        if (j < a.njobs) o += (int64_t)a.row_chunks * ((int64_t)PR * a.job[j].xcols + a.job[j].xcols + PR);
+    }
+    L.total = o;
+    return L;
+}
+
+size_t wgrad_workspace_bytes(int njobs, int RT, int xcols_max, int row_chunks) {
+    const int64_t PR = 32 * RT;
+    return (size_t)njobs * row_chunks * (PR * xcols_max + xcols_max + PR) * sizeof(float);
+}
+
+void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* rows_per_chunk) {
+    const int slices = xcols_max / 64;
+    int64_t blocks128 = (M + 127) / 128;
+    int64_t rc = (768 + (int64_t)slices * njobs - 1) / ((int64_t)slices * njobs);
+    if (rc < 1) rc = 1;
+    if (rc > blocks128) rc = blocks128;
+    int64_t per = (blocks128 + rc - 1) / rc;          // 128-row blocks per chunk
+    rc = (blocks128 + per - 1) / per;
+    *row_chunks = (int)rc;
+    *rows_per_chunk = per * 128;
+}
+
+template <typename IO, bool MASK>
+__device__ __forceinline__ Frag<IoTraits<IO>::NS> load_nat(const IO* p, bool valid, const uint8_t* keep,
+                                                           float keep_scale) {
+    constexpr int NS = IoTraits<IO>::NS;
+    float v[8];
+    if (valid) {
+        load8_f32(p, v);
+        if constexpr (MASK) {
+            if (keep != nullptr) {
+                const uint64_t k = *reinterpret_cast<const uint64_t*>(keep);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ((k >> (8 * j)) & 0xff) ? v[j] * keep_scale : 0.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    return frag_from_f32<NS>(v);
+}
+
+// transpose a [32 rows x 32 cols] tile given as two natural fragments (cols 0-15, 16-31)
+template <int NS>
+__device__ __forceinline__ f32x16 transpose_tile(const Frag<NS>& lo16, const Frag<NS>& hi16, bf16x8 I0, bf16x8 I1) {
+    f32x16 t = zero16();
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+        t = mfma32(lo16.p[p], I0, t);
+        t = mfma32(hi16.p[p], I1, t);
+    }
+    return t;
+}
+
+template <typename IO, int RT>
+__global__ __launch_bounds__(VLPET_THREADS) void wgrad_kernel(WgradArgs a) {
+    constexpr int NS = IoTraits<IO>::NS;
+    constexpr int KT = 2 * RT;
+    constexpr int PR = 32 * RT;
+    constexpr int NV = RT * 2 * 16 + RT + 2;     // per-lane values reduced across the 4 waves
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float* red = reinterpret_cast<float*>(smem);
+
+    const WgradJob& J = a.job[blockIdx.z];
+    const int n0 = blockIdx.x * 64;
+    if (n0 >= J.xcols) return;                  // uniform per block, before any barrier
+    const int rc = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int64_t r_begin = (int64_t)rc * a.rows_per_chunk;
+    int64_t r_end = r_begin + a.rows_per_chunk;
+    if (r_end > a.M) r_end = a.M;
+
+    bf16x8 I0, I1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        I0[j] = (m == 8 * h + j) ? (__bf16)1.0f : (__bf16)0.0f;
+        I1[j] = (m == 16 + 8 * h + j) ? (__bf16)1.0f : (__bf16)0.0f;
+    }
+
+    f32x16 acc[RT][2];
+    float csp[RT], csx[2];
+#pragma unroll
+    for (int ct = 0; ct < RT; ++ct) { acc[ct][0] = zero16(); acc[ct][1] = zero16(); csp[ct] = 0.f; }
+    csx[0] = csx[1] = 0.f;
+
+    const IO* P = reinterpret_cast<const IO*>(J.P);
+    const IO* X = reinterpret_cast<const IO*>(J.X);
+    for (int64_t rb = r_begin + 32 * wave; rb < r_end; rb += 128) {
+        const int64_t row = rb + m;
+        const bool valid = row < r_end;
+        const int64_t rowc = valid ? row : r_end - 1;
+        Frag<NS> pn[KT], xn[4];
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks)
+            pn[ks] = load_nat<IO, false>(P + rowc * J.ldp + 16 * ks + 8 * h, valid, nullptr, 1.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t off = rowc * J.ldx + n0 + 16 * q + 8 * h;
+            xn[q] = load_nat<IO, true>(X + off, valid, J.keep ? J.keep + off : nullptr, J.keep_scale);
+        }
+        Frag<NS> xt[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16 t = transpose_tile<NS>(xn[2 * nt], xn[2 * nt + 1], I0, I1);
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { v[i] = t[i]; csx[nt] += t[i]; }
+            xt[nt][0] = frag_from_f32<NS>(v);
+            xt[nt][1] = frag_from_f32<NS>(v + 8);
+        }
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct) {
+            f32x16 t = transpose_tile<NS>(pn[2 * ct], pn[2 * ct + 1], I0, I1);
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { v[i] = t[i]; csp[ct] += t[i]; }
+            Frag<NS> pt0 = frag_from_f32<NS>(v), pt1 = frag_from_f32<NS>(v + 8);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[ct][nt] = mfma_ns<NS>(pt0, xt[nt][0], acc[ct][nt]);
+                acc[ct][nt] = mfma_ns<NS>(pt1, xt[nt][1], acc[ct][nt]);
+            }
+        }
+    }
+
+    // ---- reduce the four waves (fixed order) and emit this chunk's partial
+    if (wave > 0) {
+        float* dst = red + (size_t)(wave - 1) * NV * 64;
+        int k = 0;
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dst[(k++) * 64 + lane] = acc[ct][nt][i];
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct) dst[(k++) * 64 + lane] = csp[ct];
+        dst[(k++) * 64 + lane] = csx[0];
+        dst[(k++) * 64 + lane] = csx[1];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 0; w < 3; ++w) {
+            const float* src = red + (size_t)w * NV * 64;
+            int k = 0;
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[ct][nt][i] += src[(k++) * 64 + lane];
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct) csp[ct] += src[(k++) * 64 + lane];
+            csx[0] += src[(k++) * 64 + lane];
+            csx[1] += src[(k++) * 64 + lane];
+        }
+        const WgradLayout L = wgrad_layout(a);
+        float* part = a.partial + L.off[blockIdx.z];
+        const int xc = J.xcols;
+        float* tile = part + (int64_t)rc * PR * xc;
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int crow = 32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    tile[(int64_t)crow * xc + n0 + 32 * nt + m] = acc[ct][nt][i];
+                }
+        // column sums: the two half-waves hold disjoint row subsets of the same column
+        float* psx = part + (int64_t)a.row_chunks * PR * xc + (int64_t)rc * xc;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float v = csx[nt] + __shfl_xor(csx[nt], 32);
+            if (h == 0) psx[n0 + 32 * nt + m] = v;
+        }
+        if (blockIdx.x == 0) {
+            float* psp = part + (int64_t)a.row_chunks * PR * xc + (int64_t)a.row_chunks * xc + (int64_t)rc * PR;
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct) {
+                const float v = csp[ct] + __shfl_xor(csp[ct], 32);
+                if (h == 0) psp[32 * ct + m] = v;
+            }
+        }
+    }
+}
+
+// sum the row-chunk partials, apply the scale, drop the rank padding, write in the parameter's layout
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(WgradArgs a) {
+    const WgradJob& J = a.job[blockIdx.y];
+    const int PR = 32 * a.RT;
+    const WgradLayout L = wgrad_layout(a);
+    const float* part = a.partial + L.off[blockIdx.y];
+    const int xc = J.xcols, R = J.out_rows, RC = a.row_chunks;
+    const int64_t nmat = (int64_t)R * xc;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < nmat) {
+        int c, n;
+        if (J.transposed) { n = (int)(gid / R); c = (int)(gid % R); }   // consecutive threads -> consecutive out
+        else { c = (int)(gid / xc); n = (int)(gid % xc); }
+        float s = 0.f;
+        for (int rc = 0; rc < RC; ++rc) s += part[((int64_t)rc * PR + c) * xc + n];
+        s *= J.scale;
+        if (J.transposed) J.out[(int64_t)n * J.ldo + c] = s;
+        else J.out[(int64_t)c * J.ldo + n] = s;
+    } else if (gid < nmat + xc) {
+        if (J.colsum_x != nullptr) {
+            const int n = (int)(gid - nmat);
+            const float* p = part + (int64_t)RC * PR * xc;
+            float s = 0.f;
+            for (int rc = 0; rc < RC; ++rc) s += p[(int64_t)rc * xc + n];
+            J.colsum_x[n] = s * J.scale;
+        }
+    } else if (gid < nmat + xc + R) {
+        if (J.colsum_p != nullptr) {
+            const int c = (int)(gid - nmat - xc);
+            const float* p = part + (int64_t)RC * PR * xc + (int64_t)RC * xc;
+            float s = 0.f;
+            for (int rc = 0; rc < RC; ++rc) s += p[(int64_t)rc * PR + c];
+            J.colsum_p[c] = s;
+        }
+    }
+}
+
+template <typename IO, int RT>
+static hipError_t launch_one(const WgradArgs& a, hipStream_t stream) {
+    constexpr int NV = RT * 2 * 16 + RT + 2;
+    const size_t lds = (size_t)3 * NV * 64 * sizeof(float);
+    auto kern = wgrad_kernel<IO, RT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int xmax = 0, rmax = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        if (a.job[j].xcols > xmax) xmax = a.job[j].xcols;
+        if (a.job[j].out_rows > rmax) rmax = a.job[j].out_rows;
+    }
+    hipLaunchKernelGGL(kern, dim3(xmax / 64, a.row_chunks, a.njobs), dim3(VLPET_THREADS), lds, stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int64_t elems = (int64_t)rmax * xmax + xmax + rmax;
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)((elems + 255) / 256), a.njobs), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+template <typename IO>
+static hipError_t launch_io(const WgradArgs& a, hipStream_t stream) {
+    switch (a.RT) {
+        case 1: return launch_one<IO, 1>(a, stream);
+        case 3: return launch_one<IO, 3>(a, stream);
+        case 6: return launch_one<IO, 6>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_wgrad(const WgradArgs& a, int io_fp32, hipStream_t stream) {
+    return io_fp32 ? launch_io<float>(a, stream) : launch_io<__bf16>(a, stream);
+}

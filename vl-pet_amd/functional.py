@@ -1,0 +1,290 @@
+"""torch.autograd glue over the C ABI (device memory, streams and autograd only -- the
+arithmetic lives in csrc/).  Every function here requires CUDA(ROCm) tensors and raises if the
+HIP library is unavailable; there is deliberately no eager fallback."""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+GATE_NONE, GATE_MUL, GATE_ADD = _lib.GATE_NONE, _lib.GATE_MUL, _lib.GATE_ADD
+
+
+def _io_dtype(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return _lib.VLPET_BF16
+    if t.dtype == torch.float32:
+        return _lib.VLPET_F32
+    raise RuntimeError(f"vl-pet_amd: unsupported activation dtype {t.dtype} (bf16 or fp32)")
+
+
+def _param_dtype(t: torch.Tensor) -> int:
+    return _io_dtype(t)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("vl-pet_amd: the PET hot path runs on the GPU only (got a CPU tensor)")
+
+
+def rank_tiles(r: int) -> int:
+    t = _lib.load().vlpet_rank_tiles(int(r))
+    if t < 0:
+        _lib.check(t, f"rank_tiles({r})")
+    return t
+
+
+class PackedPair:
+    """MFMA-fragment pack of one (down, up) projection pair (see packing.py / csrc/pack.hip)."""
+
+    __slots__ = ("buf", "tiles", "r", "d", "io_dtype")
+
+    def __init__(self, buf, tiles, r, d, io_dtype):
+        self.buf, self.tiles, self.r, self.d, self.io_dtype = buf, tiles, r, d, io_dtype
+
+
+def pack_pair(down_w: Sequence[torch.Tensor], down_b: Optional[Sequence[torch.Tensor]],
+              up_w: torch.Tensor, up_b: Optional[torch.Tensor], io_dtype: int,
+              tiles: Optional[int] = None) -> PackedPair:
+    lib = _lib.load()
+    _need_cuda(up_w, *down_w)
+    n = len(down_w)
+    rh, d = down_w[0].shape
+    r = rh * n
+    if tuple(up_w.shape) != (d, r):
+        raise RuntimeError(f"vl-pet_amd: up weight {tuple(up_w.shape)} does not match down {r}x{d}")
+    if tiles is None:
+        tiles = rank_tiles(r)
+    ws = [w.detach().contiguous() for w in down_w]
+    bs = [b.detach().contiguous() for b in down_b] if down_b is not None else None
+    uw = up_w.detach().contiguous()
+    ub = up_b.detach().contiguous() if up_b is not None else None
+    pd = _param_dtype(uw)
+    for t in ws + (bs or []) + ([ub] if ub is not None else []):
+        if _param_dtype(t) != pd:
+            raise RuntimeError("vl-pet_amd: mixed parameter dtypes in one projection pair")
+    nbytes = lib.vlpet_packed_bytes(tiles, d, io_dtype)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=uw.device)
+    arr_w = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+    arr_b = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bs]) if bs is not None else None
+    rc = lib.vlpet_pack_pair(arr_w, arr_b, n, uw.data_ptr(), _ptr(ub), r, d, tiles, pd, io_dtype,
+                             buf.data_ptr(), _stream())
+    _lib.check(rc, "vlpet_pack_pair")
+    return PackedPair(buf, tiles, r, d, io_dtype)
+
+
+class PackCache:
+    """Re-pack only when a parameter changed (optimizer steps bump ``Tensor._version``)."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, down_w, down_b, up_w, up_b, io_dtype, tiles=None) -> PackedPair:
+        ts = list(down_w) + (list(down_b) if down_b is not None else []) + [up_w] + ([up_b] if up_b is not None else [])
+        key = (io_dtype, tiles) + tuple((t.data_ptr(), t._version) for t in ts)
+        if key != self._key:
+            self._val = pack_pair(down_w, down_b, up_w, up_b, io_dtype, tiles)
+            self._key = key
+        return self._val
+
+
+def _flat(x: torch.Tensor, d: int) -> torch.Tensor:
+    x = x.reshape(-1, d)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def _grad_like(g32: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    return g32 if p.dtype == torch.float32 else g32.to(p.dtype)
+
+
+class _AdapterGateFn(torch.autograd.Function):
+    """K1.  inputs: x1, x2, then N_h down weights, N_h down biases, up w, up b, gate down w/b, gate up w/b."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, pk_a, pk_g, n_heads, gate_mode, delta_scale, x2_scale, gate_scale, *params):
+        lib = _lib.load()
+        _need_cuda(x1, x2)
+        d = x2.shape[-1]
+        io = _io_dtype(x2)
+        x2f = _flat(x2, d)
+        x1f = _flat(x1, d) if gate_mode != GATE_NONE else None
+        M = x2f.shape[0]
+        out = torch.empty_like(x2f)
+        rc = lib.vlpet_adapter_gate_fwd(_ptr(x1f), x2f.data_ptr(), pk_a.buf.data_ptr(),
+                                        pk_g.buf.data_ptr() if pk_g is not None else None,
+                                        out.data_ptr(), M, d, pk_a.tiles, gate_mode,
+                                        float(delta_scale), float(x2_scale), float(gate_scale), io, _stream())
+        _lib.check(rc, "vlpet_adapter_gate_fwd")
+        ctx.save_for_backward(x1f if x1f is not None else x2f, x2f, *params)
+        ctx.pk = (pk_a, pk_g)
+        ctx.cfg = (n_heads, gate_mode, float(delta_scale), float(x2_scale), float(gate_scale), x2.shape,
+                   x1.shape if x1 is not None else None)
+        return out.view(x2.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x1f, x2f, *params = ctx.saved_tensors
+        pk_a, pk_g = ctx.pk
+        n_heads, gate_mode, sd, s2, gs, shp2, shp1 = ctx.cfg
+        M, d = x2f.shape
+        io = _io_dtype(x2f)
+        gate = gate_mode != GATE_NONE
+        dyf = _flat(dy, d)
+        dev = x2f.device
+        r = pk_a.r
+        rg = pk_g.r if gate else 0
+        f32 = dict(dtype=torch.float32, device=dev)
+        dwd, dbd, dwu, dbu = (torch.empty(r, d, **f32), torch.empty(r, **f32), torch.empty(d, r, **f32),
+                              torch.empty(d, **f32))
+        dwgd = dbgd = dwgu = dbgu = None
+        if gate:
+            dwgd, dbgd, dwgu, dbgu = (torch.empty(rg, d, **f32), torch.empty(rg, **f32),
+                                      torch.empty(d, rg, **f32), torch.empty(d, **f32))
+        dx2 = torch.empty_like(x2f)
+        dx1 = torch.empty_like(x2f) if gate else None
+        nws = lib.vlpet_bwd_workspace_bytes(M, d, pk_a.tiles, int(gate), io)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        rc = lib.vlpet_adapter_gate_bwd(dyf.data_ptr(), _ptr(x1f) if gate else None, x2f.data_ptr(),
+                                        pk_a.buf.data_ptr(), pk_g.buf.data_ptr() if gate else None,
+                                        _ptr(dx1), dx2.data_ptr(),
+                                        dwd.data_ptr(), dbd.data_ptr(), dwu.data_ptr(), dbu.data_ptr(),
+                                        _ptr(dwgd), _ptr(dbgd), _ptr(dwgu), _ptr(dbgu), r, rg,
+                                        ws.data_ptr(), nws, M, d, pk_a.tiles, gate_mode, sd, s2, gs, io, _stream())
+        _lib.check(rc, "vlpet_adapter_gate_bwd")
+        if not gate:
+            # without a gate the kernel returns the adapter-branch gradient only; add the residual path
+            dx2 = dx2 + s2 * dyf
+        rh = r // n_heads
+        grads: List[Optional[torch.Tensor]] = []
+        for i in range(n_heads):
+            grads.append(_grad_like(dwd[i * rh:(i + 1) * rh], params[i]))
+        for i in range(n_heads):
+            grads.append(_grad_like(dbd[i * rh:(i + 1) * rh], params[n_heads + i]))
+        grads.append(_grad_like(dwu, params[2 * n_heads]))
+        grads.append(_grad_like(dbu, params[2 * n_heads + 1]))
+        if gate:
+            base = 2 * n_heads + 2
+            grads += [_grad_like(dwgd, params[base]), _grad_like(dbgd, params[base + 1]),
+                      _grad_like(dwgu, params[base + 2]), _grad_like(dbgu, params[base + 3])]
+        gx1 = dx1.view(shp1) if gate else None
+        return (gx1, dx2.view(shp2), None, None, None, None, None, None, None, *grads)
+
+
+def adapter_gate(x1, x2, down_w, down_b, up_w, up_b, gate_params, pk_a: PackedPair, pk_g: Optional[PackedPair],
+                 gate_mode=GATE_MUL, delta_scale=1.0, x2_scale=1.0, gate_scale=1.0):
+    """Encoder granularity-controlled adapter (+ low-rank gate).  ``gate_params`` =
+    (gate_down_w, gate_down_b, gate_up_w, gate_up_b) or None."""
+    params = list(down_w) + list(down_b) + [up_w, up_b]
+    if gate_mode != GATE_NONE:
+        params += list(gate_params)
+    return _AdapterGateFn.apply(x1, x2, pk_a, pk_g, len(down_w), gate_mode, delta_scale, x2_scale, gate_scale, *params)
+
+
+class _ParallelAdapterFn(torch.autograd.Function):
+    """K2: out = y + scale * up(gelu_new(down(x)))."""
+
+    @staticmethod
+    def forward(ctx, x, y, pk, scale, wd, bd, wu, bu):
+        lib = _lib.load()
+        _need_cuda(x, y)
+        d = x.shape[-1]
+        io = _io_dtype(x)
+        xf, yf = _flat(x, d), _flat(y, d)
+        M = xf.shape[0]
+        out = torch.empty_like(xf)
+        rc = lib.vlpet_parallel_adapter_fwd(xf.data_ptr(), yf.data_ptr(), pk.buf.data_ptr(), out.data_ptr(),
+                                            M, d, pk.tiles, float(scale), io, _stream())
+        _lib.check(rc, "vlpet_parallel_adapter_fwd")
+        ctx.save_for_backward(xf, wd, bd, wu, bu)
+        ctx.pk, ctx.scale, ctx.shape = pk, float(scale), x.shape
+        return out.view(y.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        xf, wd, bd, wu, bu = ctx.saved_tensors
+        pk = ctx.pk
+        M, d = xf.shape
+        io = _io_dtype(xf)
+        dyf = _flat(dy, d)
+        f32 = dict(dtype=torch.float32, device=xf.device)
+        r = pk.r
+        dwd, dbd, dwu, dbu = (torch.empty(r, d, **f32), torch.empty(r, **f32), torch.empty(d, r, **f32),
+                              torch.empty(d, **f32))
+        dx = torch.empty_like(xf)
+        nws = lib.vlpet_bwd_workspace_bytes(M, d, pk.tiles, 0, io)
+        ws = torch.empty(nws, dtype=torch.uint8, device=xf.device)
+        rc = lib.vlpet_parallel_adapter_bwd(dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), dx.data_ptr(),
+                                            dwd.data_ptr(), dbd.data_ptr(), dwu.data_ptr(), dbu.data_ptr(), r,
+                                            ws.data_ptr(), nws, M, d, pk.tiles, ctx.scale, io, _stream())
+        _lib.check(rc, "vlpet_parallel_adapter_bwd")
+        return (dx.view(ctx.shape), dy, None, None, _grad_like(dwd, wd), _grad_like(dbd, bd),
+                _grad_like(dwu, wu), _grad_like(dbu, bu))
+
+
+def parallel_adapter(x, y, wd, bd, wu, bu, pk: PackedPair, scale: float = 1.0):
+    return _ParallelAdapterFn.apply(x, y, pk, scale, wd, bd, wu, bu)
+
+
+class _LoraDeltaFn(torch.autograd.Function):
+    """K3: out = base + scaling * ((dropout(x) A^T) B^T); base comes from the library GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, base, pk, scaling, keep, keep_scale, lora_a, lora_b):
+        lib = _lib.load()
+        _need_cuda(x, base)
+        d = x.shape[-1]
+        io = _io_dtype(x)
+        xf, bf = _flat(x, d), _flat(base, d)
+        M = xf.shape[0]
+        out = torch.empty_like(bf)
+        kf = None
+        if keep is not None:
+            kf = _flat(keep, d)
+            if kf.dtype != torch.uint8:
+                kf = kf.to(torch.uint8)
+        rc = lib.vlpet_lora_delta_fwd(xf.data_ptr(), bf.data_ptr(), pk.buf.data_ptr(), _ptr(kf), float(keep_scale),
+                                      out.data_ptr(), M, d, pk.tiles, float(scaling), io, _stream())
+        _lib.check(rc, "vlpet_lora_delta_fwd")
+        ctx.save_for_backward(xf, lora_a, lora_b)
+        ctx.keep = kf
+        ctx.cfg = (pk, float(scaling), float(keep_scale), x.shape)
+        return out.view(base.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        xf, lora_a, lora_b = ctx.saved_tensors
+        pk, scaling, keep_scale, shape = ctx.cfg
+        M, d = xf.shape
+        io = _io_dtype(xf)
+        dyf = _flat(dy, d)
+        f32 = dict(dtype=torch.float32, device=xf.device)
+        r = pk.r
+        da, db = torch.empty(r, d, **f32), torch.empty(d, r, **f32)
+        dx = torch.empty_like(xf)
+        nws = lib.vlpet_bwd_workspace_bytes(M, d, pk.tiles, 0, io)
+        ws = torch.empty(nws, dtype=torch.uint8, device=xf.device)
+        rc = lib.vlpet_lora_delta_bwd(dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), _ptr(ctx.keep), keep_scale,
+                                      dx.data_ptr(), da.data_ptr(), db.data_ptr(), r, ws.data_ptr(), nws,
+                                      M, d, pk.tiles, scaling, io, _stream())
+        _lib.check(rc, "vlpet_lora_delta_bwd")
+        return dx.view(shape), dy, None, None, None, None, _grad_like(da, lora_a), _grad_like(db, lora_b)
+
+
+def lora_delta(x, base, lora_a, lora_b, pk: PackedPair, scaling: float, keep=None, keep_scale: float = 1.0):
+    return _LoraDeltaFn.apply(x, base, pk, scaling, keep, keep_scale, lora_a, lora_b)
