@@ -78,12 +78,12 @@ def run_k2(dtype, M=224, d=768, r=96, scale=1.0, seed=1):
     W = dict(wd=_rand(g, r, d, scale=1 / math.sqrt(d)), bd=_rand(g, r, scale=0.1),
              wu=_rand(g, d, r, scale=1 / math.sqrt(r)), bu=_rand(g, d, scale=0.1))
     ref = {k: v.clone().requires_grad_(True) for k, v in W.items()}
-    xr, yr = x.float().requires_grad_(True), y.float().requires_grad_(True)
+    xr, yr = x.float().clone().requires_grad_(True), y.float().clone().requires_grad_(True)
     out_ref = O.parallel_adapter(xr, yr, ref["wd"], ref["bd"], ref["wu"], ref["bu"], scale)
     out_ref.backward(dy.float())
     dev = "cuda"
     P = {k: v.to(dev).requires_grad_(True) for k, v in W.items()}
-    xg, yg = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    xg, yg = x.detach().to(dev).requires_grad_(True), y.detach().to(dev).requires_grad_(True)
     pk = F.pack_pair([P["wd"]], [P["bd"]], P["wu"], P["bu"], F._io_dtype(xg))
     out = F.parallel_adapter(xg, yg, P["wd"], P["bd"], P["wu"], P["bu"], pk, scale)
     out.backward(dy.to(dev))
@@ -102,14 +102,14 @@ def run_k3(dtype, M=200, d=768, r=8, alpha=32, p=0.0, seed=2):
     A, B = _rand(g, r, d, scale=1 / math.sqrt(d)), _rand(g, d, r, scale=0.3)
     keep = (torch.rand(M, d, generator=g) >= p) if p > 0 else None
     scaling = alpha / r
-    xr = x.float().requires_grad_(True)
+    xr = x.float().clone().requires_grad_(True)
     Ar, Br = A.clone().requires_grad_(True), B.clone().requires_grad_(True)
     base_ref = torch.nn.functional.linear(xr, w, b)
     lora_ref = O.lora_linear(xr, torch.zeros_like(w), None, Ar, Br, scaling, keep, p)
     (base_ref.detach() + lora_ref).backward(dy.float())   # LoRA share of dx only
     out_ref = base_ref.detach() + lora_ref.detach()
     dev = "cuda"
-    xg = x.to(dev).requires_grad_(True)
+    xg = x.detach().to(dev).requires_grad_(True)
     Ag, Bg = A.to(dev).requires_grad_(True), B.to(dev).requires_grad_(True)
     base = torch.nn.functional.linear(xg.detach().float(), w.to(dev), b.to(dev)).to(dtype)
     pk = F.pack_pair([Ag], None, Bg, None, F._io_dtype(xg))
