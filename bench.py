@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- multitask fine-tuning throughput of the MI355X-native VL-PET path.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): BART-base + VL-PET-large (r = r_g = dec r = 96, N_h = 4),
+image-text multitask, bf16 activations / frozen weights, fp32 trainable masters.  One step = one full
+train step (forward, backward, gradient exchange, clip 5.0, AdamW) on one task batch; steps cycle
+vqa -> gqa -> nlvr -> caption with the reference's per-task batch sizes (500 / 833 / 166 / 416,
+multitask.py:682-695) per GPU (weak scaling).  Synthetic CLIP-feature + token batches are resident in
+HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s measured achievable)
+TASK_ORDER = ["vqa", "gqa", "nlvr", "caption"]
+
+
+def cpu_baseline(steps=10, warm=3, batch=4):
+    """Reference path restated on the host CPU (kind "port"): the same host model with the PET ops
+    routed to oracle/vlpet_oracle.py (plain eager PyTorch in the reference's op order), full train step,
+    fp32, BASELINE.json configs[0] (VQA, batch 4)."""
+    import vlpet_amd.host.bart as HB
+    import vlpet_amd.train as TR
+    from vlpet_amd.adapters.adapter_modeling import Adapter
+    from oracle import vlpet_oracle as O
+
+    def cpu_apply_pet(module, which, x1, x2, config):
+        downs = getattr(module, f"{which}_adapter_multihead_down")
+        up = getattr(module, f"{which}_adapter_multihead_up")
+        gd = getattr(module, f"encoder_{which}_adapter_gating_large_x_down")
+        gu = getattr(module, f"encoder_{which}_adapter_gating_large_x_up")
+        gate = dict(down_w=gd.weight, down_b=gd.bias, up_w=gu.weight, up_b=gu.bias)
+        return O.encoder_adapter_gate(x1, x2, [m.weight for m in downs], [m.bias for m in downs], up.weight, up.bias,
+                                      gate, O.GATE_LARGE)
+
+    def cpu_fused(self, x, residual, scale=1.0):
+        return O.parallel_adapter(x, residual, self.down_sampler.weight, self.down_sampler.bias,
+                                  self.up_sampler.weight, self.up_sampler.bias, None if scale == 1.0 else scale)
+
+    saved = (HB.apply_pet, Adapter.fused)
+    HB.apply_pet, Adapter.fused = cpu_apply_pet, cpu_fused
+    try:
+        torch.manual_seed(1234)
+        cfg = HB.vlpet_config()
+        model = HB.VLBart(cfg)
+        TR.trainable_names(model, cfg)
+        model.train()
+        tr = TR.Trainer(model, cfg, total_steps=1000)
+        gen = torch.Generator().manual_seed(1234)
+        b = TR.synthetic_batch("vqa", batch, cfg, "cpu", gen)
+        for _ in range(warm):
+            tr.step(b)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step(b)
+        dt = time.perf_counter() - t0
+    finally:
+        HB.apply_pet, Adapter.fused = saved
+    return dict(value=round(batch * steps / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"configs[0]: BART-base VL-PET-large r=96, VQA batch {batch}, S=20+36, fp32, full train step "
+                       f"(fwd+bwd+clip+AdamW) through oracle/vlpet_oracle.py on the host CPU, {warm} warm-up + "
+                       f"{steps} timed steps ({dt:.1f} s)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=500, help="per-GPU VQA batch (other tasks scale like the reference)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--buckets", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import vlpet_amd.functional as VF
+    import vlpet_amd.host.bart as HB
+    import vlpet_amd.train as TR
+    from vlpet_amd import _lib
+    _lib.load()     # fail loudly before anything is timed
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(1234)      # same initial state on every rank: no parameter broadcast needed
+    cfg = HB.vlpet_config()
+    model = HB.VLBart(cfg)
+    names = TR.trainable_names(model, cfg)
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    model.to(dev)
+    TR.cast_frozen(model, dtype)
+    model.train()
+    total_steps = max(args.steps + args.warmup, 10)
+    tr = TR.Trainer(model, cfg, lr=1e-3, clip=5.0, total_steps=total_steps, world_size=world, n_buckets=args.buckets)
+
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    batches = {t: TR.synthetic_batch(t, TR.TASK_BATCH[t](args.batch), cfg, dev, gen) for t in TASK_ORDER}
+    order = [TASK_ORDER[i % 4] for i in range(args.warmup + args.steps)]
+
+    for i in range(args.warmup):
+        tr.step(batches[order[i]])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    VF.TIMER = VF.KernelTimer()
+    t0 = time.perf_counter()
+    samples = 0
+    for i in range(args.warmup, args.warmup + args.steps):
+        b = batches[order[i]]
+        tr.step(b)
+        samples += b["input_ids"].shape[0]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer, VF.TIMER = VF.TIMER, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        s = torch.tensor([samples], device=dev, dtype=torch.float64)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        samples = int(s.item())
+
+    if rank == 0:
+        esz = 2 if dtype == torch.bfloat16 else 4
+        d = cfg.d_model
+        agg = timer.summary()
+        # algorithmic bytes per row: fwd reads x1, x2, writes y; bwd rows reads dy, x1, x2, writes dx1, dx2
+        per_row = {"k1_fwd": 3 * d * esz, "k1_bwd_rows": 5 * d * esz, "k1_bwd_wgrad": 0, "k2_fwd": 3 * d * esz,
+                   "k2_bwd": 3 * d * esz}
+        kernels = {}
+        for name, a in agg.items():
+            by = per_row.get(name, 0) * a["rows"]
+            kernels[name] = dict(launches=a["launches"], avg_us=round(a["total_us"] / a["launches"], 2),
+                                 total_ms=round(a["total_us"] / 1e3, 3),
+                                 algorithmic_GBps=round(by / a["total_us"] / 1e3, 1) if by else None)
+        # dominant HIP kernel of the hot path by time: the row-parallel K1 backward
+        dom = "k1_bwd_rows" if "k1_bwd_rows" in agg else "k1_fwd"
+        a = agg[dom]
+        achieved = per_row[dom] * a["rows"] / a["total_us"] / 1e3     # GB/s
+        roof = dict(bound="hbm", kernel={"k1_bwd_rows": "pet_bwd_kernel<bf16,3,gate>",
+                                         "k1_fwd": "pet_fwd_kernel<bf16,3,gate>"}[dom],
+                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                    traffic=None, avg_launch_us=round(a["total_us"] / a["launches"], 2),
+                    avg_rows_per_launch=round(a["rows"] / a["launches"], 1),
+                    algorithmic_bytes_per_row=per_row[dom])
+        out = {
+            "metric": "multitask samples/sec (BART-base, r=96)", "value": round(samples / dt, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: BART-base + VL-PET-large (r=96) image-text multitask, full train step "
+                                   "(fwd+bwd+grad exchange+clip+AdamW), random-init weights",
+                       "per_gpu_task_batch": {t: TR.TASK_BATCH[t](args.batch) for t in TASK_ORDER},
+                       "enc_rows_per_step": {t: TR.TASK_BATCH[t](args.batch) * (TR.TEXT_LEN[t] + (72 if t == "nlvr" else 36))
+                                             for t in TASK_ORDER},
+                       "trainable_params": n_train, "parallelism": f"dp{world}"},
+            "roofline": roof, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

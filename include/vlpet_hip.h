@@ -88,6 +88,19 @@ int vlpet_adapter_gate_bwd(const void* dy, const void* x1, const void* x2,
                            float delta_scale, float x2_scale, float gate_scale,
                            int io_dtype, vlpet_stream_t stream);
 
+/* The two halves of vlpet_adapter_gate_bwd, selectable so a profiler / bench can bracket them with its
+ * own events: phases bit 0 = row-parallel kernel (dx1, dx2 + side products in the workspace),
+ * bit 1 = column-parallel weight gradients (reads the side products).  phases = 3 is the full call. */
+int vlpet_adapter_gate_bwd_phase(int phases, const void* dy, const void* x1, const void* x2,
+                                 const void* packed_a, const void* packed_g,
+                                 void* dx1, void* dx2,
+                                 float* dwd, float* dbd, float* dwu, float* dbu,
+                                 float* dwgd, float* dbgd, float* dwgu, float* dbgu,
+                                 int r, int rg, void* workspace, size_t workspace_bytes,
+                                 int64_t M, int d, int tiles, int gate_mode,
+                                 float delta_scale, float x2_scale, float gate_scale,
+                                 int io_dtype, vlpet_stream_t stream);
+
 /* ---- K2: parallel adapter (decoder cross-attention value path) ----------------------------
  * out = y + scale * up(gelu_new(down(x)))
  * replaces adapters/adapter_modeling.py:55-61 + adapters/adapter_controller.py:149-162 as called at

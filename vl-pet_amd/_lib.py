@@ -31,6 +31,10 @@ SIGNATURES = {
     "vlpet_adapter_gate_bwd": (c_int, [c_void_p] * 7 + [c_void_p] * 8 + [c_int, c_int, c_void_p, c_size_t, c_int64,
                                                                          c_int, c_int, c_int, c_float, c_float,
                                                                          c_float, c_int, c_void_p]),
+    "vlpet_adapter_gate_bwd_phase": (c_int, [c_int] + [c_void_p] * 7 + [c_void_p] * 8 + [c_int, c_int, c_void_p, c_size_t,
+                                                                                        c_int64, c_int, c_int, c_int,
+                                                                                        c_float, c_float, c_float, c_int,
+                                                                                        c_void_p]),
     "vlpet_parallel_adapter_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float,
                                            c_int, c_void_p]),
     "vlpet_parallel_adapter_bwd": (c_int, [c_void_p] * 4 + [c_void_p] * 4 + [c_int, c_void_p, c_size_t, c_int64,

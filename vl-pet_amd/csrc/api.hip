@@ -152,7 +152,8 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
                    float* dwd, float* dbd, float* dwu, float* dbu,
                    float* dwgd, float* dbgd, float* dwgu, float* dbgu, int r, int rg,
                    void* workspace, size_t workspace_bytes, int64_t M, int d, int tiles,
-                   float s2, float sd, float gs, int flags, int io_dtype, vlpet_stream_t stream) {
+                   float s2, float sd, float gs, int flags, int io_dtype, vlpet_stream_t stream,
+                   int phases = 3 /* bit0: row-parallel kernel, bit1: weight gradients */) {
     int rc = check_common(M, d, tiles, io_dtype);
     if (rc) return rc;
     const bool gate = flags & PET_GATE;
@@ -178,8 +179,11 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     b.keep = keep; b.keep_scale = keep_scale;
     b.M = M; b.d = d; b.RT = tiles;
     b.s2 = s2; b.sd = sd; b.gs = gs; b.flags = flags;
-    hipError_t e = launch_pet_bwd(b, io_dtype == VLPET_F32, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
+    if (phases & 1) {
+        hipError_t e = launch_pet_bwd(b, io_dtype == VLPET_F32, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (!(phases & 2)) return 0;
 
     WgradArgs g{};
     g.M = M; g.RT = tiles; g.row_chunks = w.row_chunks; g.rows_per_chunk = w.rows_per_chunk;
@@ -222,6 +226,29 @@ extern "C" int vlpet_adapter_gate_bwd(const void* dy, const void* x1, const void
     return run_bwd(dy, x2, x2, x1, packed_a, packed_g, nullptr, 1.f, dx2, dx1, dwd, dbd, dwu, dbu,
                    dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
                    x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream);
+}
+
+static int gate_flags(int gate_mode, int* flags) {
+    *flags = 0;
+    if (gate_mode == VLPET_GATE_MUL) *flags = PET_GATE;
+    else if (gate_mode == VLPET_GATE_ADD) *flags = PET_GATE | PET_GATE_ADD;
+    else if (gate_mode != VLPET_GATE_NONE) return VLPET_E_SHAPE;
+    return 0;
+}
+
+extern "C" int vlpet_adapter_gate_bwd_phase(int phases, const void* dy, const void* x1, const void* x2,
+                                            const void* packed_a, const void* packed_g, void* dx1, void* dx2,
+                                            float* dwd, float* dbd, float* dwu, float* dbu,
+                                            float* dwgd, float* dbgd, float* dwgu, float* dbgu, int r, int rg,
+                                            void* workspace, size_t workspace_bytes, int64_t M, int d, int tiles,
+                                            int gate_mode, float delta_scale, float x2_scale, float gate_scale,
+                                            int io_dtype, vlpet_stream_t stream) {
+    int flags;
+    if (gate_flags(gate_mode, &flags)) return VLPET_E_SHAPE;
+    if (!dbd || !dbu || (phases & 3) == 0) return VLPET_E_NULL;
+    return run_bwd(dy, x2, x2, x1, packed_a, packed_g, nullptr, 1.f, dx2, dx1, dwd, dbd, dwu, dbu,
+                   dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
+                   x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream, phases & 3);
 }
 
 extern "C" int vlpet_parallel_adapter_bwd(const void* dy, const void* x, const void* packed, void* dx,

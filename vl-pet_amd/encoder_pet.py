@@ -1,0 +1,95 @@
+"""Encoder granularity-controlled adapter ("VL-PET") as a mixin for transformer blocks.
+
+The reference has no class for it: the parameters hang directly off ``BartEncoderLayer``
+(my_transformers/modeling_bart.py:1000-1005,1044-1056) resp. ``T5LayerSelfAttention`` / ``T5LayerFF``
+(my_transformers/modeling_t5.py:706-724,312-330) and ~60 lines of inline tensor code use them
+(modeling_bart.py:1147-1155,1195-1209,1256-1257).  ``build_pet`` creates attributes with exactly
+those names (so state-dict keys, the 'adapter' / 'gating' freeze substrings and the zero-init rules
+of trainer_base.py:497-533,557-565 keep working) and ``apply_pet`` replaces the inline code with
+one fused HIP kernel call.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import functional as VF
+from .activations import get_activation
+
+GRANULARITY_FLAGS = ("use_encoder_adapter_gating_large_x_lowrank", "use_encoder_adapter_gating_small_xy_cat",
+                     "use_encoder_adapter_gating_middle_xy_add", "use_encoder_adapter_gating_middle_ia3_add")
+
+
+def _names(which: str):
+    return dict(down=f"{which}_adapter_multihead_down", up=f"{which}_adapter_multihead_up",
+                gdown=f"encoder_{which}_adapter_gating_large_x_down", gup=f"encoder_{which}_adapter_gating_large_x_up")
+
+
+def build_pet(module: nn.Module, config, embed_dim: int, which=("attn", "ff")):
+    """Create the multi-head down / up projections and the low-rank gate on ``module``."""
+    module.adapter_non_linear = get_activation("gelu_new")
+    module.gating_non_linear = get_activation("gelu_new")
+    if not hasattr(module, "_pet_caches"):
+        module._pet_caches = {}
+    for w in which:
+        n = _names(w)
+        if getattr(config, "use_encoder_adapter_down_multihead", False):
+            nh = int(config.encoder_adapter_multihead_num_head)
+            r = int(config.adapter_down_dim)
+            module.encoder_adapter_multihead_dim = int(r / nh)
+            setattr(module, n["down"], nn.ModuleList([nn.Linear(embed_dim, int(r / nh)) for _ in range(nh)]))
+            setattr(module, n["up"], nn.Linear(r, embed_dim))
+        else:
+            setattr(module, n["down"], None)
+            setattr(module, n["up"], None)
+        if getattr(config, "use_encoder_adapter_gating_large_x_lowrank", False):
+            rg = int(config.adapter_gating_down_dim)
+            setattr(module, n["gdown"], nn.Linear(embed_dim, rg))
+            setattr(module, n["gup"], nn.Linear(rg, embed_dim))
+        else:
+            setattr(module, n["gdown"], None)
+            setattr(module, n["gup"], None)
+        for flag in GRANULARITY_FLAGS[1:]:
+            if getattr(config, flag, False):
+                raise NotImplementedError(f"{flag}: the small / middleX / middleY gates are SURVEY.md 8(f) rank 2 "
+                                          "(next); only the large low-rank gate is fused so far")
+        module._pet_caches[w] = (VF.PackCache(), VF.PackCache())
+
+
+def has_pet(module: nn.Module, which: str) -> bool:
+    return getattr(module, _names(which)["down"], None) is not None
+
+
+def apply_pet(module: nn.Module, which: str, x1: torch.Tensor, x2: torch.Tensor, config) -> torch.Tensor:
+    """y = ((x2*s2 + sd*up(gelu_new(cat_i down_i(x2)))) (*|+) sigmoid(up_g(gelu_new(down_g(x1))))) * gs
+
+    x1 = sublayer input ("residual"), x2 = frozen attention / FFN output; the caller then does
+    ``LayerNorm(x1 + dropout(y))`` (BART) or ``x1 + dropout(y)`` (T5)."""
+    n = _names(which)
+    downs = getattr(module, n["down"])
+    up = getattr(module, n["up"])
+    gdown, gup = getattr(module, n["gdown"]), getattr(module, n["gup"])
+    io = VF._io_dtype(x2)
+    r = up.weight.shape[1]
+    gate = gdown is not None
+    tiles = VF.rank_tiles(r)
+    if gate:
+        tiles = max(tiles, VF.rank_tiles(gdown.weight.shape[0]))
+    ca, cg = module._pet_caches[which]
+    dws = [m.weight for m in downs]
+    dbs = [m.bias for m in downs]
+    pk_a = ca.get(dws, dbs, up.weight, up.bias, io, tiles)
+    pk_g = cg.get([gdown.weight], [gdown.bias], gup.weight, gup.bias, io, tiles) if gate else None
+    mode = VF.GATE_NONE
+    if gate:
+        mode = VF.GATE_ADD if getattr(config, "use_encoder_adapter_gating_add", False) else VF.GATE_MUL
+    sd = float(config.encoder_adapter_scaling_factor) if getattr(config, "use_encoder_adapter_scaling", False) else 1.0
+    s2 = float(config.encoder_x2_scaling_factor) if getattr(config, "use_encoder_x2_scaling", False) else 1.0
+    gs = float(config.encoder_gating_scaling_factor) if getattr(config, "use_encoder_gating_scaling", False) else 1.0
+    gp = (gdown.weight, gdown.bias, gup.weight, gup.bias) if gate else None
+    if x1.dtype != x2.dtype:
+        x1 = x1.to(x2.dtype)
+    y = VF.adapter_gate(x1, x2, dws, dbs, up.weight, up.bias, gp, pk_a, pk_g, mode, sd, s2, gs if gate else 1.0)
+    if not gate and gs != 1.0:
+        y = y * gs
+    return y

@@ -13,6 +13,42 @@ from . import _lib
 GATE_NONE, GATE_MUL, GATE_ADD = _lib.GATE_NONE, _lib.GATE_MUL, _lib.GATE_ADD
 
 
+class KernelTimer:
+    """Optional HIP-event bracketing of individual launches (bench.py's live roofline measurement).
+    Events are recorded on the stream the kernels are enqueued on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []      # (name, rows, start_event, end_event)
+
+    def bracket(self, name, rows, fn):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.records.append((name, rows, e0, e1))
+        return out
+
+    def summary(self):
+        """name -> dict(launches, rows, total_us); call after torch.cuda.synchronize()."""
+        agg = {}
+        for name, rows, e0, e1 in self.records:
+            a = agg.setdefault(name, dict(launches=0, rows=0, total_us=0.0))
+            a["launches"] += 1
+            a["rows"] += rows
+            a["total_us"] += e0.elapsed_time(e1) * 1e3
+        return agg
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def _timed(name, rows, fn):
+    if TIMER is None:
+        return fn()
+    return TIMER.bracket(name, rows, fn)
+
+
 def _io_dtype(t: torch.Tensor) -> int:
     if t.dtype == torch.bfloat16:
         return _lib.VLPET_BF16
@@ -123,10 +159,10 @@ class _AdapterGateFn(torch.autograd.Function):
         x1f = _flat(x1, d) if gate_mode != GATE_NONE else None
         M = x2f.shape[0]
         out = torch.empty_like(x2f)
-        rc = lib.vlpet_adapter_gate_fwd(_ptr(x1f), x2f.data_ptr(), pk_a.buf.data_ptr(),
-                                        pk_g.buf.data_ptr() if pk_g is not None else None,
-                                        out.data_ptr(), M, d, pk_a.tiles, gate_mode,
-                                        float(delta_scale), float(x2_scale), float(gate_scale), io, _stream())
+        rc = _timed("k1_fwd", M, lambda: lib.vlpet_adapter_gate_fwd(
+            _ptr(x1f), x2f.data_ptr(), pk_a.buf.data_ptr(), pk_g.buf.data_ptr() if pk_g is not None else None,
+            out.data_ptr(), M, d, pk_a.tiles, gate_mode, float(delta_scale), float(x2_scale), float(gate_scale),
+            io, _stream()))
         _lib.check(rc, "vlpet_adapter_gate_fwd")
         ctx.save_for_backward(x1f if x1f is not None else x2f, x2f, *params)
         ctx.pk = (pk_a, pk_g)
@@ -158,12 +194,17 @@ class _AdapterGateFn(torch.autograd.Function):
         dx1 = torch.empty_like(x2f) if gate else None
         nws = lib.vlpet_bwd_workspace_bytes(M, d, pk_a.tiles, int(gate), io)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        rc = lib.vlpet_adapter_gate_bwd(dyf.data_ptr(), _ptr(x1f) if gate else None, x2f.data_ptr(),
-                                        pk_a.buf.data_ptr(), pk_g.buf.data_ptr() if gate else None,
-                                        _ptr(dx1), dx2.data_ptr(),
-                                        dwd.data_ptr(), dbd.data_ptr(), dwu.data_ptr(), dbu.data_ptr(),
-                                        _ptr(dwgd), _ptr(dbgd), _ptr(dwgu), _ptr(dbgu), r, rg,
-                                        ws.data_ptr(), nws, M, d, pk_a.tiles, gate_mode, sd, s2, gs, io, _stream())
+        args = (dyf.data_ptr(), _ptr(x1f) if gate else None, x2f.data_ptr(),
+                pk_a.buf.data_ptr(), pk_g.buf.data_ptr() if gate else None, _ptr(dx1), dx2.data_ptr(),
+                dwd.data_ptr(), dbd.data_ptr(), dwu.data_ptr(), dbu.data_ptr(),
+                _ptr(dwgd), _ptr(dbgd), _ptr(dwgu), _ptr(dbgu), r, rg,
+                ws.data_ptr(), nws, M, d, pk_a.tiles, gate_mode, sd, s2, gs, io, _stream())
+        if TIMER is None:
+            rc = lib.vlpet_adapter_gate_bwd(*args)
+        else:       # same work, the two halves bracketed separately
+            rc = TIMER.bracket("k1_bwd_rows", M, lambda: lib.vlpet_adapter_gate_bwd_phase(1, *args))
+            if rc == 0:
+                rc = TIMER.bracket("k1_bwd_wgrad", M, lambda: lib.vlpet_adapter_gate_bwd_phase(2, *args))
         _lib.check(rc, "vlpet_adapter_gate_bwd")
         if not gate:
             # without a gate the kernel returns the adapter-branch gradient only; add the residual path
@@ -206,8 +247,8 @@ class _ParallelAdapterFn(torch.autograd.Function):
         xf, yf = _flat(x, d), _flat(y, d)
         M = xf.shape[0]
         out = torch.empty_like(xf)
-        rc = lib.vlpet_parallel_adapter_fwd(xf.data_ptr(), yf.data_ptr(), pk.buf.data_ptr(), out.data_ptr(),
-                                            M, d, pk.tiles, float(scale), io, _stream())
+        rc = _timed("k2_fwd", M, lambda: lib.vlpet_parallel_adapter_fwd(
+            xf.data_ptr(), yf.data_ptr(), pk.buf.data_ptr(), out.data_ptr(), M, d, pk.tiles, float(scale), io, _stream()))
         _lib.check(rc, "vlpet_parallel_adapter_fwd")
         ctx.save_for_backward(xf, wd, bd, wu, bu)
         ctx.pk, ctx.scale, ctx.shape = pk, float(scale), x.shape
@@ -228,9 +269,9 @@ class _ParallelAdapterFn(torch.autograd.Function):
         dx = torch.empty_like(xf)
         nws = lib.vlpet_bwd_workspace_bytes(M, d, pk.tiles, 0, io)
         ws = torch.empty(nws, dtype=torch.uint8, device=xf.device)
-        rc = lib.vlpet_parallel_adapter_bwd(dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), dx.data_ptr(),
-                                            dwd.data_ptr(), dbd.data_ptr(), dwu.data_ptr(), dbu.data_ptr(), r,
-                                            ws.data_ptr(), nws, M, d, pk.tiles, ctx.scale, io, _stream())
+        rc = _timed("k2_bwd", M, lambda: lib.vlpet_parallel_adapter_bwd(
+            dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), dx.data_ptr(), dwd.data_ptr(), dbd.data_ptr(),
+            dwu.data_ptr(), dbu.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, ctx.scale, io, _stream()))
         _lib.check(rc, "vlpet_parallel_adapter_bwd")
         return (dx.view(ctx.shape), dy, None, None, _grad_like(dwd, wd), _grad_like(dbd, bd),
                 _grad_like(dwu, wu), _grad_like(dbu, bu))

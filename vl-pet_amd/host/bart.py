@@ -1,0 +1,336 @@
+"""Minimal BART encoder-decoder host with the reference's PET hook points.
+
+This is the frozen backbone the hot path plugs into: plain PyTorch-ROCm (library GEMMs, SDPA,
+LayerNorm), no HIP code of ours -- the PET arithmetic is delegated to ``encoder_pet.apply_pet``
+(K1), ``adapters.AdapterController`` (K2), ``lora.LoRALinearController`` (K3) and
+``visual.VisualEmbedding`` (K4).  Module / parameter names follow the reference so that its
+checkpoints and its name-substring freeze rules apply:
+
+  model.shared, model.encoder.{embed_tokens,embed_positions,layernorm_embedding,visual_embedding},
+  model.encoder.layers.{l}.{self_attn.{q,k,v,out}_proj,self_attn_layer_norm,fc1,fc2,final_layer_norm,
+      attn_adapter_multihead_down.{h},attn_adapter_multihead_up,ff_adapter_multihead_*,
+      encoder_{attn,ff}_adapter_gating_large_x_{down,up}},
+  model.decoder.layers.{l}.{self_attn,encoder_attn.{...,attn_value_parallel_adapter.adapters.{task}},...}
+
+Structure restated from: src/modeling_bart.py:696-900 (JointEncoder: text LN before concat
+[text ; visual]), my_transformers/modeling_bart.py:1122-1380 (encoder layer, post-LN),
+:1611-1760 (decoder layer), :397-566 (cross-attention with value-parallel adapter),
+src/modeling_bart.py:1522-1602 (LM head + CE with reduction='none').
+"""
+from __future__ import annotations
+
+import copy
+import math
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..adapters import AdapterConfig, AdapterController
+from ..encoder_pet import apply_pet, build_pet, has_pet
+from ..lora import LoRALinearController, LoraConfig
+from ..visual import Downsample, VisualEmbedding
+
+TASKS = ["vqa", "gqa", "nlvr", "caption"]
+
+
+def vlpet_config(**over) -> SimpleNamespace:
+    """Config namespace with the attribute names the reference copies from its argparse flags onto the
+    HF config (trainer_base.py:86-87).  Defaults = scripts/image-text/VL-PET-large.sh with r=96."""
+    c = SimpleNamespace(
+        # backbone (facebook/bart-base)
+        d_model=768, encoder_layers=6, decoder_layers=6, encoder_attention_heads=12, decoder_attention_heads=12,
+        encoder_ffn_dim=3072, decoder_ffn_dim=3072, vocab_size=50265 + 200, max_position_embeddings=1024,
+        dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, pad_token_id=1, decoder_start_token_id=2,
+        scale_embedding=False, init_std=0.02,
+        # visual
+        feat_dim=2048, pos_dim=4, n_images=2, n_boxes=36, downsample=True, use_vis_order_embedding=True,
+        use_vis_layer_norm=True, individual_vis_layer_norm=True, share_vis_lang_layer_norm=False,
+        # PET flags
+        tasks=",".join(TASKS), use_adapter=True, use_single_adapter=True, no_encoder_adapter=True,
+        no_decoder_adapter=True, use_adapter_down_dim=True, adapter_down_dim=96,
+        use_encoder_adapter_down_multihead=True, encoder_adapter_multihead_num_head=4,
+        use_encoder_adapter_gating_large_x_lowrank=True, adapter_gating_down_dim=96,
+        use_encoder_adapter_gating_add=False, use_encoder_adapter_gating_small_xy_cat=False,
+        use_encoder_adapter_gating_middle_xy_add=False, use_encoder_adapter_gating_middle_ia3_add=False,
+        use_encoder_gating_scaling=False, encoder_gating_scaling_factor=1.0,
+        use_encoder_adapter_scaling=False, encoder_adapter_scaling_factor=1.0,
+        use_encoder_x2_scaling=False, encoder_x2_scaling_factor=1.0,
+        unfreeze_encoder_layer_norms=True,
+        use_decoder_enc_attn_value_parallel_adapter_down_dim=True, decoder_enc_attn_value_parallel_adapter_down_dim=96,
+        use_decoder_enc_attn_value_parallel_adapter_scaling=False,
+        decoder_enc_attn_value_parallel_adapter_scaling_factor=1.0,
+        use_lora=False, lora_dim=4, lora_alpha=32, use_single_lora=False, reduction_factor=8,
+        use_encoder_multihead_up_zero_init=False, use_encoder_gating_large_x_lowrank_up_zero_init=False,
+        use_decoder_enc_vpa_up_zero_init=False, freeze_vis_emb=False,
+    )
+    for k, v in over.items():
+        if not hasattr(c, k):
+            raise AttributeError(f"unknown config field {k}")
+        setattr(c, k, v)
+    task_list = [t for t in c.tasks.replace(" ", ",").split(",") if t]
+    c.task_list = task_list
+    if c.use_adapter or c.use_decoder_enc_attn_value_parallel_adapter_down_dim:
+        c.adapter_config = AdapterConfig(
+            tasks=task_list, input_dim=c.d_model, d_model=c.d_model, use_single_adapter=c.use_single_adapter,
+            reduction_factor=c.reduction_factor, use_adapter_down_dim=bool(c.use_adapter_down_dim),
+            adapter_down_dim=c.adapter_down_dim)
+    else:
+        c.adapter_config = None
+    c.lora_config = LoraConfig(lora_dim=c.lora_dim, lora_alpha=c.lora_alpha, tasks=task_list,
+                               use_single_lora=c.use_single_lora) if c.use_lora else None
+    return c
+
+
+class HostLayerNorm(nn.LayerNorm):
+    """LayerNorm whose (possibly fp32, trainable) affine parameters follow the activation dtype."""
+
+    def forward(self, x):
+        w, b = self.weight, self.bias
+        if w.dtype != x.dtype:
+            w, b = w.to(x.dtype), b.to(x.dtype)
+        return F.layer_norm(x, self.normalized_shape, w, b, self.eps)
+
+
+def _linear(mod: nn.Linear, x):
+    w, b = mod.weight, mod.bias
+    if w.dtype != x.dtype:
+        w = w.to(x.dtype)
+        b = b.to(x.dtype) if b is not None else None
+    return F.linear(x, w, b)
+
+
+class BartAttention(nn.Module):
+    """Multi-head attention; optional LoRA on q/v (my_transformers/modeling_bart.py:738-879) and optional
+    value-parallel adapter on the cross-attention value (:283-566, use at :427-430)."""
+
+    def __init__(self, config, embed_dim, num_heads, dropout, is_cross=False, value_adapter=False):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.head_dim = embed_dim // num_heads
+        self.use_lora = bool(config.use_lora)
+        if self.use_lora:
+            self.q_proj = LoRALinearController(embed_dim, embed_dim, config=config.lora_config, bias=True)
+            self.v_proj = LoRALinearController(embed_dim, embed_dim, config=config.lora_config, bias=True)
+        else:
+            self.q_proj = nn.Linear(embed_dim, embed_dim)
+            self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.attn_value_parallel_adapter = None
+        if value_adapter:
+            ac = copy.deepcopy(config.adapter_config)
+            ac.use_adapter_down_dim = True
+            ac.adapter_down_dim = config.decoder_enc_attn_value_parallel_adapter_down_dim
+            ac.use_parallel_adapter = True
+            if config.use_decoder_enc_attn_value_parallel_adapter_scaling:
+                ac.use_scaling_factor = True
+                ac.scaling_factor = config.decoder_enc_attn_value_parallel_adapter_scaling_factor
+            self.attn_value_parallel_adapter = AdapterController(ac)
+
+    def _shape(self, t, B):
+        return t.view(B, -1, self.num_heads, self.head_dim).transpose(1, 2)
+
+    def forward(self, hidden, kv=None, attn_mask=None, causal=False, task=None):
+        B, L, _ = hidden.shape
+        src = hidden if kv is None else kv
+        if self.use_lora:
+            q = self.q_proj(hidden, task)
+            v = self.v_proj(src, task)
+        else:
+            q = _linear(self.q_proj, hidden)
+            v = _linear(self.v_proj, src)
+        k = _linear(self.k_proj, src)
+        if kv is not None and self.attn_value_parallel_adapter is not None:
+            v = self.attn_value_parallel_adapter(src, task, y=v)
+        out = F.scaled_dot_product_attention(self._shape(q, B), self._shape(k, B), self._shape(v, B),
+                                             attn_mask=attn_mask, is_causal=causal and attn_mask is None,
+                                             dropout_p=self.dropout if self.training else 0.0)
+        out = out.transpose(1, 2).reshape(B, L, self.embed_dim)
+        return _linear(self.out_proj, out)
+
+
+class BartEncoderLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        d = config.d_model
+        self.embed_dim = d
+        self.self_attn = BartAttention(config, d, config.encoder_attention_heads, config.attention_dropout)
+        self.self_attn_layer_norm = HostLayerNorm(d)
+        self.dropout, self.activation_dropout = config.dropout, config.activation_dropout
+        self.fc1 = nn.Linear(d, config.encoder_ffn_dim)
+        self.fc2 = nn.Linear(config.encoder_ffn_dim, d)
+        self.final_layer_norm = HostLayerNorm(d)
+        build_pet(self, config, d, ("attn", "ff"))
+
+    def forward(self, hidden, attn_mask=None, task=None):
+        residual = hidden
+        h = self.self_attn(hidden, attn_mask=attn_mask, task=task)
+        if has_pet(self, "attn"):
+            h = apply_pet(self, "attn", residual, h, self.config)                 # K1
+        h = F.dropout(h, p=self.dropout, training=self.training)
+        hidden = self.self_attn_layer_norm(residual + h)
+        residual = hidden
+        h = F.gelu(_linear(self.fc1, hidden))
+        h = F.dropout(h, p=self.activation_dropout, training=self.training)
+        h = _linear(self.fc2, h)
+        if has_pet(self, "ff"):
+            h = apply_pet(self, "ff", residual, h, self.config)                   # K1
+        h = F.dropout(h, p=self.dropout, training=self.training)
+        return self.final_layer_norm(residual + h)
+
+
+class BartDecoderLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        d = config.d_model
+        self.self_attn = BartAttention(config, d, config.decoder_attention_heads, config.attention_dropout)
+        self.self_attn_layer_norm = HostLayerNorm(d)
+        vpa = bool(config.use_decoder_enc_attn_value_parallel_adapter_down_dim) and not config.use_lora
+        self.encoder_attn = BartAttention(config, d, config.decoder_attention_heads, config.attention_dropout,
+                                          is_cross=True, value_adapter=vpa)
+        self.encoder_attn_layer_norm = HostLayerNorm(d)
+        self.dropout, self.activation_dropout = config.dropout, config.activation_dropout
+        self.fc1 = nn.Linear(d, config.decoder_ffn_dim)
+        self.fc2 = nn.Linear(config.decoder_ffn_dim, d)
+        self.final_layer_norm = HostLayerNorm(d)
+
+    def forward(self, hidden, enc, enc_mask=None, task=None):
+        residual = hidden
+        h = self.self_attn(hidden, causal=True, task=task)
+        hidden = self.self_attn_layer_norm(residual + F.dropout(h, p=self.dropout, training=self.training))
+        residual = hidden
+        h = self.encoder_attn(hidden, kv=enc, attn_mask=enc_mask, task=task)      # K2 inside
+        hidden = self.encoder_attn_layer_norm(residual + F.dropout(h, p=self.dropout, training=self.training))
+        residual = hidden
+        h = F.gelu(_linear(self.fc1, hidden))
+        h = F.dropout(h, p=self.activation_dropout, training=self.training)
+        h = _linear(self.fc2, h)
+        return self.final_layer_norm(residual + F.dropout(h, p=self.dropout, training=self.training))
+
+
+class LearnedPositionalEmbedding(nn.Embedding):
+    """BART's learned positions with the historical offset of 2."""
+
+    def __init__(self, num, dim):
+        super().__init__(num + 2, dim)
+
+    def forward(self, L: int, device):
+        return super().forward(torch.arange(2, L + 2, device=device))
+
+
+class JointEncoder(nn.Module):
+    def __init__(self, config, embed_tokens):
+        super().__init__()
+        self.config = config
+        d = config.d_model
+        self.dropout = config.dropout
+        self.embed_scale = math.sqrt(d) if config.scale_embedding else 1.0
+        self.embed_tokens = embed_tokens
+        self.embed_positions = LearnedPositionalEmbedding(config.max_position_embeddings, d)
+        self.layers = nn.ModuleList([BartEncoderLayer(config) for _ in range(config.encoder_layers)])
+        self.layernorm_embedding = HostLayerNorm(d)
+        self.visual_embedding = VisualEmbedding(config, self.embed_tokens)
+        self.downsample = None
+        if config.downsample:
+            s = int(config.n_boxes ** 0.5)
+            self.downsample = Downsample((s, s))
+
+    def forward(self, input_ids, vis_inputs, attention_mask=None, task=None):
+        B, L = input_ids.shape
+        x = self.embed_tokens(input_ids) * self.embed_scale + self.embed_positions(L, input_ids.device)
+        if self.downsample is not None:
+            vis_inputs = self.downsample(vis_inputs)
+        feats, boxes = vis_inputs[0], vis_inputs[1]
+        img_ids = vis_inputs[2] if len(vis_inputs) >= 3 else None
+        obj_ids = vis_inputs[3] if len(vis_inputs) == 4 else None
+        vis = self.visual_embedding(feats, boxes, img_ids, obj_ids).to(x.dtype)   # K4
+        if self.config.share_vis_lang_layer_norm:
+            x = self.layernorm_embedding(torch.cat([x, vis], dim=1))
+        else:
+            x = torch.cat([self.layernorm_embedding(x), vis], dim=1)
+        x = F.dropout(x, p=self.dropout, training=self.training)
+        mask = None
+        if attention_mask is not None:      # [B, L] text padding mask; visual tokens always attended
+            full = torch.cat([attention_mask.bool(), torch.ones(B, vis.shape[1], dtype=torch.bool,
+                                                                device=x.device)], dim=1)
+            mask = full[:, None, None, :]
+        for layer in self.layers:
+            x = layer(x, mask, task)
+        return x, mask
+
+
+class BartDecoder(nn.Module):
+    def __init__(self, config, embed_tokens):
+        super().__init__()
+        d = config.d_model
+        self.dropout = config.dropout
+        self.embed_scale = math.sqrt(d) if config.scale_embedding else 1.0
+        self.embed_tokens = embed_tokens
+        self.embed_positions = LearnedPositionalEmbedding(config.max_position_embeddings, d)
+        self.layers = nn.ModuleList([BartDecoderLayer(config) for _ in range(config.decoder_layers)])
+        self.layernorm_embedding = HostLayerNorm(d)
+
+    def forward(self, input_ids, enc, enc_mask=None, task=None):
+        B, L = input_ids.shape
+        x = self.embed_tokens(input_ids) * self.embed_scale + self.embed_positions(L, input_ids.device)
+        x = F.dropout(self.layernorm_embedding(x), p=self.dropout, training=self.training)
+        for layer in self.layers:
+            x = layer(x, enc, enc_mask, task)
+        return x
+
+
+class VLBartModel(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.shared = nn.Embedding(config.vocab_size, config.d_model, padding_idx=config.pad_token_id)
+        self.encoder = JointEncoder(config, self.shared)
+        self.decoder = BartDecoder(config, self.shared)
+
+
+def shift_tokens_right(labels, pad_id, start_id):
+    out = labels.new_zeros(labels.shape)
+    out[:, 1:] = labels[:, :-1]
+    out[:, 0] = start_id
+    return out.masked_fill(out == -100, pad_id)
+
+
+class VLBart(nn.Module):
+    """Encoder-decoder + tied LM head; ``forward`` returns the per-token loss [B, L] like the
+    reference's ``reduce_loss=False`` path (src/modeling_bart.py:1574-1586)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.model = VLBartModel(config)
+        self.register_buffer("final_logits_bias", torch.zeros(1, config.vocab_size))
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        # my_transformers/modeling_bart.py:1819-1828: every Linear (adapters included) ~ N(0, 0.02), zero bias
+        std = self.config.init_std
+        if isinstance(m, nn.Linear):
+            m.weight.data.normal_(0.0, std)
+            if m.bias is not None:
+                m.bias.data.zero_()
+        elif isinstance(m, nn.Embedding):
+            m.weight.data.normal_(0.0, std)
+            if m.padding_idx is not None:
+                m.weight.data[m.padding_idx].zero_()
+        if isinstance(m, LoRALinearController):
+            for t in m.tasks:
+                nn.init.zeros_(m.lora_Bs[t])
+
+    def forward(self, input_ids, vis_inputs, labels, task, attention_mask=None):
+        cfg = self.config
+        enc, mask = self.model.encoder(input_ids, vis_inputs, attention_mask, task)
+        dec_in = shift_tokens_right(labels, cfg.pad_token_id, cfg.decoder_start_token_id)
+        h = self.model.decoder(dec_in, enc, mask, task)
+        logits = F.linear(h, self.model.shared.weight.to(h.dtype)) + self.final_logits_bias.to(h.dtype)
+        loss = F.cross_entropy(logits.float().view(-1, logits.shape[-1]), labels.view(-1), ignore_index=-100,
+                               reduction="none")
+        return loss.view(labels.shape), logits

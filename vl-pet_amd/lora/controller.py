@@ -1,0 +1,78 @@
+"""LoRA linear with per-task (or shared) A/B (reference: lora/controller.py:11-87)."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .layers import LoRALayer
+from .. import functional as VF
+
+
+class LoRALinearController(nn.Linear, LoRALayer):
+    """``F.linear(x, W, b) + (dropout(x) @ A[task].T @ B[task].T) * alpha/r``.
+
+    The frozen base GEMM stays a library GEMM; the low-rank update, its scale and the add run in
+    one fused HIP kernel (csrc/pet_fwd.hip, ACT_IDENTITY path).  ``weight``/``bias`` keep nn.Linear's
+    names so the pretrained q_proj / v_proj tensors load into them."""
+
+    def __init__(self, in_features: int, out_features: int, fan_in_fan_out: bool = False, config=None, **kwargs):
+        nn.Linear.__init__(self, in_features, out_features, **kwargs)
+        if fan_in_fan_out:
+            raise NotImplementedError("fan_in_fan_out layers do not occur on the BART q_proj/v_proj path")
+        self.tasks = config.tasks
+        self.use_single_lora = config.use_single_lora
+        LoRALayer.__init__(self, r=config.lora_dim, lora_alpha=config.lora_alpha,
+                           lora_dropout=config.lora_dropout, merge_weights=True)
+        self.fan_in_fan_out = fan_in_fan_out
+        self.lora_As = nn.ParameterDict()
+        self.lora_Bs = nn.ParameterDict()
+        if self.r > 0:
+            self.construct_lora_weights(self.tasks)
+            self.scaling = self.lora_alpha / self.r
+            self.weight.requires_grad = False
+        self.reset_parameters()
+        self._packs = {}
+
+    def reset_parameters(self):
+        nn.Linear.reset_parameters(self)
+        if hasattr(self, "lora_As"):
+            for task in self.tasks:
+                nn.init.kaiming_uniform_(self.lora_As[task], a=math.sqrt(5))
+                nn.init.zeros_(self.lora_Bs[task])
+
+    def get_task(self, task):
+        return task
+
+    def construct_lora_weights(self, tasks):
+        if self.use_single_lora:
+            a = nn.Parameter(self.weight.new_zeros((self.r, self.in_features)))
+            b = nn.Parameter(self.weight.new_zeros((self.out_features, self.r)))
+            for task in tasks:
+                self.lora_As[task] = a
+                self.lora_Bs[task] = b
+        else:
+            for task in tasks:
+                self.lora_As[task] = nn.Parameter(self.weight.new_zeros((self.r, self.in_features)))
+                self.lora_Bs[task] = nn.Parameter(self.weight.new_zeros((self.out_features, self.r)))
+        return self.lora_As, self.lora_Bs
+
+    def forward(self, x, task):
+        if self.in_features != self.out_features:
+            raise NotImplementedError("fused LoRA delta supports square projections (q_proj / v_proj) only")
+        w, b = self.weight, self.bias
+        if w.dtype != x.dtype:
+            w = w.to(x.dtype)
+            b = b.to(x.dtype) if b is not None else None
+        base = F.linear(x, w, b)
+        if self.r <= 0:
+            return base
+        A, B = self.lora_As[task], self.lora_Bs[task]
+        cache = self._packs.setdefault(task, VF.PackCache())
+        pk = cache.get([A], None, B, None, VF._io_dtype(x))
+        keep, keep_scale = None, 1.0
+        p = self.lora_dropout_p
+        if self.training and p > 0.0:
+            keep = (torch.rand(x.shape, device=x.device) >= p).to(torch.uint8)
+            keep_scale = 1.0 / (1.0 - p)
+        return VF.lora_delta(x, base, A, B, pk, self.scaling, keep, keep_scale)

@@ -1,0 +1,108 @@
+"""Visual front end: CLIP-grid down-sampling and the visual-feature projection.
+
+``VisualEmbedding`` keeps the reference's constructor, forward signature and state-dict keys
+(src/modeling_bart.py:77-192; T5 variant src/modeling_t5.py:44-174):
+
+    LN(Linear(feat_dim -> d)(feats)) + LN(Linear(5 -> d)([box, area]))
+        + img_order_embedding[img_ids] + obj_order_embedding[V - 1 - obj_ids]
+
+``Downsample`` is the AdaptiveMaxPool2d 7x7 -> 6x6 of src/modeling_bart.py:556-613 (frozen, no
+parameters).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class T5LayerNorm(nn.Module):
+    """RMS norm without bias (my_transformers/modeling_t5.py:235-252)."""
+
+    def __init__(self, hidden_size, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, x):
+        var = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+        x = x * torch.rsqrt(var + self.variance_epsilon)
+        return self.weight.to(x.dtype) * x.to(self.weight.dtype if self.weight.dtype != torch.float32 else x.dtype)
+
+
+class Downsample(nn.Module):
+    def __init__(self, output_size):
+        super().__init__()
+        self.output_size = output_size
+        self.pool = nn.AdaptiveMaxPool2d(output_size)
+
+    def downsample_inputs(self, x):
+        B, L, dim = x.shape
+        s = int(L ** 0.5)
+        x = x.permute(0, 2, 1).reshape(B, dim, s, s)
+        x = self.pool(x).reshape(B, dim, -1)
+        return x.permute(0, 2, 1)
+
+    def forward(self, inputs_tuple):
+        if len(inputs_tuple) == 4:   # NLVR: two images side by side along the token axis
+            x, boxes, img_ids, obj_ids = inputs_tuple
+            x = torch.cat(torch.chunk(x, 2, 1), 0)
+            x = self.downsample_inputs(x)
+            x = torch.cat(torch.chunk(x, 2, 0), 1)
+            half = x.shape[1] // 2
+
+            def crop(t):
+                t = torch.cat(torch.chunk(t, 2, 1), 0)[:, :half]
+                return torch.cat(torch.chunk(t, 2, 0), 1)
+            return x, crop(boxes), crop(img_ids), crop(obj_ids)
+        x, boxes = inputs_tuple
+        x = self.downsample_inputs(x)
+        return x, boxes[:, :x.shape[1]]
+
+
+class VisualEmbedding(nn.Module):
+    def __init__(self, config, obj_order_embedding: nn.Embedding, rms_norm: bool = False):
+        super().__init__()
+        self.config = config
+        d = config.d_model
+        feat_dim, pos_dim = int(config.feat_dim), int(config.pos_dim)
+        self.rms_norm = rms_norm
+        norm = (lambda: T5LayerNorm(d, eps=getattr(config, "layer_norm_epsilon", 1e-6))) if rms_norm \
+            else (lambda: nn.LayerNorm(d))
+        individual = config.use_vis_layer_norm and config.individual_vis_layer_norm
+        fe = [nn.Linear(feat_dim, d)]
+        if individual:
+            fe.append(norm())
+        self.feat_embedding = nn.Sequential(*fe)
+        pe = [nn.Linear(pos_dim + 1, d)]
+        if individual:
+            pe.append(norm())
+        self.absolute_vis_pos_embedding = nn.Sequential(*pe)
+        if config.use_vis_order_embedding:
+            self.obj_order_embedding = obj_order_embedding
+            self.img_order_embedding = nn.Embedding(config.n_images, d)
+        if config.use_vis_layer_norm and not config.individual_vis_layer_norm:
+            self.layer_norm = norm()
+
+    @staticmethod
+    def get_area(pos):
+        return (pos[:, :, 3] - pos[:, :, 2]) * (pos[:, :, 1] - pos[:, :, 0])
+
+    def forward(self, feats, pos, img_order_ids=None, obj_order_ids=None):
+        B, N, _ = feats.shape
+        assert pos.shape == (B, N, 4)
+        feat_embedding = self.feat_embedding(feats)
+        pos5 = torch.cat([pos, self.get_area(pos).unsqueeze(2)], dim=2)
+        vis = feat_embedding + self.absolute_vis_pos_embedding(pos5)
+        if self.config.use_vis_order_embedding:
+            dev = feats.device
+            if img_order_ids is None:
+                img_order_ids = torch.zeros(N, dtype=torch.long, device=dev).unsqueeze(0)
+            if obj_order_ids is None:
+                obj_order_ids = torch.arange(N, dtype=torch.long, device=dev).unsqueeze(0)
+            obj_order_ids = self.obj_order_embedding.num_embeddings - obj_order_ids - 1
+            vis = vis + self.img_order_embedding(img_order_ids).to(vis.dtype) \
+                + self.obj_order_embedding(obj_order_ids).to(vis.dtype)
+        if self.config.use_vis_layer_norm and not self.config.individual_vis_layer_norm:
+            vis = self.layer_norm(vis)
+        return vis
