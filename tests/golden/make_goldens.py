@@ -430,7 +430,10 @@ def golden_decoder_layer(tag, d, r, B, S_enc, S_dec, seed=5):
     layer.eval()
     hid = torch.randn(B, S_dec, d, generator=gen)
     enc = torch.randn(B, S_enc, d, generator=gen).requires_grad_(True)
-    out = layer(hid, encoder_hidden_states=enc, task="vqa")[0]
+    # causal self-attention mask exactly as BartDecoder.forward builds it (my_transformers/modeling_bart.py:93-106)
+    from my_transformers.modeling_bart import _make_causal_mask
+    causal = _make_causal_mask((B, S_dec), hid.dtype)
+    out = layer(hid, attention_mask=causal, encoder_hidden_states=enc, task="vqa")[0]
     dy = torch.randn(out.shape, generator=gen)
     out.backward(dy)
     sd = {k: T(v) for k, v in layer.state_dict().items()}

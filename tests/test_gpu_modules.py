@@ -1,0 +1,206 @@
+"""GPU: golden fixtures (made by the reference's own classes) through the HIP path, and the drop-in
+modules / host layers against them.  fp32 IO, tolerance 1e-3 (BASELINE.json)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+from gpu_cases import rel_err  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-3
+
+
+def load(name):
+    z = np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind == "f" else z[k]) for k in z.files}
+
+
+def cuda(t):
+    return t.detach().clone().cuda().requires_grad_(True)
+
+
+def ok(a, ref, what):
+    e = rel_err(a, ref)
+    assert e <= TOL, f"{what}: rel err {e:.3e}"
+
+
+@pytest.mark.parametrize("name,add", [("k1_bart_large_d768_r96", False), ("k1_bart_large_d64_r8", False),
+                                      ("k1_bart_large_add_d64_r8", True), ("k1_bart_large_scale_d64_r16", False)])
+def test_k1_bart_golden(name, add):
+    import vlpet_amd.functional as F
+    g = load(name)
+    d, r, nh, rg, B, S = [int(v) for v in g["meta"]]
+    rh = r // nh
+    x1, x2 = cuda(g["ff_x1"]), cuda(g["ff_x2"])
+    dws = [cuda(g["ff_wd"][i * rh:(i + 1) * rh]) for i in range(nh)]
+    dbs = [cuda(g["ff_bd"][i * rh:(i + 1) * rh]) for i in range(nh)]
+    wu, bu, wgd, bgd, wgu, bgu = (cuda(g["ff_" + k]) for k in ("wu", "bu", "wgd", "bgd", "wgu", "bgu"))
+    lw, lb = cuda(g["ln2_w"]), cuda(g["ln2_b"])
+    tiles = max(F.rank_tiles(r), F.rank_tiles(rg))
+    pa = F.pack_pair(dws, dbs, wu, bu, 0, tiles)
+    pg = F.pack_pair([wgd], [bgd], wgu, bgu, 0, tiles)
+    y = F.adapter_gate(x1, x2, dws, dbs, wu, bu, (wgd, bgd, wgu, bgu), pa, pg,
+                       F.GATE_ADD if add else F.GATE_MUL, 1.0, 1.0, float(g["gate_scale"]))
+    out = torch.nn.functional.layer_norm(x1 + y, (d,), lw, lb)          # BART tail, dropout off
+    ok(out, g["out"], "layer output")
+    out.backward(g["dy"].cuda())
+    ok(x2.grad, g["ff_dx2"], "dx2")
+    ok(torch.cat([w.grad for w in dws]), g["ff_dwd"], "dwd")
+    ok(torch.cat([b.grad for b in dbs]), g["ff_dbd"], "dbd")
+    for t, k in ((wu, "dwu"), (bu, "dbu"), (wgd, "dwgd"), (bgd, "dbgd"), (wgu, "dwgu"), (bgu, "dbgu")):
+        ok(t.grad, g["ff_" + k], k)
+    ok(lw.grad, g["ln2_dw"], "ln dw")
+
+
+@pytest.mark.parametrize("name", ["k1_t5_d128_r192", "k1_t5_scaled_d64_r16"])
+def test_k1_t5_golden(name):
+    import vlpet_amd.functional as F
+    g = load(name)
+    d, r, nh, rg, B, S = [int(v) for v in g["meta"]]
+    rh = r // nh
+    x1, x2 = cuda(g["x"]), cuda(g["x2"])
+    dws = [cuda(g["wd"][i * rh:(i + 1) * rh]) for i in range(nh)]
+    dbs = [cuda(g["bd"][i * rh:(i + 1) * rh]) for i in range(nh)]
+    wu, bu, wgd, bgd, wgu, bgu = (cuda(g[k]) for k in ("wu", "bu", "wgd", "bgd", "wgu", "bgu"))
+    tiles = max(F.rank_tiles(r), F.rank_tiles(rg))
+    pa = F.pack_pair(dws, dbs, wu, bu, 0, tiles)
+    pg = F.pack_pair([wgd], [bgd], wgu, bgu, 0, tiles)
+    y = F.adapter_gate(x1, x2, dws, dbs, wu, bu, (wgd, bgd, wgu, bgu), pa, pg, F.GATE_MUL,
+                       float(g["delta_scale"]), float(g["x2_scale"]), float(g["gate_scale"]))
+    out = x1 + y                                                         # T5 tail
+    ok(out, g["out"], "layer output")
+    out.backward(g["dy"].cuda())
+    ok(x2.grad, g["dx2"], "dx2")
+    ok(torch.cat([w.grad for w in dws]), g["dwd"], "dwd")
+    for t, k in ((wu, "dwu"), (bu, "dbu"), (wgd, "dwgd"), (bgd, "dbgd"), (wgu, "dwgu"), (bgu, "dbgu")):
+        ok(t.grad, g[k], k)
+
+
+@pytest.mark.parametrize("name", ["k2_d768_r96", "k2_scaled_d64_r8"])
+def test_k2_adapter_controller_golden(name):
+    from vlpet_amd.adapters import AdapterConfig, AdapterController
+    g = load(name)
+    d, r, B, S = [int(v) for v in g["meta"]]
+    sc = float(g["scaling"])
+    cfg = AdapterConfig(tasks=["vqa", "gqa", "nlvr", "caption"], d_model=d, input_dim=d, use_single_adapter=sc < 0,
+                        use_adapter_down_dim=True, adapter_down_dim=r, use_parallel_adapter=True,
+                        use_scaling_factor=sc >= 0, scaling_factor=max(sc, 1.0))
+    ctl = AdapterController(cfg).cuda()
+    ad = ctl.adapters["gqa"]
+    with torch.no_grad():
+        ad.down_sampler.weight.copy_(g["wd"]); ad.down_sampler.bias.copy_(g["bd"])
+        ad.up_sampler.weight.copy_(g["wu"]); ad.up_sampler.bias.copy_(g["bu"])
+    x, y = cuda(g["x"]), cuda(g["y"])
+    out = ctl(x, "gqa", y=y)
+    ok(out, g["out"], "out")
+    out.backward(g["dy"].cuda())
+    ok(x.grad, g["dx"], "dx"); ok(y.grad, g["dyin"], "dy")
+    ok(ad.down_sampler.weight.grad, g["dwd"], "dwd"); ok(ad.down_sampler.bias.grad, g["dbd"], "dbd")
+    ok(ad.up_sampler.weight.grad, g["dwu"], "dwu"); ok(ad.up_sampler.bias.grad, g["dbu"], "dbu")
+
+
+@pytest.mark.parametrize("name", ["k3_d256_r8", "k3_d256_r64", "k3_d64_r4", "k3_d128_r128"])
+def test_k3_lora_controller_golden(name):
+    from vlpet_amd.lora import LoraConfig, LoRALinearController
+    g = load(name)
+    d, r, alpha, M = [int(v) for v in g["meta"]]
+    lin = LoRALinearController(d, d, config=LoraConfig(lora_dim=r, lora_alpha=alpha,
+                                                       tasks=["vqa", "gqa", "nlvr", "caption"]), bias=True).cuda()
+    with torch.no_grad():
+        lin.weight.copy_(g["w"]); lin.bias.copy_(g["b"])
+        lin.lora_As["nlvr"].copy_(g["a"]); lin.lora_Bs["nlvr"].copy_(g["bb"])
+    lin.eval()
+    x = cuda(g["x"])
+    out = lin(x, "nlvr")
+    ok(out, g["out"], "out")
+    out.backward(g["dy"].cuda())
+    ok(x.grad, g["dx"], "dx")
+    ok(lin.lora_As["nlvr"].grad, g["da"], "dA"); ok(lin.lora_Bs["nlvr"].grad, g["dbb"], "dB")
+    ok(lin.bias.grad, g["dbias"], "dbias")
+
+
+def test_decoder_layer_hook_placement_golden():
+    """The reference BartDecoderLayer's state dict loads into the host layer by name and the fused
+    value-parallel adapter sits where the reference applies it (my_transformers/modeling_bart.py:427-430)."""
+    import vlpet_amd.host.bart as HB
+    g = load("dec_layer_d64_r8")
+    d, r, B, S_enc, S_dec = [int(v) for v in g["meta"]]
+    cfg = HB.vlpet_config(d_model=d, decoder_attention_heads=4, encoder_attention_heads=4, decoder_ffn_dim=4 * d,
+                          encoder_ffn_dim=4 * d, adapter_down_dim=r, adapter_gating_down_dim=r,
+                          decoder_enc_attn_value_parallel_adapter_down_dim=r, dropout=0.0, attention_dropout=0.0,
+                          activation_dropout=0.0)
+    layer = HB.BartDecoderLayer(cfg)
+    sd = {k[4:]: v for k, v in g.items() if k.startswith("sd::")}
+    missing, unexpected = layer.load_state_dict(sd, strict=True)
+    layer = layer.cuda().eval()
+    enc = cuda(g["enc"])
+    out = layer(g["hid"].cuda(), enc, None, "vqa")
+    ok(out, g["out"], "decoder layer out")
+    out.backward(g["dy"].cuda())
+    ok(enc.grad, g["denc"], "d enc")
+    for k, v in g.items():
+        if k.startswith("grad::"):
+            p = dict(layer.named_parameters())[k[6:]]
+            ok(p.grad, v, k)
+
+
+def test_tiny_host_model_fused_equals_eager():
+    """Tiny 2+2-layer BART host: loss and every trainable gradient from the HIP path (GPU) equal the same
+    model with the PET ops routed to the oracle on CPU."""
+    import vlpet_amd.host.bart as HB
+    import vlpet_amd.train as TR
+    from vlpet_amd.adapters.adapter_modeling import Adapter
+    from oracle import vlpet_oracle as O
+    cfg = HB.vlpet_config(d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
+                          decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128, vocab_size=300 + 200,
+                          max_position_embeddings=64, feat_dim=128, adapter_down_dim=8, adapter_gating_down_dim=16,
+                          decoder_enc_attn_value_parallel_adapter_down_dim=8, dropout=0.0, attention_dropout=0.0,
+                          activation_dropout=0.0)
+    torch.manual_seed(0)
+    model = HB.VLBart(cfg)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    TR.trainable_names(model, cfg)
+    gen = torch.Generator().manual_seed(5)
+    batch = TR.synthetic_batch("vqa", 6, cfg, "cpu", gen)
+
+    def loss_of(m, b):
+        per, _ = m(b["input_ids"], b["vis_inputs"], b["labels"], "vqa")
+        return TR.task_loss(per, b["labels"], b["scores"], "vqa")
+
+    # eager CPU (checker)
+    def cpu_apply(module, which, x1, x2, config):
+        downs = getattr(module, f"{which}_adapter_multihead_down"); up = getattr(module, f"{which}_adapter_multihead_up")
+        gd = getattr(module, f"encoder_{which}_adapter_gating_large_x_down")
+        gu = getattr(module, f"encoder_{which}_adapter_gating_large_x_up")
+        return O.encoder_adapter_gate(x1, x2, [m.weight for m in downs], [m.bias for m in downs], up.weight, up.bias,
+                                      dict(down_w=gd.weight, down_b=gd.bias, up_w=gu.weight, up_b=gu.bias), O.GATE_LARGE)
+
+    def cpu_fused(self, x, residual, scale=1.0):
+        return O.parallel_adapter(x, residual, self.down_sampler.weight, self.down_sampler.bias,
+                                  self.up_sampler.weight, self.up_sampler.bias, None if scale == 1.0 else scale)
+    saved = (HB.apply_pet, Adapter.fused)
+    HB.apply_pet, Adapter.fused = cpu_apply, cpu_fused
+    try:
+        model.eval()
+        l_ref = loss_of(model, batch)
+        l_ref.backward()
+        g_ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.requires_grad}
+        model.zero_grad()
+    finally:
+        HB.apply_pet, Adapter.fused = saved
+    model.cuda()
+    b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    b["vis_inputs"] = tuple(t.cuda() for t in batch["vis_inputs"])
+    l = loss_of(model, b)
+    l.backward()
+    assert abs(float(l) - float(l_ref)) <= 1e-3 * abs(float(l_ref))
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            ok(p.grad, g_ref[n], n)

@@ -1,0 +1,94 @@
+"""Host-side logic on CPU: parameter naming / freeze rules against the reference-derived fixtures,
+state-dict keys of the drop-in modules, task order, loss reduction, flat-gradient bookkeeping."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import vlpet_amd.host.bart as HB
+import vlpet_amd.train as TR
+from vlpet_amd.adapters import AdapterConfig, AdapterController
+from vlpet_amd.lora import LoraConfig, LoRALinearController
+from vlpet_amd.visual import VisualEmbedding
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+def test_layer_parameter_names_match_reference():
+    g = load("names_bart_vlpet_large")
+    cfg = HB.vlpet_config()
+    enc = HB.BartEncoderLayer(cfg)
+    dec = HB.BartDecoderLayer(cfg)
+    mine = {n: p.numel() for n, p in enc.named_parameters()}
+    ref = dict(zip([str(s) for s in g["enc_names"]], [int(v) for v in g["enc_numel"]]))
+    assert mine == ref
+    mine = {n: p.numel() for n, p in dec.named_parameters()}
+    ref = dict(zip([str(s) for s in g["dec_names"]], [int(v) for v in g["dec_numel"]]))
+    assert mine == ref
+
+
+@pytest.mark.timeout(600)
+def test_trainable_set_bart_vlpet_large():
+    cfg = HB.vlpet_config()
+    model = HB.VLBart(cfg)
+    names = TR.trainable_names(model, cfg)
+    n = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    total = sum(p.numel() for p in model.parameters())
+    assert (n, total) == (6052416, 145606464)          # README.md:360 -> 4.16 %
+    assert all(("adapter" in s or "gating" in s or "visual_embedding" in s or "layer_norm" in s or "layernorm" in s)
+               for s in names)
+    assert not any(s.startswith("model.decoder.") and "adapter" not in s for s in names)
+    assert "model.shared.weight" not in names
+
+
+def test_state_dict_keys_of_drop_in_modules():
+    keys = [str(s) for s in load("k2_d768_r96")["state_keys"]]
+    ctl = AdapterController(AdapterConfig(tasks=["vqa", "gqa", "nlvr", "caption"], d_model=768, input_dim=768,
+                                          use_single_adapter=True, use_adapter_down_dim=True, adapter_down_dim=96,
+                                          use_parallel_adapter=True))
+    assert sorted(ctl.state_dict().keys()) == keys
+    keys = [str(s) for s in load("k3_d64_r4")["state_keys"]]
+    lin = LoRALinearController(64, 64, config=LoraConfig(lora_dim=4, tasks=["vqa", "gqa", "nlvr", "caption"]), bias=True)
+    assert sorted(lin.state_dict().keys()) == keys
+    assert lin.scaling == 32 / 4 and not lin.weight.requires_grad
+    assert all(float(lin.lora_Bs[t].abs().sum()) == 0 for t in lin.tasks)    # B zero-init: step-0 output == frozen
+    keys = [str(s) for s in load("k4_bart_d64_f128")["state_keys"]]
+    cfg = HB.vlpet_config(d_model=64, feat_dim=128)
+    ve = VisualEmbedding(cfg, torch.nn.Embedding(200, 64))
+    assert sorted(ve.state_dict().keys()) == keys
+
+
+def test_task_order_and_batches():
+    steps = {"vqa": 3, "gqa": 2, "nlvr": 1, "caption": 2}
+    a = TR.epoch_task_order(["vqa", "gqa", "nlvr", "caption"], steps, 5)
+    b = TR.epoch_task_order(["vqa", "gqa", "nlvr", "caption"], steps, 5)
+    assert a == b and sorted(a) == sorted(sum(([t] * k for t, k in steps.items()), []))
+    assert a != TR.epoch_task_order(["vqa", "gqa", "nlvr", "caption"], steps, 6)
+    assert [TR.TASK_BATCH[t](500) for t in ("vqa", "gqa", "nlvr", "caption")] == [500, 833, 166, 416]
+
+
+def test_task_loss_reduction():
+    per = torch.tensor([[1.0, 3.0, 5.0], [2.0, 2.0, 2.0]])
+    labels = torch.tensor([[4, 5, -100], [7, -100, -100]])
+    scores = torch.tensor([1.0, 0.5])
+    assert torch.isclose(TR.task_loss(per, labels, scores, "vqa"), torch.tensor((2.0 * 1.0 + 2.0 * 0.5) / 2))
+    assert torch.isclose(TR.task_loss(per, labels, None, "caption"), torch.tensor((1 + 3 + 2) / 3.0))
+
+
+def test_flat_grads_views_and_clip():
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 2))
+    fg = TR.FlatGrads(m, world_size=1, n_buckets=2)
+    fg.zero()
+    x = torch.randn(4, 8)
+    m(x).sum().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in fg.params])
+    assert torch.equal(ref, fg.flat) and float(fg.flat.abs().sum()) > 0
+    norm = fg.clip_(0.1)
+    assert torch.isclose(torch.linalg.vector_norm(fg.flat), torch.tensor(0.1), atol=1e-5) and norm > 0.1
+    assert len(fg.buckets) == 2 and fg.buckets[0][0] == 0 and fg.buckets[-1][1] == fg.flat.numel()
