@@ -2,6 +2,7 @@
 #include "../../include/vlpet_hip.h"
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 #define VLPET_VERSION 100
 
@@ -85,6 +86,7 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
     a.keep = keep; a.keep_scale = keep_scale;
     a.M = M; a.d = d; a.RT = tiles;
     a.s2 = s2; a.sd = sd; a.gs = gs; a.flags = flags;
+    { const char* e = getenv("VLPET_DBG"); a.dbg = e ? atoi(e) : 0; }
     return herr(launch_pet_fwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));
 }
 

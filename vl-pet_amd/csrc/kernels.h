@@ -35,6 +35,7 @@ struct PetFwdArgs {
     int d, RT;
     float s2, sd, gs;      // x2 scale, delta scale, gate scale
     int flags;
+    int dbg;               // ablation bits (env VLPET_DBG; 0 in production): 1 no weight stream, 2 no row loads, 4 no MFMA, 8 no stores
 };
 hipError_t launch_pet_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream);
 

@@ -1,23 +1,14 @@
-// Weight re-pack: (down [r,d] as N_h head blocks, up [d,r], biases) -> MFMA fragment order.
-// Layout specification: vl-pet_amd/packing.py (pack_down / pack_up / pack_up_t / pack_down_t).
+// Weight re-pack: (down [r,d] as N_h head blocks, up [d,r], biases) -> MFMA fragment order for the
+// 16x16x32 kernels.  Layout specification: vl-pet_amd/packing.py section v3 (pack_down16 / pack_up16 /
+// pack_up_t16 / pack_down_t16), checked lane by lane in tests/test_layout_model16.py.
 // ~0.6 MB per pair, once per optimizer step; also performs the fp32 -> bf16 cast (NS = 1) or the
 // bf16 hi/lo split (NS = 2), so no separate cast pass over the parameters exists.
 #include "common.h"
 #include "kernels.h"
 
-__device__ __forceinline__ int pi_d(int ct, int i) {
-    int b = i >> 3, hp = (i >> 2) & 1, a = i & 3;
-    return 32 * ct + 16 * (b >> 1) + 8 * hp + 4 * (b & 1) + a;
-}
-__device__ __forceinline__ int pi_u(int nt, int i) {
-    int b = i >> 3, hp = (i >> 2) & 1, a = i & 3;
-    return 64 * (nt >> 1) + 32 * hp + 16 * (nt & 1) + 4 * b + a;
-}
-
 __device__ __forceinline__ float ld_src(const void* p, int64_t idx, int bf16_src) {
     return bf16_src ? (float)reinterpret_cast<const __bf16*>(p)[idx] : reinterpret_cast<const float*>(p)[idx];
 }
-
 __device__ __forceinline__ float fetch_down(const PackArgs& a, int c, int k) {
     if (c >= a.r) return 0.f;
     int head = c / a.rows_per_head;
@@ -31,41 +22,46 @@ __device__ __forceinline__ float fetch_up(const PackArgs& a, int f, int c) {
 
 template <int NS>
 __global__ __launch_bounds__(256) void pack_pair_kernel(PackArgs a) {
-    const int RT = a.RT, d = a.d, KT = 2 * RT;
-    const int NF = d / 16 * RT;
+    constexpr int FE = 64 / NS, KS = FE / 32, NQ = FE / 16, LW = FE / 4, E2 = LW / 8;
+    const int RT = a.RT, d = a.d;
+    const int NF = d / 16 * RT;                 // fragments per pack
     const int64_t slots = (int64_t)4 * NF * 64;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const PackGeom g = pack_geom(RT, d, NS);
+    const PackGeom geo = pack_geom(RT, d, NS);
     if (gid < slots) {
         const int lane = (int)(gid & 63);
         const int frag = (int)((gid >> 6) % NF);
         const int pack = (int)((gid >> 6) / NF);
-        const int i = lane & 31, hh = lane >> 5;
+        const int i = lane & 15, g = lane >> 4;
+        const int crow = 8 * (i >> 2) + (i & 3);        // + 32K + 4e : bottleneck index of MFMA row i
         float v[8];
-        if (pack == 0) {
-            int ct = frag % RT, u = (frag / RT) & 3, t = frag / (4 * RT);
-            int c = pi_d(ct, i);
+        if (pack == 0) {            // down: (stage, u, K, e)
+            const int per = KS * RT * 2, st = frag / per, rem = frag % per;
+            const int u = rem / (RT * 2), K = (rem >> 1) % RT, e = rem & 1;
+            const int c = 32 * K + crow + 4 * e;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fetch_down(a, c, 64 * t + 32 * hh + 8 * u + j);
-        } else if (pack == 1) {
-            int ks = frag % KT, nt = frag / KT;
-            int f = pi_u(nt, i);
+            for (int j = 0; j < 8; ++j) v[j] = fetch_down(a, c, FE * st + 32 * u + 8 * g + j);
+        } else if (pack == 1) {     // up: (stage, q, K)
+            const int per = NQ * RT, st = frag / per, rem = frag % per;
+            const int q = rem / RT, K = rem % RT;
+            const int f = FE * st + LW * (i >> 2) + 4 * q + (i & 3);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fetch_up(a, f, 16 * ks + 8 * hh + j);
-        } else if (pack == 2) {
-            int ct = frag % RT, e = (frag / RT) & 1, nt = frag / (2 * RT);
-            int c = pi_d(ct, i);
-            int fb = 64 * (nt >> 1) + 32 * hh + 16 * (nt & 1) + 8 * e;
+            for (int j = 0; j < 8; ++j) v[j] = fetch_up(a, f, 32 * K + 8 * g + j);
+        } else if (pack == 2) {     // up_t: (stage, e2, K, e)
+            const int per = E2 * RT * 2, st = frag / per, rem = frag % per;
+            const int e2 = rem / (RT * 2), K = (rem >> 1) % RT, e = rem & 1;
+            const int c = 32 * K + crow + 4 * e;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fetch_up(a, fb + j, c);
-        } else {
-            int ks = frag % KT, nt = frag / KT;
-            int k = pi_u(nt, i);
+            for (int j = 0; j < 8; ++j) v[j] = fetch_up(a, FE * st + LW * g + 8 * e2 + j, c);
+        } else {                    // down_t: (stage, q, K)
+            const int per = NQ * RT, st = frag / per, rem = frag % per;
+            const int q = rem / RT, K = rem % RT;
+            const int k = FE * st + LW * (i >> 2) + 4 * q + (i & 3);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fetch_down(a, 16 * ks + 8 * hh + j, k);
+            for (int j = 0; j < 8; ++j) v[j] = fetch_down(a, 32 * K + 8 * g + j, k);
         }
         Frag<NS> f = frag_from_f32<NS>(v);
-        uint8_t* base = a.out + (int64_t)pack * g.pack_bytes;
+        uint8_t* base = a.out + (int64_t)pack * geo.pack_bytes;
 #pragma unroll
         for (int p = 0; p < NS; ++p)
             *reinterpret_cast<bf16x8*>(base + ((int64_t)(frag * NS + p) * 64 + lane) * 16) = f.p[p];
@@ -73,7 +69,7 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(PackArgs a) {
     // biases (fp32, zero padded)
     const int64_t bid = gid - slots;
     if (bid >= 0 && bid < 32 * RT + d) {
-        float* bout = reinterpret_cast<float*>(a.out + g.bias_off);
+        float* bout = reinterpret_cast<float*>(a.out + geo.bias_off);
         float val = 0.f;
         if (bid < 32 * RT) {
             int c = (int)bid;

@@ -1,4 +1,4 @@
-// Fused PET backward, row-parallel part (same tiling as pet_fwd.hip):
+// Fused PET backward, row-parallel part (same v3 structure as pet_fwd.hip, see pet16.h):
 //   recompute z / zg / h / g from (xa, xg, res) -- no [M,r] or [M,d] intermediate was saved by the
 //   forward -- then
 //     dh = gs*dy (*g)           dq = gs*dy*h*g*(1-g)          (gate)
@@ -9,304 +9,364 @@
 //   the [d x r] weight-gradient accumulators of four matrices (4 x 295 KB fp32 per workgroup).
 // Autograd of: my_transformers/modeling_bart.py:1147-1155,1195-1209 (K1);
 // adapters/adapter_modeling.py:55-61 (K2); lora/controller.py:56-70 (K3).
+//
+// Stage stream (each stage = one fill of a ring slot: <= 8RT KiB of weight fragments + <= 2 row tiles):
+//   gate:     [down A|G + xa,xg] x S   [ (up A|G + res,dy), (up_t A|G) ] x S   [down_t A|G + dh] x S
+//   no gate:  [down A + xa] x S        [ up_t A + dy ] x S                      [down_t A] x S
 #include "common.h"
 #include "kernels.h"
-#include "pet_phases.h"
+#include "pet16.h"
 
-template <int NS, int RT, bool GATE>
-struct BwdCtx {
-    static constexpr int FB = NS * 1024;
-    static constexpr int STAGE_B = 4 * RT * FB;
-    static constexpr int HALF_B = 2 * RT * FB;
-    const uint8_t* pk_a;
-    const uint8_t* pk_g;
-    uint8_t* smem;
-    int64_t pack_bytes;
-    int tid, T, NT;
-    __device__ __forceinline__ uint8_t* buf(int i) const { return smem + i * STAGE_B; }
-    // stage stream: [down A: T] [down G: T] [per n-tile: (up A|up G), (up_t A|up_t G)] [per n-tile: (down_t A|down_t G)]
-    // without gate:  [down A: T] [per n-tile: up_t A] [per n-tile: down_t A]
-    __device__ __forceinline__ StageDesc stage(int s) const {
-        StageDesc r{pk_a, 0, pk_a, 0};
-        if (s < T) { r.p0 = pk_a + (int64_t)s * STAGE_B; r.u0 = STAGE_B / 16; return r; }
-        s -= T;
-        if constexpr (GATE) {
-            if (s < T) { r.p0 = pk_g + (int64_t)s * STAGE_B; r.u0 = STAGE_B / 16; return r; }
-            s -= T;
-            if (s < 2 * NT) {
-                const int nt = s >> 1;
-                const int64_t off = ((s & 1) ? 2 : 1) * pack_bytes + (int64_t)nt * HALF_B;
-                r.p0 = pk_a + off; r.u0 = HALF_B / 16; r.p1 = pk_g + off; r.u1 = HALF_B / 16;
-                return r;
-            }
-            s -= 2 * NT;
-        } else {
-            if (s < NT) { r.p0 = pk_a + 2 * pack_bytes + (int64_t)s * HALF_B; r.u0 = HALF_B / 16; return r; }
-            s -= NT;
-        }
-        if (s < NT) {
-            const int64_t off = 3 * pack_bytes + (int64_t)s * HALF_B;
-            r.p0 = pk_a + off; r.u0 = HALF_B / 16;
-            if constexpr (GATE) { r.p1 = pk_g + off; r.u1 = HALF_B / 16; }
-        }
-        return r;
-    }
+template <typename IO, int RT, bool GATE, int WAVES>
+struct BwdLds {
+    static constexpr int NS = Geo<IO>::NS;
+    static constexpr int SEG_KB = 4 * RT;
+    static constexpr int SEG_FR = SEG_KB / NS;
+    static constexpr int W_B = SEG_KB * 1024 * (GATE ? 2 : 1);
+    static constexpr int TILE_B = WAVES * 16 * 128;
+    static constexpr int SLOT_B = W_B + TILE_B * (GATE ? 2 : 1);
+    static constexpr int STAGING_OFF = 2 * SLOT_B;
+    static constexpr int BIAS_OFF = STAGING_OFF + TILE_B * (GATE ? 2 : 1);
+    static size_t bytes(int d) { return (size_t)BIAS_OFF + (size_t)2 * (32 * RT + d) * 4; }
 };
 
-template <typename IO, int RT, bool GATE, bool ACT_ID, bool DROP>
-__global__ __launch_bounds__(VLPET_THREADS) void pet_bwd_kernel(PetBwdArgs a) {
-    constexpr int NS = IoTraits<IO>::NS;
-    constexpr int KT = 2 * RT;
-    constexpr int MAXU = RT * NS;
-    using Ctx = BwdCtx<NS, RT, GATE>;
+template <typename IO, int RT, bool GATE, bool ACT_ID, bool DROP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
+    using G = Geo<IO>;
+    using L = BwdLds<IO, RT, GATE, WAVES>;
+    constexpr int NS = G::NS;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = lane & 31, h = lane >> 5;
+    const int m = lane & 15, g = lane >> 4;
+    const int trow = 16 * wave + m;
     const int d = a.d;
-    const int64_t row_raw = (int64_t)blockIdx.x * VLPET_ROWS_PER_WG + wave * 32 + m;
-    const bool row_ok = row_raw < a.M;
-    const int64_t row = row_ok ? row_raw : a.M - 1;
+    const int64_t row0_wave = (int64_t)blockIdx.x * (WAVES * 16) + wave * 16;
+    const int64_t grow_raw = row0_wave + m;
+    const bool row_ok = grow_raw < a.M;
+    const int64_t grow = row_ok ? grow_raw : a.M - 1;
+    const int S = d / G::FE;
+    const PackGeom pg = pack_geom(RT, d, NS);
+    const uint8_t* pkA = a.pk_a;
+    const uint8_t* pkG = GATE ? a.pk_g : a.pk_a;
+    const IO* xa = reinterpret_cast<const IO*>(a.xa);
+    const IO* xg = reinterpret_cast<const IO*>(a.xg);
+    const IO* res = reinterpret_cast<const IO*>(a.res);
+    const IO* dy = reinterpret_cast<const IO*>(a.dy);
+    IO* DH = reinterpret_cast<IO*>(a.dh);
+    IO* DQ = reinterpret_cast<IO*>(a.dq);
 
-    const PackGeom g = pack_geom(RT, d, NS);
-    Ctx c;
-    c.pk_a = a.pk_a; c.pk_g = a.pk_g; c.smem = smem; c.pack_bytes = g.pack_bytes;
-    c.tid = tid; c.T = d / 64; c.NT = d / 32;
-
-    float* sb = reinterpret_cast<float*>(smem + 2 * Ctx::STAGE_B);
+    auto slot_w = [&](int j) { return smem + (size_t)j * L::SLOT_B; };
+    auto slot_t0 = [&](int j) { return smem + (size_t)j * L::SLOT_B + L::W_B; };
+    auto slot_t1 = [&](int j) { return smem + (size_t)j * L::SLOT_B + L::W_B + L::TILE_B; };
+    uint8_t* stg0 = smem + L::STAGING_OFF;
+    uint8_t* stg1 = smem + L::STAGING_OFF + L::TILE_B;
+    float* sb = reinterpret_cast<float*>(smem + L::BIAS_OFF);
     const int nb = 32 * RT + d;
-    {
-        const float* ba = reinterpret_cast<const float*>(a.pk_a + g.bias_off);
-        for (int i = tid; i < nb; i += VLPET_THREADS) sb[i] = ba[i];
+    const int NU = GATE ? 2 * S : S;            // stages of the middle phase
+    const int total = S + NU + S;
+
+    auto issue = [&](int s) {
+        if (s >= total) return;
+        const int j = s & 1;
+        int pack, ss;
+        const IO* t0 = nullptr;
+        const IO* t1 = nullptr;
+        if (s < S) { pack = 0; ss = s; t0 = xa; if constexpr (GATE) t1 = xg; }
+        else if (s < S + NU) {
+            const int u = s - S;
+            if constexpr (GATE) {
+                ss = u >> 1;
+                if (u & 1) { pack = 2; }
+                else { pack = 1; t0 = res; t1 = dy; }
+            } else { ss = u; pack = 2; t0 = dy; }
+        } else { pack = 3; ss = s - S - NU; if constexpr (GATE) t0 = DH; }
+        const int64_t woff = (int64_t)pack * pg.pack_bytes + (int64_t)ss * L::SEG_KB * 1024;
+        glds_weights<WAVES>(pkA + woff, pkG + woff, L::SEG_KB, GATE ? L::SEG_KB : 0, slot_w(j), wave, lane);
+        if (t0) glds_rows<IO>(t0, row0_wave, a.M, d, ss * G::FE, slot_t0(j), wave, lane);
         if constexpr (GATE) {
-            const float* bg = reinterpret_cast<const float*>(a.pk_g + g.bias_off);
-            for (int i = tid; i < nb; i += VLPET_THREADS) sb[nb + i] = bg[i];
+            if (t1) glds_rows<IO>(t1, row0_wave, a.M, d, ss * G::FE, slot_t1(j), wave, lane);
         }
-    }
+    };
+
+    issue(0);
     {
-        StageRegs<MAXU> sr;
-        const StageDesc s0 = c.stage(0);
-        stage_load<MAXU>(sr, s0.p0, s0.u0, s0.p1, s0.u1, tid);
-        stage_store<MAXU>(sr, c.buf(0), s0.u0 + s0.u1, tid);
+        const float* ba = reinterpret_cast<const float*>(a.pk_a + pg.bias_off);
+        for (int i = tid; i < nb; i += WAVES * 64) sb[i] = ba[i];
+        if constexpr (GATE) {
+            const float* bg = reinterpret_cast<const float*>(a.pk_g + pg.bias_off);
+            for (int i = tid; i < nb; i += WAVES * 64) sb[nb + i] = bg[i];
+        }
     }
     __syncthreads();
 
+    // ---- phase 1: recompute the bottleneck pre-activations of both chains
+    f32x4 accA[RT][2];
+    f32x4 accG[GATE ? RT : 1][2];
+#pragma unroll
+    for (int K = 0; K < RT; ++K) { accA[K][0] = zero4(); accA[K][1] = zero4(); }
+    if constexpr (GATE) {
+#pragma unroll
+        for (int K = 0; K < RT; ++K) { accG[K][0] = zero4(); accG[K][1] = zero4(); }
+    }
     int s = 0;
-    // ---- recompute the bottleneck activations (+ gelu') of both chains
-    const IO* xa = reinterpret_cast<const IO*>(a.xa) + row * d + 32 * h;
-    const uint8_t* keeprow = DROP ? a.keep + row * d + 32 * h : nullptr;
-    Frag<NS> zA[KT];
-    f32x16 gpA[RT];
-    down_phase<IO, RT, ACT_ID, true, DROP>(c, s, xa, keeprow, a.keep_scale, sb + 8 * h, lane, zA, gpA);
-    Frag<NS> zG[GATE ? KT : 1];
-    f32x16 gpG[GATE ? RT : 1];
-    if constexpr (GATE) {
-        const IO* xg = reinterpret_cast<const IO*>(a.xg) + row * d + 32 * h;
-        down_phase<IO, RT, false, true, false>(c, s, xg, nullptr, 1.f, sb + nb + 8 * h, lane, zG, gpG);
-    }
-
-    const IO* dy = reinterpret_cast<const IO*>(a.dy) + row * d;
-    const float* sbu = sb + 32 * RT;
-    const float* sbgu = sb + nb + 32 * RT;
-    const float s2 = a.s2, sd = a.sd, gs = a.gs;
-    const bool gate_add = (a.flags & PET_GATE_ADD) != 0;
-
-    f32x16 dzA[RT];
-    f32x16 dzG[GATE ? RT : 1];
+    for (; s < S; ++s) {
+        issue(s + 1);
+        const uint8_t* w = slot_w(s & 1);
 #pragma unroll
-    for (int ct = 0; ct < RT; ++ct) dzA[ct] = zero16();
-    if constexpr (GATE) {
-#pragma unroll
-        for (int ct = 0; ct < RT; ++ct) dzG[ct] = zero16();
-    }
-
-    // ---- per n-tile: (gate) up projections + elementwise backward, then contraction over features
-    for (int nt = 0; nt < c.NT; ++nt) {
-        const int f0 = 64 * (nt >> 1) + 32 * h + 16 * (nt & 1);
-        Frag<NS> dfA[2], dfG[2];
-        float dyv[16];
-        load8_f32(dy + f0, dyv);
-        load8_f32(dy + f0 + 8, dyv + 8);
-        if constexpr (GATE) {
-            StageRegs<MAXU> sr;
-            const StageDesc nx = c.stage(s + 1);
-            stage_load<MAXU>(sr, nx.p0, nx.u0, nx.p1, nx.u1, tid);
-            const IO* res = reinterpret_cast<const IO*>(a.res) + row * d;
-            float r[16];
-            load8_f32(res + f0, r);
-            load8_f32(res + f0 + 8, r + 8);
-            const uint8_t* b = c.buf(s & 1);
-            f32x16 aA = zero16(), aG = zero16();
-#pragma unroll
-            for (int ks = 0; ks < KT; ++ks) aA = mfma_ns<NS>(lds_frag<NS>(b, ks, lane), zA[ks], aA);
-#pragma unroll
-            for (int ks = 0; ks < KT; ++ks) aG = mfma_ns<NS>(lds_frag<NS>(b, KT + ks, lane), zG[ks], aG);
-            float dh[16], dq[16], dd[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float hv = s2 * r[i] + sd * (aA[i] + sbu[f0 + i]);
-                const float gt = sigmoid_f(aG[i] + sbgu[f0 + i]);
-                const float dyp = gs * dyv[i];
-                dh[i] = gate_add ? dyp : dyp * gt;
-                const float dg = gate_add ? dyp : dyp * hv;
-                dq[i] = dg * gt * (1.0f - gt);
-                dd[i] = sd * dh[i];
-            }
-            if (row_ok) {
-                IO* DH = reinterpret_cast<IO*>(a.dh) + row * d + f0;
-                IO* DQ = reinterpret_cast<IO*>(a.dq) + row * d + f0;
-                store8_f32(DH, dh); store8_f32(DH + 8, dh + 8);
-                store8_f32(DQ, dq); store8_f32(DQ + 8, dq + 8);
-            }
-            dfA[0] = frag_from_f32<NS>(dd); dfA[1] = frag_from_f32<NS>(dd + 8);
-            dfG[0] = frag_from_f32<NS>(dq); dfG[1] = frag_from_f32<NS>(dq + 8);
-            stage_store<MAXU>(sr, c.buf((s + 1) & 1), nx.u0 + nx.u1, tid);
-            __syncthreads();
-            ++s;
-        } else {
-            float dd[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) dd[i] = sd * dyv[i];
-            dfA[0] = frag_from_f32<NS>(dd); dfA[1] = frag_from_f32<NS>(dd + 8);
-        }
-        {
-            StageRegs<MAXU> sr;
-            const StageDesc nx = c.stage(s + 1);
-            stage_load<MAXU>(sr, nx.p0, nx.u0, nx.p1, nx.u1, tid);
-            const uint8_t* b = c.buf(s & 1);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-#pragma unroll
-                for (int ct = 0; ct < RT; ++ct)
-                    dzA[ct] = mfma_ns<NS>(lds_frag<NS>(b, e * RT + ct, lane), dfA[e], dzA[ct]);
-            }
-            if constexpr (GATE) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-#pragma unroll
-                    for (int ct = 0; ct < RT; ++ct)
-                        dzG[ct] = mfma_ns<NS>(lds_frag<NS>(b, 2 * RT + e * RT + ct, lane), dfG[e], dzG[ct]);
-                }
-            }
-            stage_store<MAXU>(sr, c.buf((s + 1) & 1), nx.u0 + nx.u1, tid);
-            __syncthreads();
-            ++s;
-        }
-    }
-
-    // ---- dpre = dz * act'(pre); write the row-major side products for the weight gradients
-    const int ldz = 32 * RT;
-    Frag<NS> dpA[KT];
-    Frag<NS> dpG[GATE ? KT : 1];
-#pragma unroll
-    for (int ct = 0; ct < RT; ++ct) {
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = dzA[ct][8 * sh + j] * gpA[ct][8 * sh + j];
-            dpA[2 * ct + sh] = frag_from_f32<NS>(v);
-            if (row_ok) {
-                const int col = 32 * ct + 16 * sh + 8 * h;
-                float zv[8];
-                frag_to_f32<NS>(zA[2 * ct + sh], zv);
-                store8_f32(reinterpret_cast<IO*>(a.z_a) + row * ldz + col, zv);
-                store8_f32(reinterpret_cast<IO*>(a.dp_a) + row * ldz + col, v);
-            }
-        }
-    }
-    if constexpr (GATE) {
-#pragma unroll
-        for (int ct = 0; ct < RT; ++ct) {
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh) {
+        for (int u = 0; u < G::KS; ++u) {
+            Frag<NS> bA = tile_bfrag<IO>(slot_t0(s & 1), trow, g, u);
+            if constexpr (DROP) {
+                const uint64_t kp = *reinterpret_cast<const uint64_t*>(a.keep + grow * d + s * G::FE + 32 * u + 8 * g);
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = dzG[ct][8 * sh + j] * gpG[ct][8 * sh + j];
-                dpG[2 * ct + sh] = frag_from_f32<NS>(v);
-                if (row_ok) {
-                    const int col = 32 * ct + 16 * sh + 8 * h;
-                    float zv[8];
-                    frag_to_f32<NS>(zG[2 * ct + sh], zv);
-                    store8_f32(reinterpret_cast<IO*>(a.z_g) + row * ldz + col, zv);
-                    store8_f32(reinterpret_cast<IO*>(a.dp_g) + row * ldz + col, v);
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = (float)bA.p[0][j];
+                    if constexpr (NS == 2) v[j] += (float)bA.p[1][j];
+                    v[j] = ((kp >> (8 * j)) & 0xff) ? v[j] * a.keep_scale : 0.f;
                 }
+                bA = frag_from_f32<NS>(v);
+            }
+#pragma unroll
+            for (int K = 0; K < RT; ++K) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    accA[K][e] = mfma16_ns<NS>(wfrag<NS>(w, (u * RT + K) * 2 + e, lane), bA, accA[K][e]);
+            }
+            if constexpr (GATE) {
+                const Frag<NS> bG = tile_bfrag<IO>(slot_t1(s & 1), trow, g, u);
+#pragma unroll
+                for (int K = 0; K < RT; ++K) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        accG[K][e] = mfma16_ns<NS>(wfrag<NS>(w, L::SEG_FR + (u * RT + K) * 2 + e, lane), bG, accG[K][e]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // z = act(pre) as B fragments; accA / accG are overwritten with act'(pre)
+    Frag<NS> zA[RT];
+    Frag<NS> zG[GATE ? RT : 1];
+    {
+        const float* bdA = sb + 8 * g;
+        const float* bdG = sb + nb + 8 * g;
+#pragma unroll
+        for (int K = 0; K < RT; ++K) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pre = accA[K][j >> 2][j & 3] + bdA[32 * K + j];
+                v[j] = ACT_ID ? pre : gelu_new_f(pre);
+                accA[K][j >> 2][j & 3] = ACT_ID ? 1.0f : gelu_new_grad_f(pre);
+            }
+            zA[K] = frag_from_f32<NS>(v);
+            if constexpr (GATE) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pre = accG[K][j >> 2][j & 3] + bdG[32 * K + j];
+                    v[j] = gelu_new_f(pre);
+                    accG[K][j >> 2][j & 3] = gelu_new_grad_f(pre);
+                }
+                zG[K] = frag_from_f32<NS>(v);
             }
         }
     }
 
-    // ---- input gradients, n-tile by n-tile
-    for (int nt = 0; nt < c.NT; ++nt) {
-        StageRegs<MAXU> sr;
-        const StageDesc nx = c.stage(s + 1);
-        stage_load<MAXU>(sr, nx.p0, nx.u0, nx.p1, nx.u1, tid);
-        const int f0 = 64 * (nt >> 1) + 32 * h + 16 * (nt & 1);
-        float dhv[16];
+    // ---- phase 2: elementwise backward per feature group, then contraction over features
+    const float* buA = sb + 32 * RT + G::LW * g;
+    const float* buG = sb + nb + 32 * RT + G::LW * g;
+    const float s2 = a.s2, sd_ = a.sd, gs = a.gs;
+    const bool gate_add = (a.flags & PET_GATE_ADD) != 0;
+    f32x4 dzA[RT][2];
+    f32x4 dzG[GATE ? RT : 1][2];
+#pragma unroll
+    for (int K = 0; K < RT; ++K) { dzA[K][0] = zero4(); dzA[K][1] = zero4(); }
+    if constexpr (GATE) {
+#pragma unroll
+        for (int K = 0; K < RT; ++K) { dzG[K][0] = zero4(); dzG[K][1] = zero4(); }
+    }
+    for (int su = 0; su < S; ++su) {
+        Frag<NS> dfA[G::E2], dfG[G::E2];
         if constexpr (GATE) {
-            // s2*dh re-read: this lane wrote exactly these 16 elements in the n-tile loop above
-            const IO* DH = reinterpret_cast<const IO*>(a.dh) + row * d + f0;
-            load8_f32(DH, dhv);
-            load8_f32(DH + 8, dhv + 8);
-        }
-        uint64_t kp0 = 0, kp1 = 0;
-        if constexpr (DROP) {
-            kp0 = *reinterpret_cast<const uint64_t*>(a.keep + row * d + f0);
-            kp1 = *reinterpret_cast<const uint64_t*>(a.keep + row * d + f0 + 8);
-        }
-        const uint8_t* b = c.buf(s & 1);
-        f32x16 aA = zero16(), aG = zero16();
+            issue(s + 1);
+            const uint8_t* w = slot_w(s & 1);
+            float r[G::LW], dyv[G::LW], dh[G::LW], dq[G::LW], dd[G::LW];
+            tile_lane_vals<IO>(slot_t0(s & 1), trow, g, r);
+            tile_lane_vals<IO>(slot_t1(s & 1), trow, g, dyv);
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) aA = mfma_ns<NS>(lds_frag<NS>(b, ks, lane), dpA[ks], aA);
-        if constexpr (GATE) {
+            for (int q = 0; q < G::NQ; ++q) {
+                f32x4 aA = zero4(), aG = zero4();
 #pragma unroll
-            for (int ks = 0; ks < KT; ++ks) aG = mfma_ns<NS>(lds_frag<NS>(b, KT + ks, lane), dpG[ks], aG);
-        }
-        float oa[16], og[16];
+                for (int K = 0; K < RT; ++K) aA = mfma16_ns<NS>(wfrag<NS>(w, q * RT + K, lane), zA[K], aA);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float v = aA[i];
-            if constexpr (GATE) v += s2 * dhv[i];
-            if constexpr (DROP) {
-                const uint64_t k = i < 8 ? kp0 : kp1;
-                v = ((k >> (8 * (i & 7))) & 0xff) ? v * a.keep_scale : 0.f;
+                for (int K = 0; K < RT; ++K) aG = mfma16_ns<NS>(wfrag<NS>(w, L::SEG_FR + q * RT + K, lane), zG[K], aG);
+#pragma unroll
+                for (int rho = 0; rho < 4; ++rho) {
+                    const int i = 4 * q + rho;
+                    const float hv = s2 * r[i] + sd_ * (aA[rho] + buA[su * G::FE + i]);
+                    const float gt = sigmoid_f(aG[rho] + buG[su * G::FE + i]);
+                    const float dyp = gs * dyv[i];
+                    dh[i] = gate_add ? dyp : dyp * gt;
+                    const float dg = gate_add ? dyp : dyp * hv;
+                    dq[i] = dg * gt * (1.0f - gt);
+                    dd[i] = sd_ * dh[i];
+                }
             }
-            oa[i] = v;
-            og[i] = aG[i];
+            stage_lane_vals<IO>(stg0, trow, g, dh);
+            stage_lane_vals<IO>(stg1, trow, g, dq);
+            store_rows<IO>(DH, row0_wave, a.M, d, su * G::FE, stg0, wave, lane);
+            store_rows<IO>(DQ, row0_wave, a.M, d, su * G::FE, stg1, wave, lane);
+#pragma unroll
+            for (int e2 = 0; e2 < G::E2; ++e2) {
+                dfA[e2] = frag_from_f32<NS>(dd + 8 * e2);
+                dfG[e2] = frag_from_f32<NS>(dq + 8 * e2);
+            }
+            __syncthreads();
+            ++s;
         }
+        {
+            issue(s + 1);
+            const uint8_t* w = slot_w(s & 1);
+            if constexpr (!GATE) {
+                float dyv[G::LW];
+                tile_lane_vals<IO>(slot_t0(s & 1), trow, g, dyv);
+#pragma unroll
+                for (int i = 0; i < G::LW; ++i) dyv[i] *= sd_;
+#pragma unroll
+                for (int e2 = 0; e2 < G::E2; ++e2) dfA[e2] = frag_from_f32<NS>(dyv + 8 * e2);
+            }
+#pragma unroll
+            for (int e2 = 0; e2 < G::E2; ++e2) {
+#pragma unroll
+                for (int K = 0; K < RT; ++K) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        dzA[K][e] = mfma16_ns<NS>(wfrag<NS>(w, (e2 * RT + K) * 2 + e, lane), dfA[e2], dzA[K][e]);
+                }
+                if constexpr (GATE) {
+#pragma unroll
+                    for (int K = 0; K < RT; ++K) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            dzG[K][e] = mfma16_ns<NS>(wfrag<NS>(w, L::SEG_FR + (e2 * RT + K) * 2 + e, lane), dfG[e2], dzG[K][e]);
+                    }
+                }
+            }
+            __syncthreads();
+            ++s;
+        }
+    }
+
+    // ---- dpre = dz * act'(pre); row-major side products for the weight-gradient kernel
+    const int ldz = 32 * RT;
+    Frag<NS> dpA[RT];
+    Frag<NS> dpG[GATE ? RT : 1];
+#pragma unroll
+    for (int K = 0; K < RT; ++K) {
+        float v[8], zv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = dzA[K][j >> 2][j & 3] * accA[K][j >> 2][j & 3];
+        dpA[K] = frag_from_f32<NS>(v);
         if (row_ok) {
-            IO* dxa = reinterpret_cast<IO*>(a.dxa) + row * d + f0;
-            store8_f32(dxa, oa); store8_f32(dxa + 8, oa + 8);
-            if constexpr (GATE) {
-                IO* dxg = reinterpret_cast<IO*>(a.dxg) + row * d + f0;
-                store8_f32(dxg, og); store8_f32(dxg + 8, og + 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                zv[j] = (float)zA[K].p[0][j];
+                if constexpr (NS == 2) zv[j] += (float)zA[K].p[1][j];
+            }
+            store8_f32(reinterpret_cast<IO*>(a.z_a) + grow * ldz + 32 * K + 8 * g, zv);
+            store8_f32(reinterpret_cast<IO*>(a.dp_a) + grow * ldz + 32 * K + 8 * g, v);
+        }
+        if constexpr (GATE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = dzG[K][j >> 2][j & 3] * accG[K][j >> 2][j & 3];
+            dpG[K] = frag_from_f32<NS>(v);
+            if (row_ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    zv[j] = (float)zG[K].p[0][j];
+                    if constexpr (NS == 2) zv[j] += (float)zG[K].p[1][j];
+                }
+                store8_f32(reinterpret_cast<IO*>(a.z_g) + grow * ldz + 32 * K + 8 * g, zv);
+                store8_f32(reinterpret_cast<IO*>(a.dp_g) + grow * ldz + 32 * K + 8 * g, v);
             }
         }
-        stage_store<MAXU>(sr, c.buf((s + 1) & 1), nx.u0 + nx.u1, tid);
+    }
+
+    // ---- phase 3: input gradients
+    IO* dxa = reinterpret_cast<IO*>(a.dxa);
+    IO* dxg = reinterpret_cast<IO*>(a.dxg);
+    for (int su = 0; su < S; ++su, ++s) {
+        issue(s + 1);
+        const uint8_t* w = slot_w(s & 1);
+        float oa[G::LW], og[G::LW], dhv[G::LW];
+        if constexpr (GATE) tile_lane_vals<IO>(slot_t0(s & 1), trow, g, dhv);
+        uint64_t kp[2] = {0, 0};
+        if constexpr (DROP) {
+            // keep mask of the lane's LW features (uint8 each)
+            const uint8_t* kr = a.keep + grow * d + su * G::FE + G::LW * g;
+            kp[0] = *reinterpret_cast<const uint64_t*>(kr);
+            if constexpr (G::LW == 16) kp[1] = *reinterpret_cast<const uint64_t*>(kr + 8);
+        }
+#pragma unroll
+        for (int q = 0; q < G::NQ; ++q) {
+            f32x4 aA = zero4(), aG = zero4();
+#pragma unroll
+            for (int K = 0; K < RT; ++K) aA = mfma16_ns<NS>(wfrag<NS>(w, q * RT + K, lane), dpA[K], aA);
+            if constexpr (GATE) {
+#pragma unroll
+                for (int K = 0; K < RT; ++K) aG = mfma16_ns<NS>(wfrag<NS>(w, L::SEG_FR + q * RT + K, lane), dpG[K], aG);
+            }
+#pragma unroll
+            for (int rho = 0; rho < 4; ++rho) {
+                const int i = 4 * q + rho;
+                float v = aA[rho];
+                if constexpr (GATE) v += s2 * dhv[i];
+                if constexpr (DROP) v = ((kp[i >> 3] >> (8 * (i & 7))) & 0xff) ? v * a.keep_scale : 0.f;
+                oa[i] = v;
+                og[i] = aG[rho];
+            }
+        }
+        stage_lane_vals<IO>(stg0, trow, g, oa);
+        store_rows<IO>(dxa, row0_wave, a.M, d, su * G::FE, stg0, wave, lane);
+        if constexpr (GATE) {
+            stage_lane_vals<IO>(stg1, trow, g, og);
+            store_rows<IO>(dxg, row0_wave, a.M, d, su * G::FE, stg1, wave, lane);
+        }
         __syncthreads();
-        ++s;
     }
 }
 
-template <typename IO, int RT, bool GATE, bool ACT_ID, bool DROP>
+template <typename IO, int RT, bool GATE, bool ACT_ID, bool DROP, int WAVES>
 static hipError_t launch_one(const PetBwdArgs& a, hipStream_t stream) {
-    constexpr int NS = IoTraits<IO>::NS;
-    const size_t lds = 2 * (size_t)BwdCtx<NS, RT, GATE>::STAGE_B + (size_t)2 * (32 * RT + a.d) * 4;
-    auto kern = pet_bwd_kernel<IO, RT, GATE, ACT_ID, DROP>;
+    using L = BwdLds<IO, RT, GATE, WAVES>;
+    const size_t lds = L::bytes(a.d);
+    auto kern = pet_bwd_kernel<IO, RT, GATE, ACT_ID, DROP, WAVES>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const int blocks = (int)((a.M + VLPET_ROWS_PER_WG - 1) / VLPET_ROWS_PER_WG);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(VLPET_THREADS), lds, stream, a);
+    const int rows = WAVES * 16;
+    const int blocks = (int)((a.M + rows - 1) / rows);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError();
+}
+
+template <typename IO, int RT, bool GATE, bool ACT_ID, bool DROP>
+static hipError_t launch_waves(const PetBwdArgs& a, hipStream_t stream) {
+    if constexpr (BwdLds<IO, RT, GATE, 8>::BIAS_OFF + 16 * 1024 <= 160 * 1024)
+        return launch_one<IO, RT, GATE, ACT_ID, DROP, 8>(a, stream);
+    else
+        return launch_one<IO, RT, GATE, ACT_ID, DROP, 4>(a, stream);
 }
 
 template <typename IO, int RT>
 static hipError_t launch_rt(const PetBwdArgs& a, hipStream_t stream) {
     const bool gate = a.flags & PET_GATE, act_id = a.flags & PET_ACT_IDENTITY, drop = a.keep != nullptr;
-    if (gate) return launch_one<IO, RT, true, false, false>(a, stream);
-    if (act_id) return drop ? launch_one<IO, RT, false, true, true>(a, stream)
-                            : launch_one<IO, RT, false, true, false>(a, stream);
-    return launch_one<IO, RT, false, false, false>(a, stream);
+    if (gate) return launch_waves<IO, RT, true, false, false>(a, stream);
+    if (act_id) return drop ? launch_waves<IO, RT, false, true, true>(a, stream)
+                            : launch_waves<IO, RT, false, true, false>(a, stream);
+    return launch_waves<IO, RT, false, false, false>(a, stream);
 }
 
 template <typename IO>

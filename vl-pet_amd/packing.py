@@ -151,3 +151,113 @@ def packed_sizes(r: int, d: int):
     """number of fragments in each of the four packs of one (down [r,d], up [d,r]) pair."""
     RT, KT, T, NT = pad32(r) // 32, pad32(r) // 16, d // 64, d // 32
     return dict(down=T * 4 * RT, up=NT * KT, up_t=NT * 2 * RT, down_t=NT * KT)
+
+
+# ======================================================================================= v3
+# 16-row waves on v_mfma_f32_16x16x32_bf16 (8 waves per workgroup = 2 per SIMD, so MFMA, VALU and
+# memory work of different waves overlap).  A fragment: lane (i = lane & 15, g = lane >> 4) holds
+# MFMA row i, k-slots (g, j), j < 8.  C/D: register rho of lane (m = lane & 15, g) is row 4g + rho.
+# A *stage* always moves 128 bytes of every activation row: FE = 64 features (bf16 IO, NS = 1) or
+# 32 features (fp32 IO, NS = 2); KS = FE/32 MFMA k-steps (down phase), NQ = FE/16 n-tiles (up phase),
+# LW = FE/4 contiguous output features per lane.
+def stage_geom(NS: int):
+    FE = 64 // NS
+    return dict(FE=FE, KS=FE // 32, NQ=FE // 16, LW=FE // 4)
+
+
+def c_of16(K, e, i):
+    """bottleneck index of MFMA row i of c-tile (K, e): after the down projection lane (m, g) holds
+    c = 32K + 8g + 4e + rho, i.e. exactly the B operand (k-slot (g, j = 4e + rho)) of up-projection k-step K."""
+    return 32 * K + 8 * (i >> 2) + 4 * e + (i & 3)
+
+
+def f_of16(su, q, i, NS):
+    """output feature of MFMA row i of n-tile q of stage su: lane (m, g) ends with LW contiguous features."""
+    G = stage_geom(NS)
+    return G["FE"] * su + G["LW"] * (i >> 2) + 4 * q + (i & 3)
+
+
+def _lanes16():
+    lane = np.arange(64)
+    return lane & 15, lane >> 4
+
+
+def pack_down16(Wd: np.ndarray, NS: int = 1) -> np.ndarray:
+    """Wd [r, d] -> fragments (stage, u, K, e): slot = Wd[c_of16(K,e,i)][FE*stage + 32u + 8g + j]."""
+    r, d = Wd.shape
+    RT = pad32(r) // 32
+    G = stage_geom(NS)
+    S = d // G["FE"]
+    i, g = _lanes16()
+    j = np.arange(8)
+    out = np.zeros((S, G["KS"], RT, 2, 64, 8), dtype=Wd.dtype)
+    for s in range(S):
+        for u in range(G["KS"]):
+            for K in range(RT):
+                for e in range(2):
+                    rows = c_of16(K, e, i)[:, None]
+                    cols = G["FE"] * s + 32 * u + 8 * g[:, None] + j[None, :]
+                    out[s, u, K, e] = _gather(Wd, rows, cols, r, d)
+    return out.reshape(-1, FRAG)
+
+
+def pack_up16(Wu: np.ndarray, NS: int = 1) -> np.ndarray:
+    """Wu [d, r] -> fragments (stage, q, K): slot = Wu[f_of16(stage,q,i)][32K + 8g + j]."""
+    d, r = Wu.shape
+    RT = pad32(r) // 32
+    G = stage_geom(NS)
+    S = d // G["FE"]
+    i, g = _lanes16()
+    j = np.arange(8)
+    out = np.zeros((S, G["NQ"], RT, 64, 8), dtype=Wu.dtype)
+    for s in range(S):
+        for q in range(G["NQ"]):
+            for K in range(RT):
+                rows = f_of16(s, q, i, NS)[:, None]
+                cols = 32 * K + 8 * g[:, None] + j[None, :]
+                out[s, q, K] = _gather(Wu, rows, cols, d, r)
+    return out.reshape(-1, FRAG)
+
+
+def pack_up_t16(Wu: np.ndarray, NS: int = 1) -> np.ndarray:
+    """Wu [d, r] -> fragments (stage, e2, K, e): slot = Wu[FE*stage + LW*g + 8*e2 + j][c_of16(K,e,i)]."""
+    d, r = Wu.shape
+    RT = pad32(r) // 32
+    G = stage_geom(NS)
+    S = d // G["FE"]
+    i, g = _lanes16()
+    j = np.arange(8)
+    E2 = G["LW"] // 8
+    out = np.zeros((S, E2, RT, 2, 64, 8), dtype=Wu.dtype)
+    for s in range(S):
+        for e2 in range(E2):
+            for K in range(RT):
+                for e in range(2):
+                    rows = G["FE"] * s + G["LW"] * g[:, None] + 8 * e2 + j[None, :]
+                    cols = c_of16(K, e, i)[:, None]
+                    out[s, e2, K, e] = _gather(Wu, rows, cols, d, r)
+    return out.reshape(-1, FRAG)
+
+
+def pack_down_t16(Wd: np.ndarray, NS: int = 1) -> np.ndarray:
+    """Wd [r, d] -> fragments (stage, q, K): slot = Wd[32K + 8g + j][f_of16(stage,q,i)]."""
+    r, d = Wd.shape
+    RT = pad32(r) // 32
+    G = stage_geom(NS)
+    S = d // G["FE"]
+    i, g = _lanes16()
+    j = np.arange(8)
+    out = np.zeros((S, G["NQ"], RT, 64, 8), dtype=Wd.dtype)
+    for s in range(S):
+        for q in range(G["NQ"]):
+            for K in range(RT):
+                rows = 32 * K + 8 * g[:, None] + j[None, :]
+                cols = f_of16(s, q, i, NS)[:, None]
+                out[s, q, K] = _gather(Wd, rows, cols, r, d)
+    return out.reshape(-1, FRAG)
+
+
+def row_tile_slot(row_in_tile, piece):
+    """LDS slot (16-byte unit inside the 128-byte row segment) that holds `piece` of a staged row:
+    XOR swizzle so that the 16x16x32 B-fragment reads (16 rows x same piece) are bank-conflict free."""
+    return piece ^ ((row_in_tile >> 1) & 7)
