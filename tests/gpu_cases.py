@@ -141,7 +141,7 @@ def run_pack_check(r=96, d=768, nh=4, fp32=False, seed=3):
     pack_bytes = nf * NS * 1024
     wdp = np.zeros((32 * tiles, d), np.float32); wdp[:r] = wd.numpy()
     wup = np.zeros((d, 32 * tiles), np.float32); wup[:, :r] = wu.numpy()
-    specs = [PK.pack_down16(wdp, NS), PK.pack_up16(wup, NS), PK.pack_up_t16(wup, NS), PK.pack_down_t16(wdp, NS)]
+    specs = [PK.pack_down4(wdp, NS), PK.pack_up4(wup, NS), PK.pack_up_t4(wup, NS), PK.pack_down_t4(wdp, NS)]
     bad = 0
     for i, spec in enumerate(specs):
         got = raw[i * pack_bytes:(i + 1) * pack_bytes].view(np.uint16).reshape(nf, NS, 512)

@@ -3,6 +3,8 @@
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
+#include <stdio.h>
+#include <vector>
 
 #define VLPET_VERSION 100
 
@@ -87,6 +89,29 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
     a.M = M; a.d = d; a.RT = tiles;
     a.s2 = s2; a.sd = sd; a.gs = gs; a.flags = flags;
     { const char* e = getenv("VLPET_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg_ts = nullptr;
+    if (a.dbg & 16) {     // debug only: per-phase timestamps of wave 0 of every block, printed at the next call
+        static unsigned long long* dev = nullptr;
+        static int nblk = 0;
+        if (dev) {
+            hipDeviceSynchronize();
+            std::vector<unsigned long long> h((size_t)nblk * 8);
+            hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost);
+            double acc[8] = {0}; int n = 0;
+            for (int b = 0; b < nblk; b += 7) {
+                const unsigned long long* t = &h[(size_t)b * 8];
+                acc[0] += (double)(t[1] - t[0]); acc[1] += (double)(t[2] - t[1]); acc[2] += (double)(t[3] - t[2]);
+                acc[3] += (double)(t[4] - t[3]); acc[4] += (double)(t[6] - t[5]); acc[5] += (double)(t[7] - t[6]);
+                ++n;
+            }
+            fprintf(stderr, "[vlpet ts] cycles: prologue=%.0f down=%.0f act=%.0f up=%.0f | up-stage 5: reads+mfma=%.0f epilogue+stores=%.0f (n=%d)\n",
+                    acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, n);
+        } else {
+            hipMalloc(&dev, 4096 * 8 * 8);
+        }
+        nblk = (int)((M + 127) / 128); if (nblk > 4096) nblk = 4096;
+        a.dbg_ts = dev;
+    }
     return herr(launch_pet_fwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));
 }
 

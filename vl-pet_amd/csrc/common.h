@@ -52,16 +52,16 @@ __device__ __forceinline__ f32x16 zero16() {
 #define VLPET_GELU_K 0.7978845608028654f
 __device__ __forceinline__ float gelu_new_f(float x) {
     float u = VLPET_GELU_K * (x + 0.044715f * x * x * x);
-    return x / (1.0f + __expf(-2.0f * u));
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
 }
 __device__ __forceinline__ float gelu_new_grad_f(float x) {
     float x2 = x * x;
     float u = VLPET_GELU_K * (x + 0.044715f * x * x2);
-    float s = 1.0f / (1.0f + __expf(-2.0f * u));
+    float s = __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
     float du = VLPET_GELU_K * (1.0f + 3.0f * 0.044715f * x2);
     return s + x * s * (1.0f - s) * 2.0f * du;
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // ---------------------------------------------------------------- conversions
 __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {

@@ -35,7 +35,8 @@ struct PetFwdArgs {
     int d, RT;
     float s2, sd, gs;      // x2 scale, delta scale, gate scale
     int flags;
-    int dbg;               // ablation bits (env VLPET_DBG; 0 in production): 1 no weight stream, 2 no row loads, 4 no MFMA, 8 no stores
+    int dbg;               // ablation bits (env VLPET_DBG; 0 in production): 1 no weight stream, 2 no row loads, 8 no stores, 16 timestamps
+    unsigned long long* dbg_ts;   // [blocks][8] s_memtime stamps of wave 0 (only when dbg & 16)
 };
 hipError_t launch_pet_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream);
 

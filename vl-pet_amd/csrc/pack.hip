@@ -1,6 +1,6 @@
 // Weight re-pack: (down [r,d] as N_h head blocks, up [d,r], biases) -> MFMA fragment order for the
-// 16x16x32 kernels.  Layout specification: vl-pet_amd/packing.py section v3 (pack_down16 / pack_up16 /
-// pack_up_t16 / pack_down_t16), checked lane by lane in tests/test_layout_model16.py.
+// 32x32x16 kernels.  Layout specification: vl-pet_amd/packing.py section v4 (pack_down4 / pack_up4 /
+// pack_up_t4 / pack_down_t4), checked lane by lane in tests/test_layout_model32.py.
 // ~0.6 MB per pair, once per optimizer step; also performs the fp32 -> bf16 cast (NS = 1) or the
 // bf16 hi/lo split (NS = 2), so no separate cast pass over the parameters exists.
 #include "common.h"
@@ -22,8 +22,8 @@ __device__ __forceinline__ float fetch_up(const PackArgs& a, int f, int c) {
 
 template <int NS>
 __global__ __launch_bounds__(256) void pack_pair_kernel(PackArgs a) {
-    constexpr int FE = 64 / NS, KS = FE / 32, NQ = FE / 16, LW = FE / 4, E2 = LW / 8;
-    const int RT = a.RT, d = a.d;
+    constexpr int FE = 64 / NS, KU = FE / 16, NV = FE / 32, LW = FE / 2, E4 = FE / 16;
+    const int RT = a.RT, d = a.d, KT = 2 * RT;
     const int NF = d / 16 * RT;                 // fragments per pack
     const int64_t slots = (int64_t)4 * NF * 64;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -32,33 +32,31 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(PackArgs a) {
         const int lane = (int)(gid & 63);
         const int frag = (int)((gid >> 6) % NF);
         const int pack = (int)((gid >> 6) / NF);
-        const int i = lane & 15, g = lane >> 4;
-        const int crow = 8 * (i >> 2) + (i & 3);        // + 32K + 4e : bottleneck index of MFMA row i
+        const int i = lane & 31, hh = lane >> 5;
+        const int b = i >> 3, hp = (i >> 2) & 1, aa = i & 3;
+        const int crow = 16 * (b >> 1) + 8 * hp + 4 * (b & 1) + aa;   // + 32ct : bottleneck index of MFMA row i
+        const int frow = LW * hp + 4 * b + aa;                          // + FE*stage + 16v : feature of MFMA row i
         float v[8];
-        if (pack == 0) {            // down: (stage, u, K, e)
-            const int per = KS * RT * 2, st = frag / per, rem = frag % per;
-            const int u = rem / (RT * 2), K = (rem >> 1) % RT, e = rem & 1;
-            const int c = 32 * K + crow + 4 * e;
+        if (pack == 0) {            // down: (stage, u, ct)
+            const int per = KU * RT, st = frag / per, rem = frag % per;
+            const int u = rem / RT, ct = rem % RT;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fetch_down(a, c, FE * st + 32 * u + 8 * g + j);
-        } else if (pack == 1) {     // up: (stage, q, K)
-            const int per = NQ * RT, st = frag / per, rem = frag % per;
-            const int q = rem / RT, K = rem % RT;
-            const int f = FE * st + LW * (i >> 2) + 4 * q + (i & 3);
+            for (int j = 0; j < 8; ++j) v[j] = fetch_down(a, 32 * ct + crow, FE * st + 16 * u + 8 * hh + j);
+        } else if (pack == 1) {     // up: (stage, v, ks)
+            const int per = NV * KT, st = frag / per, rem = frag % per;
+            const int vv = rem / KT, ks = rem % KT;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fetch_up(a, f, 32 * K + 8 * g + j);
-        } else if (pack == 2) {     // up_t: (stage, e2, K, e)
-            const int per = E2 * RT * 2, st = frag / per, rem = frag % per;
-            const int e2 = rem / (RT * 2), K = (rem >> 1) % RT, e = rem & 1;
-            const int c = 32 * K + crow + 4 * e;
+            for (int j = 0; j < 8; ++j) v[j] = fetch_up(a, FE * st + 16 * vv + frow, 16 * ks + 8 * hh + j);
+        } else if (pack == 2) {     // up_t: (stage, e, ct)
+            const int per = E4 * RT, st = frag / per, rem = frag % per;
+            const int e = rem / RT, ct = rem % RT;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fetch_up(a, FE * st + LW * g + 8 * e2 + j, c);
-        } else {                    // down_t: (stage, q, K)
-            const int per = NQ * RT, st = frag / per, rem = frag % per;
-            const int q = rem / RT, K = rem % RT;
-            const int k = FE * st + LW * (i >> 2) + 4 * q + (i & 3);
+            for (int j = 0; j < 8; ++j) v[j] = fetch_up(a, FE * st + LW * hh + 8 * e + j, 32 * ct + crow);
+        } else {                    // down_t: (stage, v, ks)
+            const int per = NV * KT, st = frag / per, rem = frag % per;
+            const int vv = rem / KT, ks = rem % KT;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fetch_down(a, 32 * K + 8 * g + j, k);
+            for (int j = 0; j < 8; ++j) v[j] = fetch_down(a, 16 * ks + 8 * hh + j, FE * st + 16 * vv + frow);
         }
         Frag<NS> f = frag_from_f32<NS>(v);
         uint8_t* base = a.out + (int64_t)pack * geo.pack_bytes;

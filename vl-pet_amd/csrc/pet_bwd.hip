@@ -1,4 +1,4 @@
-// Fused PET backward, row-parallel part (same v3 structure as pet_fwd.hip, see pet16.h):
+// Fused PET backward, row-parallel part (same structure as pet_fwd.hip, see pet32.h):
 //   recompute z / zg / h / g from (xa, xg, res) -- no [M,r] or [M,d] intermediate was saved by the
 //   forward -- then
 //     dh = gs*dy (*g)           dq = gs*dy*h*g*(1-g)          (gate)
@@ -10,38 +10,43 @@
 // Autograd of: my_transformers/modeling_bart.py:1147-1155,1195-1209 (K1);
 // adapters/adapter_modeling.py:55-61 (K2); lora/controller.py:56-70 (K3).
 //
-// Stage stream (each stage = one fill of a ring slot: <= 8RT KiB of weight fragments + <= 2 row tiles):
+// Stage stream (a stage = <= 8RT KiB of weight fragments through the 2-slot weight ring + <= 2 row
+// tensors through the 3-slot row ring, rows prefetched two stages ahead):
 //   gate:     [down A|G + xa,xg] x S   [ (up A|G + res,dy), (up_t A|G) ] x S   [down_t A|G + dh] x S
 //   no gate:  [down A + xa] x S        [ up_t A + dy ] x S                      [down_t A] x S
+// The dh rows of the last phase are re-read from the dh side product this workgroup stored itself;
+// they are not prefetched across the phase boundary (the stores must have completed first).
 #include "common.h"
 #include "kernels.h"
-#include "pet16.h"
+#include "pet32.h"
 
 template <typename IO, int RT, bool GATE, int WAVES>
 struct BwdLds {
-    static constexpr int NS = Geo<IO>::NS;
+    static constexpr int NS = Geo4<IO>::NS;
     static constexpr int SEG_KB = 4 * RT;
     static constexpr int SEG_FR = SEG_KB / NS;
     static constexpr int W_B = SEG_KB * 1024 * (GATE ? 2 : 1);
-    static constexpr int TILE_B = WAVES * 16 * 128;
-    static constexpr int SLOT_B = W_B + TILE_B * (GATE ? 2 : 1);
-    static constexpr int STAGING_OFF = 2 * SLOT_B;
-    static constexpr int BIAS_OFF = STAGING_OFF + TILE_B * (GATE ? 2 : 1);
+    static constexpr int TILE_B = WAVES * 32 * 128;
+    static constexpr int ROW_B = TILE_B * (GATE ? 2 : 1);
+    static constexpr int NR = 3;
+    static constexpr int ROW_OFF = 2 * W_B;
+    static constexpr int BIAS_OFF = ROW_OFF + NR * ROW_B;
     static size_t bytes(int d) { return (size_t)BIAS_OFF + (size_t)2 * (32 * RT + d) * 4; }
 };
 
 template <typename IO, int RT, bool GATE, bool ACT_ID, bool DROP, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
-    using G = Geo<IO>;
+    using G = Geo4<IO>;
     using L = BwdLds<IO, RT, GATE, WAVES>;
     constexpr int NS = G::NS;
+    constexpr int KT = 2 * RT;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = lane & 15, g = lane >> 4;
-    const int trow = 16 * wave + m;
+    const int m = lane & 31, h = lane >> 5;
+    const int trow = 32 * wave + m;
     const int d = a.d;
-    const int64_t row0_wave = (int64_t)blockIdx.x * (WAVES * 16) + wave * 16;
+    const int64_t row0_wave = (int64_t)blockIdx.x * (WAVES * 32) + wave * 32;
     const int64_t grow_raw = row0_wave + m;
     const bool row_ok = grow_raw < a.M;
     const int64_t grow = row_ok ? grow_raw : a.M - 1;
@@ -49,47 +54,71 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
     const PackGeom pg = pack_geom(RT, d, NS);
     const uint8_t* pkA = a.pk_a;
     const uint8_t* pkG = GATE ? a.pk_g : a.pk_a;
-    const IO* xa = reinterpret_cast<const IO*>(a.xa);
-    const IO* xg = reinterpret_cast<const IO*>(a.xg);
-    const IO* res = reinterpret_cast<const IO*>(a.res);
-    const IO* dy = reinterpret_cast<const IO*>(a.dy);
-    IO* DH = reinterpret_cast<IO*>(a.dh);
-    IO* DQ = reinterpret_cast<IO*>(a.dq);
+    const uint8_t* xa = reinterpret_cast<const uint8_t*>(a.xa);
+    const uint8_t* xg = reinterpret_cast<const uint8_t*>(a.xg);
+    const uint8_t* res = reinterpret_cast<const uint8_t*>(a.res);
+    const uint8_t* dy = reinterpret_cast<const uint8_t*>(a.dy);
+    uint8_t* DH = reinterpret_cast<uint8_t*>(a.dh);
+    uint8_t* DQ = reinterpret_cast<uint8_t*>(a.dq);
 
-    auto slot_w = [&](int j) { return smem + (size_t)j * L::SLOT_B; };
-    auto slot_t0 = [&](int j) { return smem + (size_t)j * L::SLOT_B + L::W_B; };
-    auto slot_t1 = [&](int j) { return smem + (size_t)j * L::SLOT_B + L::W_B + L::TILE_B; };
-    uint8_t* stg0 = smem + L::STAGING_OFF;
-    uint8_t* stg1 = smem + L::STAGING_OFF + L::TILE_B;
+    auto slot_w = [&](int j) { return smem + (size_t)j * L::W_B; };
+    auto slot_t0 = [&](int j) { return smem + L::ROW_OFF + (size_t)j * L::ROW_B; };
+    auto slot_t1 = [&](int j) { return smem + L::ROW_OFF + (size_t)j * L::ROW_B + L::TILE_B; };
     float* sb = reinterpret_cast<float*>(smem + L::BIAS_OFF);
     const int nb = 32 * RT + d;
     const int NU = GATE ? 2 * S : S;            // stages of the middle phase
-    const int total = S + NU + S;
+    const int P3 = S + NU;                      // first stage of the input-gradient phase
+    const int total = P3 + S;
 
-    auto issue = [&](int s) {
-        if (s >= total) return;
-        const int j = s & 1;
-        int pack, ss;
-        const IO* t0 = nullptr;
-        const IO* t1 = nullptr;
-        if (s < S) { pack = 0; ss = s; t0 = xa; if constexpr (GATE) t1 = xg; }
-        else if (s < S + NU) {
+    const RowLanes rl = row_lanes<IO>(row0_wave, a.M, d, wave, lane);
+    const int lane16 = lane * 16;
+
+    // stage decoding: weight pack / pack stage, row tensors (t0, t1) and their stage offset
+    struct StageInfo { int pack, ss; const uint8_t* t0; const uint8_t* t1; };
+    auto info = [&](int s) {
+        StageInfo I{0, 0, nullptr, nullptr};
+        if (s < S) { I.pack = 0; I.ss = s; I.t0 = xa; if constexpr (GATE) I.t1 = xg; }
+        else if (s < P3) {
             const int u = s - S;
             if constexpr (GATE) {
-                ss = u >> 1;
-                if (u & 1) { pack = 2; }
-                else { pack = 1; t0 = res; t1 = dy; }
-            } else { ss = u; pack = 2; t0 = dy; }
-        } else { pack = 3; ss = s - S - NU; if constexpr (GATE) t0 = DH; }
-        const int64_t woff = (int64_t)pack * pg.pack_bytes + (int64_t)ss * L::SEG_KB * 1024;
-        glds_weights<WAVES>(pkA + woff, pkG + woff, L::SEG_KB, GATE ? L::SEG_KB : 0, slot_w(j), wave, lane);
-        if (t0) glds_rows<IO>(t0, row0_wave, a.M, d, ss * G::FE, slot_t0(j), wave, lane);
+                I.ss = u >> 1;
+                if (u & 1) I.pack = 2; else { I.pack = 1; I.t0 = res; I.t1 = dy; }
+            } else { I.ss = u; I.pack = 2; I.t0 = dy; }
+        } else { I.pack = 3; I.ss = s - P3; if constexpr (GATE) I.t0 = DH; }
+        return I;
+    };
+    // rows of stage s2 are issued two stages ahead, except the dh rows of phase 3 (see header)
+    auto rows_deferred = [&](int s2, int from) { return GATE && s2 >= P3 && from < P3; };
+    auto rows_count = [&](int s2, int from) {
+        if (s2 >= total || rows_deferred(s2, from)) return 0;
+        const StageInfo I = info(s2);
+        return (I.t0 ? 4 : 0) + (I.t1 ? 4 : 0);
+    };
+    auto issue_rows = [&](int s2, int from) {
+        if (s2 >= total || rows_deferred(s2, from)) return;
+        const StageInfo I = info(s2);
+        const int j = s2 % L::NR;
+        if (I.t0) glds_rows4(I.t0, rl, I.ss * 128, slot_t0(j), wave);
         if constexpr (GATE) {
-            if (t1) glds_rows<IO>(t1, row0_wave, a.M, d, ss * G::FE, slot_t1(j), wave, lane);
+            if (I.t1) glds_rows4(I.t1, rl, I.ss * 128, slot_t1(j), wave);
+        }
+    };
+    auto issue_w = [&](int s1) {
+        if (s1 >= total) return;
+        const StageInfo I = info(s1);
+        const int64_t woff = (int64_t)I.pack * pg.pack_bytes + (int64_t)I.ss * L::SEG_KB * 1024;
+        uint8_t* dst = slot_w(s1 & 1);
+        constexpr int KB = L::SEG_KB * (GATE ? 2 : 1);
+        for (int k = wave; k < KB; k += WAVES) {
+            const uint8_t* src = (k < L::SEG_KB ? pkA + woff + (size_t)k * 1024
+                                                : pkG + woff + (size_t)(k - L::SEG_KB) * 1024) + lane16;
+            glds16(src, dst + (size_t)k * 1024);
         }
     };
 
-    issue(0);
+    issue_w(0);
+    issue_rows(0, 0);
+    issue_rows(1, 0);
     {
         const float* ba = reinterpret_cast<const float*>(a.pk_a + pg.bias_off);
         for (int i = tid; i < nb; i += WAVES * 64) sb[i] = ba[i];
@@ -101,240 +130,336 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
     __syncthreads();
 
     // ---- phase 1: recompute the bottleneck pre-activations of both chains
-    f32x4 accA[RT][2];
-    f32x4 accG[GATE ? RT : 1][2];
+    f32x16 accA[RT];
+    f32x16 accG[GATE ? RT : 1];
 #pragma unroll
-    for (int K = 0; K < RT; ++K) { accA[K][0] = zero4(); accA[K][1] = zero4(); }
+    for (int ct = 0; ct < RT; ++ct) accA[ct] = zero16();
     if constexpr (GATE) {
 #pragma unroll
-        for (int K = 0; K < RT; ++K) { accG[K][0] = zero4(); accG[K][1] = zero4(); }
+        for (int ct = 0; ct < RT; ++ct) accG[ct] = zero16();
     }
     int s = 0;
     for (; s < S; ++s) {
-        issue(s + 1);
+        issue_w(s + 1);
+        issue_rows(s + 2, s);
         const uint8_t* w = slot_w(s & 1);
+        const uint8_t* ta = slot_t0(s % L::NR);
+        const uint8_t* tg = slot_t1(s % L::NR);
+        Frag<NS> bA[G::KU], wa[G::KU * RT];
 #pragma unroll
-        for (int u = 0; u < G::KS; ++u) {
-            Frag<NS> bA = tile_bfrag<IO>(slot_t0(s & 1), trow, g, u);
+        for (int u = 0; u < G::KU; ++u) {
+            bA[u] = tile_bfrag4<IO>(ta, trow, h, u);
             if constexpr (DROP) {
-                const uint64_t kp = *reinterpret_cast<const uint64_t*>(a.keep + grow * d + s * G::FE + 32 * u + 8 * g);
+                const uint64_t kp = *reinterpret_cast<const uint64_t*>(a.keep + grow * d + s * G::FE + 16 * u + 8 * h);
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    v[j] = (float)bA.p[0][j];
-                    if constexpr (NS == 2) v[j] += (float)bA.p[1][j];
+                    v[j] = (float)bA[u].p[0][j];
+                    if constexpr (NS == 2) v[j] += (float)bA[u].p[1][j];
                     v[j] = ((kp >> (8 * j)) & 0xff) ? v[j] * a.keep_scale : 0.f;
                 }
-                bA = frag_from_f32<NS>(v);
-            }
-#pragma unroll
-            for (int K = 0; K < RT; ++K) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    accA[K][e] = mfma16_ns<NS>(wfrag<NS>(w, (u * RT + K) * 2 + e, lane), bA, accA[K][e]);
-            }
-            if constexpr (GATE) {
-                const Frag<NS> bG = tile_bfrag<IO>(slot_t1(s & 1), trow, g, u);
-#pragma unroll
-                for (int K = 0; K < RT; ++K) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-                        accG[K][e] = mfma16_ns<NS>(wfrag<NS>(w, L::SEG_FR + (u * RT + K) * 2 + e, lane), bG, accG[K][e]);
-                }
+                bA[u] = frag_from_f32<NS>(v);
             }
         }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < G::KU * RT; ++i) wa[i] = wfrag<NS>(w, i, lane);
+        if constexpr (GATE) {
+            Frag<NS> bG[G::KU], wg[G::KU * RT];
+#pragma unroll
+            for (int u = 0; u < G::KU; ++u) bG[u] = tile_bfrag4<IO>(tg, trow, h, u);
+#pragma unroll
+            for (int i = 0; i < G::KU * RT; ++i) wg[i] = wfrag<NS>(w, L::SEG_FR + i, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < G::KU; ++u) {
+#pragma unroll
+                for (int ct = 0; ct < RT; ++ct) accA[ct] = mfma_ns<NS>(wa[u * RT + ct], bA[u], accA[ct]);
+            }
+#pragma unroll
+            for (int u = 0; u < G::KU; ++u) {
+#pragma unroll
+                for (int ct = 0; ct < RT; ++ct) accG[ct] = mfma_ns<NS>(wg[u * RT + ct], bG[u], accG[ct]);
+            }
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < G::KU; ++u) {
+#pragma unroll
+                for (int ct = 0; ct < RT; ++ct) accA[ct] = mfma_ns<NS>(wa[u * RT + ct], bA[u], accA[ct]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vm(rows_count(s + 2, s));
+        __builtin_amdgcn_s_barrier();
     }
 
     // z = act(pre) as B fragments; accA / accG are overwritten with act'(pre)
-    Frag<NS> zA[RT];
-    Frag<NS> zG[GATE ? RT : 1];
+    Frag<NS> zA[KT];
+    Frag<NS> zG[GATE ? KT : 1];
     {
-        const float* bdA = sb + 8 * g;
-        const float* bdG = sb + nb + 8 * g;
+        const float* bdA = sb + 8 * h;
+        const float* bdG = sb + nb + 8 * h;
 #pragma unroll
-        for (int K = 0; K < RT; ++K) {
-            float v[8];
+        for (int ct = 0; ct < RT; ++ct) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float pre = accA[K][j >> 2][j & 3] + bdA[32 * K + j];
-                v[j] = ACT_ID ? pre : gelu_new_f(pre);
-                accA[K][j >> 2][j & 3] = ACT_ID ? 1.0f : gelu_new_grad_f(pre);
-            }
-            zA[K] = frag_from_f32<NS>(v);
-            if constexpr (GATE) {
+            for (int sh = 0; sh < 2; ++sh) {
+                float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float pre = accG[K][j >> 2][j & 3] + bdG[32 * K + j];
-                    v[j] = gelu_new_f(pre);
-                    accG[K][j >> 2][j & 3] = gelu_new_grad_f(pre);
+                    const float pre = accA[ct][8 * sh + j] + bdA[32 * ct + 16 * sh + j];
+                    v[j] = ACT_ID ? pre : gelu_new_f(pre);
+                    accA[ct][8 * sh + j] = ACT_ID ? 1.0f : gelu_new_grad_f(pre);
                 }
-                zG[K] = frag_from_f32<NS>(v);
+                zA[2 * ct + sh] = frag_from_f32<NS>(v);
+                if constexpr (GATE) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float pre = accG[ct][8 * sh + j] + bdG[32 * ct + 16 * sh + j];
+                        v[j] = gelu_new_f(pre);
+                        accG[ct][8 * sh + j] = gelu_new_grad_f(pre);
+                    }
+                    zG[2 * ct + sh] = frag_from_f32<NS>(v);
+                }
             }
         }
     }
 
     // ---- phase 2: elementwise backward per feature group, then contraction over features
-    const float* buA = sb + 32 * RT + G::LW * g;
-    const float* buG = sb + nb + 32 * RT + G::LW * g;
+    const float* buA = sb + 32 * RT + G::LW * h;
+    const float* buG = sb + nb + 32 * RT + G::LW * h;
     const float s2 = a.s2, sd_ = a.sd, gs = a.gs;
     const bool gate_add = (a.flags & PET_GATE_ADD) != 0;
-    f32x4 dzA[RT][2];
-    f32x4 dzG[GATE ? RT : 1][2];
+    f32x16 dzA[RT];
+    f32x16 dzG[GATE ? RT : 1];
 #pragma unroll
-    for (int K = 0; K < RT; ++K) { dzA[K][0] = zero4(); dzA[K][1] = zero4(); }
+    for (int ct = 0; ct < RT; ++ct) dzA[ct] = zero16();
     if constexpr (GATE) {
 #pragma unroll
-        for (int K = 0; K < RT; ++K) { dzG[K][0] = zero4(); dzG[K][1] = zero4(); }
+        for (int ct = 0; ct < RT; ++ct) dzG[ct] = zero16();
     }
     for (int su = 0; su < S; ++su) {
-        Frag<NS> dfA[G::E2], dfG[G::E2];
+        Frag<NS> dfA[G::E4], dfG[G::E4];
         if constexpr (GATE) {
-            issue(s + 1);
+            issue_w(s + 1);
+            issue_rows(s + 2, s);
             const uint8_t* w = slot_w(s & 1);
-            float r[G::LW], dyv[G::LW], dh[G::LW], dq[G::LW], dd[G::LW];
-            tile_lane_vals<IO>(slot_t0(s & 1), trow, g, r);
-            tile_lane_vals<IO>(slot_t1(s & 1), trow, g, dyv);
+            uint8_t* t0 = slot_t0(s % L::NR);
+            uint8_t* t1 = slot_t1(s % L::NR);
+            f32x16 aA[G::NV], aG[G::NV];
 #pragma unroll
-            for (int q = 0; q < G::NQ; ++q) {
-                f32x4 aA = zero4(), aG = zero4();
+            for (int v = 0; v < G::NV; ++v) {
 #pragma unroll
-                for (int K = 0; K < RT; ++K) aA = mfma16_ns<NS>(wfrag<NS>(w, q * RT + K, lane), zA[K], aA);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 ta = *reinterpret_cast<const f32x4*>(buA + su * G::FE + 16 * v + 4 * q);
+                    const f32x4 tg = *reinterpret_cast<const f32x4*>(buG + su * G::FE + 16 * v + 4 * q);
 #pragma unroll
-                for (int K = 0; K < RT; ++K) aG = mfma16_ns<NS>(wfrag<NS>(w, L::SEG_FR + q * RT + K, lane), zG[K], aG);
-#pragma unroll
-                for (int rho = 0; rho < 4; ++rho) {
-                    const int i = 4 * q + rho;
-                    const float hv = s2 * r[i] + sd_ * (aA[rho] + buA[su * G::FE + i]);
-                    const float gt = sigmoid_f(aG[rho] + buG[su * G::FE + i]);
-                    const float dyp = gs * dyv[i];
-                    dh[i] = gate_add ? dyp : dyp * gt;
-                    const float dg = gate_add ? dyp : dyp * hv;
-                    dq[i] = dg * gt * (1.0f - gt);
-                    dd[i] = sd_ * dh[i];
+                    for (int c = 0; c < 4; ++c) { aA[v][4 * q + c] = ta[c]; aG[v][4 * q + c] = tg[c]; }
                 }
             }
-            stage_lane_vals<IO>(stg0, trow, g, dh);
-            stage_lane_vals<IO>(stg1, trow, g, dq);
-            store_rows<IO>(DH, row0_wave, a.M, d, su * G::FE, stg0, wave, lane);
-            store_rows<IO>(DQ, row0_wave, a.M, d, su * G::FE, stg1, wave, lane);
+            {
+                Frag<NS> wa[G::NV * KT], wg[G::NV * KT];
 #pragma unroll
-            for (int e2 = 0; e2 < G::E2; ++e2) {
-                dfA[e2] = frag_from_f32<NS>(dd + 8 * e2);
-                dfG[e2] = frag_from_f32<NS>(dq + 8 * e2);
+                for (int i = 0; i < G::NV * KT; ++i) wa[i] = wfrag<NS>(w, i, lane);
+#pragma unroll
+                for (int i = 0; i < G::NV * KT; ++i) wg[i] = wfrag<NS>(w, L::SEG_FR + i, lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KT; ++ks) {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) aG[v] = mfma_ns<NS>(wg[v * KT + ks], zG[ks], aG[v]);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KT; ++ks) {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) aA[v] = mfma_ns<NS>(wa[v * KT + ks], zA[ks], aA[v]);
+                }
             }
-            __syncthreads();
+            float r[G::LW], dyv[G::LW], dh[G::LW], dq[G::LW], dd[G::LW];
+            tile_lane_vals4<IO>(t0, trow, h, r);
+            tile_lane_vals4<IO>(t1, trow, h, dyv);
+#pragma unroll
+            for (int i = 0; i < G::LW; ++i) {
+                const float hv = s2 * r[i] + sd_ * aA[i >> 4][i & 15];
+                const float gt = sigmoid_f(aG[i >> 4][i & 15]);
+                const float dyp = gs * dyv[i];
+                dh[i] = gate_add ? dyp : dyp * gt;
+                const float dg = gate_add ? dyp : dyp * hv;
+                dq[i] = dg * gt * (1.0f - gt);
+                dd[i] = sd_ * dh[i];
+            }
+            // stage dh / dq in place of the res / dy rows of this wave, then whole-line stores
+            stage_lane_vals4<IO>(t0, trow, h, dh);
+            stage_lane_vals4<IO>(t1, trow, h, dq);
+            store_rows4(DH, rl, su * 128, t0, wave, lane);
+            store_rows4(DQ, rl, su * 128, t1, wave, lane);
+#pragma unroll
+            for (int e = 0; e < G::E4; ++e) {
+                dfA[e] = frag_from_f32<NS>(dd + 8 * e);
+                dfG[e] = frag_from_f32<NS>(dq + 8 * e);
+            }
+            wait_vm(rows_count(s + 2, s) + 2 * rl.n_inst);
+            __builtin_amdgcn_s_barrier();
             ++s;
         }
         {
-            issue(s + 1);
+            issue_w(s + 1);
+            issue_rows(s + 2, s);
             const uint8_t* w = slot_w(s & 1);
             if constexpr (!GATE) {
                 float dyv[G::LW];
-                tile_lane_vals<IO>(slot_t0(s & 1), trow, g, dyv);
+                tile_lane_vals4<IO>(slot_t0(s % L::NR), trow, h, dyv);
 #pragma unroll
                 for (int i = 0; i < G::LW; ++i) dyv[i] *= sd_;
 #pragma unroll
-                for (int e2 = 0; e2 < G::E2; ++e2) dfA[e2] = frag_from_f32<NS>(dyv + 8 * e2);
+                for (int e = 0; e < G::E4; ++e) dfA[e] = frag_from_f32<NS>(dyv + 8 * e);
             }
+            {
+                Frag<NS> wa[G::E4 * RT];
 #pragma unroll
-            for (int e2 = 0; e2 < G::E2; ++e2) {
-#pragma unroll
-                for (int K = 0; K < RT; ++K) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-                        dzA[K][e] = mfma16_ns<NS>(wfrag<NS>(w, (e2 * RT + K) * 2 + e, lane), dfA[e2], dzA[K][e]);
-                }
+                for (int i = 0; i < G::E4 * RT; ++i) wa[i] = wfrag<NS>(w, i, lane);
                 if constexpr (GATE) {
+                    Frag<NS> wg[G::E4 * RT];
 #pragma unroll
-                    for (int K = 0; K < RT; ++K) {
+                    for (int i = 0; i < G::E4 * RT; ++i) wg[i] = wfrag<NS>(w, L::SEG_FR + i, lane);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int e = 0; e < 2; ++e)
-                            dzG[K][e] = mfma16_ns<NS>(wfrag<NS>(w, L::SEG_FR + (e2 * RT + K) * 2 + e, lane), dfG[e2], dzG[K][e]);
+                    for (int e = 0; e < G::E4; ++e) {
+#pragma unroll
+                        for (int ct = 0; ct < RT; ++ct) dzA[ct] = mfma_ns<NS>(wa[e * RT + ct], dfA[e], dzA[ct]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < G::E4; ++e) {
+#pragma unroll
+                        for (int ct = 0; ct < RT; ++ct) dzG[ct] = mfma_ns<NS>(wg[e * RT + ct], dfG[e], dzG[ct]);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < G::E4; ++e) {
+#pragma unroll
+                        for (int ct = 0; ct < RT; ++ct) dzA[ct] = mfma_ns<NS>(wa[e * RT + ct], dfA[e], dzA[ct]);
                     }
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vm(rows_count(s + 2, s));
+            __builtin_amdgcn_s_barrier();
             ++s;
         }
     }
 
     // ---- dpre = dz * act'(pre); row-major side products for the weight-gradient kernel
     const int ldz = 32 * RT;
-    Frag<NS> dpA[RT];
-    Frag<NS> dpG[GATE ? RT : 1];
+    Frag<NS> dpA[KT];
+    Frag<NS> dpG[GATE ? KT : 1];
 #pragma unroll
-    for (int K = 0; K < RT; ++K) {
-        float v[8], zv[8];
+    for (int ct = 0; ct < RT; ++ct) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = dzA[K][j >> 2][j & 3] * accA[K][j >> 2][j & 3];
-        dpA[K] = frag_from_f32<NS>(v);
-        if (row_ok) {
+        for (int sh = 0; sh < 2; ++sh) {
+            float v[8], zv[8];
+            const int col = 32 * ct + 16 * sh + 8 * h;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                zv[j] = (float)zA[K].p[0][j];
-                if constexpr (NS == 2) zv[j] += (float)zA[K].p[1][j];
-            }
-            store8_f32(reinterpret_cast<IO*>(a.z_a) + grow * ldz + 32 * K + 8 * g, zv);
-            store8_f32(reinterpret_cast<IO*>(a.dp_a) + grow * ldz + 32 * K + 8 * g, v);
-        }
-        if constexpr (GATE) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = dzG[K][j >> 2][j & 3] * accG[K][j >> 2][j & 3];
-            dpG[K] = frag_from_f32<NS>(v);
+            for (int j = 0; j < 8; ++j) v[j] = dzA[ct][8 * sh + j] * accA[ct][8 * sh + j];
+            dpA[2 * ct + sh] = frag_from_f32<NS>(v);
             if (row_ok) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    zv[j] = (float)zG[K].p[0][j];
-                    if constexpr (NS == 2) zv[j] += (float)zG[K].p[1][j];
+                    zv[j] = (float)zA[2 * ct + sh].p[0][j];
+                    if constexpr (NS == 2) zv[j] += (float)zA[2 * ct + sh].p[1][j];
                 }
-                store8_f32(reinterpret_cast<IO*>(a.z_g) + grow * ldz + 32 * K + 8 * g, zv);
-                store8_f32(reinterpret_cast<IO*>(a.dp_g) + grow * ldz + 32 * K + 8 * g, v);
+                store8_f32(reinterpret_cast<IO*>(a.z_a) + grow * ldz + col, zv);
+                store8_f32(reinterpret_cast<IO*>(a.dp_a) + grow * ldz + col, v);
+            }
+            if constexpr (GATE) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = dzG[ct][8 * sh + j] * accG[ct][8 * sh + j];
+                dpG[2 * ct + sh] = frag_from_f32<NS>(v);
+                if (row_ok) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        zv[j] = (float)zG[2 * ct + sh].p[0][j];
+                        if constexpr (NS == 2) zv[j] += (float)zG[2 * ct + sh].p[1][j];
+                    }
+                    store8_f32(reinterpret_cast<IO*>(a.z_g) + grow * ldz + col, zv);
+                    store8_f32(reinterpret_cast<IO*>(a.dp_g) + grow * ldz + col, v);
+                }
             }
         }
     }
 
     // ---- phase 3: input gradients
-    IO* dxa = reinterpret_cast<IO*>(a.dxa);
-    IO* dxg = reinterpret_cast<IO*>(a.dxg);
+    uint8_t* dxa = reinterpret_cast<uint8_t*>(a.dxa);
+    uint8_t* dxg = reinterpret_cast<uint8_t*>(a.dxg);
+    if constexpr (GATE) {
+        // everything older (dh stores included) has completed at the last barrier's vmcnt(0);
+        // start the dh row stream now and wait for its first stage
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue_rows(P3, P3);
+        issue_rows(P3 + 1, P3);
+        wait_vm(rows_count(P3 + 1, P3));
+    }
     for (int su = 0; su < S; ++su, ++s) {
-        issue(s + 1);
+        issue_w(s + 1);
+        if (!(GATE && su == 0)) issue_rows(s + 2, s);
+        else issue_rows(s + 2, s);
         const uint8_t* w = slot_w(s & 1);
-        float oa[G::LW], og[G::LW], dhv[G::LW];
-        if constexpr (GATE) tile_lane_vals<IO>(slot_t0(s & 1), trow, g, dhv);
-        uint64_t kp[2] = {0, 0};
-        if constexpr (DROP) {
-            // keep mask of the lane's LW features (uint8 each)
-            const uint8_t* kr = a.keep + grow * d + su * G::FE + G::LW * g;
-            kp[0] = *reinterpret_cast<const uint64_t*>(kr);
-            if constexpr (G::LW == 16) kp[1] = *reinterpret_cast<const uint64_t*>(kr + 8);
-        }
+        uint8_t* t0 = slot_t0(s % L::NR);
+        uint8_t* t1 = slot_t1(s % L::NR);
+        f32x16 aA[G::NV], aG[G::NV];
 #pragma unroll
-        for (int q = 0; q < G::NQ; ++q) {
-            f32x4 aA = zero4(), aG = zero4();
+        for (int v = 0; v < G::NV; ++v) { aA[v] = zero16(); aG[v] = zero16(); }
+        {
+            Frag<NS> wa[G::NV * KT];
 #pragma unroll
-            for (int K = 0; K < RT; ++K) aA = mfma16_ns<NS>(wfrag<NS>(w, q * RT + K, lane), dpA[K], aA);
+            for (int i = 0; i < G::NV * KT; ++i) wa[i] = wfrag<NS>(w, i, lane);
             if constexpr (GATE) {
+                Frag<NS> wg[G::NV * KT];
 #pragma unroll
-                for (int K = 0; K < RT; ++K) aG = mfma16_ns<NS>(wfrag<NS>(w, L::SEG_FR + q * RT + K, lane), dpG[K], aG);
-            }
+                for (int i = 0; i < G::NV * KT; ++i) wg[i] = wfrag<NS>(w, L::SEG_FR + i, lane);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int rho = 0; rho < 4; ++rho) {
-                const int i = 4 * q + rho;
-                float v = aA[rho];
-                if constexpr (GATE) v += s2 * dhv[i];
-                if constexpr (DROP) v = ((kp[i >> 3] >> (8 * (i & 7))) & 0xff) ? v * a.keep_scale : 0.f;
-                oa[i] = v;
-                og[i] = aG[rho];
+                for (int ks = 0; ks < KT; ++ks) {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) aA[v] = mfma_ns<NS>(wa[v * KT + ks], dpA[ks], aA[v]);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KT; ++ks) {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) aG[v] = mfma_ns<NS>(wg[v * KT + ks], dpG[ks], aG[v]);
+                }
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KT; ++ks) {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) aA[v] = mfma_ns<NS>(wa[v * KT + ks], dpA[ks], aA[v]);
+                }
             }
         }
-        stage_lane_vals<IO>(stg0, trow, g, oa);
-        store_rows<IO>(dxa, row0_wave, a.M, d, su * G::FE, stg0, wave, lane);
+        float oa[G::LW], og[G::LW], dhv[G::LW];
+        if constexpr (GATE) tile_lane_vals4<IO>(t0, trow, h, dhv);
+        uint64_t kp[4] = {0, 0, 0, 0};
+        if constexpr (DROP) {
+            const uint8_t* kr = a.keep + grow * d + su * G::FE + G::LW * h;
+#pragma unroll
+            for (int c = 0; c < G::LW / 8; ++c) kp[c] = *reinterpret_cast<const uint64_t*>(kr + 8 * c);
+        }
+#pragma unroll
+        for (int i = 0; i < G::LW; ++i) {
+            float v = aA[i >> 4][i & 15];
+            if constexpr (GATE) v += s2 * dhv[i];
+            if constexpr (DROP) v = ((kp[i >> 3] >> (8 * (i & 7))) & 0xff) ? v * a.keep_scale : 0.f;
+            oa[i] = v;
+            og[i] = aG[i >> 4][i & 15];
+        }
+        stage_lane_vals4<IO>(t0, trow, h, oa);
+        store_rows4(dxa, rl, su * 128, t0, wave, lane);
         if constexpr (GATE) {
-            stage_lane_vals<IO>(stg1, trow, g, og);
-            store_rows<IO>(dxg, row0_wave, a.M, d, su * G::FE, stg1, wave, lane);
+            stage_lane_vals4<IO>(t1, trow, h, og);
+            store_rows4(dxg, rl, su * 128, t1, wave, lane);
         }
-        __syncthreads();
+        wait_vm(rows_count(s + 2, s) + (GATE ? 2 : 1) * rl.n_inst);
+        __builtin_amdgcn_s_barrier();
     }
 }
 
@@ -346,7 +471,7 @@ static hipError_t launch_one(const PetBwdArgs& a, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const int rows = WAVES * 16;
+    const int rows = WAVES * 32;
     const int blocks = (int)((a.M + rows - 1) / rows);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), lds, stream, a);
     return hipGetLastError();
@@ -354,10 +479,10 @@ static hipError_t launch_one(const PetBwdArgs& a, hipStream_t stream) {
 
 template <typename IO, int RT, bool GATE, bool ACT_ID, bool DROP>
 static hipError_t launch_waves(const PetBwdArgs& a, hipStream_t stream) {
-    if constexpr (BwdLds<IO, RT, GATE, 8>::BIAS_OFF + 16 * 1024 <= 160 * 1024)
-        return launch_one<IO, RT, GATE, ACT_ID, DROP, 8>(a, stream);
-    else
+    if constexpr (BwdLds<IO, RT, GATE, 4>::BIAS_OFF + 8 * 1024 <= 160 * 1024)
         return launch_one<IO, RT, GATE, ACT_ID, DROP, 4>(a, stream);
+    else
+        return launch_one<IO, RT, GATE, ACT_ID, DROP, 2>(a, stream);
 }
 
 template <typename IO, int RT>

@@ -261,3 +261,83 @@ def row_tile_slot(row_in_tile, piece):
     """LDS slot (16-byte unit inside the 128-byte row segment) that holds `piece` of a staged row:
     XOR swizzle so that the 16x16x32 B-fragment reads (16 rows x same piece) are bank-conflict free."""
     return piece ^ ((row_in_tile >> 1) & 7)
+
+
+# ======================================================================================= v4
+# 32-row waves on v_mfma_f32_32x32x16_bf16 (half the LDS fragment traffic per flop of the 16x16x32
+# form) with the v3 memory system (global_load_lds rings, 128 bytes of every row per stage).
+# Lane (m = lane & 31, h = lane >> 5); FE = 64 / NS features per stage; MFMA k-slot (h, j) of k-step u
+# is stage-local feature 16u + 8h + j; after the up phase a lane holds LW = FE/2 contiguous features.
+def stage_geom4(NS: int):
+    FE = 64 // NS
+    return dict(FE=FE, KU=FE // 16, NV=FE // 32, LW=FE // 2, E4=FE // 16)
+
+
+def f_of4(su, v, i, NS):
+    G = stage_geom4(NS)
+    b, hp, a = i >> 3, (i >> 2) & 1, i & 3
+    return G["FE"] * su + G["LW"] * hp + 16 * v + 4 * b + a
+
+
+def pack_down4(Wd: np.ndarray, NS: int = 1) -> np.ndarray:
+    """Wd [r, d] -> fragments (stage, u, ct): slot = Wd[pi_d(ct,i)][FE*stage + 16u + 8hh + j]."""
+    r, d = Wd.shape
+    RT = pad32(r) // 32
+    G = stage_geom4(NS)
+    S = d // G["FE"]
+    i, hh = _lanes()
+    j = np.arange(8)
+    out = np.zeros((S, G["KU"], RT, 64, 8), dtype=Wd.dtype)
+    for s in range(S):
+        for u in range(G["KU"]):
+            for ct in range(RT):
+                out[s, u, ct] = _gather(Wd, pi_d(ct, i)[:, None], G["FE"] * s + 16 * u + 8 * hh[:, None] + j[None, :], r, d)
+    return out.reshape(-1, FRAG)
+
+
+def pack_up4(Wu: np.ndarray, NS: int = 1) -> np.ndarray:
+    """Wu [d, r] -> fragments (stage, v, ks): slot = Wu[f_of4(stage,v,i)][16ks + 8hh + j]."""
+    d, r = Wu.shape
+    KT = pad32(r) // 16
+    G = stage_geom4(NS)
+    S = d // G["FE"]
+    i, hh = _lanes()
+    j = np.arange(8)
+    out = np.zeros((S, G["NV"], KT, 64, 8), dtype=Wu.dtype)
+    for s in range(S):
+        for v in range(G["NV"]):
+            for ks in range(KT):
+                out[s, v, ks] = _gather(Wu, f_of4(s, v, i, NS)[:, None], 16 * ks + 8 * hh[:, None] + j[None, :], d, r)
+    return out.reshape(-1, FRAG)
+
+
+def pack_up_t4(Wu: np.ndarray, NS: int = 1) -> np.ndarray:
+    """Wu [d, r] -> fragments (stage, e, ct): slot = Wu[FE*stage + LW*hh + 8e + j][pi_d(ct,i)], e < LW/8."""
+    d, r = Wu.shape
+    RT = pad32(r) // 32
+    G = stage_geom4(NS)
+    S = d // G["FE"]
+    i, hh = _lanes()
+    j = np.arange(8)
+    out = np.zeros((S, G["E4"], RT, 64, 8), dtype=Wu.dtype)
+    for s in range(S):
+        for e in range(G["E4"]):
+            for ct in range(RT):
+                out[s, e, ct] = _gather(Wu, G["FE"] * s + G["LW"] * hh[:, None] + 8 * e + j[None, :], pi_d(ct, i)[:, None], d, r)
+    return out.reshape(-1, FRAG)
+
+
+def pack_down_t4(Wd: np.ndarray, NS: int = 1) -> np.ndarray:
+    """Wd [r, d] -> fragments (stage, v, ks): slot = Wd[16ks + 8hh + j][f_of4(stage,v,i)]."""
+    r, d = Wd.shape
+    KT = pad32(r) // 16
+    G = stage_geom4(NS)
+    S = d // G["FE"]
+    i, hh = _lanes()
+    j = np.arange(8)
+    out = np.zeros((S, G["NV"], KT, 64, 8), dtype=Wd.dtype)
+    for s in range(S):
+        for v in range(G["NV"]):
+            for ks in range(KT):
+                out[s, v, ks] = _gather(Wd, 16 * ks + 8 * hh[:, None] + j[None, :], f_of4(s, v, i, NS)[:, None], r, d)
+    return out.reshape(-1, FRAG)
