@@ -7,8 +7,9 @@
 // 32 rows naturally (lane = row, 16/32 contiguous bytes) as an MFMA *A* fragment and multiplies it
 // by an identity B fragment: the product comes back in the C/D layout, i.e. transposed
 // (lane = column, registers = rows) -- exactly the A / B operand shape of the m-contraction.
-// No LDS transpose, no strided global access.  Row-chunk partials are written to a workspace
-// and summed by wgrad_finalize (deterministic: no atomics).
+// No LDS transpose, no strided global access.  The next 32-row block is loaded while the current one
+// is in the MFMAs (register double buffer).  Row-chunk partials are written to a workspace and summed
+// by wgrad_finalize (deterministic: no atomics).
 #include "common.h"
 #include "kernels.h"
 
@@ -36,7 +37,8 @@ size_t wgrad_workspace_bytes(int njobs, int RT, int xcols_max, int row_chunks) {
 void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* rows_per_chunk) {
     const int slices = xcols_max / 64;
     int64_t blocks128 = (M + 127) / 128;
-    int64_t rc = (768 + (int64_t)slices * njobs - 1) / ((int64_t)slices * njobs);
+    // ~1000 workgroups: two resident per CU, two rounds
+    int64_t rc = (1024 + (int64_t)slices * njobs - 1) / ((int64_t)slices * njobs);
     if (rc < 1) rc = 1;
     if (rc > blocks128) rc = blocks128;
     int64_t per = (blocks128 + rc - 1) / rc;          // 128-row blocks per chunk
@@ -45,21 +47,47 @@ void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* r
     *rows_per_chunk = per * 128;
 }
 
-template <typename IO, bool MASK>
-__device__ __forceinline__ Frag<IoTraits<IO>::NS> load_nat(const IO* p, bool valid, const uint8_t* keep,
-                                                           float keep_scale) {
-    constexpr int NS = IoTraits<IO>::NS;
-    float v[8];
-    if (valid) {
-        load8_f32(p, v);
-        if constexpr (MASK) {
-            if (keep != nullptr) {
-                const uint64_t k = *reinterpret_cast<const uint64_t*>(keep);
+// 8 contiguous IO elements, unconverted (what a prefetched load holds)
+template <typename IO> struct Raw8;
+template <> struct Raw8<__bf16> { bf16x8 v; };
+template <> struct Raw8<float> { f32x4 a, b; };
+
+__device__ __forceinline__ void raw_load(const __bf16* p, Raw8<__bf16>& r) { r.v = *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void raw_load(const float* p, Raw8<float>& r) {
+    r.a = reinterpret_cast<const f32x4*>(p)[0];
+    r.b = reinterpret_cast<const f32x4*>(p)[1];
+}
+__device__ __forceinline__ void raw_f32(const Raw8<__bf16>& r, float* v) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = ((k >> (8 * j)) & 0xff) ? v[j] * keep_scale : 0.f;
-            }
+    for (int j = 0; j < 8; ++j) v[j] = (float)r.v[j];
+}
+__device__ __forceinline__ void raw_f32(const Raw8<float>& r, float* v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = r.a[j]; v[4 + j] = r.b[j]; }
+}
+
+template <typename IO>
+__device__ __forceinline__ Frag<IoTraits<IO>::NS> raw_frag8(const Raw8<IO>& r, bool valid, const uint8_t* keep,
+                                                            float keep_scale) {
+    constexpr int NS = IoTraits<IO>::NS;
+    if constexpr (NS == 1) {
+        if (keep == nullptr) {
+            Frag<1> f;
+            bf16x8 z;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
+            f.p[0] = valid ? r.v : z;
+            return f;
         }
-    } else {
+    }
+    float v[8];
+    raw_f32(r, v);
+    if (keep != nullptr) {
+        const uint64_t k = *reinterpret_cast<const uint64_t*>(keep);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ((k >> (8 * j)) & 0xff) ? v[j] * keep_scale : 0.f;
+    }
+    if (!valid) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = 0.f;
     }
@@ -87,9 +115,14 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* red = reinterpret_cast<float*>(smem);
 
-    const WgradJob& J = a.job[blockIdx.z];
+    const int jb = blockIdx.z;
+    const IO* P = reinterpret_cast<const IO*>(a.job[jb].P);
+    const IO* X = reinterpret_cast<const IO*>(a.job[jb].X);
+    const uint8_t* keep = a.job[jb].keep;
+    const float keep_scale = a.job[jb].keep_scale;
+    const int ldp = a.job[jb].ldp, ldx = a.job[jb].ldx, xc = a.job[jb].xcols;
     const int n0 = blockIdx.x * 64;
-    if (n0 >= J.xcols) return;                  // uniform per block, before any barrier
+    if (n0 >= xc) return;                       // uniform per block, before any barrier
     const int rc = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, h = lane >> 5;
@@ -110,21 +143,37 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_kernel(WgradArgs a) {
     for (int ct = 0; ct < RT; ++ct) { acc[ct][0] = zero16(); acc[ct][1] = zero16(); csp[ct] = 0.f; }
     csx[0] = csx[1] = 0.f;
 
-    const IO* P = reinterpret_cast<const IO*>(J.P);
-    const IO* X = reinterpret_cast<const IO*>(J.X);
-    for (int64_t rb = r_begin + 32 * wave; rb < r_end; rb += 128) {
-        const int64_t row = rb + m;
-        const bool valid = row < r_end;
-        const int64_t rowc = valid ? row : r_end - 1;
+    Raw8<IO> rp[KT], rx[4];
+    auto load_block = [&](int64_t rb) {
+        int64_t row = rb + m;
+        if (row >= r_end) row = r_end - 1;
+        const IO* pr = P + row * ldp + 8 * h;
+        const IO* xr = X + row * ldx + n0 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) raw_load(pr + 16 * ks, rp[ks]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw_load(xr + 16 * q, rx[q]);
+    };
+
+    int64_t rb = r_begin + 32 * wave;
+    if (rb < r_end) load_block(rb);
+#pragma unroll 1
+    for (; rb < r_end; rb += 128) {
+        const bool valid = rb + m < r_end;
         Frag<NS> pn[KT], xn[4];
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks)
-            pn[ks] = load_nat<IO, false>(P + rowc * J.ldp + 16 * ks + 8 * h, valid, nullptr, 1.f);
+        for (int ks = 0; ks < KT; ++ks) pn[ks] = raw_frag8<IO>(rp[ks], valid, nullptr, 1.f);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int64_t off = rowc * J.ldx + n0 + 16 * q + 8 * h;
-            xn[q] = load_nat<IO, true>(X + off, valid, J.keep ? J.keep + off : nullptr, J.keep_scale);
+            const uint8_t* kp = nullptr;
+            if (keep != nullptr) {
+                int64_t row = rb + m;
+                if (row >= r_end) row = r_end - 1;
+                kp = keep + row * ldx + n0 + 16 * q + 8 * h;
+            }
+            xn[q] = raw_frag8<IO>(rx[q], valid, kp, keep_scale);
         }
+        if (rb + 128 < r_end) load_block(rb + 128);          // prefetch: in flight during the MFMAs below
         Frag<NS> xt[2][2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -182,8 +231,7 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_kernel(WgradArgs a) {
             csx[1] += src[(k++) * 64 + lane];
         }
         const WgradLayout L = wgrad_layout(a);
-        float* part = a.partial + L.off[blockIdx.z];
-        const int xc = J.xcols;
+        float* part = a.partial + L.off[jb];
         float* tile = part + (int64_t)rc * PR * xc;
 #pragma unroll
         for (int ct = 0; ct < RT; ++ct)
@@ -212,7 +260,8 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_kernel(WgradArgs a) {
     }
 }
 
-// sum the row-chunk partials, apply the scale, drop the rank padding, write in the parameter's layout
+// sum the row-chunk partials, apply the scale, drop the rank padding, write in the parameter's layout.
+// Threads run along n (the contiguous axis of the partials) so the reads are coalesced.
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(WgradArgs a) {
     const WgradJob& J = a.job[blockIdx.y];
     const int PR = 32 * a.RT;
@@ -222,9 +271,7 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(WgradArgs a) {
     const int64_t nmat = (int64_t)R * xc;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < nmat) {
-        int c, n;
-        if (J.transposed) { n = (int)(gid / R); c = (int)(gid % R); }   // consecutive threads -> consecutive out
-        else { c = (int)(gid / xc); n = (int)(gid % xc); }
+        const int c = (int)(gid / xc), n = (int)(gid % xc);
         float s = 0.f;
         for (int rc = 0; rc < RC; ++rc) s += part[((int64_t)rc * PR + c) * xc + n];
         s *= J.scale;
