@@ -50,8 +50,18 @@ def cpu_baseline(steps=10, warm=3, batch=4):
         return O.parallel_adapter(x, residual, self.down_sampler.weight, self.down_sampler.bias,
                                   self.up_sampler.weight, self.up_sampler.bias, None if scale == 1.0 else scale)
 
-    saved = (HB.apply_pet, Adapter.fused)
-    HB.apply_pet, Adapter.fused = cpu_apply_pet, cpu_fused
+    from vlpet_amd.visual import VisualEmbedding
+
+    def cpu_visual(self, feats, pos, img_order_ids=None, obj_order_ids=None):
+        fe, pe = self.feat_embedding, self.absolute_vis_pos_embedding
+        return O.visual_embedding(feats, pos, fe[0].weight, fe[0].bias, fe[1].weight, getattr(fe[1], "bias", None),
+                                  pe[0].weight, pe[0].bias, pe[1].weight, getattr(pe[1], "bias", None),
+                                  self.img_order_embedding.weight, self.obj_order_embedding.weight,
+                                  img_order_ids, obj_order_ids, rms=self.rms_norm)
+
+    saved = (HB.apply_pet, Adapter.fused, VisualEmbedding.forward)
+    HB.apply_pet, Adapter.fused, VisualEmbedding.forward = cpu_apply_pet, cpu_fused, cpu_visual
+    torch.set_num_threads(min(16, os.cpu_count() or 1))      # small-batch eager ops do not scale past ~16 threads
     try:
         torch.manual_seed(1234)
         cfg = HB.vlpet_config()
@@ -68,7 +78,7 @@ def cpu_baseline(steps=10, warm=3, batch=4):
             tr.step(b)
         dt = time.perf_counter() - t0
     finally:
-        HB.apply_pet, Adapter.fused = saved
+        HB.apply_pet, Adapter.fused, VisualEmbedding.forward = saved
     return dict(value=round(batch * steps / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"configs[0]: BART-base VL-PET-large r=96, VQA batch {batch}, S=20+36, fp32, full train step "
                        f"(fwd+bwd+clip+AdamW) through oracle/vlpet_oracle.py on the host CPU, {warm} warm-up + "

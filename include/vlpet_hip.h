@@ -133,6 +133,27 @@ int vlpet_lora_delta_bwd(const void* dy, const void* x, const void* packed,
                          int64_t M, int d, int tiles, float scaling,
                          int io_dtype, vlpet_stream_t stream);
 
+/* ---- K4: visual-feature projection -----------------------------------------------------------
+ * out = LayerNorm(feats @ W^T + b) * gamma + beta (+ R)
+ * replaces the feat_embedding branch of VisualEmbedding.forward (src/modeling_bart.py:91-110,157;
+ * T5: src/modeling_t5.py:56-66 with rms = 1, beta = NULL).  R [M, d_out] (IO dtype, may be NULL) is added
+ * after the norm: the caller passes the position branch + order embeddings (:162-183).
+ * feats [M, F], F % 64 == 0; d_out in {64, 128, 768}.  xhat [M, d_out] / rstd [M] (may be NULL) are the
+ * normalised activations and 1/sigma the backward needs.  W is packed once per optimizer step. */
+size_t vlpet_visproj_packed_bytes(int d_out, int feat_dim, int io_dtype);
+int vlpet_visproj_pack(const void* w, const void* b, int d_out, int feat_dim, int param_dtype, int io_dtype,
+                       void* packed, vlpet_stream_t stream);
+int vlpet_visproj_fwd(const void* feats, const void* packed, const float* gamma, const float* beta,
+                      const void* r, void* out, void* xhat, float* rstd,
+                      int64_t M, int feat_dim, int d_out, float eps, int rms,
+                      int io_dtype, vlpet_stream_t stream);
+/* Weight gradient of the projection:  dw [d_out, F] = dpre^T @ feats,  db [d_out] = column sums of dpre
+ * (dpre = gradient w.r.t. the pre-norm activations, [M, d_out], IO dtype).  fp32, overwritten. */
+size_t vlpet_visproj_wgrad_workspace_bytes(int64_t M, int feat_dim, int d_out);
+int vlpet_visproj_wgrad(const void* dpre, const void* feats, float* dw, float* db,
+                        void* workspace, size_t workspace_bytes,
+                        int64_t M, int feat_dim, int d_out, int io_dtype, vlpet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

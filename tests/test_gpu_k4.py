@@ -1,0 +1,87 @@
+"""GPU: K4 visual projection (HIP GEMM + LayerNorm kernel, MFMA weight gradient) -- the drop-in
+VisualEmbedding module against the golden fixtures of the reference class and against the oracle at the
+real shape (feat_dim 2048 -> 768)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+from gpu_cases import rel_err  # noqa: E402
+from oracle import vlpet_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind == "f" else z[k]) for k in z.files}
+
+
+def build(d, feat_dim, rms, vocab=200):
+    import vlpet_amd.host.bart as HB
+    from vlpet_amd.visual import VisualEmbedding
+    cfg = HB.vlpet_config(d_model=d, feat_dim=feat_dim)
+    table = torch.nn.Embedding(vocab, d)
+    return VisualEmbedding(cfg, table, rms_norm=rms), table
+
+
+@pytest.mark.parametrize("name", ["k4_bart_d64_f128", "k4_bart_nlvr_d64_f128", "k4_bart_d128_f256", "k4_t5_d64_f128"])
+def test_k4_golden(name):
+    g = load(name)
+    d, F, B, N = [int(v) for v in g["meta"]]
+    rms = bool(int(g["rms"]))
+    ve, table = build(d, F, rms)
+    with torch.no_grad():
+        fe, pe = ve.feat_embedding, ve.absolute_vis_pos_embedding
+        fe[0].weight.copy_(g["feat_w"]); fe[0].bias.copy_(g["feat_b"]); fe[1].weight.copy_(g["feat_ln_w"])
+        pe[0].weight.copy_(g["pos_w"]); pe[0].bias.copy_(g["pos_b"]); pe[1].weight.copy_(g["pos_ln_w"])
+        if not rms:
+            fe[1].bias.copy_(g["feat_ln_b"]); pe[1].bias.copy_(g["pos_ln_b"])
+        else:
+            fe[1].variance_epsilon = float(g["eps"]); pe[1].variance_epsilon = float(g["eps"])
+        ve.img_order_embedding.weight.copy_(g["img_table"]); table.weight.copy_(g["obj_table"])
+    ve = ve.cuda()
+    img_ids = torch.from_numpy(g["img_ids"]).cuda() if g["img_ids"].size else None
+    obj_ids = torch.from_numpy(g["obj_ids"]).cuda() if g["obj_ids"].size else None
+    out = ve(g["feats"].cuda(), g["pos"].cuda(), img_ids, obj_ids)
+    assert rel_err(out, g["out"]) <= 1e-3
+    out.backward(g["dy"].cuda())
+    fe, pe = ve.feat_embedding, ve.absolute_vis_pos_embedding
+    checks = [(fe[0].weight.grad, "d_feat_w"), (fe[0].bias.grad, "d_feat_b"), (fe[1].weight.grad, "d_feat_ln_w"),
+              (pe[0].weight.grad, "d_pos_w"), (pe[0].bias.grad, "d_pos_b"), (pe[1].weight.grad, "d_pos_ln_w"),
+              (ve.img_order_embedding.weight.grad, "d_img_table"), (ve.obj_order_embedding.weight.grad, "d_obj_table")]
+    if not rms:
+        checks += [(fe[1].bias.grad, "d_feat_ln_b"), (pe[1].bias.grad, "d_pos_ln_b")]
+    for got, key in checks:
+        assert rel_err(got, g[key]) <= 1e-3, key
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 1e-2)])
+def test_k4_real_shape_vs_oracle(dtype, tol):
+    torch.manual_seed(3)
+    B, N, F, d = 9, 36, 2048, 768            # 324 rows: a partial last workgroup
+    ve, table = build(d, F, False, vocab=300)
+    with torch.no_grad():
+        for p in ve.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    feats = torch.randn(B, N, F).to(dtype)
+    pos = torch.rand(B, N, 4)
+    dy = torch.randn(B, N, d).to(dtype)
+    fe, pe = ve.feat_embedding, ve.absolute_vis_pos_embedding
+    names = [fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias,
+             ve.img_order_embedding.weight, table.weight]
+    ref = [t.detach().clone().requires_grad_(True) for t in names]
+    out_ref = O.visual_embedding(feats.float(), pos, *ref[:8], ref[8], ref[9])
+    out_ref.backward(dy.float())
+    ve = ve.cuda()
+    out = ve(feats.cuda(), pos.cuda())
+    assert rel_err(out, out_ref) <= tol
+    out.backward(dy.cuda())
+    got = [fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias,
+           ve.img_order_embedding.weight]
+    for a, b in zip(got, ref[:9]):
+        assert rel_err(a.grad, b.grad) <= tol

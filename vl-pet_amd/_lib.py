@@ -41,6 +41,11 @@ SIGNATURES = {
                                                                              c_int, c_int, c_float, c_int, c_void_p]),
     "vlpet_lora_delta_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int,
                                      c_int, c_float, c_int, c_void_p]),
+    "vlpet_visproj_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vlpet_visproj_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vlpet_visproj_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "vlpet_visproj_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "vlpet_visproj_wgrad": (c_int, [c_void_p] * 5 + [c_size_t, c_int64, c_int, c_int, c_int, c_void_p]),
     "vlpet_lora_delta_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                                      c_int, c_void_p, c_size_t, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
 }

@@ -60,6 +60,7 @@ extern "C" int vlpet_pack_pair(const void* const* wd_heads, const void* const* b
     a.wu = wu; a.bu = bu;
     a.n_heads = n_heads; a.rows_per_head = r / n_heads;
     a.r = r; a.d = d; a.RT = tiles; a.src_bf16 = param_dtype == VLPET_BF16;
+    a.n_packs = 4;
     a.out = reinterpret_cast<uint8_t*>(packed);
     return herr(launch_pack_pair(a, io_dtype == VLPET_F32 ? 2 : 1, (hipStream_t)stream));
 }
@@ -297,4 +298,90 @@ extern "C" int vlpet_lora_delta_bwd(const void* dy, const void* x, const void* p
                    da, nullptr, db, nullptr, nullptr, nullptr, nullptr, nullptr, r, 0,
                    workspace, workspace_bytes, M, d, tiles, 1.f, scaling, 1.f, PET_ACT_IDENTITY,
                    io_dtype, stream);
+}
+
+
+// ------------------------------------------------------------------ K4: visual projection
+static inline bool dout_ok(int d) { return d == 64 || d == 128 || d == 768; }
+
+extern "C" size_t vlpet_visproj_packed_bytes(int d_out, int feat_dim, int io_dtype) {
+    const int NS = io_dtype == VLPET_F32 ? 2 : 1;
+    return align256((size_t)(feat_dim / 16) * (d_out / 32) * NS * 1024 + (size_t)(d_out + feat_dim) * 4);
+}
+
+extern "C" int vlpet_visproj_pack(const void* w, const void* b, int d_out, int feat_dim, int param_dtype,
+                                  int io_dtype, void* packed, vlpet_stream_t stream) {
+    if (!w || !packed) return VLPET_E_NULL;
+    if (!dout_ok(d_out) || feat_dim <= 0 || feat_dim % 64 != 0) return VLPET_E_SHAPE;
+    if (!dtype_ok(param_dtype) || !dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    if (!aligned16(packed)) return VLPET_E_ALIGN;
+    PackArgs a;
+    for (int i = 0; i < VLPET_MAX_HEADS; ++i) { a.wd[i] = nullptr; a.bd[i] = nullptr; }
+    a.wd[0] = w; a.bd[0] = b;
+    a.wu = nullptr; a.bu = nullptr;
+    a.n_heads = 1; a.rows_per_head = d_out;
+    a.r = d_out; a.d = feat_dim; a.RT = d_out / 32; a.src_bf16 = param_dtype == VLPET_BF16;
+    a.n_packs = 1;
+    a.out = reinterpret_cast<uint8_t*>(packed);
+    return herr(launch_pack_pair(a, io_dtype == VLPET_F32 ? 2 : 1, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_visproj_fwd(const void* feats, const void* packed, const float* gamma, const float* beta,
+                                 const void* r, void* out, void* xhat, float* rstd, int64_t M, int feat_dim,
+                                 int d_out, float eps, int rms, int io_dtype, vlpet_stream_t stream) {
+    if (!feats || !packed || !gamma || !out) return VLPET_E_NULL;
+    if (M <= 0 || !dout_ok(d_out) || feat_dim <= 0 || feat_dim % 64 != 0) return VLPET_E_SHAPE;
+    if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    if (!aligned16(feats) || !aligned16(packed) || !aligned16(out) || (r && !aligned16(r)) || (xhat && !aligned16(xhat)))
+        return VLPET_E_ALIGN;
+    VisprojArgs a;
+    a.feats = feats; a.pk = reinterpret_cast<const uint8_t*>(packed); a.gamma = gamma; a.beta = beta;
+    a.R = r; a.out = out; a.xhat = xhat; a.rstd = rstd;
+    a.M = M; a.F = feat_dim; a.d_out = d_out; a.eps = eps; a.rms = rms;
+    return herr(launch_visproj_fwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
+static void visproj_wgrad_plan(int64_t M, int feat_dim, int d_out, int* RT, int* pcols, int* rc, int64_t* rpc) {
+    *RT = (d_out % 96 == 0) ? 3 : 1;
+    *pcols = 32 * *RT;
+    wgrad_plan(M, 4, feat_dim, rc, rpc);
+}
+
+extern "C" size_t vlpet_visproj_wgrad_workspace_bytes(int64_t M, int feat_dim, int d_out) {
+    if (M <= 0 || feat_dim <= 0 || d_out <= 0) return 0;
+    int RT, pcols, rc; int64_t rpc;
+    visproj_wgrad_plan(M, feat_dim, d_out, &RT, &pcols, &rc, &rpc);
+    return align256(wgrad_workspace_bytes(4, RT, feat_dim, rc));
+}
+
+extern "C" int vlpet_visproj_wgrad(const void* dpre, const void* feats, float* dw, float* db, void* workspace,
+                                   size_t workspace_bytes, int64_t M, int feat_dim, int d_out, int io_dtype,
+                                   vlpet_stream_t stream) {
+    if (!dpre || !feats || !dw || !db || !workspace) return VLPET_E_NULL;
+    if (M <= 0 || d_out % 32 != 0 || feat_dim <= 0 || feat_dim % 64 != 0) return VLPET_E_SHAPE;
+    if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    if (!aligned16(dpre) || !aligned16(feats) || !aligned16(workspace)) return VLPET_E_ALIGN;
+    int RT, pcols, rc; int64_t rpc;
+    visproj_wgrad_plan(M, feat_dim, d_out, &RT, &pcols, &rc, &rpc);
+    if (workspace_bytes < wgrad_workspace_bytes(4, RT, feat_dim, rc)) return VLPET_E_WORKSPACE;
+    const size_t esz = io_dtype == VLPET_F32 ? 4 : 2;
+    const int njobs_total = d_out / pcols;
+    for (int j0 = 0; j0 < njobs_total; j0 += 4) {
+        WgradArgs g{};
+        g.M = M; g.RT = RT; g.row_chunks = rc; g.rows_per_chunk = rpc;
+        g.partial = reinterpret_cast<float*>(workspace);
+        g.njobs = njobs_total - j0 < 4 ? njobs_total - j0 : 4;
+        for (int j = 0; j < g.njobs; ++j) {
+            WgradJob& J = g.job[j];
+            const int c0 = (j0 + j) * pcols;
+            J.P = reinterpret_cast<const uint8_t*>(dpre) + (size_t)c0 * esz; J.ldp = d_out; J.pcols = pcols;
+            J.X = feats; J.ldx = feat_dim; J.xcols = feat_dim;
+            J.keep = nullptr; J.keep_scale = 1.f; J.scale = 1.f;
+            J.out = dw + (size_t)c0 * feat_dim; J.ldo = feat_dim; J.transposed = 0; J.out_rows = pcols;
+            J.colsum_x = nullptr; J.colsum_p = db + c0;
+        }
+        hipError_t e = launch_wgrad(g, io_dtype == VLPET_F32, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
 }

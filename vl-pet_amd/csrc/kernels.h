@@ -13,6 +13,7 @@ struct PackArgs {
     int n_heads, rows_per_head;
     int r, d, RT;                      // true rank, width, padded rank / 32
     int src_bf16;                      // parameter dtype: 0 fp32, 1 bf16
+    int n_packs;                       // 4 (adapter pair) or 1 (down pack only: visual projection; biases follow it)
     uint8_t* out;                      // packed pair (see pack_geom)
 };
 hipError_t launch_pack_pair(const PackArgs& a, int NS, hipStream_t stream);
@@ -86,3 +87,20 @@ struct WgradArgs {
 size_t wgrad_workspace_bytes(int njobs, int RT, int xcols_max, int row_chunks);
 void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* rows_per_chunk);
 hipError_t launch_wgrad(const WgradArgs& a, int io_fp32, hipStream_t stream);
+
+// K4: out = LN(feats . W^T + b) * gamma + beta (+ R); optionally stores xhat and rstd for the backward
+struct VisprojArgs {
+    const void* feats;      // [M, F]  IO dtype
+    const uint8_t* pk;      // down pack of W [d_out, F] (fragments (stage, u, ct)) followed by fp32 bias[d_out]
+    const float* gamma;     // [d_out]
+    const float* beta;      // [d_out] or nullptr (T5 RMS norm)
+    const void* R;          // [M, d_out] IO dtype or nullptr: added after the norm (position branch + order embeddings)
+    void* out;              // [M, d_out] IO dtype
+    void* xhat;             // [M, d_out] IO dtype or nullptr
+    float* rstd;            // [M] or nullptr
+    int64_t M;
+    int F, d_out;
+    float eps;
+    int rms;                // 1: no mean subtraction (T5LayerNorm)
+};
+hipError_t launch_visproj_fwd(const VisprojArgs& a, int io_fp32, hipStream_t stream);

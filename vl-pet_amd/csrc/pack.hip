@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(PackArgs a) {
     constexpr int FE = 64 / NS, KU = FE / 16, NV = FE / 32, LW = FE / 2, E4 = FE / 16;
     const int RT = a.RT, d = a.d, KT = 2 * RT;
     const int NF = d / 16 * RT;                 // fragments per pack
-    const int64_t slots = (int64_t)4 * NF * 64;
+    const int64_t slots = (int64_t)a.n_packs * NF * 64;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const PackGeom geo = pack_geom(RT, d, NS);
     if (gid < slots) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(PackArgs a) {
     // biases (fp32, zero padded)
     const int64_t bid = gid - slots;
     if (bid >= 0 && bid < 32 * RT + d) {
-        float* bout = reinterpret_cast<float*>(a.out + geo.bias_off);
+        float* bout = reinterpret_cast<float*>(a.out + (a.n_packs == 4 ? geo.bias_off : geo.pack_bytes));
         float val = 0.f;
         if (bid < 32 * RT) {
             int c = (int)bid;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(PackArgs a) {
 
 hipError_t launch_pack_pair(const PackArgs& a, int NS, hipStream_t stream) {
     const int NF = a.d / 16 * a.RT;
-    const int64_t total = (int64_t)4 * NF * 64 + 32 * a.RT + a.d;
+    const int64_t total = (int64_t)a.n_packs * NF * 64 + 32 * a.RT + a.d;
     const int blocks = (int)((total + 255) / 256);
     if (NS == 1) hipLaunchKernelGGL(pack_pair_kernel<1>, dim3(blocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(pack_pair_kernel<2>, dim3(blocks), dim3(256), 0, stream, a);

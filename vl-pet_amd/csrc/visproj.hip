@@ -1,0 +1,222 @@
+// K4 forward: visual-feature projection with fused bias + LayerNorm (+ residual add)
+//
+//     out = LN( feats . W^T + b ) * gamma + beta  (+ R)          feats [M, F], W [d_out, F]
+//
+// Reference: the feat_embedding branch of VisualEmbedding.forward (src/modeling_bart.py:157, the
+// nn.Sequential(Linear(feat_dim, d_model), LayerNorm) built at :91-110; T5: src/modeling_t5.py:56-66 with
+// T5LayerNorm); R carries the position branch + order embeddings (:162-183).
+//
+// A real contraction (K = 2048, 560 flop/B): MFMA-bound.  Same swapped-operand structure and memory
+// system as the adapter kernels (pet32.h): workgroup = 4 waves x 32 rows, every wave owns ALL d_out
+// output features of its rows (d_out/32 accumulator tiles = 384 registers at d_out = 768), so the
+// LayerNorm statistics need one cross-lane exchange (lane ^ 32) and no LDS.  W arrives as pre-packed A
+// fragments (pack_down4 layout with r = d_out) in sub-stages of 16 input features through a 2-slot ring,
+// the feature rows 128 bytes per row at a time through the 3-slot ring.  The epilogue walks the row in
+// 128-byte chunks: R in by global_load_lds, out / xhat staged in LDS and stored as whole lines.
+#include "common.h"
+#include "kernels.h"
+#include "pet32.h"
+
+template <typename IO, int NCT, int WAVES>
+struct VisLds {
+    static constexpr int NS = Geo4<IO>::NS;
+    static constexpr int WSUB_B = NCT * NS * 1024;           // one 16-feature sub-stage of W
+    static constexpr int TILE_B = WAVES * 32 * 128;
+    static constexpr int ROW_OFF = 2 * WSUB_B;
+    static constexpr int MAIN_B = ROW_OFF + 3 * TILE_B;
+    static constexpr int EPI_B = 4 * TILE_B;                 // R0, R1, OUT, XHAT tiles (alias the rings)
+    static constexpr int PARAM_OFF = MAIN_B > EPI_B ? MAIN_B : EPI_B;
+    static size_t bytes(int d_out) { return (size_t)PARAM_OFF + (size_t)3 * d_out * 4; }
+};
+
+// 8 consecutive features of the lane's row inside a 128-byte chunk tile: index idx8 (bf16: piece idx8; fp32: two pieces)
+template <typename IO>
+__device__ __forceinline__ void put8(uint8_t* tile, int trow, int idx8, const float* v) {
+    if constexpr (Geo4<IO>::NS == 1) {
+        bf16x8 t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = (__bf16)v[j];
+        *reinterpret_cast<bf16x8*>(const_cast<uint8_t*>(tile_piece(tile, trow, idx8))) = t;
+    } else {
+        const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f32x4*>(const_cast<uint8_t*>(tile_piece(tile, trow, 2 * idx8))) = a;
+        *reinterpret_cast<f32x4*>(const_cast<uint8_t*>(tile_piece(tile, trow, 2 * idx8 + 1))) = b;
+    }
+}
+template <typename IO>
+__device__ __forceinline__ void get8(const uint8_t* tile, int trow, int idx8, float* v) {
+    if constexpr (Geo4<IO>::NS == 1) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(tile_piece(tile, trow, idx8));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+    } else {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(tile_piece(tile, trow, 2 * idx8));
+        const f32x4 b = *reinterpret_cast<const f32x4*>(tile_piece(tile, trow, 2 * idx8 + 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+    }
+}
+
+template <typename IO, int NCT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void visproj_fwd_kernel(VisprojArgs a) {
+    using G = Geo4<IO>;
+    using L = VisLds<IO, NCT, WAVES>;
+    constexpr int NS = G::NS;
+    constexpr int GB = NCT < 12 ? NCT : 12;      // A fragments read per LDS burst
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int trow = 32 * wave + m;
+    const int F = a.F, d_out = 32 * NCT;
+    const int64_t row0_wave = (int64_t)blockIdx.x * (WAVES * 32) + wave * 32;
+    const int S = F / G::FE;                     // row stages
+    const int Q = S * G::KU;                     // weight sub-stages
+    const uint8_t* feats = reinterpret_cast<const uint8_t*>(a.feats);
+    const RowLanes rl = row_lanes<IO>(row0_wave, a.M, F, wave, lane);
+    const RowLanes rlo = row_lanes<IO>(row0_wave, a.M, d_out, wave, lane);
+    const int lane16 = lane * 16;
+
+    auto slot_w = [&](int j) { return smem + (size_t)j * L::WSUB_B; };
+    auto slot_t = [&](int j) { return smem + L::ROW_OFF + (size_t)j * L::TILE_B; };
+    float* sp = reinterpret_cast<float*>(smem + L::PARAM_OFF);      // bias | gamma | beta
+    auto issue_rows = [&](int s2) { if (s2 < S) glds_rows4(feats, rl, s2 * 128, slot_t(s2 % 3), wave); };
+    auto issue_w = [&](int q1) {
+        if (q1 >= Q) return;
+        const uint8_t* src0 = a.pk + (int64_t)q1 * L::WSUB_B;
+        uint8_t* dst = slot_w(q1 & 1);
+        constexpr int KB = NCT * NS;
+        for (int k = wave; k < KB; k += WAVES) glds16(src0 + (size_t)k * 1024 + lane16, dst + (size_t)k * 1024);
+    };
+
+    issue_w(0);
+    issue_rows(0);
+    issue_rows(1);
+    {
+        const float* bias = reinterpret_cast<const float*>(a.pk + (int64_t)(F / 16) * NCT * NS * 1024);
+        for (int i = tid; i < d_out; i += WAVES * 64) {
+            sp[i] = bias[i];
+            sp[d_out + i] = a.gamma[i];
+            sp[2 * d_out + i] = a.beta ? a.beta[i] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = zero16();
+    for (int q = 0; q < Q; ++q) {
+        const int s = q / G::KU, u = q % G::KU;
+        issue_w(q + 1);
+        if (u == 0) issue_rows(s + 2);
+        const uint8_t* w = slot_w(q & 1);
+        const Frag<NS> b = tile_bfrag4<IO>(slot_t(s % 3), trow, h, u);
+#pragma unroll
+        for (int g0 = 0; g0 < NCT; g0 += GB) {
+            Frag<NS> wa[GB];
+#pragma unroll
+            for (int i = 0; i < GB; ++i) wa[i] = wfrag<NS>(w, g0 + i, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < GB; ++i) acc[g0 + i] = mfma_ns<NS>(wa[i], b, acc[g0 + i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wait_vm((u == 0 && s + 2 < S) ? 4 : 0);
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- bias, LayerNorm statistics (lane + partner lane^32 hold the whole row)
+    const float* bias = sp + 8 * h;
+    const float* gam = sp + d_out + 8 * h;
+    const float* bet = sp + 2 * d_out + 8 * h;
+    float sum = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc[ct][i] += bias[32 * ct + 16 * (i >> 3) + (i & 7)];
+            sum += acc[ct][i];
+        }
+    }
+    sum += __shfl_xor(sum, 32);
+    const float mean = a.rms ? 0.f : sum / (float)d_out;
+    float sq = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float t = acc[ct][i] - mean; sq += t * t; }
+    }
+    sq += __shfl_xor(sq, 32);
+    const float rstd = rsqrtf(sq / (float)d_out + a.eps);
+    if (a.rstd != nullptr && h == 0 && row0_wave + m < a.M) a.rstd[row0_wave + m] = rstd;
+
+    // ---- epilogue in 128-byte chunks of the output row
+    constexpr int TPC = G::FE / 32;              // accumulator tiles per chunk
+    constexpr int NCH = NCT / TPC;               // chunks
+    uint8_t* tR[2] = {smem, smem + L::TILE_B};
+    uint8_t* tO = smem + 2 * L::TILE_B;
+    uint8_t* tX = smem + 3 * L::TILE_B;
+    const uint8_t* Rg = reinterpret_cast<const uint8_t*>(a.R);
+    uint8_t* Og = reinterpret_cast<uint8_t*>(a.out);
+    uint8_t* Xg = reinterpret_cast<uint8_t*>(a.xhat);
+    const int n_st = rlo.n_inst * (Xg ? 2 : 1);   // store instructions per chunk
+    __syncthreads();                              // everyone is done with the rings before they are re-used
+    if (Rg) glds_rows4(Rg, rlo, 0, tR[0], wave);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (Rg) {
+            if (ch + 1 < NCH) glds_rows4(Rg, rlo, (ch + 1) * 128, tR[(ch + 1) & 1], wave);
+            // R(ch) is older than the previous chunk's stores and the prefetch just issued
+            wait_vm((ch + 1 < NCH ? 4 : 0) + (ch > 0 ? n_st : 0));
+        }
+#pragma unroll
+        for (int tl = 0; tl < TPC; ++tl) {
+            const int ct = ch * TPC + tl;
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                const int idx8 = (TPC == 2 ? 4 * tl : 0) + 2 * sh + h;
+                float xv[8], ov[8], rv[8];
+                if (Rg) get8<IO>(tR[ch & 1], trow, idx8, rv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 32 * ct + 16 * sh + j;            // + 8h folded into gam / bet
+                    xv[j] = (acc[ct][8 * sh + j] - mean) * rstd;
+                    ov[j] = xv[j] * gam[c] + bet[c] + (Rg ? rv[j] : 0.f);
+                }
+                put8<IO>(tO, trow, idx8, ov);
+                if (Xg) put8<IO>(tX, trow, idx8, xv);
+            }
+        }
+        store_rows4(Og, rlo, ch * 128, tO, wave, lane);
+        if (Xg) store_rows4(Xg, rlo, ch * 128, tX, wave, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // staging tiles are re-written next chunk
+    }
+}
+
+template <typename IO, int NCT>
+static hipError_t launch_nct(const VisprojArgs& a, hipStream_t stream) {
+    constexpr int WAVES = 4;
+    using L = VisLds<IO, NCT, WAVES>;
+    const size_t lds = L::bytes(a.d_out);
+    auto kern = visproj_fwd_kernel<IO, NCT, WAVES>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int rows = WAVES * 32;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + rows - 1) / rows)), dim3(WAVES * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <typename IO>
+static hipError_t launch_io(const VisprojArgs& a, hipStream_t stream) {
+    switch (a.d_out) {
+        case 64: return launch_nct<IO, 2>(a, stream);
+        case 128: return launch_nct<IO, 4>(a, stream);
+        case 768: return launch_nct<IO, 24>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_visproj_fwd(const VisprojArgs& a, int io_fp32, hipStream_t stream) {
+    return io_fp32 ? launch_io<float>(a, stream) : launch_io<__bf16>(a, stream);
+}

@@ -243,6 +243,9 @@ class JointEncoder(nn.Module):
     def forward(self, input_ids, vis_inputs, attention_mask=None, task=None):
         B, L = input_ids.shape
         x = self.embed_tokens(input_ids) * self.embed_scale + self.embed_positions(L, input_ids.device)
+        if vis_inputs[0].dtype != x.dtype:
+            # compute dtype before the max-pool (rounding is monotone, so pool(round(f)) == round(pool(f)))
+            vis_inputs = (vis_inputs[0].to(x.dtype),) + tuple(vis_inputs[1:])
         if self.downsample is not None:
             vis_inputs = self.downsample(vis_inputs)
         feats, boxes = vis_inputs[0], vis_inputs[1]

@@ -1,0 +1,101 @@
+"""K4 host glue: visual-feature projection Linear(feat_dim -> d_model) + LayerNorm (+ residual add) on the
+HIP kernel (csrc/visproj.hip), weight gradient on the column-parallel MFMA kernel (csrc/wgrad.hip).
+
+The LayerNorm backward (an elementwise pass + two row reductions over [M, d_model]) is expressed with
+torch ops on the saved normalised activations; the two heavy contractions (K = feat_dim forward,
+K = M weight gradient) are the hand-written kernels.  No CPU fallback."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .functional import _flat, _io_dtype, _need_cuda, _param_dtype, _ptr, _stream, _timed, _grad_like
+
+
+class VisProjPackCache:
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, w: torch.Tensor, b: torch.Tensor, io_dtype: int) -> torch.Tensor:
+        key = (io_dtype, w.data_ptr(), w._version, b.data_ptr(), b._version)
+        if key != self._key:
+            lib = _lib.load()
+            d_out, F = w.shape
+            buf = torch.empty(lib.vlpet_visproj_packed_bytes(d_out, F, io_dtype), dtype=torch.uint8, device=w.device)
+            wc, bc = w.detach().contiguous(), b.detach().contiguous()
+            rc = lib.vlpet_visproj_pack(wc.data_ptr(), bc.data_ptr(), d_out, F, _param_dtype(wc), io_dtype,
+                                        buf.data_ptr(), _stream())
+            _lib.check(rc, "vlpet_visproj_pack")
+            self._key, self._val = key, buf
+        return self._val
+
+
+class _VisProjFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, R, w, b, gamma, beta, packed, eps, rms):
+        lib = _lib.load()
+        _need_cuda(feats, w)
+        F = feats.shape[-1]
+        d_out = w.shape[0]
+        io = _io_dtype(feats)
+        ff = _flat(feats, F)
+        M = ff.shape[0]
+        Rf = None
+        if R is not None:
+            Rf = _flat(R.to(feats.dtype), d_out)
+        out = torch.empty(M, d_out, dtype=feats.dtype, device=feats.device)
+        xhat = torch.empty_like(out)
+        rstd = torch.empty(M, dtype=torch.float32, device=feats.device)
+        g32 = gamma.detach().float().contiguous()
+        b32 = beta.detach().float().contiguous() if beta is not None else None
+        rc = _timed("k4_fwd", M, lambda: lib.vlpet_visproj_fwd(
+            ff.data_ptr(), packed.data_ptr(), g32.data_ptr(), _ptr(b32), _ptr(Rf), out.data_ptr(), xhat.data_ptr(),
+            rstd.data_ptr(), M, F, d_out, float(eps), int(bool(rms)), io, _stream()))
+        _lib.check(rc, "vlpet_visproj_fwd")
+        ctx.save_for_backward(ff, xhat, rstd, w, b, gamma, beta if beta is not None else gamma)
+        ctx.cfg = (bool(rms), beta is not None, feats.shape[:-1], R is not None, R.dtype if R is not None else None)
+        return out.view(*feats.shape[:-1], d_out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        ff, xhat, rstd, w, b, gamma, beta = ctx.saved_tensors
+        rms, has_beta, lead, has_r, r_dtype = ctx.cfg
+        M, F = ff.shape
+        d_out = w.shape[0]
+        io = _io_dtype(ff)
+        dyf = _flat(dy, d_out).float()
+        xh = xhat.float()
+        g = dyf * gamma.float()
+        c2 = (g * xh).mean(dim=1, keepdim=True)
+        if rms:
+            dpre = (g - xh * c2) * rstd[:, None]
+        else:
+            c1 = g.mean(dim=1, keepdim=True)
+            dpre = (g - c1 - xh * c2) * rstd[:, None]
+        dgamma = (dyf * xh).sum(0)
+        dbeta = dyf.sum(0) if has_beta else None
+        dpre_io = dpre.to(ff.dtype).contiguous()
+        f32 = dict(dtype=torch.float32, device=ff.device)
+        dw, db = torch.empty(d_out, F, **f32), torch.empty(d_out, **f32)
+        nws = lib.vlpet_visproj_wgrad_workspace_bytes(M, F, d_out)
+        ws = torch.empty(nws, dtype=torch.uint8, device=ff.device)
+        rc = _timed("k4_wgrad", M, lambda: lib.vlpet_visproj_wgrad(
+            dpre_io.data_ptr(), ff.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, M, F, d_out, io,
+            _stream()))
+        _lib.check(rc, "vlpet_visproj_wgrad")
+        dR = dy.to(r_dtype) if has_r else None
+        return (None, dR, _grad_like(dw, w), _grad_like(db, b), _grad_like(dgamma, gamma),
+                _grad_like(dbeta, beta) if has_beta else None, None, None, None)
+
+
+def visproj(feats, R, linear: torch.nn.Linear, norm: torch.nn.Module, cache: VisProjPackCache, rms: bool):
+    """LN(Linear(feats)) (+ R) through the HIP path; `norm` is nn.LayerNorm or the T5 RMS norm."""
+    io = _io_dtype(feats)
+    packed = cache.get(linear.weight, linear.bias, io)
+    eps = getattr(norm, "eps", None)
+    if eps is None:
+        eps = norm.variance_epsilon
+    beta = getattr(norm, "bias", None)
+    return _VisProjFn.apply(feats, R, linear.weight, linear.bias, norm.weight, beta, packed, eps, rms)

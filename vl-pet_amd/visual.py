@@ -89,11 +89,18 @@ class VisualEmbedding(nn.Module):
         return (pos[:, :, 3] - pos[:, :, 2]) * (pos[:, :, 1] - pos[:, :, 0])
 
     def forward(self, feats, pos, img_order_ids=None, obj_order_ids=None):
+        """K4.  The feature projection (Linear(feat_dim -> d) + LayerNorm, the K = feat_dim contraction) runs in
+        the fused HIP kernel, which also adds R = position branch + order embeddings after the norm; R itself is
+        a 5-wide linear + norm + two gathers (host ops)."""
         B, N, _ = feats.shape
         assert pos.shape == (B, N, 4)
-        feat_embedding = self.feat_embedding(feats)
+        if not (self.config.use_vis_layer_norm and self.config.individual_vis_layer_norm):
+            raise NotImplementedError("fused visual projection needs the per-branch LayerNorm configuration "
+                                      "(use_vis_layer_norm and individual_vis_layer_norm, the reference default)")
+        pos = pos.float()
         pos5 = torch.cat([pos, self.get_area(pos).unsqueeze(2)], dim=2)
-        vis = feat_embedding + self.absolute_vis_pos_embedding(pos5)
+        pl, pn = self.absolute_vis_pos_embedding[0], self.absolute_vis_pos_embedding[1]
+        R = pn(F.linear(pos5, pl.weight.float(), pl.bias.float())).float()
         if self.config.use_vis_order_embedding:
             dev = feats.device
             if img_order_ids is None:
@@ -101,8 +108,9 @@ class VisualEmbedding(nn.Module):
             if obj_order_ids is None:
                 obj_order_ids = torch.arange(N, dtype=torch.long, device=dev).unsqueeze(0)
             obj_order_ids = self.obj_order_embedding.num_embeddings - obj_order_ids - 1
-            vis = vis + self.img_order_embedding(img_order_ids).to(vis.dtype) \
-                + self.obj_order_embedding(obj_order_ids).to(vis.dtype)
-        if self.config.use_vis_layer_norm and not self.config.individual_vis_layer_norm:
-            vis = self.layer_norm(vis)
-        return vis
+            R = R + self.img_order_embedding(img_order_ids).float() + self.obj_order_embedding(obj_order_ids).float()
+        from .visproj import VisProjPackCache, visproj
+        if not hasattr(self, "_vis_cache"):
+            self._vis_cache = VisProjPackCache()
+        R = R.expand(B, N, R.shape[-1])
+        return visproj(feats, R, self.feat_embedding[0], self.feat_embedding[1], self._vis_cache, self.rms_norm)
