@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB
 TASK_ORDER = ["vqa", "gqa", "nlvr", "caption"]
 
 
-def cpu_baseline(steps=10, warm=3, batch=4):
+def cpu_baseline(steps=60, warm=3, batch=4):
     """Reference path restated on the host CPU (kind "port"): the same host model with the PET ops
     routed to oracle/vlpet_oracle.py (plain eager PyTorch in the reference's op order), full train step,
     fp32, BASELINE.json configs[0] (VQA, batch 4)."""
@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--buckets", type=int, default=3)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to exercise the DP path on a 1-GPU box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,11 +102,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     import vlpet_amd.functional as VF
     import vlpet_amd.host.bart as HB
