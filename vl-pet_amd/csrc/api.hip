@@ -105,7 +105,7 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
                 acc[3] += (double)(t[4] - t[3]); acc[4] += (double)(t[6] - t[5]); acc[5] += (double)(t[7] - t[6]);
                 ++n;
             }
-            fprintf(stderr, "[vlpet ts] cycles: prologue=%.0f down=%.0f act=%.0f up=%.0f | up-stage 5: reads+mfma=%.0f epilogue+stores=%.0f (n=%d)\n",
+            fprintf(stderr, "[vlpet ts] cycles: prologue=%.0f down=%.0f act=%.0f up=%.0f | down-stage 5: issue+reads+mfma=%.0f wait+barrier=%.0f (n=%d)\n",
                     acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, n);
         } else {
             hipMalloc(&dev, 4096 * 8 * 8);

@@ -35,13 +35,18 @@ struct FwdLds {
     static size_t bytes(int d) { return (size_t)BIAS_OFF + (size_t)2 * (32 * RT + d) * 4; }
 };
 
-template <typename IO, int RT, bool GATE, bool GATE_ADD, bool ACT_ID, bool DROP, int WAVES>
+// SKEEP > 0 (K1, bf16, d == 64*SKEEP): the residual is the chain input x2 itself, so each lane keeps its 64
+// bytes of every x2 stage in registers while the down phase streams by (SKEEP x 16 VGPRs) and the up phase
+// does not read x2 a second time (one d*M*b of fabric traffic less); the stage loops are fully unrolled.
+template <typename IO, int RT, bool GATE, bool GATE_ADD, bool ACT_ID, bool DROP, int WAVES, int SKEEP>
 __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
     using G = Geo4<IO>;
     using L = FwdLds<IO, RT, GATE, WAVES>;
     constexpr int NS = G::NS;
     constexpr int KT = 2 * RT;                   // k-steps (16) of the up projection
     constexpr int NTEN = GATE ? 2 : 1;           // row tensors in the down phase
+    constexpr bool KEEP = SKEEP > 0;
+    static_assert(!KEEP || NS == 1, "register-resident residual is the bf16 path");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
     const int trow = 32 * wave + m;
     const int d = a.d;
     const int64_t row0_wave = (int64_t)blockIdx.x * (WAVES * 32) + wave * 32;
-    const int S = d / G::FE;                     // stages per phase
+    const int S = KEEP ? SKEEP : d / G::FE;      // stages per phase (compile-time when KEEP)
     const PackGeom pg = pack_geom(RT, d, NS);
     const uint8_t* pkA = a.pk_a;
     const uint8_t* pkG = GATE ? a.pk_g : a.pk_a;
@@ -67,11 +72,12 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
     const RowLanes rl = row_lanes<IO>(row0_wave, a.M, d, wave, lane);
     const int lane16 = lane * 16;
 
-    auto rows_count = [&](int s2) { return s2 < S ? 4 * NTEN : (s2 < 2 * S ? 4 : 0); };
+    auto rows_count = [&](int s2) { return s2 < S ? 4 * NTEN : ((s2 < 2 * S && !KEEP) ? 4 : 0); };
     auto issue_rows = [&](int s2) {
         if (s2 >= 2 * S) return;
         const int j = s2 % L::NR;
         const bool up = s2 >= S;
+        if (up && KEEP) return;                           // residual is register resident
         const int so = (up ? s2 - S : s2) * 128;          // 128 bytes of every row per stage, both dtypes
         glds_rows4(up ? res : xa, rl, so, slot_ta(j), wave);
         if constexpr (GATE) {
@@ -91,6 +97,10 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
         }
     };
 
+    auto stamp = [&](int k) {      // debug timestamps (thread 0 of each block), see api.hip VLPET_DBG & 16
+        if ((a.dbg & 16) && tid == 0 && blockIdx.x < 4096) a.dbg_ts[blockIdx.x * 8 + k] = __builtin_readcyclecounter();
+    };
+    stamp(0);
     issue_w(0);
     issue_rows(0);
     issue_rows(1);
@@ -103,6 +113,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
         }
     }
     __syncthreads();            // drains everything issued so far (stage 0 weights, rows of stages 0 and 1)
+    stamp(1);
 
     // ---- down projections: pre[c], register 8*sh + j of c-tile ct <-> c = 32ct + 16sh + 8h + j
     f32x16 accA[RT];
@@ -113,17 +124,23 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
 #pragma unroll
         for (int ct = 0; ct < RT; ++ct) accG[ct] = zero16();
     }
-    int s = 0;
-    for (; s < S; ++s) {
+    bf16x8 xkeep[KEEP ? SKEEP : 1][4];            // the lane's 64 bytes of every x2 stage (KEEP only)
+    auto down_stage = [&](int s) {
+        if (s == 5) stamp(5);
         issue_w(s + 1);
         issue_rows(s + 2);
         const uint8_t* w = slot_w(s & 1);
         const uint8_t* ta = slot_ta(s % L::NR);
         const uint8_t* tg = slot_tg(s % L::NR);
-        // all fragment reads of a chain first (one LDS burst, counted lgkmcnt waits), then its MFMAs
-        Frag<NS> bA[G::KU], wa[G::KU * RT];
+        if constexpr (KEEP) {
 #pragma unroll
-        for (int u = 0; u < G::KU; ++u) {
+            for (int p = 0; p < 4; ++p) xkeep[s][p] = *reinterpret_cast<const bf16x8*>(tile_piece(ta, trow, 4 * h + p));
+        }
+        // software pipeline over the k-steps: the LDS reads of k-step u+1 are issued before the MFMAs of
+        // k-step u (counted lgkmcnt waits; <= 8 fragment reads in flight), so LDS and the matrix pipe overlap.
+        // (One burst of all 40 reads made hipcc emit lgkmcnt(0) before the first MFMA: reads, then MFMAs.)
+        Frag<NS> bA[G::KU], bG[GATE ? G::KU : 1], wa[G::KU][RT], wg[GATE ? G::KU : 1][RT];
+        auto load_u = [&](int u) {
             bA[u] = tile_bfrag4<IO>(ta, trow, h, u);
             if constexpr (DROP) {
                 const int64_t grow = (row0_wave + m < a.M) ? row0_wave + m : a.M - 1;
@@ -137,40 +154,47 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
                 }
                 bA[u] = frag_from_f32<NS>(v);
             }
-        }
 #pragma unroll
-        for (int i = 0; i < G::KU * RT; ++i) wa[i] = wfrag<NS>(w, i, lane);
-        if constexpr (GATE) {
-            Frag<NS> bG[G::KU], wg[G::KU * RT];
+            for (int ct = 0; ct < RT; ++ct) wa[u][ct] = wfrag<NS>(w, u * RT + ct, lane);
+            if constexpr (GATE) {
+                bG[u] = tile_bfrag4<IO>(tg, trow, h, u);
 #pragma unroll
-            for (int u = 0; u < G::KU; ++u) bG[u] = tile_bfrag4<IO>(tg, trow, h, u);
+                for (int ct = 0; ct < RT; ++ct) wg[u][ct] = wfrag<NS>(w, L::SEG_FR + u * RT + ct, lane);
+            }
+        };
+        auto mfma_u = [&](int u) {
 #pragma unroll
-            for (int i = 0; i < G::KU * RT; ++i) wg[i] = wfrag<NS>(w, L::SEG_FR + i, lane);
+            for (int ct = 0; ct < RT; ++ct) {
+                accA[ct] = mfma_ns<NS>(wa[u][ct], bA[u], accA[ct]);
+                if constexpr (GATE) accG[ct] = mfma_ns<NS>(wg[u][ct], bG[u], accG[ct]);
+            }
+        };
+        load_u(0);
+#pragma unroll
+        for (int u = 1; u < G::KU; ++u) {
+            load_u(u);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < G::KU; ++u) {
-#pragma unroll
-                for (int ct = 0; ct < RT; ++ct) accA[ct] = mfma_ns<NS>(wa[u * RT + ct], bA[u], accA[ct]);
-            }
-#pragma unroll
-            for (int u = 0; u < G::KU; ++u) {
-#pragma unroll
-                for (int ct = 0; ct < RT; ++ct) accG[ct] = mfma_ns<NS>(wg[u * RT + ct], bG[u], accG[ct]);
-            }
-        } else {
+            mfma_u(u - 1);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < G::KU; ++u) {
-#pragma unroll
-                for (int ct = 0; ct < RT; ++ct) accA[ct] = mfma_ns<NS>(wa[u * RT + ct], bA[u], accA[ct]);
-            }
         }
+        mfma_u(G::KU - 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (s == 5) stamp(6);
         // next stage needs: its weights (issued first in this stage) and its rows (issued a stage earlier)
         wait_vm(rows_count(s + 2));
         __builtin_amdgcn_s_barrier();
+        if (s == 5) stamp(7);
+    };
+    int s = 0;
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int ss = 0; ss < SKEEP; ++ss) down_stage(ss);
+        s = SKEEP;
+    } else {
+        for (; s < S; ++s) down_stage(s);
     }
 
+    stamp(2);
     // ---- bias + activation -> B fragments of the up projection (k-step 2ct+sh holds c = 32ct+16sh+8h+j)
     Frag<NS> zA[KT];
     Frag<NS> zG[GATE ? KT : 1];
@@ -197,15 +221,15 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
         }
     }
 
+    stamp(3);
     // ---- up projections + epilogue: FE features per stage, LW contiguous per lane
     const float* buA = sb + 32 * RT + G::LW * h;
     const float* buG = sb + nb + 32 * RT + G::LW * h;
     const float gs = GATE ? a.gs : 1.0f;
     const float s2g = a.s2 * gs, sdg = a.sd * gs;      // gate scale folded into the linear part
-    for (; s < 2 * S; ++s) {
+    auto up_stage = [&](int s, int su) {
         issue_w(s + 1);
         issue_rows(s + 2);
-        const int su = s - S;
         const uint8_t* w = slot_w(s & 1);
         uint8_t* tr = slot_ta(s % L::NR);
         float o[G::LW];
@@ -223,58 +247,72 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
                 }
             }
         }
-        {
-            Frag<NS> wa[G::NV * KT];
-#pragma unroll
-            for (int i = 0; i < G::NV * KT; ++i) wa[i] = wfrag<NS>(w, i, lane);
-            if constexpr (GATE) {
-                Frag<NS> wg[G::NV * KT];
-#pragma unroll
-                for (int i = 0; i < G::NV * KT; ++i) wg[i] = wfrag<NS>(w, L::SEG_FR + i, lane);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < KT; ++ks) {
-#pragma unroll
-                    for (int v = 0; v < G::NV; ++v) aG[v] = mfma_ns<NS>(wg[v * KT + ks], zG[ks], aG[v]);
-                }
-#pragma unroll
-                for (int ks = 0; ks < KT; ++ks) {
-#pragma unroll
-                    for (int v = 0; v < G::NV; ++v) aA[v] = mfma_ns<NS>(wa[v * KT + ks], zA[ks], aA[v]);
-                }
-            } else {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < KT; ++ks) {
-#pragma unroll
-                    for (int v = 0; v < G::NV; ++v) aA[v] = mfma_ns<NS>(wa[v * KT + ks], zA[ks], aA[v]);
-                }
-            }
-        }
         float r[G::LW];
-        tile_lane_vals4<IO>(tr, trow, h, r);
+        if constexpr (KEEP) {
 #pragma unroll
-        for (int i = 0; i < G::LW; ++i) {
-            float hv = s2g * r[i] + sdg * aA[i >> 4][i & 15];
-            if constexpr (GATE) {
-                const float gt = sigmoid_f(aG[i >> 4][i & 15]);
-                hv = GATE_ADD ? hv + gs * gt : hv * gt;
-            }
-            o[i] = hv;
+            for (int i = 0; i < G::LW; ++i) r[i] = (float)xkeep[su][i >> 3][i & 7];
+        } else {
+            tile_lane_vals4<IO>(tr, trow, h, r);
         }
+        // per 32-feature n-tile v: fragment reads of tile v+1 are issued before the MFMAs of tile v, and the
+        // epilogue of tile v sits in the same scheduling region as the MFMAs of tile v+1 (VALU in the MFMA shadow)
+        Frag<NS> wa[G::NV][KT], wg[GATE ? G::NV : 1][KT];
+        auto load_v = [&](int v) {
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) {
+                wa[v][ks] = wfrag<NS>(w, v * KT + ks, lane);
+                if constexpr (GATE) wg[v][ks] = wfrag<NS>(w, L::SEG_FR + v * KT + ks, lane);
+            }
+        };
+        auto mfma_v = [&](int v) {
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) {
+                aA[v] = mfma_ns<NS>(wa[v][ks], zA[ks], aA[v]);
+                if constexpr (GATE) aG[v] = mfma_ns<NS>(wg[v][ks], zG[ks], aG[v]);
+            }
+        };
+        auto epi_v = [&](int v) {
+#pragma unroll
+            for (int i = 16 * v; i < 16 * v + 16; ++i) {
+                float hv = s2g * r[i] + sdg * aA[v][i & 15];
+                if constexpr (GATE) {
+                    const float gt = sigmoid_f(aG[v][i & 15]);
+                    hv = GATE_ADD ? hv + gs * gt : hv * gt;
+                }
+                o[i] = hv;
+            }
+        };
+        load_v(0);
+#pragma unroll
+        for (int v = 1; v < G::NV; ++v) {
+            load_v(v);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_v(v - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_v(G::NV - 1);
+#pragma unroll
+        for (int v = 0; v < G::NV; ++v) epi_v(v);
         // stage the outputs in place (the wave's own rows of the residual tile), then whole-line stores
         stage_lane_vals4<IO>(tr, trow, h, o);
         store_rows4(out, rl, su * 128, tr, wave, lane);
         wait_vm(rows_count(s + 2) + rl.n_inst);
         __builtin_amdgcn_s_barrier();
+    };
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int su = 0; su < SKEEP; ++su) up_stage(SKEEP + su, su);
+    } else {
+        for (; s < 2 * S; ++s) up_stage(s, s - S);
     }
+    stamp(4);
 }
 
-template <typename IO, int RT, bool GATE, bool GATE_ADD, bool ACT_ID, bool DROP, int WAVES>
+template <typename IO, int RT, bool GATE, bool GATE_ADD, bool ACT_ID, bool DROP, int WAVES, int SKEEP = 0>
 static hipError_t launch_one(const PetFwdArgs& a, hipStream_t stream) {
     using L = FwdLds<IO, RT, GATE, WAVES>;
     const size_t lds = L::bytes(a.d);
-    auto kern = pet_fwd_kernel<IO, RT, GATE, GATE_ADD, ACT_ID, DROP, WAVES>;
+    auto kern = pet_fwd_kernel<IO, RT, GATE, GATE_ADD, ACT_ID, DROP, WAVES, SKEEP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -287,8 +325,14 @@ static hipError_t launch_one(const PetFwdArgs& a, hipStream_t stream) {
 template <typename IO, int RT, bool GATE, bool GATE_ADD, bool ACT_ID, bool DROP>
 static hipError_t launch_waves(const PetFwdArgs& a, hipStream_t stream) {
     // 4 waves (128 rows) per workgroup unless the rings would not fit the 160 KiB LDS
-    if constexpr (FwdLds<IO, RT, GATE, 4>::BIAS_OFF + 8 * 1024 <= 160 * 1024)
+    if constexpr (FwdLds<IO, RT, GATE, 4>::BIAS_OFF + 8 * 1024 <= 160 * 1024) {
+        if constexpr (GATE && IoTraits<IO>::NS == 1 && RT <= 3) {
+            // K1, bf16, d = 768: residual == chain input -> keep it in registers (12 stages x 16 VGPRs)
+            if (a.res == a.xa && a.d == 768 && !(a.dbg & 32))
+                return launch_one<IO, RT, GATE, GATE_ADD, ACT_ID, DROP, 4, 12>(a, stream);
+        }
         return launch_one<IO, RT, GATE, GATE_ADD, ACT_ID, DROP, 4>(a, stream);
+    }
     else
         return launch_one<IO, RT, GATE, GATE_ADD, ACT_ID, DROP, 2>(a, stream);
 }
