@@ -113,6 +113,8 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
         nblk = (int)((M + 127) / 128); if (nblk > 4096) nblk = 4096;
         a.dbg_ts = dev;
     }
+    if ((flags & PET_GATE) && !(a.dbg & 64))      // two-chain gate forward: one wave per chain (VLPET_DBG=64: single-wave form)
+        return herr(launch_pet_gate_fwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));
     return herr(launch_pet_fwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));
 }
 

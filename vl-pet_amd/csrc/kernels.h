@@ -40,6 +40,7 @@ struct PetFwdArgs {
     unsigned long long* dbg_ts;   // [blocks][8] s_memtime stamps of wave 0 (only when dbg & 16)
 };
 hipError_t launch_pet_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream);
+hipError_t launch_pet_gate_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream);   // PET_GATE only
 
 struct PetBwdArgs {
     const void* dy;     // [M,d]

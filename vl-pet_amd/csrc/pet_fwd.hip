@@ -75,6 +75,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
     auto rows_count = [&](int s2) { return s2 < S ? 4 * NTEN : ((s2 < 2 * S && !KEEP) ? 4 : 0); };
     auto issue_rows = [&](int s2) {
         if (s2 >= 2 * S) return;
+        if ((a.dbg & 2) && s2 >= 3) return;
         const int j = s2 % L::NR;
         const bool up = s2 >= S;
         if (up && KEEP) return;                           // residual is register resident
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
     };
     auto issue_w = [&](int s1) {
         if (s1 >= 2 * S) return;
+        if ((a.dbg & 1) && s1 >= 2) return;
         const bool up = s1 >= S;
         const int64_t woff = (up ? pg.pack_bytes : 0) + (int64_t)(up ? s1 - S : s1) * L::SEG_KB * 1024;
         uint8_t* dst = slot_w(s1 & 1);
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (s == 5) stamp(6);
         // next stage needs: its weights (issued first in this stage) and its rows (issued a stage earlier)
-        wait_vm(rows_count(s + 2));
+        if (a.dbg & 3) wait_vm(0); else wait_vm(rows_count(s + 2));
         __builtin_amdgcn_s_barrier();
         if (s == 5) stamp(7);
     };
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
         // stage the outputs in place (the wave's own rows of the residual tile), then whole-line stores
         stage_lane_vals4<IO>(tr, trow, h, o);
         store_rows4(out, rl, su * 128, tr, wave, lane);
-        wait_vm(rows_count(s + 2) + rl.n_inst);
+        if (a.dbg & 3) wait_vm(0); else wait_vm(rows_count(s + 2) + rl.n_inst);
         __builtin_amdgcn_s_barrier();
     };
     if constexpr (KEEP) {

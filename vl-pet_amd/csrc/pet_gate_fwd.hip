@@ -1,0 +1,255 @@
+// K1 forward, chain-split form:  out = ( s2*x2 + sd*up_A(gelu_new(down_A(x2))) ) (*|+) sigmoid( up_G(gelu_new(down_G(x1))) ) * gs
+// (my_transformers/modeling_bart.py:1147-1155, 1195-1209, 1256-1257).
+//
+// Why a second kernel: the one-wave-per-32-rows form (pet_fwd.hip) leaves one wave per SIMD (M/32 waves
+// for 1024 SIMDs at the benchmark's M ~ 28k), and a lone wave serialises its own VALU epilogue, MFMAs, LDS
+// reads and waits (rocprofv3: MFMA busy 17 %, VALU 32 %, waits 58 % of wave cycles).  Here the two
+// projection chains of a 32-row group run on two different waves placed on the same SIMD:
+//
+//     wave rg      (chain A): x2 -> down_A -> gelu -> up_A, residual/scale, product with the gate, stores
+//     wave rg + RG (chain G): x1 -> down_G -> gelu -> up_G, sigmoid  -> gate values to LDS
+//
+// so every SIMD holds two independent instruction streams with half the registers each; the chain-G wave
+// runs the up phase one stage ahead and hands the gate tile over through a double-buffered LDS exchange
+// (one s_barrier per stage, which the weight ring needs anyway).  Memory system as in pet_fwd.hip:
+// everything arrives by global_load_lds as whole 128-byte lines, counted vmcnt waits, outputs leave as
+// whole lines.  Stage t of the 2S+1 stages (S = d / features per stage):
+//     t <  S : both chains, down projection of feature block t
+//     t >= S : chain G, up projection + sigmoid of block t-S (t < 2S); chain A, up projection + epilogue of block t-S-1 (t > S)
+// LDS: weight ring 2 x [A segment | G segment]; 96 KiB row area = 3 down-phase slots [x2 tile | x1 tile],
+// re-used in the up phase as 2 residual slots + 2 gate-exchange buffers.
+#include "common.h"
+#include "kernels.h"
+#include "pet32.h"
+
+template <typename IO, int RT, int RG>
+struct GateLds {
+    static constexpr int NS = Geo4<IO>::NS;
+    static constexpr int SEG_KB = 4 * RT;
+    static constexpr int SEG_FR = SEG_KB / NS;
+    static constexpr int W_B = SEG_KB * 1024 * 2;
+    static constexpr int TILE_B = RG * 32 * 128;
+    static constexpr int ROW_OFF = 2 * W_B;
+    static constexpr int BIAS_OFF = ROW_OFF + 6 * TILE_B;
+    static constexpr int X_OFF = ROW_OFF + 2 * TILE_B;         // two exchange buffers of 2*TILE_B
+    static size_t bytes(int d) { return (size_t)BIAS_OFF + (size_t)2 * (32 * RT + d) * 4; }
+};
+
+template <typename IO, int RT, bool GATE_ADD, int RG>
+__global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
+    using G = Geo4<IO>;
+    using L = GateLds<IO, RT, RG>;
+    constexpr int NS = G::NS;
+    constexpr int KT = 2 * RT;
+    constexpr int NW = 2 * RG;                   // waves
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chain = wave / RG, rg = wave % RG;             // waves rg and rg + RG share a SIMD (RG = 4)
+    const bool isA = chain == 0;
+    const int m = lane & 31, h = lane >> 5;
+    const int trow = 32 * rg + m;
+    const int d = a.d;
+    const int64_t row0_wave = (int64_t)blockIdx.x * (RG * 32) + rg * 32;
+    const int S = d / G::FE;
+    const PackGeom pg = pack_geom(RT, d, NS);
+    const uint8_t* pkA = a.pk_a;
+    const uint8_t* pkG = a.pk_g;
+    const uint8_t* xin = reinterpret_cast<const uint8_t*>(isA ? a.xa : a.xg);
+    const uint8_t* res = reinterpret_cast<const uint8_t*>(a.res);
+    uint8_t* out = reinterpret_cast<uint8_t*>(a.out);
+
+    auto slot_w = [&](int j) { return smem + (size_t)j * L::W_B; };
+    auto slot_d = [&](int j) { return smem + L::ROW_OFF + (size_t)j * 2 * L::TILE_B + (isA ? 0 : L::TILE_B); };
+    auto slot_res = [&](int j) { return smem + L::ROW_OFF + (size_t)j * L::TILE_B; };
+    auto slot_x = [&](int j) { return smem + L::X_OFF + (size_t)j * 2 * L::TILE_B + (size_t)rg * (G::LW * 256); };
+    float* sb = reinterpret_cast<float*>(smem + L::BIAS_OFF);
+    const int nb = 32 * RT + d;
+
+    const RowLanes rl = row_lanes<IO>(row0_wave, a.M, d, rg, lane);
+    const int lane16 = lane * 16;
+
+    // ---- weight pieces of stage t (1 KiB each, piece k of [A segment | G segment]); returns how many this wave issued
+    auto issue_w = [&](int t) -> int {
+        if (t > 2 * S) return 0;
+        uint8_t* dst = slot_w(t & 1);
+        int n = 0;
+        for (int k = wave; k < 2 * L::SEG_KB; k += NW) {
+            const bool segA = k < L::SEG_KB;
+            const int kk = segA ? k : k - L::SEG_KB;
+            int64_t woff;
+            if (t < S) woff = (int64_t)t * L::SEG_KB * 1024;
+            else {
+                const int su = segA ? t - S - 1 : t - S;
+                if (su < 0 || su >= S) continue;
+                woff = pg.pack_bytes + (int64_t)su * L::SEG_KB * 1024;
+            }
+            glds16((segA ? pkA : pkG) + woff + (size_t)kk * 1024 + lane16, dst + (size_t)k * 1024);
+            ++n;
+        }
+        return n;
+    };
+    // ---- row pieces issued during stage t: down rows two stages ahead; chain A's residual rows one stage ahead
+    auto issue_rows = [&](int t) -> int {
+        if (t + 2 < S) {
+            glds_rows4(xin, rl, (t + 2) * 128, slot_d((t + 2) % 3), rg);
+            return 4;
+        }
+        if (isA && t >= S && t < 2 * S) {        // residual block su = t - S, consumed at stage t + 1
+            const int su = t - S;
+            glds_rows4(res, rl, su * 128, slot_res(su & 1), rg);
+            return 4;
+        }
+        return 0;
+    };
+
+    issue_w(0);
+    glds_rows4(xin, rl, 0, slot_d(0), rg);
+    if (S > 1) glds_rows4(xin, rl, 128, slot_d(1), rg);
+    {   // biases -> LDS: [bdA(32RT) | buA(d) | bdG(32RT) | buG(d)]
+        const float* ba = reinterpret_cast<const float*>(a.pk_a + pg.bias_off);
+        const float* bg = reinterpret_cast<const float*>(a.pk_g + pg.bias_off);
+        for (int i = tid; i < nb; i += NW * 64) { sb[i] = ba[i]; sb[nb + i] = bg[i]; }
+    }
+    __syncthreads();
+
+    // ---- down projection of this wave's chain: register 8*sh + j of c-tile ct <-> c = 32ct + 16sh + 8h + j
+    f32x16 acc[RT];
+#pragma unroll
+    for (int ct = 0; ct < RT; ++ct) acc[ct] = zero16();
+    int t = 0;
+    for (; t < S; ++t) {
+        issue_w(t + 1);
+        const int nrows = issue_rows(t);
+        const uint8_t* w = slot_w(t & 1) + (isA ? 0 : L::SEG_KB * 1024);
+        const uint8_t* tile = slot_d(t % 3);
+#pragma unroll
+        for (int u = 0; u < G::KU; ++u) {
+            const Frag<NS> b = tile_bfrag4<IO>(tile, trow, h, u);
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct) acc[ct] = mfma_ns<NS>(wfrag<NS>(w, u * RT + ct, lane), b, acc[ct]);
+        }
+        wait_vm(nrows);
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- bias + gelu_new -> B fragments of the up projection (k-step 2ct+sh holds c = 32ct+16sh+8h+j)
+    Frag<NS> z[KT];
+    {
+        const float* bd = sb + (isA ? 0 : nb) + 8 * h;
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct) {
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = gelu_new_f(acc[ct][8 * sh + j] + bd[32 * ct + 16 * sh + j]);
+                z[2 * ct + sh] = frag_from_f32<NS>(v);
+            }
+        }
+    }
+
+    // ---- up phase
+    const float* bu = sb + (isA ? 0 : nb) + 32 * RT + G::LW * h;
+    const float gs = a.gs;
+    const float s2g = a.s2 * gs, sdg = a.sd * gs;      // gate scale folded into the linear part
+    for (; t <= 2 * S; ++t) {
+        issue_w(t + 1);
+        const int nrows = issue_rows(t);
+        (void)nrows;
+        const int su = isA ? t - S - 1 : t - S;
+        int n_after = 0;                                // vector-memory operations allowed to stay in flight
+        if (su >= 0 && su < S) {
+            const uint8_t* w = slot_w(t & 1) + (isA ? 0 : L::SEG_KB * 1024);
+            f32x16 au[G::NV];
+#pragma unroll
+            for (int v = 0; v < G::NV; ++v) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 tb = *reinterpret_cast<const f32x4*>(bu + su * G::FE + 16 * v + 4 * q);
+                    au[v][4 * q] = tb[0]; au[v][4 * q + 1] = tb[1]; au[v][4 * q + 2] = tb[2]; au[v][4 * q + 3] = tb[3];
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) {
+#pragma unroll
+                for (int v = 0; v < G::NV; ++v) au[v] = mfma_ns<NS>(wfrag<NS>(w, v * KT + ks, lane), z[ks], au[v]);
+            }
+            if (!isA) {
+                // gate values (fp32) -> exchange buffer of this stage; piece q of the lane at q*1 KiB + lane*16
+                uint8_t* xb = slot_x(su & 1);
+#pragma unroll
+                for (int v = 0; v < G::NV; ++v) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 g4;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) g4[j] = sigmoid_f(au[v][4 * q + j]);
+                        *reinterpret_cast<f32x4*>(xb + (size_t)(4 * v + q) * 1024 + lane16) = g4;
+                    }
+                }
+            } else {
+                uint8_t* tr = slot_res(su & 1);
+                const uint8_t* xb = slot_x(su & 1);
+                float r[G::LW], o[G::LW];
+                tile_lane_vals4<IO>(tr, trow, h, r);
+#pragma unroll
+                for (int v = 0; v < G::NV; ++v) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * v + q) * 1024 + lane16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int i = 16 * v + 4 * q + j;
+                            const float lin = s2g * r[i] + sdg * au[v][4 * q + j];
+                            o[i] = GATE_ADD ? lin + gs * g4[j] : lin * g4[j];
+                        }
+                    }
+                }
+                stage_lane_vals4<IO>(tr, trow, h, o);
+                store_rows4(out, rl, su * 128, tr, rg, lane);
+                n_after = rl.n_inst;
+            }
+        }
+        wait_vm(n_after);
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+template <typename IO, int RT, bool GATE_ADD, int RG>
+static hipError_t launch_one(const PetFwdArgs& a, hipStream_t stream) {
+    using L = GateLds<IO, RT, RG>;
+    const size_t lds = L::bytes(a.d);
+    auto kern = pet_gate_fwd_kernel<IO, RT, GATE_ADD, RG>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int rows = RG * 32;
+    const int blocks = (int)((a.M + rows - 1) / rows);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(RG * 128), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <typename IO, int RT>
+static hipError_t launch_rt(const PetFwdArgs& a, hipStream_t stream) {
+    const bool add = a.flags & PET_GATE_ADD;
+    // 4 row groups (128 rows, 8 waves) unless the rings would not fit the 160 KiB LDS
+    if constexpr (GateLds<IO, RT, 4>::BIAS_OFF + 8 * 1024 <= 160 * 1024)
+        return add ? launch_one<IO, RT, true, 4>(a, stream) : launch_one<IO, RT, false, 4>(a, stream);
+    else
+        return add ? launch_one<IO, RT, true, 2>(a, stream) : launch_one<IO, RT, false, 2>(a, stream);
+}
+
+template <typename IO>
+static hipError_t launch_io(const PetFwdArgs& a, hipStream_t stream) {
+    switch (a.RT) {
+        case 1: return launch_rt<IO, 1>(a, stream);
+        case 3: return launch_rt<IO, 3>(a, stream);
+        case 6: return launch_rt<IO, 6>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_pet_gate_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream) {
+    return io_fp32 ? launch_io<float>(a, stream) : launch_io<__bf16>(a, stream);
+}
