@@ -34,35 +34,10 @@ def cpu_baseline(steps=60, warm=3, batch=4):
     fp32, BASELINE.json configs[0] (VQA, batch 4)."""
     import vlpet_amd.host.bart as HB
     import vlpet_amd.train as TR
-    from vlpet_amd.adapters.adapter_modeling import Adapter
-    from oracle import vlpet_oracle as O
+    from oracle.host_patch import cpu_reference_ops
 
-    def cpu_apply_pet(module, which, x1, x2, config):
-        downs = getattr(module, f"{which}_adapter_multihead_down")
-        up = getattr(module, f"{which}_adapter_multihead_up")
-        gd = getattr(module, f"encoder_{which}_adapter_gating_large_x_down")
-        gu = getattr(module, f"encoder_{which}_adapter_gating_large_x_up")
-        gate = dict(down_w=gd.weight, down_b=gd.bias, up_w=gu.weight, up_b=gu.bias)
-        return O.encoder_adapter_gate(x1, x2, [m.weight for m in downs], [m.bias for m in downs], up.weight, up.bias,
-                                      gate, O.GATE_LARGE)
-
-    def cpu_fused(self, x, residual, scale=1.0):
-        return O.parallel_adapter(x, residual, self.down_sampler.weight, self.down_sampler.bias,
-                                  self.up_sampler.weight, self.up_sampler.bias, None if scale == 1.0 else scale)
-
-    from vlpet_amd.visual import VisualEmbedding
-
-    def cpu_visual(self, feats, pos, img_order_ids=None, obj_order_ids=None):
-        fe, pe = self.feat_embedding, self.absolute_vis_pos_embedding
-        return O.visual_embedding(feats, pos, fe[0].weight, fe[0].bias, fe[1].weight, getattr(fe[1], "bias", None),
-                                  pe[0].weight, pe[0].bias, pe[1].weight, getattr(pe[1], "bias", None),
-                                  self.img_order_embedding.weight, self.obj_order_embedding.weight,
-                                  img_order_ids, obj_order_ids, rms=self.rms_norm)
-
-    saved = (HB.apply_pet, Adapter.fused, VisualEmbedding.forward)
-    HB.apply_pet, Adapter.fused, VisualEmbedding.forward = cpu_apply_pet, cpu_fused, cpu_visual
     torch.set_num_threads(min(16, os.cpu_count() or 1))      # small-batch eager ops do not scale past ~16 threads
-    try:
+    with cpu_reference_ops():
         torch.manual_seed(1234)
         cfg = HB.vlpet_config()
         model = HB.VLBart(cfg)
@@ -77,8 +52,6 @@ def cpu_baseline(steps=60, warm=3, batch=4):
         for _ in range(steps):
             tr.step(b)
         dt = time.perf_counter() - t0
-    finally:
-        HB.apply_pet, Adapter.fused, VisualEmbedding.forward = saved
     return dict(value=round(batch * steps / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"configs[0]: BART-base VL-PET-large r=96, VQA batch {batch}, S=20+36, fp32, full train step "
                        f"(fwd+bwd+clip+AdamW) through oracle/vlpet_oracle.py on the host CPU, {warm} warm-up + "

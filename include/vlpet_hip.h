@@ -154,6 +154,37 @@ int vlpet_visproj_wgrad(const void* dpre, const void* feats, float* dw, float* d
                         void* workspace, size_t workspace_bytes,
                         int64_t M, int feat_dim, int d_out, int io_dtype, vlpet_stream_t stream);
 
+/* ---- K5: sublayer tail ----------------------------------------------------------------------
+ * The step right after K1 (and after every decoder sublayer):
+ *     norm_mode 1:  out = LayerNorm(x1 + dropout(y)) * gamma + beta
+ *                   (my_transformers/modeling_bart.py:1259-1261, 1375-1377)
+ *     norm_mode 0:  out = x1 + dropout(y)        (my_transformers/modeling_t5.py:408, 824)
+ * one pass over [M, d] forward, one pass backward.  d % 8 == 0, d <= 4096 (bf16) / 2048 (fp32).
+ * Dropout: counter-based (Philox-4x32) mask that is a function of (seed, element index) only; the
+ * backward regenerates it from the same seed -- nothing is stored.  p = 0 switches it off.
+ *   h_save [M, d] (IO dtype), mean [M], rstd [M]: saved for the backward (norm_mode 1; h_save may
+ *       be NULL for inference);  keep_out: optional [M, d] uint8 export of the mask (tests).
+ * Backward: dx1 [M, d] always; dy [M, d] only when p > 0 (with p = 0, dy == dx1: pass NULL and
+ * alias); dgb_partials [vlpet_sublayer_tail_partials(M)][2][d] fp32 = per-workgroup partial
+ * sums of (dgamma, dbeta), or NULL when the LayerNorm is frozen. */
+int vlpet_sublayer_tail_partials(int64_t M);
+int vlpet_sublayer_tail_fwd(const void* y, const void* x1, const float* gamma, const float* beta, void* out,
+                            void* h_save, float* mean, float* rstd, uint8_t* keep_out, int64_t M, int d,
+                            float eps, float p, uint64_t seed, int norm_mode, int io_dtype,
+                            vlpet_stream_t stream);
+int vlpet_sublayer_tail_bwd(const void* dout, const void* h_save, const float* mean, const float* rstd,
+                            const float* gamma, void* dx1, void* dy, float* dgb_partials, int64_t M, int d,
+                            float p, uint64_t seed, int norm_mode, int io_dtype, vlpet_stream_t stream);
+
+/* ---- Downsample (the step before K4) -------------------------------------------------------
+ * AdaptiveMaxPool2d(s_in x s_in -> s_out x s_out) over the token grid of x [n_images, s_in*s_in, dim]
+ * -> out [n_images, s_out*s_out, dim], with the cast to the compute dtype fused (in_dtype may be
+ * fp32 CLIP features, out_dtype the IO dtype).  Replaces Downsample.downsample_inputs
+ * (src/modeling_bart.py:565-581); NLVR's two-image form is n_images = 2B on the same buffer.
+ * dim % 8 == 0.  No parameters, no backward (the features carry no gradient). */
+int vlpet_downsample_fwd(const void* x, void* out, int64_t n_images, int s_in, int s_out, int dim,
+                         int in_dtype, int out_dtype, vlpet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

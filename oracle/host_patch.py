@@ -1,0 +1,57 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): run the host model with every HIP-backed op of the hot
+path routed to the CPU restatement in oracle/vlpet_oracle.py.  Used by the parity tests (as the checker) and by
+bench.py's ``cpu_baseline`` leg; the product never imports this."""
+from __future__ import annotations
+
+import contextlib
+
+import torch.nn.functional as F
+
+from . import vlpet_oracle as O
+
+
+@contextlib.contextmanager
+def cpu_reference_ops():
+    import vlpet_amd.host.bart as HB
+    from vlpet_amd.adapters.adapter_modeling import Adapter
+    from vlpet_amd.visual import Downsample, VisualEmbedding
+
+    def apply_pet(module, which, x1, x2, config):                       # K1
+        downs = getattr(module, f"{which}_adapter_multihead_down")
+        up = getattr(module, f"{which}_adapter_multihead_up")
+        gd = getattr(module, f"encoder_{which}_adapter_gating_large_x_down")
+        gu = getattr(module, f"encoder_{which}_adapter_gating_large_x_up")
+        gate = dict(down_w=gd.weight, down_b=gd.bias, up_w=gu.weight, up_b=gu.bias)
+        return O.encoder_adapter_gate(x1, x2, [m.weight for m in downs], [m.bias for m in downs], up.weight, up.bias,
+                                      gate, O.GATE_LARGE)
+
+    def fused(self, x, residual, scale=1.0):                            # K2
+        return O.parallel_adapter(x, residual, self.down_sampler.weight, self.down_sampler.bias,
+                                  self.up_sampler.weight, self.up_sampler.bias, None if scale == 1.0 else scale)
+
+    def visual(self, feats, pos, img_order_ids=None, obj_order_ids=None):   # K4
+        fe, pe = self.feat_embedding, self.absolute_vis_pos_embedding
+        return O.visual_embedding(feats, pos, fe[0].weight, fe[0].bias, fe[1].weight, getattr(fe[1], "bias", None),
+                                  pe[0].weight, pe[0].bias, pe[1].weight, getattr(pe[1], "bias", None),
+                                  self.img_order_embedding.weight, self.obj_order_embedding.weight,
+                                  img_order_ids, obj_order_ids, rms=self.rms_norm)
+
+    def tail(residual, h, norm, p, training):                           # K5
+        return O.bart_sublayer_tail(residual, F.dropout(h, p=p, training=training), norm.weight, norm.bias, norm.eps)
+
+    def downsample(self, inputs_tuple, out_dtype=None):
+        hw = tuple(self.output_size)
+        if len(inputs_tuple) == 4:
+            y, b, i, o = O.downsample_nlvr(*inputs_tuple, out_hw=hw)
+            return (y if out_dtype is None else y.to(out_dtype)), b, i, o
+        x, boxes = inputs_tuple
+        y = O.downsample(x, hw)
+        return (y if out_dtype is None else y.to(out_dtype)), boxes[:, :y.shape[1]]
+
+    saved = (HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward)
+    HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward = \
+        apply_pet, fused, visual, tail, downsample
+    try:
+        yield
+    finally:
+        HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward = saved

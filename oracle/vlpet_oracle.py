@@ -202,6 +202,29 @@ def t5_sublayer_tail(x1, y):
     return x1 + y
 
 
+def downsample(x, out_hw=(6, 6)):
+    """CLIP-grid down-sampling: ``AdaptiveMaxPool2d(out_hw)`` over the sqrt(L) x sqrt(L) token grid of
+    ``x [B, L, dim]`` -> ``[B, out_h*out_w, dim]`` (src/modeling_bart.py:565-581)."""
+    B, Ltok, dim = x.shape
+    s = int(Ltok ** 0.5)
+    g = x.permute(0, 2, 1).reshape(B, dim, s, s)
+    g = F.adaptive_max_pool2d(g, out_hw).reshape(B, dim, -1)
+    return g.permute(0, 2, 1)
+
+
+def downsample_nlvr(x, boxes, img_ids, obj_ids, out_hw=(6, 6)):
+    """Two-image (NLVR) form: each half of the token axis is pooled on its own; boxes / ids keep the first
+    out_h*out_w entries of each half (src/modeling_bart.py:586-604)."""
+    def halves(t):
+        return torch.cat(torch.chunk(t, 2, 1), 0)
+
+    def back(t):
+        return torch.cat(torch.chunk(t, 2, 0), 1)
+    y = back(downsample(halves(x), out_hw))
+    n = y.shape[1] // 2
+    return y, back(halves(boxes)[:, :n]), back(halves(img_ids)[:, :n]), back(halves(obj_ids)[:, :n])
+
+
 # ------------------------------------------------------------ autograd helpers
 def with_grads(fn, tensors: Dict[str, torch.Tensor], dy: torch.Tensor, wrt: Sequence[str]):
     """Run ``fn(**tensors)`` and backprop ``dy``; returns (out, {name: grad})."""

@@ -442,6 +442,25 @@ def golden_decoder_layer(tag, d, r, B, S_enc, S_dec, seed=5):
          denc=T(enc.grad), **{"sd::" + k: v for k, v in sd.items()}, **grads)
 
 
+# ------------------------------------------------------------------ Downsample
+def golden_downsample(tag, B=2, dim=64, seed=6):
+    """Downsample (src/modeling_bart.py:556-613): AdaptiveMaxPool2d 7x7 -> 6x6 on [B, 49, dim] and the NLVR
+    two-image form on [B, 98, dim] with its box / id cropping."""
+    mod = load_vl_module("bart")
+    ds = mod.Downsample((6, 6))
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 49, dim, generator=gen)
+    boxes = torch.rand(B, 49, 4, generator=gen)
+    y, yb = ds((x, boxes))
+    x2 = torch.randn(B, 98, dim, generator=gen)
+    boxes2 = torch.rand(B, 98, 4, generator=gen)
+    img_ids = torch.cat([torch.zeros(B, 49), torch.ones(B, 49)], 1).long()
+    obj_ids = torch.cat([torch.arange(49), torch.arange(49)]).unsqueeze(0).expand(B, -1).contiguous()
+    y2, yb2, yi2, yo2 = ds((x2, boxes2, img_ids, obj_ids))
+    save(tag, x=T(x), boxes=T(boxes), y=T(y), yb=T(yb), x2=T(x2), boxes2=T(boxes2), img_ids=img_ids.numpy(),
+         obj_ids=obj_ids.numpy(), y2=T(y2), yb2=T(yb2), yi2=yi2.numpy(), yo2=yo2.numpy())
+
+
 # -------------------------------------------------------- trainable-name lists
 def golden_trainable_names():
     """Parameter-name lists + trainable flags for the VL-PET-large BART encoder/decoder layer
@@ -464,6 +483,9 @@ def golden_trainable_names():
 def main():
     install_shim()
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "downsample":      # add one fixture without regenerating the rest
+        golden_downsample("downsample_7to6_d64")
+        return
     # (i) K1 BART, full width and tiny, gate variants
     golden_k1_bart("k1_bart_large_d768_r96", 768, 96, 4, 96, B=2, S=8)
     golden_k1_bart("k1_bart_large_d64_r8", 64, 8, 4, 8, B=2, S=5)
@@ -500,6 +522,7 @@ def main():
     # (vi) decoder layer hook placement, (vii) names
     golden_decoder_layer("dec_layer_d64_r8", 64, 8, B=2, S_enc=6, S_dec=3)
     golden_trainable_names()
+    golden_downsample("downsample_7to6_d64")
 
 
 if __name__ == "__main__":

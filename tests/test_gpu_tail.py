@@ -1,0 +1,99 @@
+"""K5 sublayer tail (csrc/tail.hip) against the oracle: LayerNorm(x1 + dropout(y)) and the T5 form x1 + dropout(y).
+Dropout parity is checked with the kernel's own mask exported through `keep_out` (the reference's RNG stream
+cannot be matched; the op is the same for a given mask)."""
+import pytest
+import torch
+
+from oracle import vlpet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-4, torch.bfloat16: 1e-2}      # fp32: two reductions over d; bf16: north_star's 1e-2
+
+
+def _mk(M, d, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x1 = torch.randn(M, d, generator=g)
+    y = torch.randn(M, d, generator=g) * 0.7 + 0.1
+    gamma = 1.0 + 0.2 * torch.randn(d, generator=g)
+    beta = 0.1 * torch.randn(d, generator=g)
+    dout = torch.randn(M, d, generator=g)
+    q = lambda t: t.to(dtype).float()
+    return q(x1), q(y), gamma, beta, q(dout)
+
+
+def _rel(a, b):
+    return float((a.float().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+def _run(M, d, dtype, p, norm=True, seed=1234):
+    from vlpet_amd.tail import sublayer_tail
+    x1, y, gamma, beta, dout = _mk(M, d, dtype)
+    dev = "cuda"
+    X1 = x1.to(dev, dtype).requires_grad_(True)
+    Y = y.to(dev, dtype).requires_grad_(True)
+    ln = None
+    if norm:
+        ln = torch.nn.LayerNorm(d).to(dev)
+        with torch.no_grad():
+            ln.weight.copy_(gamma); ln.bias.copy_(beta)
+    res = sublayer_tail(X1, Y, ln, p=p, training=True, seed=seed, return_mask=True)
+    out, mask = res
+    out.backward(dout.to(dev, dtype))
+    mask = mask.float().cpu()
+    # oracle with the same mask
+    scale = 1.0 / (1.0 - p)
+    x1r = x1.clone().requires_grad_(True); yr = y.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    yd = yr * mask * scale
+    ref = O.bart_sublayer_tail(x1r, yd, gr, br, 1e-5) if norm else O.t5_sublayer_tail(x1r, yd)
+    ref.backward(dout)
+    tol = TOL[dtype]
+    assert _rel(out, ref.detach()) <= tol
+    assert _rel(X1.grad, x1r.grad) <= tol
+    assert _rel(Y.grad, yr.grad) <= tol
+    if norm:
+        assert _rel(ln.weight.grad, gr.grad) <= tol
+        assert _rel(ln.bias.grad, br.grad) <= tol
+    return mask
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,d", [(1, 64), (37, 768), (1000, 768), (130, 1024), (5, 2048)])
+def test_tail_layernorm_no_dropout(M, d, dtype):
+    mask = _run(M, d, dtype, 0.0)
+    assert bool((mask == 1).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_tail_layernorm_dropout(dtype):
+    mask = _run(2000, 768, dtype, 0.1)
+    keep = float(mask.mean())
+    assert abs(keep - 0.9) < 0.005
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_tail_t5_residual(dtype):
+    _run(333, 768, dtype, 0.0, norm=False)
+    mask = _run(333, 768, dtype, 0.25, norm=False)
+    assert abs(float(mask.mean()) - 0.75) < 0.01
+
+
+def test_tail_mask_is_a_function_of_seed_and_index_only():
+    m1 = _run(256, 768, torch.float32, 0.1, seed=7)
+    m2 = _run(256, 768, torch.bfloat16, 0.1, seed=7)
+    m3 = _run(256, 768, torch.bfloat16, 0.1, seed=8)
+    assert bool((m1 == m2).all())
+    assert float((m1 != m3).float().mean()) > 0.05
+    # no visible structure along rows or columns
+    assert float(m1.mean(0).std()) < 0.03 and float(m1.mean(1).std()) < 0.02
+
+
+def test_tail_inference_path_saves_nothing():
+    from vlpet_amd.tail import sublayer_tail
+    x1, y, gamma, beta, _ = _mk(64, 768, torch.bfloat16)
+    ln = torch.nn.LayerNorm(768).cuda()
+    with torch.no_grad():
+        out = sublayer_tail(x1.cuda().bfloat16(), y.cuda().bfloat16(), ln, p=0.1, training=False)
+    ref = O.bart_sublayer_tail(x1, y, torch.ones(768), torch.zeros(768))
+    assert _rel(out, ref) <= 1e-2

@@ -92,3 +92,29 @@ def test_flat_grads_views_and_clip():
     norm = fg.clip_(0.1)
     assert torch.isclose(torch.linalg.vector_norm(fg.flat), torch.tensor(0.1), atol=1e-5) and norm > 0.1
     assert len(fg.buckets) == 2 and fg.buckets[0][0] == 0 and fg.buckets[-1][1] == fg.flat.numel()
+
+
+def test_cpu_reference_ops_run_the_host_model_on_cpu():
+    """The checker path used by bench.py's cpu_baseline and the GPU model-parity test: host model on CPU with
+    every HIP-backed op routed to the oracle (one tiny train step; the product ops themselves refuse CPU tensors)."""
+    import pytest
+    import vlpet_amd.host.bart as HB
+    import vlpet_amd.train as TR
+    from oracle.host_patch import cpu_reference_ops
+    cfg = HB.vlpet_config(d_model=64, encoder_layers=1, decoder_layers=1, encoder_attention_heads=4,
+                          decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128, vocab_size=500,
+                          max_position_embeddings=64, feat_dim=128, adapter_down_dim=8, adapter_gating_down_dim=16,
+                          decoder_enc_attn_value_parallel_adapter_down_dim=8)
+    torch.manual_seed(0)
+    model = HB.VLBart(cfg)
+    TR.trainable_names(model, cfg)
+    model.train()
+    gen = torch.Generator().manual_seed(5)
+    batch = TR.synthetic_batch("nlvr", 3, cfg, "cpu", gen)
+    with cpu_reference_ops():
+        tr = TR.Trainer(model, cfg, total_steps=10)
+        l0 = tr.step(batch)
+        l1 = tr.step(batch)
+    assert l0 == l0 and l1 == l1          # finite
+    with pytest.raises(RuntimeError):      # outside the patch the product path refuses CPU tensors
+        model(batch["input_ids"], batch["vis_inputs"], batch["labels"], "nlvr")

@@ -152,3 +152,14 @@ def test_fixture_inventory():
     have = {os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, "*.npz"))}
     assert {"dec_layer_d64_r8", "names_bart_vlpet_large"} <= have
     assert len(have) >= 20
+
+
+def test_downsample_golden():
+    """oracle.downsample / downsample_nlvr against the reference's Downsample module (src/modeling_bart.py:556-613)."""
+    g = np.load(os.path.join(G, "downsample_7to6_d64.npz"))
+    t = lambda k: torch.from_numpy(g[k])
+    y = O.downsample(t("x"))
+    assert torch.equal(y, t("y"))
+    y2, b2, i2, o2 = O.downsample_nlvr(t("x2"), t("boxes2"), t("img_ids"), t("obj_ids"))
+    assert torch.equal(y2, t("y2")) and torch.equal(b2, t("yb2"))
+    assert torch.equal(i2, t("yi2")) and torch.equal(o2, t("yo2"))

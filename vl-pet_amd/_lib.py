@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvlpet_hip.so")
@@ -46,6 +46,10 @@ SIGNATURES = {
     "vlpet_visproj_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "vlpet_visproj_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "vlpet_visproj_wgrad": (c_int, [c_void_p] * 5 + [c_size_t, c_int64, c_int, c_int, c_int, c_void_p]),
+    "vlpet_downsample_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vlpet_sublayer_tail_partials": (c_int, [c_int64]),
+    "vlpet_sublayer_tail_fwd": (c_int, [c_void_p] * 9 + [c_int64, c_int, c_float, c_float, c_uint64, c_int, c_int, c_void_p]),
+    "vlpet_sublayer_tail_bwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_float, c_uint64, c_int, c_int, c_void_p]),
     "vlpet_lora_delta_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                                      c_int, c_void_p, c_size_t, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
 }

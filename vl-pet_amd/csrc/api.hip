@@ -387,3 +387,69 @@ extern "C" int vlpet_visproj_wgrad(const void* dpre, const void* feats, float* d
     }
     return 0;
 }
+
+// ---- K5 sublayer tail -------------------------------------------------------------------------------------
+static int tail_common(int64_t M, int d, float p, int io_dtype) {
+    if (M <= 0 || d <= 0 || d % 8 != 0) return VLPET_E_SHAPE;
+    if (!(p >= 0.f && p < 1.f)) return VLPET_E_SHAPE;
+    if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    const int pieces = d / (io_dtype == VLPET_F32 ? 4 : 8);
+    if (pieces > 8 * 64) return VLPET_E_SHAPE;
+    return 0;
+}
+static uint32_t tail_thr(float p) {
+    double t = (double)p * 65536.0 + 0.5;
+    if (t > 65535.0) t = 65535.0;
+    return (uint32_t)t;
+}
+
+extern "C" int vlpet_sublayer_tail_partials(int64_t M) { return M > 0 ? tail_blocks(M) : 0; }
+
+extern "C" int vlpet_sublayer_tail_fwd(const void* y, const void* x1, const float* gamma, const float* beta, void* out,
+                                       void* h_save, float* mean, float* rstd, uint8_t* keep_out, int64_t M, int d,
+                                       float eps, float p, uint64_t seed, int norm_mode, int io_dtype,
+                                       vlpet_stream_t stream) {
+    int rc = tail_common(M, d, p, io_dtype);
+    if (rc) return rc;
+    if (!y || !x1 || !out) return VLPET_E_NULL;
+    if (norm_mode && (!gamma || !mean || !rstd)) return VLPET_E_NULL;
+    if (norm_mode != 0 && norm_mode != 1) return VLPET_E_SHAPE;
+    if (!aligned16(y) || !aligned16(x1) || !aligned16(out) || (h_save && !aligned16(h_save))) return VLPET_E_ALIGN;
+    TailArgs a{};
+    a.y = y; a.x1 = x1; a.out = out; a.h = h_save; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd;
+    a.keep_out = keep_out; a.dgb = nullptr; a.M = M; a.d = d; a.eps = eps; a.thr = tail_thr(p);
+    a.keep_scale = 1.0f / (1.0f - p); a.seed = seed; a.norm = norm_mode;
+    return herr(launch_tail(a, io_dtype == VLPET_F32, false, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_sublayer_tail_bwd(const void* dout, const void* h_save, const float* mean, const float* rstd,
+                                       const float* gamma, void* dx1, void* dy, float* dgb_partials, int64_t M, int d,
+                                       float p, uint64_t seed, int norm_mode, int io_dtype, vlpet_stream_t stream) {
+    int rc = tail_common(M, d, p, io_dtype);
+    if (rc) return rc;
+    if (!dout || !dx1) return VLPET_E_NULL;
+    if (norm_mode != 0 && norm_mode != 1) return VLPET_E_SHAPE;
+    if (norm_mode && (!h_save || !mean || !rstd || !gamma)) return VLPET_E_NULL;
+    const uint32_t thr = tail_thr(p);
+    if (thr && !dy) return VLPET_E_NULL;
+    if (!aligned16(dout) || !aligned16(dx1) || (dy && !aligned16(dy)) || (h_save && !aligned16(h_save))) return VLPET_E_ALIGN;
+    TailArgs a{};
+    a.out = const_cast<void*>(dout); a.h = const_cast<void*>(h_save); a.mean = const_cast<float*>(mean);
+    a.rstd = const_cast<float*>(rstd); a.gamma = gamma; a.beta = nullptr; a.x1 = dx1; a.y = dy; a.keep_out = nullptr;
+    a.dgb = dgb_partials; a.M = M; a.d = d; a.eps = 0.f; a.thr = thr; a.keep_scale = 1.0f / (1.0f - p); a.seed = seed;
+    a.norm = norm_mode;
+    return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
+}
+
+// ---- Downsample ---------------------------------------------------------------------------------------------
+extern "C" int vlpet_downsample_fwd(const void* x, void* out, int64_t n_images, int s_in, int s_out, int dim,
+                                    int in_dtype, int out_dtype, vlpet_stream_t stream) {
+    if (!x || !out) return VLPET_E_NULL;
+    if (n_images <= 0 || s_in <= 0 || s_out <= 0 || s_out > s_in || dim <= 0 || dim % 8 != 0) return VLPET_E_SHAPE;
+    if (!dtype_ok(in_dtype) || !dtype_ok(out_dtype)) return VLPET_E_DTYPE;
+    if (!aligned16(x) || !aligned16(out)) return VLPET_E_ALIGN;
+    PoolArgs a;
+    a.x = x; a.out = out; a.n_img = n_images; a.s_in = s_in; a.s_out = s_out; a.dim = dim;
+    return herr(launch_downsample(a, in_dtype == VLPET_F32, out_dtype == VLPET_F32, (hipStream_t)stream));
+}
+

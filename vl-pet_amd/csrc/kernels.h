@@ -105,3 +105,36 @@ struct VisprojArgs {
     int rms;                // 1: no mean subtraction (T5LayerNorm)
 };
 hipError_t launch_visproj_fwd(const VisprojArgs& a, int io_fp32, hipStream_t stream);
+
+// K5 sublayer tail: out = LayerNorm(x1 + dropout(y)) (norm = 1) or x1 + dropout(y) (norm = 0); tail.hip
+struct TailArgs {
+    const void* y;          // fwd: sublayer output [M, d];          bwd: dy  (written when thr != 0)
+    const void* x1;         // fwd: residual [M, d];                 bwd: dx1 (written)
+    void* out;              // fwd: result [M, d];                   bwd: dout (read)
+    void* h;                // pre-norm sum x1 + dropout(y) [M, d] (fwd: written if non-null; bwd: read), norm = 1 only
+    const float* gamma;     // [d] (norm = 1)
+    const float* beta;      // [d] or nullptr
+    float* mean;            // [M] (norm = 1)
+    float* rstd;            // [M]
+    uint8_t* keep_out;      // optional [M, d] 0/1 export of the dropout mask (tests)
+    float* dgb;             // bwd: partial sums [tail_blocks(M)][2][d] of dgamma / dbeta, or nullptr
+    int64_t M;
+    int d;
+    float eps;
+    uint32_t thr;           // drop iff 16-bit uniform < thr;  0 = no dropout
+    float keep_scale;       // 1 / (1 - p)
+    uint64_t seed;
+    int norm;
+};
+hipError_t launch_tail(const TailArgs& a, int io_fp32, bool bwd, hipStream_t stream);
+int tail_blocks(int64_t M);
+
+// Downsample (adaptive max pool over the token grid), downsample.hip
+struct PoolArgs {
+    const void* x;      // [n_img, s_in*s_in, dim]
+    void* out;          // [n_img, s_out*s_out, dim]
+    int64_t n_img;
+    int s_in, s_out, dim;
+};
+hipError_t launch_downsample(const PoolArgs& a, int in_fp32, int out_fp32, hipStream_t stream);
+

@@ -1,0 +1,306 @@
+// K5: the sublayer tail that follows every PET op on the BART path,
+//
+//     out = LayerNorm( x1 + dropout(y) )            (my_transformers/modeling_bart.py:1259-1261, 1375-1377;
+//                                                    decoder: :1489-1491, 1513-1515, 1527-1529)
+//     out = x1 + dropout(y)                         (T5: my_transformers/modeling_t5.py:408, 824)  [norm = 0]
+//
+// as ONE pass over [M, d] (read y, read x1, write out [+ h for the backward]) instead of the three eager
+// passes (dropout, add, LayerNorm); the backward is one pass too (read dout, h; write dx1 [, dy]) and
+// regenerates the dropout mask from the same counter-based generator, so no mask is stored.
+//
+// HBM-bound row kernel: one wave per row, a lane owns 16-byte pieces lane, lane+64, ... of the row (whole
+// 128-byte lines per 8 lanes), row statistics by two wave reductions (mean, then centred variance),
+// many rows in flight per CU through occupancy (<= 64 VGPRs at d = 768 bf16).
+// Dropout: Philox-4x32 (7 rounds; Salmon et al., "Parallel random numbers: as easy as 1, 2, 3") keyed by
+// the call's 64-bit seed, counter = index of the 8-element group; element j of the group keeps iff its
+// 16-bit lane >= round(p * 65536).  The mask depends on (seed, element index) only -- not on the IO dtype.
+#include "common.h"
+#include "kernels.h"
+
+__device__ __forceinline__ void philox7(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t* o) {
+    uint32_t c2 = 0x5bd1e995u, c3 = 0x2545f491u;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+// keep flags (bit j = element j of the 8-element group kept)
+__device__ __forceinline__ uint32_t keep8(int64_t group, uint64_t seed, uint32_t thr) {
+    uint32_t o[4];
+    philox7((uint32_t)group, (uint32_t)((uint64_t)group >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t u = (o[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+        bits |= (u >= thr ? 1u : 0u) << j;
+    }
+    return bits;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename IO> struct Piece {
+    static constexpr int E = 16 / (int)sizeof(IO);     // elements per 16-byte piece (8 bf16 / 4 fp32)
+    static __device__ __forceinline__ void load(const void* p, float* v) {
+        if constexpr (E == 8) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+        } else {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = a[j];
+        }
+    }
+    static __device__ __forceinline__ void store(void* p, const float* v) {
+        if constexpr (E == 8) {
+            bf16x8 a;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (__bf16)v[j];
+            *reinterpret_cast<bf16x8*>(p) = a;
+        } else {
+            const f32x4 a = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(p) = a;
+        }
+    }
+};
+
+constexpr int TAIL_WAVES = 4;
+
+template <typename IO, int NP, bool NORM>
+__global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
+    using P = Piece<IO>;
+    constexpr int E = P::E;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = a.d, pieces = d / E;
+    const uint32_t thr = a.thr;
+    const float scale = a.keep_scale;
+    float gam[NORM ? NP : 1][E], bet[NORM ? NP : 1][E];
+    if constexpr (NORM) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = lane + 64 * k;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                gam[k][j] = p < pieces ? a.gamma[p * E + j] : 0.f;
+                bet[k][j] = (p < pieces && a.beta) ? a.beta[p * E + j] : 0.f;
+            }
+        }
+    }
+    const uint8_t* y = reinterpret_cast<const uint8_t*>(a.y);
+    const uint8_t* x1 = reinterpret_cast<const uint8_t*>(a.x1);
+    uint8_t* out = reinterpret_cast<uint8_t*>(a.out);
+    uint8_t* hs = reinterpret_cast<uint8_t*>(a.h);
+    const float inv_d = 1.0f / (float)d;
+    for (int64_t row = (int64_t)blockIdx.x * TAIL_WAVES + wave; row < a.M; row += (int64_t)gridDim.x * TAIL_WAVES) {
+        const int64_t rb = row * d * (int64_t)sizeof(IO);
+        float h[NP][E];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = lane + 64 * k;
+            if (p < pieces) {
+                float vy[E], vx[E];
+                P::load(y + rb + p * 16, vy);
+                P::load(x1 + rb + p * 16, vx);
+                uint32_t bits = 0xffu;
+                if (thr) {
+                    const int64_t e0 = row * d + (int64_t)p * E;
+                    bits = keep8(e0 >> 3, a.seed, thr) >> (e0 & 7);       // fp32 piece = half a group
+                }
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    h[k][j] = vx[j] + (((bits >> j) & 1u) ? vy[j] * scale : 0.f);
+                    s += h[k][j];
+                }
+                if (a.keep_out) {
+#pragma unroll
+                    for (int j = 0; j < E; ++j) a.keep_out[row * d + p * E + j] = (bits >> j) & 1u;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < E; ++j) h[k][j] = 0.f;
+            }
+        }
+        if constexpr (NORM) {
+            const float mean = wave_sum(s) * inv_d;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if (lane + 64 * k < pieces) {
+#pragma unroll
+                    for (int j = 0; j < E; ++j) { const float c = h[k][j] - mean; q += c * c; }
+                }
+            }
+            const float rstd = rsqrtf(wave_sum(q) * inv_d + a.eps);
+            if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = lane + 64 * k;
+                if (p < pieces) {
+                    if (hs) P::store(hs + rb + p * 16, h[k]);
+                    float o[E];
+#pragma unroll
+                    for (int j = 0; j < E; ++j) o[j] = (h[k][j] - mean) * rstd * gam[k][j] + bet[k][j];
+                    P::store(out + rb + p * 16, o);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = lane + 64 * k;
+                if (p < pieces) P::store(out + rb + p * 16, h[k]);
+            }
+        }
+    }
+}
+
+// backward: dh = LN'(dout) (or dout when NORM == 0); dx1 = dh; dy = dh * keep / (1-p) (only written when
+// dropout is on -- with p = 0 the caller aliases dy to dx1); per-workgroup partial sums of dgamma / dbeta.
+template <typename IO, int NP, bool NORM>
+__global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
+    using P = Piece<IO>;
+    constexpr int E = P::E;
+    __shared__ float red[TAIL_WAVES][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = a.d, pieces = d / E;
+    const uint32_t thr = a.thr;
+    const float scale = a.keep_scale;
+    float gam[NORM ? NP : 1][E], dg[NORM ? NP : 1][E], db[NORM ? NP : 1][E];
+    if constexpr (NORM) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = lane + 64 * k;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                gam[k][j] = p < pieces ? a.gamma[p * E + j] : 0.f;
+                dg[k][j] = 0.f; db[k][j] = 0.f;
+            }
+        }
+    }
+    const uint8_t* dout = reinterpret_cast<const uint8_t*>(a.out);     // `out` carries dout in the backward
+    const uint8_t* hs = reinterpret_cast<const uint8_t*>(a.h);
+    uint8_t* dx1 = reinterpret_cast<uint8_t*>(const_cast<void*>(a.x1));
+    uint8_t* dy = reinterpret_cast<uint8_t*>(const_cast<void*>(a.y));
+    const float inv_d = 1.0f / (float)d;
+    for (int64_t row = (int64_t)blockIdx.x * TAIL_WAVES + wave; row < a.M; row += (int64_t)gridDim.x * TAIL_WAVES) {
+        const int64_t rb = row * d * (int64_t)sizeof(IO);
+        float g[NP][E], xh[NORM ? NP : 1][E];
+        float s1 = 0.f, s2 = 0.f;
+        float mean = 0.f, rstd = 1.f;
+        if constexpr (NORM) { mean = a.mean[row]; rstd = a.rstd[row]; }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = lane + 64 * k;
+            if (p < pieces) {
+                float vd[E];
+                P::load(dout + rb + p * 16, vd);
+                if constexpr (NORM) {
+                    float vh[E];
+                    P::load(hs + rb + p * 16, vh);
+#pragma unroll
+                    for (int j = 0; j < E; ++j) {
+                        xh[k][j] = (vh[j] - mean) * rstd;
+                        g[k][j] = vd[j] * gam[k][j];
+                        s1 += g[k][j];
+                        s2 += g[k][j] * xh[k][j];
+                        dg[k][j] += vd[j] * xh[k][j];
+                        db[k][j] += vd[j];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < E; ++j) g[k][j] = vd[j];
+                }
+            }
+        }
+        if constexpr (NORM) {
+            const float c1 = wave_sum(s1) * inv_d, c2 = wave_sum(s2) * inv_d;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if (lane + 64 * k < pieces) {
+#pragma unroll
+                    for (int j = 0; j < E; ++j) g[k][j] = (g[k][j] - c1 - xh[k][j] * c2) * rstd;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = lane + 64 * k;
+            if (p < pieces) {
+                P::store(dx1 + rb + p * 16, g[k]);
+                if (thr) {
+                    const int64_t e0 = row * d + (int64_t)p * E;
+                    const uint32_t bits = keep8(e0 >> 3, a.seed, thr) >> (e0 & 7);
+                    float o[E];
+#pragma unroll
+                    for (int j = 0; j < E; ++j) o[j] = ((bits >> j) & 1u) ? g[k][j] * scale : 0.f;
+                    P::store(dy + rb + p * 16, o);
+                }
+            }
+        }
+    }
+    if constexpr (NORM) {
+        if (a.dgb) {
+            // partial sums of this workgroup: [blockIdx][2][d]; waves combined through LDS one piece at a time
+            __shared__ float acc[TAIL_WAVES][2][64 * 8];
+            (void)red;
+            float* dst = a.dgb + (size_t)blockIdx.x * 2 * d;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = lane + 64 * k;
+#pragma unroll
+                for (int j = 0; j < E; ++j) { acc[wave][0][lane * 8 + j] = dg[k][j]; acc[wave][1][lane * 8 + j] = db[k][j]; }
+                __syncthreads();
+                if (wave == 0 && p < pieces) {
+#pragma unroll
+                    for (int j = 0; j < E; ++j) {
+                        float sg = 0.f, sb = 0.f;
+#pragma unroll
+                        for (int w = 0; w < TAIL_WAVES; ++w) { sg += acc[w][0][lane * 8 + j]; sb += acc[w][1][lane * 8 + j]; }
+                        dst[p * E + j] = sg; dst[d + p * E + j] = sb;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+int tail_blocks(int64_t M) {
+    const int64_t need = (M + TAIL_WAVES - 1) / TAIL_WAVES;
+    const int64_t cap = 256 * 8;             // 8 workgroups of 4 waves per CU
+    return (int)(need < cap ? need : cap);
+}
+
+template <typename IO, int NP, bool NORM>
+static hipError_t launch_np(const TailArgs& a, bool bwd, hipStream_t stream) {
+    const int blocks = tail_blocks(a.M);
+    if (bwd) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, NORM>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+    else hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, NORM>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+    return hipGetLastError();
+}
+
+template <typename IO, bool NORM>
+static hipError_t launch_io(const TailArgs& a, bool bwd, hipStream_t stream) {
+    const int pieces = a.d / Piece<IO>::E;
+    const int np = (pieces + 63) / 64;
+    if (np <= 1) return launch_np<IO, 1, NORM>(a, bwd, stream);
+    if (np <= 2) return launch_np<IO, 2, NORM>(a, bwd, stream);
+    if (np <= 3) return launch_np<IO, 3, NORM>(a, bwd, stream);
+    if (np <= 4) return launch_np<IO, 4, NORM>(a, bwd, stream);
+    if (np <= 8) return launch_np<IO, 8, NORM>(a, bwd, stream);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_tail(const TailArgs& a, int io_fp32, bool bwd, hipStream_t stream) {
+    if (a.norm) return io_fp32 ? launch_io<float, true>(a, bwd, stream) : launch_io<__bf16, true>(a, bwd, stream);
+    return io_fp32 ? launch_io<float, false>(a, bwd, stream) : launch_io<__bf16, false>(a, bwd, stream);
+}

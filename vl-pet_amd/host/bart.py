@@ -94,6 +94,13 @@ class HostLayerNorm(nn.LayerNorm):
         return F.layer_norm(x, self.normalized_shape, w, b, self.eps)
 
 
+def sublayer_tail(residual, h, norm, p, training):
+    """K5: ``norm(residual + dropout(h))`` -- one fused HIP pass (vlpet_amd.tail); the parity / CPU-baseline harnesses
+    swap this module attribute for an eager restatement."""
+    from ..tail import sublayer_tail as _hip_tail
+    return _hip_tail(residual, h, norm, p, training)
+
+
 def _linear(mod: nn.Linear, x):
     w, b = mod.weight, mod.bias
     if w.dtype != x.dtype:
@@ -171,16 +178,14 @@ class BartEncoderLayer(nn.Module):
         h = self.self_attn(hidden, attn_mask=attn_mask, task=task)
         if has_pet(self, "attn"):
             h = apply_pet(self, "attn", residual, h, self.config)                 # K1
-        h = F.dropout(h, p=self.dropout, training=self.training)
-        hidden = self.self_attn_layer_norm(residual + h)
+        hidden = sublayer_tail(residual, h, self.self_attn_layer_norm, self.dropout, self.training)   # K5
         residual = hidden
         h = F.gelu(_linear(self.fc1, hidden))
         h = F.dropout(h, p=self.activation_dropout, training=self.training)
         h = _linear(self.fc2, h)
         if has_pet(self, "ff"):
             h = apply_pet(self, "ff", residual, h, self.config)                   # K1
-        h = F.dropout(h, p=self.dropout, training=self.training)
-        return self.final_layer_norm(residual + h)
+        return sublayer_tail(residual, h, self.final_layer_norm, self.dropout, self.training)             # K5
 
 
 class BartDecoderLayer(nn.Module):
@@ -202,15 +207,15 @@ class BartDecoderLayer(nn.Module):
     def forward(self, hidden, enc, enc_mask=None, task=None):
         residual = hidden
         h = self.self_attn(hidden, causal=True, task=task)
-        hidden = self.self_attn_layer_norm(residual + F.dropout(h, p=self.dropout, training=self.training))
+        hidden = sublayer_tail(residual, h, self.self_attn_layer_norm, self.dropout, self.training)   # K5
         residual = hidden
         h = self.encoder_attn(hidden, kv=enc, attn_mask=enc_mask, task=task)      # K2 inside
-        hidden = self.encoder_attn_layer_norm(residual + F.dropout(h, p=self.dropout, training=self.training))
+        hidden = sublayer_tail(residual, h, self.encoder_attn_layer_norm, self.dropout, self.training)  # K5
         residual = hidden
         h = F.gelu(_linear(self.fc1, hidden))
         h = F.dropout(h, p=self.activation_dropout, training=self.training)
         h = _linear(self.fc2, h)
-        return self.final_layer_norm(residual + F.dropout(h, p=self.dropout, training=self.training))
+        return sublayer_tail(residual, h, self.final_layer_norm, self.dropout, self.training)             # K5
 
 
 class LearnedPositionalEmbedding(nn.Embedding):
@@ -243,11 +248,12 @@ class JointEncoder(nn.Module):
     def forward(self, input_ids, vis_inputs, attention_mask=None, task=None):
         B, L = input_ids.shape
         x = self.embed_tokens(input_ids) * self.embed_scale + self.embed_positions(L, input_ids.device)
-        if vis_inputs[0].dtype != x.dtype:
-            # compute dtype before the max-pool (rounding is monotone, so pool(round(f)) == round(pool(f)))
-            vis_inputs = (vis_inputs[0].to(x.dtype),) + tuple(vis_inputs[1:])
         if self.downsample is not None:
-            vis_inputs = self.downsample(vis_inputs)
+            # fp32 CLIP features -> compute dtype inside the pooling kernel (rounding is monotone:
+            # pool(round(f)) == round(pool(f)))
+            vis_inputs = self.downsample(vis_inputs, out_dtype=x.dtype)
+        elif vis_inputs[0].dtype != x.dtype:
+            vis_inputs = (vis_inputs[0].to(x.dtype),) + tuple(vis_inputs[1:])
         feats, boxes = vis_inputs[0], vis_inputs[1]
         img_ids = vis_inputs[2] if len(vis_inputs) >= 3 else None
         obj_ids = vis_inputs[3] if len(vis_inputs) == 4 else None

@@ -1,0 +1,95 @@
+"""K5 host glue: the sublayer tail ``LayerNorm(residual + dropout(y))`` (BART) / ``residual + dropout(y)``
+(T5) as one HIP pass forward and one backward (csrc/tail.hip).
+
+Reference op chains replaced: my_transformers/modeling_bart.py:1259-1261, 1375-1377 (encoder),
+:1489-1491, 1513-1515, 1527-1529 (decoder); my_transformers/modeling_t5.py:408, 824.  The dropout mask
+comes from the kernel's counter-based generator: one 64-bit seed per call, drawn from torch's CPU
+generator (so ``torch.manual_seed`` makes a run repeatable); the backward regenerates the mask.
+No CPU fallback."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .functional import _flat, _grad_like, _io_dtype, _need_cuda, _ptr, _stream, _timed
+
+
+def _draw_seed() -> int:
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+class _TailFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, x1, gamma, beta, eps, p, seed, norm, want_mask):
+        lib = _lib.load()
+        _need_cuda(y, x1)
+        d = y.shape[-1]
+        io = _io_dtype(y)
+        if x1.dtype != y.dtype:
+            x1 = x1.to(y.dtype)
+        yf, xf = _flat(y, d), _flat(x1, d)
+        M = yf.shape[0]
+        out = torch.empty_like(yf)
+        need_bwd = any(t is not None and t.requires_grad for t in (y, x1, gamma, beta))
+        f32 = dict(dtype=torch.float32, device=y.device)
+        h = mean = rstd = g32 = b32 = None
+        if norm:
+            g32 = gamma.detach().float().contiguous()
+            b32 = beta.detach().float().contiguous() if beta is not None else None
+            mean, rstd = torch.empty(M, **f32), torch.empty(M, **f32)
+            h = torch.empty_like(yf) if need_bwd else None
+        mask = torch.empty(M, d, dtype=torch.uint8, device=y.device) if want_mask else None
+        rc = _timed("k5_fwd", M, lambda: lib.vlpet_sublayer_tail_fwd(
+            yf.data_ptr(), xf.data_ptr(), _ptr(g32), _ptr(b32), out.data_ptr(), _ptr(h), _ptr(mean), _ptr(rstd),
+            _ptr(mask), M, d, float(eps), float(p), seed, int(norm), io, _stream()))
+        _lib.check(rc, "vlpet_sublayer_tail_fwd")
+        ctx.save_for_backward(h, mean, rstd, g32, gamma, beta)
+        ctx.cfg = (float(p), seed, int(norm), y.shape, io)
+        out = out.view(y.shape)
+        if want_mask:
+            ctx.mark_non_differentiable(mask)
+            return out, mask.view(y.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        lib = _lib.load()
+        h, mean, rstd, g32, gamma, beta = ctx.saved_tensors
+        p, seed, norm, shape, io = ctx.cfg
+        d = shape[-1]
+        df = _flat(dout, d)
+        M = df.shape[0]
+        dx1 = torch.empty_like(df)
+        dy = torch.empty_like(df) if p > 0 else None
+        train_ln = norm and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        part = None
+        if train_ln:
+            nb = lib.vlpet_sublayer_tail_partials(M)
+            part = torch.empty(nb, 2, d, dtype=torch.float32, device=df.device)
+        rc = _timed("k5_bwd", M, lambda: lib.vlpet_sublayer_tail_bwd(
+            df.data_ptr(), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(g32), dx1.data_ptr(), _ptr(dy), _ptr(part), M, d,
+            p, seed, norm, io, _stream()))
+        _lib.check(rc, "vlpet_sublayer_tail_bwd")
+        dgamma = dbeta = None
+        if train_ln:
+            s = part.sum(0)
+            if ctx.needs_input_grad[2]:
+                dgamma = _grad_like(s[0], gamma)
+            if beta is not None and ctx.needs_input_grad[3]:
+                dbeta = _grad_like(s[1], beta)
+        dx1 = dx1.view(shape)
+        dyv = dy.view(shape) if dy is not None else dx1
+        return dyv, dx1, dgamma, dbeta, None, None, None, None, None
+
+
+def sublayer_tail(x1: torch.Tensor, y: torch.Tensor, norm: Optional[torch.nn.Module], p: float = 0.0,
+                  training: bool = False, seed: Optional[int] = None, return_mask: bool = False):
+    """``norm(x1 + dropout(y, p))``; ``norm`` is an ``nn.LayerNorm`` (BART) or None (T5: plain residual add)."""
+    p_eff = float(p) if training else 0.0
+    if seed is None:
+        seed = _draw_seed() if p_eff > 0 else 0
+    if norm is None:
+        return _TailFn.apply(y, x1, None, None, 0.0, p_eff, seed, 0, return_mask)
+    return _TailFn.apply(y, x1, norm.weight, norm.bias, norm.eps, p_eff, seed, 1, return_mask)

@@ -7,7 +7,7 @@
         + img_order_embedding[img_ids] + obj_order_embedding[V - 1 - obj_ids]
 
 ``Downsample`` is the AdaptiveMaxPool2d 7x7 -> 6x6 of src/modeling_bart.py:556-613 (frozen, no
-parameters).
+parameters), a HIP gather kernel with the fp32 -> compute-dtype cast fused.
 """
 from __future__ import annotations
 
@@ -31,32 +31,43 @@ class T5LayerNorm(nn.Module):
 
 
 class Downsample(nn.Module):
+    """AdaptiveMaxPool2d over the CLIP token grid (src/modeling_bart.py:556-613), on the HIP kernel
+    (csrc/downsample.hip) with the cast to the compute dtype fused: ``out_dtype`` (default: the input's)."""
+
     def __init__(self, output_size):
         super().__init__()
         self.output_size = output_size
-        self.pool = nn.AdaptiveMaxPool2d(output_size)
 
-    def downsample_inputs(self, x):
+    def downsample_inputs(self, x, out_dtype=None):
+        from . import _lib
+        from .functional import _io_dtype, _need_cuda, _stream
+        _need_cuda(x)
         B, L, dim = x.shape
         s = int(L ** 0.5)
-        x = x.permute(0, 2, 1).reshape(B, dim, s, s)
-        x = self.pool(x).reshape(B, dim, -1)
-        return x.permute(0, 2, 1)
+        if s * s != L or self.output_size[0] != self.output_size[1]:
+            raise ValueError("Downsample expects a square token grid and a square output size")
+        so = int(self.output_size[0])
+        x = x if x.is_contiguous() else x.contiguous()
+        out = torch.empty(B, so * so, dim, dtype=out_dtype or x.dtype, device=x.device)
+        lib = _lib.load()
+        rc = lib.vlpet_downsample_fwd(x.data_ptr(), out.data_ptr(), B, s, so, dim, _io_dtype(x), _io_dtype(out), _stream())
+        _lib.check(rc, "vlpet_downsample_fwd")
+        return out
 
-    def forward(self, inputs_tuple):
-        if len(inputs_tuple) == 4:   # NLVR: two images side by side along the token axis
+    def forward(self, inputs_tuple, out_dtype=None):
+        if len(inputs_tuple) == 4:   # NLVR: two images side by side along the token axis = 2B independent grids
             x, boxes, img_ids, obj_ids = inputs_tuple
-            x = torch.cat(torch.chunk(x, 2, 1), 0)
-            x = self.downsample_inputs(x)
-            x = torch.cat(torch.chunk(x, 2, 0), 1)
-            half = x.shape[1] // 2
+            B, L2, dim = x.shape
+            y = self.downsample_inputs(x.reshape(2 * B, L2 // 2, dim), out_dtype)
+            half = y.shape[1]
+            y = y.reshape(B, 2 * half, dim)
 
             def crop(t):
                 t = torch.cat(torch.chunk(t, 2, 1), 0)[:, :half]
                 return torch.cat(torch.chunk(t, 2, 0), 1)
-            return x, crop(boxes), crop(img_ids), crop(obj_ids)
+            return y, crop(boxes), crop(img_ids), crop(obj_ids)
         x, boxes = inputs_tuple
-        x = self.downsample_inputs(x)
+        x = self.downsample_inputs(x, out_dtype)
         return x, boxes[:, :x.shape[1]]
 
 
