@@ -11,6 +11,7 @@
 // is in the MFMAs (register double buffer).  Row-chunk partials are written to a workspace and summed
 // by wgrad_finalize (deterministic: no atomics).
 #include "common.h"
+#include <cstdlib>
 #include "kernels.h"
 
 struct WgradLayout {
@@ -37,8 +38,9 @@ size_t wgrad_workspace_bytes(int njobs, int RT, int xcols_max, int row_chunks) {
 void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* rows_per_chunk) {
     const int slices = xcols_max / 64;
     int64_t blocks128 = (M + 127) / 128;
-    // ~1000 workgroups: two resident per CU, two rounds
-    int64_t rc = (1024 + (int64_t)slices * njobs - 1) / ((int64_t)slices * njobs);
+    // 768 workgroups = three per CU in a single round (measured best of 256..2048 at M = 28k; VLPET_WGRAD_WGS overrides)
+    static const int64_t target = [] { const char* e = getenv("VLPET_WGRAD_WGS"); return e ? (int64_t)atoi(e) : (int64_t)768; }();
+    int64_t rc = (target + (int64_t)slices * njobs - 1) / ((int64_t)slices * njobs);
     if (rc < 1) rc = 1;
     if (rc > blocks128) rc = blocks128;
     int64_t per = (blocks128 + rc - 1) / rc;          // 128-row blocks per chunk
