@@ -185,6 +185,34 @@ int vlpet_sublayer_tail_bwd(const void* dout, const void* h_save, const float* m
 int vlpet_downsample_fwd(const void* x, void* out, int64_t n_images, int s_in, int s_out, int dim,
                          int in_dtype, int out_dtype, vlpet_stream_t stream);
 
+/* ---- K1 variants: small / middleX / middleY gates -------------------------------------------
+ * The other three granularity gates (my_transformers/modeling_bart.py:1210-1231, 1326-1347;
+ * my_transformers/modeling_t5.py:391-403, 807-819) act on h = vlpet_adapter_gate_fwd(..., VLPET_GATE_NONE):
+ *     small   : g_b   = mean_S sigmoid(w . [x1 ; h] + b)        y = (h * g_b | h + g_b) * gs
+ *     middleX : g_row = sigmoid(w . (x1 + h) + b)               y = (h * g_row | h + g_row) * gs
+ *     middleY :                                                 y = (h + h*z | h + 1 + z) * gs
+ * The [M, d] passes are the row kernels below; the O(M) scalar algebra (sigmoid of a row scalar,
+ * the sequence mean, alpha / beta of the backward) is the caller's.  d % 8 == 0, d <= 2048 (bf16) /
+ * 1024 (fp32).  All per-feature vectors and per-row scalars are fp32.
+ *   vlpet_row_dot     s[row] = a[row,:] . wa + c[row,:] . wc   (c, wc optional);  wa == NULL: s[row] = a[row,:] . c[row,:]
+ *   vlpet_row_affine  y[row,:] = h[row,:] * alpha[row] + gamma[row]              (gamma optional)
+ *   vlpet_rowgate_bwd dh = alpha[row]*dy + beta[row]*wc;  dx1 = beta[row]*wa;
+ *                     partials[vlpet_rowgate_partials(M)][2][d] = per-workgroup sums of (beta*x1, beta*h) = (dwa, dwc)
+ *   vlpet_vecgate_fwd y[row,:] = h[row,:] * v + u                                 (u optional)
+ *   vlpet_vecgate_bwd dh = dy * v;  partials[...][2][d] = per-workgroup sums of (dy*h, dy) */
+int vlpet_rowgate_partials(int64_t M);
+int vlpet_row_dot(const void* a, const void* c, const float* wa, const float* wc, float* s_out, int64_t M, int d,
+                  int io_dtype, vlpet_stream_t stream);
+int vlpet_row_affine(const void* h, const float* alpha, const float* gamma, void* y, int64_t M, int d,
+                     int io_dtype, vlpet_stream_t stream);
+int vlpet_rowgate_bwd(const void* dy, const void* x1, const void* h, const float* alpha, const float* beta,
+                      const float* wa, const float* wc, void* dh, void* dx1, float* partials, int64_t M, int d,
+                      int io_dtype, vlpet_stream_t stream);
+int vlpet_vecgate_fwd(const void* h, const float* v, const float* u, void* y, int64_t M, int d, int io_dtype,
+                      vlpet_stream_t stream);
+int vlpet_vecgate_bwd(const void* dy, const void* h, const float* v, void* dh, float* partials, int64_t M, int d,
+                      int io_dtype, vlpet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

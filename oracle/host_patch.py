@@ -16,14 +16,29 @@ def cpu_reference_ops():
     from vlpet_amd.adapters.adapter_modeling import Adapter
     from vlpet_amd.visual import Downsample, VisualEmbedding
 
-    def apply_pet(module, which, x1, x2, config):                       # K1
+    def apply_pet(module, which, x1, x2, config):                       # K1 (all four granularity gates)
         downs = getattr(module, f"{which}_adapter_multihead_down")
         up = getattr(module, f"{which}_adapter_multihead_up")
-        gd = getattr(module, f"encoder_{which}_adapter_gating_large_x_down")
-        gu = getattr(module, f"encoder_{which}_adapter_gating_large_x_up")
-        gate = dict(down_w=gd.weight, down_b=gd.bias, up_w=gu.weight, up_b=gu.bias)
-        return O.encoder_adapter_gate(x1, x2, [m.weight for m in downs], [m.bias for m in downs], up.weight, up.bias,
-                                      gate, O.GATE_LARGE)
+        pre = f"encoder_{which}_adapter_gating_"
+        gd, gu = getattr(module, pre + "large_x_down", None), getattr(module, pre + "large_x_up", None)
+        small, midx, midy = (getattr(module, pre + k, None) for k in ("small_xy_cat", "middle_xy_add", "middle_ia3_add"))
+        if gd is not None:
+            mode, gate = O.GATE_LARGE, dict(down_w=gd.weight, down_b=gd.bias, up_w=gu.weight, up_b=gu.bias)
+        elif small is not None:
+            mode, gate = O.GATE_SMALL, dict(w=small.weight, b=small.bias)
+        elif midx is not None:
+            mode, gate = O.GATE_MIDDLE_X, dict(w=midx.weight, b=midx.bias)
+        elif midy is not None:
+            mode, gate = O.GATE_MIDDLE_Y, dict(z=midy)
+        else:
+            mode, gate = O.GATE_NONE, None
+        flag = lambda k, v: float(getattr(config, v)) if getattr(config, k, False) else 1.0
+        return O.encoder_adapter_gate(
+            x1, x2, [m.weight for m in downs], [m.bias for m in downs], up.weight, up.bias, gate, mode,
+            bool(getattr(config, "use_encoder_adapter_gating_add", False)),
+            flag("use_encoder_adapter_scaling", "encoder_adapter_scaling_factor"),
+            flag("use_encoder_x2_scaling", "encoder_x2_scaling_factor"),
+            flag("use_encoder_gating_scaling", "encoder_gating_scaling_factor"))
 
     def fused(self, x, residual, scale=1.0):                            # K2
         return O.parallel_adapter(x, residual, self.down_sampler.weight, self.down_sampler.bias,

@@ -46,6 +46,12 @@ SIGNATURES = {
     "vlpet_visproj_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "vlpet_visproj_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "vlpet_visproj_wgrad": (c_int, [c_void_p] * 5 + [c_size_t, c_int64, c_int, c_int, c_int, c_void_p]),
+    "vlpet_rowgate_partials": (c_int, [c_int64]),
+    "vlpet_row_dot": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
+    "vlpet_row_affine": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p]),
+    "vlpet_rowgate_bwd": (c_int, [c_void_p] * 10 + [c_int64, c_int, c_int, c_void_p]),
+    "vlpet_vecgate_fwd": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p]),
+    "vlpet_vecgate_bwd": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
     "vlpet_downsample_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vlpet_sublayer_tail_partials": (c_int, [c_int64]),
     "vlpet_sublayer_tail_fwd": (c_int, [c_void_p] * 9 + [c_int64, c_int, c_float, c_float, c_uint64, c_int, c_int, c_void_p]),

@@ -453,3 +453,75 @@ extern "C" int vlpet_downsample_fwd(const void* x, void* out, int64_t n_images, 
     return herr(launch_downsample(a, in_dtype == VLPET_F32, out_dtype == VLPET_F32, (hipStream_t)stream));
 }
 
+// ---- small / middleX / middleY gates (row kernels) ------------------------------------------------------------
+static int row_common(int64_t M, int d, int io_dtype) {
+    if (M <= 0 || d <= 0 || d % 8 != 0) return VLPET_E_SHAPE;
+    if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    if (d / (io_dtype == VLPET_F32 ? 4 : 8) > 4 * 64) return VLPET_E_SHAPE;
+    return 0;
+}
+static int row_launch(RowArgs& a, int op, int64_t M, int d, int io_dtype, vlpet_stream_t stream) {
+    a.M = M; a.d = d;
+    return herr(launch_rowgate(a, op, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_rowgate_partials(int64_t M) { return M > 0 ? rowgate_blocks(M) : 0; }
+
+extern "C" int vlpet_row_dot(const void* a, const void* c, const float* wa, const float* wc, float* s_out, int64_t M,
+                             int d, int io_dtype, vlpet_stream_t stream) {
+    int rc = row_common(M, d, io_dtype);
+    if (rc) return rc;
+    if (!a || !s_out) return VLPET_E_NULL;
+    if (!wa && !c) return VLPET_E_NULL;                 // pair mode needs both row operands
+    if (wa && c && !wc) return VLPET_E_NULL;
+    if (!aligned16(a) || (c && !aligned16(c))) return VLPET_E_ALIGN;
+    RowArgs r{};
+    r.a = a; r.c = c; r.va = wa; r.vc = wc; r.rs = s_out;
+    return row_launch(r, ROW_DOT, M, d, io_dtype, stream);
+}
+
+extern "C" int vlpet_row_affine(const void* h, const float* alpha, const float* gamma, void* y, int64_t M, int d,
+                                int io_dtype, vlpet_stream_t stream) {
+    int rc = row_common(M, d, io_dtype);
+    if (rc) return rc;
+    if (!h || !alpha || !y) return VLPET_E_NULL;
+    if (!aligned16(h) || !aligned16(y)) return VLPET_E_ALIGN;
+    RowArgs r{};
+    r.a = h; r.ra = alpha; r.rb = gamma; r.o1 = y;
+    return row_launch(r, ROW_AFFINE, M, d, io_dtype, stream);
+}
+
+extern "C" int vlpet_rowgate_bwd(const void* dy, const void* x1, const void* h, const float* alpha, const float* beta,
+                                 const float* wa, const float* wc, void* dh, void* dx1, float* partials, int64_t M,
+                                 int d, int io_dtype, vlpet_stream_t stream) {
+    int rc = row_common(M, d, io_dtype);
+    if (rc) return rc;
+    if (!dy || !x1 || !h || !alpha || !beta || !wa || !wc || !dh || !dx1 || !partials) return VLPET_E_NULL;
+    if (!aligned16(dy) || !aligned16(x1) || !aligned16(h) || !aligned16(dh) || !aligned16(dx1)) return VLPET_E_ALIGN;
+    RowArgs r{};
+    r.a = dy; r.c = x1; r.e = h; r.ra = alpha; r.rb = beta; r.va = wa; r.vc = wc; r.o1 = dh; r.o2 = dx1; r.part = partials;
+    return row_launch(r, ROW_BWD, M, d, io_dtype, stream);
+}
+
+extern "C" int vlpet_vecgate_fwd(const void* h, const float* v, const float* u, void* y, int64_t M, int d, int io_dtype,
+                                 vlpet_stream_t stream) {
+    int rc = row_common(M, d, io_dtype);
+    if (rc) return rc;
+    if (!h || !v || !y) return VLPET_E_NULL;
+    if (!aligned16(h) || !aligned16(y)) return VLPET_E_ALIGN;
+    RowArgs r{};
+    r.a = h; r.va = v; r.vc = u; r.o1 = y;
+    return row_launch(r, VEC_FWD, M, d, io_dtype, stream);
+}
+
+extern "C" int vlpet_vecgate_bwd(const void* dy, const void* h, const float* v, void* dh, float* partials, int64_t M,
+                                 int d, int io_dtype, vlpet_stream_t stream) {
+    int rc = row_common(M, d, io_dtype);
+    if (rc) return rc;
+    if (!dy || !h || !v || !dh || !partials) return VLPET_E_NULL;
+    if (!aligned16(dy) || !aligned16(h) || !aligned16(dh)) return VLPET_E_ALIGN;
+    RowArgs r{};
+    r.a = dy; r.c = h; r.va = v; r.o1 = dh; r.part = partials;
+    return row_launch(r, VEC_BWD, M, d, io_dtype, stream);
+}
+

@@ -138,3 +138,23 @@ struct PoolArgs {
 };
 hipError_t launch_downsample(const PoolArgs& a, int in_fp32, int out_fp32, hipStream_t stream);
 
+// Row kernels of the small / middleX / middleY gates, rowgate.hip
+enum RowOp { ROW_DOT = 0, ROW_AFFINE = 1, ROW_BWD = 2, VEC_FWD = 3, VEC_BWD = 4 };
+struct RowArgs {
+    const void* a;      // [M, d] IO dtype
+    const void* c;      // [M, d] or nullptr
+    const void* e;      // [M, d] or nullptr
+    void* o1;           // [M, d] output or nullptr
+    void* o2;           // [M, d] output or nullptr
+    const float* va;    // [d] or nullptr
+    const float* vc;    // [d] or nullptr
+    const float* ra;    // [M] or nullptr
+    const float* rb;    // [M] or nullptr
+    float* rs;          // [M] output (ROW_DOT)
+    float* part;        // [rowgate_blocks(M)][2][d] partial column sums (ROW_BWD, VEC_BWD)
+    int64_t M;
+    int d;
+};
+hipError_t launch_rowgate(const RowArgs& a, int op, int io_fp32, hipStream_t stream);
+int rowgate_blocks(int64_t M);
+

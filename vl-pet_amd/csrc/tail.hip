@@ -16,6 +16,7 @@
 // 16-bit lane >= round(p * 65536).  The mask depends on (seed, element index) only -- not on the IO dtype.
 #include "common.h"
 #include "kernels.h"
+#include "rowops.h"
 
 __device__ __forceinline__ void philox7(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t* o) {
     uint32_t c2 = 0x5bd1e995u, c3 = 0x2545f491u;
@@ -40,38 +41,6 @@ __device__ __forceinline__ uint32_t keep8(int64_t group, uint64_t seed, uint32_t
     }
     return bits;
 }
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-template <typename IO> struct Piece {
-    static constexpr int E = 16 / (int)sizeof(IO);     // elements per 16-byte piece (8 bf16 / 4 fp32)
-    static __device__ __forceinline__ void load(const void* p, float* v) {
-        if constexpr (E == 8) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
-        } else {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(p);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = a[j];
-        }
-    }
-    static __device__ __forceinline__ void store(void* p, const float* v) {
-        if constexpr (E == 8) {
-            bf16x8 a;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = (__bf16)v[j];
-            *reinterpret_cast<bf16x8*>(p) = a;
-        } else {
-            const f32x4 a = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(p) = a;
-        }
-    }
-};
 
 constexpr int TAIL_WAVES = 4;
 

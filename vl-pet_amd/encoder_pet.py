@@ -5,8 +5,9 @@ The reference has no class for it: the parameters hang directly off ``BartEncode
 (my_transformers/modeling_t5.py:706-724,312-330) and ~60 lines of inline tensor code use them
 (modeling_bart.py:1147-1155,1195-1209,1256-1257).  ``build_pet`` creates attributes with exactly
 those names (so state-dict keys, the 'adapter' / 'gating' freeze substrings and the zero-init rules
-of trainer_base.py:497-533,557-565 keep working) and ``apply_pet`` replaces the inline code with
-one fused HIP kernel call.
+of trainer_base.py:497-533,557-599 keep working) and ``apply_pet`` replaces the inline code with
+one fused HIP kernel call (large gate) or the adapter-only kernel plus the row kernels of ``gates``
+(small / middleX / middleY, modeling_bart.py:1210-1231).
 """
 from __future__ import annotations
 
@@ -14,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as VF
+from . import gates
 from .activations import get_activation
 
 GRANULARITY_FLAGS = ("use_encoder_adapter_gating_large_x_lowrank", "use_encoder_adapter_gating_small_xy_cat",
@@ -22,7 +24,9 @@ GRANULARITY_FLAGS = ("use_encoder_adapter_gating_large_x_lowrank", "use_encoder_
 
 def _names(which: str):
     return dict(down=f"{which}_adapter_multihead_down", up=f"{which}_adapter_multihead_up",
-                gdown=f"encoder_{which}_adapter_gating_large_x_down", gup=f"encoder_{which}_adapter_gating_large_x_up")
+                gdown=f"encoder_{which}_adapter_gating_large_x_down", gup=f"encoder_{which}_adapter_gating_large_x_up",
+                small=f"encoder_{which}_adapter_gating_small_xy_cat", midx=f"encoder_{which}_adapter_gating_middle_xy_add",
+                midy=f"encoder_{which}_adapter_gating_middle_ia3_add")
 
 
 def build_pet(module: nn.Module, config, embed_dim: int, which=("attn", "ff")):
@@ -49,10 +53,15 @@ def build_pet(module: nn.Module, config, embed_dim: int, which=("attn", "ff")):
         else:
             setattr(module, n["gdown"], None)
             setattr(module, n["gup"], None)
-        for flag in GRANULARITY_FLAGS[1:]:
-            if getattr(config, flag, False):
-                raise NotImplementedError(f"{flag}: the small / middleX / middleY gates are SURVEY.md 8(f) rank 2 "
-                                          "(next); only the large low-rank gate is fused so far")
+        # the three other granularity gates (my_transformers/modeling_bart.py:976-998): same attribute names
+        setattr(module, n["small"], nn.Linear(2 * embed_dim, 1)
+                if getattr(config, "use_encoder_adapter_gating_small_xy_cat", False) else None)
+        setattr(module, n["midx"], nn.Linear(embed_dim, 1)
+                if getattr(config, "use_encoder_adapter_gating_middle_xy_add", False) else None)
+        if getattr(config, "use_encoder_adapter_gating_middle_ia3_add", False):
+            setattr(module, n["midy"], nn.Parameter(torch.zeros(embed_dim)))
+        else:
+            setattr(module, n["midy"], None)
         module._pet_caches[w] = (VF.PackCache(), VF.PackCache())
 
 
@@ -90,6 +99,17 @@ def apply_pet(module: nn.Module, which: str, x1: torch.Tensor, x2: torch.Tensor,
     if x1.dtype != x2.dtype:
         x1 = x1.to(x2.dtype)
     y = VF.adapter_gate(x1, x2, dws, dbs, up.weight, up.bias, gp, pk_a, pk_g, mode, sd, s2, gs if gate else 1.0)
-    if not gate and gs != 1.0:
+    if gate:
+        return y
+    # same precedence as the reference's elif chain (large > small > middleX > middleY)
+    add = bool(getattr(config, "use_encoder_adapter_gating_add", False))
+    small, midx, midy = getattr(module, n["small"], None), getattr(module, n["midx"], None), getattr(module, n["midy"], None)
+    if small is not None:
+        return gates.small_gate(x1, y, small, add, gs)
+    if midx is not None:
+        return gates.middle_x_gate(x1, y, midx, add, gs)
+    if midy is not None:
+        return gates.middle_y_gate(y, midy, add, gs)
+    if gs != 1.0:
         y = y * gs
     return y

@@ -74,6 +74,15 @@ def weight_initialization(model: nn.Module, config):
                 p.zero_()
             if config.use_decoder_enc_vpa_up_zero_init and "attn_value_parallel_adapter" in n and "up_sampler" in n:
                 p.zero_()
+            # trainer_base.py:577-599
+            if getattr(config, "use_encoder_gating_small_up_zero_init", False) and "adapter_gating_small_xy_cat" in n:
+                p.zero_()
+            if getattr(config, "use_encoder_gating_middle_up_zero_init", False) and "adapter_gating_middle_xy_add" in n:
+                p.zero_()
+            if getattr(config, "use_encoder_gating_middle_ia3_one_init", False) and "adapter_gating_middle_ia3_add" in n:
+                p.fill_(1.0)
+            if getattr(config, "use_encoder_gating_middle_ia3_zero_init", False) and "adapter_gating_middle_ia3_add" in n:
+                p.zero_()
 
 
 def cast_frozen(model: nn.Module, dtype: torch.dtype):
