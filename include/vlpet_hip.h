@@ -213,6 +213,23 @@ int vlpet_vecgate_fwd(const void* h, const float* v, const float* u, void* y, in
 int vlpet_vecgate_bwd(const void* dy, const void* h, const float* v, void* dh, float* partials, int64_t M, int d,
                       int io_dtype, vlpet_stream_t stream);
 
+/* ---- fused global-norm clip + AdamW over the flat trainable buffer ---------------------------
+ * Replaces torch.nn.utils.clip_grad_norm_ (multitask.py:279-300) + the per-tensor AdamW step
+ * (trainer_base.py:633-701) with two launches over the flat fp32 buffers p, g, m, v [n]:
+ *   vlpet_grad_sumsq   partials[vlpet_optim_blocks(n)] = per-workgroup sums of g^2
+ *   vlpet_adamw_step   g' = g * grad_scale * min(1, max_norm / (||g * grad_scale|| + 1e-6));  AdamW(p, g', m, v)
+ * variant 0 = transformers.optimization.AdamW as the reference configures it (bias correction on, eps
+ * added to sqrt(v), decoupled decay after the update); variant 1 = torch.optim.AdamW (decay first,
+ * eps added to sqrt(v / (1 - beta2^t))).  decay_mask [n] uint8 (4-byte aligned): 1 where weight decay
+ * applies (NULL: everywhere).  step = 1-based update count.  grad_scale folds the data-parallel average
+ * (1 / world_size) in.  zero_grad != 0 clears g.  norm_out (optional device float) receives the pre-clip norm. */
+int vlpet_optim_blocks(int64_t n);
+int vlpet_grad_sumsq(const float* g, int64_t n, float* partials, vlpet_stream_t stream);
+int vlpet_adamw_step(float* p, float* g, float* m, float* v, const uint8_t* decay_mask, int64_t n,
+                     const float* partials, int n_partials, float max_norm, float grad_scale, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int step, int variant,
+                     int zero_grad, float* norm_out, vlpet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

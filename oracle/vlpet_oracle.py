@@ -264,3 +264,36 @@ def k1_fwd_bwd(x1, x2, wd, bd, wu, bu, wgd, bgd, wgu, bgu, dy, *, n_heads=1, gat
     y.backward(dy)
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
     return y.detach(), grads
+
+
+# ------------------------------------------------------------ optimizer step
+def clip_grad_norm(grads: Sequence[torch.Tensor], max_norm: float) -> torch.Tensor:
+    """``torch.nn.utils.clip_grad_norm_`` as called at multitask.py:279-300: one global 2-norm over every
+    gradient, ``coef = max_norm / (norm + 1e-6)``, gradients scaled in place when ``coef < 1``."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    coef = max_norm / (total + 1e-6)
+    if coef < 1:
+        for g in grads:
+            g.mul_(coef)
+    return total
+
+
+def hf_adamw_step(p, g, m, v, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-6, weight_decay: float = 0.0):
+    """One update of ``transformers.optimization.AdamW`` (transformers 4.2.1, ``correct_bias=True``), the
+    optimizer the reference builds at trainer_base.py:690-701: moments, bias-corrected step size with eps
+    added to sqrt(v), then decoupled weight decay ``p -= lr * wd * p``.  In place; ``step`` is 1-based."""
+    b1, b2 = betas
+    m.mul_(b1).add_(g, alpha=1.0 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+    denom = v.sqrt().add_(eps)
+    step_size = lr * math.sqrt(1.0 - b2 ** step) / (1.0 - b1 ** step)
+    p.addcdiv_(m, denom, value=-step_size)
+    if weight_decay > 0.0:
+        p.add_(p, alpha=-lr * weight_decay)
+
+
+def linear_warmup_lr(step: int, base_lr: float, warmup_steps: int, total_steps: int) -> float:
+    """``get_linear_schedule_with_warmup`` factor for the update with 0-based index ``step``."""
+    if step < warmup_steps:
+        return base_lr * float(step) / float(max(1, warmup_steps))
+    return base_lr * max(0.0, float(total_steps - step) / float(max(1, total_steps - warmup_steps)))

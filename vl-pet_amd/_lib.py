@@ -52,6 +52,10 @@ SIGNATURES = {
     "vlpet_rowgate_bwd": (c_int, [c_void_p] * 10 + [c_int64, c_int, c_int, c_void_p]),
     "vlpet_vecgate_fwd": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p]),
     "vlpet_vecgate_bwd": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
+    "vlpet_optim_blocks": (c_int, [c_int64]),
+    "vlpet_grad_sumsq": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "vlpet_adamw_step": (c_int, [c_void_p] * 5 + [c_int64, c_void_p, c_int] + [c_float] * 7 + [c_int, c_int, c_int,
+                                                                                           c_void_p, c_void_p]),
     "vlpet_downsample_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vlpet_sublayer_tail_partials": (c_int, [c_int64]),
     "vlpet_sublayer_tail_fwd": (c_int, [c_void_p] * 9 + [c_int64, c_int, c_float, c_float, c_uint64, c_int, c_int, c_void_p]),

@@ -2,6 +2,7 @@
 #include "../../include/vlpet_hip.h"
 #include "common.h"
 #include "kernels.h"
+#include <cmath>
 #include <stdlib.h>
 #include <stdio.h>
 #include <vector>
@@ -523,5 +524,33 @@ extern "C" int vlpet_vecgate_bwd(const void* dy, const void* h, const float* v, 
     RowArgs r{};
     r.a = dy; r.c = h; r.va = v; r.o1 = dh; r.part = partials;
     return row_launch(r, VEC_BWD, M, d, io_dtype, stream);
+}
+
+// ---- fused clip + AdamW over the flat trainable buffer ------------------------------------------------------
+extern "C" int vlpet_optim_blocks(int64_t n) { return n > 0 ? optim_blocks(n) : 0; }
+
+extern "C" int vlpet_grad_sumsq(const float* g, int64_t n, float* partials, vlpet_stream_t stream) {
+    if (!g || !partials) return VLPET_E_NULL;
+    if (n <= 0) return VLPET_E_SHAPE;
+    if (!aligned16(g)) return VLPET_E_ALIGN;
+    return herr(launch_sumsq(g, n, partials, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_adamw_step(float* p, float* g, float* m, float* v, const uint8_t* decay_mask, int64_t n,
+                                const float* partials, int n_partials, float max_norm, float grad_scale, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, int step, int variant,
+                                int zero_grad, float* norm_out, vlpet_stream_t stream) {
+    if (!p || !g || !m || !v || !partials) return VLPET_E_NULL;
+    if (n <= 0 || n_partials <= 0 || step <= 0 || (variant != 0 && variant != 1)) return VLPET_E_SHAPE;
+    if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (decay_mask && ((uintptr_t)decay_mask & 3)))
+        return VLPET_E_ALIGN;
+    AdamwArgs a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.decay = decay_mask; a.n = n; a.partials = partials; a.n_partials = n_partials;
+    a.max_norm = max_norm; a.grad_scale = grad_scale; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.weight_decay = weight_decay;
+    a.bias_c1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bias_c2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    a.decay_first = variant == 1; a.eps_scaled = variant == 1; a.zero_grad = zero_grad; a.norm_out = norm_out;
+    return herr(launch_adamw(a, (hipStream_t)stream));
 }
 

@@ -158,3 +158,22 @@ struct RowArgs {
 hipError_t launch_rowgate(const RowArgs& a, int op, int io_fp32, hipStream_t stream);
 int rowgate_blocks(int64_t M);
 
+// Fused clip + AdamW over the flat trainable buffer, optim.hip
+struct AdamwArgs {
+    float* p; float* g; float* m; float* v;       // [n] fp32, 16-byte aligned
+    const uint8_t* decay;                          // [n] 1 = weight decay applies, or nullptr (all decay)
+    int64_t n;
+    const float* partials; int n_partials;         // sum of squares of g per workgroup of sumsq_kernel
+    float max_norm;                                // <= 0: no clipping
+    float grad_scale;                              // 1 / world_size (gradient averaging folded in)
+    float lr, beta1, beta2, eps, weight_decay;
+    float bias_c1, bias_c2_sqrt;                   // 1 - beta1^t, sqrt(1 - beta2^t)
+    int decay_first;                               // 1: torch.optim.AdamW order, 0: transformers.AdamW order
+    int eps_scaled;                                // 1: eps added to sqrt(v)/sqrt(bc2) (torch), 0: to sqrt(v) (transformers)
+    int zero_grad;                                 // 1: clear g after use
+    float* norm_out;                               // optional device scalar: the pre-clip global norm
+};
+hipError_t launch_sumsq(const float* g, int64_t n, float* partials, hipStream_t stream);
+hipError_t launch_adamw(const AdamwArgs& a, hipStream_t stream);
+int optim_blocks(int64_t n);
+

@@ -1,0 +1,102 @@
+// Fused optimizer step over the flat trainable buffer: global-norm clip + AdamW in two
+// launches instead of ~230 per-tensor kernels.  Reference semantics: torch.nn.utils.clip_grad_norm_(params, 5.0)
+// (multitask.py:279-300) followed by transformers' AdamW as configured in trainer_base.py:633-701
+// (eps 1e-6, weight decay 0.01 except bias / LayerNorm.weight, bias correction on):
+//     g   <- g * grad_scale * min(1, max_norm / (||g * grad_scale|| + 1e-6))
+//     m   <- b1 m + (1-b1) g ;  v <- b2 v + (1-b2) g^2
+//     p   <- p - lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)  ;  p <- p - lr * wd * p      (decay after the update)
+// (transformers.optimization.AdamW order; torch.optim.AdamW decays before the update -- selectable).
+// HBM-bound streaming kernels: 16-byte accesses, one pass over p, g, m, v (+1 byte/element decay mask).
+#include "common.h"
+#include "kernels.h"
+
+constexpr int OPT_THREADS = 256;
+
+int optim_blocks(int64_t n) {
+    const int64_t need = (n / 4 + OPT_THREADS - 1) / OPT_THREADS;
+    const int64_t cap = 1024;
+    return (int)(need < 1 ? 1 : (need < cap ? need : cap));
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* partials) {
+    __shared__ float red[OPT_THREADS / 64];
+    float s = 0.f;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * OPT_THREADS) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) { const float t = g[n4 * 4 + threadIdx.x]; s += t * t; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < OPT_THREADS / 64; ++w) t += red[w];
+        partials[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(AdamwArgs a) {
+    // every workgroup reduces the (<= 1024) partial sums itself: no host round trip, no third launch
+    __shared__ float red[OPT_THREADS / 64];
+    __shared__ float clip_s;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < a.n_partials; i += OPT_THREADS) s += a.partials[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < OPT_THREADS / 64; ++w) t += red[w];
+        const float norm = sqrtf(t) * a.grad_scale;
+        float c = a.max_norm > 0.f ? a.max_norm / (norm + 1e-6f) : 1.0f;
+        clip_s = a.grad_scale * (c < 1.0f ? c : 1.0f);
+        if (blockIdx.x == 0 && a.norm_out) *a.norm_out = norm;
+    }
+    __syncthreads();
+    const float gscale = clip_s;
+    const float b1 = a.beta1, b2 = a.beta2, lr = a.lr, eps = a.eps;
+    const float step_size = lr * a.bias_c2_sqrt / a.bias_c1;
+    auto upd = [&](float& p, float g, float& m, float& v, uint8_t dec) {
+        g *= gscale;
+        const float wd = dec ? a.weight_decay : 0.f;
+        if (a.decay_first) p -= lr * wd * p;
+        m = b1 * m + (1.f - b1) * g;
+        v = b2 * v + (1.f - b2) * g * g;
+        p -= step_size * m / (sqrtf(v) + eps * (a.eps_scaled ? a.bias_c2_sqrt : 1.0f));
+        if (!a.decay_first) p -= lr * wd * p;
+    };
+    const int64_t n4 = a.n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * OPT_THREADS) {
+        f32x4 p = reinterpret_cast<f32x4*>(a.p)[i], g = reinterpret_cast<f32x4*>(a.g)[i];
+        f32x4 m = reinterpret_cast<f32x4*>(a.m)[i], v = reinterpret_cast<f32x4*>(a.v)[i];
+        const uint32_t dk = a.decay ? reinterpret_cast<const uint32_t*>(a.decay)[i] : 0x01010101u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float pj = p[j], mj = m[j], vj = v[j];
+            upd(pj, g[j], mj, vj, (uint8_t)(dk >> (8 * j)));
+            p[j] = pj; m[j] = mj; v[j] = vj;
+        }
+        reinterpret_cast<f32x4*>(a.p)[i] = p;
+        reinterpret_cast<f32x4*>(a.m)[i] = m;
+        reinterpret_cast<f32x4*>(a.v)[i] = v;
+        if (a.zero_grad) { const f32x4 z = {0.f, 0.f, 0.f, 0.f}; reinterpret_cast<f32x4*>(a.g)[i] = z; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(a.n - n4 * 4)) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        upd(a.p[i], a.g[i], a.m[i], a.v[i], a.decay ? a.decay[i] : (uint8_t)1);
+        if (a.zero_grad) a.g[i] = 0.f;
+    }
+}
+
+hipError_t launch_sumsq(const float* g, int64_t n, float* partials, hipStream_t stream) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(optim_blocks(n)), dim3(OPT_THREADS), 0, stream, g, n, partials);
+    return hipGetLastError();
+}
+hipError_t launch_adamw(const AdamwArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(adamw_kernel, dim3(optim_blocks(a.n)), dim3(OPT_THREADS), 0, stream, a);
+    return hipGetLastError();
+}

@@ -121,8 +121,18 @@ def pack_pair(down_w: Sequence[torch.Tensor], down_b: Optional[Sequence[torch.Te
     return PackedPair(buf, tiles, r, d, io_dtype)
 
 
+# Bumped by optimizers that update parameters behind autograd's back (the fused flat-buffer AdamW writes through
+# raw pointers, which does not touch ``Tensor._version``); part of every pack-cache key.
+WEIGHTS_EPOCH = 0
+
+
+def bump_weights_epoch():
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
+
+
 class PackCache:
-    """Re-pack only when a parameter changed (optimizer steps bump ``Tensor._version``)."""
+    """Re-pack only when a parameter changed (optimizer steps bump ``Tensor._version`` or ``WEIGHTS_EPOCH``)."""
 
     def __init__(self):
         self._key = None
@@ -130,7 +140,7 @@ class PackCache:
 
     def get(self, down_w, down_b, up_w, up_b, io_dtype, tiles=None) -> PackedPair:
         ts = list(down_w) + (list(down_b) if down_b is not None else []) + [up_w] + ([up_b] if up_b is not None else [])
-        key = (io_dtype, tiles) + tuple((t.data_ptr(), t._version) for t in ts)
+        key = (io_dtype, tiles, WEIGHTS_EPOCH) + tuple((t.data_ptr(), t._version) for t in ts)
         if key != self._key:
             self._val = pack_pair(down_w, down_b, up_w, up_b, io_dtype, tiles)
             self._key = key
@@ -144,6 +154,30 @@ def _flat(x: torch.Tensor, d: int) -> torch.Tensor:
 
 def _grad_like(g32: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
     return g32 if p.dtype == torch.float32 else g32.to(p.dtype)
+
+
+def _grad_dest(p: torch.Tensor, shape, block: bool = False):
+    """Where a weight-gradient kernel writes: the parameter's slot of the trainer's flat gradient buffer when it
+    offers one for this step (train.GradSink: first write of the step, fp32, matching shape) -- then autograd
+    gets ``None`` for that input and no accumulate kernel runs -- else a fresh fp32 tensor returned to autograd."""
+    sink = getattr(p, "_vlpet_block_sink" if block else "_vlpet_sink", None)
+    if sink is not None and tuple(sink.view.shape) == tuple(shape) and sink.view.device == p.device:
+        v = sink.take()
+        if v is not None:
+            return v, sink
+    return torch.empty(*shape, dtype=torch.float32, device=p.device), None
+
+
+def _finish(dests):
+    """Autograd return values for (tensor, sink, param) triples: None where the kernel wrote into a sink."""
+    out = []
+    for t, sink, p in dests:
+        if sink is not None:
+            sink.done()
+            out.append(None)
+        else:
+            out.append(_grad_like(t, p))
+    return out
 
 
 class _AdapterGateFn(torch.autograd.Function):
@@ -183,13 +217,13 @@ class _AdapterGateFn(torch.autograd.Function):
         dev = x2f.device
         r = pk_a.r
         rg = pk_g.r if gate else 0
-        f32 = dict(dtype=torch.float32, device=dev)
-        dwd, dbd, dwu, dbu = (torch.empty(r, d, **f32), torch.empty(r, **f32), torch.empty(d, r, **f32),
-                              torch.empty(d, **f32))
+        nh2 = 2 * n_heads
+        (dwd, s_wd), (dbd, s_bd) = _grad_dest(params[0], (r, d), block=True), _grad_dest(params[n_heads], (r,), block=True)
+        (dwu, s_wu), (dbu, s_bu) = _grad_dest(params[nh2], (d, r)), _grad_dest(params[nh2 + 1], (d,))
         dwgd = dbgd = dwgu = dbgu = None
         if gate:
-            dwgd, dbgd, dwgu, dbgu = (torch.empty(rg, d, **f32), torch.empty(rg, **f32),
-                                      torch.empty(d, rg, **f32), torch.empty(d, **f32))
+            (dwgd, s_gd), (dbgd, s_gdb) = _grad_dest(params[nh2 + 2], (rg, d)), _grad_dest(params[nh2 + 3], (rg,))
+            (dwgu, s_gu), (dbgu, s_gub) = _grad_dest(params[nh2 + 4], (d, rg)), _grad_dest(params[nh2 + 5], (d,))
         dx2 = torch.empty_like(x2f)
         dx1 = torch.empty_like(x2f) if gate else None
         nws = lib.vlpet_bwd_workspace_bytes(M, d, pk_a.tiles, int(gate), io)
@@ -211,16 +245,20 @@ class _AdapterGateFn(torch.autograd.Function):
             dx2 = dx2 + s2 * dyf
         rh = r // n_heads
         grads: List[Optional[torch.Tensor]] = []
-        for i in range(n_heads):
-            grads.append(_grad_like(dwd[i * rh:(i + 1) * rh], params[i]))
-        for i in range(n_heads):
-            grads.append(_grad_like(dbd[i * rh:(i + 1) * rh], params[n_heads + i]))
-        grads.append(_grad_like(dwu, params[2 * n_heads]))
-        grads.append(_grad_like(dbu, params[2 * n_heads + 1]))
+        if s_wd is not None:
+            s_wd.done()
+            grads += [None] * n_heads
+        else:
+            grads += [_grad_like(dwd[i * rh:(i + 1) * rh], params[i]) for i in range(n_heads)]
+        if s_bd is not None:
+            s_bd.done()
+            grads += [None] * n_heads
+        else:
+            grads += [_grad_like(dbd[i * rh:(i + 1) * rh], params[n_heads + i]) for i in range(n_heads)]
+        grads += _finish([(dwu, s_wu, params[nh2]), (dbu, s_bu, params[nh2 + 1])])
         if gate:
-            base = 2 * n_heads + 2
-            grads += [_grad_like(dwgd, params[base]), _grad_like(dbgd, params[base + 1]),
-                      _grad_like(dwgu, params[base + 2]), _grad_like(dbgu, params[base + 3])]
+            grads += _finish([(dwgd, s_gd, params[nh2 + 2]), (dbgd, s_gdb, params[nh2 + 3]),
+                              (dwgu, s_gu, params[nh2 + 4]), (dbgu, s_gub, params[nh2 + 5])])
         gx1 = dx1.view(shp1) if gate else None
         return (gx1, dx2.view(shp2), None, None, None, None, None, None, None, *grads)
 
@@ -264,8 +302,8 @@ class _ParallelAdapterFn(torch.autograd.Function):
         dyf = _flat(dy, d)
         f32 = dict(dtype=torch.float32, device=xf.device)
         r = pk.r
-        dwd, dbd, dwu, dbu = (torch.empty(r, d, **f32), torch.empty(r, **f32), torch.empty(d, r, **f32),
-                              torch.empty(d, **f32))
+        (dwd, s0), (dbd, s1), (dwu, s2), (dbu, s3) = (_grad_dest(wd, (r, d)), _grad_dest(bd, (r,)),
+                                                      _grad_dest(wu, (d, r)), _grad_dest(bu, (d,)))
         dx = torch.empty_like(xf)
         nws = lib.vlpet_bwd_workspace_bytes(M, d, pk.tiles, 0, io)
         ws = torch.empty(nws, dtype=torch.uint8, device=xf.device)
@@ -273,8 +311,7 @@ class _ParallelAdapterFn(torch.autograd.Function):
             dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), dx.data_ptr(), dwd.data_ptr(), dbd.data_ptr(),
             dwu.data_ptr(), dbu.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, ctx.scale, io, _stream()))
         _lib.check(rc, "vlpet_parallel_adapter_bwd")
-        return (dx.view(ctx.shape), dy, None, None, _grad_like(dwd, wd), _grad_like(dbd, bd),
-                _grad_like(dwu, wu), _grad_like(dbu, bu))
+        return (dx.view(ctx.shape), dy, None, None, *_finish([(dwd, s0, wd), (dbd, s1, bd), (dwu, s2, wu), (dbu, s3, bu)]))
 
 
 def parallel_adapter(x, y, wd, bd, wu, bu, pk: PackedPair, scale: float = 1.0):
@@ -316,7 +353,7 @@ class _LoraDeltaFn(torch.autograd.Function):
         dyf = _flat(dy, d)
         f32 = dict(dtype=torch.float32, device=xf.device)
         r = pk.r
-        da, db = torch.empty(r, d, **f32), torch.empty(d, r, **f32)
+        (da, s0), (db, s1) = _grad_dest(lora_a, (r, d)), _grad_dest(lora_b, (d, r))
         dx = torch.empty_like(xf)
         nws = lib.vlpet_bwd_workspace_bytes(M, d, pk.tiles, 0, io)
         ws = torch.empty(nws, dtype=torch.uint8, device=xf.device)
@@ -324,7 +361,7 @@ class _LoraDeltaFn(torch.autograd.Function):
                                       dx.data_ptr(), da.data_ptr(), db.data_ptr(), r, ws.data_ptr(), nws,
                                       M, d, pk.tiles, scaling, io, _stream())
         _lib.check(rc, "vlpet_lora_delta_bwd")
-        return dx.view(shape), dy, None, None, None, None, _grad_like(da, lora_a), _grad_like(db, lora_b)
+        return (dx.view(shape), dy, None, None, None, None, *_finish([(da, s0, lora_a), (db, s1, lora_b)]))
 
 
 def lora_delta(x, base, lora_a, lora_b, pk: PackedPair, scaling: float, keep=None, keep_scale: float = 1.0):

@@ -137,25 +137,73 @@ def task_loss(per_token: torch.Tensor, labels: torch.Tensor, scores: Optional[to
     return (per_token * mask).sum() / mask.sum().clamp(min=1)
 
 
-# ------------------------------------------------------------------ flat gradients + DP exchange
-class FlatGrads:
-    def __init__(self, model: nn.Module, world_size: int = 1, n_buckets: int = 3, process_group=None):
-        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+# ------------------------------------------------------------------ flat trainable state + DP exchange
+class GradSink:
+    """Destination of a weight gradient inside the flat gradient buffer.  The PET autograd functions hand
+    ``view`` straight to the weight-gradient kernels (no temporary, no AccumulateGrad add kernel) and then call
+    ``done()``, which does the bucket accounting the post-accumulate hook would have done."""
 
-        def readiness(n):          # backward produces decoder grads first, visual embedding last
-            if ".decoder." in n:
-                return 0
-            if "visual_embedding" in n or "layernorm_embedding" in n:
-                return 2
-            return 1
-        named.sort(key=lambda t: readiness(t[0]))
+    def __init__(self, owner: "FlatGrads", view: torch.Tensor, indices: Sequence[int]):
+        self.owner, self.view, self.indices = owner, view, tuple(indices)
+        self.epoch = -1
+
+    def take(self) -> Optional[torch.Tensor]:
+        """The view if this is the first write of the step (the kernels overwrite), else None (-> autograd adds)."""
+        if not self.owner.sinks_enabled or self.epoch == self.owner.epoch:
+            return None
+        self.epoch = self.owner.epoch
+        return self.view
+
+    def done(self):
+        for i in self.indices:
+            self.owner._ready(i)
+
+
+def _flat_order(named):
+    """Backward-readiness classes (decoder first, visual embedding last); inside a class the parameters keep
+    their order except that the N_h blocks of a multi-head down projection become adjacent
+    ([w0..w3 | b0..b3]) so that their gradient is ONE [r, d] block of the flat buffer."""
+    import re
+
+    def readiness(n):
+        if ".decoder." in n:
+            return 0
+        if "visual_embedding" in n or "layernorm_embedding" in n:
+            return 2
+        return 1
+    pat = re.compile(r"(.*adapter_multihead_down)\.(\d+)\.(weight|bias)$")
+    first_seen = {}
+    keyed = []
+    for pos, (n, p) in enumerate(named):
+        mm = pat.match(n)
+        if mm:
+            g = mm.group(1)
+            first_seen.setdefault(g, pos)
+            keyed.append(((readiness(n), first_seen[g], 0 if mm.group(3) == "weight" else 1, int(mm.group(2))), n, p))
+        else:
+            keyed.append(((readiness(n), pos, 0, 0), n, p))
+    keyed.sort(key=lambda t: t[0])
+    return [(n, p) for _, n, p in keyed]
+
+
+class FlatGrads:
+    """Flat fp32 gradient buffer with ``.grad`` views, bucketed asynchronous all-reduce, and (optionally) the
+    parameters themselves + Adam moments as flat buffers for the fused optimizer."""
+
+    def __init__(self, model: nn.Module, world_size: int = 1, n_buckets: int = 3, process_group=None,
+                 flatten_params: bool = False, sinks: bool = False):
+        named = _flat_order([(n, p) for n, p in model.named_parameters() if p.requires_grad])
         self.names = [n for n, _ in named]
         self.params = [p for _, p in named]
         total = sum(p.numel() for p in self.params)
+        total_pad = (total + 3) // 4 * 4
         dev = self.params[0].device
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.total = total
+        self.flat = torch.zeros(total_pad, dtype=torch.float32, device=dev)
         self.world_size = world_size
         self.group = process_group
+        self.epoch = 0
+        self.sinks_enabled = bool(sinks)
         off = 0
         self.slices = []
         for p in self.params:
@@ -163,6 +211,12 @@ class FlatGrads:
             p.grad = self.flat[off:off + n].view_as(p)
             self.slices.append((off, off + n))
             off += n
+        self.flat_p = None
+        if flatten_params:
+            self.flat_p = torch.zeros(total_pad, dtype=torch.float32, device=dev)
+            for p, (a, b) in zip(self.params, self.slices):
+                self.flat_p[a:b].copy_(p.data.reshape(-1).float())
+                p.data = self.flat_p[a:b].view_as(p)
         # buckets = contiguous ranges of roughly equal size, cut at parameter boundaries
         self.bucket_of = []
         self.buckets = []
@@ -185,37 +239,77 @@ class FlatGrads:
         if world_size > 1:
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        if sinks:
+            self._attach_sinks()
 
-    def _make_hook(self, i):
-        def hook(param):
+    # ---- direct-write destinations for the weight-gradient kernels
+    def _attach_sinks(self):
+        import re
+        pat = re.compile(r"(.*adapter_multihead_down)\.(\d+)\.(weight|bias)$")
+        groups: Dict[tuple, List[int]] = {}
+        for i, n in enumerate(self.names):
+            mm = pat.match(n)
+            if mm:
+                groups.setdefault((mm.group(1), mm.group(3)), []).append(i)
+        in_group = set()
+        for (_, kind), idx in groups.items():
+            idx.sort()
+            a, b = self.slices[idx[0]][0], self.slices[idx[-1]][1]
+            contiguous = all(self.slices[idx[k]][1] == self.slices[idx[k + 1]][0] for k in range(len(idx) - 1))
+            if not contiguous:
+                continue
+            first = self.params[idx[0]]
+            rows = sum(self.params[i].shape[0] for i in idx)
+            view = self.flat[a:b].view(rows, *first.shape[1:]) if kind == "weight" else self.flat[a:b]
+            first._vlpet_block_sink = GradSink(self, view, idx)
+            in_group.update(idx)
+        for i, p in enumerate(self.params):
+            if i not in in_group:
+                a, b = self.slices[i]
+                p._vlpet_sink = GradSink(self, self.flat[a:b].view_as(p), [i])
+
+    def _ready(self, i):
+        if self.world_size > 1:
             b = self.bucket_of[i]
             self._pending[b] += 1
             if self._pending[b] == self.bucket_count[b]:
                 self._launch(b)
+
+    def _make_hook(self, i):
+        def hook(param):
+            self._ready(i)
         return hook
 
     def _launch(self, b):
         a, e = self.buckets[b]
         self._handles.append(dist.all_reduce(self.flat[a:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def finish(self, used: Optional[Sequence[bool]] = None):
+    def finish(self, average: bool = True):
         """Wait for the bucket all-reduces (launching any bucket whose parameters did not all receive a
-        gradient this step -- per-task adapters / LoRA leave other tasks' grads at zero) and average."""
+        gradient this step -- per-task adapters / LoRA leave other tasks' grads at zero) and average
+        (``average=False``: the caller folds 1/world_size into its optimizer kernel)."""
         if self.world_size > 1:
             for b in range(len(self.buckets)):
-                if self._pending[b] != self.bucket_count[b]:
+                if self._pending[b] < self.bucket_count[b]:
                     self._launch(b)
             for h in self._handles:
                 h.wait()
             self._handles.clear()
             self._pending = [0] * len(self.buckets)
-            self.flat.div_(self.world_size)
+            if average:
+                self.flat.div_(self.world_size)
 
-    def zero(self):
-        self.flat.zero_()
+    def begin_step(self, zero: bool = True):
+        """New accumulation epoch: every sink accepts one direct write again."""
+        self.epoch += 1
+        if zero:
+            self.flat.zero_()
         for p, (a, b) in zip(self.params, self.slices):     # re-attach in case something replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.flat[a:b].data_ptr():
                 p.grad = self.flat[a:b].view_as(p)
+
+    def zero(self):
+        self.begin_step(zero=True)
 
     def clip_(self, max_norm: float) -> torch.Tensor:
         norm = torch.linalg.vector_norm(self.flat)
@@ -224,43 +318,89 @@ class FlatGrads:
         return norm
 
 
-def build_optimizer(model: nn.Module, lr=1e-3, weight_decay=0.01, eps=1e-6):
-    no_decay = ("bias", "LayerNorm.weight")
-    decay, nodecay = [], []
-    for n, p in model.named_parameters():
-        if not p.requires_grad:
-            continue
-        (nodecay if any(nd in n for nd in no_decay) else decay).append(p)
-    groups = [dict(params=decay, weight_decay=weight_decay), dict(params=nodecay, weight_decay=0.0)]
-    return torch.optim.AdamW(groups, lr=lr, eps=eps, fused=decay[0].is_cuda if decay else False)
+NO_DECAY = ("bias", "LayerNorm.weight")     # trainer_base.py:635 (substring rule; BART's *_layer_norm.weight DOES decay)
 
 
-def linear_schedule(optimizer, warmup_steps: int, total_steps: int):
-    def f(step):
-        if step < warmup_steps:
-            return step / max(1, warmup_steps)
-        return max(0.0, (total_steps - step) / max(1, total_steps - warmup_steps))
-    return torch.optim.lr_scheduler.LambdaLR(optimizer, f)
+def lr_at(step: int, base_lr: float, warmup_steps: int, total_steps: int) -> float:
+    """get_linear_schedule_with_warmup (trainer_base.py:633-720): factor for the update with 0-based index ``step``."""
+    if step < warmup_steps:
+        return base_lr * step / max(1, warmup_steps)
+    return base_lr * max(0.0, (total_steps - step) / max(1, total_steps - warmup_steps))
+
+
+class FusedAdamW:
+    """Global-norm clip + AdamW (transformers.optimization.AdamW semantics, trainer_base.py:690-701) over the
+    flat trainable buffer: two HIP launches per step (csrc/optim.hip).  GPU only."""
+
+    def __init__(self, flat: FlatGrads, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, max_norm=5.0,
+                 variant=0):
+        from . import _lib
+        if flat.flat_p is None or not flat.flat.is_cuda:
+            raise RuntimeError("vl-pet_amd: FusedAdamW needs FlatGrads(flatten_params=True) on the GPU")
+        self.lib = _lib.load()
+        self.flat, self.lr, self.betas, self.eps, self.wd, self.max_norm, self.variant = \
+            flat, lr, betas, eps, weight_decay, max_norm, variant
+        dev = flat.flat.device
+        n = flat.flat.numel()
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        mask = torch.zeros(n, dtype=torch.uint8)
+        for name, (a, b) in zip(flat.names, flat.slices):
+            if not any(nd in name for nd in NO_DECAY):
+                mask[a:b] = 1
+        self.decay = mask.to(dev)
+        self.nb = self.lib.vlpet_optim_blocks(n)
+        self.partials = torch.empty(self.nb, dtype=torch.float32, device=dev)
+        self.norm = torch.zeros((), dtype=torch.float32, device=dev)
+        self.t = 0
+
+    def step(self, lr: Optional[float] = None):
+        from . import _lib
+        from . import functional as VF
+        f = self.flat
+        n = f.flat.numel()
+        st = torch.cuda.current_stream().cuda_stream
+        self.t += 1
+        rc = self.lib.vlpet_grad_sumsq(f.flat.data_ptr(), n, self.partials.data_ptr(), st)
+        _lib.check(rc, "vlpet_grad_sumsq")
+        rc = self.lib.vlpet_adamw_step(f.flat_p.data_ptr(), f.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                       self.decay.data_ptr(), n, self.partials.data_ptr(), self.nb, float(self.max_norm),
+                                       1.0 / f.world_size, float(self.lr if lr is None else lr), self.betas[0],
+                                       self.betas[1], self.eps, self.wd, self.t, self.variant, 1, self.norm.data_ptr(), st)
+        _lib.check(rc, "vlpet_adamw_step")
+        VF.bump_weights_epoch()
+
+
+# Set by the test / CPU-baseline harness: factory(flat: FlatGrads, lr, max_norm) -> object with .step(lr).
+# The product has no CPU optimizer of its own.
+CPU_OPTIMIZER_FACTORY = None
 
 
 class Trainer:
     """One process per GPU.  ``step(batch)`` = forward, backward (with overlapped gradient exchange),
-    clip, AdamW, scheduler."""
+    clip, AdamW, scheduler -- multitask.py:217-342."""
 
     def __init__(self, model: nn.Module, config, lr=1e-3, clip=5.0, total_steps=1000, warmup_ratio=0.1,
                  world_size=1, n_buckets=3, process_group=None):
-        self.model, self.config, self.clip = model, config, clip
-        self.flat = FlatGrads(model, world_size, n_buckets, process_group)
-        self.optim = build_optimizer(model, lr=lr)
-        self.sched = linear_schedule(self.optim, int(total_steps * warmup_ratio), total_steps)
+        self.model, self.config, self.clip, self.base_lr = model, config, clip, lr
+        on_gpu = next(model.parameters()).is_cuda
+        self.flat = FlatGrads(model, world_size, n_buckets, process_group, flatten_params=True, sinks=on_gpu)
+        if on_gpu:
+            self.optim = FusedAdamW(self.flat, lr=lr, max_norm=clip)
+        elif CPU_OPTIMIZER_FACTORY is not None:
+            self.optim = CPU_OPTIMIZER_FACTORY(self.flat, lr, clip)
+        else:
+            raise RuntimeError("vl-pet_amd: the trainer's optimizer step runs on the GPU only")
+        self.warmup, self.total = int(total_steps * warmup_ratio), total_steps
+        self.step_idx = 0
+        self.flat.begin_step(zero=True)
 
     def step(self, batch) -> torch.Tensor:
-        self.flat.zero()
         per_token, _ = self.model(batch["input_ids"], batch["vis_inputs"], batch["labels"], batch["task"])
         loss = task_loss(per_token, batch["labels"], batch.get("scores"), batch["task"])
         loss.backward()
-        self.flat.finish()
-        self.flat.clip_(self.clip)
-        self.optim.step()
-        self.sched.step()
+        self.flat.finish(average=False)
+        self.optim.step(lr_at(self.step_idx, self.base_lr, self.warmup, self.total))   # clips, updates, zeroes the grads
+        self.step_idx += 1
+        self.flat.begin_step(zero=False)
         return loss.detach()

@@ -9,7 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from .functional import _flat, _io_dtype, _need_cuda, _param_dtype, _ptr, _stream, _timed, _grad_like
+from .functional import _finish, _flat, _grad_dest, _grad_like, _io_dtype, _need_cuda, _param_dtype, _ptr, _stream, _timed
 
 
 class VisProjPackCache:
@@ -18,7 +18,8 @@ class VisProjPackCache:
         self._val = None
 
     def get(self, w: torch.Tensor, b: torch.Tensor, io_dtype: int) -> torch.Tensor:
-        key = (io_dtype, w.data_ptr(), w._version, b.data_ptr(), b._version)
+        from . import functional as _VF
+        key = (io_dtype, _VF.WEIGHTS_EPOCH, w.data_ptr(), w._version, b.data_ptr(), b._version)
         if key != self._key:
             lib = _lib.load()
             d_out, F = w.shape
@@ -77,8 +78,7 @@ class _VisProjFn(torch.autograd.Function):
         dgamma = (dyf * xh).sum(0)
         dbeta = dyf.sum(0) if has_beta else None
         dpre_io = dpre.to(ff.dtype).contiguous()
-        f32 = dict(dtype=torch.float32, device=ff.device)
-        dw, db = torch.empty(d_out, F, **f32), torch.empty(d_out, **f32)
+        (dw, s_w), (db, s_b) = _grad_dest(w, (d_out, F)), _grad_dest(b, (d_out,))
         nws = lib.vlpet_visproj_wgrad_workspace_bytes(M, F, d_out)
         ws = torch.empty(nws, dtype=torch.uint8, device=ff.device)
         rc = _timed("k4_wgrad", M, lambda: lib.vlpet_visproj_wgrad(
@@ -86,7 +86,8 @@ class _VisProjFn(torch.autograd.Function):
             _stream()))
         _lib.check(rc, "vlpet_visproj_wgrad")
         dR = dy.to(r_dtype) if has_r else None
-        return (None, dR, _grad_like(dw, w), _grad_like(db, b), _grad_like(dgamma, gamma),
+        gw, gb = _finish([(dw, s_w, w), (db, s_b, b)])
+        return (None, dR, gw, gb, _grad_like(dgamma, gamma),
                 _grad_like(dbeta, beta) if has_beta else None, None, None, None)
 
 
