@@ -25,6 +25,9 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s measured achievable)
+# HBM-side bytes per row of pet_bwd_kernel<bf16,3,gate> from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE;
+# profiles/r01_pmc_traffic_k1_bwd.md).  Collected with rocprofv3 --pmc in its own run, not inside this script.
+PMC_TRAFFIC_BYTES_PER_ROW = {"k1_bwd_rows": 15694.0}
 TASK_ORDER = ["vqa", "gqa", "nlvr", "caption"]
 
 
@@ -154,7 +157,10 @@ def main():
         roof = dict(bound="hbm", kernel={"k1_bwd_rows": "pet_bwd_kernel<bf16,3,gate>",
                                          "k1_fwd": "pet_fwd_kernel<bf16,3,gate>"}[dom],
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=None, avg_launch_us=round(a["total_us"] / a["launches"], 2),
+                    traffic=(round(PMC_TRAFFIC_BYTES_PER_ROW[dom] * a["rows"] / a["launches"])
+                             if dom in PMC_TRAFFIC_BYTES_PER_ROW and args.dtype == "bf16" else None),
+                    traffic_source="profiles/r01_pmc_traffic_k1_bwd.md (PMC passes at M=28000, scaled by rows per launch)",
+                    avg_launch_us=round(a["total_us"] / a["launches"], 2),
                     avg_rows_per_launch=round(a["rows"] / a["launches"], 1),
                     algorithmic_bytes_per_row=per_row[dom])
         out = {
