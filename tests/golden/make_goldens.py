@@ -461,6 +461,106 @@ def golden_downsample(tag, B=2, dim=64, seed=6):
          obj_ids=obj_ids.numpy(), y2=T(y2), yb2=T(yb2), yi2=yi2.numpy(), yo2=yo2.numpy())
 
 
+# ------------------------------------------------------------------ whole tiny VLBart (host + trainer pin)
+def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7):
+    """2+2-layer, d=64 ``VLBart`` built from the reference's own classes (src/modeling_bart.py:1458-1530 over
+    JointEncoder :690-1010 and my_transformers BartDecoder): state dict, three task batches, eval-mode per-token
+    losses + logits (pins the host: [text ; visual] concat order, text-only LayerNorm before the concat, hook
+    placement, Downsample, label shifting), and the losses of 5 training steps (pins the trainer: loss reduction
+    per task vqa_model.py:216-227 / nlvr_model.py / caption_model.py, clip_grad_norm_ 5.0, AdamW, linear warm-up,
+    which parameters train).  transformers 4.2.1's AdamW is not importable here, so the optimizer update is the
+    oracle's restatement (oracle.hf_adamw_step); everything else is reference code."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from oracle import vlpet_oracle as O
+    mod = load_vl_module("bart")
+    flags = list(VLPET_LARGE_FLAGS) + ["--adapter_down_dim", "8", "--encoder_adapter_multihead_num_head", "4",
+                                       "--adapter_gating_down_dim", "16",
+                                       "--decoder_enc_attn_value_parallel_adapter_down_dim", "8",
+                                       "--downsample", "--n_boxes", "36"]
+    config, args = make_config("bart", flags, d_model=64, heads=4, ffn=128)
+    config.vocab_size = 500
+    config.feat_dim = 128
+    config.default_obj_order_ids = list(range(400, 500))
+    config.encoder_prompt_config = None
+    config.decoder_prompt_config = None
+    from transformers import PreTrainedModel
+    PreTrainedModel.init_weights = lambda self: self.apply(self._init_weights)
+    torch.manual_seed(seed)
+    model = mod.VLBart(config)
+    gen = torch.Generator().manual_seed(seed)
+    randomize(model, gen)
+    model.lm_head.weight = model.model.shared.weight          # tied, as in the pretrained checkpoints
+    # trainable set: TrainerBase.unfreeze_parameters' substring rules (trainer_base.py:308-542) for this flag set
+    for n, p in model.named_parameters():
+        p.requires_grad = ("adapter" in n) or ("gating" in n) or ("visual_embedding" in n) or \
+            ("encoder." in n and ("layer_norm" in n or "layernorm" in n))
+    B = 3
+    V = 300
+
+    def batch(task, L, T):
+        ids = torch.randint(5, V, (B, L), generator=gen)
+        labels = torch.randint(5, V, (B, T), generator=gen)
+        if task == "nlvr":
+            feats = torch.randn(B, 98, 128, generator=gen)
+            boxes = torch.zeros(B, 98, 4)
+            img = torch.cat([torch.zeros(49), torch.ones(49)]).long().unsqueeze(0).expand(B, -1).contiguous()
+            obj = torch.cat([torch.arange(49), torch.arange(49)]).unsqueeze(0).expand(B, -1).contiguous()
+            vis = (feats, boxes, img, obj)
+        else:
+            vis = (torch.randn(B, 49, 128, generator=gen), torch.zeros(B, 49, 4))
+        scores = torch.rand(B, generator=gen) * 0.5 + 0.5
+        return dict(task=task, ids=ids, labels=labels, vis=vis, scores=scores)
+    batches = [batch("vqa", 20, 5), batch("nlvr", 20, 2), batch("caption", 12, 9)]
+
+    def run(b):
+        out = model(input_ids=b["ids"], vis_inputs=b["vis"], labels=b["labels"], return_dict=True, task=b["task"])
+        return out["loss"].view(b["labels"].shape), out["logits"]
+
+    def reduce(b, per):
+        mask = (b["labels"] != -100).float()
+        if b["task"] in ("vqa", "gqa"):                      # vqa_model.py:216-227
+            return ((per * mask).sum(1) / mask.sum(1).clamp(min=1) * b["scores"]).mean()
+        return (per * mask).sum() / mask.sum().clamp(min=1)   # reduce_loss=True: token mean
+
+    arrs = {"sd::" + k: T(v) for k, v in model.state_dict().items()}
+    model.eval()
+    with torch.no_grad():
+        for i, b in enumerate(batches):
+            per, logits = run(b)
+            arrs.update({f"b{i}::task": np.array(b["task"]), f"b{i}::ids": b["ids"].numpy(), f"b{i}::labels": b["labels"].numpy(),
+                         f"b{i}::scores": T(b["scores"]), f"b{i}::per_token": T(per), f"b{i}::logits": T(logits),
+                         f"b{i}::loss": T(reduce(b, per))})
+            for j, v in enumerate(b["vis"]):
+                arrs[f"b{i}::vis{j}"] = v.numpy()
+    # ---- 5 training steps (multitask.py:217-342): batches cycled, lr 5e-3, 10 total steps, 10 % warm-up
+    model.train()
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    state = {n: (torch.zeros_like(p), torch.zeros_like(p)) for n, p in named}
+    losses = []
+    total, warm, base_lr = 10, 1, 5e-3
+    for step in range(5):
+        b = batches[step % 3]
+        for _, p in named:
+            p.grad = None
+        per, _ = run(b)
+        loss = reduce(b, per)
+        loss.backward()
+        losses.append(float(loss))
+        torch.nn.utils.clip_grad_norm_([p for _, p in named], 5.0)
+        lr = O.linear_warmup_lr(step, base_lr, warm, total)
+        for n, p in named:
+            wd = 0.0 if any(nd in n for nd in ("bias", "LayerNorm.weight")) else 0.01
+            m, v = state[n]
+            if p.grad is None:
+                continue
+            O.hf_adamw_step(p.data, p.grad, m, v, step + 1, lr, eps=1e-6, weight_decay=wd)
+    arrs["train::losses"] = np.array(losses, dtype=np.float64)
+    arrs["train::hparams"] = np.array([base_lr, total, warm, 5.0])
+    for n, p in named:
+        arrs["final::" + n] = T(p.data)
+    save(tag, **arrs)
+
+
 # -------------------------------------------------------- trainable-name lists
 def golden_trainable_names():
     """Parameter-name lists + trainable flags for the VL-PET-large BART encoder/decoder layer
@@ -485,6 +585,9 @@ def main():
     torch.manual_seed(0)
     if len(sys.argv) > 1 and sys.argv[1] == "downsample":      # add one fixture without regenerating the rest
         golden_downsample("downsample_7to6_d64")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "vlbart":
+        golden_vlbart_tiny()
         return
     # (i) K1 BART, full width and tiny, gate variants
     golden_k1_bart("k1_bart_large_d768_r96", 768, 96, 4, 96, B=2, S=8)
@@ -523,6 +626,7 @@ def main():
     golden_decoder_layer("dec_layer_d64_r8", 64, 8, B=2, S_enc=6, S_dec=3)
     golden_trainable_names()
     golden_downsample("downsample_7to6_d64")
+    golden_vlbart_tiny()
 
 
 if __name__ == "__main__":

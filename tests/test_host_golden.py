@@ -1,0 +1,87 @@
+"""Host model + trainer against a tiny VLBart captured from the reference's own classes
+(tests/golden/vlbart_tiny_d64.npz, make_goldens.golden_vlbart_tiny): state-dict keys, [text ; visual] encoder
+order, hook placement, Downsample, label shifting, per-task loss reduction, clip + AdamW + warm-up schedule,
+trainable set.  CPU leg: host model with the HIP-backed ops swapped for the oracle; GPU leg: the product path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load():
+    z = np.load(os.path.join(G, "vlbart_tiny_d64.npz"), allow_pickle=False)
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    batches = []
+    for i in range(3):
+        vis = tuple(torch.from_numpy(z[f"b{i}::vis{j}"]) for j in range(4) if f"b{i}::vis{j}" in z.files)
+        batches.append(dict(task=str(z[f"b{i}::task"]), input_ids=torch.from_numpy(z[f"b{i}::ids"]),
+                            labels=torch.from_numpy(z[f"b{i}::labels"]), scores=torch.from_numpy(z[f"b{i}::scores"]),
+                            vis_inputs=vis, per_token=torch.from_numpy(z[f"b{i}::per_token"]),
+                            logits=torch.from_numpy(z[f"b{i}::logits"]), loss=float(z[f"b{i}::loss"])))
+    final = {k[7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("final::")}
+    return sd, batches, z["train::losses"], z["train::hparams"], final
+
+
+def _build(sd):
+    import vlpet_amd.host.bart as HB
+    import vlpet_amd.train as TR
+    cfg = HB.vlpet_config(d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
+                          decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128, vocab_size=500,
+                          max_position_embeddings=64, feat_dim=128, adapter_down_dim=8, adapter_gating_down_dim=16,
+                          decoder_enc_attn_value_parallel_adapter_down_dim=8, dropout=0.0, attention_dropout=0.0,
+                          activation_dropout=0.0)
+    model = HB.VLBart(cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not missing, missing                                       # every host parameter exists in the reference
+    assert set(unexpected) <= {"lm_head.weight"}, unexpected          # tied head: the host reuses model.shared.weight
+    names = TR.trainable_names(model, cfg)
+    return model, cfg, names
+
+
+def _to(b, dev):
+    out = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+    out["vis_inputs"] = tuple(t.to(dev) for t in b["vis_inputs"])
+    return out
+
+
+def _check(model, cfg, names, batches, ref_losses, hp, final, dev, tol):
+    import vlpet_amd.train as TR
+    assert sorted(names) == sorted(final.keys())                      # the reference's trainable set, name for name
+    model.eval()
+    with torch.no_grad():
+        for b in batches:
+            bb = _to(b, dev)
+            per, logits = model(bb["input_ids"], bb["vis_inputs"], bb["labels"], b["task"])
+            torch.testing.assert_close(logits.float().cpu(), b["logits"], rtol=tol, atol=tol)
+            torch.testing.assert_close(per.float().cpu(), b["per_token"], rtol=tol, atol=tol)
+            loss = TR.task_loss(per.float().cpu(), b["labels"], b["scores"], b["task"])
+            assert abs(float(loss) - b["loss"]) <= tol * max(1.0, abs(b["loss"]))
+    model.train()
+    base_lr, total, warm, clip = [float(x) for x in hp]
+    tr = TR.Trainer(model, cfg, lr=base_lr, clip=clip, total_steps=int(total), warmup_ratio=warm / total)
+    losses = [float(tr.step(_to(batches[i % 3], dev))) for i in range(5)]
+    for a, r in zip(losses, ref_losses):
+        assert abs(a - float(r)) <= 5 * tol * max(1.0, abs(float(r))), (losses, list(ref_losses))
+    cur = dict(model.named_parameters())
+    for n, ref in final.items():
+        err = float((cur[n].detach().float().cpu() - ref).abs().max())
+        assert err <= 20 * tol * max(1e-2, float(ref.abs().max())), (n, err)
+
+
+def test_host_and_trainer_match_reference_vlbart_cpu():
+    from oracle.host_patch import cpu_reference_ops
+    sd, batches, ref_losses, hp, final = _load()
+    model, cfg, names = _build(sd)
+    with cpu_reference_ops():
+        _check(model, cfg, names, batches, ref_losses, hp, final, "cpu", 2e-5)
+
+
+@pytest.mark.gpu
+def test_host_and_trainer_match_reference_vlbart_gpu():
+    sd, batches, ref_losses, hp, final = _load()
+    model, cfg, names = _build(sd)
+    model.cuda()
+    _check(model, cfg, names, batches, ref_losses, hp, final, "cuda", 1e-3)       # fp32 IO tolerance of north_star
