@@ -51,6 +51,13 @@ def cpu_reference_ops():
                                   self.img_order_embedding.weight, self.obj_order_embedding.weight,
                                   img_order_ids, obj_order_ids, rms=self.rms_norm)
 
+    def lora_forward(self, x, task):                                    # K3
+        keep, p = None, self.lora_dropout_p
+        if self.training and p > 0.0:
+            import torch
+            keep = (torch.rand(x.shape) >= p)
+        return O.lora_linear(x, self.weight, self.bias, self.lora_As[task], self.lora_Bs[task], self.scaling, keep, p)
+
     def tail(residual, h, norm, p, training):                           # K5
         return O.bart_sublayer_tail(residual, F.dropout(h, p=p, training=training), norm.weight, norm.bias, norm.eps)
 
@@ -81,13 +88,15 @@ def cpu_reference_ops():
                 O.hf_adamw_step(p.data, p.grad, m, v, self.t, lr, eps=1e-6, weight_decay=wd)
             self.flat.flat.zero_()
 
+    from vlpet_amd.lora.controller import LoRALinearController
     saved = (HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward,
-             TR.CPU_OPTIMIZER_FACTORY)
+             TR.CPU_OPTIMIZER_FACTORY, LoRALinearController.forward)
     HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward = \
         apply_pet, fused, visual, tail, downsample
     TR.CPU_OPTIMIZER_FACTORY = CpuAdamW
+    LoRALinearController.forward = lora_forward
     try:
         yield
     finally:
         (HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward,
-         TR.CPU_OPTIMIZER_FACTORY) = saved
+         TR.CPU_OPTIMIZER_FACTORY, LoRALinearController.forward) = saved

@@ -462,7 +462,10 @@ def golden_downsample(tag, B=2, dim=64, seed=6):
 
 
 # ------------------------------------------------------------------ whole tiny VLBart (host + trainer pin)
-def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7):
+LORA_FLAGS = ["--tasks", "vqa,gqa,nlvr,caption", "--use_lora", "--lora_dim", "8", "--use_single_lora"]   # single_lora.sh:49-56
+
+
+def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7, lora=False):
     """2+2-layer, d=64 ``VLBart`` built from the reference's own classes (src/modeling_bart.py:1458-1530 over
     JointEncoder :690-1010 and my_transformers BartDecoder): state dict, three task batches, eval-mode per-token
     losses + logits (pins the host: [text ; visual] concat order, text-only LayerNorm before the concat, hook
@@ -473,11 +476,16 @@ def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from oracle import vlpet_oracle as O
     mod = load_vl_module("bart")
-    flags = list(VLPET_LARGE_FLAGS) + ["--adapter_down_dim", "8", "--encoder_adapter_multihead_num_head", "4",
-                                       "--adapter_gating_down_dim", "16",
-                                       "--decoder_enc_attn_value_parallel_adapter_down_dim", "8",
-                                       "--downsample", "--n_boxes", "36"]
+    if lora:
+        flags = list(LORA_FLAGS) + ["--downsample", "--n_boxes", "36"]
+    else:
+        flags = list(VLPET_LARGE_FLAGS) + ["--adapter_down_dim", "8", "--encoder_adapter_multihead_num_head", "4",
+                                           "--adapter_gating_down_dim", "16",
+                                           "--decoder_enc_attn_value_parallel_adapter_down_dim", "8",
+                                           "--downsample", "--n_boxes", "36"]
     config, args = make_config("bart", flags, d_model=64, heads=4, ffn=128)
+    if lora:
+        config.lora_config.lora_dropout = 0.0      # LoraConfig's default 0.1 would make the captured steps random
     config.vocab_size = 500
     config.feat_dim = 128
     config.default_obj_order_ids = list(range(400, 500))
@@ -492,8 +500,11 @@ def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7):
     model.lm_head.weight = model.model.shared.weight          # tied, as in the pretrained checkpoints
     # trainable set: TrainerBase.unfreeze_parameters' substring rules (trainer_base.py:308-542) for this flag set
     for n, p in model.named_parameters():
-        p.requires_grad = ("adapter" in n) or ("gating" in n) or ("visual_embedding" in n) or \
-            ("encoder." in n and ("layer_norm" in n or "layernorm" in n))
+        if lora:    # trainer_base.py:339-344: lora matrices and every bias; visual embedding stays trainable (:318-322)
+            p.requires_grad = ("lora" in n) or ("bias" in n) or ("visual_embedding" in n)
+        else:
+            p.requires_grad = ("adapter" in n) or ("gating" in n) or ("visual_embedding" in n) or \
+                ("encoder." in n and ("layer_norm" in n or "layernorm" in n))
     B = 3
     V = 300
 
@@ -588,6 +599,7 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "vlbart":
         golden_vlbart_tiny()
+        golden_vlbart_tiny("vlbart_tiny_lora_d64", seed=8, lora=True)
         return
     # (i) K1 BART, full width and tiny, gate variants
     golden_k1_bart("k1_bart_large_d768_r96", 768, 96, 4, 96, B=2, S=8)
@@ -627,6 +639,7 @@ def main():
     golden_trainable_names()
     golden_downsample("downsample_7to6_d64")
     golden_vlbart_tiny()
+    golden_vlbart_tiny("vlbart_tiny_lora_d64", seed=8, lora=True)
 
 
 if __name__ == "__main__":

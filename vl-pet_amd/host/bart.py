@@ -62,7 +62,7 @@ def vlpet_config(**over) -> SimpleNamespace:
         use_decoder_enc_attn_value_parallel_adapter_down_dim=True, decoder_enc_attn_value_parallel_adapter_down_dim=96,
         use_decoder_enc_attn_value_parallel_adapter_scaling=False,
         decoder_enc_attn_value_parallel_adapter_scaling_factor=1.0,
-        use_lora=False, lora_dim=4, lora_alpha=32, use_single_lora=False, reduction_factor=8,
+        use_lora=False, lora_dim=4, lora_alpha=32, lora_dropout=0.1, use_single_lora=False, reduction_factor=8,
         use_encoder_multihead_up_zero_init=False, use_encoder_gating_large_x_lowrank_up_zero_init=False,
         use_decoder_enc_vpa_up_zero_init=False, freeze_vis_emb=False,
     )
@@ -79,8 +79,8 @@ def vlpet_config(**over) -> SimpleNamespace:
             adapter_down_dim=c.adapter_down_dim)
     else:
         c.adapter_config = None
-    c.lora_config = LoraConfig(lora_dim=c.lora_dim, lora_alpha=c.lora_alpha, tasks=task_list,
-                               use_single_lora=c.use_single_lora) if c.use_lora else None
+    c.lora_config = LoraConfig(lora_dim=c.lora_dim, lora_alpha=c.lora_alpha, lora_dropout=c.lora_dropout,
+                               tasks=task_list, use_single_lora=c.use_single_lora) if c.use_lora else None
     return c
 
 
