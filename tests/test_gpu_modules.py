@@ -191,3 +191,24 @@ def test_tiny_host_model_fused_equals_eager():
     for n, p in model.named_parameters():
         if p.requires_grad:
             ok(p.grad, g_ref[n], n)
+
+
+def test_empty_batches_need_no_launch():
+    """Zero rows (an empty task shard): every op returns an empty result of the right shape and the parameters
+    still receive (zero) gradients -- the reference's op chain behaves the same on an empty batch."""
+    import torch.nn as nn
+    from types import SimpleNamespace
+    from vlpet_amd.encoder_pet import apply_pet, build_pet
+    from vlpet_amd.tail import sublayer_tail
+    from vlpet_amd.adapters import AdapterConfig, AdapterController
+    cfg = SimpleNamespace(use_encoder_adapter_down_multihead=True, encoder_adapter_multihead_num_head=4, adapter_down_dim=8,
+                          use_encoder_adapter_gating_large_x_lowrank=True, adapter_gating_down_dim=16)
+    m = nn.Module(); build_pet(m, cfg, 64, ("attn",)); m.ln = nn.LayerNorm(64); m.cuda()
+    x1 = torch.zeros(0, 7, 64, device="cuda", requires_grad=True)
+    x2 = torch.zeros(0, 7, 64, device="cuda", requires_grad=True)
+    y = apply_pet(m, "attn", x1, x2, cfg)
+    out = sublayer_tail(x1, y, m.ln, 0.1, True)
+    assert out.shape == (0, 7, 64)
+    out.sum().backward()
+    assert m.attn_adapter_multihead_up.weight.grad is not None and float(m.attn_adapter_multihead_up.weight.grad.abs().sum()) == 0.0
+    assert m.ln.weight.grad is not None

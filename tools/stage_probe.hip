@@ -36,6 +36,23 @@ __global__ __launch_bounds__(WAVES * 64) void probe(float* out, int stages, unsi
                 for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[u][c], bk[u], acc[c], 0, 0, 0);
             }
         }
+        if constexpr (MODE & 8) {      // epilogue-like VALU: 32 sigmoids (v_mul, v_exp, v_add, v_rcp) on accumulator values
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float a0 = acc[0][j], a1 = acc[NT - 1][j];
+                acc[0][j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a0 * -1.442695f));
+                acc[NT - 1][j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a1 * -1.442695f));
+            }
+        }
+        if constexpr (MODE & 16) {     // same count of plain VALU (4 v_fma per element) instead of the transcendental pair
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float a0 = acc[0][j], a1 = acc[NT - 1][j];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a0 = __builtin_fmaf(a0, 0.999f, 0.001f); a1 = __builtin_fmaf(a1, 0.999f, 0.001f); }
+                acc[0][j] = a0; acc[NT - 1][j] = a1;
+            }
+        }
         if constexpr (MODE & 4) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -75,6 +92,11 @@ int main() {
         run<8, 3, 2>("8w x 16 ds_read_b128", blocks);
         run<8, 3, 3>("8w x (16 reads + 12 MFMA)", blocks);
         run<8, 3, 7>("8w x (16 reads + 12 MFMA) + barrier", blocks);
+        run<4, 6, 8>("4w x 32 sigmoid only", blocks);
+        run<4, 6, 16>("4w x 128 v_fma only", blocks);
+        run<4, 6, 9>("4w x (24 MFMA + 32 sigmoid)", blocks);
+        run<4, 6, 17>("4w x (24 MFMA + 128 v_fma)", blocks);
+        run<8, 3, 9>("8w x (12 MFMA + 32 sigmoid)", blocks);
     }
     return 0;
 }

@@ -156,6 +156,16 @@ def _grad_like(g32: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
     return g32 if p.dtype == torch.float32 else g32.to(p.dtype)
 
 
+def _empty_result(x: torch.Tensor, params) -> torch.Tensor:
+    """Zero-row input: nothing to launch.  The (empty) result stays connected to every parameter so that
+    their gradients are zeros rather than None, like the reference's op chain on an empty batch."""
+    out = x.clone()
+    for p in params:
+        if p is not None and p.requires_grad:
+            out = out + (p.reshape(-1)[:1].sum() * 0).to(out.dtype)
+    return out
+
+
 def _grad_dest(p: torch.Tensor, shape, block: bool = False):
     """Where a weight-gradient kernel writes: the parameter's slot of the trainer's flat gradient buffer when it
     offers one for this step (train.GradSink: first write of the step, fp32, matching shape) -- then autograd
@@ -270,6 +280,8 @@ def adapter_gate(x1, x2, down_w, down_b, up_w, up_b, gate_params, pk_a: PackedPa
     params = list(down_w) + list(down_b) + [up_w, up_b]
     if gate_mode != GATE_NONE:
         params += list(gate_params)
+    if x2.numel() == 0:
+        return _empty_result(x2, params)
     return _AdapterGateFn.apply(x1, x2, pk_a, pk_g, len(down_w), gate_mode, delta_scale, x2_scale, gate_scale, *params)
 
 
@@ -315,6 +327,8 @@ class _ParallelAdapterFn(torch.autograd.Function):
 
 
 def parallel_adapter(x, y, wd, bd, wu, bu, pk: PackedPair, scale: float = 1.0):
+    if x.numel() == 0:
+        return _empty_result(y, [wd, bd, wu, bu])
     return _ParallelAdapterFn.apply(x, y, pk, scale, wd, bd, wu, bu)
 
 
@@ -365,4 +379,6 @@ class _LoraDeltaFn(torch.autograd.Function):
 
 
 def lora_delta(x, base, lora_a, lora_b, pk: PackedPair, scaling: float, keep=None, keep_scale: float = 1.0):
+    if x.numel() == 0:
+        return _empty_result(base, [lora_a, lora_b])
     return _LoraDeltaFn.apply(x, base, pk, scaling, keep, keep_scale, lora_a, lora_b)

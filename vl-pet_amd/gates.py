@@ -9,6 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from .functional import _empty_result as _empty
 from .functional import _flat, _grad_like, _io_dtype, _need_cuda, _ptr, _stream, _timed
 
 
@@ -126,14 +127,20 @@ def small_gate(x1, h, linear, gating_add=False, gate_scale=1.0):
     """VL-PET-small: ``linear`` = Linear(2d, 1) on cat(x1, h); sigmoid; mean over the sequence."""
     if h.dim() != 3:
         raise ValueError("the small gate averages over the sequence axis: expected [B, S, d]")
+    if h.numel() == 0:
+        return _empty(h, [linear.weight, linear.bias])
     return _RowGateFn.apply(x1, h, linear.weight, linear.bias, True, gating_add, gate_scale)
 
 
 def middle_x_gate(x1, h, linear, gating_add=False, gate_scale=1.0):
     """VL-PET-middleX: ``linear`` = Linear(d, 1) on x1 + h; sigmoid; one scalar per token."""
+    if h.numel() == 0:
+        return _empty(h, [linear.weight, linear.bias])
     return _RowGateFn.apply(x1, h, linear.weight, linear.bias, False, gating_add, gate_scale)
 
 
 def middle_y_gate(h, z, gating_add=False, gate_scale=1.0):
     """VL-PET-middleY: one learnable vector z in R^d (IA3-style)."""
+    if h.numel() == 0:
+        return _empty(h, [z])
     return _VecGateFn.apply(h, z, gating_add, gate_scale)

@@ -88,6 +88,10 @@ def sublayer_tail(x1: torch.Tensor, y: torch.Tensor, norm: Optional[torch.nn.Mod
                   training: bool = False, seed: Optional[int] = None, return_mask: bool = False):
     """``norm(x1 + dropout(y, p))``; ``norm`` is an ``nn.LayerNorm`` (BART) or None (T5: plain residual add)."""
     p_eff = float(p) if training else 0.0
+    if y.numel() == 0:
+        from .functional import _empty_result
+        out = _empty_result(y + x1.to(y.dtype), [] if norm is None else [norm.weight, norm.bias])
+        return (out, torch.empty(y.shape, dtype=torch.uint8, device=y.device)) if return_mask else out
     if seed is None:
         seed = _draw_seed() if p_eff > 0 else 0
     if norm is None:

@@ -93,6 +93,10 @@ class _VisProjFn(torch.autograd.Function):
 
 def visproj(feats, R, linear: torch.nn.Linear, norm: torch.nn.Module, cache: VisProjPackCache, rms: bool):
     """LN(Linear(feats)) (+ R) through the HIP path; `norm` is nn.LayerNorm or the T5 RMS norm."""
+    if feats.numel() == 0:
+        from .functional import _empty_result
+        base = feats.new_zeros(*feats.shape[:-1], linear.weight.shape[0]) if R is None else R.to(feats.dtype)
+        return _empty_result(base, [linear.weight, linear.bias, norm.weight, getattr(norm, "bias", None)])
     io = _io_dtype(feats)
     packed = cache.get(linear.weight, linear.bias, io)
     eps = getattr(norm, "eps", None)
