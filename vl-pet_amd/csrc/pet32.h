@@ -70,6 +70,35 @@ __device__ __forceinline__ void stage_lane_vals4(uint8_t* tile, int trow, int h,
     }
 }
 
+// elements 8e .. 8e+7 of the lane's LW contiguous features (bf16: piece 4h+e; fp32: pieces 4h+2e, 4h+2e+1) -- lets an
+// epilogue walk its 64 bytes in MFMA-fragment-sized steps with 8 live values instead of LW
+template <typename IO>
+__device__ __forceinline__ void tile_lane_vals8(const uint8_t* tile, int trow, int h, int e, float* v) {
+    if constexpr (Geo4<IO>::NS == 1) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(tile_piece(tile, trow, 4 * h + e));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+    } else {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(tile_piece(tile, trow, 4 * h + 2 * e));
+        const f32x4 b = *reinterpret_cast<const f32x4*>(tile_piece(tile, trow, 4 * h + 2 * e + 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+    }
+}
+template <typename IO>
+__device__ __forceinline__ void stage_lane_vals8(uint8_t* tile, int trow, int h, int e, const float* v) {
+    if constexpr (Geo4<IO>::NS == 1) {
+        bf16x8 a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = (__bf16)v[j];
+        *reinterpret_cast<bf16x8*>(const_cast<uint8_t*>(tile_piece(tile, trow, 4 * h + e))) = a;
+    } else {
+        const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f32x4*>(const_cast<uint8_t*>(tile_piece(tile, trow, 4 * h + 2 * e))) = a;
+        *reinterpret_cast<f32x4*>(const_cast<uint8_t*>(tile_piece(tile, trow, 4 * h + 2 * e + 1))) = b;
+    }
+}
+
 // per-lane addressing of the four row-piece instructions of a wave (8 rows x 128 B each)
 struct RowLanes {
     int64_t off[4];     // byte offset of the lane's 16-byte piece inside a row-major [M, d] tensor (stage excluded)

@@ -145,50 +145,30 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         const uint8_t* w = slot_w(s & 1);
         const uint8_t* ta = slot_t0(s % L::NR);
         const uint8_t* tg = slot_t1(s % L::NR);
-        Frag<NS> bA[G::KU], wa[G::KU * RT];
+        // fragments are read where they are used (k-step by k-step): a handful of live fragment registers instead
+        // of a whole stage's worth, which kept this kernel at 512 registers with spills
 #pragma unroll
         for (int u = 0; u < G::KU; ++u) {
-            bA[u] = tile_bfrag4<IO>(ta, trow, h, u);
+            Frag<NS> bA = tile_bfrag4<IO>(ta, trow, h, u);
             if constexpr (DROP) {
                 const uint64_t kp = *reinterpret_cast<const uint64_t*>(a.keep + grow * d + s * G::FE + 16 * u + 8 * h);
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    v[j] = (float)bA[u].p[0][j];
-                    if constexpr (NS == 2) v[j] += (float)bA[u].p[1][j];
+                    v[j] = (float)bA.p[0][j];
+                    if constexpr (NS == 2) v[j] += (float)bA.p[1][j];
                     v[j] = ((kp >> (8 * j)) & 0xff) ? v[j] * a.keep_scale : 0.f;
                 }
-                bA[u] = frag_from_f32<NS>(v);
+                bA = frag_from_f32<NS>(v);
+            }
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct) accA[ct] = mfma_ns<NS>(wfrag<NS>(w, u * RT + ct, lane), bA, accA[ct]);
+            if constexpr (GATE) {
+                const Frag<NS> bG = tile_bfrag4<IO>(tg, trow, h, u);
+#pragma unroll
+                for (int ct = 0; ct < RT; ++ct) accG[ct] = mfma_ns<NS>(wfrag<NS>(w, L::SEG_FR + u * RT + ct, lane), bG, accG[ct]);
             }
         }
-#pragma unroll
-        for (int i = 0; i < G::KU * RT; ++i) wa[i] = wfrag<NS>(w, i, lane);
-        if constexpr (GATE) {
-            Frag<NS> bG[G::KU], wg[G::KU * RT];
-#pragma unroll
-            for (int u = 0; u < G::KU; ++u) bG[u] = tile_bfrag4<IO>(tg, trow, h, u);
-#pragma unroll
-            for (int i = 0; i < G::KU * RT; ++i) wg[i] = wfrag<NS>(w, L::SEG_FR + i, lane);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < G::KU; ++u) {
-#pragma unroll
-                for (int ct = 0; ct < RT; ++ct) accA[ct] = mfma_ns<NS>(wa[u * RT + ct], bA[u], accA[ct]);
-            }
-#pragma unroll
-            for (int u = 0; u < G::KU; ++u) {
-#pragma unroll
-                for (int ct = 0; ct < RT; ++ct) accG[ct] = mfma_ns<NS>(wg[u * RT + ct], bG[u], accG[ct]);
-            }
-        } else {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < G::KU; ++u) {
-#pragma unroll
-                for (int ct = 0; ct < RT; ++ct) accA[ct] = mfma_ns<NS>(wa[u * RT + ct], bA[u], accA[ct]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
         wait_vm(rows_count(s + 2, s));
         __builtin_amdgcn_s_barrier();
     }
@@ -256,47 +236,39 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
                     for (int c = 0; c < 4; ++c) { aA[v][4 * q + c] = ta[c]; aG[v][4 * q + c] = tg[c]; }
                 }
             }
-            {
-                Frag<NS> wa[G::NV * KT], wg[G::NV * KT];
 #pragma unroll
-                for (int i = 0; i < G::NV * KT; ++i) wa[i] = wfrag<NS>(w, i, lane);
+            for (int ks = 0; ks < KT; ++ks) {
 #pragma unroll
-                for (int i = 0; i < G::NV * KT; ++i) wg[i] = wfrag<NS>(w, L::SEG_FR + i, lane);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < KT; ++ks) {
-#pragma unroll
-                    for (int v = 0; v < G::NV; ++v) aG[v] = mfma_ns<NS>(wg[v * KT + ks], zG[ks], aG[v]);
-                }
-#pragma unroll
-                for (int ks = 0; ks < KT; ++ks) {
-#pragma unroll
-                    for (int v = 0; v < G::NV; ++v) aA[v] = mfma_ns<NS>(wa[v * KT + ks], zA[ks], aA[v]);
+                for (int v = 0; v < G::NV; ++v) {
+                    aG[v] = mfma_ns<NS>(wfrag<NS>(w, L::SEG_FR + v * KT + ks, lane), zG[ks], aG[v]);
+                    aA[v] = mfma_ns<NS>(wfrag<NS>(w, v * KT + ks, lane), zA[ks], aA[v]);
                 }
             }
-            float r[G::LW], dyv[G::LW], dh[G::LW], dq[G::LW], dd[G::LW];
-            tile_lane_vals4<IO>(t0, trow, h, r);
-            tile_lane_vals4<IO>(t1, trow, h, dyv);
-#pragma unroll
-            for (int i = 0; i < G::LW; ++i) {
-                const float hv = s2 * r[i] + sd_ * aA[i >> 4][i & 15];
-                const float gt = sigmoid_f(aG[i >> 4][i & 15]);
-                const float dyp = gs * dyv[i];
-                dh[i] = gate_add ? dyp : dyp * gt;
-                const float dg = gate_add ? dyp : dyp * hv;
-                dq[i] = dg * gt * (1.0f - gt);
-                dd[i] = sd_ * dh[i];
-            }
-            // stage dh / dq in place of the res / dy rows of this wave, then whole-line stores
-            stage_lane_vals4<IO>(t0, trow, h, dh);
-            stage_lane_vals4<IO>(t1, trow, h, dq);
-            store_rows4(DH, rl, su * 128, t0, wave, lane);
-            store_rows4(DQ, rl, su * 128, t1, wave, lane);
+            // elementwise backward in fragment-sized steps (8 features): dh / dq are staged in place of the res / dy
+            // rows of this wave and become the B fragments of the feature contraction
 #pragma unroll
             for (int e = 0; e < G::E4; ++e) {
-                dfA[e] = frag_from_f32<NS>(dd + 8 * e);
-                dfG[e] = frag_from_f32<NS>(dq + 8 * e);
+                float r8[8], dy8[8], dh8[8], dq8[8], dd8[8];
+                tile_lane_vals8<IO>(t0, trow, h, e, r8);
+                tile_lane_vals8<IO>(t1, trow, h, e, dy8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = 8 * e + j;
+                    const float hv = s2 * r8[j] + sd_ * aA[i >> 4][i & 15];
+                    const float gt = sigmoid_f(aG[i >> 4][i & 15]);
+                    const float dyp = gs * dy8[j];
+                    dh8[j] = gate_add ? dyp : dyp * gt;
+                    const float dg = gate_add ? dyp : dyp * hv;
+                    dq8[j] = dg * gt * (1.0f - gt);
+                    dd8[j] = sd_ * dh8[j];
+                }
+                stage_lane_vals8<IO>(t0, trow, h, e, dh8);
+                stage_lane_vals8<IO>(t1, trow, h, e, dq8);
+                dfA[e] = frag_from_f32<NS>(dd8);
+                dfG[e] = frag_from_f32<NS>(dq8);
             }
+            store_rows4(DH, rl, su * 128, t0, wave, lane);
+            store_rows4(DQ, rl, su * 128, t1, wave, lane);
             wait_vm(rows_count(s + 2, s) + 2 * rl.n_inst);
             __builtin_amdgcn_s_barrier();
             ++s;
@@ -313,35 +285,14 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < G::E4; ++e) dfA[e] = frag_from_f32<NS>(dyv + 8 * e);
             }
-            {
-                Frag<NS> wa[G::E4 * RT];
 #pragma unroll
-                for (int i = 0; i < G::E4 * RT; ++i) wa[i] = wfrag<NS>(w, i, lane);
-                if constexpr (GATE) {
-                    Frag<NS> wg[G::E4 * RT];
+            for (int e = 0; e < G::E4; ++e) {
 #pragma unroll
-                    for (int i = 0; i < G::E4 * RT; ++i) wg[i] = wfrag<NS>(w, L::SEG_FR + i, lane);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int e = 0; e < G::E4; ++e) {
-#pragma unroll
-                        for (int ct = 0; ct < RT; ++ct) dzA[ct] = mfma_ns<NS>(wa[e * RT + ct], dfA[e], dzA[ct]);
-                    }
-#pragma unroll
-                    for (int e = 0; e < G::E4; ++e) {
-#pragma unroll
-                        for (int ct = 0; ct < RT; ++ct) dzG[ct] = mfma_ns<NS>(wg[e * RT + ct], dfG[e], dzG[ct]);
-                    }
-                } else {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int e = 0; e < G::E4; ++e) {
-#pragma unroll
-                        for (int ct = 0; ct < RT; ++ct) dzA[ct] = mfma_ns<NS>(wa[e * RT + ct], dfA[e], dzA[ct]);
-                    }
+                for (int ct = 0; ct < RT; ++ct) {
+                    dzA[ct] = mfma_ns<NS>(wfrag<NS>(w, e * RT + ct, lane), dfA[e], dzA[ct]);
+                    if constexpr (GATE) dzG[ct] = mfma_ns<NS>(wfrag<NS>(w, L::SEG_FR + e * RT + ct, lane), dfG[e], dzG[ct]);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
             wait_vm(rows_count(s + 2, s));
             __builtin_amdgcn_s_barrier();
             ++s;
@@ -408,36 +359,14 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         f32x16 aA[G::NV], aG[G::NV];
 #pragma unroll
         for (int v = 0; v < G::NV; ++v) { aA[v] = zero16(); aG[v] = zero16(); }
-        {
-            Frag<NS> wa[G::NV * KT];
 #pragma unroll
-            for (int i = 0; i < G::NV * KT; ++i) wa[i] = wfrag<NS>(w, i, lane);
-            if constexpr (GATE) {
-                Frag<NS> wg[G::NV * KT];
+        for (int ks = 0; ks < KT; ++ks) {
 #pragma unroll
-                for (int i = 0; i < G::NV * KT; ++i) wg[i] = wfrag<NS>(w, L::SEG_FR + i, lane);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < KT; ++ks) {
-#pragma unroll
-                    for (int v = 0; v < G::NV; ++v) aA[v] = mfma_ns<NS>(wa[v * KT + ks], dpA[ks], aA[v]);
-                }
-#pragma unroll
-                for (int ks = 0; ks < KT; ++ks) {
-#pragma unroll
-                    for (int v = 0; v < G::NV; ++v) aG[v] = mfma_ns<NS>(wg[v * KT + ks], dpG[ks], aG[v]);
-                }
-            } else {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < KT; ++ks) {
-#pragma unroll
-                    for (int v = 0; v < G::NV; ++v) aA[v] = mfma_ns<NS>(wa[v * KT + ks], dpA[ks], aA[v]);
-                }
+            for (int v = 0; v < G::NV; ++v) {
+                aA[v] = mfma_ns<NS>(wfrag<NS>(w, v * KT + ks, lane), dpA[ks], aA[v]);
+                if constexpr (GATE) aG[v] = mfma_ns<NS>(wfrag<NS>(w, L::SEG_FR + v * KT + ks, lane), dpG[ks], aG[v]);
             }
         }
-        float oa[G::LW], og[G::LW], dhv[G::LW];
-        if constexpr (GATE) tile_lane_vals4<IO>(t0, trow, h, dhv);
         uint64_t kp[4] = {0, 0, 0, 0};
         if constexpr (DROP) {
             const uint8_t* kr = a.keep + grow * d + su * G::FE + G::LW * h;
@@ -445,19 +374,23 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
             for (int c = 0; c < G::LW / 8; ++c) kp[c] = *reinterpret_cast<const uint64_t*>(kr + 8 * c);
         }
 #pragma unroll
-        for (int i = 0; i < G::LW; ++i) {
-            float v = aA[i >> 4][i & 15];
-            if constexpr (GATE) v += s2 * dhv[i];
-            if constexpr (DROP) v = ((kp[i >> 3] >> (8 * (i & 7))) & 0xff) ? v * a.keep_scale : 0.f;
-            oa[i] = v;
-            og[i] = aG[i >> 4][i & 15];
+        for (int e = 0; e < G::E4; ++e) {
+            float oa8[8], og8[8], dh8[8];
+            if constexpr (GATE) tile_lane_vals8<IO>(t0, trow, h, e, dh8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = 8 * e + j;
+                float v = aA[i >> 4][i & 15];
+                if constexpr (GATE) v += s2 * dh8[j];
+                if constexpr (DROP) v = ((kp[i >> 3] >> (8 * (i & 7))) & 0xff) ? v * a.keep_scale : 0.f;
+                oa8[j] = v;
+                if constexpr (GATE) og8[j] = aG[i >> 4][i & 15];
+            }
+            stage_lane_vals8<IO>(t0, trow, h, e, oa8);
+            if constexpr (GATE) stage_lane_vals8<IO>(t1, trow, h, e, og8);
         }
-        stage_lane_vals4<IO>(t0, trow, h, oa);
         store_rows4(dxa, rl, su * 128, t0, wave, lane);
-        if constexpr (GATE) {
-            stage_lane_vals4<IO>(t1, trow, h, og);
-            store_rows4(dxg, rl, su * 128, t1, wave, lane);
-        }
+        if constexpr (GATE) store_rows4(dxg, rl, su * 128, t1, wave, lane);
         wait_vm(rows_count(s + 2, s) + (GATE ? 2 : 1) * rl.n_inst);
         __builtin_amdgcn_s_barrier();
     }
