@@ -59,7 +59,10 @@ def cpu_reference_ops():
         return O.lora_linear(x, self.weight, self.bias, self.lora_As[task], self.lora_Bs[task], self.scaling, keep, p)
 
     def tail(residual, h, norm, p, training):                           # K5
-        return O.bart_sublayer_tail(residual, F.dropout(h, p=p, training=training), norm.weight, norm.bias, norm.eps)
+        hd = F.dropout(h, p=p, training=training)
+        if norm is None:                                                # T5: pre-LN stream, plain residual add
+            return O.t5_sublayer_tail(residual, hd)
+        return O.bart_sublayer_tail(residual, hd, norm.weight, norm.bias, norm.eps)
 
     def downsample(self, inputs_tuple, out_dtype=None):
         hw = tuple(self.output_size)
@@ -89,14 +92,16 @@ def cpu_reference_ops():
             self.flat.flat.zero_()
 
     from vlpet_amd.lora.controller import LoRALinearController
+    import vlpet_amd.host.t5 as HT
     saved = (HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward,
-             TR.CPU_OPTIMIZER_FACTORY, LoRALinearController.forward)
+             TR.CPU_OPTIMIZER_FACTORY, LoRALinearController.forward, HT.apply_pet, HT.sublayer_tail)
     HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward = \
         apply_pet, fused, visual, tail, downsample
     TR.CPU_OPTIMIZER_FACTORY = CpuAdamW
     LoRALinearController.forward = lora_forward
+    HT.apply_pet, HT.sublayer_tail = apply_pet, tail
     try:
         yield
     finally:
         (HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward,
-         TR.CPU_OPTIMIZER_FACTORY, LoRALinearController.forward) = saved
+         TR.CPU_OPTIMIZER_FACTORY, LoRALinearController.forward, HT.apply_pet, HT.sublayer_tail) = saved

@@ -465,7 +465,40 @@ def golden_downsample(tag, B=2, dim=64, seed=6):
 LORA_FLAGS = ["--tasks", "vqa,gqa,nlvr,caption", "--use_lora", "--lora_dim", "8", "--use_single_lora"]   # single_lora.sh:49-56
 
 
-def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7, lora=False):
+def install_t5_runtime_shim():
+    """HF 4.2.1 ``ModuleUtilsMixin`` helpers the reference's T5 stack calls with their old signatures
+    (get_extended_attention_mask(mask, shape, device), get_head_mask, invert_attention_mask), restated on the
+    harness side: additive masks (1 - m) * -10000 (self) / -1e9 (cross, fp32), causal for the decoder."""
+    from transformers import PreTrainedModel
+
+    def gext(self, attention_mask, input_shape, device=None, dtype=None):
+        if attention_mask.dim() == 3:
+            ext = attention_mask[:, None, :, :]
+        elif self.config.is_decoder:
+            b, L = input_shape
+            ids = torch.arange(L, device=attention_mask.device)
+            causal = (ids[None, None, :].repeat(b, L, 1) <= ids[None, :, None]).to(attention_mask.dtype)
+            ext = causal[:, None, :, :] * attention_mask[:, None, None, :]
+        else:
+            ext = attention_mask[:, None, None, :]
+        return (1.0 - ext.to(torch.float32)) * -10000.0
+
+    def inv(self, m):
+        e = m[:, None, None, :] if m.dim() == 2 else m[:, None, :, :]
+        return (1.0 - e.to(torch.float32)) * -1e9
+    PreTrainedModel.get_extended_attention_mask = gext
+    PreTrainedModel.get_head_mask = lambda self, head_mask, n, is_attention_chunked=False: [None] * n
+    PreTrainedModel.invert_attention_mask = inv
+
+
+T5_VLPET_FLAGS = ["--tasks", "vqa,gqa,nlvr,caption", "--use_adapter", "--use_single_adapter", "--no_encoder_adapter",
+                  "--no_decoder_adapter", "--use_adapter_down_dim", "--use_encoder_adapter_down_multihead",
+                  "--unfreeze_encoder_layer_norms", "--use_encoder_adapter_gating_large_x_lowrank",
+                  "--use_decoder_enc_attn_value_parallel_adapter_down_dim",
+                  "--use_encoder_gating_scaling", "--encoder_gating_scaling_factor", "0.3"]   # T5-VL-PET-large.sh:41-59
+
+
+def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7, lora=False, kind="bart"):
     """2+2-layer, d=64 ``VLBart`` built from the reference's own classes (src/modeling_bart.py:1458-1530 over
     JointEncoder :690-1010 and my_transformers BartDecoder): state dict, three task batches, eval-mode per-token
     losses + logits (pins the host: [text ; visual] concat order, text-only LayerNorm before the concat, hook
@@ -475,15 +508,20 @@ def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7, lora=False):
     oracle's restatement (oracle.hf_adamw_step); everything else is reference code."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from oracle import vlpet_oracle as O
-    mod = load_vl_module("bart")
+    mod = load_vl_module(kind)
     if lora:
         flags = list(LORA_FLAGS) + ["--downsample", "--n_boxes", "36"]
     else:
-        flags = list(VLPET_LARGE_FLAGS) + ["--adapter_down_dim", "8", "--encoder_adapter_multihead_num_head", "4",
-                                           "--adapter_gating_down_dim", "16",
-                                           "--decoder_enc_attn_value_parallel_adapter_down_dim", "8",
-                                           "--downsample", "--n_boxes", "36"]
-    config, args = make_config("bart", flags, d_model=64, heads=4, ffn=128)
+        base = VLPET_LARGE_FLAGS if kind == "bart" else T5_VLPET_FLAGS
+        flags = list(base) + ["--adapter_down_dim", "8", "--encoder_adapter_multihead_num_head", "4",
+                              "--adapter_gating_down_dim", "16",
+                              "--decoder_enc_attn_value_parallel_adapter_down_dim", "8",
+                              "--downsample", "--n_boxes", "36"]
+    config, args = make_config(kind, flags, d_model=64, heads=4, ffn=128)
+    if kind == "t5":
+        install_t5_runtime_shim()
+        config.decoder_start_token_id = 0
+        config.pad_token_id = 0
     if lora:
         config.lora_config.lora_dropout = 0.0      # LoraConfig's default 0.1 would make the captured steps random
     config.vocab_size = 500
@@ -494,10 +532,10 @@ def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7, lora=False):
     from transformers import PreTrainedModel
     PreTrainedModel.init_weights = lambda self: self.apply(self._init_weights)
     torch.manual_seed(seed)
-    model = mod.VLBart(config)
+    model = mod.VLBart(config) if kind == "bart" else mod.VLT5(config)
     gen = torch.Generator().manual_seed(seed)
     randomize(model, gen)
-    model.lm_head.weight = model.model.shared.weight          # tied, as in the pretrained checkpoints
+    model.lm_head.weight = model.model.shared.weight if kind == "bart" else model.shared.weight   # tied head
     # trainable set: TrainerBase.unfreeze_parameters' substring rules (trainer_base.py:308-542) for this flag set
     for n, p in model.named_parameters():
         if lora:    # trainer_base.py:339-344: lora matrices and every bias; visual embedding stays trainable (:318-322)
@@ -600,6 +638,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "vlbart":
         golden_vlbart_tiny()
         golden_vlbart_tiny("vlbart_tiny_lora_d64", seed=8, lora=True)
+        golden_vlbart_tiny("vlt5_tiny_d64", seed=9, kind="t5")
         return
     # (i) K1 BART, full width and tiny, gate variants
     golden_k1_bart("k1_bart_large_d768_r96", 768, 96, 4, 96, B=2, S=8)
@@ -640,6 +679,7 @@ def main():
     golden_downsample("downsample_7to6_d64")
     golden_vlbart_tiny()
     golden_vlbart_tiny("vlbart_tiny_lora_d64", seed=8, lora=True)
+    golden_vlbart_tiny("vlt5_tiny_d64", seed=9, kind="t5")
 
 
 if __name__ == "__main__":

@@ -17,7 +17,9 @@ FIXTURES = {"vlpet_large": ("vlbart_tiny_d64", {}),
                                                   use_encoder_adapter_gating_large_x_lowrank=False,
                                                   use_decoder_enc_attn_value_parallel_adapter_down_dim=False,
                                                   unfreeze_encoder_layer_norms=False, use_lora=True, lora_dim=8, lora_dropout=0.0,
-                                                  use_single_lora=True))}
+                                                  use_single_lora=True)),
+            # scripts/image-text/T5-VL-PET-large.sh on the reference's VLT5 (gate scale 0.3, RMS norms, pre-LN tails)
+            "t5": ("vlt5_tiny_d64", None)}
 
 
 def _load(name):
@@ -35,8 +37,19 @@ def _load(name):
 
 
 def _build(sd, over):
-    import vlpet_amd.host.bart as HB
     import vlpet_amd.train as TR
+    if over is None:
+        import vlpet_amd.host.t5 as HT
+        cfg = HT.vlt5_config(d_model=64, d_kv=16, d_ff=128, num_layers=2, num_decoder_layers=2, num_heads=4, vocab_size=500,
+                             feat_dim=128, adapter_down_dim=8, adapter_gating_down_dim=16,
+                             decoder_enc_attn_value_parallel_adapter_down_dim=8, dropout_rate=0.0)
+        model = HT.VLT5(cfg)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not missing, missing
+        # aliases of the shared embedding in the reference's state dict
+        assert set(unexpected) <= {"lm_head.weight", "encoder.embed_tokens.weight", "decoder.embed_tokens.weight"}, unexpected
+        return model, cfg, TR.trainable_names(model, cfg)
+    import vlpet_amd.host.bart as HB
     cfg = HB.vlpet_config(d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
                           decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128, vocab_size=500,
                           max_position_embeddings=64, feat_dim=128, adapter_down_dim=8, adapter_gating_down_dim=16,

@@ -1,0 +1,333 @@
+"""Minimal VL-T5 host (frozen T5 encoder-decoder in plain PyTorch-ROCm: relative-position attention, RMS
+norms, ReLU feed-forward), no HIP code of ours -- the PET arithmetic is delegated to ``encoder_pet.apply_pet``
+(K1, with the T5-only delta / x2 / gate scaling factors), ``adapters.AdapterController`` (K2 on the
+cross-attention value), ``visual.VisualEmbedding`` (K4, RMS-norm form) and ``tail.sublayer_tail`` (K5 without a
+norm: T5 is pre-LN, the tail is ``hidden + dropout(y)``).
+
+Mirrors, with the reference's parameter names (state-dict compatible):
+  my_transformers/modeling_t5.py:288-410 (T5LayerFF + inline adapter/gate), :412-678 (T5Attention incl.
+  ``project_vpa``), :679-827 (T5LayerSelfAttention + inline adapter/gate), :829-894 (T5LayerCrossAttention),
+  :896-1000 (T5Block), :1090-1458 (T5Stack);  src/modeling_t5.py:176-405 (JointEncoder: [text ; visual] order,
+  relative-position bias only inside the text block), :407-700 (VLT5: tied head rescaled by d_model**-0.5).
+"""
+from __future__ import annotations
+
+import copy
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..adapters import AdapterConfig, AdapterController
+from ..encoder_pet import apply_pet, build_pet, has_pet
+from ..visual import Downsample, T5LayerNorm, VisualEmbedding
+from .bart import TASKS, _linear
+
+
+def sublayer_tail(residual, h, norm, p, training):
+    """K5 (T5 form): ``residual + dropout(h)`` -- one fused HIP pass; harnesses swap this attribute for an eager
+    restatement, exactly as for host.bart."""
+    from ..tail import sublayer_tail as _hip_tail
+    return _hip_tail(residual, h, norm, p, training)
+
+
+def vlt5_config(**over) -> SimpleNamespace:
+    """t5-base + scripts/image-text/T5-VL-PET-large.sh (r = r_g = 192, decoder value adapter 96, gate scale 0.3)."""
+    c = SimpleNamespace(
+        d_model=768, d_kv=64, d_ff=3072, num_layers=12, num_decoder_layers=12, num_heads=12,
+        relative_attention_num_buckets=32, dropout_rate=0.1, layer_norm_epsilon=1e-6, vocab_size=32100 + 100,
+        pad_token_id=0, decoder_start_token_id=0, initializer_factor=1.0,
+        feat_dim=2048, pos_dim=4, n_images=2, n_boxes=36, downsample=True, use_vis_order_embedding=True,
+        use_vis_layer_norm=True, individual_vis_layer_norm=True, share_vis_lang_layer_norm=False,
+        tasks=",".join(TASKS), use_adapter=True, use_single_adapter=True, no_encoder_adapter=True,
+        no_decoder_adapter=True, use_adapter_down_dim=True, adapter_down_dim=192,
+        use_encoder_adapter_down_multihead=True, encoder_adapter_multihead_num_head=4,
+        use_encoder_adapter_gating_large_x_lowrank=True, adapter_gating_down_dim=192,
+        use_encoder_adapter_gating_add=False, use_encoder_adapter_gating_small_xy_cat=False,
+        use_encoder_adapter_gating_middle_xy_add=False, use_encoder_adapter_gating_middle_ia3_add=False,
+        use_encoder_gating_scaling=True, encoder_gating_scaling_factor=0.3,
+        use_encoder_adapter_scaling=False, encoder_adapter_scaling_factor=1.0,
+        use_encoder_x2_scaling=False, encoder_x2_scaling_factor=1.0,
+        unfreeze_encoder_layer_norms=True,
+        use_decoder_enc_attn_value_parallel_adapter_down_dim=True, decoder_enc_attn_value_parallel_adapter_down_dim=96,
+        use_decoder_enc_attn_value_parallel_adapter_scaling=False,
+        decoder_enc_attn_value_parallel_adapter_scaling_factor=1.0,
+        use_lora=False, reduction_factor=8,
+        use_encoder_multihead_up_zero_init=True, use_encoder_gating_large_x_lowrank_up_zero_init=True,
+        use_decoder_enc_vpa_up_zero_init=True, freeze_vis_emb=False,
+    )
+    for k, v in over.items():
+        if not hasattr(c, k):
+            raise AttributeError(f"unknown config field {k}")
+        setattr(c, k, v)
+    c.task_list = [t for t in c.tasks.replace(" ", ",").split(",") if t]
+    c.adapter_config = AdapterConfig(
+        tasks=c.task_list, input_dim=c.d_model, d_model=c.d_model, use_single_adapter=c.use_single_adapter,
+        reduction_factor=c.reduction_factor, use_adapter_down_dim=bool(c.use_adapter_down_dim),
+        adapter_down_dim=c.adapter_down_dim)
+    c.lora_config = None
+    return c
+
+
+def relative_position_bucket(relative_position, bidirectional, num_buckets=32, max_distance=128):
+    """T5's log-spaced relative-position buckets (my_transformers/modeling_t5.py:464-507; Mesh-TensorFlow rule)."""
+    buckets = torch.zeros_like(relative_position)
+    if bidirectional:
+        num_buckets //= 2
+        buckets = buckets + (relative_position > 0).long() * num_buckets
+        relative_position = relative_position.abs()
+    else:
+        relative_position = -torch.min(relative_position, torch.zeros_like(relative_position))
+    max_exact = num_buckets // 2
+    small = relative_position < max_exact
+    large = max_exact + (torch.log(relative_position.float() / max_exact) / math.log(max_distance / max_exact)
+                         * (num_buckets - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, num_buckets - 1))
+    return buckets + torch.where(small, relative_position, large)
+
+
+class T5Attention(nn.Module):
+    """softmax(Q K^T + bias) V without the 1/sqrt(d) scale (folded into T5's initialisation); optional
+    value-parallel adapter on the cross-attention value (``project_vpa``, :588-613)."""
+
+    def __init__(self, config, is_decoder, has_relative_attention_bias=False, value_adapter=False):
+        super().__init__()
+        self.is_decoder = is_decoder
+        self.n_heads, self.d_kv = config.num_heads, config.d_kv
+        self.inner = self.n_heads * self.d_kv
+        self.dropout = config.dropout_rate
+        self.num_buckets = config.relative_attention_num_buckets
+        d = config.d_model
+        self.q = nn.Linear(d, self.inner, bias=False)
+        self.k = nn.Linear(d, self.inner, bias=False)
+        self.v = nn.Linear(d, self.inner, bias=False)
+        self.o = nn.Linear(self.inner, d, bias=False)
+        self.attn_value_parallel_adapter = None
+        if value_adapter:
+            ac = copy.deepcopy(config.adapter_config)
+            ac.use_adapter_down_dim = True
+            ac.adapter_down_dim = config.decoder_enc_attn_value_parallel_adapter_down_dim
+            ac.use_parallel_adapter = True
+            if config.use_decoder_enc_attn_value_parallel_adapter_scaling:
+                ac.use_scaling_factor = True
+                ac.scaling_factor = config.decoder_enc_attn_value_parallel_adapter_scaling_factor
+            self.attn_value_parallel_adapter = AdapterController(ac)
+        self.has_relative_attention_bias = has_relative_attention_bias
+        if has_relative_attention_bias:
+            self.relative_attention_bias = nn.Embedding(self.num_buckets, self.n_heads)
+
+    def compute_bias(self, q_len, k_len):
+        dev = self.relative_attention_bias.weight.device
+        ctx = torch.arange(q_len, dtype=torch.long, device=dev)[:, None]
+        mem = torch.arange(k_len, dtype=torch.long, device=dev)[None, :]
+        bucket = relative_position_bucket(mem - ctx, bidirectional=not self.is_decoder, num_buckets=self.num_buckets)
+        return self.relative_attention_bias(bucket).permute(2, 0, 1).unsqueeze(0)        # [1, H, q, k]
+
+    def _shape(self, t, B):
+        return t.view(B, -1, self.n_heads, self.d_kv).transpose(1, 2)
+
+    def forward(self, hidden, bias, kv=None, task=None):
+        B, Lq, _ = hidden.shape
+        src = hidden if kv is None else kv
+        q, k, v = _linear(self.q, hidden), _linear(self.k, src), _linear(self.v, src)
+        if kv is not None and self.attn_value_parallel_adapter is not None:
+            v = self.attn_value_parallel_adapter(src, task, y=v)                          # K2
+        mask = None if bias is None else bias.to(q.dtype)
+        out = F.scaled_dot_product_attention(self._shape(q, B), self._shape(k, B), self._shape(v, B), attn_mask=mask,
+                                             dropout_p=self.dropout if self.training else 0.0, scale=1.0)
+        return _linear(self.o, out.transpose(1, 2).reshape(B, Lq, self.inner))
+
+
+class T5DenseReluDense(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.wi = nn.Linear(config.d_model, config.d_ff, bias=False)
+        self.wo = nn.Linear(config.d_ff, config.d_model, bias=False)
+        self.dropout = config.dropout_rate
+
+    def forward(self, x):
+        h = F.dropout(F.relu(_linear(self.wi, x)), p=self.dropout, training=self.training)
+        return _linear(self.wo, h)
+
+
+class T5LayerSelfAttention(nn.Module):
+    def __init__(self, config, is_decoder, has_relative_attention_bias):
+        super().__init__()
+        self.config, self.is_decoder, self.p = config, is_decoder, config.dropout_rate
+        self.SelfAttention = T5Attention(config, is_decoder, has_relative_attention_bias)
+        self.layer_norm = T5LayerNorm(config.d_model, eps=config.layer_norm_epsilon)
+        if not is_decoder:
+            build_pet(self, config, config.d_model, ("attn",))
+
+    def forward(self, hidden, bias, task=None):
+        y = self.SelfAttention(self.layer_norm(hidden), bias)
+        if not self.is_decoder and has_pet(self, "attn"):
+            y = apply_pet(self, "attn", hidden, y, self.config)                           # K1 (x1 = un-normalised stream)
+        return sublayer_tail(hidden, y, None, self.p, self.training)                      # K5
+
+
+class T5LayerCrossAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.p = config.dropout_rate
+        self.EncDecAttention = T5Attention(config, True, False,
+                                           value_adapter=bool(config.use_decoder_enc_attn_value_parallel_adapter_down_dim))
+        self.layer_norm = T5LayerNorm(config.d_model, eps=config.layer_norm_epsilon)
+
+    def forward(self, hidden, enc, bias, task=None):
+        y = self.EncDecAttention(self.layer_norm(hidden), bias, kv=enc, task=task)
+        return sublayer_tail(hidden, y, None, self.p, self.training)
+
+
+class T5LayerFF(nn.Module):
+    def __init__(self, config, is_decoder):
+        super().__init__()
+        self.config, self.is_decoder, self.p = config, is_decoder, config.dropout_rate
+        self.DenseReluDense = T5DenseReluDense(config)
+        self.layer_norm = T5LayerNorm(config.d_model, eps=config.layer_norm_epsilon)
+        if not is_decoder:
+            build_pet(self, config, config.d_model, ("ff",))
+
+    def forward(self, hidden, task=None):
+        y = self.DenseReluDense(self.layer_norm(hidden))
+        if not self.is_decoder and has_pet(self, "ff"):
+            y = apply_pet(self, "ff", hidden, y, self.config)                             # K1
+        return sublayer_tail(hidden, y, None, self.p, self.training)
+
+
+class T5Block(nn.Module):
+    def __init__(self, config, is_decoder, has_relative_attention_bias):
+        super().__init__()
+        self.is_decoder = is_decoder
+        layers = [T5LayerSelfAttention(config, is_decoder, has_relative_attention_bias)]
+        if is_decoder:
+            layers.append(T5LayerCrossAttention(config))
+        layers.append(T5LayerFF(config, is_decoder))
+        self.layer = nn.ModuleList(layers)
+
+    def forward(self, hidden, self_bias, enc=None, cross_bias=None, task=None):
+        hidden = self.layer[0](hidden, self_bias, task)
+        if self.is_decoder:
+            hidden = self.layer[1](hidden, enc, cross_bias, task)
+        return self.layer[-1](hidden, task)
+
+
+def _pad_bias(mask, dtype):
+    """[B, K] keep-mask -> additive [B, 1, 1, K] (the reference's (1 - mask) * -10000 form)."""
+    return (1.0 - mask[:, None, None, :].to(torch.float32)) * -10000.0
+
+
+class JointEncoder(nn.Module):
+    def __init__(self, config, embed_tokens):
+        super().__init__()
+        self.config = config
+        self.embed_tokens = embed_tokens
+        self.block = nn.ModuleList([T5Block(config, False, i == 0) for i in range(config.num_layers)])
+        self.final_layer_norm = T5LayerNorm(config.d_model, eps=config.layer_norm_epsilon)
+        self.p = config.dropout_rate
+        vcfg = copy.copy(config)
+        self.visual_embedding = VisualEmbedding(vcfg, embed_tokens, rms_norm=True)
+        self.downsample = None
+        if config.downsample:
+            s = int(config.n_boxes ** 0.5)
+            self.downsample = Downsample((s, s))
+
+    def forward(self, input_ids, vis_inputs, attention_mask=None, task=None):
+        B, L = input_ids.shape
+        x = self.embed_tokens(input_ids)
+        if self.downsample is not None:
+            vis_inputs = self.downsample(vis_inputs, out_dtype=x.dtype)
+        elif vis_inputs[0].dtype != x.dtype:
+            vis_inputs = (vis_inputs[0].to(x.dtype),) + tuple(vis_inputs[1:])
+        feats, boxes = vis_inputs[0], vis_inputs[1]
+        img_ids = vis_inputs[2] if len(vis_inputs) >= 3 else None
+        obj_ids = vis_inputs[3] if len(vis_inputs) == 4 else None
+        vis = self.visual_embedding(feats, boxes, img_ids, obj_ids).to(x.dtype)             # K4
+        V = vis.shape[1]
+        x = torch.cat([x, vis], dim=1)
+        if attention_mask is None:
+            attention_mask = input_ids.ne(self.config.pad_token_id)
+        full = torch.cat([attention_mask.to(torch.float32), torch.ones(B, V, device=x.device)], dim=1)
+        # relative position bias only between text positions (src/modeling_t5.py:311-327)
+        text_bias = self.block[0].layer[0].SelfAttention.compute_bias(L, L)
+        bias = text_bias.new_zeros(1, text_bias.shape[1], L + V, L + V)
+        bias[:, :, :L, :L] = text_bias
+        bias = bias + _pad_bias(full, bias.dtype)
+        x = F.dropout(x, p=self.p, training=self.training)
+        for blk in self.block:
+            x = blk(x, bias, task=task)
+        x = F.dropout(self.final_layer_norm(x), p=self.p, training=self.training)
+        return x, full
+
+
+class T5Decoder(nn.Module):
+    def __init__(self, config, embed_tokens):
+        super().__init__()
+        self.config = config
+        self.embed_tokens = embed_tokens
+        self.block = nn.ModuleList([T5Block(config, True, i == 0) for i in range(config.num_decoder_layers)])
+        self.final_layer_norm = T5LayerNorm(config.d_model, eps=config.layer_norm_epsilon)
+        self.p = config.dropout_rate
+
+    def forward(self, input_ids, enc, enc_keep, task=None):
+        B, L = input_ids.shape
+        x = F.dropout(self.embed_tokens(input_ids), p=self.p, training=self.training)
+        causal = torch.tril(torch.ones(L, L, device=x.device))
+        self_bias = self.block[0].layer[0].SelfAttention.compute_bias(L, L) + (1.0 - causal)[None, None] * -10000.0
+        cross_bias = (1.0 - enc_keep[:, None, None, :].to(torch.float32)) * -1e9      # invert_attention_mask (fp32 form)
+        for blk in self.block:
+            x = blk(x, self_bias, enc, cross_bias, task)
+        return F.dropout(self.final_layer_norm(x), p=self.p, training=self.training)
+
+
+def shift_right(labels, pad_id, start_id):
+    """T5PreTrainedModel._shift_right (my_transformers/modeling_t5.py:1068-1087)."""
+    out = labels.new_zeros(labels.shape)
+    out[:, 1:] = labels[:, :-1]
+    out[:, 0] = start_id
+    return out.masked_fill(out == -100, pad_id)
+
+
+class VLT5(nn.Module):
+    """``forward`` returns (per-token loss [B, L], logits) like the reference's ``reduce_loss=False`` path
+    (src/modeling_t5.py:670-700); the LM head is the shared embedding, inputs rescaled by d_model**-0.5."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.shared = nn.Embedding(config.vocab_size, config.d_model)
+        self.encoder = JointEncoder(config, self.shared)
+        self.decoder = T5Decoder(config, self.shared)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        # my_transformers/modeling_t5.py:1026-1066: T5's Mesh-TensorFlow rules for its own layers; adapter / gate
+        # Linears keep the nn.Linear default (no generic branch there)
+        f = self.config.initializer_factor
+        d, dkv, H = self.config.d_model, self.config.d_kv, self.config.num_heads
+        if isinstance(m, T5LayerNorm):
+            m.weight.data.fill_(f * 1.0)
+        elif isinstance(m, VLT5):
+            m.shared.weight.data.normal_(0.0, f * 1.0)
+        elif isinstance(m, T5DenseReluDense):
+            m.wi.weight.data.normal_(0.0, f * d ** -0.5)
+            m.wo.weight.data.normal_(0.0, f * self.config.d_ff ** -0.5)
+        elif isinstance(m, T5Attention):
+            m.q.weight.data.normal_(0.0, f * (d * dkv) ** -0.5)
+            m.k.weight.data.normal_(0.0, f * d ** -0.5)
+            m.v.weight.data.normal_(0.0, f * d ** -0.5)
+            m.o.weight.data.normal_(0.0, f * (H * dkv) ** -0.5)
+            if m.has_relative_attention_bias:
+                m.relative_attention_bias.weight.data.normal_(0.0, f * d ** -0.5)
+
+    def forward(self, input_ids, vis_inputs, labels, task, attention_mask=None):
+        cfg = self.config
+        enc, keep = self.encoder(input_ids, vis_inputs, attention_mask, task)
+        dec_in = shift_right(labels, cfg.pad_token_id, cfg.decoder_start_token_id)
+        h = self.decoder(dec_in, enc, keep, task) * (cfg.d_model ** -0.5)
+        logits = F.linear(h, self.shared.weight.to(h.dtype))
+        loss = F.cross_entropy(logits.float().view(-1, logits.shape[-1]), labels.view(-1), ignore_index=-100,
+                               reduction="none")
+        return loss.view(labels.shape), logits
