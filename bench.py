@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--buckets", type=int, default=3)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to exercise the DP path on a 1-GPU box")
+    ap.add_argument("--model", default="bart", choices=["bart", "t5"],
+                    help="bart = BASELINE configs[1] (the headline line); t5 = configs[2] (T5-base, r = r_g = 192, --batch 300)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,8 +98,13 @@ def main():
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(1234)      # same initial state on every rank: no parameter broadcast needed
-    cfg = HB.vlpet_config()
-    model = HB.VLBart(cfg)
+    if args.model == "t5":
+        import vlpet_amd.host.t5 as HT
+        cfg = HT.vlt5_config()
+        model = HT.VLT5(cfg)
+    else:
+        cfg = HB.vlpet_config()
+        model = HB.VLBart(cfg)
     names = TR.trainable_names(model, cfg)
     n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
     model.to(dev)
@@ -154,21 +161,24 @@ def main():
         dom = "k1_bwd_rows" if "k1_bwd_rows" in agg else "k1_fwd"
         a = agg[dom]
         achieved = per_row[dom] * a["rows"] / a["total_us"] / 1e3     # GB/s
-        roof = dict(bound="hbm", kernel={"k1_bwd_rows": "pet_bwd_kernel<bf16,3,gate>",
-                                         "k1_fwd": "pet_fwd_kernel<bf16,3,gate>"}[dom],
+        tiles = 3 if args.model == "bart" else 6
+        roof = dict(bound="hbm", kernel={"k1_bwd_rows": f"pet_bwd_kernel<{args.dtype},{tiles},gate>",
+                                         "k1_fwd": f"pet_gate_fwd_kernel<{args.dtype},{tiles}>"}[dom],
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                     traffic=(round(PMC_TRAFFIC_BYTES_PER_ROW[dom] * a["rows"] / a["launches"])
-                             if dom in PMC_TRAFFIC_BYTES_PER_ROW and args.dtype == "bf16" else None),
+                             if dom in PMC_TRAFFIC_BYTES_PER_ROW and args.dtype == "bf16" and args.model == "bart" else None),
                     traffic_source="profiles/r01_pmc_traffic_k1_bwd.md (PMC passes at M=28000, scaled by rows per launch)",
                     avg_launch_us=round(a["total_us"] / a["launches"], 2),
                     avg_rows_per_launch=round(a["rows"] / a["launches"], 1),
                     algorithmic_bytes_per_row=per_row[dom])
         out = {
-            "metric": "multitask samples/sec (BART-base, r=96)", "value": round(samples / dt, 2), "unit": "samples/s",
+            "metric": "multitask samples/sec (BART-base, r=96)" if args.model == "bart" else "multitask samples/sec (T5-base, r=192)",
+            "value": round(samples / dt, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: BART-base + VL-PET-large (r=96) image-text multitask, full train step "
-                                   "(fwd+bwd+grad exchange+clip+AdamW), random-init weights",
+            "config": {"workload": ("configs[1]: BART-base + VL-PET-large (r=96)" if args.model == "bart" else
+                                    "configs[2]: T5-base + VL-PET-large (r=192, gate scale 0.3)") +
+                                   " image-text multitask, full train step (fwd+bwd+grad exchange+clip+AdamW), random-init weights",
                        "per_gpu_task_batch": {t: TR.TASK_BATCH[t](args.batch) for t in TASK_ORDER},
                        "enc_rows_per_step": {t: TR.TASK_BATCH[t](args.batch) * (TR.TEXT_LEN[t] + (72 if t == "nlvr" else 36))
                                              for t in TASK_ORDER},
