@@ -58,3 +58,10 @@ def test_fails_loudly_on_cpu_tensor():
     import vlpet_amd.functional as F
     with pytest.raises(RuntimeError):
         F.pack_pair([torch.zeros(8, 64)], [torch.zeros(8)], torch.zeros(64, 8), torch.zeros(64), 1)
+
+
+def test_k1_backward_transpose_read_wgrad_variant(monkeypatch):
+    """The opt-in weight-gradient kernel built on ds_read_b64_tr_b16 (VLPET_WGRAD_TR=1) gives the same gradients."""
+    monkeypatch.setenv("VLPET_WGRAD_TR", "1")
+    C.run_k1(torch.bfloat16, M=1000, d=768, r=96, rg=96, nh=4)
+    C.run_k1(torch.bfloat16, M=333, d=256, r=8, rg=16, nh=4)

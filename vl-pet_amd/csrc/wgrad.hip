@@ -12,6 +12,7 @@
 // by wgrad_finalize (deterministic: no atomics).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 #include "kernels.h"
 
 struct WgradLayout {
@@ -262,6 +263,194 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 fast path: the m-contraction operands come from gfx950's LDS transpose read.
+//
+// Each wave stages its own 32 rows (P: 32 x 64RT bytes, X: 32 x 128 bytes; coalesced 16-byte global loads, one block
+// ahead in registers) into a PRIVATE double-buffered row-major LDS tile -- same-wave LDS accesses are ordered, so the
+// row loop has no barrier.  ds_read_b64_tr_b16 then hands every lane four consecutive ROWS of its own column
+// (measured mapping, tools/tr_probe.hip: within a 16-lane group, out(lane t, elem j) = in(lane 4j + (t >> 2), elem t & 3);
+// with lane s of a group addressing row (s >> 2), columns 4(s & 3).. of a [4 rows x 16 cols] block, lane t receives
+// column t of the four rows), i.e. exactly the 32x32x16 MFMA operand of a contraction over rows: two reads per
+// operand, no identity-MFMA transposes, no fp32 -> bf16 re-conversion, no AGPR shuffling.  Bias gradients (column
+// sums) are one extra MFMA against an all-ones A fragment.
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_operand(const uint8_t* tile, int row_stride, int kb, int cb, int lane) {
+    // operand of k-step rows kb .. kb+15 and columns cb .. cb+31: lane (i = lane & 31, h = lane >> 5) gets rows kb+8h .. +7 of column cb+i
+    const int g = lane >> 4, sl = lane & 15;
+    const uint8_t* p = tile + (size_t)(kb + 8 * (g >> 1) + (sl >> 2)) * row_stride + (cb + 16 * (g & 1) + 4 * (sl & 3)) * 2;
+    typedef __attribute__((address_space(3))) v4s16 lds_v4;
+    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p));
+    const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 4 * row_stride));
+    typedef short v8s16 __attribute__((ext_vector_type(8)));
+    const v8s16 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int RT>
+__global__ __launch_bounds__(VLPET_THREADS) void wgrad_tr_kernel(WgradArgs a) {
+    constexpr int PR = 32 * RT;
+    constexpr int PB = PR * 2;                       // bytes of a P row in the tile
+    constexpr int XB = 128;                          // bytes of an X row (64-column slice)
+    constexpr int NPP = PB * 32 / 16 / 64;           // 16-byte pieces per lane of a 32-row P block (= 2 RT)
+    constexpr int NPR = PB / 16;                     // pieces per P row
+    constexpr int BUF = 32 * (PB + XB);              // one buffer of a wave
+    constexpr int NV = RT * 2 * 16 + RT + 2;         // per-lane values reduced across the 4 waves (as wgrad_kernel)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int jb = blockIdx.z;
+    const uint8_t* P = reinterpret_cast<const uint8_t*>(a.job[jb].P);
+    const uint8_t* X = reinterpret_cast<const uint8_t*>(a.job[jb].X);
+    const int ldp = a.job[jb].ldp, ldx = a.job[jb].ldx, xc = a.job[jb].xcols;
+    const int n0 = blockIdx.x * 64;
+    if (n0 >= xc) return;
+    const int rc = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int64_t r_begin = (int64_t)rc * a.rows_per_chunk;
+    int64_t r_end = r_begin + a.rows_per_chunk;
+    if (r_end > a.M) r_end = a.M;
+    uint8_t* mine = smem + (size_t)wave * 2 * BUF;
+    const bool want_csp = blockIdx.x == 0;
+
+    f32x16 acc[RT][2];
+    f32x16 sx[2], sp[RT];                            // column sums through the all-ones A fragment
+#pragma unroll
+    for (int ct = 0; ct < RT; ++ct) { acc[ct][0] = zero16(); acc[ct][1] = zero16(); sp[ct] = zero16(); }
+    sx[0] = zero16(); sx[1] = zero16();
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    u32x4 rp[NPP], rx[4];
+    auto load_block = [&](int64_t rb) {              // unconditional (rows clamped): exact vmcnt bookkeeping by hipcc
+#pragma unroll
+        for (int i = 0; i < NPP; ++i) {
+            const int q = lane + 64 * i;
+            int64_t row = rb + q / NPR;
+            if (row >= r_end) row = r_end - 1;
+            rp[i] = *reinterpret_cast<const u32x4*>(P + row * ldp * 2 + (q % NPR) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t row = rb + 8 * i + (lane >> 3);
+            if (row >= r_end) row = r_end - 1;
+            rx[i] = *reinterpret_cast<const u32x4*>(X + (row * ldx + n0) * 2 + (lane & 7) * 16);
+        }
+    };
+    auto store_block = [&](int64_t rb, int buf) {    // registers -> the wave's tile; rows past the end become zeros
+        uint8_t* tp = mine + (size_t)buf * BUF;
+        uint8_t* tx = tp + 32 * PB;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NPP; ++i) {
+            const int q = lane + 64 * i;
+            const bool ok = rb + q / NPR < r_end;
+            *reinterpret_cast<u32x4*>(tp + (size_t)q * 16) = ok ? rp[i] : z;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = rb + 8 * i + (lane >> 3) < r_end;
+            *reinterpret_cast<u32x4*>(tx + (size_t)(8 * i + (lane >> 3)) * XB + (lane & 7) * 16) = ok ? rx[i] : z;
+        }
+    };
+
+    int64_t rb = r_begin + 32 * wave;
+    int it = 0;
+    if (rb < r_end) {
+        load_block(rb);
+        store_block(rb, 0);
+        load_block(rb + 128);
+    }
+#pragma unroll 1
+    for (; rb < r_end; rb += 128, ++it) {
+        const uint8_t* tp = mine + (size_t)(it & 1) * BUF;
+        const uint8_t* tx = tp + 32 * PB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bx[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                bx[nt] = tr_operand(tx, XB, 16 * ks, 32 * nt, lane);
+                sx[nt] = mfma32(ones, bx[nt], sx[nt]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct) {
+                const bf16x8 ap = tr_operand(tp, PB, 16 * ks, 32 * ct, lane);
+                acc[ct][0] = mfma32(ap, bx[0], acc[ct][0]);
+                acc[ct][1] = mfma32(ap, bx[1], acc[ct][1]);
+                if (want_csp) sp[ct] = mfma32(ones, ap, sp[ct]);
+            }
+        }
+        // next block: registers (loaded during the previous iteration) -> the other buffer; request the block after it
+        store_block(rb + 128, (it + 1) & 1);
+        load_block(rb + 256);
+    }
+
+    // ---- reduce the four waves (fixed order) and emit this chunk's partial: identical layout to wgrad_kernel
+    float csp[RT], csx[2];
+#pragma unroll
+    for (int ct = 0; ct < RT; ++ct) csp[ct] = h == 0 ? sp[ct][0] : 0.f;       // every row of the ones-product holds the column sum
+    csx[0] = h == 0 ? sx[0][0] : 0.f;
+    csx[1] = h == 0 ? sx[1][0] : 0.f;
+    float* red = reinterpret_cast<float*>(smem);
+    __syncthreads();                                 // the row tiles are dead: the reduction buffer aliases them
+    if (wave > 0) {
+        float* dst = red + (size_t)(wave - 1) * NV * 64;
+        int k = 0;
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dst[(k++) * 64 + lane] = acc[ct][nt][i];
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct) dst[(k++) * 64 + lane] = csp[ct];
+        dst[(k++) * 64 + lane] = csx[0];
+        dst[(k++) * 64 + lane] = csx[1];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 0; w < 3; ++w) {
+            const float* src = red + (size_t)w * NV * 64;
+            int k = 0;
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[ct][nt][i] += src[(k++) * 64 + lane];
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct) csp[ct] += src[(k++) * 64 + lane];
+            csx[0] += src[(k++) * 64 + lane];
+            csx[1] += src[(k++) * 64 + lane];
+        }
+        const WgradLayout L = wgrad_layout(a);
+        float* part = a.partial + L.off[jb];
+        float* tile = part + (int64_t)rc * PR * xc;
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int crow = 32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    tile[(int64_t)crow * xc + n0 + 32 * nt + m] = acc[ct][nt][i];
+                }
+        float* psx = part + (int64_t)a.row_chunks * PR * xc + (int64_t)rc * xc;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            if (h == 0) psx[n0 + 32 * nt + m] = csx[nt];
+        if (blockIdx.x == 0) {
+            float* psp = part + (int64_t)a.row_chunks * PR * xc + (int64_t)a.row_chunks * xc + (int64_t)rc * PR;
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct)
+                if (h == 0) psp[32 * ct + m] = csp[ct];
+        }
+    }
+}
+
 // sum the row-chunk partials, apply the scale, drop the rank padding, write in the parameter's layout.
 // Threads run along n (the contiguous axis of the partials) so the reads are coalesced.
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(WgradArgs a) {
@@ -301,16 +490,40 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(WgradArgs a) {
 template <typename IO, int RT>
 static hipError_t launch_one(const WgradArgs& a, hipStream_t stream) {
     constexpr int NV = RT * 2 * 16 + RT + 2;
-    const size_t lds = (size_t)3 * NV * 64 * sizeof(float);
-    auto kern = wgrad_kernel<IO, RT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
     int xmax = 0, rmax = 0;
+    bool plain = true;                       // no dropout mask on X, 16-byte aligned rows: the transpose-read path applies
     for (int j = 0; j < a.njobs; ++j) {
         if (a.job[j].xcols > xmax) xmax = a.job[j].xcols;
         if (a.job[j].out_rows > rmax) rmax = a.job[j].out_rows;
+        if (a.job[j].keep != nullptr || a.job[j].ldp % 8 != 0 || a.job[j].ldx % 8 != 0) plain = false;
     }
+    // opt-in (VLPET_WGRAD_TR=1): same time as the identity-transpose kernel at M = 28k (89 vs 87 us) -- both are bound by
+    // the re-read of P per 64-column slice (L2 hit rate 24 %), not by the operand construction; kept as the base of the
+    // P-resident redesign
+    const char* tr_env = getenv("VLPET_WGRAD_TR");
+    const bool use_tr = tr_env != nullptr && atoi(tr_env) != 0;
+    hipError_t e;
+    if constexpr (std::is_same<IO, __bf16>::value && RT <= 3) {
+        if (plain && use_tr) {
+            const size_t tiles = (size_t)4 * 2 * 32 * (64 * RT + 128);
+            const size_t redb = (size_t)3 * NV * 64 * sizeof(float);
+            const size_t lds = tiles > redb ? tiles : redb;
+            auto kern = wgrad_tr_kernel<RT>;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(xmax / 64, a.row_chunks, a.njobs), dim3(VLPET_THREADS), lds, stream, a);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            const int64_t elems = (int64_t)rmax * xmax + xmax + rmax;
+            hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)((elems + 255) / 256), a.njobs), dim3(256), 0, stream, a);
+            return hipGetLastError();
+        }
+    }
+    const size_t lds = (size_t)3 * NV * 64 * sizeof(float);
+    auto kern = wgrad_kernel<IO, RT>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(xmax / 64, a.row_chunks, a.njobs), dim3(VLPET_THREADS), lds, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
