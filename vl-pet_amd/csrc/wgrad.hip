@@ -315,13 +315,16 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_tr_kernel(WgradArgs a) {
     const bool want_csp = blockIdx.x == 0;
 
     f32x16 acc[RT][2];
-    f32x16 sx[2], sp[RT];                            // column sums through the all-ones A fragment
+    // column sums: A fragment "row t all ones" puts sum_k B[k][j] into row t of ONE accumulator, so the RT P tiles
+    // (and the two X tiles) share a single f32x16 each: D[t][j] -- lane (j, h = 0), register t
+    f32x16 sx = zero16(), sp = zero16();
 #pragma unroll
-    for (int ct = 0; ct < RT; ++ct) { acc[ct][0] = zero16(); acc[ct][1] = zero16(); sp[ct] = zero16(); }
-    sx[0] = zero16(); sx[1] = zero16();
-    bf16x8 ones;
+    for (int ct = 0; ct < RT; ++ct) { acc[ct][0] = zero16(); acc[ct][1] = zero16(); }
+    bf16x8 erow[RT > 2 ? RT : 2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    for (int t = 0; t < (RT > 2 ? RT : 2); ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) erow[t][j] = (m == t) ? (__bf16)1.0f : (__bf16)0.0f;
 
     u32x4 rp[NPP], rx[4];
     auto load_block = [&](int64_t rb) {              // unconditional (rows clamped): exact vmcnt bookkeeping by hipcc
@@ -373,14 +376,14 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_tr_kernel(WgradArgs a) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 bx[nt] = tr_operand(tx, XB, 16 * ks, 32 * nt, lane);
-                sx[nt] = mfma32(ones, bx[nt], sx[nt]);
+                sx = mfma32(erow[nt], bx[nt], sx);
             }
 #pragma unroll
             for (int ct = 0; ct < RT; ++ct) {
                 const bf16x8 ap = tr_operand(tp, PB, 16 * ks, 32 * ct, lane);
                 acc[ct][0] = mfma32(ap, bx[0], acc[ct][0]);
                 acc[ct][1] = mfma32(ap, bx[1], acc[ct][1]);
-                if (want_csp) sp[ct] = mfma32(ones, ap, sp[ct]);
+                if (want_csp) sp = mfma32(erow[ct], ap, sp);
             }
         }
         // next block: registers (loaded during the previous iteration) -> the other buffer; request the block after it
@@ -391,9 +394,9 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_tr_kernel(WgradArgs a) {
     // ---- reduce the four waves (fixed order) and emit this chunk's partial: identical layout to wgrad_kernel
     float csp[RT], csx[2];
 #pragma unroll
-    for (int ct = 0; ct < RT; ++ct) csp[ct] = h == 0 ? sp[ct][0] : 0.f;       // every row of the ones-product holds the column sum
-    csx[0] = h == 0 ? sx[0][0] : 0.f;
-    csx[1] = h == 0 ? sx[1][0] : 0.f;
+    for (int ct = 0; ct < RT; ++ct) csp[ct] = h == 0 ? sp[ct] : 0.f;          // row ct of the shared accumulator
+    csx[0] = h == 0 ? sx[0] : 0.f;
+    csx[1] = h == 0 ? sx[1] : 0.f;
     float* red = reinterpret_cast<float*>(smem);
     __syncthreads();                                 // the row tiles are dead: the reduction buffer aliases them
     if (wave > 0) {
