@@ -103,6 +103,10 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
         return 0;
     };
 
+    auto stamp = [&](int k) {      // debug timestamps (VLPET_DBG & 16; lane 0 of the first chain-A wave of every block)
+        if ((a.dbg & 16) && tid == 0 && blockIdx.x < 4096) a.dbg_ts[blockIdx.x * 8 + k] = __builtin_readcyclecounter();
+    };
+    stamp(0);
     issue_w(0);
     glds_rows4(xin, rl, 0, slot_d(0), rg);
     if (S > 1) glds_rows4(xin, rl, 128, slot_d(1), rg);
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
         for (int i = tid; i < nb; i += NW * 64) { sb[i] = ba[i]; sb[nb + i] = bg[i]; }
     }
     __syncthreads();
+    stamp(1);
 
     // ---- down projection of this wave's chain: register 8*sh + j of c-tile ct <-> c = 32ct + 16sh + 8h + j
     f32x16 acc[RT];
@@ -119,6 +124,7 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
     for (int ct = 0; ct < RT; ++ct) acc[ct] = zero16();
     int t = 0;
     for (; t < S; ++t) {
+        if (t == 5) stamp(5);
         issue_w(t + 1);
         const int nrows = issue_rows(t);
         const uint8_t* w = slot_w(t & 1) + (isA ? 0 : L::SEG_KB * 1024);
@@ -129,9 +135,12 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
 #pragma unroll
             for (int ct = 0; ct < RT; ++ct) acc[ct] = mfma_ns<NS>(wfrag<NS>(w, u * RT + ct, lane), b, acc[ct]);
         }
+        if (t == 5) stamp(6);
         wait_vm(nrows);
         __builtin_amdgcn_s_barrier();
+        if (t == 5) stamp(7);
     }
+    stamp(2);
 
     // ---- bias + gelu_new -> B fragments of the up projection (k-step 2ct+sh holds c = 32ct+16sh+8h+j)
     Frag<NS> z[KT];
@@ -149,6 +158,7 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
         }
     }
 
+    stamp(3);
     // ---- up phase
     const float* bu = sb + (isA ? 0 : nb) + 32 * RT + G::LW * h;
     const float gs = a.gs;
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
         wait_vm(n_after);
         __builtin_amdgcn_s_barrier();
     }
+    stamp(4);
 }
 
 template <typename IO, int RT, bool GATE_ADD, int RG>
