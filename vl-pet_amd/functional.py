@@ -42,6 +42,12 @@ class KernelTimer:
 
 TIMER: Optional[KernelTimer] = None
 
+# Side stream for the weight-gradient half of the K1 backward (set by train.Trainer).  The row-parallel half stays
+# on the autograd stream -- the next backward op needs dx1 / dx2 -- while the column-parallel weight gradients, which
+# nobody reads before the optimizer step, run concurrently with the frozen backward that follows.  Only used when
+# every weight gradient of the call goes straight into the trainer's flat buffer (train.GradSink).
+WGRAD_STREAM: Optional["torch.cuda.Stream"] = None
+
 
 def _timed(name, rows, fn):
     if TIMER is None:
@@ -243,7 +249,18 @@ class _AdapterGateFn(torch.autograd.Function):
                 dwd.data_ptr(), dbd.data_ptr(), dwu.data_ptr(), dbu.data_ptr(),
                 _ptr(dwgd), _ptr(dbgd), _ptr(dwgu), _ptr(dbgu), r, rg,
                 ws.data_ptr(), nws, M, d, pk_a.tiles, gate_mode, sd, s2, gs, io, _stream())
-        if TIMER is None:
+        sinks = [s_wd, s_bd, s_wu, s_bu] + ([s_gd, s_gdb, s_gu, s_gub] if gate else [])
+        side = WGRAD_STREAM if all(s is not None for s in sinks) else None
+        if side is not None:
+            rc = _timed("k1_bwd_rows", M, lambda: lib.vlpet_adapter_gate_bwd_phase(1, *args))
+            if rc == 0:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    sargs = args[:-1] + (_stream(),)
+                    rc = _timed("k1_bwd_wgrad", M, lambda: lib.vlpet_adapter_gate_bwd_phase(2, *sargs))
+                for t in (x1f, x2f, dyf, ws, pk_a.buf) + ((pk_g.buf,) if gate else ()):
+                    t.record_stream(side)        # the caching allocator must not recycle them under the side stream
+        elif TIMER is None:
             rc = lib.vlpet_adapter_gate_bwd(*args)
         else:       # same work, the two halves bracketed separately
             rc = TIMER.bracket("k1_bwd_rows", M, lambda: lib.vlpet_adapter_gate_bwd_phase(1, *args))

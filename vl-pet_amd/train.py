@@ -282,12 +282,21 @@ class FlatGrads:
 
     def _launch(self, b):
         a, e = self.buckets[b]
+        self._join_side_stream()
         self._handles.append(dist.all_reduce(self.flat[a:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _join_side_stream(self):
+        """Weight gradients written on the side stream (functional.WGRAD_STREAM) must be visible to whatever reads
+        the flat buffer next (a bucket all-reduce, the optimizer)."""
+        from . import functional as VF
+        if VF.WGRAD_STREAM is not None and self.flat.is_cuda:
+            torch.cuda.current_stream().wait_stream(VF.WGRAD_STREAM)
 
     def finish(self, average: bool = True):
         """Wait for the bucket all-reduces (launching any bucket whose parameters did not all receive a
         gradient this step -- per-task adapters / LoRA leave other tasks' grads at zero) and average
         (``average=False``: the caller folds 1/world_size into its optimizer kernel)."""
+        self._join_side_stream()
         if self.world_size > 1:
             for b in range(len(self.buckets)):
                 if self._pending[b] < self.bucket_count[b]:
@@ -381,9 +390,12 @@ class Trainer:
     clip, AdamW, scheduler -- multitask.py:217-342."""
 
     def __init__(self, model: nn.Module, config, lr=1e-3, clip=5.0, total_steps=1000, warmup_ratio=0.1,
-                 world_size=1, n_buckets=3, process_group=None):
+                 world_size=1, n_buckets=3, process_group=None, overlap_wgrad=True):
         self.model, self.config, self.clip, self.base_lr = model, config, clip, lr
         on_gpu = next(model.parameters()).is_cuda
+        if on_gpu:
+            from . import functional as VF
+            VF.WGRAD_STREAM = torch.cuda.Stream() if overlap_wgrad else None
         self.flat = FlatGrads(model, world_size, n_buckets, process_group, flatten_params=True, sinks=on_gpu)
         if on_gpu:
             self.optim = FusedAdamW(self.flat, lr=lr, max_norm=clip)
