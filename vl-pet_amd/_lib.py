@@ -74,6 +74,13 @@ def load():
         raise RuntimeError(
             f"vl-pet_amd: HIP library not found at {LIB_PATH}; run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` (there is no CPU fallback for the PET hot path)")
+    # The library shares torch's HIP runtime (same libamdhip64 SONAME).  Loading it registers its code objects,
+    # which initialises the runtime; if that happens BEFORE torch has initialised its device context, later launches
+    # from this library fail with hipErrorNoDevice (seen with build() followed by smoke() in one process).
+    # So: let torch bring the device up first whenever a GPU is present.
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
