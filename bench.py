@@ -149,8 +149,9 @@ def main():
         d = cfg.d_model
         agg = timer.summary()
         # algorithmic bytes per row: fwd reads x1, x2, writes y; bwd rows reads dy, x1, x2, writes dx1, dx2
+        # K5 tail: fwd reads y, x1, writes out; bwd reads dout, writes dx1, dy (the saved pre-norm sum is extra traffic)
         per_row = {"k1_fwd": 3 * d * esz, "k1_bwd_rows": 5 * d * esz, "k1_bwd_wgrad": 0, "k2_fwd": 3 * d * esz,
-                   "k2_bwd": 3 * d * esz}
+                   "k2_bwd": 3 * d * esz, "k5_fwd": 3 * d * esz, "k5_bwd": 3 * d * esz}
         kernels = {}
         for name, a in agg.items():
             by = per_row.get(name, 0) * a["rows"]
