@@ -455,39 +455,75 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_tr_kernel(WgradArgs a) {
 }
 
 // sum the row-chunk partials, apply the scale, drop the rank padding, write in the parameter's layout.
-// Threads run along n (the contiguous axis of the partials) so the reads are coalesced.
+// A block owns a [32 c x 64 n] tile: reads run along n (the contiguous axis of the partials, 8 independent sums per
+// thread in flight), writes are contiguous in the OUTPUT layout -- along n for [r, d] gradients, and through an LDS
+// transpose along c for the transposed [d, r] ones (a direct store there scatters 4-byte writes r*4 bytes apart and
+// cost 32 us per launch).  The last blocks of a job sum the bias-gradient partials.
+__host__ __device__ inline int finalize_tiles(int PR, int xcols) { return (PR / 32) * (xcols / 64); }
+
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(WgradArgs a) {
+    __shared__ float tile[32][65];
     const WgradJob& J = a.job[blockIdx.y];
     const int PR = 32 * a.RT;
     const WgradLayout L = wgrad_layout(a);
     const float* part = a.partial + L.off[blockIdx.y];
     const int xc = J.xcols, R = J.out_rows, RC = a.row_chunks;
-    const int64_t nmat = (int64_t)R * xc;
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < nmat) {
-        const int c = (int)(gid / xc), n = (int)(gid % xc);
-        float s = 0.f;
-        for (int rc = 0; rc < RC; ++rc) s += part[((int64_t)rc * PR + c) * xc + n];
-        s *= J.scale;
-        if (J.transposed) J.out[(int64_t)n * J.ldo + c] = s;
-        else J.out[(int64_t)c * J.ldo + n] = s;
-    } else if (gid < nmat + xc) {
-        if (J.colsum_x != nullptr) {
-            const int n = (int)(gid - nmat);
-            const float* p = part + (int64_t)RC * PR * xc;
-            float s = 0.f;
-            for (int rc = 0; rc < RC; ++rc) s += p[(int64_t)rc * xc + n];
-            J.colsum_x[n] = s * J.scale;
+    const int ntile = finalize_tiles(PR, xc);
+    const int t = threadIdx.x;
+    if ((int)blockIdx.x < ntile) {
+        const int c0 = 32 * ((int)blockIdx.x / (xc / 64)), n0 = 64 * ((int)blockIdx.x % (xc / 64));
+        float s[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = 0.f;
+        for (int rc = 0; rc < RC; ++rc) {
+            const float* p = part + ((int64_t)rc * PR + c0) * xc + n0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = t + 256 * k;                       // cc = e / 64, nn = e % 64
+                s[k] += p[(int64_t)(e >> 6) * xc + (e & 63)];
+            }
         }
-    } else if (gid < nmat + xc + R) {
+        if (!J.transposed) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = t + 256 * k, cc = e >> 6, nn = e & 63;
+                if (c0 + cc < R) J.out[(int64_t)(c0 + cc) * J.ldo + n0 + nn] = s[k] * J.scale;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int e = t + 256 * k; tile[e >> 6][e & 63] = s[k] * J.scale; }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = t + 256 * k, nn = e >> 5, cc = e & 31;      // c fastest: contiguous in out[n * ldo + c]
+                if (c0 + cc < R) J.out[(int64_t)(n0 + nn) * J.ldo + c0 + cc] = tile[cc][nn];
+            }
+        }
+        return;
+    }
+    const int64_t gid = (int64_t)((int)blockIdx.x - ntile) * 256 + t;
+    if (gid < xc) {
+        if (J.colsum_x != nullptr) {
+            const float* p = part + (int64_t)RC * PR * xc;
+            float sum = 0.f;
+            for (int rc = 0; rc < RC; ++rc) sum += p[(int64_t)rc * xc + gid];
+            J.colsum_x[gid] = sum * J.scale;
+        }
+    } else if (gid < xc + R) {
         if (J.colsum_p != nullptr) {
-            const int c = (int)(gid - nmat - xc);
+            const int c = (int)(gid - xc);
             const float* p = part + (int64_t)RC * PR * xc + (int64_t)RC * xc;
-            float s = 0.f;
-            for (int rc = 0; rc < RC; ++rc) s += p[(int64_t)rc * PR + c];
-            J.colsum_p[c] = s;
+            float sum = 0.f;
+            for (int rc = 0; rc < RC; ++rc) sum += p[(int64_t)rc * PR + c];
+            J.colsum_p[c] = sum;
         }
     }
+}
+
+static hipError_t launch_finalize(const WgradArgs& a, int RT, int xmax, int rmax, hipStream_t stream) {
+    const int blocks = finalize_tiles(32 * RT, xmax) + (xmax + rmax + 255) / 256;   // tiles of every job fit: xcols <= xmax
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)blocks, a.njobs), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 template <typename IO, int RT>
@@ -517,9 +553,7 @@ static hipError_t launch_one(const WgradArgs& a, hipStream_t stream) {
             hipLaunchKernelGGL(kern, dim3(xmax / 64, a.row_chunks, a.njobs), dim3(VLPET_THREADS), lds, stream, a);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
-            const int64_t elems = (int64_t)rmax * xmax + xmax + rmax;
-            hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)((elems + 255) / 256), a.njobs), dim3(256), 0, stream, a);
-            return hipGetLastError();
+            return launch_finalize(a, RT, xmax, rmax, stream);
         }
     }
     const size_t lds = (size_t)3 * NV * 64 * sizeof(float);
@@ -530,9 +564,7 @@ static hipError_t launch_one(const WgradArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(xmax / 64, a.row_chunks, a.njobs), dim3(VLPET_THREADS), lds, stream, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const int64_t elems = (int64_t)rmax * xmax + xmax + rmax;
-    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)((elems + 255) / 256), a.njobs), dim3(256), 0, stream, a);
-    return hipGetLastError();
+    return launch_finalize(a, RT, xmax, rmax, stream);
 }
 
 template <typename IO>
