@@ -64,3 +64,82 @@ def test_two_ranks_equal_one_rank(tmp_path):
     torch.testing.assert_close(got["flat"], fg.flat, rtol=1e-5, atol=1e-6)
     for a, b in zip(got["params"], fg.params):
         torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
+
+
+# ---- the direct-write gradient sinks (train.GradSink) under data parallelism ---------------------------------------
+class _SinkLinearFn(torch.autograd.Function):
+    """Stands in for the HIP weight-gradient kernels: writes dW / db straight into the parameter's slot of the flat
+    buffer when the trainer offers one (first write of the step) and returns None to autograd, exactly like
+    functional._grad_dest / _finish do around the real kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w, b)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        import vlpet_amd.functional as VF
+        x, w, b = ctx.saved_tensors
+        (dw, sw), (db, sb) = VF._grad_dest(w, w.shape), VF._grad_dest(b, b.shape)
+        dw.copy_(dy.t() @ x)
+        db.copy_(dy.sum(0))
+        gw, gb = VF._finish([(dw, sw, w), (db, sb, b)])
+        return dy @ w, gw, gb
+
+
+class _SinkNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(11)
+        self.a = torch.nn.Linear(16, 24)      # gradients through the sinks
+        self.mid = torch.nn.Linear(24, 24)    # ordinary autograd accumulation (post-accumulate hooks)
+        self.b = torch.nn.Linear(24, 4)       # sinks again; used TWICE per step -> second use must fall back to autograd
+
+    def forward(self, x):
+        h = torch.tanh(_SinkLinearFn.apply(x, self.a.weight, self.a.bias))
+        h = torch.tanh(self.mid(h))
+        return _SinkLinearFn.apply(h, self.b.weight, self.b.bias) + 0.5 * _SinkLinearFn.apply(h * h, self.b.weight, self.b.bias)
+
+
+def _sink_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _SinkNet()
+    fg = TR.FlatGrads(m, world_size=world, n_buckets=3, flatten_params=True, sinks=True)
+    x, y = _data()
+    xs, ys = x.chunk(world)[rank], y.chunk(world)[rank]
+    launches = []
+    orig = fg._launch
+    fg._launch = lambda b: (launches.append(b), orig(b))[1]
+    res = []
+    for _ in range(2):
+        fg.begin_step(zero=True)
+        ((m(xs) - ys) ** 2).mean().backward()
+        fg.finish(average=True)
+        res.append(fg.flat.clone())
+    if rank == 0:
+        taken = sum(1 for p in fg.params for s in (getattr(p, "_vlpet_sink", None),) if s is not None and s.epoch == fg.epoch)
+        torch.save(dict(flats=res, launches=launches, taken=taken, nb=len(fg.buckets)), out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gradient_sinks_under_data_parallel(tmp_path):
+    """Two gloo ranks with half the batch each: gradients written through the sinks, accumulated by autograd, and a
+    twice-used parameter (second use falls back to autograd accumulation) all arrive averaged in the flat buffer;
+    every bucket is all-reduced exactly once per step."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "sink.pt")
+    mp.spawn(_sink_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["taken"] == 4                                   # a.weight, a.bias, b.weight, b.bias took the direct path
+    assert sorted(got["launches"]) == sorted(list(range(got["nb"])) * 2)
+    # one rank, whole batch, plain autograd
+    m = _SinkNet()
+    x, y = _data()
+    ref = TR.FlatGrads(m, world_size=1, sinks=False)
+    ref.begin_step(zero=True)
+    ((m(x) - y) ** 2).mean().backward()
+    for f in got["flats"]:
+        torch.testing.assert_close(f, ref.flat, rtol=1e-5, atol=1e-6)
