@@ -17,6 +17,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "rowops.h"
+#include <cstdlib>
 
 __device__ __forceinline__ void philox7(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t* o) {
     uint32_t c2 = 0x5bd1e995u, c3 = 0x2545f491u;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
 
 int tail_blocks(int64_t M) {
     const int64_t need = (M + TAIL_WAVES - 1) / TAIL_WAVES;
-    const int64_t cap = 256 * 8;             // 8 workgroups of 4 waves per CU
+    static const int64_t cap = [] { const char* e = getenv("VLPET_TAIL_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)(256 * 4); }();   // 4 workgroups of 4 waves per CU (best of 512 / 1024 / 2048; halves the partial sums)
     return (int)(need < cap ? need : cap);
 }
 
