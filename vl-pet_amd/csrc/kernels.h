@@ -84,6 +84,7 @@ struct WgradArgs {
     int row_chunks;        // RC
     int64_t rows_per_chunk;  // multiple of 128
     float* partial;        // workspace, see wgrad_workspace_bytes
+    int nslice;            // 64-column slices of the widest job (set by the launcher)
 };
 size_t wgrad_workspace_bytes(int njobs, int RT, int xcols_max, int row_chunks);
 void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* rows_per_chunk);

@@ -50,6 +50,26 @@ void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* r
     *rows_per_chunk = per * 128;
 }
 
+// XCD-aware workgroup numbering.  The slices of one (row chunk, job) group all read the same P rows, and consecutive
+// workgroup ids are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8, each with its own L2): with the natural
+// (slice, chunk, job) grid the 12 slices of a group land on 8 different L2s and P is fetched 8 times over (measured L2 hit
+// rate 24 %).  Here a 1-D grid is decoded so that all slices of a group share b % 8.
+struct WgId { int slice, rc, job; bool ok; };
+__device__ __forceinline__ WgId wg_decode(const WgradArgs& a, int nslice) {
+    const int b = blockIdx.x, xcd = b & 7, k = b >> 3;
+    WgId w;
+    w.slice = k % nslice;
+    const int g = (k / nslice) * 8 + xcd;
+    w.ok = g < a.row_chunks * a.njobs;
+    w.rc = g % a.row_chunks;
+    w.job = g / a.row_chunks;
+    return w;
+}
+static inline unsigned wg_grid(const WgradArgs& a, int nslice) {
+    const int groups = a.row_chunks * a.njobs;
+    return 8u * (unsigned)nslice * (unsigned)((groups + 7) / 8);
+}
+
 // 8 contiguous IO elements, unconverted (what a prefetched load holds)
 template <typename IO> struct Raw8;
 template <> struct Raw8<__bf16> { bf16x8 v; };
@@ -118,15 +138,18 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* red = reinterpret_cast<float*>(smem);
 
-    const int jb = blockIdx.z;
+    const WgId wg = wg_decode(a, a.nslice);
+    if (!wg.ok) return;                         // uniform per block, before any barrier
+    const int jb = wg.job;
     const IO* P = reinterpret_cast<const IO*>(a.job[jb].P);
     const IO* X = reinterpret_cast<const IO*>(a.job[jb].X);
     const uint8_t* keep = a.job[jb].keep;
     const float keep_scale = a.job[jb].keep_scale;
     const int ldp = a.job[jb].ldp, ldx = a.job[jb].ldx, xc = a.job[jb].xcols;
-    const int n0 = blockIdx.x * 64;
-    if (n0 >= xc) return;                       // uniform per block, before any barrier
-    const int rc = blockIdx.y;
+    const int n0 = wg.slice * 64;
+    if (n0 >= xc) return;
+    const int rc = wg.rc;
+    const bool first_slice = wg.slice == 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, h = lane >> 5;
     const int64_t r_begin = (int64_t)rc * a.rows_per_chunk;
@@ -252,7 +275,7 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_kernel(WgradArgs a) {
             const float v = csx[nt] + __shfl_xor(csx[nt], 32);
             if (h == 0) psx[n0 + 32 * nt + m] = v;
         }
-        if (blockIdx.x == 0) {
+        if (first_slice) {
             float* psp = part + (int64_t)a.row_chunks * PR * xc + (int64_t)a.row_chunks * xc + (int64_t)rc * PR;
 #pragma unroll
             for (int ct = 0; ct < RT; ++ct) {
@@ -299,20 +322,22 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_tr_kernel(WgradArgs a) {
     constexpr int NV = RT * 2 * 16 + RT + 2;         // per-lane values reduced across the 4 waves (as wgrad_kernel)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
-    const int jb = blockIdx.z;
+    const WgId wg = wg_decode(a, a.nslice);
+    if (!wg.ok) return;
+    const int jb = wg.job;
     const uint8_t* P = reinterpret_cast<const uint8_t*>(a.job[jb].P);
     const uint8_t* X = reinterpret_cast<const uint8_t*>(a.job[jb].X);
     const int ldp = a.job[jb].ldp, ldx = a.job[jb].ldx, xc = a.job[jb].xcols;
-    const int n0 = blockIdx.x * 64;
+    const int n0 = wg.slice * 64;
     if (n0 >= xc) return;
-    const int rc = blockIdx.y;
+    const int rc = wg.rc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, h = lane >> 5;
     const int64_t r_begin = (int64_t)rc * a.rows_per_chunk;
     int64_t r_end = r_begin + a.rows_per_chunk;
     if (r_end > a.M) r_end = a.M;
     uint8_t* mine = smem + (size_t)wave * 2 * BUF;
-    const bool want_csp = blockIdx.x == 0;
+    const bool want_csp = wg.slice == 0;
 
     f32x16 acc[RT][2];
     // column sums: A fragment "row t all ones" puts sum_k B[k][j] into row t of ONE accumulator, so the RT P tiles
@@ -445,7 +470,7 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_tr_kernel(WgradArgs a) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
             if (h == 0) psx[n0 + 32 * nt + m] = csx[nt];
-        if (blockIdx.x == 0) {
+        if (want_csp) {
             float* psp = part + (int64_t)a.row_chunks * PR * xc + (int64_t)a.row_chunks * xc + (int64_t)rc * PR;
 #pragma unroll
             for (int ct = 0; ct < RT; ++ct)
@@ -550,7 +575,8 @@ static hipError_t launch_one(const WgradArgs& a, hipStream_t stream) {
             auto kern = wgrad_tr_kernel<RT>;
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(xmax / 64, a.row_chunks, a.njobs), dim3(VLPET_THREADS), lds, stream, a);
+            WgradArgs b = a; b.nslice = xmax / 64;
+            hipLaunchKernelGGL(kern, dim3(wg_grid(b, b.nslice)), dim3(VLPET_THREADS), lds, stream, b);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             return launch_finalize(a, RT, xmax, rmax, stream);
@@ -561,7 +587,8 @@ static hipError_t launch_one(const WgradArgs& a, hipStream_t stream) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(xmax / 64, a.row_chunks, a.njobs), dim3(VLPET_THREADS), lds, stream, a);
+    WgradArgs b = a; b.nslice = xmax / 64;
+    hipLaunchKernelGGL(kern, dim3(wg_grid(b, b.nslice)), dim3(VLPET_THREADS), lds, stream, b);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_finalize(a, RT, xmax, rmax, stream);
