@@ -266,6 +266,37 @@ def k1_fwd_bwd(x1, x2, wd, bd, wu, bu, wgd, bgd, wgu, bgu, dy, *, n_heads=1, gat
     return y.detach(), grads
 
 
+def lowrank_visual_embedding(
+    feats: torch.Tensor, pos: torch.Tensor,
+    down_w: Sequence[torch.Tensor], down_b: Sequence[torch.Tensor], up_w: torch.Tensor, up_b: torch.Tensor,
+    ln_w: torch.Tensor, ln_b: torch.Tensor,
+    pos_w: torch.Tensor, pos_b: torch.Tensor, pos_ln_w: torch.Tensor, pos_ln_b: torch.Tensor,
+    img_order_table: torch.Tensor, obj_order_table: torch.Tensor,
+    img_order_ids: Optional[torch.Tensor] = None, obj_order_ids: Optional[torch.Tensor] = None,
+    gate: Optional[Dict[str, torch.Tensor]] = None, gate_residual: bool = False, eps: float = 1e-5,
+) -> torch.Tensor:
+    """``LowRankVisualEmbedding.forward`` (src/modeling_bart.py:251-334): multi-head down projection of the CLIP
+    features, gelu_new, up projection, optional low-rank sigmoid gate on the features (``proj * gate`` or, with
+    ``use_visual_projector_residual_connection``, ``proj + proj * gate``), LayerNorm, then the same position /
+    order-embedding terms as ``VisualEmbedding``."""
+    B, N, _ = feats.shape
+    d = up_w.shape[0]
+    z = gelu_new(torch.cat([F.linear(feats, w, b) for w, b in zip(down_w, down_b)], dim=-1))
+    fe = F.linear(z, up_w, up_b)
+    if gate is not None:
+        g = torch.sigmoid(F.linear(gelu_new(F.linear(feats, gate["down_w"], gate["down_b"])), gate["up_w"], gate["up_b"]))
+        fe = fe + fe * g if gate_residual else fe * g
+    fe = F.layer_norm(fe, (d,), ln_w, ln_b, eps)
+    area = ((pos[:, :, 3] - pos[:, :, 2]) * (pos[:, :, 1] - pos[:, :, 0])).unsqueeze(2)
+    pe = F.layer_norm(F.linear(torch.cat([pos, area], dim=2), pos_w, pos_b), (d,), pos_ln_w, pos_ln_b, eps)
+    if img_order_ids is None:
+        img_order_ids = torch.zeros(N, dtype=torch.long).unsqueeze(0)
+    if obj_order_ids is None:
+        obj_order_ids = torch.arange(N, dtype=torch.long).unsqueeze(0)
+    obj_ids = obj_order_table.shape[0] - obj_order_ids - 1
+    return fe + pe + F.embedding(img_order_ids, img_order_table) + F.embedding(obj_ids, obj_order_table)
+
+
 # ------------------------------------------------------------ optimizer step
 def clip_grad_norm(grads: Sequence[torch.Tensor], max_norm: float) -> torch.Tensor:
     """``torch.nn.utils.clip_grad_norm_`` as called at multitask.py:279-300: one global 2-norm over every

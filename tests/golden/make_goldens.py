@@ -610,6 +610,41 @@ def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7, lora=False, kind="bart"):
     save(tag, **arrs)
 
 
+# ------------------------------------------------------------------ LowRankVisualEmbedding
+def golden_lowrank_vis(tag, gated, d=64, feat_dim=128, r=16, nh=4, rg=8, B=2, N=6, seed=10):
+    """LowRankVisualEmbedding (src/modeling_bart.py:195-334), plain and with the low-rank gate."""
+    import torch.nn as nn
+    flags = list(VLPET_LARGE_FLAGS) + ["--feat_dim", str(feat_dim), "--visual_projector_down_dim", str(r),
+                                       "--visual_projector_multihead_num_head", str(nh),
+                                       "--visual_projector_gating_down_dim", str(rg)]
+    if gated:
+        flags.append("--use_visual_projector_gating_large_x_lowrank")
+    config, args = make_config("bart", flags, d_model=d, heads=4, ffn=4 * d)
+    config.feat_dim = int(feat_dim); config.pos_dim = 4
+    config.vis_use_transformer = False
+    config.use_vis_order_embedding = True
+    config.use_vis_layer_norm = True
+    config.individual_vis_layer_norm = True
+    config.default_obj_order_ids = None
+    mod = load_vl_module("bart")
+    gen = torch.Generator().manual_seed(seed)
+    table = nn.Embedding(200, d)
+    ve = mod.LowRankVisualEmbedding(config, table)
+    randomize(ve, gen, std=0.05)
+    with torch.no_grad():
+        for m in ve.modules():
+            if isinstance(m, nn.LayerNorm):
+                m.weight.add_(1.0)
+    feats = torch.randn(B, N, int(feat_dim), generator=gen)
+    pos = torch.rand(B, N, 4, generator=gen)
+    out = ve(feats, pos)
+    dy = torch.randn(out.shape, generator=gen)
+    out.backward(dy)
+    arrs = {"sd::" + k: T(v) for k, v in ve.state_dict().items()}
+    arrs.update({"grad::" + n: T(p.grad) for n, p in ve.named_parameters() if p.grad is not None})
+    save(tag, meta=np.array([d, feat_dim, r, nh, rg, B, N, int(gated)]), feats=T(feats), pos=T(pos), out=T(out), dy=T(dy), **arrs)
+
+
 # -------------------------------------------------------- trainable-name lists
 def golden_trainable_names():
     """Parameter-name lists + trainable flags for the VL-PET-large BART encoder/decoder layer
@@ -634,6 +669,10 @@ def main():
     torch.manual_seed(0)
     if len(sys.argv) > 1 and sys.argv[1] == "downsample":      # add one fixture without regenerating the rest
         golden_downsample("downsample_7to6_d64")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "lowrank":
+        golden_lowrank_vis("lowrank_vis_d64", gated=False)
+        golden_lowrank_vis("lowrank_vis_gated_d64", gated=True)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "vlbart":
         golden_vlbart_tiny()
@@ -680,6 +719,8 @@ def main():
     golden_vlbart_tiny()
     golden_vlbart_tiny("vlbart_tiny_lora_d64", seed=8, lora=True)
     golden_vlbart_tiny("vlt5_tiny_d64", seed=9, kind="t5")
+    golden_lowrank_vis("lowrank_vis_d64", gated=False)
+    golden_lowrank_vis("lowrank_vis_gated_d64", gated=True)
 
 
 if __name__ == "__main__":

@@ -163,3 +163,29 @@ def test_downsample_golden():
     y2, b2, i2, o2 = O.downsample_nlvr(t("x2"), t("boxes2"), t("img_ids"), t("obj_ids"))
     assert torch.equal(y2, t("y2")) and torch.equal(b2, t("yb2"))
     assert torch.equal(i2, t("yi2")) and torch.equal(o2, t("yo2"))
+
+
+@pytest.mark.parametrize("name", ["lowrank_vis_d64", "lowrank_vis_gated_d64"])
+def test_lowrank_visual_embedding_golden(name):
+    """oracle.lowrank_visual_embedding against the reference's LowRankVisualEmbedding (src/modeling_bart.py:195-334)."""
+    g = load(name)
+    d, F_, r, nh, rg, B, N, gated = [int(v) for v in g["meta"]]
+    P = {k[4:]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith("sd::") and "obj_order" not in k}
+    table = g["sd::obj_order_embedding.weight"].clone().requires_grad_(True)
+    gate = None
+    if gated:
+        gate = dict(down_w=P["visual_projector_gating_large_x_down.weight"], down_b=P["visual_projector_gating_large_x_down.bias"],
+                    up_w=P["visual_projector_gating_large_x_up.weight"], up_b=P["visual_projector_gating_large_x_up.bias"])
+    out = O.lowrank_visual_embedding(
+        g["feats"], g["pos"], [P[f"visual_projector_multihead_down.{i}.weight"] for i in range(nh)],
+        [P[f"visual_projector_multihead_down.{i}.bias"] for i in range(nh)],
+        P["visual_projector_multihead_up.weight"], P["visual_projector_multihead_up.bias"],
+        P["visual_projector_layer_norm.weight"], P["visual_projector_layer_norm.bias"],
+        P["absolute_vis_pos_embedding.0.weight"], P["absolute_vis_pos_embedding.0.bias"],
+        P["absolute_vis_pos_embedding.1.weight"], P["absolute_vis_pos_embedding.1.bias"],
+        P["img_order_embedding.weight"], table, gate=gate)
+    close(out, g["out"])
+    out.backward(g["dy"])
+    for k, v in g.items():
+        if k.startswith("grad::") and "obj_order" not in k:
+            close(P[k[6:]].grad, v, atol=2e-5)

@@ -31,7 +31,7 @@ import torch.nn.functional as F
 from ..adapters import AdapterConfig, AdapterController
 from ..encoder_pet import apply_pet, build_pet, has_pet
 from ..lora import LoRALinearController, LoraConfig
-from ..visual import Downsample, VisualEmbedding
+from ..visual import Downsample, LowRankVisualEmbedding, VisualEmbedding
 
 TASKS = ["vqa", "gqa", "nlvr", "caption"]
 
@@ -48,6 +48,9 @@ def vlpet_config(**over) -> SimpleNamespace:
         # visual
         feat_dim=2048, pos_dim=4, n_images=2, n_boxes=36, downsample=True, use_vis_order_embedding=True,
         use_vis_layer_norm=True, individual_vis_layer_norm=True, share_vis_lang_layer_norm=False,
+        use_lowrank_visual_projector=False, visual_projector_down_dim=96, visual_projector_multihead_num_head=1,
+        use_visual_projector_gating_large_x_lowrank=False, visual_projector_gating_down_dim=96,
+        use_visual_projector_residual_connection=False,
         # PET flags
         tasks=",".join(TASKS), use_adapter=True, use_single_adapter=True, no_encoder_adapter=True,
         no_decoder_adapter=True, use_adapter_down_dim=True, adapter_down_dim=96,
@@ -239,7 +242,9 @@ class JointEncoder(nn.Module):
         self.embed_positions = LearnedPositionalEmbedding(config.max_position_embeddings, d)
         self.layers = nn.ModuleList([BartEncoderLayer(config) for _ in range(config.encoder_layers)])
         self.layernorm_embedding = HostLayerNorm(d)
-        self.visual_embedding = VisualEmbedding(config, self.embed_tokens)
+        # src/modeling_bart.py:704-709: the low-rank projector replaces the full feat_dim x d_model Linear when asked for
+        vis_cls = LowRankVisualEmbedding if getattr(config, "use_lowrank_visual_projector", False) else VisualEmbedding
+        self.visual_embedding = vis_cls(config, self.embed_tokens)
         self.downsample = None
         if config.downsample:
             s = int(config.n_boxes ** 0.5)

@@ -87,7 +87,9 @@ class _VisProjFn(torch.autograd.Function):
         _lib.check(rc, "vlpet_visproj_wgrad")
         dR = dy.to(r_dtype) if has_r else None
         gw, gb = _finish([(dw, s_w, w), (db, s_b, b)])
-        return (None, dR, gw, gb, _grad_like(dgamma, gamma),
+        # the CLIP features of K4 carry no gradient; the low-rank projector's bottleneck activations do (library GEMM)
+        dfeats = (dpre_io @ w.detach().to(dpre_io.dtype)).view(*lead, F) if ctx.needs_input_grad[0] else None
+        return (dfeats, dR, gw, gb, _grad_like(dgamma, gamma),
                 _grad_like(dbeta, beta) if has_beta else None, None, None, None)
 
 

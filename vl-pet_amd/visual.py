@@ -125,3 +125,79 @@ class VisualEmbedding(nn.Module):
             self._vis_cache = VisProjPackCache()
         R = R.expand(B, N, R.shape[-1])
         return visproj(feats, R, self.feat_embedding[0], self.feat_embedding[1], self._vis_cache, self.rms_norm)
+
+
+class LowRankVisualEmbedding(nn.Module):
+    """Low-rank visual projector (src/modeling_bart.py:195-334): ``LN(up(gelu_new(cat_i down_i(feats))))`` with an
+    optional low-rank sigmoid gate on the features, plus the position / order-embedding terms of ``VisualEmbedding``.
+    Same constructor, forward signature and state-dict keys as the reference.
+
+    No launch script of the reference enables it (``--use_lowrank_visual_projector`` is an ablation flag), so it is a
+    composition rather than a dedicated kernel: the feat_dim -> r down projections are plain library GEMMs, and the
+    r -> d_model up projection + LayerNorm + residual add run on the K4 HIP kernel (csrc/visproj.hip) with the
+    bottleneck zero-padded to a multiple of 64.  The gated form (``use_visual_projector_gating_large_x_lowrank``)
+    needs the product before the norm and is expressed with library GEMMs + elementwise ops."""
+
+    def __init__(self, config, obj_order_embedding: nn.Embedding):
+        super().__init__()
+        from .activations import get_activation
+        self.config = config
+        d, feat_dim, pos_dim = config.d_model, int(config.feat_dim), int(config.pos_dim)
+        nh, r = int(config.visual_projector_multihead_num_head), int(config.visual_projector_down_dim)
+        self.visual_projector_multihead_dim = int(r / nh)
+        self.visual_projector_multihead_down = nn.ModuleList([nn.Linear(feat_dim, int(r / nh)) for _ in range(nh)])
+        self.visual_projector_multihead_up = nn.Linear(r, d)
+        self.visual_projector_non_linear = get_activation("gelu_new")
+        if getattr(config, "use_visual_projector_gating_large_x_lowrank", False):
+            rg = int(config.visual_projector_gating_down_dim)
+            self.visual_projector_gating_large_x_down = nn.Linear(feat_dim, rg)
+            self.visual_projector_gating_large_x_up = nn.Linear(rg, d)
+            self.gating_non_linear = get_activation("gelu_new")
+        if not (config.use_vis_layer_norm and config.individual_vis_layer_norm):
+            raise NotImplementedError("LowRankVisualEmbedding: the per-branch LayerNorm configuration is the supported one")
+        self.visual_projector_layer_norm = nn.LayerNorm(d)
+        self.absolute_vis_pos_embedding = nn.Sequential(nn.Linear(pos_dim + 1, d), nn.LayerNorm(d))
+        if config.use_vis_order_embedding:
+            self.obj_order_embedding = obj_order_embedding
+            self.img_order_embedding = nn.Embedding(config.n_images, d)
+
+    get_area = staticmethod(VisualEmbedding.get_area)
+
+    def forward(self, feats, pos, img_order_ids=None, obj_order_ids=None):
+        B, N, _ = feats.shape
+        assert pos.shape == (B, N, 4)
+        dt = feats.dtype
+
+        def lin(m, x):
+            return F.linear(x, m.weight.to(x.dtype), m.bias.to(x.dtype))
+        z = self.visual_projector_non_linear(torch.cat([lin(m, feats) for m in self.visual_projector_multihead_down], dim=-1))
+        pos = pos.float()
+        pos5 = torch.cat([pos, self.get_area(pos).unsqueeze(2)], dim=2)
+        pl, pn = self.absolute_vis_pos_embedding[0], self.absolute_vis_pos_embedding[1]
+        R = pn(F.linear(pos5, pl.weight.float(), pl.bias.float())).float()
+        if self.config.use_vis_order_embedding:
+            dev = feats.device
+            if img_order_ids is None:
+                img_order_ids = torch.zeros(N, dtype=torch.long, device=dev).unsqueeze(0)
+            if obj_order_ids is None:
+                obj_order_ids = torch.arange(N, dtype=torch.long, device=dev).unsqueeze(0)
+            obj_order_ids = self.obj_order_embedding.num_embeddings - obj_order_ids - 1
+            R = R + self.img_order_embedding(img_order_ids).float() + self.obj_order_embedding(obj_order_ids).float()
+        R = R.expand(B, N, R.shape[-1])
+        up, ln = self.visual_projector_multihead_up, self.visual_projector_layer_norm
+        if hasattr(self, "visual_projector_gating_large_x_down"):
+            fe = lin(up, z)
+            g = torch.sigmoid(lin(self.visual_projector_gating_large_x_up,
+                                  self.gating_non_linear(lin(self.visual_projector_gating_large_x_down, feats))))
+            fe = fe + fe * g if getattr(self.config, "use_visual_projector_residual_connection", False) else fe * g
+            return F.layer_norm(fe.float(), (fe.shape[-1],), ln.weight.float(), ln.bias.float(), ln.eps).to(dt) + R.to(dt)
+        from types import SimpleNamespace
+        from .visproj import VisProjPackCache, visproj
+        r = z.shape[-1]
+        rp = (r + 63) // 64 * 64
+        zp = F.pad(z, (0, rp - r)).contiguous()
+        wp = F.pad(up.weight, (0, rp - r)).contiguous()          # zero columns: the padding contributes nothing
+        if not hasattr(self, "_vis_cache"):
+            self._vis_cache = VisProjPackCache()
+        return visproj(zp, R, SimpleNamespace(weight=wp, bias=up.bias), ln, self._vis_cache, False)
+
