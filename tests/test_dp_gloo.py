@@ -94,12 +94,16 @@ class _SinkNet(torch.nn.Module):
         torch.manual_seed(11)
         self.a = torch.nn.Linear(16, 24)      # gradients through the sinks
         self.mid = torch.nn.Linear(24, 24)    # ordinary autograd accumulation (post-accumulate hooks)
-        self.b = torch.nn.Linear(24, 4)       # sinks again; used TWICE per step -> second use must fall back to autograd
+        self.b = torch.nn.Linear(24, 4)       # sinks again
+        self.twice = False                    # use b twice per step (second use must fall back to autograd; world 1 only)
 
     def forward(self, x):
         h = torch.tanh(_SinkLinearFn.apply(x, self.a.weight, self.a.bias))
         h = torch.tanh(self.mid(h))
-        return _SinkLinearFn.apply(h, self.b.weight, self.b.bias) + 0.5 * _SinkLinearFn.apply(h * h, self.b.weight, self.b.bias)
+        y = _SinkLinearFn.apply(h, self.b.weight, self.b.bias)
+        if self.twice:
+            y = y + 0.5 * _SinkLinearFn.apply(h * h, self.b.weight, self.b.bias)
+        return y
 
 
 def _sink_worker(rank, world, port, out):
@@ -126,9 +130,8 @@ def _sink_worker(rank, world, port, out):
 
 @pytest.mark.timeout(300)
 def test_gradient_sinks_under_data_parallel(tmp_path):
-    """Two gloo ranks with half the batch each: gradients written through the sinks, accumulated by autograd, and a
-    twice-used parameter (second use falls back to autograd accumulation) all arrive averaged in the flat buffer;
-    every bucket is all-reduced exactly once per step."""
+    """Two gloo ranks with half the batch each: gradients written through the sinks and gradients accumulated by
+    autograd arrive averaged in the flat buffer; every bucket is all-reduced exactly once per step."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "sink.pt")
     mp.spawn(_sink_worker, args=(2, port, out), nprocs=2, join=True)
@@ -143,3 +146,23 @@ def test_gradient_sinks_under_data_parallel(tmp_path):
     ((m(x) - y) ** 2).mean().backward()
     for f in got["flats"]:
         torch.testing.assert_close(f, ref.flat, rtol=1e-5, atol=1e-6)
+
+
+def test_gradient_sink_second_use_falls_back_to_autograd():
+    """One process: a parameter used twice in a step takes the direct-write path once and autograd accumulation for
+    the second contribution; the flat buffer holds the sum.  (Under data parallelism the same model is rejected.)"""
+    m = _SinkNet(); m.twice = True
+    x, y = _data()
+    fg = TR.FlatGrads(m, world_size=1, flatten_params=True, sinks=True)
+    fg.begin_step(zero=True)
+    ((m(x) - y) ** 2).mean().backward()
+    ref_m = _SinkNet(); ref_m.twice = True
+    ref = TR.FlatGrads(ref_m, world_size=1, sinks=False)
+    ref.begin_step(zero=True)
+    ((ref_m(x) - y) ** 2).mean().backward()
+    torch.testing.assert_close(fg.flat, ref.flat, rtol=1e-5, atol=1e-6)
+    fg.world_size = 2                          # pretend DP: the second use must be refused, not silently raced
+    fg.begin_step(zero=True)
+    with pytest.raises(RuntimeError):
+        ((m(x) - y) ** 2).mean().backward()
+

@@ -148,8 +148,17 @@ class GradSink:
         self.epoch = -1
 
     def take(self) -> Optional[torch.Tensor]:
-        """The view if this is the first write of the step (the kernels overwrite), else None (-> autograd adds)."""
-        if not self.owner.sinks_enabled or self.epoch == self.owner.epoch:
+        """The view if this is the first write of the step (the kernels overwrite), else None (-> autograd adds).
+
+        Under data parallelism a sunk parameter must be used ONCE per backward: ``done()`` of the first use already
+        counted it ready, so its bucket may be in flight when a second contribution arrives.  (True for every PET
+        parameter of the reference: one adapter / gate / LoRA pair per module and step.)"""
+        if not self.owner.sinks_enabled:
+            return None
+        if self.epoch == self.owner.epoch:
+            if self.owner.world_size > 1:
+                raise RuntimeError("vl-pet_amd: a parameter with a direct-write gradient slot was used twice in one "
+                                   "backward under data parallelism; build FlatGrads(sinks=False) for such models")
             return None
         self.epoch = self.owner.epoch
         return self.view
@@ -234,6 +243,7 @@ class FlatGrads:
         for bidx in self.bucket_of:
             self.bucket_count[bidx] += 1
         self._pending = [0] * len(self.buckets)
+        self._ready_epoch = [-1] * len(self.params)
         self._handles = []
         self._hooks = []
         if world_size > 1:
@@ -269,6 +279,13 @@ class FlatGrads:
                 p._vlpet_sink = GradSink(self, self.flat[a:b].view_as(p), [i])
 
     def _ready(self, i):
+        """Parameter i has its gradient of this step in the flat buffer.  Idempotent per step: a sunk parameter is
+        reported by ``GradSink.done()`` AND by its post-accumulate hook (autograd runs the hook even though the PET
+        function returned None for it) -- counting both launched the bucket's all-reduce before the other members had
+        their gradients (caught by tests/test_dp_gloo.py and tests/test_gpu_dp.py)."""
+        if self._ready_epoch[i] == self.epoch:
+            return
+        self._ready_epoch[i] = self.epoch
         if self.world_size > 1:
             b = self.bucket_of[i]
             self._pending[b] += 1
