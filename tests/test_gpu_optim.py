@@ -116,3 +116,32 @@ def test_trainer_step_gpu_equals_cpu_reference():
             err = float((p.detach().cpu() - ref[n].detach()).abs().max())
             worst = max(worst, err / max(1e-3, float(ref[n].detach().abs().max())))
     assert worst <= 2e-2, worst        # Adam's m/sqrt(v) amplifies tiny gradient differences in the first steps
+
+
+def test_training_with_dropout_reduces_the_loss():
+    """Sanity of the whole stochastic path (in-kernel dropout of the tails regenerated in the backward, attention /
+    activation dropout, fused optimizer): 40 steps on one fixed batch must overfit it."""
+    import vlpet_amd.host.bart as HB
+    import vlpet_amd.train as TR
+    cfg = HB.vlpet_config(d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
+                          decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128, vocab_size=500,
+                          max_position_embeddings=64, feat_dim=128, adapter_down_dim=8, adapter_gating_down_dim=16,
+                          decoder_enc_attn_value_parallel_adapter_down_dim=8, dropout=0.1, attention_dropout=0.1,
+                          activation_dropout=0.1)
+    torch.manual_seed(1)
+    model = HB.VLBart(cfg)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    TR.trainable_names(model, cfg)
+    model.train().cuda()
+    tr = TR.Trainer(model, cfg, lr=5e-3, total_steps=80, warmup_ratio=0.05)
+    gen = torch.Generator().manual_seed(2)
+    b = TR.synthetic_batch("caption", 8, cfg, "cpu", gen)
+    bb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    bb["vis_inputs"] = tuple(t.cuda() for t in b["vis_inputs"])
+    losses = [float(tr.step(bb)) for _ in range(40)]
+    assert all(l == l for l in losses)                       # finite
+    # only the PET parameters, the encoder LayerNorms and the visual embedding train (4 % of a random frozen backbone): the
+    # loss falls slowly but steadily
+    assert sum(losses[-5:]) / 5 < sum(losses[:3]) / 3 - 0.1, (losses[:3], losses[-5:])
