@@ -161,7 +161,7 @@ def test_gradient_sink_second_use_falls_back_to_autograd():
     ref.begin_step(zero=True)
     ((ref_m(x) - y) ** 2).mean().backward()
     torch.testing.assert_close(fg.flat, ref.flat, rtol=1e-5, atol=1e-6)
-    fg.world_size = 2                          # pretend DP: the second use must be refused, not silently raced
+    fg.dp = True                               # pretend DP: the second use must be refused, not silently raced
     fg.begin_step(zero=True)
     with pytest.raises(RuntimeError):
         ((m(x) - y) ** 2).mean().backward()

@@ -83,3 +83,38 @@ def test_two_gpu_ranks_equal_one_rank(tmp_path):
             ref = p.detach().cpu()
             worst = max(worst, float((got[n] - ref).abs().max() / ref.abs().max().clamp_min(1e-3)))
     assert worst <= 2e-2, worst        # same bound as the GPU-vs-CPU trainer test (Adam amplifies rounding in the first steps)
+
+
+def _rccl_worker(rank, world, port, out):
+    import vlpet_amd.train as TR
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    cfg, model = _cfg_model()
+    model.cuda()
+    tr = TR.Trainer(model, cfg, lr=1e-2, total_steps=10, warmup_ratio=0.1, world_size=1, n_buckets=3, force_collectives=True)
+    for b in _batches(cfg, 8):
+        tr.step(_shard(b, 0, 1))
+    torch.cuda.synchronize()
+    torch.save({n: p.detach().cpu() for n, p in model.named_parameters() if p.requires_grad}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_collectives_on_one_rank(tmp_path):
+    """backend "nccl" (= RCCL): the bucketed asynchronous all-reduces, the side-stream join and the fused optimizer on
+    the real collective library, with a 1-rank communicator (the test box has one GPU).  Result == the plain run."""
+    import vlpet_amd.train as TR
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "rccl.pt")
+    mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    got = torch.load(out)
+    cfg, model = _cfg_model()
+    model.cuda()
+    tr = TR.Trainer(model, cfg, lr=1e-2, total_steps=10, warmup_ratio=0.1)
+    for b in _batches(cfg, 8):
+        tr.step(_shard(b, 0, 1))
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            ref = p.detach().cpu()
+            assert float((got[n] - ref).abs().max() / ref.abs().max().clamp_min(1e-3)) <= 2e-2, n

@@ -156,7 +156,7 @@ class GradSink:
         if not self.owner.sinks_enabled:
             return None
         if self.epoch == self.owner.epoch:
-            if self.owner.world_size > 1:
+            if self.owner.dp:
                 raise RuntimeError("vl-pet_amd: a parameter with a direct-write gradient slot was used twice in one "
                                    "backward under data parallelism; build FlatGrads(sinks=False) for such models")
             return None
@@ -200,7 +200,7 @@ class FlatGrads:
     parameters themselves + Adam moments as flat buffers for the fused optimizer."""
 
     def __init__(self, model: nn.Module, world_size: int = 1, n_buckets: int = 3, process_group=None,
-                 flatten_params: bool = False, sinks: bool = False):
+                 flatten_params: bool = False, sinks: bool = False, force_collectives: bool = False):
         named = _flat_order([(n, p) for n, p in model.named_parameters() if p.requires_grad])
         self.names = [n for n, _ in named]
         self.params = [p for _, p in named]
@@ -210,6 +210,7 @@ class FlatGrads:
         self.total = total
         self.flat = torch.zeros(total_pad, dtype=torch.float32, device=dev)
         self.world_size = world_size
+        self.dp = world_size > 1 or force_collectives      # force: run the bucket all-reduces on a 1-rank group (RCCL smoke test)
         self.group = process_group
         self.epoch = 0
         self.sinks_enabled = bool(sinks)
@@ -246,7 +247,7 @@ class FlatGrads:
         self._ready_epoch = [-1] * len(self.params)
         self._handles = []
         self._hooks = []
-        if world_size > 1:
+        if self.dp:
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         if sinks:
@@ -286,7 +287,7 @@ class FlatGrads:
         if self._ready_epoch[i] == self.epoch:
             return
         self._ready_epoch[i] = self.epoch
-        if self.world_size > 1:
+        if self.dp:
             b = self.bucket_of[i]
             self._pending[b] += 1
             if self._pending[b] == self.bucket_count[b]:
@@ -314,7 +315,7 @@ class FlatGrads:
         gradient this step -- per-task adapters / LoRA leave other tasks' grads at zero) and average
         (``average=False``: the caller folds 1/world_size into its optimizer kernel)."""
         self._join_side_stream()
-        if self.world_size > 1:
+        if self.dp:
             for b in range(len(self.buckets)):
                 if self._pending[b] < self.bucket_count[b]:
                     self._launch(b)
@@ -407,13 +408,14 @@ class Trainer:
     clip, AdamW, scheduler -- multitask.py:217-342."""
 
     def __init__(self, model: nn.Module, config, lr=1e-3, clip=5.0, total_steps=1000, warmup_ratio=0.1,
-                 world_size=1, n_buckets=3, process_group=None, overlap_wgrad=True):
+                 world_size=1, n_buckets=3, process_group=None, overlap_wgrad=True, force_collectives=False):
         self.model, self.config, self.clip, self.base_lr = model, config, clip, lr
         on_gpu = next(model.parameters()).is_cuda
         if on_gpu:
             from . import functional as VF
             VF.WGRAD_STREAM = torch.cuda.Stream() if overlap_wgrad else None
-        self.flat = FlatGrads(model, world_size, n_buckets, process_group, flatten_params=True, sinks=on_gpu)
+        self.flat = FlatGrads(model, world_size, n_buckets, process_group, flatten_params=True, sinks=on_gpu,
+                              force_collectives=force_collectives)
         if on_gpu:
             self.optim = FusedAdamW(self.flat, lr=lr, max_norm=clip)
         elif CPU_OPTIMIZER_FACTORY is not None:
