@@ -212,3 +212,52 @@ def test_empty_batches_need_no_launch():
     out.sum().backward()
     assert m.attn_adapter_multihead_up.weight.grad is not None and float(m.attn_adapter_multihead_up.weight.grad.abs().sum()) == 0.0
     assert m.ln.weight.grad is not None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("add,gs", [(False, 0.3), (True, 1.0)])
+def test_apply_pet_wide_bottleneck(dtype, add, gs):
+    """r = r_g = 192 (T5-VL-PET-large.sh): apply_pet runs the layer as a composition of 3-tile kernels (two bottleneck
+    halves); forward and every gradient against the oracle, and against the fused 6-tile kernels."""
+    import torch.nn as nn
+    from types import SimpleNamespace
+    import vlpet_amd.encoder_pet as EP
+    from oracle import vlpet_oracle as O
+    torch.manual_seed(3)
+    B, S, d, r, nh = 5, 56, 768, 192, 4
+    cfg = SimpleNamespace(use_encoder_adapter_down_multihead=True, encoder_adapter_multihead_num_head=nh, adapter_down_dim=r,
+                          use_encoder_adapter_gating_large_x_lowrank=True, adapter_gating_down_dim=r,
+                          use_encoder_adapter_gating_add=add, use_encoder_gating_scaling=gs != 1.0,
+                          encoder_gating_scaling_factor=gs)
+    m = nn.Module(); EP.build_pet(m, cfg, d, ("ff",))
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn_like(p) * 0.04)
+    q = lambda t: t.to(dtype).float()
+    x1, x2, dy = q(torch.randn(B, S, d)), q(torch.randn(B, S, d)), q(torch.randn(B, S, d))
+    P = {n: p.detach().clone().requires_grad_(True) for n, p in m.named_parameters()}
+    x1r, x2r = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    gate = dict(down_w=P["encoder_ff_adapter_gating_large_x_down.weight"], down_b=P["encoder_ff_adapter_gating_large_x_down.bias"],
+                up_w=P["encoder_ff_adapter_gating_large_x_up.weight"], up_b=P["encoder_ff_adapter_gating_large_x_up.bias"])
+    ref = O.encoder_adapter_gate(x1r, x2r, [P[f"ff_adapter_multihead_down.{i}.weight"] for i in range(nh)],
+                                 [P[f"ff_adapter_multihead_down.{i}.bias"] for i in range(nh)],
+                                 P["ff_adapter_multihead_up.weight"], P["ff_adapter_multihead_up.bias"], gate, O.GATE_LARGE,
+                                 add, 1.0, 1.0, gs)
+    ref.backward(dy)
+    m.cuda()
+    tol = 1e-3 if dtype == torch.float32 else 1e-2
+    rel = lambda a, b: float((a.detach().float().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-6))
+    for split in (True, False):
+        EP.SPLIT_WIDE_BOTTLENECK = split
+        try:
+            for p in m.parameters():
+                p.grad = None
+            X1, X2 = x1.cuda().to(dtype).requires_grad_(True), x2.cuda().to(dtype).requires_grad_(True)
+            y = EP.apply_pet(m, "ff", X1, X2, cfg)
+            y.backward(dy.cuda().to(dtype))
+            assert rel(y, ref.detach()) <= tol, ("y", split)
+            assert rel(X1.grad, x1r.grad) <= tol and rel(X2.grad, x2r.grad) <= tol, ("dx", split)
+            for n, p in m.named_parameters():
+                assert rel(p.grad, P[n].grad) <= (tol if dtype == torch.float32 else 2e-2), (n, split)
+        finally:
+            EP.SPLIT_WIDE_BOTTLENECK = True

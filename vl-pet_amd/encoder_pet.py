@@ -65,6 +65,45 @@ def build_pet(module: nn.Module, config, embed_dim: int, which=("attn", "ff")):
         module._pet_caches[w] = (VF.PackCache(), VF.PackCache())
 
 
+# r, r_g in (96, 192] (the T5 script): the 6-tile instantiation of the fused backward needs four [32 x 192] fp32
+# accumulator sets at once and spills.  Until that kernel is blocked in two 3-tile halves, such
+# layers run as a composition of 3-tile kernels, which is exact: the bottleneck splits into two halves whose up
+# projections add,   lin = s2*x2 + sd*(D1 + D2),   G = G1 + G2,   y = lin (*|+) sigmoid(G) * gs.
+SPLIT_WIDE_BOTTLENECK = True
+
+
+def _apply_pet_split(module, which, x1, x2, dws, dbs, up, gdown, gup, mode, sd, s2, gs, io):
+    caches = module._pet_caches.setdefault(which + "/split", tuple(VF.PackCache() for _ in range(4)))
+    nh = len(dws)
+    r = up.weight.shape[1]
+    if nh % 2 == 0:
+        wa, ba, wb, bb = list(dws[:nh // 2]), list(dbs[:nh // 2]), list(dws[nh // 2:]), list(dbs[nh // 2:])
+        ra = sum(w.shape[0] for w in wa)
+    else:                                   # a single down projection: split its rows
+        ra = r // 2
+        wa, ba, wb, bb = [dws[0][:ra]], [dbs[0][:ra]], [dws[0][ra:]], [dbs[0][ra:]]
+    cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(list(ts), 0)
+    ua, ub = up.weight[:, :ra].contiguous(), up.weight[:, ra:].contiguous()
+    t3 = 3
+    # adapter chain: h1 = s2*x2 + sd*(up_a(gelu(down_a x2)) + bu);  lin = h1 + sd*up_b(gelu(down_b x2))
+    pk = caches[0].get(wa, ba, ua, up.bias, io, t3)
+    h1 = VF.adapter_gate(None, x2, wa, ba, ua, up.bias, None, pk, None, VF.GATE_NONE, sd, s2, 1.0)
+    wbc, bbc = cat(wb), cat(bb)
+    pk = caches[1].get([wbc], [bbc], ub, None, io, t3)
+    lin = VF.parallel_adapter(x2, h1, wbc, bbc, ub, None, pk, sd)
+    # gate chain on x1
+    rg = gup.weight.shape[1]
+    ga = rg // 2
+    gwa, gba, gwb, gbb = gdown.weight[:ga], gdown.bias[:ga], gdown.weight[ga:], gdown.bias[ga:]
+    gua, gub = gup.weight[:, :ga].contiguous(), gup.weight[:, ga:].contiguous()
+    pk = caches[2].get([gwa], [gba], gua, gup.bias, io, t3)
+    g1 = VF.adapter_gate(None, x1, [gwa], [gba], gua, gup.bias, None, pk, None, VF.GATE_NONE, 1.0, 0.0, 1.0)
+    pk = caches[3].get([gwb], [gbb], gub, None, io, t3)
+    g = torch.sigmoid(VF.parallel_adapter(x1, g1, gwb, gbb, gub, None, pk, 1.0).float()).to(lin.dtype)
+    y = lin + g if mode == VF.GATE_ADD else lin * g
+    return y * gs if gs != 1.0 else y
+
+
 def has_pet(module: nn.Module, which: str) -> bool:
     return getattr(module, _names(which)["down"], None) is not None
 
@@ -98,6 +137,8 @@ def apply_pet(module: nn.Module, which: str, x1: torch.Tensor, x2: torch.Tensor,
     gp = (gdown.weight, gdown.bias, gup.weight, gup.bias) if gate else None
     if x1.dtype != x2.dtype:
         x1 = x1.to(x2.dtype)
+    if gate and tiles == 6 and SPLIT_WIDE_BOTTLENECK:
+        return _apply_pet_split(module, which, x1, x2, dws, dbs, up, gdown, gup, mode, sd, s2, gs, io)
     y = VF.adapter_gate(x1, x2, dws, dbs, up.weight, up.bias, gp, pk_a, pk_g, mode, sd, s2, gs if gate else 1.0)
     if gate:
         return y

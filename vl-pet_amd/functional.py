@@ -331,8 +331,9 @@ class _ParallelAdapterFn(torch.autograd.Function):
         dyf = _flat(dy, d)
         f32 = dict(dtype=torch.float32, device=xf.device)
         r = pk.r
-        (dwd, s0), (dbd, s1), (dwu, s2), (dbu, s3) = (_grad_dest(wd, (r, d)), _grad_dest(bd, (r,)),
-                                                      _grad_dest(wu, (d, r)), _grad_dest(bu, (d,)))
+        (dwd, s0), (dbd, s1), (dwu, s2) = _grad_dest(wd, (r, d)), _grad_dest(bd, (r,)), _grad_dest(wu, (d, r))
+        # bu is None when the up bias belongs to another half of a split bottleneck (encoder_pet._apply_pet_split)
+        (dbu, s3) = _grad_dest(bu, (d,)) if bu is not None else (torch.empty(d, dtype=torch.float32, device=xf.device), None)
         dx = torch.empty_like(xf)
         nws = lib.vlpet_bwd_workspace_bytes(M, d, pk.tiles, 0, io)
         ws = torch.empty(nws, dtype=torch.uint8, device=xf.device)
@@ -340,7 +341,9 @@ class _ParallelAdapterFn(torch.autograd.Function):
             dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), dx.data_ptr(), dwd.data_ptr(), dbd.data_ptr(),
             dwu.data_ptr(), dbu.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, ctx.scale, io, _stream()))
         _lib.check(rc, "vlpet_parallel_adapter_bwd")
-        return (dx.view(ctx.shape), dy, None, None, *_finish([(dwd, s0, wd), (dbd, s1, bd), (dwu, s2, wu), (dbu, s3, bu)]))
+        gw = _finish([(dwd, s0, wd), (dbd, s1, bd), (dwu, s2, wu)])
+        gbu = _finish([(dbu, s3, bu)])[0] if bu is not None else None
+        return (dx.view(ctx.shape), dy, None, None, *gw, gbu)
 
 
 def parallel_adapter(x, y, wd, bd, wu, bu, pk: PackedPair, scale: float = 1.0):
