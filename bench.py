@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--buckets", type=int, default=3)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to exercise the DP path on a 1-GPU box")
+    ap.add_argument("--overlap-wgrad", action="store_true",
+                    help="K1 weight gradients on a side stream (measured 5 %% SLOWER on one MI355X: the step is GPU-bound)")
     ap.add_argument("--model", default="bart", choices=["bart", "t5"],
                     help="bart = BASELINE configs[1] (the headline line); t5 = configs[2] (T5-base, r = r_g = 192, --batch 300)")
     args = ap.parse_args()
@@ -111,7 +113,8 @@ def main():
     TR.cast_frozen(model, dtype)
     model.train()
     total_steps = max(args.steps + args.warmup, 10)
-    tr = TR.Trainer(model, cfg, lr=1e-3, clip=5.0, total_steps=total_steps, world_size=world, n_buckets=args.buckets)
+    tr = TR.Trainer(model, cfg, lr=1e-3, clip=5.0, total_steps=total_steps, world_size=world, n_buckets=args.buckets,
+                    overlap_wgrad=args.overlap_wgrad)
 
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     batches = {t: TR.synthetic_batch(t, TR.TASK_BATCH[t](args.batch), cfg, dev, gen) for t in TASK_ORDER}

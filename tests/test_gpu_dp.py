@@ -56,7 +56,8 @@ def _worker(rank, world, port, out):
     torch.cuda.set_device(0)
     cfg, model = _cfg_model()
     model.cuda()
-    tr = TR.Trainer(model, cfg, lr=1e-2, total_steps=10, warmup_ratio=0.1, world_size=world, n_buckets=3)
+    tr = TR.Trainer(model, cfg, lr=1e-2, total_steps=10, warmup_ratio=0.1, world_size=world, n_buckets=3,
+                    overlap_wgrad=True)         # also covers the optional side-stream weight gradients
     for b in _batches(cfg, 8):
         tr.step(_shard(b, rank, world))
     torch.cuda.synchronize()

@@ -42,7 +42,9 @@ class KernelTimer:
 
 TIMER: Optional[KernelTimer] = None
 
-# Side stream for the weight-gradient half of the K1 backward (set by train.Trainer).  The row-parallel half stays
+# Optional side stream for the weight-gradient half of the K1 backward (train.Trainer(overlap_wgrad=True); OFF by
+# default: on one MI355X the step is GPU-bound and the overlap measured 5 % slower, 15.2 k vs 16.0 k samples/s).
+# The row-parallel half stays
 # on the autograd stream -- the next backward op needs dx1 / dx2 -- while the column-parallel weight gradients, which
 # nobody reads before the optimizer step, run concurrently with the frozen backward that follows.  Only used when
 # every weight gradient of the call goes straight into the trainer's flat buffer (train.GradSink).

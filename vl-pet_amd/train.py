@@ -408,7 +408,7 @@ class Trainer:
     clip, AdamW, scheduler -- multitask.py:217-342."""
 
     def __init__(self, model: nn.Module, config, lr=1e-3, clip=5.0, total_steps=1000, warmup_ratio=0.1,
-                 world_size=1, n_buckets=3, process_group=None, overlap_wgrad=True, force_collectives=False):
+                 world_size=1, n_buckets=3, process_group=None, overlap_wgrad=False, force_collectives=False):
         self.model, self.config, self.clip, self.base_lr = model, config, clip, lr
         on_gpu = next(model.parameters()).is_cuda
         if on_gpu:
