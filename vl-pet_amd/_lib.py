@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvlpet_hip.so")
+LIB_PATH = os.environ.get("VLPET_LIB") or os.path.join(_HERE, "lib", "libvlpet_hip.so")   # override: same-box A/B of two builds
 
 VLPET_F32 = 0
 VLPET_BF16 = 1

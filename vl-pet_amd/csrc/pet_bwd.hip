@@ -42,7 +42,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
     constexpr int KT = 2 * RT;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar registers and scalar branches for everything derived from it
     const int m = lane & 31, h = lane >> 5;
     const int trow = 32 * wave + m;
     const int d = a.d;

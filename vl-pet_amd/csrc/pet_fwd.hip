@@ -49,7 +49,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
     static_assert(!KEEP || NS == 1, "register-resident residual is the bf16 path");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar registers and scalar branches for everything derived from it
     const int m = lane & 31, h = lane >> 5;
     const int trow = 32 * wave + m;
     const int d = a.d;

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
     constexpr int NW = 2 * RG;                   // waves
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar registers and scalar branches for everything derived from it
     const int chain = wave / RG, rg = wave % RG;             // waves rg and rg + RG share a SIMD (RG = 4)
     const bool isA = chain == 0;
     const int m = lane & 31, h = lane >> 5;
@@ -129,11 +129,33 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
         const int nrows = issue_rows(t);
         const uint8_t* w = slot_w(t & 1) + (isA ? 0 : L::SEG_KB * 1024);
         const uint8_t* tile = slot_d(t % 3);
+        // all LDS fragment reads of the stage first, then the MFMAs behind counted lgkmcnt waits: with two waves per
+        // SIMD a read -> wait -> MFMA chain per fragment leaves the matrix pipe idle for the LDS latency every time
+        if constexpr (G::KU * RT <= 12) {
+            Frag<NS> bf[G::KU], wf[G::KU * RT];
 #pragma unroll
-        for (int u = 0; u < G::KU; ++u) {
-            const Frag<NS> b = tile_bfrag4<IO>(tile, trow, h, u);
+            for (int u = 0; u < G::KU; ++u) {
+                bf[u] = tile_bfrag4<IO>(tile, trow, h, u);
 #pragma unroll
-            for (int ct = 0; ct < RT; ++ct) acc[ct] = mfma_ns<NS>(wfrag<NS>(w, u * RT + ct, lane), b, acc[ct]);
+                for (int ct = 0; ct < RT; ++ct) wf[u * RT + ct] = wfrag<NS>(w, u * RT + ct, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < G::KU; ++u) {
+#pragma unroll
+                for (int ct = 0; ct < RT; ++ct) acc[ct] = mfma_ns<NS>(wf[u * RT + ct], bf[u], acc[ct]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < G::KU; ++u) {
+                const Frag<NS> b = tile_bfrag4<IO>(tile, trow, h, u);
+                Frag<NS> wf[RT];
+#pragma unroll
+                for (int ct = 0; ct < RT; ++ct) wf[ct] = wfrag<NS>(w, u * RT + ct, lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = 0; ct < RT; ++ct) acc[ct] = mfma_ns<NS>(wf[ct], b, acc[ct]);
+            }
         }
         if (t == 5) stamp(6);
         wait_vm(nrows);
@@ -180,10 +202,25 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
                     au[v][4 * q] = tb[0]; au[v][4 * q + 1] = tb[1]; au[v][4 * q + 2] = tb[2]; au[v][4 * q + 3] = tb[3];
                 }
             }
+            if constexpr (G::NV * KT <= 12) {
+                Frag<NS> wf[G::NV * KT];
 #pragma unroll
-            for (int ks = 0; ks < KT; ++ks) {
+                for (int ks = 0; ks < KT; ++ks) {
 #pragma unroll
-                for (int v = 0; v < G::NV; ++v) au[v] = mfma_ns<NS>(wfrag<NS>(w, v * KT + ks, lane), z[ks], au[v]);
+                    for (int v = 0; v < G::NV; ++v) wf[v * KT + ks] = wfrag<NS>(w, v * KT + ks, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KT; ++ks) {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) au[v] = mfma_ns<NS>(wf[v * KT + ks], z[ks], au[v]);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KT; ++ks) {
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) au[v] = mfma_ns<NS>(wfrag<NS>(w, v * KT + ks, lane), z[ks], au[v]);
+                }
             }
             if (!isA) {
                 // gate values (fp32) -> exchange buffer of this stage; piece q of the lane at q*1 KiB + lane*16

@@ -48,7 +48,7 @@ template <typename IO, int NP, int OP>
 __global__ __launch_bounds__(RG_WAVES * 64) void rowgate_kernel(RowArgs a) {
     using P = Piece<IO>;
     constexpr int E = P::E;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int d = a.d, pieces = d / E;
     const uint8_t* A = reinterpret_cast<const uint8_t*>(a.a);
     const uint8_t* C = reinterpret_cast<const uint8_t*>(a.c);

@@ -49,7 +49,7 @@ template <typename IO, int NP, bool NORM>
 __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
     using P = Piece<IO>;
     constexpr int E = P::E;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int d = a.d, pieces = d / E;
     const uint32_t thr = a.thr;
     const float scale = a.keep_scale;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
     using P = Piece<IO>;
     constexpr int E = P::E;
     __shared__ float red[TAIL_WAVES][2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int d = a.d, pieces = d / E;
     const uint32_t thr = a.thr;
     const float scale = a.keep_scale;

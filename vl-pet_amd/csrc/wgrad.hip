@@ -150,7 +150,7 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_kernel(WgradArgs a) {
     if (n0 >= xc) return;
     const int rc = wg.rc;
     const bool first_slice = wg.slice == 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar registers and scalar branches for everything derived from it
     const int m = lane & 31, h = lane >> 5;
     const int64_t r_begin = (int64_t)rc * a.rows_per_chunk;
     int64_t r_end = r_begin + a.rows_per_chunk;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_tr_kernel(WgradArgs a) {
     const int n0 = wg.slice * 64;
     if (n0 >= xc) return;
     const int rc = wg.rc;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar registers and scalar branches for everything derived from it
     const int m = lane & 31, h = lane >> 5;
     const int64_t r_begin = (int64_t)rc * a.rows_per_chunk;
     int64_t r_end = r_begin + a.rows_per_chunk;
