@@ -35,6 +35,26 @@ struct GateLds {
     static size_t bytes(int d) { return (size_t)BIAS_OFF + (size_t)2 * (32 * RT + d) * 4; }
 };
 
+template <bool B> struct BoolC { static constexpr bool value = B; };
+
+// one 16-byte piece of a row tile -> fp32 (8 bf16 or 4 fp32 values)
+template <typename IO>
+__device__ __forceinline__ void piece_to_f32(const u32x4& raw, float* v) {
+    if constexpr (Geo4<IO>::NS == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __builtin_bit_cast(float, raw[i] << 16);
+            v[2 * i + 1] = __builtin_bit_cast(float, raw[i] & 0xffff0000u);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned int u = raw[i];      // (bit_cast straight from the vector-element lvalue reads element 0)
+            v[i] = __builtin_bit_cast(float, u);
+        }
+    }
+}
+
 template <typename IO, int RT, bool GATE_ADD, int RG>
 __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
     using G = Geo4<IO>;
@@ -93,11 +113,6 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
     auto issue_rows = [&](int t) -> int {
         if (t + 2 < S) {
             glds_rows4(xin, rl, (t + 2) * 128, slot_d((t + 2) % 3), rg);
-            return 4;
-        }
-        if (isA && t >= S && t < 2 * S) {        // residual block su = t - S, consumed at stage t + 1
-            const int su = t - S;
-            glds_rows4(res, rl, su * 128, slot_res(su & 1), rg);
             return 4;
         }
         return 0;
@@ -181,35 +196,58 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
     }
 
     stamp(3);
-    // ---- up phase
+    // ---- up phase, software-pipelined inside each wave: the MFMAs of feature block b share a stage (one basic
+    // block) with the VALU epilogue of block b-1, which lives in other registers -- the matrix pipe works while the
+    // wave's own VALU/transcendental stream issues, instead of both waves of a SIMD doing MFMAs, then both VALU.
+    //   chain G: MFMAs of block b at stage S+b,   epilogue (sigmoid -> exchange buffer b&1) at stage S+b+1
+    //   chain A: MFMAs of block b at stage S+b+1, epilogue (residual, gate, stores)         at stage S+b+2
+    // residual rows of block b are issued at stage S+b+1 into residual slot b&1 (free since the stores of b-2).
     const float* bu = sb + (isA ? 0 : nb) + 32 * RT + G::LW * h;
     const float gs = a.gs;
     const float s2g = a.s2 * gs, sdg = a.sd * gs;      // gate scale folded into the linear part
-    for (; t <= 2 * S; ++t) {
-        issue_w(t + 1);
-        const int nrows = issue_rows(t);
-        (void)nrows;
-        const int su = isA ? t - S - 1 : t - S;
-        int n_after = 0;                                // vector-memory operations allowed to stay in flight
-        if (su >= 0 && su < S) {
-            const uint8_t* w = slot_w(t & 1) + (isA ? 0 : L::SEG_KB * 1024);
-            f32x16 au[G::NV];
+    f32x16 au_prev[G::NV];
+#pragma unroll
+    for (int v = 0; v < G::NV; ++v) au_prev[v] = zero16();
+
+    auto up_stage = [&](auto chain_c, auto mm_c, auto ep_c, int tt) {
+        constexpr bool CA = decltype(chain_c)::value, MM = decltype(mm_c)::value, EP = decltype(ep_c)::value;
+        issue_w(tt + 1);
+        const int bm = CA ? tt - S - 1 : tt - S;        // block whose MFMAs run in this stage
+        const int be = bm - 1;                          // block whose epilogue runs in this stage
+        if (CA && bm >= 0 && bm < S) glds_rows4(res, rl, bm * 128, slot_res(bm & 1), rg);
+        const uint8_t* w = slot_w(tt & 1) + (CA ? 0 : L::SEG_KB * 1024);
+        f32x16 au[G::NV];
+        Frag<NS> wf[(MM && G::NV * KT <= 12) ? G::NV * KT : 1];
+        u32x4 rraw[4];
+        f32x4 gt[4 * G::NV];
+        if constexpr (MM) {
 #pragma unroll
             for (int v = 0; v < G::NV; ++v) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 tb = *reinterpret_cast<const f32x4*>(bu + su * G::FE + 16 * v + 4 * q);
+                    const f32x4 tb = *reinterpret_cast<const f32x4*>(bu + bm * G::FE + 16 * v + 4 * q);
                     au[v][4 * q] = tb[0]; au[v][4 * q + 1] = tb[1]; au[v][4 * q + 2] = tb[2]; au[v][4 * q + 3] = tb[3];
                 }
             }
             if constexpr (G::NV * KT <= 12) {
-                Frag<NS> wf[G::NV * KT];
 #pragma unroll
                 for (int ks = 0; ks < KT; ++ks) {
 #pragma unroll
                     for (int v = 0; v < G::NV; ++v) wf[v * KT + ks] = wfrag<NS>(w, v * KT + ks, lane);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (EP && CA) {       // operands of the epilogue: residual pieces and the gate tile, read up front
+            const uint8_t* tr = slot_res(be & 1);
+            const uint8_t* xb = slot_x(be & 1);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) rraw[p] = *reinterpret_cast<const u32x4*>(tile_piece(tr, trow, 4 * h + p));
+#pragma unroll
+            for (int i = 0; i < 4 * G::NV; ++i) gt[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)i * 1024 + lane16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MM) {
+            if constexpr (G::NV * KT <= 12) {
 #pragma unroll
                 for (int ks = 0; ks < KT; ++ks) {
 #pragma unroll
@@ -222,44 +260,63 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
                     for (int v = 0; v < G::NV; ++v) au[v] = mfma_ns<NS>(wfrag<NS>(w, v * KT + ks, lane), z[ks], au[v]);
                 }
             }
-            if (!isA) {
-                // gate values (fp32) -> exchange buffer of this stage; piece q of the lane at q*1 KiB + lane*16
-                uint8_t* xb = slot_x(su & 1);
+        }
+        int n_after = 0;                                // vector-memory operations allowed to stay in flight
+        if constexpr (EP && !CA) {
+            // gate values (fp32) -> exchange buffer of the block; piece q of the lane at q*1 KiB + lane*16
+            uint8_t* xb = slot_x(be & 1);
 #pragma unroll
-                for (int v = 0; v < G::NV; ++v) {
+            for (int v = 0; v < G::NV; ++v) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 g4;
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 g4;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) g4[j] = sigmoid_f(au[v][4 * q + j]);
-                        *reinterpret_cast<f32x4*>(xb + (size_t)(4 * v + q) * 1024 + lane16) = g4;
-                    }
+                    for (int j = 0; j < 4; ++j) g4[j] = sigmoid_f(au_prev[v][4 * q + j]);
+                    *reinterpret_cast<f32x4*>(xb + (size_t)(4 * v + q) * 1024 + lane16) = g4;
                 }
-            } else {
-                uint8_t* tr = slot_res(su & 1);
-                const uint8_t* xb = slot_x(su & 1);
-                float r[G::LW], o[G::LW];
-                tile_lane_vals4<IO>(tr, trow, h, r);
-#pragma unroll
-                for (int v = 0; v < G::NV; ++v) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(xb + (size_t)(4 * v + q) * 1024 + lane16);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int i = 16 * v + 4 * q + j;
-                            const float lin = s2g * r[i] + sdg * au[v][4 * q + j];
-                            o[i] = GATE_ADD ? lin + gs * g4[j] : lin * g4[j];
-                        }
-                    }
-                }
-                stage_lane_vals4<IO>(tr, trow, h, o);
-                store_rows4(out, rl, su * 128, tr, rg, lane);
-                n_after = rl.n_inst;
             }
+        }
+        if constexpr (EP && CA) {
+            uint8_t* tr = slot_res(be & 1);
+            float r[G::LW], o[G::LW];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) piece_to_f32<IO>(rraw[p], r + p * G::EPP);
+#pragma unroll
+            for (int v = 0; v < G::NV; ++v) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 g4 = gt[4 * v + q];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 16 * v + 4 * q + j;
+                        const float lin = s2g * r[i] + sdg * au_prev[v][4 * q + j];
+                        o[i] = GATE_ADD ? lin + gs * g4[j] : lin * g4[j];
+                    }
+                }
+            }
+            stage_lane_vals4<IO>(tr, trow, h, o);
+            store_rows4(out, rl, be * 128, tr, rg, lane);
+            n_after = rl.n_inst;
+        }
+        if constexpr (MM) {
+#pragma unroll
+            for (int v = 0; v < G::NV; ++v) au_prev[v] = au[v];
         }
         wait_vm(n_after);
         __builtin_amdgcn_s_barrier();
+    };
+    using T_ = BoolC<true>; using F_ = BoolC<false>;
+    // stages S .. 2S+1 for both chains (every wave passes the same number of barriers)
+    if (isA) {
+        up_stage(T_{}, F_{}, F_{}, S);                                       // (the gate chain starts one stage ahead)
+        up_stage(T_{}, T_{}, F_{}, S + 1);
+        for (int tt = S + 2; tt <= 2 * S; ++tt) up_stage(T_{}, T_{}, T_{}, tt);
+        up_stage(T_{}, F_{}, T_{}, 2 * S + 1);
+    } else {
+        up_stage(F_{}, T_{}, F_{}, S);
+        for (int tt = S + 1; tt <= 2 * S - 1; ++tt) up_stage(F_{}, T_{}, T_{}, tt);
+        up_stage(F_{}, F_{}, T_{}, 2 * S);
+        up_stage(F_{}, F_{}, F_{}, 2 * S + 1);
     }
     stamp(4);
 }
