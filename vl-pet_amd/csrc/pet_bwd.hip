@@ -95,6 +95,9 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         return (I.t0 ? 4 : 0) + (I.t1 ? 4 : 0);
     };
     auto issue_rows = [&](int s2, int from) {
+#ifdef BABL_NOROWS
+        if (s2 > 1) return;
+#endif
         if (s2 >= total || rows_deferred(s2, from)) return;
         const StageInfo I = info(s2);
         const int j = s2 % L::NR;
@@ -104,6 +107,9 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         }
     };
     auto issue_w = [&](int s1) {
+#ifdef BABL_NOW
+        if (s1 > 0) return;
+#endif
         if (s1 >= total) return;
         const StageInfo I = info(s1);
         const int64_t woff = (int64_t)I.pack * pg.pack_bytes + (int64_t)I.ss * L::SEG_KB * 1024;

@@ -30,33 +30,12 @@ struct GateLds {
     static constexpr int W_B = SEG_KB * 1024 * 2;
     static constexpr int TILE_B = RG * 32 * 128;
     static constexpr int ROW_OFF = 2 * W_B;
-    static constexpr int BIAS_OFF = ROW_OFF + 6 * TILE_B;
-    static constexpr int X_OFF = ROW_OFF + 2 * TILE_B;         // two exchange buffers of 2*TILE_B
+    static constexpr int BIAS_OFF = ROW_OFF + 6 * TILE_B;      // row area: 3 down-phase slots of [x2 tile | x1 tile]
     static size_t bytes(int d) { return (size_t)BIAS_OFF + (size_t)2 * (32 * RT + d) * 4; }
 };
 
-template <bool B> struct BoolC { static constexpr bool value = B; };
-
-// one 16-byte piece of a row tile -> fp32 (8 bf16 or 4 fp32 values)
-template <typename IO>
-__device__ __forceinline__ void piece_to_f32(const u32x4& raw, float* v) {
-    if constexpr (Geo4<IO>::NS == 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[2 * i] = __builtin_bit_cast(float, raw[i] << 16);
-            v[2 * i + 1] = __builtin_bit_cast(float, raw[i] & 0xffff0000u);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned int u = raw[i];      // (bit_cast straight from the vector-element lvalue reads element 0)
-            v[i] = __builtin_bit_cast(float, u);
-        }
-    }
-}
-
-template <typename IO, int RT, bool GATE_ADD, int RG>
-__global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
+template <typename IO, int RT, bool GATE_ADD, int RG, bool LD>
+__global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(PetFwdArgs a) {
     using G = Geo4<IO>;
     using L = GateLds<IO, RT, RG>;
     constexpr int NS = G::NS;
@@ -81,8 +60,13 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
 
     auto slot_w = [&](int j) { return smem + (size_t)j * L::W_B; };
     auto slot_d = [&](int j) { return smem + L::ROW_OFF + (size_t)j * 2 * L::TILE_B + (isA ? 0 : L::TILE_B); };
-    auto slot_res = [&](int j) { return smem + L::ROW_OFF + (size_t)j * L::TILE_B; };
-    auto slot_x = [&](int j) { return smem + L::X_OFF + (size_t)j * 2 * L::TILE_B + (size_t)rg * (G::LW * 256); };
+    // up-phase use of the row area, placed by when each down-phase slot was last read (slot (S-1)%3 at stage S-1,
+    // (S-2)%3 at S-2, S%3 at S-3): three residual tiles (block b in tile b%3) in slots S%3, S%3, (S+1)%3 and the two
+    // gate-exchange buffers (block b in buffer b&1, 16 bytes per lane and piece: 8 bf16 or 4 fp32 values) in the second
+    // half of slot (S+1)%3 and the first half of slot (S+2)%3
+    auto region = [&](int r) { return smem + L::ROW_OFF + (size_t)(r % 3) * 2 * L::TILE_B; };
+    auto slot_res = [&](int j) { return j == 0 ? region(S) : j == 1 ? region(S) + L::TILE_B : region(S + 1); };
+    auto slot_x = [&](int j) { return (j == 0 ? region(S + 1) + L::TILE_B : region(S + 2)) + (size_t)rg * 4096; };
     float* sb = reinterpret_cast<float*>(smem + L::BIAS_OFF);
     const int nb = 32 * RT + d;
 
@@ -91,7 +75,7 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
 
     // ---- weight pieces of stage t (1 KiB each, piece k of [A segment | G segment]); returns how many this wave issued
     auto issue_w = [&](int t) -> int {
-        if (t > 2 * S) return 0;
+        if (LD || t > 2 * S) return 0;
         uint8_t* dst = slot_w(t & 1);
         int n = 0;
         for (int k = wave; k < 2 * L::SEG_KB; k += NW) {
@@ -111,20 +95,74 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
     };
     // ---- row pieces issued during stage t: down rows two stages ahead; chain A's residual rows one stage ahead
     auto issue_rows = [&](int t) -> int {
+        if (LD) return 0;
         if (t + 2 < S) {
             glds_rows4(xin, rl, (t + 2) * 128, slot_d((t + 2) % 3), rg);
+            return 4;
+        }
+        if (isA && t >= S && t < 2 * S) {        // residual block su = t - S, consumed at stage t + 1
+            const int su = t - S;
+            glds_rows4(res, rl, su * 128, slot_res(su % 3), rg);
             return 4;
         }
         return 0;
     };
 
     auto stamp = [&](int k) {      // debug timestamps (VLPET_DBG & 16; lane 0 of the first chain-A wave of every block)
-        if ((a.dbg & 16) && tid == 0 && blockIdx.x < 4096) a.dbg_ts[blockIdx.x * 8 + k] = __builtin_readcyclecounter();
+        if ((a.dbg & 16) && tid == ((a.dbg & 128) ? RG * 64 : 0) && blockIdx.x < 4096) a.dbg_ts[blockIdx.x * 8 + k] = __builtin_readcyclecounter();
     };
+    if constexpr (LD) {
+        // ---- loader waves (one per row group, so one per SIMD): every global_load_lds of the workgroup.  A wave that is
+        // waiting for the memory pipe to accept its next piece costs no issue slots, so the compute waves never stall on
+        // memory issue; what must have landed at which barrier is the same protocol as without loaders.
+        if (wave >= NW) {
+            const uint8_t* x2p = reinterpret_cast<const uint8_t*>(a.xa);
+            const uint8_t* x1p = reinterpret_cast<const uint8_t*>(a.xg);
+            auto ld_w = [&](int t) {
+                if (t > 2 * S) return;
+                uint8_t* dst = slot_w(t & 1);
+                for (int k = rg; k < 2 * L::SEG_KB; k += RG) {
+                    const bool segA = k < L::SEG_KB;
+                    const int kk = segA ? k : k - L::SEG_KB;
+                    int64_t woff;
+                    if (t < S) woff = (int64_t)t * L::SEG_KB * 1024;
+                    else {
+                        const int su = segA ? t - S - 1 : t - S;
+                        if (su < 0 || su >= S) continue;
+                        woff = pg.pack_bytes + (int64_t)su * L::SEG_KB * 1024;
+                    }
+                    glds16((segA ? pkA : pkG) + woff + (size_t)kk * 1024 + lane16, dst + (size_t)k * 1024);
+                }
+            };
+            auto ld_rows = [&](int t2) {        // down-phase rows of stage t2, both chains of this row group
+                uint8_t* base = smem + L::ROW_OFF + (size_t)(t2 % 3) * 2 * L::TILE_B;
+                glds_rows4(x2p, rl, t2 * 128, base, rg);
+                glds_rows4(x1p, rl, t2 * 128, base + L::TILE_B, rg);
+            };
+            ld_w(0);
+            ld_rows(0);
+            if (S > 1) ld_rows(1);
+            __syncthreads();
+            // residual block b goes out at stage S+b-1 and is consumed at S+b+1: like the down-phase rows, the newest
+            // row pieces stay in flight across the barrier (only the weights have a prefetch distance of one stage)
+            for (int t = 0; t <= 2 * S; ++t) {
+                ld_w(t + 1);
+                int nrows = 0;
+                const int b = t - S + 1;
+                if (t + 2 < S) { ld_rows(t + 2); nrows = 8; }
+                else if (b >= 0 && b < S) { glds_rows4(res, rl, b * 128, slot_res(b % 3), rg); nrows = 4; }
+                wait_vm(nrows);
+                __builtin_amdgcn_s_barrier();
+            }
+            return;
+        }
+    }
     stamp(0);
-    issue_w(0);
-    glds_rows4(xin, rl, 0, slot_d(0), rg);
-    if (S > 1) glds_rows4(xin, rl, 128, slot_d(1), rg);
+    if constexpr (!LD) {
+        issue_w(0);
+        glds_rows4(xin, rl, 0, slot_d(0), rg);
+        if (S > 1) glds_rows4(xin, rl, 128, slot_d(1), rg);
+    }
     {   // biases -> LDS: [bdA(32RT) | buA(d) | bdG(32RT) | buG(d)]
         const float* ba = reinterpret_cast<const float*>(a.pk_a + pg.bias_off);
         const float* bg = reinterpret_cast<const float*>(a.pk_g + pg.bias_off);
@@ -139,7 +177,7 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
     for (int ct = 0; ct < RT; ++ct) acc[ct] = zero16();
     int t = 0;
     for (; t < S; ++t) {
-        if (t == 5) stamp(5);
+        if (t == 5 && !(a.dbg & 32)) stamp(5);
         issue_w(t + 1);
         const int nrows = issue_rows(t);
         const uint8_t* w = slot_w(t & 1) + (isA ? 0 : L::SEG_KB * 1024);
@@ -172,10 +210,10 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
                 for (int ct = 0; ct < RT; ++ct) acc[ct] = mfma_ns<NS>(wf[ct], b, acc[ct]);
             }
         }
-        if (t == 5) stamp(6);
+        if (t == 5 && !(a.dbg & 32)) stamp(6);
         wait_vm(nrows);
         __builtin_amdgcn_s_barrier();
-        if (t == 5) stamp(7);
+        if (t == 5 && !(a.dbg & 32)) stamp(7);
     }
     stamp(2);
 
@@ -196,58 +234,36 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
     }
 
     stamp(3);
-    // ---- up phase, software-pipelined inside each wave: the MFMAs of feature block b share a stage (one basic
-    // block) with the VALU epilogue of block b-1, which lives in other registers -- the matrix pipe works while the
-    // wave's own VALU/transcendental stream issues, instead of both waves of a SIMD doing MFMAs, then both VALU.
-    //   chain G: MFMAs of block b at stage S+b,   epilogue (sigmoid -> exchange buffer b&1) at stage S+b+1
-    //   chain A: MFMAs of block b at stage S+b+1, epilogue (residual, gate, stores)         at stage S+b+2
-    // residual rows of block b are issued at stage S+b+1 into residual slot b&1 (free since the stores of b-2).
+    // ---- up phase
     const float* bu = sb + (isA ? 0 : nb) + 32 * RT + G::LW * h;
     const float gs = a.gs;
     const float s2g = a.s2 * gs, sdg = a.sd * gs;      // gate scale folded into the linear part
-    f32x16 au_prev[G::NV];
-#pragma unroll
-    for (int v = 0; v < G::NV; ++v) au_prev[v] = zero16();
-
-    auto up_stage = [&](auto chain_c, auto mm_c, auto ep_c, int tt) {
-        constexpr bool CA = decltype(chain_c)::value, MM = decltype(mm_c)::value, EP = decltype(ep_c)::value;
-        issue_w(tt + 1);
-        const int bm = CA ? tt - S - 1 : tt - S;        // block whose MFMAs run in this stage
-        const int be = bm - 1;                          // block whose epilogue runs in this stage
-        if (CA && bm >= 0 && bm < S) glds_rows4(res, rl, bm * 128, slot_res(bm & 1), rg);
-        const uint8_t* w = slot_w(tt & 1) + (CA ? 0 : L::SEG_KB * 1024);
-        f32x16 au[G::NV];
-        Frag<NS> wf[(MM && G::NV * KT <= 12) ? G::NV * KT : 1];
-        u32x4 rraw[4];
-        f32x4 gt[4 * G::NV];
-        if constexpr (MM) {
+    for (; t <= 2 * S; ++t) {
+        if (t == S + 5 && (a.dbg & 32)) stamp(5);      // VLPET_DBG & 32: stage stamps from the up phase instead
+        issue_w(t + 1);
+        const int nrows = issue_rows(t);
+        (void)nrows;
+        const int su = isA ? t - S - 1 : t - S;
+        int n_after = 0;                                // vector-memory operations allowed to stay in flight
+        if (su >= 0 && su < S) {
+            const uint8_t* w = slot_w(t & 1) + (isA ? 0 : L::SEG_KB * 1024);
+            f32x16 au[G::NV];
 #pragma unroll
             for (int v = 0; v < G::NV; ++v) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 tb = *reinterpret_cast<const f32x4*>(bu + bm * G::FE + 16 * v + 4 * q);
+                    const f32x4 tb = *reinterpret_cast<const f32x4*>(bu + su * G::FE + 16 * v + 4 * q);
                     au[v][4 * q] = tb[0]; au[v][4 * q + 1] = tb[1]; au[v][4 * q + 2] = tb[2]; au[v][4 * q + 3] = tb[3];
                 }
             }
             if constexpr (G::NV * KT <= 12) {
+                Frag<NS> wf[G::NV * KT];
 #pragma unroll
                 for (int ks = 0; ks < KT; ++ks) {
 #pragma unroll
                     for (int v = 0; v < G::NV; ++v) wf[v * KT + ks] = wfrag<NS>(w, v * KT + ks, lane);
                 }
-            }
-        }
-        if constexpr (EP && CA) {       // operands of the epilogue: residual pieces and the gate tile, read up front
-            const uint8_t* tr = slot_res(be & 1);
-            const uint8_t* xb = slot_x(be & 1);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) rraw[p] = *reinterpret_cast<const u32x4*>(tile_piece(tr, trow, 4 * h + p));
-#pragma unroll
-            for (int i = 0; i < 4 * G::NV; ++i) gt[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)i * 1024 + lane16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MM) {
-            if constexpr (G::NV * KT <= 12) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < KT; ++ks) {
 #pragma unroll
@@ -260,78 +276,71 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_fwd_kernel(PetFwdArgs a) {
                     for (int v = 0; v < G::NV; ++v) au[v] = mfma_ns<NS>(wfrag<NS>(w, v * KT + ks, lane), z[ks], au[v]);
                 }
             }
-        }
-        int n_after = 0;                                // vector-memory operations allowed to stay in flight
-        if constexpr (EP && !CA) {
-            // gate values (fp32) -> exchange buffer of the block; piece q of the lane at q*1 KiB + lane*16
-            uint8_t* xb = slot_x(be & 1);
+            constexpr int XE = 16 / (int)sizeof(IO);        // gate values per 16-byte exchange piece (IO precision)
+            if (!isA) {
+                // gate values -> exchange buffer of this block; piece p of the lane at p*1 KiB + lane*16
+                uint8_t* xb = slot_x(su & 1);
 #pragma unroll
-            for (int v = 0; v < G::NV; ++v) {
+                for (int p = 0; p < 4; ++p) {
+                    float g[XE];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 g4;
+                    for (int e = 0; e < XE; ++e) { const int i = XE * p + e; g[e] = sigmoid_f(au[i >> 4][i & 15]); }
+                    if constexpr (NS == 1) {
+                        bf16x8 pk;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) g4[j] = sigmoid_f(au_prev[v][4 * q + j]);
-                    *reinterpret_cast<f32x4*>(xb + (size_t)(4 * v + q) * 1024 + lane16) = g4;
-                }
-            }
-        }
-        if constexpr (EP && CA) {
-            uint8_t* tr = slot_res(be & 1);
-            float r[G::LW], o[G::LW];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) piece_to_f32<IO>(rraw[p], r + p * G::EPP);
-#pragma unroll
-            for (int v = 0; v < G::NV; ++v) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 g4 = gt[4 * v + q];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int i = 16 * v + 4 * q + j;
-                        const float lin = s2g * r[i] + sdg * au_prev[v][4 * q + j];
-                        o[i] = GATE_ADD ? lin + gs * g4[j] : lin * g4[j];
+                        for (int e = 0; e < 8; ++e) pk[e] = (__bf16)g[e];
+                        *reinterpret_cast<bf16x8*>(xb + (size_t)p * 1024 + lane16) = pk;
+                    } else {
+                        const f32x4 pk = {g[0], g[1], g[2], g[3]};
+                        *reinterpret_cast<f32x4*>(xb + (size_t)p * 1024 + lane16) = pk;
                     }
                 }
-            }
-            stage_lane_vals4<IO>(tr, trow, h, o);
-            store_rows4(out, rl, be * 128, tr, rg, lane);
-            n_after = rl.n_inst;
-        }
-        if constexpr (MM) {
+            } else {
+                uint8_t* tr = slot_res(su % 3);
+                const uint8_t* xb = slot_x(su & 1);
+                float r[G::LW], o[G::LW], gv[G::LW];
+                tile_lane_vals4<IO>(tr, trow, h, r);
 #pragma unroll
-            for (int v = 0; v < G::NV; ++v) au_prev[v] = au[v];
+                for (int p = 0; p < 4; ++p) {
+                    if constexpr (NS == 1) {
+                        const bf16x8 pk = *reinterpret_cast<const bf16x8*>(xb + (size_t)p * 1024 + lane16);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gv[8 * p + e] = (float)pk[e];
+                    } else {
+                        const f32x4 pk = *reinterpret_cast<const f32x4*>(xb + (size_t)p * 1024 + lane16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gv[4 * p + e] = pk[e];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < G::LW; ++i) {
+                    const float lin = s2g * r[i] + sdg * au[i >> 4][i & 15];
+                    o[i] = GATE_ADD ? lin + gs * gv[i] : lin * gv[i];
+                }
+                stage_lane_vals4<IO>(tr, trow, h, o);
+                store_rows4(out, rl, su * 128, tr, rg, lane);
+                n_after = rl.n_inst;
+            }
         }
+        if (t == S + 5 && (a.dbg & 32)) stamp(6);
         wait_vm(n_after);
         __builtin_amdgcn_s_barrier();
-    };
-    using T_ = BoolC<true>; using F_ = BoolC<false>;
-    // stages S .. 2S+1 for both chains (every wave passes the same number of barriers)
-    if (isA) {
-        up_stage(T_{}, F_{}, F_{}, S);                                       // (the gate chain starts one stage ahead)
-        up_stage(T_{}, T_{}, F_{}, S + 1);
-        for (int tt = S + 2; tt <= 2 * S; ++tt) up_stage(T_{}, T_{}, T_{}, tt);
-        up_stage(T_{}, F_{}, T_{}, 2 * S + 1);
-    } else {
-        up_stage(F_{}, T_{}, F_{}, S);
-        for (int tt = S + 1; tt <= 2 * S - 1; ++tt) up_stage(F_{}, T_{}, T_{}, tt);
-        up_stage(F_{}, F_{}, T_{}, 2 * S);
-        up_stage(F_{}, F_{}, F_{}, 2 * S + 1);
+        if (t == S + 5 && (a.dbg & 32)) stamp(7);
     }
     stamp(4);
 }
 
-template <typename IO, int RT, bool GATE_ADD, int RG>
+template <typename IO, int RT, bool GATE_ADD, int RG, bool LD>
 static hipError_t launch_one(const PetFwdArgs& a, hipStream_t stream) {
     using L = GateLds<IO, RT, RG>;
     const size_t lds = L::bytes(a.d);
-    auto kern = pet_gate_fwd_kernel<IO, RT, GATE_ADD, RG>;
+    auto kern = pet_gate_fwd_kernel<IO, RT, GATE_ADD, RG, LD>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int rows = RG * 32;
     const int blocks = (int)((a.M + rows - 1) / rows);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(RG * 128), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3((LD ? 3 : 2) * RG * 64), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -340,9 +349,9 @@ static hipError_t launch_rt(const PetFwdArgs& a, hipStream_t stream) {
     const bool add = a.flags & PET_GATE_ADD;
     // 4 row groups (128 rows, 8 waves) unless the rings would not fit the 160 KiB LDS
     if constexpr (GateLds<IO, RT, 4>::BIAS_OFF + 8 * 1024 <= 160 * 1024)
-        return add ? launch_one<IO, RT, true, 4>(a, stream) : launch_one<IO, RT, false, 4>(a, stream);
+        return add ? launch_one<IO, RT, true, 4, true>(a, stream) : launch_one<IO, RT, false, 4, true>(a, stream);
     else
-        return add ? launch_one<IO, RT, true, 2>(a, stream) : launch_one<IO, RT, false, 2>(a, stream);
+        return add ? launch_one<IO, RT, true, 2, false>(a, stream) : launch_one<IO, RT, false, 2, false>(a, stream);
 }
 
 template <typename IO>
