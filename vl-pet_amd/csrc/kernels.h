@@ -1,5 +1,6 @@
 // Internal kernel argument blocks and launchers (the public C ABI is include/vlpet_hip.h).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -177,4 +178,24 @@ struct AdamwArgs {
 hipError_t launch_sumsq(const float* g, int64_t n, float* partials, hipStream_t stream);
 hipError_t launch_adamw(const AdamwArgs& a, hipStream_t stream);
 int optim_blocks(int64_t n);
+
+// Row groups (32 rows each) per workgroup.  One workgroup per CU is resident (LDS), a workgroup's time is
+// roughly (rows + a fixed part for the weight stream and the prologue), and the chip takes the workgroups in
+// rounds of 256: pick the size with the cheapest rounds x (RG + 1).  At M = 46,648 that is 3 (486 workgroups,
+// two rounds of 96 rows instead of two of 128); at M = 15,272 it is 2 (239 workgroups in one round instead of
+// 120 CUs working and 136 idle).
+inline int pick_row_groups(int64_t M, int max_rg, int min_rg) {
+    if (const char* e = getenv("VLPET_RG")) {          // experiments: force the workgroup size
+        const int rg = atoi(e);
+        if (rg >= min_rg && rg <= max_rg) return rg;
+    }
+    int best = max_rg;
+    int64_t best_cost = -1;
+    for (int rg = max_rg; rg >= min_rg; --rg) {
+        const int64_t wgs = (M + 32 * rg - 1) / (32 * rg);
+        const int64_t cost = ((wgs + 255) / 256) * (rg + 1);
+        if (best_cost < 0 || cost < best_cost) { best = rg; best_cost = cost; }
+    }
+    return best;
+}
 

@@ -418,10 +418,15 @@ static hipError_t launch_one(const PetBwdArgs& a, hipStream_t stream) {
 
 template <typename IO, int RT, bool GATE, bool ACT_ID, bool DROP>
 static hipError_t launch_waves(const PetBwdArgs& a, hipStream_t stream) {
-    if constexpr (BwdLds<IO, RT, GATE, 4>::BIAS_OFF + 8 * 1024 <= 160 * 1024)
-        return launch_one<IO, RT, GATE, ACT_ID, DROP, 4>(a, stream);
-    else
+    if constexpr (BwdLds<IO, RT, GATE, 4>::BIAS_OFF + 8 * 1024 <= 160 * 1024) {
+        switch (pick_row_groups(a.M, 4, 2)) {       // rows per workgroup by rounds of 256 workgroups (kernels.h)
+            case 4: return launch_one<IO, RT, GATE, ACT_ID, DROP, 4>(a, stream);
+            case 3: return launch_one<IO, RT, GATE, ACT_ID, DROP, 3>(a, stream);
+            default: return launch_one<IO, RT, GATE, ACT_ID, DROP, 2>(a, stream);
+        }
+    } else {
         return launch_one<IO, RT, GATE, ACT_ID, DROP, 2>(a, stream);
+    }
 }
 
 template <typename IO, int RT>

@@ -347,11 +347,16 @@ static hipError_t launch_one(const PetFwdArgs& a, hipStream_t stream) {
 template <typename IO, int RT>
 static hipError_t launch_rt(const PetFwdArgs& a, hipStream_t stream) {
     const bool add = a.flags & PET_GATE_ADD;
-    // 4 row groups (128 rows, 8 waves) unless the rings would not fit the 160 KiB LDS
-    if constexpr (GateLds<IO, RT, 4>::BIAS_OFF + 8 * 1024 <= 160 * 1024)
-        return add ? launch_one<IO, RT, true, 4, true>(a, stream) : launch_one<IO, RT, false, 4, true>(a, stream);
-    else
+    // up to 4 row groups (128 rows) with loader waves unless the rings would not fit the 160 KiB LDS
+    if constexpr (GateLds<IO, RT, 4>::BIAS_OFF + 8 * 1024 <= 160 * 1024) {
+        switch (pick_row_groups(a.M, 4, 2)) {
+            case 4: return add ? launch_one<IO, RT, true, 4, true>(a, stream) : launch_one<IO, RT, false, 4, true>(a, stream);
+            case 3: return add ? launch_one<IO, RT, true, 3, true>(a, stream) : launch_one<IO, RT, false, 3, true>(a, stream);
+            default: return add ? launch_one<IO, RT, true, 2, true>(a, stream) : launch_one<IO, RT, false, 2, true>(a, stream);
+        }
+    } else {
         return add ? launch_one<IO, RT, true, 2, false>(a, stream) : launch_one<IO, RT, false, 2, false>(a, stream);
+    }
 }
 
 template <typename IO>
