@@ -61,11 +61,7 @@ __device__ __forceinline__ float gelu_new_grad_f(float x) {
     float du = VLPET_GELU_K * (1.0f + 3.0f * 0.044715f * x2);
     return s + x * s * (1.0f - s) * 2.0f * du;
 }
-#ifdef BABL_NOSIG
-__device__ __forceinline__ float sigmoid_f(float x) { return x * 0.25f + 0.5f; }
-#else
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-#endif
 
 // ---------------------------------------------------------------- conversions
 __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {

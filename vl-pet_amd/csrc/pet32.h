@@ -130,9 +130,6 @@ __device__ __forceinline__ void glds_rows4(const uint8_t* base, const RowLanes& 
 // the wave's rows of `tile` (slot order) -> whole-line stores
 __device__ __forceinline__ void store_rows4(uint8_t* base, const RowLanes& rl, int so, const uint8_t* tile,
                                             int wave, int lane) {
-#ifdef BABL_NOSTORE
-    return;
-#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(tile + ((size_t)(32 * wave + 8 * i + (lane >> 3)) * 8 + (lane & 7)) * 16);
@@ -142,9 +139,6 @@ __device__ __forceinline__ void store_rows4(uint8_t* base, const RowLanes& rl, i
 
 __device__ __forceinline__ void wait_vm(int n) {
     // counted wait: at most n vector-memory operations of this wave may still be in flight; LDS drained
-#ifdef BABL_NOWAIT
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return;
-#endif
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
         case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
     using L = BwdLds<IO, RT, GATE, WAVES>;
     constexpr int NS = G::NS;
     constexpr int KT = 2 * RT;
+    constexpr bool PIPE = NS == 1 && RT <= 3;      // LDS fragment reads one k-step ahead (bf16 IO; fp32 IO has no registers left)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar registers and scalar branches for everything derived from it
@@ -95,9 +96,6 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         return (I.t0 ? 4 : 0) + (I.t1 ? 4 : 0);
     };
     auto issue_rows = [&](int s2, int from) {
-#ifdef BABL_NOROWS
-        if (s2 > 1) return;
-#endif
         if (s2 >= total || rows_deferred(s2, from)) return;
         const StageInfo I = info(s2);
         const int j = s2 % L::NR;
@@ -107,9 +105,6 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         }
     };
     auto issue_w = [&](int s1) {
-#ifdef BABL_NOW
-        if (s1 > 0) return;
-#endif
         if (s1 >= total) return;
         const StageInfo I = info(s1);
         const int64_t woff = (int64_t)I.pack * pg.pack_bytes + (int64_t)I.ss * L::SEG_KB * 1024;
@@ -151,11 +146,33 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         const uint8_t* w = slot_w(s & 1);
         const uint8_t* ta = slot_t0(s % L::NR);
         const uint8_t* tg = slot_t1(s % L::NR);
-        // fragments are read where they are used (k-step by k-step): a handful of live fragment registers instead
-        // of a whole stage's worth, which kept this kernel at 512 registers with spills
+        // k-steps are software-pipelined: the LDS fragments of k-step u+1 are requested before the MFMAs of k-step u
+        // (a lone wave per SIMD has nobody else to hide the LDS latency behind; left alone, hipcc issues each read
+        // right before its use and waits for it).  One k-step ahead, not a whole stage: the kernel is at 512 registers.
+        struct KFr { Frag<NS> bA, bG, wA[RT], wG[GATE ? RT : 1]; };
+        auto load_k = [&](int u) {
+            KFr f;
+            f.bA = tile_bfrag4<IO>(ta, trow, h, u);
+            if constexpr (GATE) f.bG = tile_bfrag4<IO>(tg, trow, h, u);
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct) {
+                f.wA[ct] = wfrag<NS>(w, u * RT + ct, lane);
+                if constexpr (GATE) f.wG[ct] = wfrag<NS>(w, L::SEG_FR + u * RT + ct, lane);
+            }
+            return f;
+        };
+        KFr cur;
+                if constexpr (PIPE) cur = load_k(0);
 #pragma unroll
         for (int u = 0; u < G::KU; ++u) {
-            Frag<NS> bA = tile_bfrag4<IO>(ta, trow, h, u);
+            KFr nxt;
+            if constexpr (PIPE) {
+                if (u + 1 < G::KU) nxt = load_k(u + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                cur = load_k(u);
+            }
+            Frag<NS> bA = cur.bA;
             if constexpr (DROP) {
                 const uint64_t kp = *reinterpret_cast<const uint64_t*>(a.keep + grow * d + s * G::FE + 16 * u + 8 * h);
                 float v[8];
@@ -168,12 +185,11 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
                 bA = frag_from_f32<NS>(v);
             }
 #pragma unroll
-            for (int ct = 0; ct < RT; ++ct) accA[ct] = mfma_ns<NS>(wfrag<NS>(w, u * RT + ct, lane), bA, accA[ct]);
-            if constexpr (GATE) {
-                const Frag<NS> bG = tile_bfrag4<IO>(tg, trow, h, u);
-#pragma unroll
-                for (int ct = 0; ct < RT; ++ct) accG[ct] = mfma_ns<NS>(wfrag<NS>(w, L::SEG_FR + u * RT + ct, lane), bG, accG[ct]);
+            for (int ct = 0; ct < RT; ++ct) {
+                accA[ct] = mfma_ns<NS>(cur.wA[ct], bA, accA[ct]);
+                if constexpr (GATE) accG[ct] = mfma_ns<NS>(cur.wG[ct], cur.bG, accG[ct]);
             }
+            if constexpr (PIPE) { if (u + 1 < G::KU) cur = nxt; }
         }
         wait_vm(rows_count(s + 2, s));
         __builtin_amdgcn_s_barrier();
@@ -242,12 +258,34 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
                     for (int c = 0; c < 4; ++c) { aA[v][4 * q + c] = ta[c]; aG[v][4 * q + c] = tg[c]; }
                 }
             }
+            {   // weight fragments one k-step ahead of their MFMAs (see phase 1)
+                struct UFr { Frag<NS> wA[G::NV], wG[G::NV]; };
+                auto load_u = [&](int ks) {
+                    UFr f;
 #pragma unroll
-            for (int ks = 0; ks < KT; ++ks) {
+                    for (int v = 0; v < G::NV; ++v) {
+                        f.wG[v] = wfrag<NS>(w, L::SEG_FR + v * KT + ks, lane);
+                        f.wA[v] = wfrag<NS>(w, v * KT + ks, lane);
+                    }
+                    return f;
+                };
+                UFr cur;
+                if constexpr (PIPE) cur = load_u(0);
 #pragma unroll
-                for (int v = 0; v < G::NV; ++v) {
-                    aG[v] = mfma_ns<NS>(wfrag<NS>(w, L::SEG_FR + v * KT + ks, lane), zG[ks], aG[v]);
-                    aA[v] = mfma_ns<NS>(wfrag<NS>(w, v * KT + ks, lane), zA[ks], aA[v]);
+                for (int ks = 0; ks < KT; ++ks) {
+                    UFr nxt;
+                    if constexpr (PIPE) {
+                        if (ks + 1 < KT) nxt = load_u(ks + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        cur = load_u(ks);
+                    }
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) {
+                        aG[v] = mfma_ns<NS>(cur.wG[v], zG[ks], aG[v]);
+                        aA[v] = mfma_ns<NS>(cur.wA[v], zA[ks], aA[v]);
+                    }
+                    if constexpr (PIPE) { if (ks + 1 < KT) cur = nxt; }
                 }
             }
             // elementwise backward in fragment-sized steps (8 features): dh / dq are staged in place of the res / dy
@@ -291,12 +329,34 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < G::E4; ++e) dfA[e] = frag_from_f32<NS>(dyv + 8 * e);
             }
+            {
+                struct CFr { Frag<NS> wA[RT], wG[GATE ? RT : 1]; };
+                auto load_c = [&](int e) {
+                    CFr f;
 #pragma unroll
-            for (int e = 0; e < G::E4; ++e) {
+                    for (int ct = 0; ct < RT; ++ct) {
+                        f.wA[ct] = wfrag<NS>(w, e * RT + ct, lane);
+                        if constexpr (GATE) f.wG[ct] = wfrag<NS>(w, L::SEG_FR + e * RT + ct, lane);
+                    }
+                    return f;
+                };
+                CFr cur;
+                if constexpr (PIPE) cur = load_c(0);
 #pragma unroll
-                for (int ct = 0; ct < RT; ++ct) {
-                    dzA[ct] = mfma_ns<NS>(wfrag<NS>(w, e * RT + ct, lane), dfA[e], dzA[ct]);
-                    if constexpr (GATE) dzG[ct] = mfma_ns<NS>(wfrag<NS>(w, L::SEG_FR + e * RT + ct, lane), dfG[e], dzG[ct]);
+                for (int e = 0; e < G::E4; ++e) {
+                    CFr nxt;
+                    if constexpr (PIPE) {
+                        if (e + 1 < G::E4) nxt = load_c(e + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        cur = load_c(e);
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < RT; ++ct) {
+                        dzA[ct] = mfma_ns<NS>(cur.wA[ct], dfA[e], dzA[ct]);
+                        if constexpr (GATE) dzG[ct] = mfma_ns<NS>(cur.wG[ct], dfG[e], dzG[ct]);
+                    }
+                    if constexpr (PIPE) { if (e + 1 < G::E4) cur = nxt; }
                 }
             }
             wait_vm(rows_count(s + 2, s));
@@ -365,12 +425,34 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         f32x16 aA[G::NV], aG[G::NV];
 #pragma unroll
         for (int v = 0; v < G::NV; ++v) { aA[v] = zero16(); aG[v] = zero16(); }
+        {
+            struct DFr { Frag<NS> wA[G::NV], wG[GATE ? G::NV : 1]; };
+            auto load_d = [&](int ks) {
+                DFr f;
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) {
+                for (int v = 0; v < G::NV; ++v) {
+                    f.wA[v] = wfrag<NS>(w, v * KT + ks, lane);
+                    if constexpr (GATE) f.wG[v] = wfrag<NS>(w, L::SEG_FR + v * KT + ks, lane);
+                }
+                return f;
+            };
+            DFr cur;
+                if constexpr (PIPE) cur = load_d(0);
 #pragma unroll
-            for (int v = 0; v < G::NV; ++v) {
-                aA[v] = mfma_ns<NS>(wfrag<NS>(w, v * KT + ks, lane), dpA[ks], aA[v]);
-                if constexpr (GATE) aG[v] = mfma_ns<NS>(wfrag<NS>(w, L::SEG_FR + v * KT + ks, lane), dpG[ks], aG[v]);
+            for (int ks = 0; ks < KT; ++ks) {
+                DFr nxt;
+                if constexpr (PIPE) {
+                    if (ks + 1 < KT) nxt = load_d(ks + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    cur = load_d(ks);
+                }
+#pragma unroll
+                for (int v = 0; v < G::NV; ++v) {
+                    aA[v] = mfma_ns<NS>(cur.wA[v], dpA[ks], aA[v]);
+                    if constexpr (GATE) aG[v] = mfma_ns<NS>(cur.wG[v], dpG[ks], aG[v]);
+                }
+                if constexpr (PIPE) { if (ks + 1 < KT) cur = nxt; }
             }
         }
         uint64_t kp[4] = {0, 0, 0, 0};

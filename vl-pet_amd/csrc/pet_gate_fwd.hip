@@ -108,8 +108,15 @@ __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(Pe
         return 0;
     };
 
-    auto stamp = [&](int k) {      // debug timestamps (VLPET_DBG & 16; lane 0 of the first chain-A wave of every block)
+    // debug timestamps (build with -DVLPET_STAMPS, run with VLPET_DBG & 16; lane 0 of the first chain-A wave -- or, with
+    // VLPET_DBG & 128, the first chain-G wave -- of every block).  Compiled out by default: an s_memtime anywhere in a
+    // loop makes hipcc fall back to s_waitcnt lgkmcnt(0) for every LDS read in it (scalar-memory returns are unordered).
+    auto stamp = [&](int k) {
+#ifdef VLPET_STAMPS
         if ((a.dbg & 16) && tid == ((a.dbg & 128) ? RG * 64 : 0) && blockIdx.x < 4096) a.dbg_ts[blockIdx.x * 8 + k] = __builtin_readcyclecounter();
+#else
+        (void)k;
+#endif
     };
     if constexpr (LD) {
         // ---- loader waves (one per row group, so one per SIMD): every global_load_lds of the workgroup.  A wave that is
