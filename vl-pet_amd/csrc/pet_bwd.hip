@@ -16,6 +16,8 @@
 //   no gate:  [down A + xa] x S        [ up_t A + dy ] x S                      [down_t A] x S
 // The dh rows of the last phase are re-read from the dh side product this workgroup stored itself;
 // they are not prefetched across the phase boundary (the stores must have completed first).
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 #include "pet32.h"
@@ -33,6 +35,14 @@ struct BwdLds {
     static constexpr int BIAS_OFF = ROW_OFF + NR * ROW_B;
     static size_t bytes(int d) { return (size_t)BIAS_OFF + (size_t)2 * (32 * RT + d) * 4; }
 };
+
+#ifdef VLPET_STAMPS
+// diagnosis build only (-DVLPET_STAMPS): cycle stamps of wave 0 of workgroup 0, printed after the launch when VLPET_DBG & 16
+__device__ unsigned long long g_bwd_ts[64];
+#define BSTAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bwd_ts[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BSTAMP(k) do { } while (0)
+#endif
 
 template <typename IO, int RT, bool GATE, bool ACT_ID, bool DROP, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
@@ -104,19 +114,78 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
             if (I.t1) glds_rows4(I.t1, rl, I.ss * 128, slot_t1(j), wave);
         }
     };
+    // weight pieces of stage s1: this wave's share is pieces wave, wave+WAVES, ... of each segment.  The per-piece
+    // address work is what a memory instruction costs here (stamps: 90-150 cycles per global_load_lds with the piece
+    // index decoded inside the loop, mostly scalar address arithmetic), so: one scalar base per segment and stage, one
+    // per-lane offset computed once, constant strides.
+    const uint32_t wv_off = (uint32_t)(wave * 1024 + lane16);
     auto issue_w = [&](int s1) {
         if (s1 >= total) return;
         const StageInfo I = info(s1);
         const int64_t woff = (int64_t)I.pack * pg.pack_bytes + (int64_t)I.ss * L::SEG_KB * 1024;
-        uint8_t* dst = slot_w(s1 & 1);
-        constexpr int KB = L::SEG_KB * (GATE ? 2 : 1);
-        for (int k = wave; k < KB; k += WAVES) {
-            const uint8_t* src = (k < L::SEG_KB ? pkA + woff + (size_t)k * 1024
-                                                : pkG + woff + (size_t)(k - L::SEG_KB) * 1024) + lane16;
-            glds16(src, dst + (size_t)k * 1024);
+        uint8_t* dst = slot_w(s1 & 1) + wave * 1024;
+        if constexpr (L::SEG_KB % WAVES == 0) {
+            const uint8_t* bA = pkA + woff;
+            const uint8_t* bG = pkG + woff;
+#pragma unroll
+            for (int j = 0; j < L::SEG_KB / WAVES; ++j) glds16(bA + (wv_off + j * WAVES * 1024), dst + j * WAVES * 1024);
+            if constexpr (GATE) {
+#pragma unroll
+                for (int j = 0; j < L::SEG_KB / WAVES; ++j)
+                    glds16(bG + (wv_off + j * WAVES * 1024), dst + L::SEG_KB * 1024 + j * WAVES * 1024);
+            }
+        } else {
+            constexpr int KB = L::SEG_KB * (GATE ? 2 : 1);
+            for (int k = wave; k < KB; k += WAVES) {
+                const uint8_t* src = (k < L::SEG_KB ? pkA + woff + (size_t)k * 1024
+                                                    : pkG + woff + (size_t)(k - L::SEG_KB) * 1024) + lane16;
+                glds16(src, dst - wave * 1024 + (size_t)k * 1024);
+            }
         }
     };
 
+    // ---- the memory instructions of a stage as one flat list (weights of stage s+1, then rows of stage s+2: the order
+    // the counted vmcnt waits rely on) with every address precomputed per stage.  The texture path takes one 1 KiB piece
+    // per ~16 cycles and four waves feed it, so a wave's 14-20 pieces cost it >= 0.9-1.3 k cycles per stage however they
+    // are placed: handing them out between the MFMA groups was measured 3 % SLOWER than issuing them up front (in-order
+    // issue: the MFMAs behind a blocked global_load_lds wait with it).
+    constexpr int PW = (L::SEG_KB % WAVES == 0) ? L::SEG_KB / WAVES : 0;      // weight pieces per segment and wave
+    constexpr int NWP = PW * (GATE ? 2 : 1);
+    constexpr int NPIECE = NWP + (GATE ? 8 : 4);
+    struct Plan { const uint8_t* wA; const uint8_t* wG; uint8_t* wd; const uint8_t* r0; const uint8_t* r1; uint8_t* d0; uint8_t* d1; };
+    auto plan = [&](int sc) {          // what stage sc issues
+        Plan P{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if constexpr (PW == 0) { issue_w(sc + 1); issue_rows(sc + 2, sc); return P; }
+        if (sc + 1 < total) {
+            const StageInfo I = info(sc + 1);
+            const int64_t woff = (int64_t)I.pack * pg.pack_bytes + (int64_t)I.ss * L::SEG_KB * 1024;
+            P.wA = pkA + woff; P.wG = pkG + woff;
+            P.wd = slot_w((sc + 1) & 1) + wave * 1024;
+        }
+        if (sc + 2 < total && !rows_deferred(sc + 2, sc)) {
+            const StageInfo I = info(sc + 2);
+            const int j = (sc + 2) % L::NR;
+            if (I.t0) { P.r0 = I.t0 + I.ss * 128; P.d0 = slot_t0(j) + (size_t)(32 * wave) * 128; }
+            if constexpr (GATE) { if (I.t1) { P.r1 = I.t1 + I.ss * 128; P.d1 = slot_t1(j) + (size_t)(32 * wave) * 128; } }
+        }
+        return P;
+    };
+    auto emit = [&](const Plan& P, int lo, int hi) {       // pieces lo .. hi-1 of the stage's list
+        if constexpr (PW == 0) return;
+#pragma unroll
+        for (int i = lo; i < hi && i < NPIECE; ++i) {
+            if (i < NWP) {
+                const int seg = i / (PW > 0 ? PW : 1), j = i % (PW > 0 ? PW : 1);
+                if (P.wd) glds16((seg ? P.wG : P.wA) + (wv_off + j * WAVES * 1024), P.wd + seg * L::SEG_KB * 1024 + j * WAVES * 1024);
+            } else {
+                const int k = (i - NWP) / 4, q = (i - NWP) % 4;
+                const uint8_t* base = k ? P.r1 : P.r0;
+                uint8_t* dst = k ? P.d1 : P.d0;
+                if (base) glds16(base + rl.off[q], dst + q * 1024);
+            }
+        }
+    };
+    BSTAMP(0);
     issue_w(0);
     issue_rows(0, 0);
     issue_rows(1, 0);
@@ -140,9 +209,12 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         for (int ct = 0; ct < RT; ++ct) accG[ct] = zero16();
     }
     int s = 0;
+    BSTAMP(1);
     for (; s < S; ++s) {
-        issue_w(s + 1);
-        issue_rows(s + 2, s);
+        if (s == 5) BSTAMP(8);
+        const Plan pl = plan(s);
+        emit(pl, 0, NPIECE);
+        if (s == 5) BSTAMP(9);
         const uint8_t* w = slot_w(s & 1);
         const uint8_t* ta = slot_t0(s % L::NR);
         const uint8_t* tg = slot_t1(s % L::NR);
@@ -191,9 +263,13 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
             }
             if constexpr (PIPE) { if (u + 1 < G::KU) cur = nxt; }
         }
+        if (s == 5) BSTAMP(10);
         wait_vm(rows_count(s + 2, s));
+        if (s == 5) BSTAMP(11);
         __builtin_amdgcn_s_barrier();
+        if (s == 5) BSTAMP(12);
     }
+    BSTAMP(2);
 
     // z = act(pre) as B fragments; accA / accG are overwritten with act'(pre)
     Frag<NS> zA[KT];
@@ -239,11 +315,14 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
 #pragma unroll
         for (int ct = 0; ct < RT; ++ct) dzG[ct] = zero16();
     }
+    BSTAMP(3);
     for (int su = 0; su < S; ++su) {
         Frag<NS> dfA[G::E4], dfG[G::E4];
         if constexpr (GATE) {
-            issue_w(s + 1);
-            issue_rows(s + 2, s);
+            if (su == 5) BSTAMP(16);
+            const Plan pl = plan(s);
+        emit(pl, 0, NPIECE);
+            if (su == 5) BSTAMP(17);
             const uint8_t* w = slot_w(s & 1);
             uint8_t* t0 = slot_t0(s % L::NR);
             uint8_t* t1 = slot_t1(s % L::NR);
@@ -288,6 +367,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
                     if constexpr (PIPE) { if (ks + 1 < KT) cur = nxt; }
                 }
             }
+            if (su == 5) BSTAMP(18);
             // elementwise backward in fragment-sized steps (8 features): dh / dq are staged in place of the res / dy
             // rows of this wave and become the B fragments of the feature contraction
 #pragma unroll
@@ -311,15 +391,19 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
                 dfA[e] = frag_from_f32<NS>(dd8);
                 dfG[e] = frag_from_f32<NS>(dq8);
             }
+            if (su == 5) BSTAMP(19);
             store_rows4(DH, rl, su * 128, t0, wave, lane);
             store_rows4(DQ, rl, su * 128, t1, wave, lane);
+            if (su == 5) BSTAMP(20);
             wait_vm(rows_count(s + 2, s) + 2 * rl.n_inst);
+            if (su == 5) BSTAMP(21);
             __builtin_amdgcn_s_barrier();
+            if (su == 5) BSTAMP(22);
             ++s;
         }
         {
-            issue_w(s + 1);
-            issue_rows(s + 2, s);
+            const Plan pl = plan(s);
+        emit(pl, 0, NPIECE);
             const uint8_t* w = slot_w(s & 1);
             if constexpr (!GATE) {
                 float dyv[G::LW];
@@ -359,11 +443,14 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
                     if constexpr (PIPE) { if (e + 1 < G::E4) cur = nxt; }
                 }
             }
+            if (su == 5) BSTAMP(23);
             wait_vm(rows_count(s + 2, s));
             __builtin_amdgcn_s_barrier();
+            if (su == 5) BSTAMP(24);
             ++s;
         }
     }
+    BSTAMP(4);
 
     // ---- dpre = dz * act'(pre); row-major side products for the weight-gradient kernel
     const int ldz = 32 * RT;
@@ -415,10 +502,11 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         issue_rows(P3 + 1, P3);
         wait_vm(rows_count(P3 + 1, P3));
     }
+    BSTAMP(5);
     for (int su = 0; su < S; ++su, ++s) {
-        issue_w(s + 1);
-        if (!(GATE && su == 0)) issue_rows(s + 2, s);
-        else issue_rows(s + 2, s);
+        if (su == 5) BSTAMP(32);
+        const Plan pl = plan(s);
+        emit(pl, 0, NPIECE);
         const uint8_t* w = slot_w(s & 1);
         uint8_t* t0 = slot_t0(s % L::NR);
         uint8_t* t1 = slot_t1(s % L::NR);
@@ -455,6 +543,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
                 if constexpr (PIPE) { if (ks + 1 < KT) cur = nxt; }
             }
         }
+        if (su == 5) BSTAMP(33);
         uint64_t kp[4] = {0, 0, 0, 0};
         if constexpr (DROP) {
             const uint8_t* kr = a.keep + grow * d + su * G::FE + G::LW * h;
@@ -479,9 +568,12 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         }
         store_rows4(dxa, rl, su * 128, t0, wave, lane);
         if constexpr (GATE) store_rows4(dxg, rl, su * 128, t1, wave, lane);
+        if (su == 5) BSTAMP(34);
         wait_vm(rows_count(s + 2, s) + (GATE ? 2 : 1) * rl.n_inst);
         __builtin_amdgcn_s_barrier();
+        if (su == 5) BSTAMP(35);
     }
+    BSTAMP(6);
 }
 
 template <typename IO, int RT, bool GATE, bool ACT_ID, bool DROP, int WAVES>
@@ -495,6 +587,18 @@ static hipError_t launch_one(const PetBwdArgs& a, hipStream_t stream) {
     const int rows = WAVES * 32;
     const int blocks = (int)((a.M + rows - 1) / rows);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), lds, stream, a);
+#ifdef VLPET_STAMPS
+    if (const char* e = getenv("VLPET_DBG"); e && (atoi(e) & 16) && GATE) {
+        (void)hipDeviceSynchronize();
+        unsigned long long t[64];
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_bwd_ts), sizeof(t));
+        auto d = [&](int i, int j) { return (long long)(t[j] - t[i]); };
+        fprintf(stderr, "[vlpet bwd ts] prologue=%lld phase1=%lld gelu=%lld phase2=%lld dpre=%lld phase3=%lld | p1 stage: issue=%lld mfma=%lld wait=%lld barrier=%lld | "
+                        "gate stage: issue=%lld mfma=%lld elementwise=%lld stores=%lld wait=%lld barrier=%lld contraction stage=%lld | p3 stage: issue=%lld mfma=%lld rest=%lld\n",
+                d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(5, 6), d(8, 9), d(9, 10), d(10, 11), d(11, 12),
+                d(16, 17), d(17, 18), d(18, 19), d(19, 20), d(20, 21), d(21, 22), d(22, 24), d(32, 33), d(33, 34), d(34, 35));
+    }
+#endif
     return hipGetLastError();
 }
 
