@@ -452,6 +452,13 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
     }
     BSTAMP(4);
 
+    if constexpr (GATE) {
+        // The dh rows of phase 3 are read back from the dh side product this wave stored itself: once those stores
+        // have completed, start the row stream -- it lands while the dpre block below computes and stores.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue_rows(P3, P3);
+        issue_rows(P3 + 1, P3);
+    }
     // ---- dpre = dz * act'(pre); row-major side products for the weight-gradient kernel
     const int ldz = 32 * RT;
     Frag<NS> dpA[KT];
@@ -495,12 +502,9 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
     uint8_t* dxa = reinterpret_cast<uint8_t*>(a.dxa);
     uint8_t* dxg = reinterpret_cast<uint8_t*>(a.dxg);
     if constexpr (GATE) {
-        // everything older (dh stores included) has completed at the last barrier's vmcnt(0);
-        // start the dh row stream now and wait for its first stage
+        // rows of the first two phase-3 stages and the side-product stores issued after them (a counted wait would have
+        // to know how many of those predicated stores this wave really issued)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        issue_rows(P3, P3);
-        issue_rows(P3 + 1, P3);
-        wait_vm(rows_count(P3 + 1, P3));
     }
     BSTAMP(5);
     for (int su = 0; su < S; ++su, ++s) {
