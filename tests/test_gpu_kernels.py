@@ -37,6 +37,17 @@ def test_k1_variants(dtype):
     check(C.run_k1(dtype, M=100, r=192, rg=192, delta_scale=4.0, x2_scale=0.5, gate_scale=0.3), dtype)  # T5 script
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rg", [2, 3, 4])
+def test_k1_every_workgroup_size(dtype, rg, monkeypatch):
+    # rows per workgroup are picked per launch (csrc/kernels.h pick_row_groups): 64 / 96 / 128-row workgroups of the
+    # forward (with loader waves) and the backward rows kernel, forced one by one; M leaves a ragged last workgroup
+    monkeypatch.setenv("VLPET_RG", str(rg))
+    check(C.run_k1(dtype, M=1000, d=768, r=96, rg=96, nh=4), dtype)
+    check(C.run_k1(dtype, M=333, d=128, r=16, rg=40, nh=2, gate_mode=2, gate_scale=0.3), dtype)
+    check(C.run_k2(dtype, M=777), dtype)
+
+
 def test_k1_full_size_bf16():
     # config 2 (VQA step): M = 500 * 56 rows
     check(C.run_k1(torch.bfloat16, M=28000), torch.bfloat16)
