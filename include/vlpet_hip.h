@@ -72,6 +72,17 @@ int vlpet_adapter_gate_fwd(const void* x1, const void* x2, const void* packed_a,
                            float delta_scale, float x2_scale, float gate_scale,
                            int io_dtype, vlpet_stream_t stream);
 
+/* Training form of the gated forward: also leaves the bottleneck activations the backward needs
+ * (z = gelu_new(pre) and gelu_new'(pre) of both chains, four [M, 32*tiles] tensors of the IO dtype --
+ * what torch.autograd keeps for the same lines of the reference, in a quarter of the bytes) in `saved`
+ * (vlpet_saved_bytes(M, tiles, io_dtype) bytes, 16-byte aligned).  vlpet_adapter_gate_bwd_saved then
+ * skips the recompute of the two down projections: it reads x1 not at all and x2 once. */
+size_t vlpet_saved_bytes(int64_t M, int tiles, int io_dtype);
+int vlpet_adapter_gate_fwd_save(const void* x1, const void* x2, const void* packed_a, const void* packed_g,
+                                void* out, void* saved, int64_t M, int d, int tiles, int gate_mode,
+                                float delta_scale, float x2_scale, float gate_scale,
+                                int io_dtype, vlpet_stream_t stream);
+
 size_t vlpet_bwd_workspace_bytes(int64_t M, int d, int tiles, int has_gate, int io_dtype);
 
 /* Backward of the above (torch.autograd through the same lines in the reference).  Recomputes
@@ -92,6 +103,18 @@ int vlpet_adapter_gate_bwd(const void* dy, const void* x1, const void* x2,
  * own events: phases bit 0 = row-parallel kernel (dx1, dx2 + side products in the workspace),
  * bit 1 = column-parallel weight gradients (reads the side products).  phases = 3 is the full call. */
 int vlpet_adapter_gate_bwd_phase(int phases, const void* dy, const void* x1, const void* x2,
+                                 const void* packed_a, const void* packed_g,
+                                 void* dx1, void* dx2,
+                                 float* dwd, float* dbd, float* dwu, float* dbu,
+                                 float* dwgd, float* dbgd, float* dwgu, float* dbgu,
+                                 int r, int rg, void* workspace, size_t workspace_bytes,
+                                 int64_t M, int d, int tiles, int gate_mode,
+                                 float delta_scale, float x2_scale, float gate_scale,
+                                 int io_dtype, vlpet_stream_t stream);
+
+/* vlpet_adapter_gate_bwd_phase with the activations saved by vlpet_adapter_gate_fwd_save (gated forms only; x1 is
+ * still an argument because the gate's down-weight gradient contracts it). */
+int vlpet_adapter_gate_bwd_saved(int phases, const void* dy, const void* x1, const void* x2, const void* saved,
                                  const void* packed_a, const void* packed_g,
                                  void* dx1, void* dx2,
                                  float* dwd, float* dbd, float* dwu, float* dbu,

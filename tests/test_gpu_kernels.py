@@ -48,6 +48,15 @@ def test_k1_every_workgroup_size(dtype, rg, monkeypatch):
     check(C.run_k2(dtype, M=777), dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_k1_backward_recompute_path(dtype, monkeypatch):
+    # default: the gated forward saves z / gelu' for the backward; this is the other path (backward recomputes from x1, x2)
+    import vlpet_amd.functional as F
+    monkeypatch.setattr(F, "SAVE_ACTIVATIONS", False)
+    check(C.run_k1(dtype, M=1000, d=768, r=96, rg=48, nh=4), dtype)
+    check(C.run_k1(dtype, M=130, gate_mode=2, gate_scale=0.3), dtype)
+
+
 def test_k1_full_size_bf16():
     # config 2 (VQA step): M = 500 * 56 rows
     check(C.run_k1(torch.bfloat16, M=28000), torch.bfloat16)

@@ -57,6 +57,18 @@ def main():
                                                   M, d, tiles, 1, 1.0, 1.0, 1.0, io, st); assert rc == 0
         return f
     t_rows, t_wg = timeit(bwd_ph(1)), timeit(bwd_ph(2))
+    # training form: forward saves z / gelu'(pre), backward rows kernel skips the recompute phase
+    nsv = lib.vlpet_saved_bytes(M, tiles, io)
+    sv = torch.empty(nsv, dtype=torch.uint8, device=dev)
+    def fwd_save():
+        rc = lib.vlpet_adapter_gate_fwd_save(x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(), out.data_ptr(),
+                                             sv.data_ptr(), M, d, tiles, 1, 1.0, 1.0, 1.0, io, st); assert rc == 0
+    t_fwd_s = timeit(fwd_save)
+    def bwd_saved():
+        rc = lib.vlpet_adapter_gate_bwd_saved(1, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(),
+                                              dx1.data_ptr(), dx2.data_ptr(), *[t.data_ptr() for t in G], r, r, ws.data_ptr(), nws,
+                                              M, d, tiles, 1, 1.0, 1.0, 1.0, io, st); assert rc == 0
+    t_rows_s = timeit(bwd_saved)
     def k2f():
         rc = lib.vlpet_parallel_adapter_fwd(x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), out.data_ptr(), M, d, tiles, 1.0, io, st); assert rc == 0
     t_k2 = timeit(k2f)
@@ -67,6 +79,7 @@ def main():
     print(f"K1 bwd (3 krn) : {t_bwd:8.1f} us   {bb/t_bwd/1e3:8.1f} GB/s algorithmic ({bb/1e6:.1f} MB)  frac(8TB/s)={bb/t_bwd/1e3/8000:.3f}")
     print(f"   bwd rows krn: {t_rows:8.1f} us   {bb/t_rows/1e3:8.1f} GB/s algorithmic  frac(8TB/s)={bb/t_rows/1e3/8000:.3f}")
     print(f"   bwd wgrad+fin: {t_wg:7.1f} us")
+    print(f"K1 fwd + save  : {t_fwd_s:8.1f} us   bwd rows with saved activations: {t_rows_s:8.1f} us   {bb/t_rows_s/1e3:8.1f} GB/s algorithmic  frac(8TB/s)={bb/t_rows_s/1e3/8000:.3f}")
     print(f"K2 fwd         : {t_k2:8.1f} us   {fb/t_k2/1e3:8.1f} GB/s algorithmic")
     # eager reference chain on the GPU for comparison (what the reference runs today)
     sys.path.insert(0, ROOT)

@@ -73,12 +73,25 @@ static int check_common(int64_t M, int d, int tiles, int io_dtype) {
     return 0;
 }
 
+static int gate_flags(int gate_mode, int* flags);
+
+// the forward's saved bottleneck activations: four [M, 32*tiles] IO-dtype tensors (z_a, gelu'_a, z_g, gelu'_g)
+static size_t saved_stride(int64_t M, int tiles, int io_dtype) {
+    return align256((size_t)M * 32 * tiles * (io_dtype == VLPET_F32 ? 4 : 2));
+}
+extern "C" size_t vlpet_saved_bytes(int64_t M, int tiles, int io_dtype) {
+    if (M <= 0 || !tiles_ok(tiles)) return 0;
+    return 4 * saved_stride(M, tiles, io_dtype);
+}
+
 static int run_fwd(const void* xa, const void* res, const void* xg, const void* pk_a, const void* pk_g,
                    const uint8_t* keep, float keep_scale, void* out, int64_t M, int d, int tiles,
-                   float s2, float sd, float gs, int flags, int io_dtype, vlpet_stream_t stream) {
+                   float s2, float sd, float gs, int flags, int io_dtype, vlpet_stream_t stream,
+                   void* saved = nullptr) {
     int rc = check_common(M, d, tiles, io_dtype);
     if (rc) return rc;
     if (!xa || !res || !pk_a || !out) return VLPET_E_NULL;
+    if (saved && (!(flags & PET_GATE) || !aligned16(saved))) return VLPET_E_ALIGN;
     if ((flags & PET_GATE) && (!xg || !pk_g)) return VLPET_E_NULL;
     if (!aligned16(xa) || !aligned16(res) || !aligned16(out) || !aligned16(pk_a) ||
         ((flags & PET_GATE) && (!aligned16(xg) || !aligned16(pk_g))) || (keep && !aligned16(keep)))
@@ -90,6 +103,7 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
     a.keep = keep; a.keep_scale = keep_scale;
     a.M = M; a.d = d; a.RT = tiles;
     a.s2 = s2; a.sd = sd; a.gs = gs; a.flags = flags;
+    a.save = saved; a.save_stride = (int64_t)saved_stride(M, tiles, io_dtype);
     { const char* e = getenv("VLPET_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.dbg_ts = nullptr;
     if (a.dbg & 16) {     // debug only: per-phase timestamps of wave 0 of every block, printed at the next call
@@ -129,6 +143,17 @@ extern "C" int vlpet_adapter_gate_fwd(const void* x1, const void* x2, const void
     else if (gate_mode != VLPET_GATE_NONE) return VLPET_E_SHAPE;
     return run_fwd(x2, x2, x1, packed_a, packed_g, nullptr, 1.f, out, M, d, tiles, x2_scale, delta_scale,
                    flags ? gate_scale : 1.f, flags, io_dtype, stream);
+}
+
+extern "C" int vlpet_adapter_gate_fwd_save(const void* x1, const void* x2, const void* packed_a,
+                                           const void* packed_g, void* out, void* saved, int64_t M, int d, int tiles,
+                                           int gate_mode, float delta_scale, float x2_scale, float gate_scale,
+                                           int io_dtype, vlpet_stream_t stream) {
+    int flags;
+    if (gate_flags(gate_mode, &flags) || !flags) return VLPET_E_SHAPE;      // gated forms only
+    if (!saved) return VLPET_E_NULL;
+    return run_fwd(x2, x2, x1, packed_a, packed_g, nullptr, 1.f, out, M, d, tiles, x2_scale, delta_scale,
+                   gate_scale, flags, io_dtype, stream, saved);
 }
 
 extern "C" int vlpet_parallel_adapter_fwd(const void* x, const void* y, const void* packed, void* out,
@@ -184,7 +209,8 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
                    float* dwgd, float* dbgd, float* dwgu, float* dbgu, int r, int rg,
                    void* workspace, size_t workspace_bytes, int64_t M, int d, int tiles,
                    float s2, float sd, float gs, int flags, int io_dtype, vlpet_stream_t stream,
-                   int phases = 3 /* bit0: row-parallel kernel, bit1: weight gradients */) {
+                   int phases = 3 /* bit0: row-parallel kernel, bit1: weight gradients */,
+                   const void* saved = nullptr /* vlpet_adapter_gate_fwd_save's block */) {
     int rc = check_common(M, d, tiles, io_dtype);
     if (rc) return rc;
     const bool gate = flags & PET_GATE;
@@ -210,6 +236,12 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     b.keep = keep; b.keep_scale = keep_scale;
     b.M = M; b.d = d; b.RT = tiles;
     b.s2 = s2; b.sd = sd; b.gs = gs; b.flags = flags;
+    if (saved && (!gate || !aligned16(saved))) return VLPET_E_ALIGN;
+    b.saved = saved; b.saved_stride = (int64_t)saved_stride(M, tiles, io_dtype);
+    if (saved) {        // z comes from the forward; the rows kernel does not write it
+        b.z_a = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(saved));
+        b.z_g = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(saved)) + 2 * b.saved_stride;
+    }
     if (phases & 1) {
         hipError_t e = launch_pet_bwd(b, io_dtype == VLPET_F32, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
@@ -280,6 +312,21 @@ extern "C" int vlpet_adapter_gate_bwd_phase(int phases, const void* dy, const vo
     return run_bwd(dy, x2, x2, x1, packed_a, packed_g, nullptr, 1.f, dx2, dx1, dwd, dbd, dwu, dbu,
                    dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
                    x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream, phases & 3);
+}
+
+extern "C" int vlpet_adapter_gate_bwd_saved(int phases, const void* dy, const void* x1, const void* x2, const void* saved,
+                                            const void* packed_a, const void* packed_g, void* dx1, void* dx2,
+                                            float* dwd, float* dbd, float* dwu, float* dbu,
+                                            float* dwgd, float* dbgd, float* dwgu, float* dbgu, int r, int rg,
+                                            void* workspace, size_t workspace_bytes, int64_t M, int d, int tiles,
+                                            int gate_mode, float delta_scale, float x2_scale, float gate_scale,
+                                            int io_dtype, vlpet_stream_t stream) {
+    int flags;
+    if (gate_flags(gate_mode, &flags) || !flags) return VLPET_E_SHAPE;
+    if (!dbd || !dbu || !saved || (phases & 3) == 0) return VLPET_E_NULL;
+    return run_bwd(dy, x2, x2, x1, packed_a, packed_g, nullptr, 1.f, dx2, dx1, dwd, dbd, dwu, dbu,
+                   dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
+                   x2_scale, delta_scale, gate_scale, flags, io_dtype, stream, phases & 3, saved);
 }
 
 extern "C" int vlpet_parallel_adapter_bwd(const void* dy, const void* x, const void* packed, void* dx,

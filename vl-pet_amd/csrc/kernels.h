@@ -37,6 +37,8 @@ struct PetFwdArgs {
     int d, RT;
     float s2, sd, gs;      // x2 scale, delta scale, gate scale
     int flags;
+    void* save;            // optional (gated K1, training): bottleneck activations for the backward, four [M, 32*RT] IO-dtype
+    int64_t save_stride;   //   tensors at save + k*save_stride bytes: z_a, gelu'(pre_a), z_g, gelu'(pre_g)
     int dbg;               // ablation bits (env VLPET_DBG; 0 in production): 1 no weight stream, 2 no row loads, 8 no stores, 16 timestamps
     unsigned long long* dbg_ts;   // [blocks][8] s_memtime stamps of wave 0 (only when dbg & 16)
 };
@@ -58,6 +60,8 @@ struct PetBwdArgs {
     const uint8_t* pk_g;
     const uint8_t* keep;
     float keep_scale;
+    const void* saved;      // optional (gated K1): the forward's PetFwdArgs::save block -- skips the recompute of the
+    int64_t saved_stride;   //   bottleneck activations (phase 1: no x1 / second x2 read) and the z side products
     int64_t M;
     int d, RT;
     float s2, sd, gs;

@@ -185,10 +185,13 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
             }
         }
     };
+    // with the forward's saved activations phase 1 (stages 0 .. S-1) does not exist
+    const bool use_saved = GATE && a.saved != nullptr;
+    const int S0 = use_saved ? S : 0;
     BSTAMP(0);
-    issue_w(0);
-    issue_rows(0, 0);
-    issue_rows(1, 0);
+    issue_w(S0);
+    issue_rows(S0, S0);
+    issue_rows(S0 + 1, S0);
     {
         const float* ba = reinterpret_cast<const float*>(a.pk_a + pg.bias_off);
         for (int i = tid; i < nb; i += WAVES * 64) sb[i] = ba[i];
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
 #pragma unroll
         for (int ct = 0; ct < RT; ++ct) accG[ct] = zero16();
     }
-    int s = 0;
+    int s = S0;
     BSTAMP(1);
     for (; s < S; ++s) {
         if (s == 5) BSTAMP(8);
@@ -274,29 +277,57 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
     // z = act(pre) as B fragments; accA / accG are overwritten with act'(pre)
     Frag<NS> zA[KT];
     Frag<NS> zG[GATE ? KT : 1];
-    {
-        const float* bdA = sb + 8 * h;
-        const float* bdG = sb + nb + 8 * h;
+    if (use_saved) {
+        if constexpr (GATE) {
+            const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved);
+            const int64_t ro = grow * (int64_t)(32 * RT) + 8 * h;
+            const IO* sza = reinterpret_cast<const IO*>(sv) + ro;
+            const IO* sga = reinterpret_cast<const IO*>(sv + a.saved_stride) + ro;
+            const IO* szg = reinterpret_cast<const IO*>(sv + 2 * a.saved_stride) + ro;
+            const IO* sgg = reinterpret_cast<const IO*>(sv + 3 * a.saved_stride) + ro;
 #pragma unroll
-        for (int ct = 0; ct < RT; ++ct) {
+            for (int ct = 0; ct < RT; ++ct) {
 #pragma unroll
-            for (int sh = 0; sh < 2; ++sh) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float pre = accA[ct][8 * sh + j] + bdA[32 * ct + 16 * sh + j];
-                    v[j] = ACT_ID ? pre : gelu_new_f(pre);
-                    accA[ct][8 * sh + j] = ACT_ID ? 1.0f : gelu_new_grad_f(pre);
-                }
-                zA[2 * ct + sh] = frag_from_f32<NS>(v);
-                if constexpr (GATE) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float pre = accG[ct][8 * sh + j] + bdG[32 * ct + 16 * sh + j];
-                        v[j] = gelu_new_f(pre);
-                        accG[ct][8 * sh + j] = gelu_new_grad_f(pre);
-                    }
+                for (int sh = 0; sh < 2; ++sh) {
+                    float v[8];
+                    load8_f32(sza + 32 * ct + 16 * sh, v);
+                    zA[2 * ct + sh] = frag_from_f32<NS>(v);
+                    load8_f32(szg + 32 * ct + 16 * sh, v);
                     zG[2 * ct + sh] = frag_from_f32<NS>(v);
+                    load8_f32(sga + 32 * ct + 16 * sh, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) accA[ct][8 * sh + j] = v[j];
+                    load8_f32(sgg + 32 * ct + 16 * sh, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) accG[ct][8 * sh + j] = v[j];
+                }
+            }
+        }
+    } else {
+        {
+            const float* bdA = sb + 8 * h;
+            const float* bdG = sb + nb + 8 * h;
+    #pragma unroll
+            for (int ct = 0; ct < RT; ++ct) {
+    #pragma unroll
+                for (int sh = 0; sh < 2; ++sh) {
+                    float v[8];
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float pre = accA[ct][8 * sh + j] + bdA[32 * ct + 16 * sh + j];
+                        v[j] = ACT_ID ? pre : gelu_new_f(pre);
+                        accA[ct][8 * sh + j] = ACT_ID ? 1.0f : gelu_new_grad_f(pre);
+                    }
+                    zA[2 * ct + sh] = frag_from_f32<NS>(v);
+                    if constexpr (GATE) {
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float pre = accG[ct][8 * sh + j] + bdG[32 * ct + 16 * sh + j];
+                            v[j] = gelu_new_f(pre);
+                            accG[ct][8 * sh + j] = gelu_new_grad_f(pre);
+                        }
+                        zG[2 * ct + sh] = frag_from_f32<NS>(v);
+                    }
                 }
             }
         }
@@ -478,7 +509,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
                     zv[j] = (float)zA[2 * ct + sh].p[0][j];
                     if constexpr (NS == 2) zv[j] += (float)zA[2 * ct + sh].p[1][j];
                 }
-                store8_f32(reinterpret_cast<IO*>(a.z_a) + grow * ldz + col, zv);
+                if (!use_saved) store8_f32(reinterpret_cast<IO*>(a.z_a) + grow * ldz + col, zv);
                 store8_f32(reinterpret_cast<IO*>(a.dp_a) + grow * ldz + col, v);
             }
             if constexpr (GATE) {
@@ -491,7 +522,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
                         zv[j] = (float)zG[2 * ct + sh].p[0][j];
                         if constexpr (NS == 2) zv[j] += (float)zG[2 * ct + sh].p[1][j];
                     }
-                    store8_f32(reinterpret_cast<IO*>(a.z_g) + grow * ldz + col, zv);
+                    if (!use_saved) store8_f32(reinterpret_cast<IO*>(a.z_g) + grow * ldz + col, zv);
                     store8_f32(reinterpret_cast<IO*>(a.dp_g) + grow * ldz + col, v);
                 }
             }

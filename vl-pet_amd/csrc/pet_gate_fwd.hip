@@ -228,13 +228,29 @@ __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(Pe
     Frag<NS> z[KT];
     {
         const float* bd = sb + (isA ? 0 : nb) + 8 * h;
+        // training: leave z and gelu'(pre) of this chain for the backward ([M, 32RT] each, IO dtype), which then
+        // neither recomputes the down projections nor re-reads x1 / x2 for them
+        const bool save = a.save != nullptr && row0_wave + m < a.M;
+        IO* sv_z = reinterpret_cast<IO*>(reinterpret_cast<uint8_t*>(a.save) + (isA ? 0 : 2) * a.save_stride) +
+                   (row0_wave + m) * (int64_t)(32 * RT) + 8 * h;
+        IO* sv_g = reinterpret_cast<IO*>(reinterpret_cast<uint8_t*>(a.save) + (isA ? 1 : 3) * a.save_stride) +
+                   (row0_wave + m) * (int64_t)(32 * RT) + 8 * h;
 #pragma unroll
         for (int ct = 0; ct < RT; ++ct) {
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = gelu_new_f(acc[ct][8 * sh + j] + bd[32 * ct + 16 * sh + j]);
+                for (int j = 0; j < 8; ++j) v[j] = acc[ct][8 * sh + j] + bd[32 * ct + 16 * sh + j];
+                if (save) {
+                    float g[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] = gelu_new_grad_f(v[j]);
+                    store8_f32(sv_g + 32 * ct + 16 * sh, g);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = gelu_new_f(v[j]);
+                if (save) store8_f32(sv_z + 32 * ct + 16 * sh, v);
                 z[2 * ct + sh] = frag_from_f32<NS>(v);
             }
         }

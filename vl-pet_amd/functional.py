@@ -131,6 +131,10 @@ def pack_pair(down_w: Sequence[torch.Tensor], down_b: Optional[Sequence[torch.Te
 
 # Bumped by optimizers that update parameters behind autograd's back (the fused flat-buffer AdamW writes through
 # raw pointers, which does not touch ``Tensor._version``); part of every pack-cache key.
+# keep the gated forward's bottleneck activations for the backward (vlpet_adapter_gate_fwd_save / _bwd_saved); False = the
+# backward recomputes them from x1, x2 (no extra memory between forward and backward)
+SAVE_ACTIVATIONS = True
+
 WEIGHTS_EPOCH = 0
 
 
@@ -211,11 +215,21 @@ class _AdapterGateFn(torch.autograd.Function):
         x1f = _flat(x1, d) if gate_mode != GATE_NONE else None
         M = x2f.shape[0]
         out = torch.empty_like(x2f)
-        rc = _timed("k1_fwd", M, lambda: lib.vlpet_adapter_gate_fwd(
-            _ptr(x1f), x2f.data_ptr(), pk_a.buf.data_ptr(), pk_g.buf.data_ptr() if pk_g is not None else None,
-            out.data_ptr(), M, d, pk_a.tiles, gate_mode, float(delta_scale), float(x2_scale), float(gate_scale),
-            io, _stream()))
+        # training, gated form: the forward leaves z and gelu'(pre) of both chains (4 x [M, 32*tiles], IO dtype) and the
+        # backward neither recomputes the down projections nor reads x1 / x2 for them
+        act = None
+        if SAVE_ACTIVATIONS and gate_mode != GATE_NONE and any(ctx.needs_input_grad):
+            act = torch.empty(lib.vlpet_saved_bytes(M, pk_a.tiles, io), dtype=torch.uint8, device=x2f.device)
+            rc = _timed("k1_fwd", M, lambda: lib.vlpet_adapter_gate_fwd_save(
+                _ptr(x1f), x2f.data_ptr(), pk_a.buf.data_ptr(), pk_g.buf.data_ptr(), out.data_ptr(), act.data_ptr(),
+                M, d, pk_a.tiles, gate_mode, float(delta_scale), float(x2_scale), float(gate_scale), io, _stream()))
+        else:
+            rc = _timed("k1_fwd", M, lambda: lib.vlpet_adapter_gate_fwd(
+                _ptr(x1f), x2f.data_ptr(), pk_a.buf.data_ptr(), pk_g.buf.data_ptr() if pk_g is not None else None,
+                out.data_ptr(), M, d, pk_a.tiles, gate_mode, float(delta_scale), float(x2_scale), float(gate_scale),
+                io, _stream()))
         _lib.check(rc, "vlpet_adapter_gate_fwd")
+        ctx.act = act
         ctx.save_for_backward(x1f if x1f is not None else x2f, x2f, *params)
         ctx.pk = (pk_a, pk_g)
         ctx.cfg = (n_heads, gate_mode, float(delta_scale), float(x2_scale), float(gate_scale), x2.shape,
@@ -253,21 +267,29 @@ class _AdapterGateFn(torch.autograd.Function):
                 ws.data_ptr(), nws, M, d, pk_a.tiles, gate_mode, sd, s2, gs, io, _stream())
         sinks = [s_wd, s_bd, s_wu, s_bu] + ([s_gd, s_gdb, s_gu, s_gub] if gate else [])
         side = WGRAD_STREAM if all(s is not None for s in sinks) else None
+        act = ctx.act
+
+        def phase(ph, a):       # one or both halves of the backward, with or without the forward's saved activations
+            if act is not None:
+                return lib.vlpet_adapter_gate_bwd_saved(ph, a[0], a[1], a[2], act.data_ptr(), *a[3:])
+            return lib.vlpet_adapter_gate_bwd_phase(ph, *a)
+
         if side is not None:
-            rc = _timed("k1_bwd_rows", M, lambda: lib.vlpet_adapter_gate_bwd_phase(1, *args))
+            rc = _timed("k1_bwd_rows", M, lambda: phase(1, args))
             if rc == 0:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     sargs = args[:-1] + (_stream(),)
-                    rc = _timed("k1_bwd_wgrad", M, lambda: lib.vlpet_adapter_gate_bwd_phase(2, *sargs))
-                for t in (x1f, x2f, dyf, ws, pk_a.buf) + ((pk_g.buf,) if gate else ()):
+                    rc = _timed("k1_bwd_wgrad", M, lambda: phase(2, sargs))
+                for t in (x1f, x2f, dyf, ws, pk_a.buf) + ((pk_g.buf,) if gate else ()) + ((act,) if act is not None else ()):
                     t.record_stream(side)        # the caching allocator must not recycle them under the side stream
         elif TIMER is None:
-            rc = lib.vlpet_adapter_gate_bwd(*args)
+            rc = phase(3, args)
         else:       # same work, the two halves bracketed separately
-            rc = TIMER.bracket("k1_bwd_rows", M, lambda: lib.vlpet_adapter_gate_bwd_phase(1, *args))
+            rc = TIMER.bracket("k1_bwd_rows", M, lambda: phase(1, args))
             if rc == 0:
-                rc = TIMER.bracket("k1_bwd_wgrad", M, lambda: lib.vlpet_adapter_gate_bwd_phase(2, *args))
+                rc = TIMER.bracket("k1_bwd_wgrad", M, lambda: phase(2, args))
+        ctx.act = None
         _lib.check(rc, "vlpet_adapter_gate_bwd")
         if not gate:
             # without a gate the kernel returns the adapter-branch gradient only; add the residual path
