@@ -27,7 +27,7 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s measured achievable)
 # HBM-side bytes per row of pet_bwd_kernel<bf16,3,gate> from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE;
 # profiles/r01_pmc_traffic_k1_bwd.md).  Collected with rocprofv3 --pmc in its own run, not inside this script.
-PMC_TRAFFIC_BYTES_PER_ROW = {"k1_bwd_rows": 15262.0}
+PMC_TRAFFIC_BYTES_PER_ROW = {"k1_bwd_rows": 12175.0}
 TASK_ORDER = ["vqa", "gqa", "nlvr", "caption"]
 
 
