@@ -156,3 +156,22 @@ __device__ __forceinline__ void wait_vm(int n) {
         default: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;   // n > 12: stricter is safe
     }
 }
+
+// fp32 bias vectors -> LDS with all loads of a thread in flight before the first is waited for (a plain copy loop
+// compiles to load -> vmcnt(0) -> ds_write per trip: one global latency per 256 floats, paid in every prologue)
+template <int THREADS>
+__device__ __forceinline__ void copy_bias(float* dst, const float* src, int n, int tid) {
+    for (int base = 0; base < n; base += 4 * THREADS) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k * THREADS + tid;
+            v[k] = src[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k * THREADS + tid;
+            if (i < n) dst[i] = v[k];
+        }
+    }
+}

@@ -193,12 +193,8 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
     issue_rows(S0, S0);
     issue_rows(S0 + 1, S0);
     {
-        const float* ba = reinterpret_cast<const float*>(a.pk_a + pg.bias_off);
-        for (int i = tid; i < nb; i += WAVES * 64) sb[i] = ba[i];
-        if constexpr (GATE) {
-            const float* bg = reinterpret_cast<const float*>(a.pk_g + pg.bias_off);
-            for (int i = tid; i < nb; i += WAVES * 64) sb[nb + i] = bg[i];
-        }
+        copy_bias<WAVES * 64>(sb, reinterpret_cast<const float*>(a.pk_a + pg.bias_off), nb, tid);
+        if constexpr (GATE) copy_bias<WAVES * 64>(sb + nb, reinterpret_cast<const float*>(a.pk_g + pg.bias_off), nb, tid);
     }
     __syncthreads();
 

@@ -171,9 +171,8 @@ __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(Pe
         if (S > 1) glds_rows4(xin, rl, 128, slot_d(1), rg);
     }
     {   // biases -> LDS: [bdA(32RT) | buA(d) | bdG(32RT) | buG(d)]
-        const float* ba = reinterpret_cast<const float*>(a.pk_a + pg.bias_off);
-        const float* bg = reinterpret_cast<const float*>(a.pk_g + pg.bias_off);
-        for (int i = tid; i < nb; i += NW * 64) { sb[i] = ba[i]; sb[nb + i] = bg[i]; }
+        copy_bias<NW * 64>(sb, reinterpret_cast<const float*>(a.pk_a + pg.bias_off), nb, tid);
+        copy_bias<NW * 64>(sb + nb, reinterpret_cast<const float*>(a.pk_g + pg.bias_off), nb, tid);
     }
     __syncthreads();
     stamp(1);
