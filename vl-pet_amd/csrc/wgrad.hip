@@ -497,26 +497,52 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(WgradArgs a) {
     const int t = threadIdx.x;
     if ((int)blockIdx.x < ntile) {
         const int c0 = 32 * ((int)blockIdx.x / (xc / 64)), n0 = 64 * ((int)blockIdx.x % (xc / 64));
-        float s[8];
+        // thread -> two float4 of the tile: e4 = t + 256 k, row cc = e4 / 16, columns 4 (e4 % 16) .. +3
+        f32x4 s[2];
+        s[0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[1] = s[0];
+        // four row chunks per trip, 16-byte loads: 8 independent loads in flight per thread (one 4-byte load per element
+        // and one chunk per trip was 16 serial global latencies: 27 us for a 19 MB reduction)
+        int rc = 0;
+        for (; rc + 4 <= RC; rc += 4) {
+            f32x4 v[4][2];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] = 0.f;
-        for (int rc = 0; rc < RC; ++rc) {
+            for (int q = 0; q < 4; ++q) {
+                const float* p = part + ((int64_t)(rc + q) * PR + c0) * xc + n0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int e4 = t + 256 * k;
+                    v[q][k] = *reinterpret_cast<const f32x4*>(p + (int64_t)(e4 >> 4) * xc + 4 * (e4 & 15));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s[0] += v[q][0]; s[1] += v[q][1]; }       // chunk order kept
+        }
+        for (; rc < RC; ++rc) {
             const float* p = part + ((int64_t)rc * PR + c0) * xc + n0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int e = t + 256 * k;                       // cc = e / 64, nn = e % 64
-                s[k] += p[(int64_t)(e >> 6) * xc + (e & 63)];
+            for (int k = 0; k < 2; ++k) {
+                const int e4 = t + 256 * k;
+                s[k] += *reinterpret_cast<const f32x4*>(p + (int64_t)(e4 >> 4) * xc + 4 * (e4 & 15));
             }
         }
         if (!J.transposed) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int e = t + 256 * k, cc = e >> 6, nn = e & 63;
-                if (c0 + cc < R) J.out[(int64_t)(c0 + cc) * J.ldo + n0 + nn] = s[k] * J.scale;
+            for (int k = 0; k < 2; ++k) {
+                const int e4 = t + 256 * k, cc = e4 >> 4, nn = 4 * (e4 & 15);
+                if (c0 + cc < R) {
+                    float* o = J.out + (int64_t)(c0 + cc) * J.ldo + n0 + nn;
+                    const f32x4 r4 = s[k] * J.scale;
+                    if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) *reinterpret_cast<f32x4*>(o) = r4;     // (a gradient view in the
+                    else { o[0] = r4[0]; o[1] = r4[1]; o[2] = r4[2]; o[3] = r4[3]; }                       // flat buffer may sit at any 4-byte offset)
+                }
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const int e = t + 256 * k; tile[e >> 6][e & 63] = s[k] * J.scale; }
+            for (int k = 0; k < 2; ++k) {
+                const int e4 = t + 256 * k, cc = e4 >> 4, nn = 4 * (e4 & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tile[cc][nn + j] = s[k][j] * J.scale;
+            }
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
