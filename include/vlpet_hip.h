@@ -138,6 +138,15 @@ int vlpet_parallel_adapter_bwd(const void* dy, const void* x, const void* packed
                                int64_t M, int d, int tiles, float scale,
                                int io_dtype, vlpet_stream_t stream);
 
+/* Training form of K2 (as vlpet_adapter_gate_fwd_save / _bwd_saved): the forward leaves z and gelu_new'(pre) in `saved`
+ * (the first half of a vlpet_saved_bytes(M, tiles, io_dtype) block is used), the backward starts after the recompute. */
+int vlpet_parallel_adapter_fwd_save(const void* x, const void* y, const void* packed, void* out, void* saved,
+                                    int64_t M, int d, int tiles, float scale, int io_dtype, vlpet_stream_t stream);
+int vlpet_parallel_adapter_bwd_saved(const void* dy, const void* x, const void* saved, const void* packed, void* dx,
+                                     float* dwd, float* dbd, float* dwu, float* dbu, int r,
+                                     void* workspace, size_t workspace_bytes, int64_t M, int d, int tiles,
+                                     float scale, int io_dtype, vlpet_stream_t stream);
+
 /* ---- K3: LoRA low-rank update on top of the frozen linear ---------------------------------
  * out = base + scaling * ((dropout(x) @ A^T) @ B^T),  base = F.linear(x, W, b) computed by the caller
  * replaces lora/controller.py:61-68 (the base GEMM at :59 stays a library GEMM).

@@ -55,6 +55,8 @@ def test_k1_backward_recompute_path(dtype, monkeypatch):
     monkeypatch.setattr(F, "SAVE_ACTIVATIONS", False)
     check(C.run_k1(dtype, M=1000, d=768, r=96, rg=48, nh=4), dtype)
     check(C.run_k1(dtype, M=130, gate_mode=2, gate_scale=0.3), dtype)
+    check(C.run_k2(dtype, M=333, r=8, d=64, scale=4.0), dtype)
+    check(C.run_k2(dtype), dtype)
 
 
 def test_k1_full_size_bf16():

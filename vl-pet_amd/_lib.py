@@ -46,6 +46,10 @@ SIGNATURES = {
                                            c_int, c_void_p]),
     "vlpet_parallel_adapter_bwd": (c_int, [c_void_p] * 4 + [c_void_p] * 4 + [c_int, c_void_p, c_size_t, c_int64,
                                                                              c_int, c_int, c_float, c_int, c_void_p]),
+    "vlpet_parallel_adapter_fwd_save": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                                c_float, c_int, c_void_p]),
+    "vlpet_parallel_adapter_bwd_saved": (c_int, [c_void_p] * 5 + [c_void_p] * 4 + [c_int, c_void_p, c_size_t, c_int64,
+                                                                                   c_int, c_int, c_float, c_int, c_void_p]),
     "vlpet_lora_delta_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int,
                                      c_int, c_float, c_int, c_void_p]),
     "vlpet_visproj_packed_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -91,7 +91,7 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
     int rc = check_common(M, d, tiles, io_dtype);
     if (rc) return rc;
     if (!xa || !res || !pk_a || !out) return VLPET_E_NULL;
-    if (saved && (!(flags & PET_GATE) || !aligned16(saved))) return VLPET_E_ALIGN;
+    if (saved && ((flags & PET_ACT_IDENTITY) || keep || !aligned16(saved))) return VLPET_E_ALIGN;
     if ((flags & PET_GATE) && (!xg || !pk_g)) return VLPET_E_NULL;
     if (!aligned16(xa) || !aligned16(res) || !aligned16(out) || !aligned16(pk_a) ||
         ((flags & PET_GATE) && (!aligned16(xg) || !aligned16(pk_g))) || (keep && !aligned16(keep)))
@@ -160,6 +160,13 @@ extern "C" int vlpet_parallel_adapter_fwd(const void* x, const void* y, const vo
                                           int64_t M, int d, int tiles, float scale, int io_dtype,
                                           vlpet_stream_t stream) {
     return run_fwd(x, y, nullptr, packed, nullptr, nullptr, 1.f, out, M, d, tiles, 1.f, scale, 1.f, 0, io_dtype, stream);
+}
+
+extern "C" int vlpet_parallel_adapter_fwd_save(const void* x, const void* y, const void* packed, void* out, void* saved,
+                                               int64_t M, int d, int tiles, float scale, int io_dtype,
+                                               vlpet_stream_t stream) {
+    if (!saved) return VLPET_E_NULL;
+    return run_fwd(x, y, nullptr, packed, nullptr, nullptr, 1.f, out, M, d, tiles, 1.f, scale, 1.f, 0, io_dtype, stream, saved);
 }
 
 extern "C" int vlpet_lora_delta_fwd(const void* x, const void* base, const void* packed,
@@ -236,11 +243,11 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     b.keep = keep; b.keep_scale = keep_scale;
     b.M = M; b.d = d; b.RT = tiles;
     b.s2 = s2; b.sd = sd; b.gs = gs; b.flags = flags;
-    if (saved && (!gate || !aligned16(saved))) return VLPET_E_ALIGN;
+    if (saved && ((flags & PET_ACT_IDENTITY) || keep || !aligned16(saved))) return VLPET_E_ALIGN;
     b.saved = saved; b.saved_stride = (int64_t)saved_stride(M, tiles, io_dtype);
     if (saved) {        // z comes from the forward; the rows kernel does not write it
         b.z_a = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(saved));
-        b.z_g = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(saved)) + 2 * b.saved_stride;
+        if (gate) b.z_g = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(saved)) + 2 * b.saved_stride;
     }
     if (phases & 1) {
         hipError_t e = launch_pet_bwd(b, io_dtype == VLPET_F32, (hipStream_t)stream);
@@ -337,6 +344,16 @@ extern "C" int vlpet_parallel_adapter_bwd(const void* dy, const void* x, const v
     return run_bwd(dy, x, nullptr, nullptr, packed, nullptr, nullptr, 1.f, dx, nullptr, dwd, dbd, dwu, dbu,
                    nullptr, nullptr, nullptr, nullptr, r, 0, workspace, workspace_bytes, M, d, tiles,
                    1.f, scale, 1.f, 0, io_dtype, stream);
+}
+
+extern "C" int vlpet_parallel_adapter_bwd_saved(const void* dy, const void* x, const void* saved, const void* packed, void* dx,
+                                                float* dwd, float* dbd, float* dwu, float* dbu, int r,
+                                                void* workspace, size_t workspace_bytes, int64_t M, int d,
+                                                int tiles, float scale, int io_dtype, vlpet_stream_t stream) {
+    if (!dbd || !dbu || !saved) return VLPET_E_NULL;
+    return run_bwd(dy, x, nullptr, nullptr, packed, nullptr, nullptr, 1.f, dx, nullptr, dwd, dbd, dwu, dbu,
+                   nullptr, nullptr, nullptr, nullptr, r, 0, workspace, workspace_bytes, M, d, tiles,
+                   1.f, scale, 1.f, 0, io_dtype, stream, 3, saved);
 }
 
 extern "C" int vlpet_lora_delta_bwd(const void* dy, const void* x, const void* packed,

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         }
     };
     // with the forward's saved activations phase 1 (stages 0 .. S-1) does not exist
-    const bool use_saved = GATE && a.saved != nullptr;
+    const bool use_saved = !ACT_ID && !DROP && a.saved != nullptr;
     const int S0 = use_saved ? S : 0;
     BSTAMP(0);
     issue_w(S0);
@@ -274,25 +274,25 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
     Frag<NS> zA[KT];
     Frag<NS> zG[GATE ? KT : 1];
     if (use_saved) {
-        if constexpr (GATE) {
-            const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved);
-            const int64_t ro = grow * (int64_t)(32 * RT) + 8 * h;
-            const IO* sza = reinterpret_cast<const IO*>(sv) + ro;
-            const IO* sga = reinterpret_cast<const IO*>(sv + a.saved_stride) + ro;
-            const IO* szg = reinterpret_cast<const IO*>(sv + 2 * a.saved_stride) + ro;
-            const IO* sgg = reinterpret_cast<const IO*>(sv + 3 * a.saved_stride) + ro;
+        const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved);
+        const int64_t ro = grow * (int64_t)(32 * RT) + 8 * h;
+        const IO* sza = reinterpret_cast<const IO*>(sv) + ro;
+        const IO* sga = reinterpret_cast<const IO*>(sv + a.saved_stride) + ro;
+        const IO* szg = reinterpret_cast<const IO*>(sv + 2 * a.saved_stride) + ro;
+        const IO* sgg = reinterpret_cast<const IO*>(sv + 3 * a.saved_stride) + ro;
 #pragma unroll
-            for (int ct = 0; ct < RT; ++ct) {
+        for (int ct = 0; ct < RT; ++ct) {
 #pragma unroll
-                for (int sh = 0; sh < 2; ++sh) {
-                    float v[8];
-                    load8_f32(sza + 32 * ct + 16 * sh, v);
-                    zA[2 * ct + sh] = frag_from_f32<NS>(v);
+            for (int sh = 0; sh < 2; ++sh) {
+                float v[8];
+                load8_f32(sza + 32 * ct + 16 * sh, v);
+                zA[2 * ct + sh] = frag_from_f32<NS>(v);
+                load8_f32(sga + 32 * ct + 16 * sh, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) accA[ct][8 * sh + j] = v[j];
+                if constexpr (GATE) {
                     load8_f32(szg + 32 * ct + 16 * sh, v);
                     zG[2 * ct + sh] = frag_from_f32<NS>(v);
-                    load8_f32(sga + 32 * ct + 16 * sh, v);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) accA[ct][8 * sh + j] = v[j];
                     load8_f32(sgg + 32 * ct + 16 * sh, v);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) accG[ct][8 * sh + j] = v[j];

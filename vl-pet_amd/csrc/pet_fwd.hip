@@ -203,16 +203,26 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
     {
         const float* bdA = sb + 8 * h;
         const float* bdG = sb + nb + 8 * h;
+        // training form (kernels.h PetFwdArgs::save): z and gelu'(pre) of the adapter chain for the backward
+        const bool save = !GATE && !ACT_ID && a.save != nullptr && row0_wave + m < a.M;
+        IO* sv_z = reinterpret_cast<IO*>(a.save) + (row0_wave + m) * (int64_t)(32 * RT) + 8 * h;
+        IO* sv_g = reinterpret_cast<IO*>(reinterpret_cast<uint8_t*>(a.save) + a.save_stride) + (row0_wave + m) * (int64_t)(32 * RT) + 8 * h;
 #pragma unroll
         for (int ct = 0; ct < RT; ++ct) {
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float pre = accA[ct][8 * sh + j] + bdA[32 * ct + 16 * sh + j];
-                    v[j] = ACT_ID ? pre : gelu_new_f(pre);
+                for (int j = 0; j < 8; ++j) v[j] = accA[ct][8 * sh + j] + bdA[32 * ct + 16 * sh + j];
+                if (save) {
+                    float g[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] = gelu_new_grad_f(v[j]);
+                    store8_f32(sv_g + 32 * ct + 16 * sh, g);
                 }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ACT_ID ? v[j] : gelu_new_f(v[j]);
+                if (save) store8_f32(sv_z + 32 * ct + 16 * sh, v);
                 zA[2 * ct + sh] = frag_from_f32<NS>(v);
                 if constexpr (GATE) {
 #pragma unroll

@@ -338,9 +338,17 @@ class _ParallelAdapterFn(torch.autograd.Function):
         xf, yf = _flat(x, d), _flat(y, d)
         M = xf.shape[0]
         out = torch.empty_like(xf)
-        rc = _timed("k2_fwd", M, lambda: lib.vlpet_parallel_adapter_fwd(
-            xf.data_ptr(), yf.data_ptr(), pk.buf.data_ptr(), out.data_ptr(), M, d, pk.tiles, float(scale), io, _stream()))
+        act = None
+        if SAVE_ACTIVATIONS and any(ctx.needs_input_grad):      # training: z / gelu'(pre) for the backward (see K1)
+            act = torch.empty(lib.vlpet_saved_bytes(M, pk.tiles, io), dtype=torch.uint8, device=xf.device)
+            rc = _timed("k2_fwd", M, lambda: lib.vlpet_parallel_adapter_fwd_save(
+                xf.data_ptr(), yf.data_ptr(), pk.buf.data_ptr(), out.data_ptr(), act.data_ptr(), M, d, pk.tiles,
+                float(scale), io, _stream()))
+        else:
+            rc = _timed("k2_fwd", M, lambda: lib.vlpet_parallel_adapter_fwd(
+                xf.data_ptr(), yf.data_ptr(), pk.buf.data_ptr(), out.data_ptr(), M, d, pk.tiles, float(scale), io, _stream()))
         _lib.check(rc, "vlpet_parallel_adapter_fwd")
+        ctx.act = act
         ctx.save_for_backward(xf, wd, bd, wu, bu)
         ctx.pk, ctx.scale, ctx.shape = pk, float(scale), x.shape
         return out.view(y.shape)
@@ -361,9 +369,16 @@ class _ParallelAdapterFn(torch.autograd.Function):
         dx = torch.empty_like(xf)
         nws = lib.vlpet_bwd_workspace_bytes(M, d, pk.tiles, 0, io)
         ws = torch.empty(nws, dtype=torch.uint8, device=xf.device)
-        rc = _timed("k2_bwd", M, lambda: lib.vlpet_parallel_adapter_bwd(
-            dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), dx.data_ptr(), dwd.data_ptr(), dbd.data_ptr(),
-            dwu.data_ptr(), dbu.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, ctx.scale, io, _stream()))
+        act = ctx.act
+        if act is not None:
+            rc = _timed("k2_bwd", M, lambda: lib.vlpet_parallel_adapter_bwd_saved(
+                dyf.data_ptr(), xf.data_ptr(), act.data_ptr(), pk.buf.data_ptr(), dx.data_ptr(), dwd.data_ptr(), dbd.data_ptr(),
+                dwu.data_ptr(), dbu.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, ctx.scale, io, _stream()))
+        else:
+            rc = _timed("k2_bwd", M, lambda: lib.vlpet_parallel_adapter_bwd(
+                dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), dx.data_ptr(), dwd.data_ptr(), dbd.data_ptr(),
+                dwu.data_ptr(), dbu.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, ctx.scale, io, _stream()))
+        ctx.act = None
         _lib.check(rc, "vlpet_parallel_adapter_bwd")
         gw = _finish([(dwd, s0, wd), (dbd, s1, bd), (dwu, s2, wu)])
         gbu = _finish([(dbu, s3, bu)])[0] if bu is not None else None
