@@ -22,6 +22,8 @@
 #include "kernels.h"
 #include "pet32.h"
 
+template <bool B> struct BoolK { static constexpr bool value = B; };
+
 template <typename IO, int RT, bool GATE, int WAVES>
 struct BwdLds {
     static constexpr int NS = Geo4<IO>::NS;
@@ -396,28 +398,37 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
             }
             if (su == 5) BSTAMP(18);
             // elementwise backward in fragment-sized steps (8 features): dh / dq are staged in place of the res / dy
-            // rows of this wave and become the B fragments of the feature contraction
+            // rows of this wave and become the B fragments of the feature contraction (dh itself: the delta scale of
+            // dz = sd * Wu^T dh is applied once to dz after the phase).  The multiplicative / additive forms are two
+            // copies of the loop (a per-element select on a wave-uniform flag otherwise).
+            auto elementwise = [&](auto add_c) {
+                constexpr bool ADD = decltype(add_c)::value;
 #pragma unroll
-            for (int e = 0; e < G::E4; ++e) {
-                float r8[8], dy8[8], dh8[8], dq8[8], dd8[8];
-                tile_lane_vals8<IO>(t0, trow, h, e, r8);
-                tile_lane_vals8<IO>(t1, trow, h, e, dy8);
+                for (int e = 0; e < G::E4; ++e) {
+                    float r8[8], dy8[8], dh8[8], dq8[8];
+                    tile_lane_vals8<IO>(t0, trow, h, e, r8);
+                    tile_lane_vals8<IO>(t1, trow, h, e, dy8);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int i = 8 * e + j;
-                    const float hv = s2 * r8[j] + sd_ * aA[i >> 4][i & 15];
-                    const float gt = sigmoid_f(aG[i >> 4][i & 15]);
-                    const float dyp = gs * dy8[j];
-                    dh8[j] = gate_add ? dyp : dyp * gt;
-                    const float dg = gate_add ? dyp : dyp * hv;
-                    dq8[j] = dg * gt * (1.0f - gt);
-                    dd8[j] = sd_ * dh8[j];
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = 8 * e + j;
+                        const float gt = sigmoid_f(aG[i >> 4][i & 15]);
+                        const float dyp = gs * dy8[j];
+                        if constexpr (ADD) {
+                            dh8[j] = dyp;
+                            dq8[j] = dyp * gt * (1.0f - gt);
+                        } else {
+                            const float hv = s2 * r8[j] + sd_ * aA[i >> 4][i & 15];
+                            dh8[j] = dyp * gt;
+                            dq8[j] = dh8[j] * hv * (1.0f - gt);
+                        }
+                    }
+                    stage_lane_vals8<IO>(t0, trow, h, e, dh8);
+                    stage_lane_vals8<IO>(t1, trow, h, e, dq8);
+                    dfA[e] = frag_from_f32<NS>(dh8);
+                    dfG[e] = frag_from_f32<NS>(dq8);
                 }
-                stage_lane_vals8<IO>(t0, trow, h, e, dh8);
-                stage_lane_vals8<IO>(t1, trow, h, e, dq8);
-                dfA[e] = frag_from_f32<NS>(dd8);
-                dfG[e] = frag_from_f32<NS>(dq8);
-            }
+            };
+            if (gate_add) elementwise(BoolK<true>{}); else elementwise(BoolK<false>{});
             if (su == 5) BSTAMP(19);
             store_rows4(DH, rl, su * 128, t0, wave, lane);
             store_rows4(DQ, rl, su * 128, t1, wave, lane);
@@ -435,8 +446,6 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
             if constexpr (!GATE) {
                 float dyv[G::LW];
                 tile_lane_vals4<IO>(slot_t0(s % L::NR), trow, h, dyv);
-#pragma unroll
-                for (int i = 0; i < G::LW; ++i) dyv[i] *= sd_;
 #pragma unroll
                 for (int e = 0; e < G::E4; ++e) dfA[e] = frag_from_f32<NS>(dyv + 8 * e);
             }
@@ -497,7 +506,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
             float v[8], zv[8];
             const int col = 32 * ct + 16 * sh + 8 * h;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = dzA[ct][8 * sh + j] * accA[ct][8 * sh + j];
+            for (int j = 0; j < 8; ++j) v[j] = sd_ * dzA[ct][8 * sh + j] * accA[ct][8 * sh + j];
             dpA[2 * ct + sh] = frag_from_f32<NS>(v);
             if (row_ok) {
 #pragma unroll
