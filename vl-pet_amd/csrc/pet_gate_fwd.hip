@@ -18,6 +18,7 @@
 //     t >= S : chain G, up projection + sigmoid of block t-S (t < 2S); chain A, up projection + epilogue of block t-S-1 (t > S)
 // LDS: weight ring 2 x [A segment | G segment]; 96 KiB row area = 3 down-phase slots [x2 tile | x1 tile],
 // re-used in the up phase as 2 residual slots + 2 gate-exchange buffers.
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 #include "pet32.h"
@@ -371,7 +372,12 @@ static hipError_t launch_rt(const PetFwdArgs& a, hipStream_t stream) {
     const bool add = a.flags & PET_GATE_ADD;
     // up to 4 row groups (128 rows) with loader waves unless the rings would not fit the 160 KiB LDS
     if constexpr (GateLds<IO, RT, 4>::BIAS_OFF + 8 * 1024 <= 160 * 1024) {
-        switch (pick_row_groups(a.M, 4, 2)) {
+        // forward: 128-row workgroups unless 64-row ones still fit one round of 256 (measured at M = 15 k / 32 k / 47 k:
+        // 96-row workgroups -- 9 waves, uneven over the 4 SIMDs -- are the slowest form at every size, and two rounds of
+        // 128 rows beat three of 64); the backward rows kernel follows pick_row_groups' cost model
+        int rg = a.M <= 256 * 64 ? 2 : 4;
+        if (const char* e = getenv("VLPET_RG")) { const int v = atoi(e); if (v >= 2 && v <= 4) rg = v; }
+        switch (rg) {
             case 4: return add ? launch_one<IO, RT, true, 4, true>(a, stream) : launch_one<IO, RT, false, 4, true>(a, stream);
             case 3: return add ? launch_one<IO, RT, true, 3, true>(a, stream) : launch_one<IO, RT, false, 3, true>(a, stream);
             default: return add ? launch_one<IO, RT, true, 2, true>(a, stream) : launch_one<IO, RT, false, 2, true>(a, stream);
