@@ -15,7 +15,12 @@
 //   gate:     [down A|G + xa,xg] x S   [ (up A|G + res,dy), (up_t A|G) ] x S   [down_t A|G + dh] x S
 //   no gate:  [down A + xa] x S        [ up_t A + dy ] x S                      [down_t A] x S
 // The dh rows of the last phase are re-read from the dh side product this workgroup stored itself;
-// they are not prefetched across the phase boundary (the stores must have completed first).
+// their stream starts once those stores have completed, before the dpre block.
+// With the forward's saved activations (PetBwdArgs::saved: z and act'(pre) of each chain) the first phase does
+// not exist: the kernel starts at the middle phase, reads x1 not at all and x2 once, and leaves the z side
+// products to the forward's copy.  Rows per workgroup (WAVES = 2 / 3 / 4 row groups) are chosen per launch
+// (kernels.h pick_row_groups): a workgroup's time hardly depends on its rows, the number of 256-workgroup
+// rounds does.
 #include <cstdio>
 #include <cstdlib>
 #include "common.h"

@@ -17,7 +17,13 @@
 //     t <  S : both chains, down projection of feature block t
 //     t >= S : chain G, up projection + sigmoid of block t-S (t < 2S); chain A, up projection + epilogue of block t-S-1 (t > S)
 // LDS: weight ring 2 x [A segment | G segment]; 96 KiB row area = 3 down-phase slots [x2 tile | x1 tile],
-// re-used in the up phase as 2 residual slots + 2 gate-exchange buffers.
+// re-used in the up phase as 3 residual tiles + 2 gate-exchange buffers (IO precision).
+//
+// Loader waves (template LD, one per row group, i.e. one per SIMD): with them the compute waves issue no
+// global_load_lds at all -- a wave that waits for the memory pipe to take its next piece costs no issue slots --
+// and the down phase runs at the HBM rate.  Rows per workgroup (RG = 2 / 4 row groups) are
+// chosen per launch.  Training form (PetFwdArgs::save): after the activation each chain also stores z and
+// gelu_new'(pre) for the backward, which then skips its recompute phase.
 #include <cstdlib>
 #include "common.h"
 #include "kernels.h"
