@@ -76,7 +76,8 @@ int vlpet_adapter_gate_fwd(const void* x1, const void* x2, const void* packed_a,
  * (z = gelu_new(pre) and gelu_new'(pre) of both chains, four [M, 32*tiles] tensors of the IO dtype --
  * what torch.autograd keeps for the same lines of the reference, in a quarter of the bytes) in `saved`
  * (vlpet_saved_bytes(M, tiles, io_dtype) bytes, 16-byte aligned).  vlpet_adapter_gate_bwd_saved then
- * skips the recompute of the two down projections: it reads x1 not at all and x2 once. */
+ * skips the recompute of the two down projections: it reads x1 not at all and x2 once.  VLPET_GATE_NONE is accepted too
+ * (adapter chain only: the first half of the block is used). */
 size_t vlpet_saved_bytes(int64_t M, int tiles, int io_dtype);
 int vlpet_adapter_gate_fwd_save(const void* x1, const void* x2, const void* packed_a, const void* packed_g,
                                 void* out, void* saved, int64_t M, int d, int tiles, int gate_mode,
@@ -112,7 +113,7 @@ int vlpet_adapter_gate_bwd_phase(int phases, const void* dy, const void* x1, con
                                  float delta_scale, float x2_scale, float gate_scale,
                                  int io_dtype, vlpet_stream_t stream);
 
-/* vlpet_adapter_gate_bwd_phase with the activations saved by vlpet_adapter_gate_fwd_save (gated forms only; x1 is
+/* vlpet_adapter_gate_bwd_phase with the activations saved by vlpet_adapter_gate_fwd_save (x1 is
  * still an argument because the gate's down-weight gradient contracts it). */
 int vlpet_adapter_gate_bwd_saved(int phases, const void* dy, const void* x1, const void* x2, const void* saved,
                                  const void* packed_a, const void* packed_g,

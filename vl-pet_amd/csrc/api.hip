@@ -150,10 +150,10 @@ extern "C" int vlpet_adapter_gate_fwd_save(const void* x1, const void* x2, const
                                            int gate_mode, float delta_scale, float x2_scale, float gate_scale,
                                            int io_dtype, vlpet_stream_t stream) {
     int flags;
-    if (gate_flags(gate_mode, &flags) || !flags) return VLPET_E_SHAPE;      // gated forms only
+    if (gate_flags(gate_mode, &flags)) return VLPET_E_SHAPE;
     if (!saved) return VLPET_E_NULL;
     return run_fwd(x2, x2, x1, packed_a, packed_g, nullptr, 1.f, out, M, d, tiles, x2_scale, delta_scale,
-                   gate_scale, flags, io_dtype, stream, saved);
+                   flags ? gate_scale : 1.f, flags, io_dtype, stream, saved);
 }
 
 extern "C" int vlpet_parallel_adapter_fwd(const void* x, const void* y, const void* packed, void* out,
@@ -329,11 +329,11 @@ extern "C" int vlpet_adapter_gate_bwd_saved(int phases, const void* dy, const vo
                                             int gate_mode, float delta_scale, float x2_scale, float gate_scale,
                                             int io_dtype, vlpet_stream_t stream) {
     int flags;
-    if (gate_flags(gate_mode, &flags) || !flags) return VLPET_E_SHAPE;
+    if (gate_flags(gate_mode, &flags)) return VLPET_E_SHAPE;
     if (!dbd || !dbu || !saved || (phases & 3) == 0) return VLPET_E_NULL;
     return run_bwd(dy, x2, x2, x1, packed_a, packed_g, nullptr, 1.f, dx2, dx1, dwd, dbd, dwu, dbu,
                    dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
-                   x2_scale, delta_scale, gate_scale, flags, io_dtype, stream, phases & 3, saved);
+                   x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream, phases & 3, saved);
 }
 
 extern "C" int vlpet_parallel_adapter_bwd(const void* dy, const void* x, const void* packed, void* dx,

@@ -215,14 +215,15 @@ class _AdapterGateFn(torch.autograd.Function):
         x1f = _flat(x1, d) if gate_mode != GATE_NONE else None
         M = x2f.shape[0]
         out = torch.empty_like(x2f)
-        # training, gated form: the forward leaves z and gelu'(pre) of both chains (4 x [M, 32*tiles], IO dtype) and the
+        # training: the forward leaves z and gelu'(pre) of its chains (up to 4 x [M, 32*tiles], IO dtype) and the
         # backward neither recomputes the down projections nor reads x1 / x2 for them
         act = None
-        if SAVE_ACTIVATIONS and gate_mode != GATE_NONE and any(ctx.needs_input_grad):
+        if SAVE_ACTIVATIONS and any(ctx.needs_input_grad):
             act = torch.empty(lib.vlpet_saved_bytes(M, pk_a.tiles, io), dtype=torch.uint8, device=x2f.device)
             rc = _timed("k1_fwd", M, lambda: lib.vlpet_adapter_gate_fwd_save(
-                _ptr(x1f), x2f.data_ptr(), pk_a.buf.data_ptr(), pk_g.buf.data_ptr(), out.data_ptr(), act.data_ptr(),
-                M, d, pk_a.tiles, gate_mode, float(delta_scale), float(x2_scale), float(gate_scale), io, _stream()))
+                _ptr(x1f), x2f.data_ptr(), pk_a.buf.data_ptr(), pk_g.buf.data_ptr() if pk_g is not None else None,
+                out.data_ptr(), act.data_ptr(), M, d, pk_a.tiles, gate_mode, float(delta_scale), float(x2_scale),
+                float(gate_scale), io, _stream()))
         else:
             rc = _timed("k1_fwd", M, lambda: lib.vlpet_adapter_gate_fwd(
                 _ptr(x1f), x2f.data_ptr(), pk_a.buf.data_ptr(), pk_g.buf.data_ptr() if pk_g is not None else None,
