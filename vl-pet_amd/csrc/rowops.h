@@ -22,6 +22,21 @@ template <typename IO> struct Piece {
             for (int j = 0; j < 4; ++j) v[j] = a[j];
         }
     }
+    // the same piece kept raw (a prefetched row lives in registers unconverted)
+    static __device__ __forceinline__ u32x4 load_raw(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+    static __device__ __forceinline__ void from_raw(const u32x4& r, float* v) {
+        if constexpr (E == 8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned int u = r[i];
+                v[2 * i] = __builtin_bit_cast(float, u << 16);
+                v[2 * i + 1] = __builtin_bit_cast(float, u & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const unsigned int u = r[i]; v[i] = __builtin_bit_cast(float, u); }
+        }
+    }
     static __device__ __forceinline__ void store(void* p, const float* v) {
         if constexpr (E == 8) {
             bf16x8 a;
