@@ -203,17 +203,47 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         copy_bias<WAVES * 64>(sb, reinterpret_cast<const float*>(a.pk_a + pg.bias_off), nb, tid);
         if constexpr (GATE) copy_bias<WAVES * 64>(sb + nb, reinterpret_cast<const float*>(a.pk_g + pg.bias_off), nb, tid);
     }
-    __syncthreads();
-
-    // ---- phase 1: recompute the bottleneck pre-activations of both chains
     f32x16 accA[RT];
     f32x16 accG[GATE ? RT : 1];
+    Frag<NS> zA[KT];
+    Frag<NS> zG[GATE ? KT : 1];
 #pragma unroll
     for (int ct = 0; ct < RT; ++ct) accA[ct] = zero16();
     if constexpr (GATE) {
 #pragma unroll
         for (int ct = 0; ct < RT; ++ct) accG[ct] = zero16();
     }
+    // the forward's saved activations are fetched while the prologue's weight / row pieces are still landing
+    if (use_saved) {
+        const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved);
+        const int64_t ro = grow * (int64_t)(32 * RT) + 8 * h;
+        const IO* sza = reinterpret_cast<const IO*>(sv) + ro;
+        const IO* sga = reinterpret_cast<const IO*>(sv + a.saved_stride) + ro;
+        const IO* szg = reinterpret_cast<const IO*>(sv + 2 * a.saved_stride) + ro;
+        const IO* sgg = reinterpret_cast<const IO*>(sv + 3 * a.saved_stride) + ro;
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct) {
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                float v[8];
+                load8_f32(sza + 32 * ct + 16 * sh, v);
+                zA[2 * ct + sh] = frag_from_f32<NS>(v);
+                load8_f32(sga + 32 * ct + 16 * sh, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) accA[ct][8 * sh + j] = v[j];
+                if constexpr (GATE) {
+                    load8_f32(szg + 32 * ct + 16 * sh, v);
+                    zG[2 * ct + sh] = frag_from_f32<NS>(v);
+                    load8_f32(sgg + 32 * ct + 16 * sh, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) accG[ct][8 * sh + j] = v[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: recompute the bottleneck pre-activations of both chains
     int s = S0;
     BSTAMP(1);
     for (; s < S; ++s) {
@@ -278,35 +308,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
     BSTAMP(2);
 
     // z = act(pre) as B fragments; accA / accG are overwritten with act'(pre)
-    Frag<NS> zA[KT];
-    Frag<NS> zG[GATE ? KT : 1];
-    if (use_saved) {
-        const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved);
-        const int64_t ro = grow * (int64_t)(32 * RT) + 8 * h;
-        const IO* sza = reinterpret_cast<const IO*>(sv) + ro;
-        const IO* sga = reinterpret_cast<const IO*>(sv + a.saved_stride) + ro;
-        const IO* szg = reinterpret_cast<const IO*>(sv + 2 * a.saved_stride) + ro;
-        const IO* sgg = reinterpret_cast<const IO*>(sv + 3 * a.saved_stride) + ro;
-#pragma unroll
-        for (int ct = 0; ct < RT; ++ct) {
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh) {
-                float v[8];
-                load8_f32(sza + 32 * ct + 16 * sh, v);
-                zA[2 * ct + sh] = frag_from_f32<NS>(v);
-                load8_f32(sga + 32 * ct + 16 * sh, v);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) accA[ct][8 * sh + j] = v[j];
-                if constexpr (GATE) {
-                    load8_f32(szg + 32 * ct + 16 * sh, v);
-                    zG[2 * ct + sh] = frag_from_f32<NS>(v);
-                    load8_f32(sgg + 32 * ct + 16 * sh, v);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) accG[ct][8 * sh + j] = v[j];
-                }
-            }
-        }
-    } else {
+    if (!use_saved) {
         {
             const float* bdA = sb + 8 * h;
             const float* bdG = sb + nb + 8 * h;
