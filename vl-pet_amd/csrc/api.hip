@@ -250,7 +250,8 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
         if (gate) b.z_g = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(saved)) + 2 * b.saved_stride;
     }
     if (phases & 1) {
-        hipError_t e = launch_pet_bwd(b, io_dtype == VLPET_F32, (hipStream_t)stream);
+        hipError_t e = pet_gate_bwd2_applies(b) ? launch_pet_gate_bwd2(b, io_dtype == VLPET_F32, (hipStream_t)stream)
+                                                : launch_pet_bwd(b, io_dtype == VLPET_F32, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
     if (!(phases & 2)) return 0;

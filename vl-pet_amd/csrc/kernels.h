@@ -68,6 +68,9 @@ struct PetBwdArgs {
     int flags;
 };
 hipError_t launch_pet_bwd(const PetBwdArgs& a, int io_fp32, hipStream_t stream);
+// chain-split form of the same (pet_gate_bwd2.hip): gated K1 with saved activations
+bool pet_gate_bwd2_applies(const PetBwdArgs& a);
+hipError_t launch_pet_gate_bwd2(const PetBwdArgs& a, int io_fp32, hipStream_t stream);
 
 // Weight gradients:  Out[c, n] = scale * sum_m P[m, c] * X[m, n]   (P skinny, X wide), plus the
 // column sums of X (bias of the "up" side) and of P (bias of the "down" side).
