@@ -166,7 +166,9 @@ def main():
         a = agg[dom]
         achieved = per_row[dom] * a["rows"] / a["total_us"] / 1e3     # GB/s
         tiles = 3 if args.model == "bart" else 6
-        roof = dict(bound="hbm", kernel={"k1_bwd_rows": f"pet_bwd_kernel<{args.dtype},{tiles},gate>",
+        # (r = 96: the chain-split kernel pet_gate_bwd2.hip with the forward's saved activations; r = 192: pet_bwd.hip)
+        roof = dict(bound="hbm", kernel={"k1_bwd_rows": (f"pet_gate_bwd2_kernel<{args.dtype},{tiles}>" if tiles <= 3
+                                                         else f"pet_bwd_kernel<{args.dtype},{tiles},gate>"),
                                          "k1_fwd": f"pet_gate_fwd_kernel<{args.dtype},{tiles}>"}[dom],
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                     traffic=(round(PMC_TRAFFIC_BYTES_PER_ROW[dom] * a["rows"] / a["launches"])
