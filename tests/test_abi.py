@@ -42,6 +42,13 @@ def test_error_codes_without_gpu():
     raw = 4 * (768 // 16 * 3) * 1024 + (96 + 768) * 4
     assert lib.vlpet_packed_bytes(3, 768, 1) == (raw + 255) // 256 * 256
     assert lib.vlpet_bwd_workspace_bytes(28000, 768, 3, 1, 1) > 2 * 28000 * 768 * 2
+    # training forms: the saved-activation block is four [M, 32*tiles] IO tensors, each padded to 256 bytes
+    assert lib.vlpet_saved_bytes(28000, 3, 1) == 4 * ((28000 * 96 * 2 + 255) // 256 * 256)
+    assert lib.vlpet_saved_bytes(10, 3, 0) == 4 * ((10 * 96 * 4 + 255) // 256 * 256)
+    assert lib.vlpet_saved_bytes(0, 3, 1) == 0 and lib.vlpet_saved_bytes(16, 2, 1) == 0
+    assert lib.vlpet_adapter_gate_fwd_save(16, 16, 16, 16, 16, None, 16, 768, 3, 1, 1.0, 1.0, 1.0, 1, None) == -5   # no block
+    assert lib.vlpet_adapter_gate_fwd_save(16, 16, 16, 16, 16, 8, 16, 768, 3, 1, 1.0, 1.0, 1.0, 1, None) == -3      # misaligned block
+    assert lib.vlpet_parallel_adapter_fwd_save(16, 16, 16, 16, None, 16, 768, 3, 1.0, 1, None) == -5
 
 
 def test_product_path_has_no_cpu_fallback():

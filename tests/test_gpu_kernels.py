@@ -59,6 +59,49 @@ def test_k1_backward_recompute_path(dtype, monkeypatch):
     check(C.run_k2(dtype), dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_k1_saved_and_recompute_backward_agree(dtype):
+    # same inputs through the C ABI: forward + recompute backward vs forward_save + backward_saved (chain-split rows
+    # kernel); outputs identical, gradients equal up to the rounding of the saved gelu' (IO dtype)
+    import vlpet_amd.functional as F
+    from vlpet_amd import _lib
+    lib = _lib.load()
+    M, d, r, dev = 1000, 768, 96, "cuda"
+    g = torch.Generator(device=dev).manual_seed(3)
+    x1, x2, dy = (torch.randn(M, d, device=dev, generator=g).to(dtype) for _ in range(3))
+    mk = lambda *s: torch.randn(*s, device=dev, generator=g) * 0.05
+    W = [mk(r, d), mk(r), mk(d, r), mk(d), mk(r, d), mk(r), mk(d, r), mk(d)]
+    io, tiles = F._io_dtype(x2), F.rank_tiles(r)
+    pa = F.pack_pair([W[0]], [W[1]], W[2], W[3], io, tiles); pg = F.pack_pair([W[4]], [W[5]], W[6], W[7], io, tiles)
+    st = torch.cuda.current_stream().cuda_stream
+    nws = lib.vlpet_bwd_workspace_bytes(M, d, tiles, 1, io)
+    res = []
+    for saved in (False, True):
+        out = torch.empty_like(x2); dx1 = torch.empty_like(x1); dx2 = torch.empty_like(x2)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        G = [torch.empty_like(w) for w in W]
+        gp = [G[0], G[1], G[2], G[3], G[4], G[5], G[6], G[7]]
+        if saved:
+            sv = torch.empty(lib.vlpet_saved_bytes(M, tiles, io), dtype=torch.uint8, device=dev)
+            assert lib.vlpet_adapter_gate_fwd_save(x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(), out.data_ptr(),
+                                                   sv.data_ptr(), M, d, tiles, 1, 1.0, 1.0, 1.0, io, st) == 0
+            assert lib.vlpet_adapter_gate_bwd_saved(3, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(),
+                                                    pg.buf.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), *[t.data_ptr() for t in gp],
+                                                    r, r, ws.data_ptr(), nws, M, d, tiles, 1, 1.0, 1.0, 1.0, io, st) == 0
+        else:
+            assert lib.vlpet_adapter_gate_fwd(x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(), out.data_ptr(),
+                                              M, d, tiles, 1, 1.0, 1.0, 1.0, io, st) == 0
+            assert lib.vlpet_adapter_gate_bwd(dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(),
+                                              dx1.data_ptr(), dx2.data_ptr(), *[t.data_ptr() for t in gp], r, r, ws.data_ptr(), nws,
+                                              M, d, tiles, 1, 1.0, 1.0, 1.0, io, st) == 0
+        torch.cuda.synchronize()
+        res.append([out.float(), dx1.float(), dx2.float()] + [t.float() for t in gp])
+    assert torch.equal(res[0][0], res[1][0])                       # the forward's output does not depend on saving
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert (a - b).abs().max().item() <= tol * max(a.abs().max().item(), 1e-6)
+
+
 def test_k1_full_size_bf16():
     # config 2 (VQA step): M = 500 * 56 rows
     check(C.run_k1(torch.bfloat16, M=28000), torch.bfloat16)
