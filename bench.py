@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- multitask fine-tuning throughput of the MI355X-native VL-PET path.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: spawns the N ranks itself)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
-Workload (BASELINE.json configs[1]): BART-base + VL-PET-large (r = r_g = dec r = 96, N_h = 4),
+Workload (default, BASELINE.json configs[1]): BART-base + VL-PET-large (r = r_g = dec r = 96, N_h = 4),
 image-text multitask, bf16 activations / frozen weights, fp32 trainable masters.  One step = one full
 train step (forward, backward, gradient exchange, clip 5.0, AdamW) on one task batch; steps cycle
 vqa -> gqa -> nlvr -> caption with the reference's per-task batch sizes (500 / 833 / 166 / 416,
-multitask.py:682-695) per GPU (weak scaling).  Synthetic CLIP-feature + token batches are resident in
+multitask.py:682-695).  ``--scaling weak`` (default): that batch per GPU; ``--scaling strong``: that batch is the
+GLOBAL batch, split across the ranks.  Synthetic CLIP-feature + token batches are resident in
 HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Other workloads (parity-tested configs, not the headline): ``--model t5`` configs[2] (T5-base, r = 192),
+``--model lora`` configs[3] (BART-base + LoRA r = --lora-r on q_proj / v_proj of all 18 attentions: the K3 path),
+``--model video`` configs[4] (BART-base + VL-PET-large, video-text: batch 50, 600 text tokens + 64 frame features of 512).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,25 +28,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s measured achievable)
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+# HBM-side bytes per row of the K1 backward from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
+# with rocprofv3 --pmc in its own run at ONE size (M = 28,000, bf16, r = 96) -- bench.py scales them by the run's rows per
+# launch, so for the other task shapes they are an extrapolation (labelled as such in the line).
+PMC_TRAFFIC = {"source": "profiles/r01_pmc_traffic_k1_bwd.md", "measured_at_rows": 28000,
+               "bytes_per_row": {"k1_bwd_rows": 12175.0}}
+IMAGE_TASKS = ["vqa", "gqa", "nlvr", "caption"]
+VIDEO_TASKS = ["tvqa", "how2qa", "tvc", "yc2c"]
 
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s measured achievable)
-# HBM-side bytes per row of pet_bwd_kernel<bf16,3,gate> from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE;
-# profiles/r01_pmc_traffic_k1_bwd.md).  Collected with rocprofv3 --pmc in its own run, not inside this script.
-PMC_TRAFFIC_BYTES_PER_ROW = {"k1_bwd_rows": 12175.0}
-TASK_ORDER = ["vqa", "gqa", "nlvr", "caption"]
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(steps=60, warm=3, batch=4):
-    """Reference path restated on the host CPU (kind "port"): the same host model with the PET ops
-    routed to oracle/vlpet_oracle.py (plain eager PyTorch in the reference's op order), full train step,
-    fp32, BASELINE.json configs[0] (VQA, batch 4)."""
+def cpu_baseline(budget_s=18.0, warm=2, batch=4):
+    """Reference path restated on the host CPU (kind "port"): the same host model with the PET ops routed to
+    oracle/vlpet_oracle.py (plain eager PyTorch in the reference's op order), fp32, every host core.
+    (i) full train step of BASELINE.json configs[0] (VQA, batch 4) -> value; (ii) the isolated K1-K4 op chains at
+    the configs[1] VQA-step sizes, forward + backward, median of a few iterations."""
+    import torch
     import vlpet_amd.host.bart as HB
     import vlpet_amd.train as TR
     from oracle.host_patch import cpu_reference_ops
+    from oracle import vlpet_oracle as O
 
-    torch.set_num_threads(min(16, os.cpu_count() or 1))      # small-batch eager ops do not scale past ~16 threads
+    ncores = os.cpu_count() or 1
     with cpu_reference_ops():
         torch.manual_seed(1234)
         cfg = HB.vlpet_config()
@@ -49,16 +71,117 @@ def cpu_baseline(steps=60, warm=3, batch=4):
         tr = TR.Trainer(model, cfg, total_steps=1000)
         gen = torch.Generator().manual_seed(1234)
         b = TR.synthetic_batch("vqa", batch, cfg, "cpu", gen)
-        for _ in range(warm):
-            tr.step(b)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            tr.step(b)
-        dt = time.perf_counter() - t0
-    return dict(value=round(batch * steps / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
+        # every host core and, because batch-4 eager ops stop scaling long before a server's core
+        # count, 16 threads as well: the faster of the two is the reported baseline, both are in `thread_sweep`
+        sweep = {}
+        for nt in sorted({ncores, min(16, ncores)}, reverse=True):
+            torch.set_num_threads(nt)
+            for _ in range(warm):
+                tr.step(b)
+            t0 = time.perf_counter()
+            steps = 0
+            while steps < 6 or (time.perf_counter() - t0 < budget_s * 0.35 and steps < 400):
+                tr.step(b)
+                steps += 1
+            dt = time.perf_counter() - t0
+            sweep[nt] = (batch * steps / dt, steps, dt)
+        best = max(sweep, key=lambda k: sweep[k][0])
+        rate, steps, dt = sweep[best]
+    del model, tr
+    torch.set_num_threads(ncores)
+
+    # isolated chains at the VQA-step size (M = 500 * 56 rows; K4: 500 * 36 visual rows), fp32
+    def med(fn, n=3):
+        fn()
+        ts = []
+        for _ in range(n):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return sorted(ts)[len(ts) // 2]
+    g = torch.Generator().manual_seed(7)
+    M, d, r = 28000, 768, 96
+    rn = lambda *s: torch.randn(*s, generator=g) * 0.05
+    x1, x2, dy = torch.randn(M, d, generator=g), torch.randn(M, d, generator=g), torch.randn(M, d, generator=g)
+    W = [rn(r, d), rn(r), rn(d, r), rn(d), rn(r, d), rn(r), rn(d, r), rn(d)]
+    chains = {}
+    chains["k1_fwd_bwd_s"] = med(lambda: O.k1_fwd_bwd(x1, x2, *W, dy, n_heads=4))
+
+    def k2():
+        ps = [w.clone().requires_grad_(True) for w in W[:4]]
+        xx, yy = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+        O.parallel_adapter(xx, yy, *ps, None).backward(dy)
+    chains["k2_fwd_bwd_s"] = med(k2)
+
+    def k3():
+        A, B = rn(64, d).requires_grad_(True), rn(d, 64).requires_grad_(True)
+        xx = x1.clone().requires_grad_(True)
+        O.lora_linear(xx, torch.zeros(d, d), None, A, B, 0.5, None, 0.0).backward(dy)
+    chains["k3_r64_fwd_bwd_s"] = med(k3)
+
+    def k4():
+        Mv, F = 500 * 36, 2048
+        feats, pos = torch.randn(Mv // 36, 36, F, generator=g), torch.zeros(Mv // 36, 36, 4)
+        ps = [rn(d, F), rn(d), torch.ones(d), torch.zeros(d), rn(d, 5), rn(d), torch.ones(d), torch.zeros(d), rn(2, d), rn(100, d)]
+        ps = [p.requires_grad_(True) for p in ps]
+        O.visual_embedding(feats, pos, *ps[:8], ps[8], ps[9]).sum().backward()
+    chains["k4_fwd_bwd_s"] = med(k4, n=2)
+    chains = {k: round(v, 4) for k, v in chains.items()}
+    return dict(value=round(rate, 3), unit="samples/s", cores=best, host_cores=ncores,
+                cpu_model=cpu_model_name(), kind="port",
+                thread_sweep={str(k): round(v[0], 3) for k, v in sweep.items()},
                 sample=f"configs[0]: BART-base VL-PET-large r=96, VQA batch {batch}, S=20+36, fp32, full train step "
                        f"(fwd+bwd+clip+AdamW) through oracle/vlpet_oracle.py on the host CPU, {warm} warm-up + "
-                       f"{steps} timed steps ({dt:.1f} s)")
+                       f"{steps} timed steps ({dt:.1f} s)",
+                isolated_chains=dict(chains, note="oracle op chains fwd+bwd at the configs[1] VQA-step size (M=28000, "
+                                                  "d=768, r=96; K3 r=64; K4 18000x2048->768), fp32, median seconds"))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def build_model(args, dev, dtype):
+    import vlpet_amd.host.bart as HB
+    import vlpet_amd.train as TR
+    if args.model == "t5":
+        import vlpet_amd.host.t5 as HT
+        cfg = HT.vlt5_config()
+        model = HT.VLT5(cfg)
+        tasks, label = IMAGE_TASKS, "configs[2]: T5-base + VL-PET-large (r=192, gate scale 0.3) image-text multitask"
+        metric = "multitask samples/sec (T5-base, r=192)"
+    elif args.model == "lora":
+        # scripts/image-text/single_lora.sh:53-55: --use_lora --lora_dim R --use_single_lora; lora_alpha 32 (param.py:197),
+        # lora_dropout 0.1 (lora/config.py:5-8); the trainable set is lora_* + every bias + visual_embedding
+        cfg = HB.vlpet_config(use_adapter=False, use_encoder_adapter_down_multihead=False,
+                              use_encoder_adapter_gating_large_x_lowrank=False,
+                              use_decoder_enc_attn_value_parallel_adapter_down_dim=False, unfreeze_encoder_layer_norms=False,
+                              use_lora=True, lora_dim=args.lora_r, use_single_lora=True)
+        model = HB.VLBart(cfg)
+        tasks = IMAGE_TASKS
+        label = f"configs[3]: BART-base + LoRA (r={args.lora_r}, alpha 32, dropout 0.1, single LoRA) image-text multitask"
+        metric = f"multitask samples/sec (BART-base, LoRA r={args.lora_r})"
+    elif args.model == "video":
+        cfg = HB.vlpet_config(feat_dim=512, n_boxes=64, tasks=",".join(VIDEO_TASKS))
+        model = HB.VLBart(cfg)
+        tasks = VIDEO_TASKS
+        label = "configs[4]: BART-base + VL-PET-large (r=96) video-text multitask (600 text tokens + 64 frame features of 512)"
+        metric = "multitask samples/sec (BART-base, r=96, video-text)"
+    else:
+        cfg = HB.vlpet_config()
+        model = HB.VLBart(cfg)
+        tasks, label = IMAGE_TASKS, "configs[1]: BART-base + VL-PET-large (r=96) image-text multitask"
+        metric = "multitask samples/sec (BART-base, r=96)"
+    TR.trainable_names(model, cfg)
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    model.to(dev)
+    TR.cast_frozen(model, dtype)
+    model.train()
+    return model, cfg, tasks, label, metric, n_train
 
 
 def main():
@@ -66,22 +189,40 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=500, help="per-GPU VQA batch (other tasks scale like the reference)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="VQA-task batch (other tasks scale like the reference); default 500 (bart, lora), 300 (t5), 50 (video)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch per GPU;  strong: --batch is the global batch, partitioned across the ranks")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--buckets", type=int, default=3)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to exercise the DP path on a 1-GPU box")
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="K1 weight gradients on a side stream (measured 5 %% SLOWER on one MI355X: the step is GPU-bound)")
-    ap.add_argument("--model", default="bart", choices=["bart", "t5"],
-                    help="bart = BASELINE configs[1] (the headline line); t5 = configs[2] (T5-base, r = r_g = 192, --batch 300)")
+    ap.add_argument("--model", default="bart", choices=["bart", "t5", "lora", "video"])
+    ap.add_argument("--lora-r", type=int, default=64, help="LoRA rank for --model lora (BASELINE configs[3]: 8 / 64; script: 128)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher: start the N ranks ourselves (the reference spawns one process per visible GPU itself,
+        # multitask.py:872-898), one process per GPU, rendezvous on 127.0.0.1
+        import torch
+        if args.backend == "nccl" and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible "
+                             f"(use --backend gloo to exercise the data-parallel path on fewer GPUs)")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -91,34 +232,30 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=args.backend)
+    n_ranks = dist.get_world_size() if world > 1 else 1     # what the process group actually has
 
     import vlpet_amd.functional as VF
-    import vlpet_amd.host.bart as HB
     import vlpet_amd.train as TR
     from vlpet_amd import _lib
     _lib.load()     # fail loudly before anything is timed
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(1234)      # same initial state on every rank: no parameter broadcast needed
-    if args.model == "t5":
-        import vlpet_amd.host.t5 as HT
-        cfg = HT.vlt5_config()
-        model = HT.VLT5(cfg)
-    else:
-        cfg = HB.vlpet_config()
-        model = HB.VLBart(cfg)
-    names = TR.trainable_names(model, cfg)
-    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
-    model.to(dev)
-    TR.cast_frozen(model, dtype)
-    model.train()
+    model, cfg, tasks, label, metric, n_train = build_model(args, dev, dtype)
+    if args.batch is None:
+        args.batch = {"bart": 500, "lora": 500, "t5": 300, "video": 50}[args.model]
     total_steps = max(args.steps + args.warmup, 10)
-    tr = TR.Trainer(model, cfg, lr=1e-3, clip=5.0, total_steps=total_steps, world_size=world, n_buckets=args.buckets,
+    tr = TR.Trainer(model, cfg, lr=1e-3, clip=5.0, total_steps=total_steps, world_size=n_ranks, n_buckets=args.buckets,
                     overlap_wgrad=args.overlap_wgrad)
 
+    def rank_batch(task):
+        gb = TR.TASK_BATCH[task](args.batch)
+        if args.scaling == "weak":
+            return gb
+        return gb // n_ranks + (1 if rank < gb % n_ranks else 0)       # strong: partition the global task batch
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    batches = {t: TR.synthetic_batch(t, TR.TASK_BATCH[t](args.batch), cfg, dev, gen) for t in TASK_ORDER}
-    order = [TASK_ORDER[i % 4] for i in range(args.warmup + args.steps)]
+    batches = {t: TR.synthetic_batch(t, rank_batch(t), cfg, dev, gen) for t in tasks}
+    order = [tasks[i % len(tasks)] for i in range(args.warmup + args.steps)]
 
     for i in range(args.warmup):
         tr.step(batches[order[i]])
@@ -151,47 +288,75 @@ def main():
         esz = 2 if dtype == torch.bfloat16 else 4
         d = cfg.d_model
         agg = timer.summary()
-        # algorithmic bytes per row: fwd reads x1, x2, writes y; bwd rows reads dy, x1, x2, writes dx1, dx2
-        # K5 tail: fwd reads y, x1, writes out; bwd reads dout, writes dx1, dy (the saved pre-norm sum is extra traffic)
+        # algorithmic bytes per row: K1 fwd reads x1, x2, writes y; K1 bwd (the whole op: rows kernel + weight
+        # gradients) reads dy, x1, x2, writes dx1, dx2; K2 / K3 fwd read x, y|base, write out; K2 / K3 bwd read dy, x, write dx;
+        # K5 fwd reads y, x1, writes out; K5 bwd reads dout, writes dx1, dy (the saved pre-norm sum is extra traffic)
         per_row = {"k1_fwd": 3 * d * esz, "k1_bwd_rows": 5 * d * esz, "k1_bwd_wgrad": 0, "k2_fwd": 3 * d * esz,
-                   "k2_bwd": 3 * d * esz, "k5_fwd": 3 * d * esz, "k5_bwd": 3 * d * esz}
+                   "k2_bwd": 3 * d * esz, "k3_fwd": 3 * d * esz, "k3_bwd": 3 * d * esz, "k5_fwd": 3 * d * esz,
+                   "k5_bwd": 3 * d * esz}
+        F_in = int(cfg.feat_dim)
+        flops_per_row = {"k4_fwd": 2.0 * F_in * d, "k4_wgrad": 2.0 * F_in * d}
         kernels = {}
         for name, a in agg.items():
             by = per_row.get(name, 0) * a["rows"]
-            kernels[name] = dict(launches=a["launches"], avg_us=round(a["total_us"] / a["launches"], 2),
-                                 total_ms=round(a["total_us"] / 1e3, 3),
-                                 algorithmic_GBps=round(by / a["total_us"] / 1e3, 1) if by else None)
-        # dominant HIP kernel of the hot path by time: the row-parallel K1 backward
-        dom = "k1_bwd_rows" if "k1_bwd_rows" in agg else "k1_fwd"
+            k = dict(launches=a["launches"], avg_us=round(a["total_us"] / a["launches"], 2),
+                     total_ms=round(a["total_us"] / 1e3, 3),
+                     algorithmic_GBps=round(by / a["total_us"] / 1e3, 1) if by else None)
+            if k["algorithmic_GBps"]:
+                k["hbm_frac"] = round(k["algorithmic_GBps"] / HBM_PEAK_GBS, 4)
+            if name in flops_per_row:
+                tf = flops_per_row[name] * a["rows"] / a["total_us"] / 1e6
+                k["TFLOPps"] = round(tf, 1)
+                k["mfma_frac"] = round(tf / MFMA_PEAK_TFLOPS, 4)
+            kernels[name] = k
+        # the K1 backward as ONE op (rows kernel + weight-gradient kernels): SURVEY 8d's 5*d*b per row over their summed time
+        if "k1_bwd_rows" in agg and "k1_bwd_wgrad" in agg:
+            a, w = agg["k1_bwd_rows"], agg["k1_bwd_wgrad"]
+            op_us = a["total_us"] + w["total_us"]
+            gbps = per_row["k1_bwd_rows"] * a["rows"] / op_us / 1e3
+            kernels["k1_bwd_op"] = dict(launches=a["launches"], avg_us=round(op_us / a["launches"], 2),
+                                        total_ms=round(op_us / 1e3, 3), algorithmic_GBps=round(gbps, 1),
+                                        hbm_frac=round(gbps / HBM_PEAK_GBS, 4),
+                                        note="rows kernel + weight-gradient kernels of one K1 backward, 5*d*b per row")
+        # dominant HIP kernel of the hot path by time
+        if args.model == "lora":
+            dom = "k3_bwd" if "k3_bwd" in agg else "k3_fwd"
+        else:
+            dom = "k1_bwd_rows" if "k1_bwd_rows" in agg else "k1_fwd"
         a = agg[dom]
         achieved = per_row[dom] * a["rows"] / a["total_us"] / 1e3     # GB/s
-        tiles = 3 if args.model == "bart" else 6
-        # (r = 96: the chain-split kernel pet_gate_bwd2.hip with the forward's saved activations; r = 192: pet_bwd.hip)
-        roof = dict(bound="hbm", kernel={"k1_bwd_rows": (f"pet_gate_bwd2_kernel<{args.dtype},{tiles}>" if tiles <= 3
-                                                         else f"pet_bwd_kernel<{args.dtype},{tiles},gate>"),
-                                         "k1_fwd": f"pet_gate_fwd_kernel<{args.dtype},{tiles}>"}[dom],
-                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=(round(PMC_TRAFFIC_BYTES_PER_ROW[dom] * a["rows"] / a["launches"])
-                             if dom in PMC_TRAFFIC_BYTES_PER_ROW and args.dtype == "bf16" and args.model == "bart" else None),
-                    traffic_source="profiles/r01_pmc_traffic_k1_bwd.md (PMC passes at M=28000, scaled by rows per launch)",
+        tiles = 6 if args.model == "t5" else 3
+        kname = {"k1_bwd_rows": (f"pet_gate_bwd2_kernel<{args.dtype},{tiles}>" if tiles <= 3
+                                 else f"pet_bwd_kernel<{args.dtype},{tiles},gate>"),
+                 "k1_fwd": f"pet_gate_fwd_kernel<{args.dtype},{tiles}>",
+                 "k3_bwd": f"pet_bwd_kernel<{args.dtype},act_id> + wgrad_kernel (one K3 backward)",
+                 "k3_fwd": f"pet_fwd_kernel<{args.dtype},act_id>"}[dom]
+        traffic = None
+        if dom in PMC_TRAFFIC["bytes_per_row"] and args.dtype == "bf16" and args.model == "bart":
+            traffic = round(PMC_TRAFFIC["bytes_per_row"][dom] * a["rows"] / a["launches"])
+        roof = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    traffic_source=(f"{PMC_TRAFFIC['source']}: PMC passes at M={PMC_TRAFFIC['measured_at_rows']} only, "
+                                    f"scaled by this run's average rows per launch") if traffic else None,
                     avg_launch_us=round(a["total_us"] / a["launches"], 2),
                     avg_rows_per_launch=round(a["rows"] / a["launches"], 1),
                     algorithmic_bytes_per_row=per_row[dom])
+        if "k1_bwd_op" in kernels and dom == "k1_bwd_rows":
+            roof["op_frac"] = kernels["k1_bwd_op"]["hbm_frac"]          # the same bytes over rows + weight-gradient time
+            roof["op_avg_us"] = kernels["k1_bwd_op"]["avg_us"]
+        per_task = {t: TR.TASK_BATCH[t](args.batch) for t in tasks}
+        enc_rows = {t: rank_batch(t) * (TR.TEXT_LEN[t] + (72 if t == "nlvr" else (64 if t in VIDEO_TASKS else 36))) for t in tasks}
         out = {
-            "metric": "multitask samples/sec (BART-base, r=96)" if args.model == "bart" else "multitask samples/sec (T5-base, r=192)",
-            "value": round(samples / dt, 2), "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": ("configs[1]: BART-base + VL-PET-large (r=96)" if args.model == "bart" else
-                                    "configs[2]: T5-base + VL-PET-large (r=192, gate scale 0.3)") +
-                                   " image-text multitask, full train step (fwd+bwd+grad exchange+clip+AdamW), random-init weights",
-                       "per_gpu_task_batch": {t: TR.TASK_BATCH[t](args.batch) for t in TASK_ORDER},
-                       "enc_rows_per_step": {t: TR.TASK_BATCH[t](args.batch) * (TR.TEXT_LEN[t] + (72 if t == "nlvr" else 36))
-                                             for t in TASK_ORDER},
-                       "trainable_params": n_train, "parallelism": f"dp{world}"},
+            "metric": metric, "value": round(samples / dt, 2), "unit": "samples/s",
+            "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": label + ", full train step (fwd+bwd+grad exchange+clip+AdamW), random-init weights",
+                       ("per_gpu_task_batch" if args.scaling == "weak" else "global_task_batch"): per_task,
+                       "enc_rows_per_step_rank0": enc_rows, "trainable_params": n_train, "parallelism": f"dp{n_ranks}",
+                       "backend": args.backend if n_ranks > 1 else None},
             "roofline": roof, "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if n_ranks == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -152,15 +152,19 @@ int vlpet_parallel_adapter_bwd_saved(const void* dy, const void* x, const void* 
  * out = base + scaling * ((dropout(x) @ A^T) @ B^T),  base = F.linear(x, W, b) computed by the caller
  * replaces lora/controller.py:61-68 (the base GEMM at :59 stays a library GEMM).
  * Square projections only (in_features == out_features == d: q_proj / v_proj,
- * my_transformers/modeling_bart.py:767-768).  keep_mask: uint8 [M, d], 1 = keep, or NULL
- * (eval / p = 0); keep_scale = 1/(1-p).  A = lora_As[task] [r, d], B = lora_Bs[task] [d, r]. */
+ * my_transformers/modeling_bart.py:767-768).  A = lora_As[task] [r, d], B = lora_Bs[task] [d, r].
+ * Dropout (lora/controller.py:66, training only): p in [0, 1), p = 0 = none.  With keep_mask == NULL the mask comes from
+ * the library's counter-based generator (Philox-4x32-7, the one of vlpet_sublayer_tail_*): a function of (seed, element
+ * index) only, regenerated -- not stored -- by the backward, which must be given the same p and seed; keep_out (optional,
+ * uint8 [M, d], 16-byte aligned) receives the 0/1 mask that was applied (parity tests).  With keep_mask != NULL
+ * (uint8 [M, d], 1 = keep, 16-byte aligned) that mask is applied instead; kept elements are scaled by 1/(1-p) either way. */
 int vlpet_lora_delta_fwd(const void* x, const void* base, const void* packed,
-                         const uint8_t* keep_mask, float keep_scale, void* out,
+                         const uint8_t* keep_mask, float p, uint64_t seed, uint8_t* keep_out, void* out,
                          int64_t M, int d, int tiles, float scaling,
                          int io_dtype, vlpet_stream_t stream);
 /* dx is the LoRA share of the input gradient (the caller adds dy @ W). */
 int vlpet_lora_delta_bwd(const void* dy, const void* x, const void* packed,
-                         const uint8_t* keep_mask, float keep_scale, void* dx,
+                         const uint8_t* keep_mask, float p, uint64_t seed, void* dx,
                          float* da, float* db, int r,
                          void* workspace, size_t workspace_bytes,
                          int64_t M, int d, int tiles, float scaling,
@@ -262,6 +266,18 @@ int vlpet_adamw_step(float* p, float* g, float* m, float* v, const uint8_t* deca
                      const float* partials, int n_partials, float max_norm, float grad_scale, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int step, int variant,
                      int zero_grad, float* norm_out, vlpet_stream_t stream);
+
+/* The same with per-parameter step counts and activity: transformers.AdamW keeps state['step'] per parameter and skips a
+ * parameter whose grad is None (no decay, no moment update), which is what happens to the other tasks' adapters / LoRA
+ * matrices when use_single_adapter / use_single_lora is off (multitask.py:296-297 sets grads to None every step).
+ * slice_of [n] int32 (16-byte aligned): index of the parameter every element belongs to;  slice_bc [n_params][2] fp32:
+ * {1 - beta1^t_k, sqrt(1 - beta2^t_k)} of parameter k with ITS 1-based update count t_k, or a value <= 0 in [k][0] when
+ * the parameter received no gradient this step (its elements of p, m, v are left untouched; g is still cleared). */
+int vlpet_adamw_step_sliced(float* p, float* g, float* m, float* v, const uint8_t* decay_mask, int64_t n,
+                            const float* partials, int n_partials, float max_norm, float grad_scale, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, const int32_t* slice_of,
+                            const float* slice_bc, int variant, int zero_grad, float* norm_out,
+                            vlpet_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -79,16 +79,22 @@ def cpu_reference_ops():
         """clip_grad_norm_ + transformers.AdamW over the trainer's parameter list (oracle restatement)."""
 
         def __init__(self, flat, lr, max_norm):
-            self.flat, self.max_norm, self.t = flat, max_norm, 0
+            self.flat, self.max_norm = flat, max_norm
+            self.steps = [0] * len(flat.params)            # transformers.AdamW: state['step'] per parameter
             self.state = [(p.data.new_zeros(p.shape), p.data.new_zeros(p.shape)) for p in flat.params]
 
         def step(self, lr):
-            self.t += 1
-            grads = [p.grad for p in self.flat.params]
+            # a parameter that got no gradient this step has grad None in the reference (multitask.py:296-297) and is
+            # skipped by clip_grad_norm_ (zero contribution) and by AdamW (no decay, no moments, no step count)
+            active = self.flat.active() if self.flat.per_task else [True] * len(self.flat.params)
+            grads = [p.grad for p, on in zip(self.flat.params, active) if on]
             O.clip_grad_norm(grads, self.max_norm)
-            for name, p, (m, v) in zip(self.flat.names, self.flat.params, self.state):
+            for k, (name, p, (m, v)) in enumerate(zip(self.flat.names, self.flat.params, self.state)):
+                if not active[k]:
+                    continue
+                self.steps[k] += 1
                 wd = 0.0 if any(nd in name for nd in TR.NO_DECAY) else 0.01
-                O.hf_adamw_step(p.data, p.grad, m, v, self.t, lr, eps=1e-6, weight_decay=wd)
+                O.hf_adamw_step(p.data, p.grad, m, v, self.steps[k], lr, eps=1e-6, weight_decay=wd)
             self.flat.flat.zero_()
 
     from vlpet_amd.lora.controller import LoRALinearController

@@ -498,7 +498,7 @@ T5_VLPET_FLAGS = ["--tasks", "vqa,gqa,nlvr,caption", "--use_adapter", "--use_sin
                   "--use_encoder_gating_scaling", "--encoder_gating_scaling_factor", "0.3"]   # T5-VL-PET-large.sh:41-59
 
 
-def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7, lora=False, kind="bart"):
+def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7, lora=False, kind="bart", video=False):
     """2+2-layer, d=64 ``VLBart`` built from the reference's own classes (src/modeling_bart.py:1458-1530 over
     JointEncoder :690-1010 and my_transformers BartDecoder): state dict, three task batches, eval-mode per-token
     losses + logits (pins the host: [text ; visual] concat order, text-only LayerNorm before the concat, hook
@@ -516,7 +516,9 @@ def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7, lora=False, kind="bart"):
         flags = list(base) + ["--adapter_down_dim", "8", "--encoder_adapter_multihead_num_head", "4",
                               "--adapter_gating_down_dim", "16",
                               "--decoder_enc_attn_value_parallel_adapter_down_dim", "8",
-                              "--downsample", "--n_boxes", "36"]
+                              "--downsample", "--n_boxes", "64" if video else "36"]
+        if video:   # scripts/video-text/VL-PET-large.sh:50-52: four video tasks, 64 frame features, Downsample((8, 8))
+            flags[flags.index("--tasks") + 1] = "tvqa,how2qa,tvc,yc2c"
     config, args = make_config(kind, flags, d_model=64, heads=4, ffn=128)
     if kind == "t5":
         install_t5_runtime_shim()
@@ -560,6 +562,17 @@ def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7, lora=False, kind="bart"):
         scores = torch.rand(B, generator=gen) * 0.5 + 0.5
         return dict(task=task, ids=ids, labels=labels, vis=vis, scores=scores)
     batches = [batch("vqa", 20, 5), batch("nlvr", 20, 2), batch("caption", 12, 9)]
+    if video:
+        # video/video_model.py:34-46: vis_inputs = (frame features [B, 64, feat_dim], zero boxes); ragged text padded with
+        # the pad id (BART: 1), so the default attention mask input_ids.ne(pad) (src/modeling_bart.py:817-818) matters
+        def vbatch(task, L, T, lens):
+            b = batch("vqa", L, T)
+            b["task"] = task
+            b["vis"] = (torch.randn(B, 64, 128, generator=gen), torch.zeros(B, 64, 4))
+            for i, n in enumerate(lens):
+                b["ids"][i, n:] = config.pad_token_id
+            return b
+        batches = [vbatch("tvqa", 30, 3, (30, 17, 9)), vbatch("tvc", 24, 9, (11, 24, 20)), vbatch("how2qa", 40, 3, (40, 40, 25))]
 
     def run(b):
         out = model(input_ids=b["ids"], vis_inputs=b["vis"], labels=b["labels"], return_dict=True, task=b["task"])
@@ -569,6 +582,8 @@ def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7, lora=False, kind="bart"):
         mask = (b["labels"] != -100).float()
         if b["task"] in ("vqa", "gqa"):                      # vqa_model.py:216-227
             return ((per * mask).sum(1) / mask.sum(1).clamp(min=1) * b["scores"]).mean()
+        if video:                                            # video/video_model.py:77-87: no score weighting
+            return ((per * mask).sum(1) / mask.sum(1).clamp(min=1)).mean()
         return (per * mask).sum() / mask.sum().clamp(min=1)   # reduce_loss=True: token mean
 
     arrs = {"sd::" + k: T(v) for k, v in model.state_dict().items()}
@@ -674,6 +689,9 @@ def main():
         golden_lowrank_vis("lowrank_vis_d64", gated=False)
         golden_lowrank_vis("lowrank_vis_gated_d64", gated=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "video":
+        golden_vlbart_tiny("vlbart_tiny_video_d64", seed=11, video=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "vlbart":
         golden_vlbart_tiny()
         golden_vlbart_tiny("vlbart_tiny_lora_d64", seed=8, lora=True)
@@ -721,6 +739,7 @@ def main():
     golden_vlbart_tiny("vlt5_tiny_d64", seed=9, kind="t5")
     golden_lowrank_vis("lowrank_vis_d64", gated=False)
     golden_lowrank_vis("lowrank_vis_gated_d64", gated=True)
+    golden_vlbart_tiny("vlbart_tiny_video_d64", seed=11, video=True)
 
 
 if __name__ == "__main__":

@@ -16,6 +16,17 @@ def rel_err(a: torch.Tensor, ref: torch.Tensor) -> float:
     return float((a - ref).abs().max() / (ref.abs().max() + 1e-6))
 
 
+def col_rel_err(a: torch.Tensor, ref: torch.Tensor) -> float:
+    """Worst per-element relative error of a vector (bias gradients): |a_j - ref_j| / max(|ref_j|, 0.1 * mean|ref|).
+    rel_err above is a global norm and hides small-magnitude columns; this one does not (VERDICT r01 weak #2)."""
+    a = a.detach().float().cpu().reshape(-1)
+    ref = ref.detach().float().cpu().reshape(-1)
+    if not torch.isfinite(a).all():
+        return float("inf")
+    floor = 0.1 * float(ref.abs().mean()) + 1e-12
+    return float(((a - ref).abs() / ref.abs().clamp_min(floor)).max())
+
+
 def _rand(gen, *shape, scale=1.0):
     return torch.randn(*shape, generator=gen) * scale
 
@@ -32,8 +43,9 @@ def make_k1(seed, M, d, r, rg, nh, wscale=None):
 
 
 def run_k1(dtype, M=224, d=768, r=96, rg=96, nh=4, gate_mode=1, delta_scale=1.0, x2_scale=1.0, gate_scale=1.0,
-           seed=0, tensors=None):
-    """returns dict name -> relative error (max-abs / max-abs-ref) for y, dx1, dx2 and the 8 grads"""
+           seed=0, tensors=None, col_errs=None):
+    """returns dict name -> relative error (max-abs / max-abs-ref) for y, dx1, dx2 and the 8 grads; ``col_errs`` (a dict)
+    additionally receives the per-column relative errors of the four bias gradients"""
     import vlpet_amd.functional as F
     t = tensors if tensors is not None else make_k1(seed, M, d, r, rg, nh)
     dev = "cuda"
@@ -68,6 +80,12 @@ def run_k1(dtype, M=224, d=768, r=96, rg=96, nh=4, gate_mode=1, delta_scale=1.0,
     if has_gate:
         for k in ("wgd", "bgd", "wgu", "bgu"):
             errs["d" + k] = rel_err(P[k].grad, g_ref[k])
+    if col_errs is not None:        # per-column view of the bias gradients (sums over all M rows)
+        col_errs["dbd"] = col_rel_err(torch.cat([b.grad for b in dbs]), g_ref["bd"])
+        col_errs["dbu"] = col_rel_err(P["bu"].grad, g_ref["bu"])
+        if has_gate:
+            col_errs["dbgd"] = col_rel_err(P["bgd"].grad, g_ref["bgd"])
+            col_errs["dbgu"] = col_rel_err(P["bgu"].grad, g_ref["bgu"])
     return errs
 
 
@@ -94,31 +112,39 @@ def run_k2(dtype, M=224, d=768, r=96, scale=1.0, seed=1):
     return errs
 
 
-def run_k3(dtype, M=200, d=768, r=8, alpha=32, p=0.0, seed=2):
+def run_k3(dtype, M=200, d=768, r=8, alpha=32, p=0.0, seed=2, explicit_mask=False, rng_seed=0x5eed1234abcd):
+    """K3 forward + backward vs the oracle.  Dropout parity is stated per mask (the reference's RNG stream cannot be
+    matched): by default the mask comes from the kernels' generator, is exported by the forward and handed to the
+    oracle; ``explicit_mask`` feeds a torch-drawn mask to both instead.  Returns the errors (+ ``keep_frac``)."""
     import vlpet_amd.functional as F
     g = torch.Generator().manual_seed(seed)
     x, dy = _rand(g, M, d).to(dtype), _rand(g, M, d).to(dtype)
     w, b = _rand(g, d, d, scale=1 / math.sqrt(d)), _rand(g, d, scale=0.1)
     A, B = _rand(g, r, d, scale=1 / math.sqrt(d)), _rand(g, d, r, scale=0.3)
-    keep = (torch.rand(M, d, generator=g) >= p) if p > 0 else None
+    keep = (torch.rand(M, d, generator=g) >= p) if (p > 0 and explicit_mask) else None
     scaling = alpha / r
+    dev = "cuda"
+    xg = x.detach().to(dev).requires_grad_(True)
+    Ag, Bg = A.to(dev).requires_grad_(True), B.to(dev).requires_grad_(True)
+    base = torch.nn.functional.linear(xg.detach().float(), w.to(dev), b.to(dev)).to(dtype)
+    pk = F.pack_pair([Ag], None, Bg, None, F._io_dtype(xg))
+    out, mask = F.lora_delta(xg, base, Ag, Bg, pk, scaling, keep.to(dev).to(torch.uint8) if keep is not None else None,
+                             p, rng_seed, return_mask=True)
+    out.backward(dy.to(dev))
+    torch.cuda.synchronize()
+    if p > 0 and keep is None:
+        keep = mask.cpu().bool()
     xr = x.float().clone().requires_grad_(True)
     Ar, Br = A.clone().requires_grad_(True), B.clone().requires_grad_(True)
     base_ref = torch.nn.functional.linear(xr, w, b)
     lora_ref = O.lora_linear(xr, torch.zeros_like(w), None, Ar, Br, scaling, keep, p)
     (base_ref.detach() + lora_ref).backward(dy.float())   # LoRA share of dx only
     out_ref = base_ref.detach() + lora_ref.detach()
-    dev = "cuda"
-    xg = x.detach().to(dev).requires_grad_(True)
-    Ag, Bg = A.to(dev).requires_grad_(True), B.to(dev).requires_grad_(True)
-    base = torch.nn.functional.linear(xg.detach().float(), w.to(dev), b.to(dev)).to(dtype)
-    pk = F.pack_pair([Ag], None, Bg, None, F._io_dtype(xg))
-    out = F.lora_delta(xg, base, Ag, Bg, pk, scaling, keep.to(dev).to(torch.uint8) if keep is not None else None,
-                       1.0 / (1.0 - p))
-    out.backward(dy.to(dev))
-    torch.cuda.synchronize()
-    return dict(out=rel_err(out, out_ref), dx=rel_err(xg.grad, xr.grad), da=rel_err(Ag.grad, Ar.grad),
+    errs = dict(out=rel_err(out, out_ref), dx=rel_err(xg.grad, xr.grad), da=rel_err(Ag.grad, Ar.grad),
                 db=rel_err(Bg.grad, Br.grad))
+    if p > 0:
+        errs["keep_frac"] = float(keep.float().mean())
+    return errs
 
 
 def run_pack_check(r=96, d=768, nh=4, fp32=False, seed=3):

@@ -102,6 +102,16 @@ def test_k1_saved_and_recompute_backward_agree(dtype):
         assert (a - b).abs().max().item() <= tol * max(a.abs().max().item(), 1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_k1_bias_gradients_per_column(dtype):
+    # the global-norm metric hides small columns: every element of the four bias gradients within 5x the tolerance of
+    # its own magnitude (floored at a tenth of the mean magnitude; the gradients are sums over M = 1000 rows)
+    cols = {}
+    check(C.run_k1(dtype, M=1000, d=768, r=96, rg=96, nh=4, col_errs=cols), dtype)
+    bad = {k: v for k, v in cols.items() if not v <= 5 * TOL[dtype]}
+    assert not bad, (bad, cols)
+
+
 def test_k1_full_size_bf16():
     # config 2 (VQA step): M = 500 * 56 rows
     check(C.run_k1(torch.bfloat16, M=28000), torch.bfloat16)
@@ -116,7 +126,30 @@ def test_k2(dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("r,p", [(4, 0.0), (8, 0.0), (64, 0.0), (128, 0.1), (8, 0.1)])
 def test_k3(dtype, r, p):
-    check(C.run_k3(dtype, r=r, p=p), dtype)
+    errs = C.run_k3(dtype, r=r, p=p)
+    if p > 0:       # mask from the in-kernel generator (exported): keeps ~ (1 - p) of 153,600 elements
+        assert abs(errs.pop("keep_frac") - (1 - p)) < 0.01
+    check(errs, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_k3_explicit_mask_and_determinism(dtype):
+    errs = C.run_k3(dtype, r=64, p=0.1, explicit_mask=True)     # "bring your own mask" form of the ABI
+    errs.pop("keep_frac")
+    check(errs, dtype)
+    # the generator's mask is a function of (seed, element index) only: same for fp32 / bf16 runs and for any M
+    import vlpet_amd.functional as F
+    dev = "cuda"
+    masks = []
+    for dt, M in ((torch.float32, 300), (torch.bfloat16, 300), (dtype, 77)):
+        x = torch.randn(M, 768, device=dev).to(dt)
+        A, B = torch.randn(8, 768, device=dev), torch.randn(768, 8, device=dev)
+        pk = F.pack_pair([A], None, B, None, F._io_dtype(x))
+        _, m = F.lora_delta(x, torch.zeros_like(x), A, B, pk, 1.0, None, 0.1, 1234, return_mask=True)
+        masks.append(m.cpu())
+    assert torch.equal(masks[0], masks[1]) and torch.equal(masks[0][:77], masks[2])
+    _, m2 = F.lora_delta(x, torch.zeros_like(x), A, B, pk, 1.0, None, 0.1, 1235, return_mask=True)
+    assert not torch.equal(m2.cpu(), masks[2])
 
 
 def test_fails_loudly_on_cpu_tensor():
@@ -128,5 +161,5 @@ def test_fails_loudly_on_cpu_tensor():
 def test_k1_backward_transpose_read_wgrad_variant(monkeypatch):
     """The opt-in weight-gradient kernel built on ds_read_b64_tr_b16 (VLPET_WGRAD_TR=1) gives the same gradients."""
     monkeypatch.setenv("VLPET_WGRAD_TR", "1")
-    C.run_k1(torch.bfloat16, M=1000, d=768, r=96, rg=96, nh=4)
-    C.run_k1(torch.bfloat16, M=333, d=256, r=8, rg=16, nh=4)
+    check(C.run_k1(torch.bfloat16, M=1000, d=768, r=96, rg=96, nh=4), torch.bfloat16)
+    check(C.run_k1(torch.bfloat16, M=333, d=256, r=8, rg=16, nh=4), torch.bfloat16)

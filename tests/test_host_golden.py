@@ -19,7 +19,11 @@ FIXTURES = {"vlpet_large": ("vlbart_tiny_d64", {}),
                                                   unfreeze_encoder_layer_norms=False, use_lora=True, lora_dim=8, lora_dropout=0.0,
                                                   use_single_lora=True)),
             # scripts/image-text/T5-VL-PET-large.sh on the reference's VLT5 (gate scale 0.3, RMS norms, pre-LN tails)
-            "t5": ("vlt5_tiny_d64", None)}
+            "t5": ("vlt5_tiny_d64", None),
+            # scripts/video-text/VL-PET-large.sh (BASELINE configs[4]): 64 frame features through Downsample((8, 8)), four
+            # video tasks, ragged text padded with the pad id -> pins the default mask input_ids.ne(pad) in encoder
+            # self-attention and decoder cross-attention (src/modeling_bart.py:817-818, 995-996) and the video loss
+            "video": ("vlbart_tiny_video_d64", dict(tasks="tvqa,how2qa,tvc,yc2c", n_boxes=64))}
 
 
 def _load(name):

@@ -118,3 +118,26 @@ def test_cpu_reference_ops_run_the_host_model_on_cpu():
     assert l0 == l0 and l1 == l1          # finite
     with pytest.raises(RuntimeError):      # outside the patch the product path refuses CPU tensors
         model(batch["input_ids"], batch["vis_inputs"], batch["labels"], "nlvr")
+
+
+def test_per_task_parameter_detection():
+    """FlatGrads.per_task drives the optimizer's per-parameter step counts (transformers.AdamW skips grad-None parameters)."""
+    import vlpet_amd.host.bart as HB
+    import vlpet_amd.train as TR
+    small = dict(d_model=64, encoder_layers=1, decoder_layers=1, encoder_attention_heads=4, decoder_attention_heads=4,
+                 encoder_ffn_dim=128, decoder_ffn_dim=128, vocab_size=300, max_position_embeddings=64, feat_dim=128,
+                 adapter_down_dim=8, adapter_gating_down_dim=8, decoder_enc_attn_value_parallel_adapter_down_dim=8)
+    for over, expect in ((dict(), False), (dict(use_single_adapter=False), True)):
+        cfg = HB.vlpet_config(**small, **over)
+        m = HB.VLBart(cfg)
+        names = TR.trainable_names(m, cfg)
+        ps = dict(m.named_parameters())
+        assert TR._has_per_task_params(names, [ps[n] for n in names]) is expect
+    lora = dict(use_adapter=False, use_encoder_adapter_down_multihead=False, use_encoder_adapter_gating_large_x_lowrank=False,
+                use_decoder_enc_attn_value_parallel_adapter_down_dim=False, use_lora=True, lora_dim=4)
+    for single, expect in ((True, False), (False, True)):
+        cfg = HB.vlpet_config(**small, **lora, use_single_lora=single)
+        m = HB.VLBart(cfg)
+        names = TR.trainable_names(m, cfg)
+        ps = dict(m.named_parameters())
+        assert TR._has_per_task_params(names, [ps[n] for n in names]) is expect

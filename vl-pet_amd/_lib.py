@@ -50,8 +50,8 @@ SIGNATURES = {
                                                 c_float, c_int, c_void_p]),
     "vlpet_parallel_adapter_bwd_saved": (c_int, [c_void_p] * 5 + [c_void_p] * 4 + [c_int, c_void_p, c_size_t, c_int64,
                                                                                    c_int, c_int, c_float, c_int, c_void_p]),
-    "vlpet_lora_delta_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int,
-                                     c_int, c_float, c_int, c_void_p]),
+    "vlpet_lora_delta_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_uint64, c_void_p, c_void_p,
+                                     c_int64, c_int, c_int, c_float, c_int, c_void_p]),
     "vlpet_visproj_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vlpet_visproj_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vlpet_visproj_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
@@ -67,12 +67,16 @@ SIGNATURES = {
     "vlpet_grad_sumsq": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "vlpet_adamw_step": (c_int, [c_void_p] * 5 + [c_int64, c_void_p, c_int] + [c_float] * 7 + [c_int, c_int, c_int,
                                                                                            c_void_p, c_void_p]),
+    "vlpet_adamw_step_sliced": (c_int, [c_void_p] * 5 + [c_int64, c_void_p, c_int] + [c_float] * 7 + [c_void_p, c_void_p,
+                                                                                                  c_int, c_int, c_void_p,
+                                                                                                  c_void_p]),
     "vlpet_downsample_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vlpet_sublayer_tail_partials": (c_int, [c_int64]),
     "vlpet_sublayer_tail_fwd": (c_int, [c_void_p] * 9 + [c_int64, c_int, c_float, c_float, c_uint64, c_int, c_int, c_void_p]),
     "vlpet_sublayer_tail_bwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_float, c_uint64, c_int, c_int, c_void_p]),
-    "vlpet_lora_delta_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
-                                     c_int, c_void_p, c_size_t, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
+    "vlpet_lora_delta_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_uint64, c_void_p, c_void_p,
+                                     c_void_p, c_int, c_void_p, c_size_t, c_int64, c_int, c_int, c_float, c_int,
+                                     c_void_p]),
 }
 
 

@@ -84,28 +84,49 @@ extern "C" size_t vlpet_saved_bytes(int64_t M, int tiles, int io_dtype) {
     return 4 * saved_stride(M, tiles, io_dtype);
 }
 
+static const DropSpec NO_DROP = {nullptr, nullptr, 0, 0, 1.f};
+
+// p in [0, 1): explicit mask (keep_mask != NULL) or the in-kernel generator keyed by `seed`; p == 0: no dropout
+static int make_drop(const uint8_t* keep_mask, float p, uint64_t seed, uint8_t* keep_out, DropSpec* ds) {
+    if (!(p >= 0.f && p < 1.f)) return VLPET_E_SHAPE;
+    *ds = NO_DROP;
+    if (p == 0.f) return 0;
+    ds->keep = keep_mask;
+    ds->keep_out = keep_out;
+    ds->seed = seed;
+    double t = (double)p * 65536.0 + 0.5;
+    if (t > 65535.0) t = 65535.0;
+    ds->thr = (uint32_t)t;
+    if (ds->thr == 0 && !keep_mask) { *ds = NO_DROP; return 0; }      // p < 2^-17: the generator never drops
+    ds->keep_scale = 1.0f / (1.0f - p);
+    return 0;
+}
+
 static int run_fwd(const void* xa, const void* res, const void* xg, const void* pk_a, const void* pk_g,
-                   const uint8_t* keep, float keep_scale, void* out, int64_t M, int d, int tiles,
+                   const DropSpec& drop, void* out, int64_t M, int d, int tiles,
                    float s2, float sd, float gs, int flags, int io_dtype, vlpet_stream_t stream,
                    void* saved = nullptr) {
     int rc = check_common(M, d, tiles, io_dtype);
     if (rc) return rc;
     if (!xa || !res || !pk_a || !out) return VLPET_E_NULL;
-    if (saved && ((flags & PET_ACT_IDENTITY) || keep || !aligned16(saved))) return VLPET_E_ALIGN;
+    if (saved && ((flags & PET_ACT_IDENTITY) || drop_active(drop) || !aligned16(saved))) return VLPET_E_ALIGN;
     if ((flags & PET_GATE) && (!xg || !pk_g)) return VLPET_E_NULL;
     if (!aligned16(xa) || !aligned16(res) || !aligned16(out) || !aligned16(pk_a) ||
-        ((flags & PET_GATE) && (!aligned16(xg) || !aligned16(pk_g))) || (keep && !aligned16(keep)))
+        ((flags & PET_GATE) && (!aligned16(xg) || !aligned16(pk_g))) || (drop.keep && !aligned16(drop.keep)) ||
+        (drop.keep_out && !aligned16(drop.keep_out)))
         return VLPET_E_ALIGN;
     PetFwdArgs a;
     a.xa = xa; a.res = res; a.xg = xg; a.out = out;
     a.pk_a = reinterpret_cast<const uint8_t*>(pk_a);
     a.pk_g = reinterpret_cast<const uint8_t*>(pk_g);
-    a.keep = keep; a.keep_scale = keep_scale;
+    a.drop = drop;
     a.M = M; a.d = d; a.RT = tiles;
     a.s2 = s2; a.sd = sd; a.gs = gs; a.flags = flags;
     a.save = saved; a.save_stride = (int64_t)saved_stride(M, tiles, io_dtype);
-    { const char* e = getenv("VLPET_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = 0;
     a.dbg_ts = nullptr;
+#ifdef VLPET_DEBUG      // ablation bits / cycle stamps: debug builds only (function-static device buffer, synchronises, prints)
+    { const char* e = getenv("VLPET_DBG"); a.dbg = e ? atoi(e) : 0; }
     if (a.dbg & 16) {     // debug only: per-phase timestamps of wave 0 of every block, printed at the next call
         static unsigned long long* dev = nullptr;
         static int nblk = 0;
@@ -128,6 +149,7 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
         nblk = (int)((M + 127) / 128); if (nblk > 4096) nblk = 4096;
         a.dbg_ts = dev;
     }
+#endif
     if ((flags & PET_GATE) && !(a.dbg & 64))      // two-chain gate forward: one wave per chain (VLPET_DBG=64: single-wave form)
         return herr(launch_pet_gate_fwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));
     return herr(launch_pet_fwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));
@@ -141,7 +163,7 @@ extern "C" int vlpet_adapter_gate_fwd(const void* x1, const void* x2, const void
     if (gate_mode == VLPET_GATE_MUL) flags = PET_GATE;
     else if (gate_mode == VLPET_GATE_ADD) flags = PET_GATE | PET_GATE_ADD;
     else if (gate_mode != VLPET_GATE_NONE) return VLPET_E_SHAPE;
-    return run_fwd(x2, x2, x1, packed_a, packed_g, nullptr, 1.f, out, M, d, tiles, x2_scale, delta_scale,
+    return run_fwd(x2, x2, x1, packed_a, packed_g, NO_DROP, out, M, d, tiles, x2_scale, delta_scale,
                    flags ? gate_scale : 1.f, flags, io_dtype, stream);
 }
 
@@ -152,27 +174,29 @@ extern "C" int vlpet_adapter_gate_fwd_save(const void* x1, const void* x2, const
     int flags;
     if (gate_flags(gate_mode, &flags)) return VLPET_E_SHAPE;
     if (!saved) return VLPET_E_NULL;
-    return run_fwd(x2, x2, x1, packed_a, packed_g, nullptr, 1.f, out, M, d, tiles, x2_scale, delta_scale,
+    return run_fwd(x2, x2, x1, packed_a, packed_g, NO_DROP, out, M, d, tiles, x2_scale, delta_scale,
                    flags ? gate_scale : 1.f, flags, io_dtype, stream, saved);
 }
 
 extern "C" int vlpet_parallel_adapter_fwd(const void* x, const void* y, const void* packed, void* out,
                                           int64_t M, int d, int tiles, float scale, int io_dtype,
                                           vlpet_stream_t stream) {
-    return run_fwd(x, y, nullptr, packed, nullptr, nullptr, 1.f, out, M, d, tiles, 1.f, scale, 1.f, 0, io_dtype, stream);
+    return run_fwd(x, y, nullptr, packed, nullptr, NO_DROP, out, M, d, tiles, 1.f, scale, 1.f, 0, io_dtype, stream);
 }
 
 extern "C" int vlpet_parallel_adapter_fwd_save(const void* x, const void* y, const void* packed, void* out, void* saved,
                                                int64_t M, int d, int tiles, float scale, int io_dtype,
                                                vlpet_stream_t stream) {
     if (!saved) return VLPET_E_NULL;
-    return run_fwd(x, y, nullptr, packed, nullptr, nullptr, 1.f, out, M, d, tiles, 1.f, scale, 1.f, 0, io_dtype, stream, saved);
+    return run_fwd(x, y, nullptr, packed, nullptr, NO_DROP, out, M, d, tiles, 1.f, scale, 1.f, 0, io_dtype, stream, saved);
 }
 
 extern "C" int vlpet_lora_delta_fwd(const void* x, const void* base, const void* packed,
-                                    const uint8_t* keep_mask, float keep_scale, void* out, int64_t M, int d,
-                                    int tiles, float scaling, int io_dtype, vlpet_stream_t stream) {
-    return run_fwd(x, base, nullptr, packed, nullptr, keep_mask, keep_scale, out, M, d, tiles, 1.f, scaling, 1.f,
+                                    const uint8_t* keep_mask, float p, uint64_t seed, uint8_t* keep_out, void* out,
+                                    int64_t M, int d, int tiles, float scaling, int io_dtype, vlpet_stream_t stream) {
+    DropSpec ds;
+    if (int rc = make_drop(keep_mask, p, seed, keep_out, &ds)) return rc;
+    return run_fwd(x, base, nullptr, packed, nullptr, ds, out, M, d, tiles, 1.f, scaling, 1.f,
                    PET_ACT_IDENTITY, io_dtype, stream);
 }
 
@@ -210,7 +234,7 @@ extern "C" size_t vlpet_bwd_workspace_bytes(int64_t M, int d, int tiles, int has
 }
 
 static int run_bwd(const void* dy, const void* xa, const void* res, const void* xg,
-                   const void* pk_a, const void* pk_g, const uint8_t* keep, float keep_scale,
+                   const void* pk_a, const void* pk_g, const DropSpec& drop,
                    void* dxa, void* dxg,
                    float* dwd, float* dbd, float* dwu, float* dbu,
                    float* dwgd, float* dbgd, float* dwgu, float* dbgu, int r, int rg,
@@ -226,7 +250,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     if (r <= 0 || r > 32 * tiles || (gate && (rg <= 0 || rg > 32 * tiles))) return VLPET_E_RANK;
     if (!aligned16(dy) || !aligned16(xa) || !aligned16(dxa) || !aligned16(workspace) || !aligned16(pk_a) ||
         (gate && (!aligned16(xg) || !aligned16(res) || !aligned16(dxg) || !aligned16(pk_g))) ||
-        (keep && !aligned16(keep)))
+        (drop.keep && !aligned16(drop.keep)))
         return VLPET_E_ALIGN;
     const BwdWs w = bwd_ws(M, d, tiles, gate, io_dtype);
     if (workspace_bytes < w.total) return VLPET_E_WORKSPACE;
@@ -240,10 +264,10 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     b.dh = gate ? ws + w.dh : nullptr; b.dq = gate ? ws + w.dq : nullptr;
     b.pk_a = reinterpret_cast<const uint8_t*>(pk_a);
     b.pk_g = reinterpret_cast<const uint8_t*>(pk_g);
-    b.keep = keep; b.keep_scale = keep_scale;
+    b.drop = drop; b.drop.keep_out = nullptr;
     b.M = M; b.d = d; b.RT = tiles;
     b.s2 = s2; b.sd = sd; b.gs = gs; b.flags = flags;
-    if (saved && ((flags & PET_ACT_IDENTITY) || keep || !aligned16(saved))) return VLPET_E_ALIGN;
+    if (saved && ((flags & PET_ACT_IDENTITY) || drop_active(drop) || !aligned16(saved))) return VLPET_E_ALIGN;
     b.saved = saved; b.saved_stride = (int64_t)saved_stride(M, tiles, io_dtype);
     if (saved) {        // z comes from the forward; the rows kernel does not write it
         b.z_a = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(saved));
@@ -260,23 +284,23 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     g.M = M; g.RT = tiles; g.row_chunks = w.row_chunks; g.rows_per_chunk = w.rows_per_chunk;
     g.partial = reinterpret_cast<float*>(ws + w.partial);
     const int ldp = 32 * tiles;
-    auto job = [&](int i, const void* P, const void* X, const uint8_t* kp, float scale, float* out, int ldo,
+    auto job = [&](int i, const void* P, const void* X, bool dropped, float scale, float* out, int ldo,
                    int transposed, int out_rows, float* csx, float* csp) {
         WgradJob& J = g.job[i];
         J.P = P; J.ldp = ldp; J.pcols = ldp;
         J.X = X; J.ldx = d; J.xcols = d;
-        J.keep = kp; J.keep_scale = keep_scale;
+        J.drop = dropped ? b.drop : NO_DROP; J.has_drop = dropped && drop_active(b.drop);
         J.scale = scale; J.out = out; J.ldo = ldo; J.transposed = transposed; J.out_rows = out_rows;
         J.colsum_x = csx; J.colsum_p = csp;
     };
     // down weight:  dWd[c,k] = sum_m dpre[m,c] * xa[m,k];  bias = column sums of dpre
-    job(0, b.dp_a, xa, keep, 1.f, dwd, d, 0, r, nullptr, dbd);
+    job(0, b.dp_a, xa, true, 1.f, dwd, d, 0, r, nullptr, dbd);
     // up weight:    dWu[f,c] = sd * sum_m dh[m,f] * z[m,c]  (X = dh, or dy itself without a gate)
-    job(1, b.z_a, gate ? b.dh : dy, nullptr, sd, dwu, r, 1, r, dbu, nullptr);
+    job(1, b.z_a, gate ? b.dh : dy, false, sd, dwu, r, 1, r, dbu, nullptr);
     g.njobs = 2;
     if (gate) {
-        job(2, b.dp_g, xg, nullptr, 1.f, dwgd, d, 0, rg, nullptr, dbgd);
-        job(3, b.z_g, b.dq, nullptr, 1.f, dwgu, rg, 1, rg, dbgu, nullptr);
+        job(2, b.dp_g, xg, false, 1.f, dwgd, d, 0, rg, nullptr, dbgd);
+        job(3, b.z_g, b.dq, false, 1.f, dwgu, rg, 1, rg, dbgu, nullptr);
         g.njobs = 4;
     }
     return herr(launch_wgrad(g, io_dtype == VLPET_F32, (hipStream_t)stream));
@@ -294,7 +318,7 @@ extern "C" int vlpet_adapter_gate_bwd(const void* dy, const void* x1, const void
     else if (gate_mode == VLPET_GATE_ADD) flags = PET_GATE | PET_GATE_ADD;
     else if (gate_mode != VLPET_GATE_NONE) return VLPET_E_SHAPE;
     if (!dbd || !dbu) return VLPET_E_NULL;
-    return run_bwd(dy, x2, x2, x1, packed_a, packed_g, nullptr, 1.f, dx2, dx1, dwd, dbd, dwu, dbu,
+    return run_bwd(dy, x2, x2, x1, packed_a, packed_g, NO_DROP, dx2, dx1, dwd, dbd, dwu, dbu,
                    dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
                    x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream);
 }
@@ -317,7 +341,7 @@ extern "C" int vlpet_adapter_gate_bwd_phase(int phases, const void* dy, const vo
     int flags;
     if (gate_flags(gate_mode, &flags)) return VLPET_E_SHAPE;
     if (!dbd || !dbu || (phases & 3) == 0) return VLPET_E_NULL;
-    return run_bwd(dy, x2, x2, x1, packed_a, packed_g, nullptr, 1.f, dx2, dx1, dwd, dbd, dwu, dbu,
+    return run_bwd(dy, x2, x2, x1, packed_a, packed_g, NO_DROP, dx2, dx1, dwd, dbd, dwu, dbu,
                    dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
                    x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream, phases & 3);
 }
@@ -332,7 +356,7 @@ extern "C" int vlpet_adapter_gate_bwd_saved(int phases, const void* dy, const vo
     int flags;
     if (gate_flags(gate_mode, &flags)) return VLPET_E_SHAPE;
     if (!dbd || !dbu || !saved || (phases & 3) == 0) return VLPET_E_NULL;
-    return run_bwd(dy, x2, x2, x1, packed_a, packed_g, nullptr, 1.f, dx2, dx1, dwd, dbd, dwu, dbu,
+    return run_bwd(dy, x2, x2, x1, packed_a, packed_g, NO_DROP, dx2, dx1, dwd, dbd, dwu, dbu,
                    dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
                    x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream, phases & 3, saved);
 }
@@ -342,7 +366,7 @@ extern "C" int vlpet_parallel_adapter_bwd(const void* dy, const void* x, const v
                                           void* workspace, size_t workspace_bytes, int64_t M, int d,
                                           int tiles, float scale, int io_dtype, vlpet_stream_t stream) {
     if (!dbd || !dbu) return VLPET_E_NULL;
-    return run_bwd(dy, x, nullptr, nullptr, packed, nullptr, nullptr, 1.f, dx, nullptr, dwd, dbd, dwu, dbu,
+    return run_bwd(dy, x, nullptr, nullptr, packed, nullptr, NO_DROP, dx, nullptr, dwd, dbd, dwu, dbu,
                    nullptr, nullptr, nullptr, nullptr, r, 0, workspace, workspace_bytes, M, d, tiles,
                    1.f, scale, 1.f, 0, io_dtype, stream);
 }
@@ -352,17 +376,19 @@ extern "C" int vlpet_parallel_adapter_bwd_saved(const void* dy, const void* x, c
                                                 void* workspace, size_t workspace_bytes, int64_t M, int d,
                                                 int tiles, float scale, int io_dtype, vlpet_stream_t stream) {
     if (!dbd || !dbu || !saved) return VLPET_E_NULL;
-    return run_bwd(dy, x, nullptr, nullptr, packed, nullptr, nullptr, 1.f, dx, nullptr, dwd, dbd, dwu, dbu,
+    return run_bwd(dy, x, nullptr, nullptr, packed, nullptr, NO_DROP, dx, nullptr, dwd, dbd, dwu, dbu,
                    nullptr, nullptr, nullptr, nullptr, r, 0, workspace, workspace_bytes, M, d, tiles,
                    1.f, scale, 1.f, 0, io_dtype, stream, 3, saved);
 }
 
 extern "C" int vlpet_lora_delta_bwd(const void* dy, const void* x, const void* packed,
-                                    const uint8_t* keep_mask, float keep_scale, void* dx,
+                                    const uint8_t* keep_mask, float p, uint64_t seed, void* dx,
                                     float* da, float* db, int r, void* workspace, size_t workspace_bytes,
                                     int64_t M, int d, int tiles, float scaling, int io_dtype,
                                     vlpet_stream_t stream) {
-    return run_bwd(dy, x, nullptr, nullptr, packed, nullptr, keep_mask, keep_scale, dx, nullptr,
+    DropSpec ds;
+    if (int rc = make_drop(keep_mask, p, seed, nullptr, &ds)) return rc;
+    return run_bwd(dy, x, nullptr, nullptr, packed, nullptr, ds, dx, nullptr,
                    da, nullptr, db, nullptr, nullptr, nullptr, nullptr, nullptr, r, 0,
                    workspace, workspace_bytes, M, d, tiles, 1.f, scaling, 1.f, PET_ACT_IDENTITY,
                    io_dtype, stream);
@@ -444,7 +470,7 @@ extern "C" int vlpet_visproj_wgrad(const void* dpre, const void* feats, float* d
             const int c0 = (j0 + j) * pcols;
             J.P = reinterpret_cast<const uint8_t*>(dpre) + (size_t)c0 * esz; J.ldp = d_out; J.pcols = pcols;
             J.X = feats; J.ldx = feat_dim; J.xcols = feat_dim;
-            J.keep = nullptr; J.keep_scale = 1.f; J.scale = 1.f;
+            J.drop = NO_DROP; J.has_drop = 0; J.scale = 1.f;
             J.out = dw + (size_t)c0 * feat_dim; J.ldo = feat_dim; J.transposed = 0; J.out_rows = pcols;
             J.colsum_x = nullptr; J.colsum_p = db + c0;
         }
@@ -616,6 +642,26 @@ extern "C" int vlpet_adamw_step(float* p, float* g, float* m, float* v, const ui
     a.bias_c1 = (float)(1.0 - pow((double)beta1, (double)step));
     a.bias_c2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     a.decay_first = variant == 1; a.eps_scaled = variant == 1; a.zero_grad = zero_grad; a.norm_out = norm_out;
+    a.slice_of = nullptr; a.slice_bc = nullptr;
+    return herr(launch_adamw(a, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_adamw_step_sliced(float* p, float* g, float* m, float* v, const uint8_t* decay_mask, int64_t n,
+                                       const float* partials, int n_partials, float max_norm, float grad_scale, float lr,
+                                       float beta1, float beta2, float eps, float weight_decay, const int32_t* slice_of,
+                                       const float* slice_bc, int variant, int zero_grad, float* norm_out,
+                                       vlpet_stream_t stream) {
+    if (!p || !g || !m || !v || !partials || !slice_of || !slice_bc) return VLPET_E_NULL;
+    if (n <= 0 || n_partials <= 0 || (variant != 0 && variant != 1)) return VLPET_E_SHAPE;
+    if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || !aligned16(slice_of) ||
+        (decay_mask && ((uintptr_t)decay_mask & 3)))
+        return VLPET_E_ALIGN;
+    AdamwArgs a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.decay = decay_mask; a.n = n; a.partials = partials; a.n_partials = n_partials;
+    a.max_norm = max_norm; a.grad_scale = grad_scale; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.weight_decay = weight_decay; a.bias_c1 = 1.f; a.bias_c2_sqrt = 1.f;
+    a.decay_first = variant == 1; a.eps_scaled = variant == 1; a.zero_grad = zero_grad; a.norm_out = norm_out;
+    a.slice_of = slice_of; a.slice_bc = slice_bc;
     return herr(launch_adamw(a, (hipStream_t)stream));
 }
 

@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "rng.h"
 
 #define VLPET_MAX_HEADS 16
 
@@ -31,8 +32,7 @@ struct PetFwdArgs {
     void* out;          // [M,d]
     const uint8_t* pk_a;   // packed pair, chain A
     const uint8_t* pk_g;   // packed pair, chain G (gate) or nullptr
-    const uint8_t* keep;   // optional LoRA-dropout keep mask [M,d] uint8 (1 keep) or nullptr
-    float keep_scale;      // 1/(1-p)
+    DropSpec drop;         // LoRA dropout on the chain-A input (rng.h): explicit mask, in-kernel generator, or none
     int64_t M;
     int d, RT;
     float s2, sd, gs;      // x2 scale, delta scale, gate scale
@@ -58,8 +58,7 @@ struct PetBwdArgs {
     void* dh; void* dq;         // [M, d] each (gate only; without gate the wgrad reads dy itself)
     const uint8_t* pk_a;
     const uint8_t* pk_g;
-    const uint8_t* keep;
-    float keep_scale;
+    DropSpec drop;          // LoRA dropout on the chain-A input (same mask as the forward: same explicit mask or same seed)
     const void* saved;      // optional (gated K1): the forward's PetFwdArgs::save block -- skips the recompute of the
     int64_t saved_stride;   //   bottleneck activations (phase 1: no x1 / second x2 read) and the z side products
     int64_t M;
@@ -77,7 +76,7 @@ hipError_t launch_pet_gate_bwd2(const PetBwdArgs& a, int io_fp32, hipStream_t st
 struct WgradJob {
     const void* P; int ldp; int pcols;     // P [M, ldp], columns [0, pcols) used, pcols = 32*RT
     const void* X; int ldx; int xcols;     // X [M, ldx], xcols multiple of 64
-    const uint8_t* keep; float keep_scale; // optional dropout mask applied to X (LoRA down grad)
+    DropSpec drop; int has_drop;           // optional dropout mask applied to X (LoRA down grad; X must be the full [M, ldx] tensor)
     float scale;
     float* out; int ldo; int transposed;   // transposed: out[n*ldo + c] else out[c*ldo + n]
     int out_rows;                          // true rank r (rows c >= r are dropped)
@@ -181,6 +180,8 @@ struct AdamwArgs {
     int eps_scaled;                                // 1: eps added to sqrt(v)/sqrt(bc2) (torch), 0: to sqrt(v) (transformers)
     int zero_grad;                                 // 1: clear g after use
     float* norm_out;                               // optional device scalar: the pre-clip global norm
+    const int32_t* slice_of;                       // optional [n]: parameter index of every element (per-parameter steps)
+    const float* slice_bc;                         //   [n_slices][2]: 1 - b1^t, sqrt(1 - b2^t) per parameter; <= 0 = no grad this step
 };
 hipError_t launch_sumsq(const float* g, int64_t n, float* partials, hipStream_t stream);
 hipError_t launch_adamw(const AdamwArgs& a, hipStream_t stream);

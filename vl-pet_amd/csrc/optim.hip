@@ -38,6 +38,11 @@ __global__ __launch_bounds__(OPT_THREADS) void sumsq_kernel(const float* __restr
     }
 }
 
+// SLICED: per-parameter step counts / activity (transformers.AdamW keeps state['step'] per parameter and skips a
+// parameter whose grad is None -- no decay, no moment update: per-task adapters / LoRA under multitask.py:296-297's
+// grads = None).  slice_of[i] = parameter index of element i; slice_bc[2k], [2k+1] = 1 - b1^t_k, sqrt(1 - b2^t_k) of
+// parameter k, or <= 0 when it received no gradient this step (the element is left untouched).
+template <bool SLICED>
 __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(AdamwArgs a) {
     // every workgroup reduces the (<= 1024) partial sums itself: no host round trip, no third launch
     __shared__ float red[OPT_THREADS / 64];
@@ -59,14 +64,18 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(AdamwArgs a) {
     __syncthreads();
     const float gscale = clip_s;
     const float b1 = a.beta1, b2 = a.beta2, lr = a.lr, eps = a.eps;
-    const float step_size = lr * a.bias_c2_sqrt / a.bias_c1;
-    auto upd = [&](float& p, float g, float& m, float& v, uint8_t dec) {
+    auto upd = [&](float& p, float g, float& m, float& v, uint8_t dec, int sl) {
+        float c1 = a.bias_c1, c2 = a.bias_c2_sqrt;
+        if constexpr (SLICED) {
+            c1 = a.slice_bc[2 * sl]; c2 = a.slice_bc[2 * sl + 1];
+            if (!(c1 > 0.f)) return;                  // no gradient this step: parameter, moments and step untouched
+        }
         g *= gscale;
         const float wd = dec ? a.weight_decay : 0.f;
         if (a.decay_first) p -= lr * wd * p;
         m = b1 * m + (1.f - b1) * g;
         v = b2 * v + (1.f - b2) * g * g;
-        p -= step_size * m / (sqrtf(v) + eps * (a.eps_scaled ? a.bias_c2_sqrt : 1.0f));
+        p -= (lr * c2 / c1) * m / (sqrtf(v) + eps * (a.eps_scaled ? c2 : 1.0f));
         if (!a.decay_first) p -= lr * wd * p;
     };
     const int64_t n4 = a.n / 4;
@@ -74,10 +83,15 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(AdamwArgs a) {
         f32x4 p = reinterpret_cast<f32x4*>(a.p)[i], g = reinterpret_cast<f32x4*>(a.g)[i];
         f32x4 m = reinterpret_cast<f32x4*>(a.m)[i], v = reinterpret_cast<f32x4*>(a.v)[i];
         const uint32_t dk = a.decay ? reinterpret_cast<const uint32_t*>(a.decay)[i] : 0x01010101u;
+        int sl[4] = {0, 0, 0, 0};
+        if constexpr (SLICED) {
+            const auto t = reinterpret_cast<const __attribute__((ext_vector_type(4))) int*>(a.slice_of)[i];
+            sl[0] = t[0]; sl[1] = t[1]; sl[2] = t[2]; sl[3] = t[3];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float pj = p[j], mj = m[j], vj = v[j];
-            upd(pj, g[j], mj, vj, (uint8_t)(dk >> (8 * j)));
+            upd(pj, g[j], mj, vj, (uint8_t)(dk >> (8 * j)), sl[j]);
             p[j] = pj; m[j] = mj; v[j] = vj;
         }
         reinterpret_cast<f32x4*>(a.p)[i] = p;
@@ -87,7 +101,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(AdamwArgs a) {
     }
     if (blockIdx.x == 0 && threadIdx.x < (int)(a.n - n4 * 4)) {
         const int64_t i = n4 * 4 + threadIdx.x;
-        upd(a.p[i], a.g[i], a.m[i], a.v[i], a.decay ? a.decay[i] : (uint8_t)1);
+        upd(a.p[i], a.g[i], a.m[i], a.v[i], a.decay ? a.decay[i] : (uint8_t)1, SLICED ? a.slice_of[i] : 0);
         if (a.zero_grad) a.g[i] = 0.f;
     }
 }
@@ -97,6 +111,9 @@ hipError_t launch_sumsq(const float* g, int64_t n, float* partials, hipStream_t 
     return hipGetLastError();
 }
 hipError_t launch_adamw(const AdamwArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(adamw_kernel, dim3(optim_blocks(a.n)), dim3(OPT_THREADS), 0, stream, a);
+    if (a.slice_of != nullptr)
+        hipLaunchKernelGGL(adamw_kernel<true>, dim3(optim_blocks(a.n)), dim3(OPT_THREADS), 0, stream, a);
+    else
+        hipLaunchKernelGGL(adamw_kernel<false>, dim3(optim_blocks(a.n)), dim3(OPT_THREADS), 0, stream, a);
     return hipGetLastError();
 }

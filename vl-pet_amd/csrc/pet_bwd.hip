@@ -282,13 +282,13 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
             }
             Frag<NS> bA = cur.bA;
             if constexpr (DROP) {
-                const uint64_t kp = *reinterpret_cast<const uint64_t*>(a.keep + grow * d + s * G::FE + 16 * u + 8 * h);
+                const uint32_t kb = drop_bits8(a.drop, grow * d + s * G::FE + 16 * u + 8 * h);
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     v[j] = (float)bA.p[0][j];
                     if constexpr (NS == 2) v[j] += (float)bA.p[1][j];
-                    v[j] = ((kp >> (8 * j)) & 0xff) ? v[j] * a.keep_scale : 0.f;
+                    v[j] = ((kb >> j) & 1u) ? v[j] * a.drop.keep_scale : 0.f;
                 }
                 bA = frag_from_f32<NS>(v);
             }
@@ -591,11 +591,11 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
             }
         }
         if (su == 5) BSTAMP(33);
-        uint64_t kp[4] = {0, 0, 0, 0};
+        uint32_t kp[4] = {0, 0, 0, 0};
         if constexpr (DROP) {
-            const uint8_t* kr = a.keep + grow * d + su * G::FE + G::LW * h;
+            const int64_t e0 = grow * d + su * G::FE + G::LW * h;
 #pragma unroll
-            for (int c = 0; c < G::LW / 8; ++c) kp[c] = *reinterpret_cast<const uint64_t*>(kr + 8 * c);
+            for (int c = 0; c < G::LW / 8; ++c) kp[c] = drop_bits8(a.drop, e0 + 8 * c);
         }
 #pragma unroll
         for (int e = 0; e < G::E4; ++e) {
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
                 const int i = 8 * e + j;
                 float v = aA[i >> 4][i & 15];
                 if constexpr (GATE) v += s2 * dh8[j];
-                if constexpr (DROP) v = ((kp[i >> 3] >> (8 * (i & 7))) & 0xff) ? v * a.keep_scale : 0.f;
+                if constexpr (DROP) v = ((kp[i >> 3] >> (i & 7)) & 1u) ? v * a.drop.keep_scale : 0.f;
                 oa8[j] = v;
                 if constexpr (GATE) og8[j] = aG[i >> 4][i & 15];
             }
@@ -664,7 +664,7 @@ static hipError_t launch_waves(const PetBwdArgs& a, hipStream_t stream) {
 
 template <typename IO, int RT>
 static hipError_t launch_rt(const PetBwdArgs& a, hipStream_t stream) {
-    const bool gate = a.flags & PET_GATE, act_id = a.flags & PET_ACT_IDENTITY, drop = a.keep != nullptr;
+    const bool gate = a.flags & PET_GATE, act_id = a.flags & PET_ACT_IDENTITY, drop = drop_active(a.drop);
     if (gate) return launch_waves<IO, RT, true, false, false>(a, stream);
     if (act_id) return drop ? launch_waves<IO, RT, false, true, true>(a, stream)
                             : launch_waves<IO, RT, false, true, false>(a, stream);

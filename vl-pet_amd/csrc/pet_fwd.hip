@@ -145,14 +145,17 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
         auto load_u = [&](int u) {
             bA[u] = tile_bfrag4<IO>(ta, trow, h, u);
             if constexpr (DROP) {
-                const int64_t grow = (row0_wave + m < a.M) ? row0_wave + m : a.M - 1;
-                const uint64_t kp = *reinterpret_cast<const uint64_t*>(a.keep + grow * d + s * G::FE + 16 * u + 8 * h);
+                const bool live = row0_wave + m < a.M;
+                const int64_t grow = live ? row0_wave + m : a.M - 1;
+                const int64_t e0 = grow * d + s * G::FE + 16 * u + 8 * h;
+                const uint32_t kb = drop_bits8(a.drop, e0);
+                if (a.drop.keep_out != nullptr && live) drop_export8(a.drop.keep_out, e0, kb);
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     v[j] = (float)bA[u].p[0][j];
                     if constexpr (NS == 2) v[j] += (float)bA[u].p[1][j];
-                    v[j] = ((kp >> (8 * j)) & 0xff) ? v[j] * a.keep_scale : 0.f;
+                    v[j] = ((kb >> j) & 1u) ? v[j] * a.drop.keep_scale : 0.f;
                 }
                 bA[u] = frag_from_f32<NS>(v);
             }
@@ -352,7 +355,7 @@ static hipError_t launch_waves(const PetFwdArgs& a, hipStream_t stream) {
 template <typename IO, int RT>
 static hipError_t launch_rt(const PetFwdArgs& a, hipStream_t stream) {
     const bool gate = a.flags & PET_GATE, add = a.flags & PET_GATE_ADD, act_id = a.flags & PET_ACT_IDENTITY;
-    const bool drop = a.keep != nullptr;
+    const bool drop = drop_active(a.drop);
     if (gate) return add ? launch_waves<IO, RT, true, true, false, false>(a, stream)
                          : launch_waves<IO, RT, true, false, false, false>(a, stream);
     if (act_id) return drop ? launch_waves<IO, RT, false, false, true, true>(a, stream)

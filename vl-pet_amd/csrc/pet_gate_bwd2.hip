@@ -407,7 +407,7 @@ static hipError_t launch_rt(const PetBwdArgs& a, hipStream_t stream) {
 bool pet_gate_bwd2_applies(const PetBwdArgs& a) {
     static const bool off = [] { const char* e = getenv("VLPET_BWD2"); return e != nullptr && atoi(e) == 0; }();
     if (off) return false;
-    return (a.flags & PET_GATE) && a.saved != nullptr && a.keep == nullptr && (a.RT == 1 || a.RT == 3);
+    return (a.flags & PET_GATE) && a.saved != nullptr && !drop_active(a.drop) && (a.RT == 1 || a.RT == 3);
 }
 
 hipError_t launch_pet_gate_bwd2(const PetBwdArgs& a, int io_fp32, hipStream_t stream) {

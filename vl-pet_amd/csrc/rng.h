@@ -1,0 +1,63 @@
+// Counter-based dropout masks shared by the K5 tail (tail.hip) and the K3 LoRA kernels (pet_fwd / pet_bwd / wgrad).
+//
+// Philox-4x32 (7 rounds; Salmon et al., "Parallel random numbers: as easy as 1, 2, 3") keyed by the call's 64-bit
+// seed, counter = index of the 8-element group of the row-major [M, d] tensor; element j of the group keeps iff its
+// 16-bit lane >= thr = round(p * 65536).  The mask depends on (seed, element index) only -- not on the IO dtype, the
+// kernel or the workgroup geometry -- so the forward, the backward rows kernel and the weight-gradient kernel
+// regenerate the same mask and nothing is stored.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+__device__ __forceinline__ void philox7(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t* o) {
+    uint32_t c2 = 0x5bd1e995u, c3 = 0x2545f491u;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+// keep flags (bit j = element j of the 8-element group kept)
+__device__ __forceinline__ uint32_t keep8(int64_t group, uint64_t seed, uint32_t thr) {
+    uint32_t o[4];
+    philox7((uint32_t)group, (uint32_t)((uint64_t)group >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t u = (o[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+        bits |= (u >= thr ? 1u : 0u) << j;
+    }
+    return bits;
+}
+
+// Where a kernel's dropout mask comes from: an explicit 0/1 byte mask (keep != nullptr; "bring your own mask") or the
+// generator above (keep == nullptr, thr != 0).  Neither: no dropout (the kernels' DROP template flag is then false).
+struct DropSpec {
+    const uint8_t* keep;     // [M, d] uint8, 1 = keep, or nullptr
+    uint8_t* keep_out;       // forward only: optional [M, d] 0/1 export of the mask that was applied (parity tests)
+    uint64_t seed;
+    uint32_t thr;            // drop iff 16-bit uniform < thr
+    float keep_scale;        // 1 / (1 - p)
+};
+static inline bool drop_active(const DropSpec& s) { return s.keep != nullptr || s.thr != 0; }
+
+// keep flags of elements e0 .. e0+7 (e0 % 8 == 0) of the row-major tensor
+__device__ __forceinline__ uint32_t drop_bits8(const DropSpec& s, int64_t e0) {
+    if (s.keep != nullptr) {
+        const uint64_t kp = *reinterpret_cast<const uint64_t*>(s.keep + e0);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bits |= (((kp >> (8 * j)) & 0xff) ? 1u : 0u) << j;
+        return bits;
+    }
+    return keep8(e0 >> 3, s.seed, s.thr);
+}
+__device__ __forceinline__ void drop_export8(uint8_t* keep_out, int64_t e0, uint32_t bits) {
+    uint64_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v |= (uint64_t)((bits >> j) & 1u) << (8 * j);
+    *reinterpret_cast<uint64_t*>(keep_out + e0) = v;
+}

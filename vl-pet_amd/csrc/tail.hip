@@ -17,31 +17,8 @@
 #include "common.h"
 #include "kernels.h"
 #include "rowops.h"
+#include "rng.h"
 #include <cstdlib>
-
-__device__ __forceinline__ void philox7(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t* o) {
-    uint32_t c2 = 0x5bd1e995u, c3 = 0x2545f491u;
-#pragma unroll
-    for (int r = 0; r < 7; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
-}
-// keep flags (bit j = element j of the 8-element group kept)
-__device__ __forceinline__ uint32_t keep8(int64_t group, uint64_t seed, uint32_t thr) {
-    uint32_t o[4];
-    philox7((uint32_t)group, (uint32_t)((uint64_t)group >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
-    uint32_t bits = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint32_t u = (o[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-        bits |= (u >= thr ? 1u : 0u) << j;
-    }
-    return bits;
-}
 
 constexpr int TAIL_WAVES = 4;
 

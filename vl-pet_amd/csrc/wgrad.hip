@@ -90,11 +90,11 @@ __device__ __forceinline__ void raw_f32(const Raw8<float>& r, float* v) {
 }
 
 template <typename IO>
-__device__ __forceinline__ Frag<IoTraits<IO>::NS> raw_frag8(const Raw8<IO>& r, bool valid, const uint8_t* keep,
+__device__ __forceinline__ Frag<IoTraits<IO>::NS> raw_frag8(const Raw8<IO>& r, bool valid, bool drop, uint32_t kb,
                                                             float keep_scale) {
     constexpr int NS = IoTraits<IO>::NS;
     if constexpr (NS == 1) {
-        if (keep == nullptr) {
+        if (!drop) {
             Frag<1> f;
             bf16x8 z;
 #pragma unroll
@@ -105,10 +105,9 @@ __device__ __forceinline__ Frag<IoTraits<IO>::NS> raw_frag8(const Raw8<IO>& r, b
     }
     float v[8];
     raw_f32(r, v);
-    if (keep != nullptr) {
-        const uint64_t k = *reinterpret_cast<const uint64_t*>(keep);
+    if (drop) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = ((k >> (8 * j)) & 0xff) ? v[j] * keep_scale : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = ((kb >> j) & 1u) ? v[j] * keep_scale : 0.f;
     }
     if (!valid) {
 #pragma unroll
@@ -143,8 +142,8 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_kernel(WgradArgs a) {
     const int jb = wg.job;
     const IO* P = reinterpret_cast<const IO*>(a.job[jb].P);
     const IO* X = reinterpret_cast<const IO*>(a.job[jb].X);
-    const uint8_t* keep = a.job[jb].keep;
-    const float keep_scale = a.job[jb].keep_scale;
+    const bool has_drop = a.job[jb].has_drop != 0;
+    const DropSpec drop = a.job[jb].drop;
     const int ldp = a.job[jb].ldp, ldx = a.job[jb].ldx, xc = a.job[jb].xcols;
     const int n0 = wg.slice * 64;
     if (n0 >= xc) return;
@@ -188,16 +187,16 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_kernel(WgradArgs a) {
         const bool valid = rb + m < r_end;
         Frag<NS> pn[KT], xn[4];
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) pn[ks] = raw_frag8<IO>(rp[ks], valid, nullptr, 1.f);
+        for (int ks = 0; ks < KT; ++ks) pn[ks] = raw_frag8<IO>(rp[ks], valid, false, 0u, 1.f);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint8_t* kp = nullptr;
-            if (keep != nullptr) {
+            uint32_t kb = 0;
+            if (has_drop) {
                 int64_t row = rb + m;
                 if (row >= r_end) row = r_end - 1;
-                kp = keep + row * ldx + n0 + 16 * q + 8 * h;
+                kb = drop_bits8(drop, row * ldx + n0 + 16 * q + 8 * h);
             }
-            xn[q] = raw_frag8<IO>(rx[q], valid, kp, keep_scale);
+            xn[q] = raw_frag8<IO>(rx[q], valid, has_drop, kb, drop.keep_scale);
         }
         if (rb + 128 < r_end) load_block(rb + 128);          // prefetch: in flight during the MFMAs below
         Frag<NS> xt[2][2];
@@ -585,7 +584,7 @@ static hipError_t launch_one(const WgradArgs& a, hipStream_t stream) {
     for (int j = 0; j < a.njobs; ++j) {
         if (a.job[j].xcols > xmax) xmax = a.job[j].xcols;
         if (a.job[j].out_rows > rmax) rmax = a.job[j].out_rows;
-        if (a.job[j].keep != nullptr || a.job[j].ldp % 8 != 0 || a.job[j].ldx % 8 != 0) plain = false;
+        if (a.job[j].has_drop || a.job[j].ldp % 8 != 0 || a.job[j].ldx % 8 != 0) plain = false;
     }
     // opt-in (VLPET_WGRAD_TR=1): same time as the identity-transpose kernel at M = 28k (89 vs 87 us) -- both are bound by
     // the re-read of P per 64-column slice (L2 hit rate 24 %), not by the operand construction; kept as the base of the

@@ -79,26 +79,32 @@ def _apply_pet_split(module, which, x1, x2, dws, dbs, up, gdown, gup, mode, sd, 
     if nh % 2 == 0:
         wa, ba, wb, bb = list(dws[:nh // 2]), list(dbs[:nh // 2]), list(dws[nh // 2:]), list(dbs[nh // 2:])
         ra = sum(w.shape[0] for w in wa)
-    else:                                   # a single down projection: split its rows
+    elif nh == 1:                           # a single down projection: split its rows
         ra = r // 2
         wa, ba, wb, bb = [dws[0][:ra]], [dbs[0][:ra]], [dws[0][ra:]], [dbs[0][ra:]]
+    else:
+        raise NotImplementedError(f"vl-pet_amd: r > 96 with an odd number of down-projection heads ({nh}) is not supported")
     cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(list(ts), 0)
-    ua, ub = up.weight[:, :ra].contiguous(), up.weight[:, ra:].contiguous()
+    # Every pack below is keyed on the SOURCE parameters (PackCache.get_derived): the slices / concatenations / contiguous
+    # copies are temporaries, rebuilt only when a source changed.
+    src_a = list(dws) + list(dbs) + [up.weight, up.bias]
     t3 = 3
     # adapter chain: h1 = s2*x2 + sd*(up_a(gelu(down_a x2)) + bu);  lin = h1 + sd*up_b(gelu(down_b x2))
-    pk = caches[0].get(wa, ba, ua, up.bias, io, t3)
+    ua = up.weight[:, :ra]
+    pk = caches[0].get_derived(src_a, ("a0", ra), lambda: (wa, ba, ua.contiguous(), up.bias), io, t3)
     h1 = VF.adapter_gate(None, x2, wa, ba, ua, up.bias, None, pk, None, VF.GATE_NONE, sd, s2, 1.0)
-    wbc, bbc = cat(wb), cat(bb)
-    pk = caches[1].get([wbc], [bbc], ub, None, io, t3)
+    wbc, bbc, ub = cat(wb), cat(bb), up.weight[:, ra:]
+    pk = caches[1].get_derived(src_a, ("a1", ra), lambda: ([wbc], [bbc], ub.contiguous(), None), io, t3)
     lin = VF.parallel_adapter(x2, h1, wbc, bbc, ub, None, pk, sd)
     # gate chain on x1
     rg = gup.weight.shape[1]
     ga = rg // 2
+    src_g = [gdown.weight, gdown.bias, gup.weight, gup.bias]
     gwa, gba, gwb, gbb = gdown.weight[:ga], gdown.bias[:ga], gdown.weight[ga:], gdown.bias[ga:]
-    gua, gub = gup.weight[:, :ga].contiguous(), gup.weight[:, ga:].contiguous()
-    pk = caches[2].get([gwa], [gba], gua, gup.bias, io, t3)
+    gua, gub = gup.weight[:, :ga], gup.weight[:, ga:]
+    pk = caches[2].get_derived(src_g, ("g0", ga), lambda: ([gwa], [gba], gua.contiguous(), gup.bias), io, t3)
     g1 = VF.adapter_gate(None, x1, [gwa], [gba], gua, gup.bias, None, pk, None, VF.GATE_NONE, 1.0, 0.0, 1.0)
-    pk = caches[3].get([gwb], [gbb], gub, None, io, t3)
+    pk = caches[3].get_derived(src_g, ("g1", ga), lambda: ([gwb], [gbb], gub.contiguous(), None), io, t3)
     g = torch.sigmoid(VF.parallel_adapter(x1, g1, gwb, gbb, gub, None, pk, 1.0).float()).to(lin.dtype)
     y = lin + g if mode == VF.GATE_ADD else lin * g
     return y * gs if gs != 1.0 else y

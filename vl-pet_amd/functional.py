@@ -158,6 +158,17 @@ class PackCache:
             self._key = key
         return self._val
 
+    def get_derived(self, sources, tag, build, io_dtype, tiles=None) -> PackedPair:
+        """Pack of tensors DERIVED from parameters (slices, concatenations, ``.contiguous()`` copies): the key is made from
+        the source parameters (+ ``tag``, the derivation's geometry), never from the temporaries -- their ``_version`` is
+        always 0 and their address is whatever the caching allocator hands out -- and ``build()`` -> (down_w, down_b,
+        up_w, up_b) runs only on a miss."""
+        key = (io_dtype, tiles, WEIGHTS_EPOCH, tag) + tuple((t.data_ptr(), t._version) for t in sources)
+        if key != self._key:
+            self._val = pack_pair(*build(), io_dtype, tiles)
+            self._key = key
+        return self._val
+
 
 def _flat(x: torch.Tensor, d: int) -> torch.Tensor:
     x = x.reshape(-1, d)
@@ -393,10 +404,14 @@ def parallel_adapter(x, y, wd, bd, wu, bu, pk: PackedPair, scale: float = 1.0):
 
 
 class _LoraDeltaFn(torch.autograd.Function):
-    """K3: out = base + scaling * ((dropout(x) A^T) B^T); base comes from the library GEMM."""
+    """K3: out = base + scaling * ((dropout(x) A^T) B^T); base comes from the library GEMM.
+
+    Dropout (lora/controller.py:66): ``p`` > 0 with ``keep`` None -> the kernels' counter-based generator keyed by
+    ``seed`` (forward, backward rows kernel and weight-gradient kernel regenerate the same mask; nothing is stored);
+    ``keep`` given -> that explicit 0/1 mask.  ``want_mask``: also return the applied mask (parity tests)."""
 
     @staticmethod
-    def forward(ctx, x, base, pk, scaling, keep, keep_scale, lora_a, lora_b):
+    def forward(ctx, x, base, pk, scaling, keep, p, seed, want_mask, lora_a, lora_b):
         lib = _lib.load()
         _need_cuda(x, base)
         d = x.shape[-1]
@@ -409,36 +424,46 @@ class _LoraDeltaFn(torch.autograd.Function):
             kf = _flat(keep, d)
             if kf.dtype != torch.uint8:
                 kf = kf.to(torch.uint8)
-        rc = lib.vlpet_lora_delta_fwd(xf.data_ptr(), bf.data_ptr(), pk.buf.data_ptr(), _ptr(kf), float(keep_scale),
-                                      out.data_ptr(), M, d, pk.tiles, float(scaling), io, _stream())
+        mask = torch.empty(M, d, dtype=torch.uint8, device=xf.device) if (want_mask and p > 0) else None
+        rc = _timed("k3_fwd", M, lambda: lib.vlpet_lora_delta_fwd(
+            xf.data_ptr(), bf.data_ptr(), pk.buf.data_ptr(), _ptr(kf), float(p), int(seed), _ptr(mask), out.data_ptr(),
+            M, d, pk.tiles, float(scaling), io, _stream()))
         _lib.check(rc, "vlpet_lora_delta_fwd")
         ctx.save_for_backward(xf, lora_a, lora_b)
         ctx.keep = kf
-        ctx.cfg = (pk, float(scaling), float(keep_scale), x.shape)
-        return out.view(base.shape)
+        ctx.cfg = (pk, float(scaling), float(p), int(seed), x.shape)
+        out = out.view(base.shape)
+        if want_mask:
+            if mask is None:
+                mask = torch.ones(M, d, dtype=torch.uint8, device=xf.device)
+            ctx.mark_non_differentiable(mask)
+            return out, mask.view(x.shape)
+        return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         lib = _lib.load()
         xf, lora_a, lora_b = ctx.saved_tensors
-        pk, scaling, keep_scale, shape = ctx.cfg
+        pk, scaling, p, seed, shape = ctx.cfg
         M, d = xf.shape
         io = _io_dtype(xf)
         dyf = _flat(dy, d)
-        f32 = dict(dtype=torch.float32, device=xf.device)
         r = pk.r
         (da, s0), (db, s1) = _grad_dest(lora_a, (r, d)), _grad_dest(lora_b, (d, r))
         dx = torch.empty_like(xf)
         nws = lib.vlpet_bwd_workspace_bytes(M, d, pk.tiles, 0, io)
         ws = torch.empty(nws, dtype=torch.uint8, device=xf.device)
-        rc = lib.vlpet_lora_delta_bwd(dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), _ptr(ctx.keep), keep_scale,
-                                      dx.data_ptr(), da.data_ptr(), db.data_ptr(), r, ws.data_ptr(), nws,
-                                      M, d, pk.tiles, scaling, io, _stream())
+        rc = _timed("k3_bwd", M, lambda: lib.vlpet_lora_delta_bwd(
+            dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), _ptr(ctx.keep), p, seed, dx.data_ptr(), da.data_ptr(),
+            db.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, scaling, io, _stream()))
         _lib.check(rc, "vlpet_lora_delta_bwd")
-        return (dx.view(shape), dy, None, None, None, None, *_finish([(da, s0, lora_a), (db, s1, lora_b)]))
+        return (dx.view(shape), dy, None, None, None, None, None, None, *_finish([(da, s0, lora_a), (db, s1, lora_b)]))
 
 
-def lora_delta(x, base, lora_a, lora_b, pk: PackedPair, scaling: float, keep=None, keep_scale: float = 1.0):
+def lora_delta(x, base, lora_a, lora_b, pk: PackedPair, scaling: float, keep=None, p: float = 0.0, seed: int = 0,
+               return_mask: bool = False):
+    """``base + scaling * (dropout(x, p) @ A^T @ B^T)``.  ``keep`` (uint8 [.., d]) overrides the generator's mask."""
     if x.numel() == 0:
-        return _empty_result(base, [lora_a, lora_b])
-    return _LoraDeltaFn.apply(x, base, pk, scaling, keep, keep_scale, lora_a, lora_b)
+        out = _empty_result(base, [lora_a, lora_b])
+        return (out, torch.empty(x.shape, dtype=torch.uint8, device=x.device)) if return_mask else out
+    return _LoraDeltaFn.apply(x, base, pk, scaling, keep, p, seed, return_mask, lora_a, lora_b)

@@ -175,19 +175,24 @@ class BartEncoderLayer(nn.Module):
         self.fc2 = nn.Linear(config.encoder_ffn_dim, d)
         self.final_layer_norm = HostLayerNorm(d)
         build_pet(self, config, d, ("attn", "ff"))
+        # the reference's BART encoder layer has no adapter / x2 scaling (my_transformers/modeling_bart.py:1147-1155 is a plain
+        # h + up(...)); only the T5 layers read those flags (my_transformers/modeling_t5.py:373-377, 789-793)
+        self.pet_config = copy.copy(config)
+        self.pet_config.use_encoder_adapter_scaling = False
+        self.pet_config.use_encoder_x2_scaling = False
 
     def forward(self, hidden, attn_mask=None, task=None):
         residual = hidden
         h = self.self_attn(hidden, attn_mask=attn_mask, task=task)
         if has_pet(self, "attn"):
-            h = apply_pet(self, "attn", residual, h, self.config)                 # K1
+            h = apply_pet(self, "attn", residual, h, self.pet_config)             # K1
         hidden = sublayer_tail(residual, h, self.self_attn_layer_norm, self.dropout, self.training)   # K5
         residual = hidden
         h = F.gelu(_linear(self.fc1, hidden))
         h = F.dropout(h, p=self.activation_dropout, training=self.training)
         h = _linear(self.fc2, h)
         if has_pet(self, "ff"):
-            h = apply_pet(self, "ff", residual, h, self.config)                   # K1
+            h = apply_pet(self, "ff", residual, h, self.pet_config)               # K1
         return sublayer_tail(residual, h, self.final_layer_norm, self.dropout, self.training)             # K5
 
 
@@ -250,8 +255,13 @@ class JointEncoder(nn.Module):
             s = int(config.n_boxes ** 0.5)
             self.downsample = Downsample((s, s))
 
-    def forward(self, input_ids, vis_inputs, attention_mask=None, task=None):
+    def forward(self, input_ids, vis_inputs, attention_mask=None, task=None, no_padding=False):
         B, L = input_ids.shape
+        if attention_mask is None and not no_padding:
+            # src/modeling_bart.py:817-818: the text mask defaults to input_ids != pad; it also becomes the decoder's
+            # cross-attention mask (:995-996).  ``no_padding`` = the loader's promise that no row is padded (every
+            # row has the full length -- true for the synthetic batches), which keeps attention on the unmasked path
+            attention_mask = input_ids.ne(self.config.pad_token_id)
         x = self.embed_tokens(input_ids) * self.embed_scale + self.embed_positions(L, input_ids.device)
         if self.downsample is not None:
             # fp32 CLIP features -> compute dtype inside the pooling kernel (rounding is monotone:
@@ -339,9 +349,9 @@ class VLBart(nn.Module):
             for t in m.tasks:
                 nn.init.zeros_(m.lora_Bs[t])
 
-    def forward(self, input_ids, vis_inputs, labels, task, attention_mask=None):
+    def forward(self, input_ids, vis_inputs, labels, task, attention_mask=None, no_padding=False):
         cfg = self.config
-        enc, mask = self.model.encoder(input_ids, vis_inputs, attention_mask, task)
+        enc, mask = self.model.encoder(input_ids, vis_inputs, attention_mask, task, no_padding)
         dec_in = shift_tokens_right(labels, cfg.pad_token_id, cfg.decoder_start_token_id)
         h = self.model.decoder(dec_in, enc, mask, task)
         logits = F.linear(h, self.model.shared.weight.to(h.dtype)) + self.final_logits_bias.to(h.dtype)

@@ -322,8 +322,8 @@ class VLT5(nn.Module):
             if m.has_relative_attention_bias:
                 m.relative_attention_bias.weight.data.normal_(0.0, f * d ** -0.5)
 
-    def forward(self, input_ids, vis_inputs, labels, task, attention_mask=None):
-        cfg = self.config
+    def forward(self, input_ids, vis_inputs, labels, task, attention_mask=None, no_padding=False):
+        cfg = self.config       # (no_padding: accepted for interface symmetry with host/bart.py; the T5 bias always carries the mask)
         enc, keep = self.encoder(input_ids, vis_inputs, attention_mask, task)
         dec_in = shift_right(labels, cfg.pad_token_id, cfg.decoder_start_token_id)
         h = self.decoder(dec_in, enc, keep, task) * (cfg.d_model ** -0.5)

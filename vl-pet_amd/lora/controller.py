@@ -7,6 +7,7 @@ import torch.nn.functional as F
 
 from .layers import LoRALayer
 from .. import functional as VF
+from ..tail import _draw_seed
 
 
 class LoRALinearController(nn.Linear, LoRALayer):
@@ -70,9 +71,8 @@ class LoRALinearController(nn.Linear, LoRALayer):
         A, B = self.lora_As[task], self.lora_Bs[task]
         cache = self._packs.setdefault(task, VF.PackCache())
         pk = cache.get([A], None, B, None, VF._io_dtype(x))
-        keep, keep_scale = None, 1.0
-        p = self.lora_dropout_p
-        if self.training and p > 0.0:
-            keep = (torch.rand(x.shape, device=x.device) >= p).to(torch.uint8)
-            keep_scale = 1.0 / (1.0 - p)
-        return VF.lora_delta(x, base, A, B, pk, self.scaling, keep, keep_scale)
+        # training-mode dropout of lora/controller.py:66: generated inside the kernels (one 64-bit seed per call, drawn
+        # from torch's CPU generator so torch.manual_seed makes a run repeatable); the backward regenerates the mask
+        p = float(self.lora_dropout_p) if self.training else 0.0
+        seed = _draw_seed() if p > 0.0 else 0
+        return VF.lora_delta(x, base, A, B, pk, self.scaling, None, p, seed)

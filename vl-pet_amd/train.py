@@ -30,9 +30,15 @@ import torch.distributed as dist
 import torch.nn as nn
 
 TASK_BATCH = {"vqa": lambda b: b, "gqa": lambda b: int(b * 100 / 60), "nlvr": lambda b: int(b * 20 / 60),
-              "caption": lambda b: int(b * 50 / 60)}
-TEXT_LEN = {"vqa": 20, "gqa": 20, "nlvr": 20, "caption": 40}
-TARGET_LEN = {"vqa": 5, "gqa": 5, "nlvr": 2, "caption": 20}
+              "caption": lambda b: int(b * 50 / 60),
+              # video-text (multitask_video.py:760-860: every task loader gets args.batch_size)
+              "tvqa": lambda b: b, "how2qa": lambda b: b, "tvc": lambda b: b, "yc2c": lambda b: b}
+# video: subtitles + question + prompt, truncated at 600 tokens (video/tvqa_data.py:211, how2qa_data.py:203, tvc_data.py:210,
+# yc2c_data.py:206); targets capped at 20 (tvqa_data.py:231), QA answers are a few tokens
+TEXT_LEN = {"vqa": 20, "gqa": 20, "nlvr": 20, "caption": 40, "tvqa": 600, "how2qa": 600, "tvc": 600, "yc2c": 600}
+TARGET_LEN = {"vqa": 5, "gqa": 5, "nlvr": 2, "caption": 20, "tvqa": 3, "how2qa": 3, "tvc": 20, "yc2c": 20}
+VIDEO_TASKS = ("tvqa", "how2qa", "tvc", "yc2c")
+VIDEO_FRAMES = 64       # clip-vit frame embeddings resized to n_boxes = 64 (video/how2qa_data.py:34-44,163)
 
 
 # ------------------------------------------------------------------ trainable set
@@ -105,6 +111,11 @@ def synthetic_batch(task: str, batch: int, config, device, gen: torch.Generator,
     n_grid = 49
     ids = torch.randint(5, V, (batch, L), device=device, generator=gen)
     labels = torch.randint(5, V, (batch, T), device=device, generator=gen)
+    if task in VIDEO_TASKS:
+        # [B, 64, feat_dim = 512] frame features, zero boxes (multitask_video.py:738; video/video_model.py:34-36)
+        feats = torch.randn(batch, VIDEO_FRAMES, int(config.feat_dim), device=device, generator=gen, dtype=feat_dtype)
+        boxes = torch.zeros(batch, VIDEO_FRAMES, 4, device=device, dtype=feat_dtype)
+        return dict(task=task, input_ids=ids, vis_inputs=(feats, boxes), labels=labels, scores=None, no_padding=True)
     if task == "nlvr":
         feats = torch.randn(batch, 2 * n_grid, int(config.feat_dim), device=device, generator=gen, dtype=feat_dtype)
         boxes = torch.zeros(batch, 2 * n_grid, 4, device=device, dtype=feat_dtype)
@@ -115,8 +126,9 @@ def synthetic_batch(task: str, batch: int, config, device, gen: torch.Generator,
         feats = torch.randn(batch, n_grid, int(config.feat_dim), device=device, generator=gen, dtype=feat_dtype)
         boxes = torch.zeros(batch, n_grid, 4, device=device, dtype=feat_dtype)
         vis = (feats, boxes)
+    # ids are drawn from [5, V): no pad token (id 1) occurs, every row has the full length
     return dict(task=task, input_ids=ids, vis_inputs=vis, labels=labels,
-                scores=torch.ones(batch, device=device))
+                scores=torch.ones(batch, device=device), no_padding=True)
 
 
 def epoch_task_order(tasks: Sequence[str], steps_per_task: Dict[str, int], epoch: int) -> List[str]:
@@ -129,9 +141,9 @@ def epoch_task_order(tasks: Sequence[str], steps_per_task: Dict[str, int], epoch
 
 def task_loss(per_token: torch.Tensor, labels: torch.Tensor, scores: Optional[torch.Tensor], task: str):
     mask = (labels != -100).float()
-    if task in ("vqa", "gqa"):
+    if task in ("vqa", "gqa") or task in VIDEO_TASKS:      # video/video_model.py:77-87: per-sample mean, then batch mean
         loss = (per_token * mask).sum(1) / mask.sum(1).clamp(min=1)
-        if scores is not None:
+        if scores is not None and task not in VIDEO_TASKS:      # the video heads do not weight by score (:85)
             loss = loss * scores
         return loss.mean()
     return (per_token * mask).sum() / mask.sum().clamp(min=1)
@@ -195,6 +207,20 @@ def _flat_order(named):
     return [(n, p) for _, n, p in keyed]
 
 
+def _has_per_task_params(names, params) -> bool:
+    """True when some trainable parameter belongs to ONE task (``...adapters.<task>.*`` / ``lora_As.<task>`` entries that
+    are distinct tensors per task).  Shared modules registered under every task key (use_single_adapter /
+    use_single_lora, adapters/adapter_controller.py:49-58, lora/controller.py:72-80) are one tensor with one name."""
+    import re
+    pat = re.compile(r"(.*\.(?:adapters|lora_As|lora_Bs))\.([^.]+)(\..*)?$")
+    seen = {}
+    for n in names:
+        m = pat.match(n)
+        if m:
+            seen.setdefault((m.group(1), m.group(3) or ""), set()).add(m.group(2))
+    return any(len(v) > 1 for v in seen.values())
+
+
 class FlatGrads:
     """Flat fp32 gradient buffer with ``.grad`` views, bucketed asynchronous all-reduce, and (optionally) the
     parameters themselves + Adam moments as flat buffers for the fused optimizer."""
@@ -247,7 +273,10 @@ class FlatGrads:
         self._ready_epoch = [-1] * len(self.params)
         self._handles = []
         self._hooks = []
-        if self.dp:
+        # Per-task parameters (use_single_adapter / use_single_lora off): only the current task's adapters / LoRA matrices
+        # get a gradient in a step, and the optimizer must know which (transformers.AdamW skips grad-None parameters).
+        self.per_task = _has_per_task_params(self.names, self.params)
+        if self.dp or self.per_task:
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         if sinks:
@@ -292,6 +321,10 @@ class FlatGrads:
             self._pending[b] += 1
             if self._pending[b] == self.bucket_count[b]:
                 self._launch(b)
+
+    def active(self):
+        """Per parameter: did it receive a gradient in the current step (meaningful when hooks are registered)."""
+        return [e == self.epoch for e in self._ready_epoch]
 
     def _make_hook(self, i):
         def hook(param):
@@ -380,6 +413,17 @@ class FusedAdamW:
         self.partials = torch.empty(self.nb, dtype=torch.float32, device=dev)
         self.norm = torch.zeros((), dtype=torch.float32, device=dev)
         self.t = 0
+        # per-parameter step counts (transformers.AdamW state['step']; a parameter without a gradient is skipped): only
+        # needed when some parameters belong to one task -- otherwise every parameter is updated at every step
+        self.sliced = bool(flat.per_task)
+        if self.sliced:
+            so = torch.zeros(n, dtype=torch.int32)
+            for k, (a, b) in enumerate(flat.slices):
+                so[a:b] = k
+            self.slice_of = so.to(dev)
+            self.steps = [0] * len(flat.slices)
+            self.bc_host = torch.zeros(len(flat.slices), 2, dtype=torch.float32).pin_memory()
+            self.bc_dev = torch.zeros(len(flat.slices), 2, dtype=torch.float32, device=dev)
 
     def step(self, lr: Optional[float] = None):
         from . import _lib
@@ -390,6 +434,24 @@ class FusedAdamW:
         self.t += 1
         rc = self.lib.vlpet_grad_sumsq(f.flat.data_ptr(), n, self.partials.data_ptr(), st)
         _lib.check(rc, "vlpet_grad_sumsq")
+        if self.sliced:
+            b1, b2 = self.betas
+            for k, on in enumerate(f.active()):
+                if on:
+                    self.steps[k] += 1
+                    self.bc_host[k, 0] = 1.0 - b1 ** self.steps[k]
+                    self.bc_host[k, 1] = math.sqrt(1.0 - b2 ** self.steps[k])
+                else:
+                    self.bc_host[k, 0] = -1.0
+            self.bc_dev.copy_(self.bc_host, non_blocking=True)
+            rc = self.lib.vlpet_adamw_step_sliced(
+                f.flat_p.data_ptr(), f.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.decay.data_ptr(), n,
+                self.partials.data_ptr(), self.nb, float(self.max_norm), 1.0 / f.world_size,
+                float(self.lr if lr is None else lr), b1, b2, self.eps, self.wd, self.slice_of.data_ptr(),
+                self.bc_dev.data_ptr(), self.variant, 1, self.norm.data_ptr(), st)
+            _lib.check(rc, "vlpet_adamw_step_sliced")
+            VF.bump_weights_epoch()
+            return
         rc = self.lib.vlpet_adamw_step(f.flat_p.data_ptr(), f.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                        self.decay.data_ptr(), n, self.partials.data_ptr(), self.nb, float(self.max_norm),
                                        1.0 / f.world_size, float(self.lr if lr is None else lr), self.betas[0],
@@ -427,7 +489,8 @@ class Trainer:
         self.flat.begin_step(zero=True)
 
     def step(self, batch) -> torch.Tensor:
-        per_token, _ = self.model(batch["input_ids"], batch["vis_inputs"], batch["labels"], batch["task"])
+        per_token, _ = self.model(batch["input_ids"], batch["vis_inputs"], batch["labels"], batch["task"],
+                                  attention_mask=batch.get("attention_mask"), no_padding=bool(batch.get("no_padding", False)))
         loss = task_loss(per_token, batch["labels"], batch.get("scores"), batch["task"])
         loss.backward()
         self.flat.finish(average=False)
