@@ -148,9 +148,9 @@ def run_k3(dtype, M=200, d=768, r=8, alpha=32, p=0.0, seed=2, explicit_mask=Fals
 
 
 def run_pack_check(r=96, d=768, nh=4, fp32=False, seed=3):
-    """bytes of the HIP pack kernel vs the numpy specification (vl-pet_amd/packing.py)"""
+    """bytes of the HIP pack kernel vs the numpy specification (tests/packing_spec.py)"""
     import vlpet_amd.functional as F
-    import vlpet_amd.packing as PK
+    import packing_spec as PK
     g = torch.Generator().manual_seed(seed)
     wd, bd = _rand(g, r, d), _rand(g, r)
     wu, bu = _rand(g, d, r), _rand(g, d)

@@ -2,7 +2,7 @@
 
 Emulates v_mfma_f32_32x32x16 per its documented register layout (A row = lane&31, B col =
 lane&31, k-slot = (lane>>5, j); D: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)) and
-replays, lane by lane, exactly the index algebra csrc/ uses on top of vl-pet_amd/packing.py:
+replays, lane by lane, exactly the index algebra csrc/ uses on top of tests/packing_spec.py:
 forward chain, backward chain (dz, dx) and the MFMA-transpose weight-gradient.  Values are kept
 in float64 so the comparison with the oracle is about layout only."""
 import numpy as np
@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import vlpet_oracle as O
-import vlpet_amd.packing as PK
+import packing_spec as PK
 
 LANE = np.arange(64)
 M_ = LANE & 31

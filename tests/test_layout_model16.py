@@ -2,14 +2,14 @@
 
 MFMA layout emulated: A row = lane&15, B col = lane&15, k-slot = (lane>>4, j); C/D: col = lane&15,
 row = 4*(lane>>4) + reg.  Replays the index algebra of csrc/pet_fwd.hip / pet_bwd.hip on top of
-vl-pet_amd/packing.py (pack_*16): forward chain, backward chain (dz, dx) for both stage geometries
+tests/packing_spec.py (pack_*16): forward chain, backward chain (dz, dx) for both stage geometries
 (bf16 IO: 64 features per stage, fp32 IO: 32)."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import vlpet_oracle as O
-import vlpet_amd.packing as PK
+import packing_spec as PK
 
 
 def mfma16(A, B, C):

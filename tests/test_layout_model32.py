@@ -1,11 +1,11 @@
 """Wavefront-level model of the v4 kernels (32-row waves, v_mfma_f32_32x32x16, 128 bytes of every row
-per stage) on top of vl-pet_amd/packing.py pack_*4 -- CPU, float64, both stage geometries."""
+per stage) on top of tests/packing_spec.py pack_*4 -- CPU, float64, both stage geometries."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import vlpet_oracle as O
-import vlpet_amd.packing as PK
+import packing_spec as PK
 from test_layout_model import mfma32, gelu, dgelu
 
 

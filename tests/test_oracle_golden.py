@@ -189,3 +189,26 @@ def test_lowrank_visual_embedding_golden(name):
     for k, v in g.items():
         if k.startswith("grad::") and "obj_order" not in k:
             close(P[k[6:]].grad, v, atol=2e-5)
+
+
+def test_hf_adamw_restatement_against_independent_transcription():
+    """oracle.hf_adamw_step (the checker of csrc/optim.hip and of the captured training steps) against the fp64
+    known-answer vector of tests/golden/make_adamw_golden.py -- an independent scalar transcription of
+    transformers 4.2.1's AdamW.step (eps on sqrt(v), bias-corrected step size, decoupled decay after the update,
+    per-parameter step count that does not advance on grad-None steps)."""
+    z = np.load(os.path.join(G, "adamw_hf421.npz"))
+    b1, b2, eps = [float(x) for x in z["hparams"]]
+    lrs = [float(x) for x in z["lrs"]]
+    for tag in ("decay", "nodecay"):
+        p = torch.from_numpy(z[f"{tag}::p0"]).clone()
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        wd = float(z[f"{tag}::wd"])
+        t = 0
+        for s, on in enumerate(z[f"{tag}::has_grad"]):
+            if on:
+                t += 1
+                O.hf_adamw_step(p, torch.from_numpy(z[f"{tag}::grads"][s]), m, v, t, lrs[s], betas=(b1, b2), eps=eps,
+                                weight_decay=wd)
+            torch.testing.assert_close(p, torch.from_numpy(z[f"{tag}::p"][s]), rtol=1e-12, atol=1e-14)
+            torch.testing.assert_close(m, torch.from_numpy(z[f"{tag}::m"][s]), rtol=1e-12, atol=1e-16)
+            torch.testing.assert_close(v, torch.from_numpy(z[f"{tag}::v"][s]), rtol=1e-12, atol=1e-18)

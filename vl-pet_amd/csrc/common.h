@@ -1,6 +1,6 @@
 // Shared device helpers for the VL-PET hot-path kernels (gfx950 / CDNA4 only).
 //
-// Conventions (see vl-pet_amd/packing.py for the layout specification):
+// Conventions (see tests/packing_spec.py for the layout specification):
 //   * one wavefront (64 lanes) owns 32 activation rows; lane (m = lane & 31, h = lane >> 5);
 //   * every contraction is v_mfma_f32_32x32x16_bf16 in swapped form (weights = A operand,
 //     activation rows = B operand), so results land as "16 values of row m per lane";

@@ -1,5 +1,5 @@
 // Weight re-pack: (down [r,d] as N_h head blocks, up [d,r], biases) -> MFMA fragment order for the
-// 32x32x16 kernels.  Layout specification: vl-pet_amd/packing.py section v4 (pack_down4 / pack_up4 /
+// 32x32x16 kernels.  Layout specification: tests/packing_spec.py section v4 (pack_down4 / pack_up4 /
 // pack_up_t4 / pack_down_t4), checked lane by lane in tests/test_layout_model32.py.
 // ~0.6 MB per pair, once per optimizer step; also performs the fp32 -> bf16 cast (NS = 1) or the
 // bf16 hi/lo split (NS = 2), so no separate cast pass over the parameters exists.

@@ -1,6 +1,6 @@
 // v3 building blocks: 16-row waves on v_mfma_f32_16x16x32_bf16, every global read through LDS by
 // global_load_lds (no staging VGPRs, fully coalesced 128-byte lines), outputs staged through LDS
-// and stored as whole lines.  Layout specification: vl-pet_amd/packing.py (section v3) and
+// and stored as whole lines.  Layout specification: tests/packing_spec.py (section v3) and
 // tests/test_layout_model16.py.
 //
 //   lane (m = lane & 15, g = lane >> 4) owns activation row m of its wave's 16 rows;

@@ -1,7 +1,7 @@
 // v4 building blocks: 32-row waves on v_mfma_f32_32x32x16_bf16 (half the LDS fragment bytes per flop
 // of the 16x16x32 form, which measured LDS-bound) on the v3 memory system: every global read arrives by
 // global_load_lds as whole 128-byte lines, outputs leave as whole lines.  Layout specification:
-// vl-pet_amd/packing.py (section v4), checked lane by lane in tests/test_layout_model32.py.
+// tests/packing_spec.py (section v4), checked lane by lane in tests/test_layout_model32.py.
 //
 //   lane (m = lane & 31, h = lane >> 5) owns activation row m of its wave's 32 rows;
 //   a *stage* moves 128 bytes of every row: FE = 64 features (bf16 IO) or 32 (fp32 IO);

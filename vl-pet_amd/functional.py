@@ -91,7 +91,7 @@ def rank_tiles(r: int) -> int:
 
 
 class PackedPair:
-    """MFMA-fragment pack of one (down, up) projection pair (see packing.py / csrc/pack.hip)."""
+    """MFMA-fragment pack of one (down, up) projection pair (see tests/packing_spec.py / csrc/pack.hip)."""
 
     __slots__ = ("buf", "tiles", "r", "d", "io_dtype")
 
