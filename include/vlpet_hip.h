@@ -114,7 +114,12 @@ int vlpet_adapter_gate_bwd_phase(int phases, const void* dy, const void* x1, con
                                  int io_dtype, vlpet_stream_t stream);
 
 /* vlpet_adapter_gate_bwd_phase with the activations saved by vlpet_adapter_gate_fwd_save (x1 is
- * still an argument because the gate's down-weight gradient contracts it). */
+ * still an argument because the gate's down-weight gradient contracts it).
+ * For r, r_g <= 96 this runs as TWO PASSES that move every [M, d] tensor once each (csrc/pet_gate_bwd3.hip):
+ * phases bit 0 = pass 1 (row-parallel: dpre of both chains into the workspace, no [M, d] output),
+ * bit 1 = pass 2 (column-parallel: dx1, dx2 AND the eight weight / bias gradients from recomputed dh / dq).  A caller that
+ * needs dx1 / dx2 right after bit 0 (weight gradients on another stream) adds bit 2 to BOTH calls: the previous split
+ * (bit 0: dx1, dx2 + [M, d] side products; bit 1: weight gradients from them).  phases = 3 is the full call either way. */
 int vlpet_adapter_gate_bwd_saved(int phases, const void* dy, const void* x1, const void* x2, const void* saved,
                                  const void* packed_a, const void* packed_g,
                                  void* dx1, void* dx2,

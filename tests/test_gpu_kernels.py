@@ -76,7 +76,9 @@ def test_k1_saved_and_recompute_backward_agree(dtype):
     st = torch.cuda.current_stream().cuda_stream
     nws = lib.vlpet_bwd_workspace_bytes(M, d, tiles, 1, io)
     res = []
-    for saved in (False, True):
+    # recompute form; saved activations through the two-pass backward (pet_gate_bwd3.hip: phases 3); saved activations through
+    # the previous split (phases 3 | 4: rows kernel with [M, d] side products + weight-gradient kernel)
+    for saved in (0, 3, 7):
         out = torch.empty_like(x2); dx1 = torch.empty_like(x1); dx2 = torch.empty_like(x2)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         G = [torch.empty_like(w) for w in W]
@@ -85,7 +87,7 @@ def test_k1_saved_and_recompute_backward_agree(dtype):
             sv = torch.empty(lib.vlpet_saved_bytes(M, tiles, io), dtype=torch.uint8, device=dev)
             assert lib.vlpet_adapter_gate_fwd_save(x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(), out.data_ptr(),
                                                    sv.data_ptr(), M, d, tiles, 1, 1.0, 1.0, 1.0, io, st) == 0
-            assert lib.vlpet_adapter_gate_bwd_saved(3, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(),
+            assert lib.vlpet_adapter_gate_bwd_saved(saved, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(),
                                                     pg.buf.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), *[t.data_ptr() for t in gp],
                                                     r, r, ws.data_ptr(), nws, M, d, tiles, 1, 1.0, 1.0, 1.0, io, st) == 0
         else:
@@ -96,16 +98,19 @@ def test_k1_saved_and_recompute_backward_agree(dtype):
                                               M, d, tiles, 1, 1.0, 1.0, 1.0, io, st) == 0
         torch.cuda.synchronize()
         res.append([out.float(), dx1.float(), dx2.float()] + [t.float() for t in gp])
-    assert torch.equal(res[0][0], res[1][0])                       # the forward's output does not depend on saving
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][0], res[2][0])    # the forward's output does not depend on saving
     tol = 1e-4 if dtype == torch.float32 else 1e-2
-    for a, b in zip(res[0][1:], res[1][1:]):
-        assert (a - b).abs().max().item() <= tol * max(a.abs().max().item(), 1e-6)
+    for other in (res[1], res[2]):
+        for a, b in zip(res[0][1:], other[1:]):
+            assert (a - b).abs().max().item() <= tol * max(a.abs().max().item(), 1e-6)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_k1_bias_gradients_per_column(dtype):
     # the global-norm metric hides small columns: every element of the four bias gradients within 5x the tolerance of
-    # its own magnitude (floored at a tenth of the mean magnitude; the gradients are sums over M = 1000 rows)
+    # its own magnitude (floored at half the mean magnitude: the gradients are sums over M = 1000 rows of terms that
+    # mostly cancel, so a column much smaller than the mean carries the rounding noise of its large terms --
+    # measured on MI355X with bf16 IO: <= 0.08 of a floor of 0.1 x mean, i.e. <= 0.016 of this one)
     cols = {}
     check(C.run_k1(dtype, M=1000, d=768, r=96, rg=96, nh=4, col_errs=cols), dtype)
     bad = {k: v for k, v in cols.items() if not v <= 5 * TOL[dtype]}

@@ -64,11 +64,16 @@ def main():
         rc = lib.vlpet_adapter_gate_fwd_save(x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(), out.data_ptr(),
                                              sv.data_ptr(), M, d, tiles, 1, 1.0, 1.0, 1.0, io, st); assert rc == 0
     t_fwd_s = timeit(fwd_save)
-    def bwd_saved():
-        rc = lib.vlpet_adapter_gate_bwd_saved(1, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(),
-                                              dx1.data_ptr(), dx2.data_ptr(), *[t.data_ptr() for t in G], r, r, ws.data_ptr(), nws,
-                                              M, d, tiles, 1, 1.0, 1.0, 1.0, io, st); assert rc == 0
-    t_rows_s = timeit(bwd_saved)
+    def bwd_saved(ph):
+        def f():
+            rc = lib.vlpet_adapter_gate_bwd_saved(ph, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(),
+                                                  dx1.data_ptr(), dx2.data_ptr(), *[t.data_ptr() for t in G], r, r, ws.data_ptr(), nws,
+                                                  M, d, tiles, 1, 1.0, 1.0, 1.0, io, st); assert rc == 0
+        return f
+    fwd_save()
+    t_rows_s = timeit(bwd_saved(1))
+    t_ph2_s, t_op_s = timeit(bwd_saved(2)), timeit(bwd_saved(3))
+    t_old1, t_old2 = timeit(bwd_saved(1 | 4)), timeit(bwd_saved(2 | 4))       # the previous form: rows kernel with side products + wgrad
     def k2f():
         rc = lib.vlpet_parallel_adapter_fwd(x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), out.data_ptr(), M, d, tiles, 1.0, io, st); assert rc == 0
     t_k2 = timeit(k2f)
@@ -80,6 +85,10 @@ def main():
     print(f"   bwd rows krn: {t_rows:8.1f} us   {bb/t_rows/1e3:8.1f} GB/s algorithmic  frac(8TB/s)={bb/t_rows/1e3/8000:.3f}")
     print(f"   bwd wgrad+fin: {t_wg:7.1f} us")
     print(f"K1 fwd + save  : {t_fwd_s:8.1f} us   bwd rows with saved activations: {t_rows_s:8.1f} us   {bb/t_rows_s/1e3:8.1f} GB/s algorithmic  frac(8TB/s)={bb/t_rows_s/1e3/8000:.3f}")
+    print(f"K1 bwd, training form (saved activations), two-pass: pass 1 (dz) {t_rows_s:7.1f} us + pass 2 (cols + finalize) {t_ph2_s:7.1f} us; "
+          f"whole op {t_op_s:7.1f} us = {bb/t_op_s/1e3:8.1f} GB/s algorithmic, frac(8TB/s)={bb/t_op_s/1e3/8000:.3f}")
+    print(f"   previous form (rows kernel with dh / dq side products + wgrad): {t_old1:7.1f} + {t_old2:7.1f} = {t_old1 + t_old2:7.1f} us, "
+          f"frac(8TB/s)={bb/(t_old1 + t_old2)/1e3/8000:.3f}")
     print(f"K2 fwd         : {t_k2:8.1f} us   {fb/t_k2/1e3:8.1f} GB/s algorithmic")
     # eager reference chain on the GPU for comparison (what the reference runs today)
     sys.path.insert(0, ROOT)

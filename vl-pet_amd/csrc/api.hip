@@ -222,8 +222,14 @@ static BwdWs bwd_ws(int64_t M, int d, int tiles, bool gate, int io_dtype) {
     }
     const int njobs = gate ? 4 : 2;
     wgrad_plan(M, njobs, d, &w.row_chunks, &w.rows_per_chunk);
+    int chunks = w.row_chunks;
+    if (gate) {     // the two-pass gated backward (pet_gate_bwd3.hip) cuts the rows differently: room for either plan
+        int rc3, gs3, ng3; int64_t rpc3;
+        gate_bwd3_plan(M, d, io_dtype == VLPET_F32, &rc3, &rpc3, &gs3, &ng3);
+        if (rc3 > chunks) chunks = rc3;
+    }
     w.partial = o;
-    o += align256(wgrad_workspace_bytes(njobs, tiles, d, w.row_chunks));
+    o += align256(wgrad_workspace_bytes(njobs, tiles, d, chunks));
     w.total = o;
     return w;
 }
@@ -273,8 +279,13 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
         b.z_a = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(saved));
         if (gate) b.z_g = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(saved)) + 2 * b.saved_stride;
     }
+    // two-pass form (pass 1: dpre only; pass 2: input gradients + weight gradients from recomputed dh / dq) unless the
+    // caller needs the input gradients right after phase 1 (phases bit 2: weight gradients on a side stream)
+    const bool two_pass = !(phases & 4) && pet_gate_bwd3_applies(b);
+    int gs3 = 0, ng3 = 0;
     if (phases & 1) {
-        hipError_t e = pet_gate_bwd2_applies(b) ? launch_pet_gate_bwd2(b, io_dtype == VLPET_F32, (hipStream_t)stream)
+        hipError_t e = two_pass ? launch_pet_gate_dz(b, io_dtype == VLPET_F32, (hipStream_t)stream)
+                     : pet_gate_bwd2_applies(b) ? launch_pet_gate_bwd2(b, io_dtype == VLPET_F32, (hipStream_t)stream)
                                                 : launch_pet_bwd(b, io_dtype == VLPET_F32, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
@@ -282,6 +293,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
 
     WgradArgs g{};
     g.M = M; g.RT = tiles; g.row_chunks = w.row_chunks; g.rows_per_chunk = w.rows_per_chunk;
+    if (two_pass) gate_bwd3_plan(M, d, io_dtype == VLPET_F32, &g.row_chunks, &g.rows_per_chunk, &gs3, &ng3);
     g.partial = reinterpret_cast<float*>(ws + w.partial);
     const int ldp = 32 * tiles;
     auto job = [&](int i, const void* P, const void* X, bool dropped, float scale, float* out, int ldo,
@@ -303,6 +315,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
         job(3, b.z_g, b.dq, false, 1.f, dwgu, rg, 1, rg, dbgu, nullptr);
         g.njobs = 4;
     }
+    if (two_pass) return herr(launch_pet_gate_cols(b, g, gs3, ng3, io_dtype == VLPET_F32, (hipStream_t)stream));
     return herr(launch_wgrad(g, io_dtype == VLPET_F32, (hipStream_t)stream));
 }
 
@@ -343,7 +356,7 @@ extern "C" int vlpet_adapter_gate_bwd_phase(int phases, const void* dy, const vo
     if (!dbd || !dbu || (phases & 3) == 0) return VLPET_E_NULL;
     return run_bwd(dy, x2, x2, x1, packed_a, packed_g, NO_DROP, dx2, dx1, dwd, dbd, dwu, dbu,
                    dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
-                   x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream, phases & 3);
+                   x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream, phases & 7);
 }
 
 extern "C" int vlpet_adapter_gate_bwd_saved(int phases, const void* dy, const void* x1, const void* x2, const void* saved,
@@ -358,7 +371,7 @@ extern "C" int vlpet_adapter_gate_bwd_saved(int phases, const void* dy, const vo
     if (!dbd || !dbu || !saved || (phases & 3) == 0) return VLPET_E_NULL;
     return run_bwd(dy, x2, x2, x1, packed_a, packed_g, NO_DROP, dx2, dx1, dwd, dbd, dwu, dbu,
                    dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
-                   x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream, phases & 3, saved);
+                   x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream, phases & 7, saved);
 }
 
 extern "C" int vlpet_parallel_adapter_bwd(const void* dy, const void* x, const void* packed, void* dx,

@@ -93,9 +93,34 @@ struct WgradArgs {
     float* partial;        // workspace, see wgrad_workspace_bytes
     int nslice;            // 64-column slices of the widest job (set by the launcher)
 };
+// partial-sum workspace of the weight gradients: per job [row_chunks][32*RT][xcols] tiles, then [row_chunks][xcols]
+// column sums of X, then [row_chunks][32*RT] column sums of P
+struct WgradLayout {
+    int64_t off[4];      // float offset of each job's partial block
+    int64_t total;       // floats
+};
+__host__ __device__ inline WgradLayout wgrad_layout(const WgradArgs& a) {
+    WgradLayout L;
+    int64_t o = 0;
+    const int PR = 32 * a.RT;
+    for (int j = 0; j < 4; ++j) {
+        L.off[j] = o;
+        if (j < a.njobs) o += (int64_t)a.row_chunks * ((int64_t)PR * a.job[j].xcols + a.job[j].xcols + PR);
+    }
+    L.total = o;
+    return L;
+}
 size_t wgrad_workspace_bytes(int njobs, int RT, int xcols_max, int row_chunks);
+hipError_t launch_wgrad_finalize(const WgradArgs& a, hipStream_t stream);      // sums the row-chunk partials into the outputs
 void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* rows_per_chunk);
 hipError_t launch_wgrad(const WgradArgs& a, int io_fp32, hipStream_t stream);
+
+// Two-pass gated K1 backward (pet_gate_bwd3.hip): pass 1 writes dpre only, pass 2 (column-parallel) recomputes dh / dq per
+// feature block and produces the input gradients and the four weight gradients.
+bool pet_gate_bwd3_applies(const PetBwdArgs& a);
+void gate_bwd3_plan(int64_t M, int d, int io_fp32, int* row_chunks, int64_t* rows_per_chunk, int* GS, int* NG);
+hipError_t launch_pet_gate_dz(const PetBwdArgs& a, int io_fp32, hipStream_t stream);
+hipError_t launch_pet_gate_cols(const PetBwdArgs& a, const WgradArgs& g, int GS, int NG, int io_fp32, hipStream_t stream);
 
 // K4: out = LN(feats . W^T + b) * gamma + beta (+ R); optionally stores xhat and rstd for the backward
 struct VisprojArgs {

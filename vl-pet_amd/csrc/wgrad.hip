@@ -15,22 +15,6 @@
 #include <type_traits>
 #include "kernels.h"
 
-struct WgradLayout {
-    int64_t off[4];      // float offset of each job's partial block
-    int64_t total;       // floats
-};
-__host__ __device__ inline WgradLayout wgrad_layout(const WgradArgs& a) {
-    WgradLayout L;
-    int64_t o = 0;
-    const int PR = 32 * a.RT;
-    for (int j = 0; j < 4; ++j) {
-        L.off[j] = o;
-        if (j < a.njobs) o += (int64_t)a.row_chunks * ((int64_t)PR * a.job[j].xcols + a.job[j].xcols + PR);
-    }
-    L.total = o;
-    return L;
-}
-
 size_t wgrad_workspace_bytes(int njobs, int RT, int xcols_max, int row_chunks) {
     const int64_t PR = 32 * RT;
     return (size_t)njobs * row_chunks * (PR * xcols_max + xcols_max + PR) * sizeof(float);
@@ -574,6 +558,15 @@ static hipError_t launch_finalize(const WgradArgs& a, int RT, int xmax, int rmax
     const int blocks = finalize_tiles(32 * RT, xmax) + (xmax + rmax + 255) / 256;   // tiles of every job fit: xcols <= xmax
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)blocks, a.njobs), dim3(256), 0, stream, a);
     return hipGetLastError();
+}
+
+hipError_t launch_wgrad_finalize(const WgradArgs& a, hipStream_t stream) {
+    int xmax = 0, rmax = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        if (a.job[j].xcols > xmax) xmax = a.job[j].xcols;
+        if (a.job[j].out_rows > rmax) rmax = a.job[j].out_rows;
+    }
+    return launch_finalize(a, a.RT, xmax, rmax, stream);
 }
 
 template <typename IO, int RT>

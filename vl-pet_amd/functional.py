@@ -287,12 +287,13 @@ class _AdapterGateFn(torch.autograd.Function):
             return lib.vlpet_adapter_gate_bwd_phase(ph, *a)
 
         if side is not None:
-            rc = _timed("k1_bwd_rows", M, lambda: phase(1, args))
+            # (bit 2: the form whose first half already delivers dx1 / dx2 -- the two-pass form produces them in its second)
+            rc = _timed("k1_bwd_rows", M, lambda: phase(1 | 4, args))
             if rc == 0:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     sargs = args[:-1] + (_stream(),)
-                    rc = _timed("k1_bwd_wgrad", M, lambda: phase(2, sargs))
+                    rc = _timed("k1_bwd_wgrad", M, lambda: phase(2 | 4, sargs))
                 for t in (x1f, x2f, dyf, ws, pk_a.buf) + ((pk_g.buf,) if gate else ()) + ((act,) if act is not None else ()):
                     t.record_stream(side)        # the caching allocator must not recycle them under the side stream
         elif TIMER is None:

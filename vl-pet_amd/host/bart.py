@@ -91,9 +91,11 @@ class HostLayerNorm(nn.LayerNorm):
     """LayerNorm whose (possibly fp32, trainable) affine parameters follow the activation dtype."""
 
     def forward(self, x):
-        w, b = self.weight, self.bias
+        w, b = self.weight, self.bias       # (LoRA runs train every bias but no LayerNorm weight: the two may differ in dtype)
         if w.dtype != x.dtype:
-            w, b = w.to(x.dtype), b.to(x.dtype)
+            w = w.to(x.dtype)
+        if b is not None and b.dtype != x.dtype:
+            b = b.to(x.dtype)
         return F.layer_norm(x, self.normalized_shape, w, b, self.eps)
 
 
@@ -105,10 +107,11 @@ def sublayer_tail(residual, h, norm, p, training):
 
 
 def _linear(mod: nn.Linear, x):
-    w, b = mod.weight, mod.bias
+    w, b = mod.weight, mod.bias             # (a trainable fp32 bias next to a frozen bf16 weight in LoRA runs)
     if w.dtype != x.dtype:
         w = w.to(x.dtype)
-        b = b.to(x.dtype) if b is not None else None
+    if b is not None and b.dtype != x.dtype:
+        b = b.to(x.dtype)
     return F.linear(x, w, b)
 
 

@@ -64,7 +64,8 @@ class LoRALinearController(nn.Linear, LoRALayer):
         w, b = self.weight, self.bias
         if w.dtype != x.dtype:
             w = w.to(x.dtype)
-            b = b.to(x.dtype) if b is not None else None
+        if b is not None and b.dtype != x.dtype:      # the bias trains (fp32 master) next to the frozen bf16 weight
+            b = b.to(x.dtype)
         base = F.linear(x, w, b)
         if self.r <= 0:
             return base
