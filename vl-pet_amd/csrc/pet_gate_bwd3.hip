@@ -109,26 +109,19 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_dz_kernel(PetBwdArgs a) {
     copy_bias<RG * 128>(sb, reinterpret_cast<const float*>(a.pk_a + pg.bias_off), nb, tid);
     copy_bias<RG * 128>(sb + nb, reinterpret_cast<const float*>(a.pk_g + pg.bias_off), nb, tid);
     Frag<NS> z[KT];
-    f32x16 gp[RT];                                  // act'(pre)
+    const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved) + (isA ? 0 : 2) * a.saved_stride;
+    const int64_t ro = grow * (int64_t)(32 * RT) + 8 * h;
     {
-        const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved) + (isA ? 0 : 2) * a.saved_stride;
-        const int64_t ro = grow * (int64_t)(32 * RT) + 8 * h;
         const IO* sz = reinterpret_cast<const IO*>(sv) + ro;
-        const IO* sg = reinterpret_cast<const IO*>(sv + a.saved_stride) + ro;
 #pragma unroll
-        for (int ct = 0; ct < RT; ++ct) {
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh) {
-                float v[8];
-                load8_f32(sz + 32 * ct + 16 * sh, v);
-                z[2 * ct + sh] = frag_from_f32<NS>(v);
-                load8_f32(sg + 32 * ct + 16 * sh, v);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) gp[ct][8 * sh + j] = v[j];
-            }
+        for (int ks = 0; ks < KT; ++ks) {
+            float v[8];
+            load8_f32(sz + 16 * ks, v);
+            z[ks] = frag_from_f32<NS>(v);
         }
     }
     __syncthreads();
+    constexpr bool PIPE = RT > 3;                   // r = 192: fragment reads one k-step ahead instead of a stage's worth up front
 
     const float* bu = sb + (isA ? 0 : nb) + 32 * RT + G::LW * h;
     const float s2 = a.s2, sd_ = a.sd, gs = a.gs;
@@ -154,17 +147,38 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_dz_kernel(PetBwdArgs a) {
                     au[v][4 * q] = tb[0]; au[v][4 * q + 1] = tb[1]; au[v][4 * q + 2] = tb[2]; au[v][4 * q + 3] = tb[3];
                 }
             }
-            Frag<NS> wf[G::NV * KT];
+            if constexpr (!PIPE) {
+                Frag<NS> wf[G::NV * KT];
 #pragma unroll
-            for (int ks = 0; ks < KT; ++ks) {
+                for (int ks = 0; ks < KT; ++ks) {
 #pragma unroll
-                for (int v = 0; v < G::NV; ++v) wf[v * KT + ks] = wfrag<NS>(w, v * KT + ks, lane);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int v = 0; v < G::NV; ++v) wf[v * KT + ks] = wfrag<NS>(w, v * KT + ks, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < KT; ++ks) {
+                for (int ks = 0; ks < KT; ++ks) {
 #pragma unroll
-                for (int v = 0; v < G::NV; ++v) au[v] = mfma_ns<NS>(wf[v * KT + ks], z[ks], au[v]);
+                    for (int v = 0; v < G::NV; ++v) au[v] = mfma_ns<NS>(wf[v * KT + ks], z[ks], au[v]);
+                }
+            } else {
+                Frag<NS> cur[G::NV], nxt[G::NV];
+#pragma unroll
+                for (int v = 0; v < G::NV; ++v) cur[v] = wfrag<NS>(w, v * KT, lane);
+#pragma unroll
+                for (int ks = 0; ks < KT; ++ks) {
+                    if (ks + 1 < KT) {
+#pragma unroll
+                        for (int v = 0; v < G::NV; ++v) nxt[v] = wfrag<NS>(w, v * KT + ks + 1, lane);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int v = 0; v < G::NV; ++v) au[v] = mfma_ns<NS>(cur[v], z[ks], au[v]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks + 1 < KT) {
+#pragma unroll
+                        for (int v = 0; v < G::NV; ++v) cur[v] = nxt[v];
+                    }
+                }
             }
             {
                 uint8_t* xb = xslot(chain);
@@ -225,20 +239,36 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_dz_kernel(PetBwdArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();           // both halves of the dh / dq tiles of this row group are complete
             const uint8_t* mine = isA ? t0 : t1;
-            Frag<NS> df[G::E4], wf[G::E4 * RT];
+            if constexpr (!PIPE) {
+                Frag<NS> df[G::E4], wf[G::E4 * RT];
 #pragma unroll
-            for (int e = 0; e < G::E4; ++e) {
-                float v8[8];
-                tile_lane_vals8<IO>(mine, trow, h, e, v8);
-                df[e] = frag_from_f32<NS>(v8);
+                for (int e = 0; e < G::E4; ++e) {
+                    float v8[8];
+                    tile_lane_vals8<IO>(mine, trow, h, e, v8);
+                    df[e] = frag_from_f32<NS>(v8);
 #pragma unroll
-                for (int ct = 0; ct < RT; ++ct) wf[e * RT + ct] = wfrag<NS>(w, e * RT + ct, lane);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int ct = 0; ct < RT; ++ct) wf[e * RT + ct] = wfrag<NS>(w, e * RT + ct, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < G::E4; ++e) {
+                for (int e = 0; e < G::E4; ++e) {
 #pragma unroll
-                for (int ct = 0; ct < RT; ++ct) dz[ct] = mfma_ns<NS>(wf[e * RT + ct], df[e], dz[ct]);
+                    for (int ct = 0; ct < RT; ++ct) dz[ct] = mfma_ns<NS>(wf[e * RT + ct], df[e], dz[ct]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < G::E4; ++e) {
+                    float v8[8];
+                    tile_lane_vals8<IO>(mine, trow, h, e, v8);
+                    const Frag<NS> dfe = frag_from_f32<NS>(v8);
+                    Frag<NS> wf[RT];
+#pragma unroll
+                    for (int ct = 0; ct < RT; ++ct) wf[ct] = wfrag<NS>(w, e * RT + ct, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ct = 0; ct < RT; ++ct) dz[ct] = mfma_ns<NS>(wf[ct], dfe, dz[ct]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             wait_vm(0);                             // the next stage's weights (and the rows issued a stage ago) have landed
             __builtin_amdgcn_s_barrier();
@@ -249,14 +279,16 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_dz_kernel(PetBwdArgs a) {
     {
         const int ldz = 32 * RT;
         IO* dps = reinterpret_cast<IO*>(isA ? a.dp_a : a.dp_g);
+        const IO* sg = reinterpret_cast<const IO*>(sv + a.saved_stride) + ro;      // act'(pre), saved by the forward
         const float sc = isA ? sd_ : 1.0f;          // dz_a = sd * Wu^T dh: the delta scale once, here
 #pragma unroll
         for (int ct = 0; ct < RT; ++ct) {
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
-                float v[8];
+                float v[8], gp[8];
+                load8_f32(sg + 32 * ct + 16 * sh, gp);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = sc * dz[ct][8 * sh + j] * gp[ct][8 * sh + j];
+                for (int j = 0; j < 8; ++j) v[j] = sc * dz[ct][8 * sh + j] * gp[j];
                 if (row_ok) store8_f32(dps + grow * ldz + 32 * ct + 16 * sh + 8 * h, v);
             }
         }
@@ -278,17 +310,17 @@ struct ColsArgs {
     WgradArgs wg;                           // partial layout (job 0 dWd, 1 dWu, 2 dWgd, 3 dWgu), row_chunks, rows_per_chunk
 };
 
-template <typename IO>
+template <typename IO, int NRG, int NBUF_>
 struct ColsLds {
     using G = Geo4<IO>;
-    static constexpr int NBUF = 2;                                  // input tile buffers (one iteration ahead)
+    static constexpr int NBUF = NBUF_;                              // input tile buffers (NBUF - 1 iterations ahead)
     static constexpr int TILE_B = 32 * 128;
     static constexpr int XH_B = 32 * G::FE * 4;                     // fp32 exchange of h: LW values per lane
     static constexpr int RG_B = (3 * NBUF + 2) * TILE_B + XH_B;     // x2, dy, x1 buffers; dh, dq tiles; exchange
     static int w_bytes(int RT) { return 4 * 4 * RT * 1024; }        // [up A | up G | down_t A | down_t G] of one stage
     static size_t bytes(int RT) {
-        const size_t main = (size_t)w_bytes(RT) + 2 * RG_B + 2 * G::FE * 4;
-        const size_t red = (size_t)4 * (RT * G::NV * 16 + RT + G::NV) * 64 * 4;     // end-of-kernel reduction over the row groups
+        const size_t main = (size_t)w_bytes(RT) + NRG * RG_B + 2 * G::FE * 4;
+        const size_t red = NRG > 1 ? (size_t)4 * (RT * G::NV * 16 + RT + G::NV) * 64 * 4 : 0;     // end-of-kernel reduction over the row groups
         return main > red ? main : red;
     }
 };
@@ -314,10 +346,15 @@ __device__ __forceinline__ Frag<NS> zero_frag() {
     return f;
 }
 
-template <typename IO, int RT>
-__global__ __launch_bounds__(512) void pet_gate_cols_kernel(ColsArgs a) {
+// NRG = row groups (32 rows) per workgroup: 2 for r <= 96 (8 waves, two per SIMD, 256 registers each); 1 for r = 192
+// (4 waves, one per SIMD: the 192 accumulator registers of a role need the whole register file of a SIMD lane)
+// NBUF = row-tile buffers (tiles are requested NBUF - 1 iterations ahead); PPF = the P rows of the next iteration are
+// requested at the top of the current one into a second register set (needs the registers: NRG = 1)
+template <typename IO, int RT, int NRG, int NBUF, bool PPF>
+__global__ __launch_bounds__(NRG * 256) void pet_gate_cols_kernel(ColsArgs a) {
     using G = Geo4<IO>;
-    using L = ColsLds<IO>;
+    using L = ColsLds<IO, NRG, NBUF>;
+    constexpr int IR = 32 * NRG;                                     // rows per iteration
     constexpr int NS = G::NS, KT = 2 * RT, NV = G::NV, FE = G::FE, LW = G::LW;
     constexpr int SEG_B = 4 * RT * 1024;
     constexpr int PR = 32 * RT;
@@ -333,10 +370,10 @@ __global__ __launch_bounds__(512) void pet_gate_cols_kernel(ColsArgs a) {
     if (r_begin >= a.M) return;
     int64_t r_end = r_begin + a.wg.rows_per_chunk;
     if (r_end > a.M) r_end = a.M;
-    const int n_it = (int)((r_end - r_begin + 63) / 64);
+    const int n_it = (int)((r_end - r_begin + IR - 1) / IR);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = wave & 1, role = wave >> 1;                       // role 0 A1, 1 A2, 2 G1, 3 G2
+    const int rg = wave % NRG, role = wave / NRG;                    // role 0 A1, 1 A2, 2 G1, 3 G2
     const bool chainA = role < 2;
     const int m = lane & 31, h = lane >> 5;
     const int lane16 = lane * 16;
@@ -353,10 +390,10 @@ __global__ __launch_bounds__(512) void pet_gate_cols_kernel(ColsArgs a) {
     uint8_t* Tdh = rgb + (size_t)(3 * L::NBUF) * L::TILE_B;
     uint8_t* Tdq = Tdh + L::TILE_B;
     uint8_t* XHb = Tdq + L::TILE_B;
-    float* sbias = reinterpret_cast<float*>(smem + 4 * SEG_B + 2 * L::RG_B);     // [bu block (FE) | bgu block (FE)]
+    float* sbias = reinterpret_cast<float*>(smem + 4 * SEG_B + NRG * L::RG_B);   // [bu block (FE) | bgu block (FE)]
 
     // ---- prologue: this stage's weight fragments and bias blocks
-    for (int k = wave; k < 16 * RT; k += 8) {
+    for (int k = wave; k < 16 * RT; k += 4 * NRG) {
         const int blk = k / (4 * RT), piece = k % (4 * RT);          // 0 up A, 1 up G, 2 down_t A, 3 down_t G
         const uint8_t* pkx = (blk & 1) ? a.pk_g : a.pk_a;
         const uint8_t* src = pkx + (int64_t)(blk < 2 ? 1 : 3) * pg.pack_bytes + (int64_t)su * SEG_B + (size_t)piece * 1024;
@@ -391,21 +428,56 @@ __global__ __launch_bounds__(512) void pet_gate_cols_kernel(ColsArgs a) {
     for (int nt = 0; nt < NV; ++nt) csx[nt] = 0.f;
 
     auto tile_of = [&](int bf) { return role == 0 ? Tx2(bf) : (role == 2 ? Tx1(bf) : Tdy(bf)); };
+    // row-tile addressing: instruction i of a wave moves rows 8i + (lane >> 3), 16-byte piece (lane & 7) ^ swz(row) -- a
+    // wave-uniform 64-bit base per block plus a 32-bit per-lane offset (full blocks; the ragged last block clamps per lane)
+    uint32_t voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tr = 8 * i + (lane >> 3);
+        voff[i] = (uint32_t)tr * (uint32_t)(d * (int)sizeof(IO)) + (uint32_t)(((lane & 7) ^ swz(tr)) * 16);
+    }
     auto issue_tile = [&](int it) {                                  // this wave's input tile of iteration it
-        if (role == 1 || it >= n_it) return;
-        const RowLanes rl = row_lanes<IO>(r_begin + (int64_t)it * 64 + 32 * rg, a.M, d, 0, lane);
-        glds_rows4(Xsrc, rl, su * 128, tile_of(it & 1), 0);
+        if (role == 1 || it >= n_it) return 0;
+        const int64_t row0t = r_begin + (int64_t)it * IR + 32 * rg;
+        uint8_t* dst = tile_of(it % NBUF);
+        if (row0t + 32 <= a.M) {
+            const uint8_t* base = Xsrc + row0t * d * (int64_t)sizeof(IO) + su * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(base + voff[i], dst + i * 1024);
+        } else {
+            const RowLanes rl = row_lanes<IO>(row0t, a.M, d, 0, lane);
+            glds_rows4(Xsrc, rl, su * 128, dst, 0);
+        }
+        return 4;
+    };
+    // whole-line stores of a staged tile (the wave's 32 rows of feature block su)
+    auto store_tile = [&](uint8_t* base_out, int64_t row0t, const uint8_t* tile) {
+        if (row0t + 32 <= a.M) {
+            uint8_t* base = base_out + row0t * d * (int64_t)sizeof(IO) + su * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(tile + ((size_t)(8 * i + (lane >> 3)) * 8 + (lane & 7)) * 16);
+                *reinterpret_cast<u32x4*>(base + voff[i]) = v;
+            }
+            return 4;
+        }
+        const RowLanes rl = row_lanes<IO>(row0t, a.M, d, 0, lane);
+        store_rows4(base_out, rl, su * 128, tile, 0, lane);
+        return rl.n_inst;
     };
     Frag<NS> pn[KT];                                                 // this role's P rows, natural fragments
+    Frag<NS> pnn[PPF ? KT : 1];                                      // ... of the next iteration (PPF)
     constexpr int NPL = KT * (int)(sizeof(IO) / 2);                  // global loads of one load_p
-    auto load_p = [&](int it) {                                      // (rows past the end: clamped address, zeroed at use)
-        int64_t row = r_begin + (int64_t)it * 64 + 32 * rg + m;
+    auto load_p = [&](int it, Frag<NS>* dst) {                       // (rows past the end: clamped address, zeroed at use)
+        int64_t row = r_begin + (int64_t)it * IR + 32 * rg + m;
         if (row >= a.M) row = a.M - 1;
         const IO* pr = Psrc + row * (int64_t)PR + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < KT; ++ks) pn[ks] = load_frag8(pr + 16 * ks);
+        for (int ks = 0; ks < KT; ++ks) dst[ks] = load_frag8(pr + 16 * ks);
     };
     // accumulate  Out[c, n] += sum_m P[m, c] X[m, n]  for this wave's 32 rows (P = pn, X = the NV natural-fragment pairs)
+    // (scheduling fences between the sub-steps: without them hipcc interleaves all transposes and keeps every intermediate
+    // alive at once -- the wave holds 96 accumulator registers and has 256 in all)
     auto accumulate = [&](const Frag<NS>* xn) {
         Frag<NS> xt[NV][2];
 #pragma unroll
@@ -416,6 +488,7 @@ __global__ __launch_bounds__(512) void pet_gate_cols_kernel(ColsArgs a) {
             for (int i = 0; i < 16; ++i) { v[i] = t[i]; csx[nt] += t[i]; }
             xt[nt][0] = frag_from_f32<NS>(v);
             xt[nt][1] = frag_from_f32<NS>(v + 8);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int ct = 0; ct < RT; ++ct) {
@@ -429,6 +502,7 @@ __global__ __launch_bounds__(512) void pet_gate_cols_kernel(ColsArgs a) {
                 acc[ct][nt] = mfma_ns<NS>(pt0, xt[nt][0], acc[ct][nt]);
                 acc[ct][nt] = mfma_ns<NS>(pt1, xt[nt][1], acc[ct][nt]);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // X natural fragments of a row tile (rows past the chunk contribute nothing)
@@ -463,17 +537,19 @@ __global__ __launch_bounds__(512) void pet_gate_cols_kernel(ColsArgs a) {
         }
     };
 
-    issue_tile(0);
-    load_p(0);
+#pragma unroll
+    for (int k = 0; k < NBUF - 1; ++k) issue_tile(k);
+    load_p(0, pn);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const float* bb = sbias + (chainA ? 0 : FE) + LW * h;
     for (int it = 0; it < n_it; ++it) {
-        const int bf = it & 1;
-        const int64_t row0 = r_begin + (int64_t)it * 64 + 32 * rg;
+        const int bf = it % NBUF;
+        const int64_t row0 = r_begin + (int64_t)it * IR + 32 * rg;
         const bool valid = row0 + m < r_end;
-        issue_tile(it + 1);                                          // in flight during this iteration
+        if constexpr (PPF) load_p(it + 1, pnn);                      // requested first: the end-of-iteration wait covers it
+        const int n_tile = issue_tile(it + NBUF - 1);                // in flight during this (and the next NBUF - 2) iterations
         if (row0 + 32 > r_end) {                                     // ragged end of the last chunk (wave-uniform branch)
 #pragma unroll
             for (int ks = 0; ks < KT; ++ks) pn[ks] = valid ? pn[ks] : zero_frag<NS>();
@@ -570,9 +646,7 @@ __global__ __launch_bounds__(512) void pet_gate_cols_kernel(ColsArgs a) {
                 for (int j = 0; j < 8; ++j) { const int i = 8 * e + j; o8[j] = ax[(i >> 4) % NV][i & 15]; }
                 stage_lane_vals8<IO>(tile, m, h, e, o8);
             }
-            const RowLanes rl = row_lanes<IO>(row0, a.M, d, 0, lane);
-            store_rows4(dxo, rl, su * 128, tile, 0, lane);
-            n_store = rl.n_inst;
+            n_store = store_tile(dxo, row0, tile);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                // B2: the dh / dq tiles are complete
@@ -592,25 +666,30 @@ __global__ __launch_bounds__(512) void pet_gate_cols_kernel(ColsArgs a) {
                 for (int j = 0; j < 8; ++j) { const int i = 8 * e + j; o8[j] = ax[(i >> 4) % NV][i & 15] + s2 * dh8[j]; }
                 stage_lane_vals8<IO>(tile, m, h, e, o8);
             }
-            const RowLanes rl = row_lanes<IO>(row0, a.M, d, 0, lane);
-            store_rows4(dxo, rl, su * 128, tile, 0, lane);
-            n_store = rl.n_inst;
+            n_store = store_tile(dxo, row0, tile);
         } else if (role == 1 || role == 3) {                         // A2: dWu = z_a^T dh;  G2: dWgu = z_g^T dq
             Frag<NS> xn[G::KU];
             tile_frags(role == 1 ? Tdh : Tdq, valid, xn);
             accumulate(xn);
         }
-        load_p(it + 1);                                              // this role's P rows of the next iteration
-        // the next iteration's tile (the oldest operation in flight) must have landed; this iteration's output stores and
-        // the P rows just requested stay in flight
-        wait_vm(NPL + n_store);
+        // Vector-memory operations retire in order.  Issued this iteration, oldest first: [P rows of it+1 (PPF)], the tile of
+        // it+NBUF-1, the output stores, [P rows of it+1 (!PPF)].  The next iteration needs the tile of it+1 (this
+        // iteration's when NBUF = 2, the previous one's otherwise) and the P rows; the stores may stay in flight.
+        if constexpr (PPF) {
+            wait_vm((NBUF > 2 ? n_tile : 0) + n_store);
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) pn[ks] = pnn[ks];
+        } else {
+            load_p(it + 1, pn);                                      // (consumed at the top of the next iteration: the compiler's wait)
+            wait_vm(NPL + n_store + (NBUF > 2 ? n_tile : 0));
+        }
         __builtin_amdgcn_s_barrier();                                // B3: next tiles landed; dh / dq / exchange free again
     }
 
     // ---- reduce the two row groups (fixed order) and emit this chunk's partial
     constexpr int NVAL = RT * NV * 16 + RT + NV;
     float* red = reinterpret_cast<float*>(smem) + (size_t)role * NVAL * 64;
-    if (rg == 1) {
+    if (NRG > 1 && rg == 1) {
         int k = 0;
 #pragma unroll
         for (int ct = 0; ct < RT; ++ct)
@@ -625,17 +704,19 @@ __global__ __launch_bounds__(512) void pet_gate_cols_kernel(ColsArgs a) {
     }
     __syncthreads();
     if (rg == 0) {
-        int k = 0;
+        if constexpr (NRG > 1) {
+            int k = 0;
 #pragma unroll
-        for (int ct = 0; ct < RT; ++ct)
+            for (int ct = 0; ct < RT; ++ct)
 #pragma unroll
-            for (int nt = 0; nt < NV; ++nt)
+                for (int nt = 0; nt < NV; ++nt)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[ct][nt][i] += red[(k++) * 64 + lane];
+                    for (int i = 0; i < 16; ++i) acc[ct][nt][i] += red[(k++) * 64 + lane];
 #pragma unroll
-        for (int ct = 0; ct < RT; ++ct) csp[ct] += red[(k++) * 64 + lane];
+            for (int ct = 0; ct < RT; ++ct) csp[ct] += red[(k++) * 64 + lane];
 #pragma unroll
-        for (int nt = 0; nt < NV; ++nt) csx[nt] += red[(k++) * 64 + lane];
+            for (int nt = 0; nt < NV; ++nt) csx[nt] += red[(k++) * 64 + lane];
+        }
 
         // (all four jobs have xcols = d: job j's block starts at j * RC * (PR*d + d + PR) floats -- wgrad_layout)
         const int xc = d, RC = a.wg.row_chunks, n0 = su * FE;
@@ -685,11 +766,12 @@ void gate_bwd3_plan(int64_t M, int d, int io_fp32, int* row_chunks, int64_t* row
     rc = (blocks64 + per - 1) / per;
     *row_chunks = (int)rc; *rows_per_chunk = per * 64; *GS = gs; *NG = ng;
 }
+static inline bool bwd3_rt_ok(int RT) { return RT == 1 || RT == 3 || RT == 6; }
 
 bool pet_gate_bwd3_applies(const PetBwdArgs& a) {
     static const bool off = [] { const char* e = getenv("VLPET_BWD3"); return e != nullptr && atoi(e) == 0; }();
     if (off) return false;
-    return (a.flags & PET_GATE) && a.saved != nullptr && !drop_active(a.drop) && (a.RT == 1 || a.RT == 3);
+    return (a.flags & PET_GATE) && a.saved != nullptr && !drop_active(a.drop) && bwd3_rt_ok(a.RT);
 }
 
 template <typename IO, int RT, int RG>
@@ -705,28 +787,52 @@ static hipError_t launch_dz_one(const PetBwdArgs& a, hipStream_t stream) {
 }
 template <typename IO, int RT>
 static hipError_t launch_dz_rt(const PetBwdArgs& a, hipStream_t stream) {
-    switch (pick_row_groups(a.M, 4, 2)) {
-        case 4: return launch_dz_one<IO, RT, 4>(a, stream);
-        case 3: if constexpr ((4 * RT) % 3 == 0) return launch_dz_one<IO, RT, 3>(a, stream);   // (else: falls through)
-        default: return launch_dz_one<IO, RT, 2>(a, stream);
+    if constexpr (RT == 6) {
+        return launch_dz_one<IO, RT, 2>(a, stream);      // r = 192: the 2 x 48 KiB weight ring leaves room for 64 rows
+    } else {
+        switch (pick_row_groups(a.M, 4, 2)) {
+            case 4: return launch_dz_one<IO, RT, 4>(a, stream);
+            case 3: if constexpr ((4 * RT) % 3 == 0) return launch_dz_one<IO, RT, 3>(a, stream);   // (else: falls through)
+            default: return launch_dz_one<IO, RT, 2>(a, stream);
+        }
     }
 }
 hipError_t launch_pet_gate_dz(const PetBwdArgs& a, int io_fp32, hipStream_t stream) {
     if (a.RT == 1) return io_fp32 ? launch_dz_rt<float, 1>(a, stream) : launch_dz_rt<__bf16, 1>(a, stream);
     if (a.RT == 3) return io_fp32 ? launch_dz_rt<float, 3>(a, stream) : launch_dz_rt<__bf16, 3>(a, stream);
+    if (a.RT == 6) return io_fp32 ? launch_dz_rt<float, 6>(a, stream) : launch_dz_rt<__bf16, 6>(a, stream);
     return hipErrorInvalidValue;
 }
 
-template <typename IO, int RT>
-static hipError_t launch_cols_one(const ColsArgs& c, hipStream_t stream) {
-    const size_t lds = ColsLds<IO>::bytes(RT);
-    auto kern = pet_gate_cols_kernel<IO, RT>;
+template <typename IO, int RT, int NRG, int NBUF, bool PPF>
+static hipError_t launch_cols_cfg(const ColsArgs& c, hipStream_t stream) {
+    const size_t lds = ColsLds<IO, NRG, NBUF>::bytes(RT);
+    auto kern = pet_gate_cols_kernel<IO, RT, NRG, NBUF, PPF>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int units = c.NG * c.wg.row_chunks;
     const unsigned grid = 8u * (unsigned)c.GS * (unsigned)((units + 7) / 8);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, c);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NRG * 256), lds, stream, c);
     return hipGetLastError();
+}
+
+// workgroup shape of pass 2 (VLPET_BWD3_CFG = 0..2 selects it for experiments):
+//   0: 8 waves (2 row groups x 4 roles), tiles one iteration ahead                       -- the r <= 32 default
+//   1: 4 waves (1 row group), one per SIMD with the whole register file, tiles one ahead, P rows prefetched
+//   2: as 1, tiles two iterations ahead                                                   -- the default for r > 32
+template <typename IO, int RT>
+static hipError_t launch_cols_one(const ColsArgs& c, hipStream_t stream) {
+    static const int cfg_env = [] { const char* e = getenv("VLPET_BWD3_CFG"); return e ? atoi(e) : -1; }();
+    if constexpr (RT == 6) {
+        return launch_cols_cfg<IO, RT, 1, 2, false>(c, stream);     // 96 KiB of weight fragments: room for two buffers
+    } else if constexpr (RT == 1) {
+        return launch_cols_cfg<IO, RT, 2, 2, false>(c, stream);
+    } else {
+        const int cfg = cfg_env >= 0 ? cfg_env : 2;
+        if (cfg == 0) return launch_cols_cfg<IO, RT, 2, 2, false>(c, stream);
+        if (cfg == 1) return launch_cols_cfg<IO, RT, 1, 2, true>(c, stream);
+        return launch_cols_cfg<IO, RT, 1, 3, true>(c, stream);
+    }
 }
 
 // pass 2 + the partial reduction.  `g` = the four weight-gradient jobs as run_bwd builds them for launch_wgrad (job order
@@ -742,6 +848,7 @@ hipError_t launch_pet_gate_cols(const PetBwdArgs& a, const WgradArgs& g, int GS,
     hipError_t e;
     if (a.RT == 1) e = io_fp32 ? launch_cols_one<float, 1>(c, stream) : launch_cols_one<__bf16, 1>(c, stream);
     else if (a.RT == 3) e = io_fp32 ? launch_cols_one<float, 3>(c, stream) : launch_cols_one<__bf16, 3>(c, stream);
+    else if (a.RT == 6) e = io_fp32 ? launch_cols_one<float, 6>(c, stream) : launch_cols_one<__bf16, 6>(c, stream);
     else return hipErrorInvalidValue;
     if (e != hipSuccess) return e;
     return launch_wgrad_finalize(g, stream);

@@ -69,7 +69,8 @@ def build_pet(module: nn.Module, config, embed_dim: int, which=("attn", "ff")):
 # accumulator sets at once and spills.  Until that kernel is blocked in two 3-tile halves, such
 # layers run as a composition of 3-tile kernels, which is exact: the bottleneck splits into two halves whose up
 # projections add,   lin = s2*x2 + sd*(D1 + D2),   G = G1 + G2,   y = lin (*|+) sigmoid(G) * gs.
-SPLIT_WIDE_BOTTLENECK = True
+import os as _os
+SPLIT_WIDE_BOTTLENECK = _os.environ.get("VLPET_FUSED_WIDE", "0") != "1"     # (VLPET_FUSED_WIDE=1: the fused r = 192 kernels, for A/B)
 
 
 def _apply_pet_split(module, which, x1, x2, dws, dbs, up, gdown, gup, mode, sd, s2, gs, io):
