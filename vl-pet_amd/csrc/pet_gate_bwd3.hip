@@ -768,10 +768,15 @@ void gate_bwd3_plan(int64_t M, int d, int io_fp32, int* row_chunks, int64_t* row
 }
 static inline bool bwd3_rt_ok(int RT) { return RT == 1 || RT == 3 || RT == 6; }
 
+// Where the two-pass form is the default: r = 192, whose one-kernel row pass (pet_bwd_kernel<.., 6, gate>) spills 350
+// registers (two-pass 358 us vs 451 us at M = 16,800).  For r <= 96 the previous split (pet_gate_bwd2 + wgrad) is faster on
+// MI355X despite its 11 units of traffic (164 us vs 234 us at M = 28,000): pass 2 is latency-chain bound (see launch_cols_one).
+// VLPET_BWD3 = 1 / 0 forces it on / off for every supported rank.
 bool pet_gate_bwd3_applies(const PetBwdArgs& a) {
-    static const bool off = [] { const char* e = getenv("VLPET_BWD3"); return e != nullptr && atoi(e) == 0; }();
-    if (off) return false;
-    return (a.flags & PET_GATE) && a.saved != nullptr && !drop_active(a.drop) && bwd3_rt_ok(a.RT);
+    static const int force = [] { const char* e = getenv("VLPET_BWD3"); return e == nullptr ? -1 : atoi(e); }();
+    if (force == 0) return false;
+    if (!((a.flags & PET_GATE) && a.saved != nullptr && !drop_active(a.drop) && bwd3_rt_ok(a.RT))) return false;
+    return force == 1 || a.RT == 6;
 }
 
 template <typename IO, int RT, int RG>
@@ -816,21 +821,18 @@ static hipError_t launch_cols_cfg(const ColsArgs& c, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// workgroup shape of pass 2 (VLPET_BWD3_CFG = 0..2 selects it for experiments):
-//   0: 8 waves (2 row groups x 4 roles), tiles one iteration ahead                       -- the r <= 32 default
-//   1: 4 waves (1 row group), one per SIMD with the whole register file, tiles one ahead, P rows prefetched
-//   2: as 1, tiles two iterations ahead                                                   -- the default for r > 32
+// workgroup shape of pass 2.  Measured at M = 28,000, bf16, r = 96 (profiles/r02_kbench_two_pass_ab.txt): 8 waves (2 row
+// groups x 4 roles, 256 registers each) spill 70-140 registers and take 290-410 us -- every scratch reload waits, in order,
+// behind the tile prefetches; 4 waves (one per SIMD, no spill, P rows prefetched) take 189 us whether the tiles run one or
+// two iterations ahead, i.e. the pass is bound by the three-phase dependency chain of an iteration (~7k cycles per 32 rows),
+// not by memory.  Kept: the 4-wave shape (r > 32) and the 8-wave shape where it does not spill (r <= 32).
 template <typename IO, int RT>
 static hipError_t launch_cols_one(const ColsArgs& c, hipStream_t stream) {
-    static const int cfg_env = [] { const char* e = getenv("VLPET_BWD3_CFG"); return e ? atoi(e) : -1; }();
     if constexpr (RT == 6) {
-        return launch_cols_cfg<IO, RT, 1, 2, false>(c, stream);     // 96 KiB of weight fragments: room for two buffers
+        return launch_cols_cfg<IO, RT, 1, 2, false>(c, stream);     // 96 KiB of weight fragments: room for two tile buffers
     } else if constexpr (RT == 1) {
         return launch_cols_cfg<IO, RT, 2, 2, false>(c, stream);
     } else {
-        const int cfg = cfg_env >= 0 ? cfg_env : 2;
-        if (cfg == 0) return launch_cols_cfg<IO, RT, 2, 2, false>(c, stream);
-        if (cfg == 1) return launch_cols_cfg<IO, RT, 1, 2, true>(c, stream);
         return launch_cols_cfg<IO, RT, 1, 3, true>(c, stream);
     }
 }

@@ -65,12 +65,13 @@ def build_pet(module: nn.Module, config, embed_dim: int, which=("attn", "ff")):
         module._pet_caches[w] = (VF.PackCache(), VF.PackCache())
 
 
-# r, r_g in (96, 192] (the T5 script): the 6-tile instantiation of the fused backward needs four [32 x 192] fp32
-# accumulator sets at once and spills.  Until that kernel is blocked in two 3-tile halves, such
-# layers run as a composition of 3-tile kernels, which is exact: the bottleneck splits into two halves whose up
-# projections add,   lin = s2*x2 + sd*(D1 + D2),   G = G1 + G2,   y = lin (*|+) sigmoid(G) * gs.
+# r, r_g in (96, 192] (the T5 script) run on the fused 6-tile kernels: two-chain forward (pet_gate_fwd.hip, 64-row
+# workgroups) with saved activations and the two-pass backward (pet_gate_bwd3.hip).  T5 bench, same box: 2,121 samples/s
+# fused vs 1,989 through the composition of 3-tile kernels below (profiles/r02_bench_t5_*.json.log).  The composition
+# (exact: the bottleneck splits into two halves whose up projections add,  lin = s2*x2 + sd*(D1 + D2),  G = G1 + G2,
+# y = lin (*|+) sigmoid(G) * gs) stays for A/B (VLPET_SPLIT_WIDE=1) and as the reference of test_apply_pet_wide_bottleneck.
 import os as _os
-SPLIT_WIDE_BOTTLENECK = _os.environ.get("VLPET_FUSED_WIDE", "0") != "1"     # (VLPET_FUSED_WIDE=1: the fused r = 192 kernels, for A/B)
+SPLIT_WIDE_BOTTLENECK = _os.environ.get("VLPET_SPLIT_WIDE", "0") == "1"
 
 
 def _apply_pet_split(module, which, x1, x2, dws, dbs, up, gdown, gup, mode, sd, s2, gs, io):
