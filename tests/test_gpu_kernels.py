@@ -57,6 +57,9 @@ def test_k1_backward_recompute_path(dtype, monkeypatch):
     check(C.run_k1(dtype, M=130, gate_mode=2, gate_scale=0.3), dtype)
     check(C.run_k2(dtype, M=333, r=8, d=64, scale=4.0), dtype)
     check(C.run_k2(dtype), dtype)
+    errs = C.run_k3(dtype, r=64, p=0.1)             # K3 without the saved z: the backward recomputes dropout(x) A^T
+    errs.pop("keep_frac")
+    check(errs, dtype)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -109,7 +109,7 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
     int rc = check_common(M, d, tiles, io_dtype);
     if (rc) return rc;
     if (!xa || !res || !pk_a || !out) return VLPET_E_NULL;
-    if (saved && ((flags & PET_ACT_IDENTITY) || drop_active(drop) || !aligned16(saved))) return VLPET_E_ALIGN;
+    if (saved && !aligned16(saved)) return VLPET_E_ALIGN;
     if ((flags & PET_GATE) && (!xg || !pk_g)) return VLPET_E_NULL;
     if (!aligned16(xa) || !aligned16(res) || !aligned16(out) || !aligned16(pk_a) ||
         ((flags & PET_GATE) && (!aligned16(xg) || !aligned16(pk_g))) || (drop.keep && !aligned16(drop.keep)) ||
@@ -200,6 +200,22 @@ extern "C" int vlpet_lora_delta_fwd(const void* x, const void* base, const void*
                    PET_ACT_IDENTITY, io_dtype, stream);
 }
 
+extern "C" size_t vlpet_lora_saved_bytes(int64_t M, int tiles, int io_dtype) {
+    if (M <= 0 || !tiles_ok(tiles)) return 0;
+    return saved_stride(M, tiles, io_dtype);
+}
+
+extern "C" int vlpet_lora_delta_fwd_save(const void* x, const void* base, const void* packed,
+                                         const uint8_t* keep_mask, float p, uint64_t seed, uint8_t* keep_out, void* out,
+                                         void* saved, int64_t M, int d, int tiles, float scaling, int io_dtype,
+                                         vlpet_stream_t stream) {
+    if (!saved) return VLPET_E_NULL;
+    DropSpec ds;
+    if (int rc = make_drop(keep_mask, p, seed, keep_out, &ds)) return rc;
+    return run_fwd(x, base, nullptr, packed, nullptr, ds, out, M, d, tiles, 1.f, scaling, 1.f,
+                   PET_ACT_IDENTITY, io_dtype, stream, saved);
+}
+
 // ------------------------------------------------------------------ backward workspace
 struct BwdWs {
     size_t z_a, dp_a, z_g, dp_g, dh, dq, partial, total;
@@ -273,7 +289,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     b.drop = drop; b.drop.keep_out = nullptr;
     b.M = M; b.d = d; b.RT = tiles;
     b.s2 = s2; b.sd = sd; b.gs = gs; b.flags = flags;
-    if (saved && ((flags & PET_ACT_IDENTITY) || drop_active(drop) || !aligned16(saved))) return VLPET_E_ALIGN;
+    if (saved && !aligned16(saved)) return VLPET_E_ALIGN;
     b.saved = saved; b.saved_stride = (int64_t)saved_stride(M, tiles, io_dtype);
     if (saved) {        // z comes from the forward; the rows kernel does not write it
         b.z_a = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(saved));
@@ -405,6 +421,20 @@ extern "C" int vlpet_lora_delta_bwd(const void* dy, const void* x, const void* p
                    da, nullptr, db, nullptr, nullptr, nullptr, nullptr, nullptr, r, 0,
                    workspace, workspace_bytes, M, d, tiles, 1.f, scaling, 1.f, PET_ACT_IDENTITY,
                    io_dtype, stream);
+}
+
+extern "C" int vlpet_lora_delta_bwd_saved(const void* dy, const void* x, const void* saved, const void* packed,
+                                          const uint8_t* keep_mask, float p, uint64_t seed, void* dx,
+                                          float* da, float* db, int r, void* workspace, size_t workspace_bytes,
+                                          int64_t M, int d, int tiles, float scaling, int io_dtype,
+                                          vlpet_stream_t stream) {
+    if (!saved) return VLPET_E_NULL;
+    DropSpec ds;
+    if (int rc = make_drop(keep_mask, p, seed, nullptr, &ds)) return rc;
+    return run_bwd(dy, x, nullptr, nullptr, packed, nullptr, ds, dx, nullptr,
+                   da, nullptr, db, nullptr, nullptr, nullptr, nullptr, nullptr, r, 0,
+                   workspace, workspace_bytes, M, d, tiles, 1.f, scaling, 1.f, PET_ACT_IDENTITY,
+                   io_dtype, stream, 3, saved);
 }
 
 

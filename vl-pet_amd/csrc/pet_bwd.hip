@@ -193,7 +193,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         }
     };
     // with the forward's saved activations phase 1 (stages 0 .. S-1) does not exist
-    const bool use_saved = !ACT_ID && !DROP && a.saved != nullptr;
+    const bool use_saved = a.saved != nullptr;      // (K3: z only -- the identity activation has no act'(pre) to save)
     const int S0 = use_saved ? S : 0;
     BSTAMP(0);
     issue_w(S0);
@@ -228,9 +228,14 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
                 float v[8];
                 load8_f32(sza + 32 * ct + 16 * sh, v);
                 zA[2 * ct + sh] = frag_from_f32<NS>(v);
-                load8_f32(sga + 32 * ct + 16 * sh, v);
+                if constexpr (ACT_ID) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) accA[ct][8 * sh + j] = v[j];
+                    for (int j = 0; j < 8; ++j) accA[ct][8 * sh + j] = 1.0f;
+                } else {
+                    load8_f32(sga + 32 * ct + 16 * sh, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) accA[ct][8 * sh + j] = v[j];
+                }
                 if constexpr (GATE) {
                     load8_f32(szg + 32 * ct + 16 * sh, v);
                     zG[2 * ct + sh] = frag_from_f32<NS>(v);

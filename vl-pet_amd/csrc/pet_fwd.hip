@@ -207,7 +207,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
         const float* bdA = sb + 8 * h;
         const float* bdG = sb + nb + 8 * h;
         // training form (kernels.h PetFwdArgs::save): z and gelu'(pre) of the adapter chain for the backward
-        const bool save = !GATE && !ACT_ID && a.save != nullptr && row0_wave + m < a.M;
+        const bool save = !GATE && a.save != nullptr && row0_wave + m < a.M;      // (K3: z only)
         IO* sv_z = reinterpret_cast<IO*>(a.save) + (row0_wave + m) * (int64_t)(32 * RT) + 8 * h;
         IO* sv_g = reinterpret_cast<IO*>(reinterpret_cast<uint8_t*>(a.save) + a.save_stride) + (row0_wave + m) * (int64_t)(32 * RT) + 8 * h;
 #pragma unroll
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = accA[ct][8 * sh + j] + bdA[32 * ct + 16 * sh + j];
-                if (save) {
+                if (save && !ACT_ID) {
                     float g[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) g[j] = gelu_new_grad_f(v[j]);

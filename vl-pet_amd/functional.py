@@ -426,10 +426,18 @@ class _LoraDeltaFn(torch.autograd.Function):
             if kf.dtype != torch.uint8:
                 kf = kf.to(torch.uint8)
         mask = torch.empty(M, d, dtype=torch.uint8, device=xf.device) if (want_mask and p > 0) else None
-        rc = _timed("k3_fwd", M, lambda: lib.vlpet_lora_delta_fwd(
-            xf.data_ptr(), bf.data_ptr(), pk.buf.data_ptr(), _ptr(kf), float(p), int(seed), _ptr(mask), out.data_ptr(),
-            M, d, pk.tiles, float(scaling), io, _stream()))
+        act = None
+        if SAVE_ACTIVATIONS and any(ctx.needs_input_grad):      # training: z = dropout(x) A^T for the backward (see K1 / K2)
+            act = torch.empty(lib.vlpet_lora_saved_bytes(M, pk.tiles, io), dtype=torch.uint8, device=xf.device)
+            rc = _timed("k3_fwd", M, lambda: lib.vlpet_lora_delta_fwd_save(
+                xf.data_ptr(), bf.data_ptr(), pk.buf.data_ptr(), _ptr(kf), float(p), int(seed), _ptr(mask), out.data_ptr(),
+                act.data_ptr(), M, d, pk.tiles, float(scaling), io, _stream()))
+        else:
+            rc = _timed("k3_fwd", M, lambda: lib.vlpet_lora_delta_fwd(
+                xf.data_ptr(), bf.data_ptr(), pk.buf.data_ptr(), _ptr(kf), float(p), int(seed), _ptr(mask), out.data_ptr(),
+                M, d, pk.tiles, float(scaling), io, _stream()))
         _lib.check(rc, "vlpet_lora_delta_fwd")
+        ctx.act = act
         ctx.save_for_backward(xf, lora_a, lora_b)
         ctx.keep = kf
         ctx.cfg = (pk, float(scaling), float(p), int(seed), x.shape)
@@ -454,9 +462,16 @@ class _LoraDeltaFn(torch.autograd.Function):
         dx = torch.empty_like(xf)
         nws = lib.vlpet_bwd_workspace_bytes(M, d, pk.tiles, 0, io)
         ws = torch.empty(nws, dtype=torch.uint8, device=xf.device)
-        rc = _timed("k3_bwd", M, lambda: lib.vlpet_lora_delta_bwd(
-            dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), _ptr(ctx.keep), p, seed, dx.data_ptr(), da.data_ptr(),
-            db.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, scaling, io, _stream()))
+        act = ctx.act
+        if act is not None:
+            rc = _timed("k3_bwd", M, lambda: lib.vlpet_lora_delta_bwd_saved(
+                dyf.data_ptr(), xf.data_ptr(), act.data_ptr(), pk.buf.data_ptr(), _ptr(ctx.keep), p, seed, dx.data_ptr(),
+                da.data_ptr(), db.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, scaling, io, _stream()))
+        else:
+            rc = _timed("k3_bwd", M, lambda: lib.vlpet_lora_delta_bwd(
+                dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), _ptr(ctx.keep), p, seed, dx.data_ptr(), da.data_ptr(),
+                db.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, scaling, io, _stream()))
+        ctx.act = None
         _lib.check(rc, "vlpet_lora_delta_bwd")
         return (dx.view(shape), dy, None, None, None, None, None, None, *_finish([(da, s0, lora_a), (db, s1, lora_b)]))
 
