@@ -168,6 +168,8 @@ def test_fails_loudly_on_cpu_tensor():
 
 def test_k1_backward_transpose_read_wgrad_variant(monkeypatch):
     """The opt-in weight-gradient kernel built on ds_read_b64_tr_b16 (VLPET_WGRAD_TR=1) gives the same gradients."""
+    # (the transpose-read kernel is the bf16 default since round 2; the switch is read once per process, so this test is
+    # meaningful in a fresh process: VLPET_WGRAD_TR=0 pytest ... exercises the identity-transpose kernel instead)
     monkeypatch.setenv("VLPET_WGRAD_TR", "1")
     check(C.run_k1(torch.bfloat16, M=1000, d=768, r=96, rg=96, nh=4), torch.bfloat16)
     check(C.run_k1(torch.bfloat16, M=333, d=256, r=8, rg=16, nh=4), torch.bfloat16)

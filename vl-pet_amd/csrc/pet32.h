@@ -153,7 +153,11 @@ __device__ __forceinline__ void wait_vm(int n) {
         case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
         case 11: asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory"); break;
         case 12: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;   // n > 12: stricter is safe
+        case 13: asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15) lgkmcnt(0)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); break;   // n > 16: stricter is safe
     }
 }
 

@@ -13,6 +13,7 @@
 // fragments (pack_down4 layout with r = d_out) in sub-stages of 16 input features through a 2-slot ring,
 // the feature rows 128 bytes per row at a time through the 3-slot ring.  The epilogue walks the row in
 // 128-byte chunks: R in by global_load_lds, out / xhat staged in LDS and stored as whole lines.
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 #include "pet32.h"
@@ -22,7 +23,12 @@ struct VisLds {
     static constexpr int NS = Geo4<IO>::NS;
     static constexpr int WSUB_B = NCT * NS * 1024;           // one 16-feature sub-stage of W
     static constexpr int TILE_B = WAVES * 32 * 128;
-    static constexpr int ROW_OFF = 2 * WSUB_B;
+    // weight ring: as many sub-stage slots as fit next to the 3-slot row ring and the parameters (d_out = 768, bf16: 4 slots of
+    // 24 KiB = three sub-stages, ~2.3k MFMA cycles, of prefetch distance; with 2 slots every sub-stage waited ~1 us for
+    // its fragments: 241 us per launch at M = 18.7k, 10 % of the MFMA peak)
+    static constexpr int NW_MAX = (160 * 1024 - 3 * TILE_B - 3 * 32 * NCT * 4 - 1024) / WSUB_B;
+    static constexpr int NW = NW_MAX < 2 ? 2 : (NW_MAX > 6 ? 6 : NW_MAX);
+    static constexpr int ROW_OFF = NW * WSUB_B;
     static constexpr int MAIN_B = ROW_OFF + 3 * TILE_B;
     static constexpr int EPI_B = 4 * TILE_B;                 // R0, R1, OUT, XHAT tiles (alias the rings)
     static constexpr int PARAM_OFF = MAIN_B > EPI_B ? MAIN_B : EPI_B;
@@ -84,12 +90,16 @@ __global__ __launch_bounds__(WAVES * 64) void visproj_fwd_kernel(VisprojArgs a) 
     auto issue_w = [&](int q1) {
         if (q1 >= Q) return;
         const uint8_t* src0 = a.pk + (int64_t)q1 * L::WSUB_B;
-        uint8_t* dst = slot_w(q1 & 1);
+        uint8_t* dst = slot_w(q1 % L::NW);
         constexpr int KB = NCT * NS;
         for (int k = wave; k < KB; k += WAVES) glds16(src0 + (size_t)k * 1024 + lane16, dst + (size_t)k * 1024);
     };
 
-    issue_w(0);
+    constexpr int KBW = NCT * NS;                                     // 1 KiB weight pieces per sub-stage
+    // pieces this wave issues per sub-stage (k = wave, wave + WAVES, ...): the counted waits below need the exact number
+    const int npw = (KBW - wave + WAVES - 1) / WAVES;
+#pragma unroll
+    for (int q0 = 0; q0 < L::NW - 1; ++q0) issue_w(q0);
     issue_rows(0);
     issue_rows(1);
     {
@@ -107,9 +117,9 @@ __global__ __launch_bounds__(WAVES * 64) void visproj_fwd_kernel(VisprojArgs a) 
     for (int ct = 0; ct < NCT; ++ct) acc[ct] = zero16();
     for (int q = 0; q < Q; ++q) {
         const int s = q / G::KU, u = q % G::KU;
-        issue_w(q + 1);
+        issue_w(q + L::NW - 1);
         if (u == 0) issue_rows(s + 2);
-        const uint8_t* w = slot_w(q & 1);
+        const uint8_t* w = slot_w(q % L::NW);
         const Frag<NS> b = tile_bfrag4<IO>(slot_t(s % 3), trow, h, u);
 #pragma unroll
         for (int g0 = 0; g0 < NCT; g0 += GB) {
@@ -121,7 +131,17 @@ __global__ __launch_bounds__(WAVES * 64) void visproj_fwd_kernel(VisprojArgs a) 
             for (int i = 0; i < GB; ++i) acc[g0 + i] = mfma_ns<NS>(wa[i], b, acc[g0 + i]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        wait_vm((u == 0 && s + 2 < S) ? 4 : 0);
+        // In flight, oldest first: weights of q+1 .. q+NW-1 (npw pieces each) with the row pieces of stage s+2 (4, issued
+        // right after the weights of q+NW-1 when u == 0) in between.  The next sub-stage needs the weights of q+1 and, when
+        // it starts a new row stage, rows issued a whole stage (KU sub-stages) ago -- older than everything kept here.
+        {
+            int keep = 0;
+            for (int j = 2; j <= L::NW - 1; ++j) if (q + j < Q) keep += npw;
+            // row pieces of stage s+2 were issued at u == 0 of this stage, after the weights of (first sub-stage of s) + NW - 1:
+            // they are younger than the weights of q+1 iff that sub-stage index is >= q+1, i.e. u <= NW - 2
+            if (s + 2 < S && u <= L::NW - 2) keep += 4;
+            wait_vm(keep);
+        }
         __builtin_amdgcn_s_barrier();
     }
 
@@ -193,6 +213,205 @@ __global__ __launch_bounds__(WAVES * 64) void visproj_fwd_kernel(VisprojArgs a) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Column-split form for d_out = 768 (the real shape): 8 waves = 4 row groups x 2 column halves.
+//
+// The 4-wave kernel above keeps all d_out / 32 = 24 accumulator tiles of its 32 rows in one wave: 384 of the 512
+// registers a lane of a SIMD has, and hipcc spills an accumulator tile INSIDE the sub-stage loop (75-180 registers in
+// all).  Scratch traffic retires in order with the LDS-DMA prefetches on vmcnt, so every reload waited for the weight
+// stream just requested: 1.9 us per 16-feature sub-stage against 0.37 us of MFMA issue -- 241 us per launch at
+// M = 18.7k, 10 % of the MFMA peak.  Here a wave owns 12 tiles (192 registers, two waves per SIMD, nothing spilled):
+// same rows per workgroup, same weight bytes per MFMA (the fragment stream is shared by the eight waves, the row
+// tile by the two halves of a row group), the LayerNorm statistics cross the two halves through LDS (two exchanges:
+// mean, then centred variance -- the reference's two-pass order).
+template <typename IO, int NCT>
+struct VisLds2 {
+    static constexpr int NS = Geo4<IO>::NS;
+    static constexpr int RGN = 4, CH = 2, WAVES = RGN * CH;
+    static constexpr int WSUB_B = NCT * NS * 1024;           // one 16-feature sub-stage of W (all d_out columns)
+    static constexpr int TILE_B = RGN * 32 * 128;
+    static constexpr int STAT_B = CH * RGN * 32 * 4;          // one float per row and column half
+    static constexpr int NW_MAX = (160 * 1024 - 3 * TILE_B - 3 * 32 * NCT * 4 - 2 * STAT_B - 1024) / WSUB_B;
+    static constexpr int NW = NW_MAX < 2 ? 2 : (NW_MAX > 6 ? 6 : NW_MAX);
+    static constexpr int ROW_OFF = NW * WSUB_B;
+    static constexpr int MAIN_B = ROW_OFF + 3 * TILE_B;
+    static constexpr int EPI_B = CH * 4 * TILE_B;             // per column half: R0, R1, OUT, XHAT tiles (alias the rings)
+    static constexpr int STAT_OFF = MAIN_B > EPI_B ? MAIN_B : EPI_B;
+    static constexpr int PARAM_OFF = STAT_OFF + 2 * STAT_B;
+    static size_t bytes(int d_out) { return (size_t)PARAM_OFF + (size_t)3 * d_out * 4; }
+};
+
+template <typename IO, int NCT>
+__global__ __launch_bounds__(512) void visproj_fwd2_kernel(VisprojArgs a) {
+    using G = Geo4<IO>;
+    using L = VisLds2<IO, NCT>;
+    constexpr int NS = G::NS;
+    constexpr int WAVES = L::WAVES, RGN = L::RGN;
+    constexpr int NCW = NCT / L::CH;             // accumulator tiles per wave
+    constexpr int GB = NCW < 6 ? NCW : 6;        // A fragments read per LDS burst
+    static_assert(NCW % GB == 0, "burst must divide the tiles of a wave");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rgi = wave % RGN, ch = wave / RGN;             // waves rgi and rgi + 4 (the two column halves of a row group) share a SIMD
+    const int m = lane & 31, h = lane >> 5;
+    const int trow = 32 * rgi + m;
+    const int F = a.F, d_out = 32 * NCT;
+    const int64_t row0_wave = (int64_t)blockIdx.x * (RGN * 32) + rgi * 32;
+    const int S = F / G::FE;
+    const int Q = S * G::KU;
+    const uint8_t* feats = reinterpret_cast<const uint8_t*>(a.feats);
+    const RowLanes rl = row_lanes<IO>(row0_wave, a.M, F, rgi, lane);
+    const RowLanes rlo = row_lanes<IO>(row0_wave, a.M, d_out, rgi, lane);
+    const int lane16 = lane * 16;
+
+    auto slot_w = [&](int j) { return smem + (size_t)j * L::WSUB_B; };
+    auto slot_t = [&](int j) { return smem + L::ROW_OFF + (size_t)j * L::TILE_B; };
+    float* sstat = reinterpret_cast<float*>(smem + L::STAT_OFF);    // [2 exchanges][CH][RGN * 32]
+    float* sp = reinterpret_cast<float*>(smem + L::PARAM_OFF);      // bias | gamma | beta
+    // the row tile of a row group is requested by its column-half-0 wave; the weight pieces by all eight waves
+    auto issue_rows = [&](int s2) { if (ch == 0 && s2 < S) glds_rows4(feats, rl, s2 * 128, slot_t(s2 % 3), rgi); };
+    constexpr int KBW = NCT * NS;
+    auto issue_w = [&](int q1) {
+        if (q1 >= Q) return;
+        const uint8_t* src0 = a.pk + (int64_t)q1 * L::WSUB_B;
+        uint8_t* dst = slot_w(q1 % L::NW);
+        for (int k = wave; k < KBW; k += WAVES) glds16(src0 + (size_t)k * 1024 + lane16, dst + (size_t)k * 1024);
+    };
+    const int npw = wave < KBW ? (KBW - wave + WAVES - 1) / WAVES : 0;     // weight pieces this wave issues per sub-stage
+    const int nrow = ch == 0 ? 4 : 0;                                        // row pieces this wave issues per stage
+
+#pragma unroll
+    for (int q0 = 0; q0 < L::NW - 1; ++q0) issue_w(q0);
+    issue_rows(0);
+    issue_rows(1);
+    {
+        const float* bias = reinterpret_cast<const float*>(a.pk + (int64_t)(F / 16) * NCT * NS * 1024);
+        for (int i = tid; i < d_out; i += WAVES * 64) {
+            sp[i] = bias[i];
+            sp[d_out + i] = a.gamma[i];
+            sp[2 * d_out + i] = a.beta ? a.beta[i] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NCW];
+#pragma unroll
+    for (int ct = 0; ct < NCW; ++ct) acc[ct] = zero16();
+    for (int q = 0; q < Q; ++q) {
+        const int s = q / G::KU, u = q % G::KU;
+        issue_w(q + L::NW - 1);
+        if (u == 0) issue_rows(s + 2);
+        const uint8_t* w = slot_w(q % L::NW);
+        const Frag<NS> b = tile_bfrag4<IO>(slot_t(s % 3), trow, h, u);
+#pragma unroll
+        for (int g0 = 0; g0 < NCW; g0 += GB) {
+            Frag<NS> wa[GB];
+#pragma unroll
+            for (int i = 0; i < GB; ++i) wa[i] = wfrag<NS>(w, ch * NCW + g0 + i, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < GB; ++i) acc[g0 + i] = mfma_ns<NS>(wa[i], b, acc[g0 + i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // (see visproj_fwd_kernel: what may stay in flight while the next sub-stage's weights and rows must have landed)
+        {
+            int keep = 0;
+            for (int j = 2; j <= L::NW - 1; ++j) if (q + j < Q) keep += npw;
+            if (s + 2 < S && u <= L::NW - 2) keep += nrow;
+            wait_vm(keep);
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- bias, LayerNorm statistics: this wave holds half of the row (lane + partner lane^32), the partner wave the rest
+    const float* bias = sp + 32 * NCW * ch + 8 * h;
+    const float* gam = sp + d_out + 32 * NCW * ch + 8 * h;
+    const float* bet = sp + 2 * d_out + 32 * NCW * ch + 8 * h;
+    float sum = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < NCW; ++ct) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc[ct][i] += bias[32 * ct + 16 * (i >> 3) + (i & 7)];
+            sum += acc[ct][i];
+        }
+    }
+    sum += __shfl_xor(sum, 32);
+    if (h == 0) sstat[ch * (RGN * 32) + trow] = sum;
+    __syncthreads();                              // (also: everyone is done with the rings before they are re-used)
+    sum += sstat[(1 - ch) * (RGN * 32) + trow];
+    const float mean = a.rms ? 0.f : sum / (float)d_out;
+    float sq = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < NCW; ++ct) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float t = acc[ct][i] - mean; sq += t * t; }
+    }
+    sq += __shfl_xor(sq, 32);
+    float* sstat2 = sstat + L::CH * RGN * 32;
+    if (h == 0) sstat2[ch * (RGN * 32) + trow] = sq;
+    __syncthreads();
+    sq += sstat2[(1 - ch) * (RGN * 32) + trow];
+    const float rstd = rsqrtf(sq / (float)d_out + a.eps);
+    if (a.rstd != nullptr && ch == 0 && h == 0 && row0_wave + m < a.M) a.rstd[row0_wave + m] = rstd;
+
+    // ---- epilogue in 128-byte chunks of this wave's half of the output row
+    constexpr int TPC = G::FE / 32;              // accumulator tiles per chunk
+    constexpr int NCHW = NCW / TPC;              // chunks per wave
+    uint8_t* ebase = smem + (size_t)ch * 4 * L::TILE_B;
+    uint8_t* tR[2] = {ebase, ebase + L::TILE_B};
+    uint8_t* tO = ebase + 2 * L::TILE_B;
+    uint8_t* tX = ebase + 3 * L::TILE_B;
+    const uint8_t* Rg = reinterpret_cast<const uint8_t*>(a.R);
+    uint8_t* Og = reinterpret_cast<uint8_t*>(a.out);
+    uint8_t* Xg = reinterpret_cast<uint8_t*>(a.xhat);
+    const int n_st = rlo.n_inst * (Xg ? 2 : 1);
+    const int c0 = ch * NCHW;                    // first chunk of this half
+    if (Rg) glds_rows4(Rg, rlo, c0 * 128, tR[0], rgi);
+#pragma unroll
+    for (int cl = 0; cl < NCHW; ++cl) {
+        if (Rg) {
+            if (cl + 1 < NCHW) glds_rows4(Rg, rlo, (c0 + cl + 1) * 128, tR[(cl + 1) & 1], rgi);
+            wait_vm((cl + 1 < NCHW ? 4 : 0) + (cl > 0 ? n_st : 0));
+        }
+#pragma unroll
+        for (int tl = 0; tl < TPC; ++tl) {
+            const int ct = cl * TPC + tl;
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                const int idx8 = (TPC == 2 ? 4 * tl : 0) + 2 * sh + h;
+                float xv[8], ov[8], rv[8];
+                if (Rg) get8<IO>(tR[cl & 1], trow, idx8, rv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 32 * ct + 16 * sh + j;            // (+ this half's offset and 8h folded into gam / bet)
+                    xv[j] = (acc[ct][8 * sh + j] - mean) * rstd;
+                    ov[j] = xv[j] * gam[c] + bet[c] + (Rg ? rv[j] : 0.f);
+                }
+                put8<IO>(tO, trow, idx8, ov);
+                if (Xg) put8<IO>(tX, trow, idx8, xv);
+            }
+        }
+        store_rows4(Og, rlo, (c0 + cl) * 128, tO, rgi, lane);
+        if (Xg) store_rows4(Xg, rlo, (c0 + cl) * 128, tX, rgi, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // staging tiles are re-written next chunk
+    }
+}
+
+template <typename IO, int NCT>
+static hipError_t launch_nct2(const VisprojArgs& a, hipStream_t stream) {
+    using L = VisLds2<IO, NCT>;
+    const size_t lds = L::bytes(a.d_out);
+    auto kern = visproj_fwd2_kernel<IO, NCT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int rows = L::RGN * 32;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + rows - 1) / rows)), dim3(512), lds, stream, a);
+    return hipGetLastError();
+}
+
 template <typename IO, int NCT>
 static hipError_t launch_nct(const VisprojArgs& a, hipStream_t stream) {
     constexpr int WAVES = 4;
@@ -212,7 +431,10 @@ static hipError_t launch_io(const VisprojArgs& a, hipStream_t stream) {
     switch (a.d_out) {
         case 64: return launch_nct<IO, 2>(a, stream);
         case 128: return launch_nct<IO, 4>(a, stream);
-        case 768: return launch_nct<IO, 24>(a, stream);
+        case 768: {
+            static const bool old_form = [] { const char* e = getenv("VLPET_K4_WAVES4"); return e != nullptr && atoi(e) != 0; }();
+            return old_form ? launch_nct<IO, 24>(a, stream) : launch_nct2<IO, 24>(a, stream);      // (VLPET_K4_WAVES4=1: A/B)
+        }
         default: return hipErrorInvalidValue;
     }
 }

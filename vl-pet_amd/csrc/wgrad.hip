@@ -579,11 +579,11 @@ static hipError_t launch_one(const WgradArgs& a, hipStream_t stream) {
         if (a.job[j].out_rows > rmax) rmax = a.job[j].out_rows;
         if (a.job[j].has_drop || a.job[j].ldp % 8 != 0 || a.job[j].ldx % 8 != 0) plain = false;
     }
-    // opt-in (VLPET_WGRAD_TR=1): same time as the identity-transpose kernel at M = 28k (89 vs 87 us) -- both are bound by
-    // the re-read of P per 64-column slice (L2 hit rate 24 %), not by the operand construction; kept as the base of the
-    // P-resident redesign
-    const char* tr_env = getenv("VLPET_WGRAD_TR");
-    const bool use_tr = tr_env != nullptr && atoi(tr_env) != 0;
+    // bf16, r <= 96, no dropout mask: the LDS transpose-read kernel (ds_read_b64_tr_b16 operands, no identity-MFMA
+    // transposes, no fp32 -> bf16 re-conversion).  Round 2, after the XCD-aware numbering: 83.0 vs 86.7 us at M = 28 k,
+    // and in the bench 96.6 vs 104.3 us per K1 call, 235 vs 279 us for the K4 weight gradient (16,415 vs 16,319 samples/s;
+    // profiles/r02_kbench_wgrad_variants.txt).  VLPET_WGRAD_TR=0 selects the identity-transpose kernel.
+    static const bool use_tr = [] { const char* e = getenv("VLPET_WGRAD_TR"); return e == nullptr || atoi(e) != 0; }();
     hipError_t e;
     if constexpr (std::is_same<IO, __bf16>::value && RT <= 3) {
         if (plain && use_tr) {
