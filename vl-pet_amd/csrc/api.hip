@@ -7,7 +7,7 @@
 #include <stdio.h>
 #include <vector>
 
-#define VLPET_VERSION 100
+#define VLPET_VERSION 200      // round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
