@@ -33,8 +33,8 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # HBM-side bytes per row of the K1 backward from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
 # with rocprofv3 --pmc in its own run at ONE size (M = 28,000, bf16, r = 96) -- bench.py scales them by the run's rows per
 # launch, so for the other task shapes they are an extrapolation (labelled as such in the line).
-PMC_TRAFFIC = {"source": "profiles/r01_pmc_traffic_k1_bwd.md", "measured_at_rows": 28000,
-               "bytes_per_row": {"k1_bwd_rows": 12175.0}}
+PMC_TRAFFIC = {"source": "profiles/r02_pmc_traffic_k1_bwd.md", "measured_at_rows": 28000,
+               "bytes_per_row": {"k1_bwd_rows": 11881.0, "k1_bwd_op": 20264.0}}
 IMAGE_TASKS = ["vqa", "gqa", "nlvr", "caption"]
 VIDEO_TASKS = ["tvqa", "how2qa", "tvc", "yc2c"]
 
@@ -354,6 +354,8 @@ def main():
         if "k1_bwd_op" in kernels and dom == "k1_bwd_rows":
             roof["op_frac"] = kernels["k1_bwd_op"]["hbm_frac"]          # the same bytes over rows + weight-gradient time
             roof["op_avg_us"] = kernels["k1_bwd_op"]["avg_us"]
+            if traffic:
+                roof["op_traffic"] = round(PMC_TRAFFIC["bytes_per_row"]["k1_bwd_op"] * a["rows"] / a["launches"])
         per_task = {t: TR.TASK_BATCH[t](args.batch) for t in tasks}
         enc_rows = {t: rank_batch(t) * (TR.TEXT_LEN[t] + (72 if t == "nlvr" else (64 if t in VIDEO_TASKS else 36))) for t in tasks}
         out = {

@@ -175,10 +175,10 @@ int vlpet_lora_delta_bwd(const void* dy, const void* x, const void* packed,
                          int64_t M, int d, int tiles, float scaling,
                          int io_dtype, vlpet_stream_t stream);
 
-/* Training form of K3 (as the K1 / K2 forms): the forward also leaves z = dropout(x) @ A^T  [M, 32*tiles] (IO dtype) in
- * `saved` (vlpet_lora_saved_bytes), and the backward neither re-reads x for the down projection nor regenerates the
- * dropout mask for it (x is still read once, by the weight gradient of A). */
-size_t vlpet_lora_saved_bytes(int64_t M, int tiles, int io_dtype);
+/* Training form of K3 (as the K1 / K2 forms): the forward also leaves z = dropout(x) @ A^T  [M, 32*tiles] (IO dtype) and
+ * the dropout mask it applied (1 bit per element) in `saved` (vlpet_lora_saved_bytes): the backward neither re-reads x
+ * for the down projection nor regenerates the mask (x is still read once, by the weight gradient of A). */
+size_t vlpet_lora_saved_bytes(int64_t M, int d, int tiles, int io_dtype);
 int vlpet_lora_delta_fwd_save(const void* x, const void* base, const void* packed,
                               const uint8_t* keep_mask, float p, uint64_t seed, uint8_t* keep_out, void* out,
                               void* saved, int64_t M, int d, int tiles, float scaling,

@@ -34,6 +34,7 @@ def main():
         nws = lib.vlpet_bwd_workspace_bytes(M, d, tiles, 0, io)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         da, db = torch.empty(r, d, device=dev), torch.empty(d, r, device=dev)
+        sv = torch.empty(lib.vlpet_lora_saved_bytes(M, d, tiles, io), dtype=torch.uint8, device=dev)
         for label, km, p in (("no dropout", None, 0.0), ("generator p=0.1", None, 0.1), ("byte mask p=0.1", keep, 0.1)):
             kp = km.data_ptr() if km is not None else None
             def fwd():
@@ -42,9 +43,17 @@ def main():
             def bwd():
                 rc = lib.vlpet_lora_delta_bwd(dy.data_ptr(), x.data_ptr(), pk.buf.data_ptr(), kp, p, 1234, dx.data_ptr(), da.data_ptr(),
                                               db.data_ptr(), r, ws.data_ptr(), nws, M, d, tiles, 0.5, io, st); assert rc == 0
+            def fwd_s():        # training form: z and the packed mask are left for the backward
+                rc = lib.vlpet_lora_delta_fwd_save(x.data_ptr(), base.data_ptr(), pk.buf.data_ptr(), kp, p, 1234, None, out.data_ptr(),
+                                                   sv.data_ptr(), M, d, tiles, 0.5, io, st); assert rc == 0
+            def bwd_s():
+                rc = lib.vlpet_lora_delta_bwd_saved(dy.data_ptr(), x.data_ptr(), sv.data_ptr(), pk.buf.data_ptr(), kp, p, 1234, dx.data_ptr(),
+                                                    da.data_ptr(), db.data_ptr(), r, ws.data_ptr(), nws, M, d, tiles, 0.5, io, st); assert rc == 0
             tf, tb = timeit(fwd), timeit(bwd)
+            tfs = timeit(fwd_s); tbs = timeit(bwd_s)
             print(f"r={r:4d} tiles={tiles} {label:18s}: fwd {tf:7.1f} us ({by/tf/1e3:7.1f} GB/s, frac {by/tf/1e3/8000:.3f})   "
-                  f"bwd rows+wgrad {tb:7.1f} us ({by/tb/1e3:7.1f} GB/s, frac {by/tb/1e3/8000:.3f})")
+                  f"bwd rows+wgrad {tb:7.1f} us ({by/tb/1e3:7.1f} GB/s, frac {by/tb/1e3/8000:.3f})   | training form: fwd {tfs:7.1f} us "
+                  f"(frac {by/tfs/1e3/8000:.3f}), bwd {tbs:7.1f} us (frac {by/tbs/1e3/8000:.3f})")
 
 
 if __name__ == "__main__":

@@ -84,7 +84,7 @@ extern "C" size_t vlpet_saved_bytes(int64_t M, int tiles, int io_dtype) {
     return 4 * saved_stride(M, tiles, io_dtype);
 }
 
-static const DropSpec NO_DROP = {nullptr, nullptr, 0, 0, 1.f};
+static const DropSpec NO_DROP = {nullptr, nullptr, nullptr, nullptr, 0, 0, 1.f};
 
 // p in [0, 1): explicit mask (keep_mask != NULL) or the in-kernel generator keyed by `seed`; p == 0: no dropout
 static int make_drop(const uint8_t* keep_mask, float p, uint64_t seed, uint8_t* keep_out, DropSpec* ds) {
@@ -120,6 +120,9 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
     a.pk_a = reinterpret_cast<const uint8_t*>(pk_a);
     a.pk_g = reinterpret_cast<const uint8_t*>(pk_g);
     a.drop = drop;
+    // K3 training form: the packed dropout mask goes into the saved block, right after z
+    if (saved && (flags & PET_ACT_IDENTITY) && drop_active(drop))
+        a.drop.bits_out = reinterpret_cast<uint8_t*>(saved) + saved_stride(M, tiles, io_dtype);
     a.M = M; a.d = d; a.RT = tiles;
     a.s2 = s2; a.sd = sd; a.gs = gs; a.flags = flags;
     a.save = saved; a.save_stride = (int64_t)saved_stride(M, tiles, io_dtype);
@@ -200,9 +203,9 @@ extern "C" int vlpet_lora_delta_fwd(const void* x, const void* base, const void*
                    PET_ACT_IDENTITY, io_dtype, stream);
 }
 
-extern "C" size_t vlpet_lora_saved_bytes(int64_t M, int tiles, int io_dtype) {
-    if (M <= 0 || !tiles_ok(tiles)) return 0;
-    return saved_stride(M, tiles, io_dtype);
+extern "C" size_t vlpet_lora_saved_bytes(int64_t M, int d, int tiles, int io_dtype) {
+    if (M <= 0 || d <= 0 || !tiles_ok(tiles)) return 0;
+    return saved_stride(M, tiles, io_dtype) + align256((size_t)M * (d / 8));      // z, then 1 bit per element of the mask
 }
 
 extern "C" int vlpet_lora_delta_fwd_save(const void* x, const void* base, const void* packed,
@@ -286,7 +289,11 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     b.dh = gate ? ws + w.dh : nullptr; b.dq = gate ? ws + w.dq : nullptr;
     b.pk_a = reinterpret_cast<const uint8_t*>(pk_a);
     b.pk_g = reinterpret_cast<const uint8_t*>(pk_g);
-    b.drop = drop; b.drop.keep_out = nullptr;
+    b.drop = drop; b.drop.keep_out = nullptr; b.drop.bits_out = nullptr;
+    if (saved && (flags & PET_ACT_IDENTITY) && drop_active(drop)) {        // the forward's packed mask instead of regenerating it
+        b.drop.bits = reinterpret_cast<const uint8_t*>(saved) + saved_stride(M, tiles, io_dtype);
+        b.drop.keep = nullptr;
+    }
     b.M = M; b.d = d; b.RT = tiles;
     b.s2 = s2; b.sd = sd; b.gs = gs; b.flags = flags;
     if (saved && !aligned16(saved)) return VLPET_E_ALIGN;

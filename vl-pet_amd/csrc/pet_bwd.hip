@@ -287,7 +287,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
             }
             Frag<NS> bA = cur.bA;
             if constexpr (DROP) {
-                const uint32_t kb = drop_bits8(a.drop, grow * d + s * G::FE + 16 * u + 8 * h);
+                const uint32_t kb = drop_bits8(a.drop, grow, s * G::FE + 16 * u + 8 * h, d);
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -598,9 +598,8 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         if (su == 5) BSTAMP(33);
         uint32_t kp[4] = {0, 0, 0, 0};
         if constexpr (DROP) {
-            const int64_t e0 = grow * d + su * G::FE + G::LW * h;
 #pragma unroll
-            for (int c = 0; c < G::LW / 8; ++c) kp[c] = drop_bits8(a.drop, e0 + 8 * c);
+            for (int c = 0; c < G::LW / 8; ++c) kp[c] = drop_bits8(a.drop, grow, su * G::FE + G::LW * h + 8 * c, d);
         }
 #pragma unroll
         for (int e = 0; e < G::E4; ++e) {

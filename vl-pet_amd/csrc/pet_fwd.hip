@@ -142,14 +142,16 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
         // k-step u (counted lgkmcnt waits; <= 8 fragment reads in flight), so LDS and the matrix pipe overlap.
         // (One burst of all 40 reads made hipcc emit lgkmcnt(0) before the first MFMA: reads, then MFMAs.)
         Frag<NS> bA[G::KU], bG[GATE ? G::KU : 1], wa[G::KU][RT], wg[GATE ? G::KU : 1][RT];
+        uint32_t kbw = 0;
         auto load_u = [&](int u) {
             bA[u] = tile_bfrag4<IO>(ta, trow, h, u);
             if constexpr (DROP) {
                 const bool live = row0_wave + m < a.M;
                 const int64_t grow = live ? row0_wave + m : a.M - 1;
-                const int64_t e0 = grow * d + s * G::FE + 16 * u + 8 * h;
-                const uint32_t kb = drop_bits8(a.drop, e0);
-                if (a.drop.keep_out != nullptr && live) drop_export8(a.drop.keep_out, e0, kb);
+                const int f0 = s * G::FE + 16 * u + 8 * h;
+                const uint32_t kb = drop_bits8(a.drop, grow, f0, d);
+                if (a.drop.keep_out != nullptr && live) drop_export8(a.drop.keep_out, grow * d + f0, kb);
+                kbw |= kb << (8 * u);                    // packed mask of this lane's KU groups of the stage (training form)
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -184,6 +186,14 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
         }
         mfma_u(G::KU - 1);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DROP) {
+            // the lane's KU mask bytes of this stage are contiguous in the packed layout (rng.h drop_pos): one store
+            if (a.drop.bits_out != nullptr && row0_wave + m < a.M) {
+                uint8_t* bp = a.drop.bits_out + (row0_wave + m) * (int64_t)(d >> 3) + drop_pos((s * G::FE + 8 * h) >> 3);
+                if constexpr (G::KU == 4) *reinterpret_cast<uint32_t*>(bp) = kbw;
+                else *reinterpret_cast<uint16_t*>(bp) = (uint16_t)kbw;
+            }
+        }
         if (s == 5) stamp(6);
         // next stage needs: its weights (issued first in this stage) and its rows (issued a stage earlier)
         if (a.dbg & 3) wait_vm(0); else wait_vm(rows_count(s + 2));

@@ -33,27 +33,36 @@ __device__ __forceinline__ uint32_t keep8(int64_t group, uint64_t seed, uint32_t
     return bits;
 }
 
-// Where a kernel's dropout mask comes from: an explicit 0/1 byte mask (keep != nullptr; "bring your own mask") or the
-// generator above (keep == nullptr, thr != 0).  Neither: no dropout (the kernels' DROP template flag is then false).
+// Where a kernel's dropout mask comes from: an explicit 0/1 byte mask (keep != nullptr; "bring your own mask"), the packed
+// mask an earlier kernel of the same call chain left behind (bits != nullptr: 1 bit per element, see drop_pos), or the
+// generator above (thr != 0).  None of them: no dropout (the kernels' DROP template flag is then false).
 struct DropSpec {
     const uint8_t* keep;     // [M, d] uint8, 1 = keep, or nullptr
     uint8_t* keep_out;       // forward only: optional [M, d] 0/1 export of the mask that was applied (parity tests)
+    const uint8_t* bits;     // [M, d/8] packed mask written by the forward (training form), or nullptr
+    uint8_t* bits_out;       // forward only: where to leave the packed mask for the backward, or nullptr
     uint64_t seed;
     uint32_t thr;            // drop iff 16-bit uniform < thr
     float keep_scale;        // 1 / (1 - p)
 };
-static inline bool drop_active(const DropSpec& s) { return s.keep != nullptr || s.thr != 0; }
+static inline bool drop_active(const DropSpec& s) { return s.keep != nullptr || s.bits != nullptr || s.thr != 0; }
 
-// keep flags of elements e0 .. e0+7 (e0 % 8 == 0) of the row-major tensor
-__device__ __forceinline__ uint32_t drop_bits8(const DropSpec& s, int64_t e0) {
+// Byte position, inside a row's d/8 mask bytes, of 8-element group G (elements 8G .. 8G+7).  Not the natural order: inside
+// every block of 8 groups the even groups come first -- lane (row, h) of the forward kernels owns groups 2u + h of a
+// 64-feature stage, so with this order its four mask bytes are one aligned dword (one store per stage instead of four).
+__host__ __device__ inline int drop_pos(int G) { return (G & ~7) + ((G & 1) << 2) + ((G >> 1) & 3); }
+
+// keep flags of elements f0 .. f0+7 (f0 % 8 == 0) of row `row` of the row-major [M, d] tensor
+__device__ __forceinline__ uint32_t drop_bits8(const DropSpec& s, int64_t row, int f0, int d) {
     if (s.keep != nullptr) {
-        const uint64_t kp = *reinterpret_cast<const uint64_t*>(s.keep + e0);
+        const uint64_t kp = *reinterpret_cast<const uint64_t*>(s.keep + row * d + f0);
         uint32_t bits = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) bits |= (((kp >> (8 * j)) & 0xff) ? 1u : 0u) << j;
         return bits;
     }
-    return keep8(e0 >> 3, s.seed, s.thr);
+    if (s.bits != nullptr) return s.bits[row * (int64_t)(d >> 3) + drop_pos(f0 >> 3)];
+    return keep8((row * d + f0) >> 3, s.seed, s.thr);
 }
 __device__ __forceinline__ void drop_export8(uint8_t* keep_out, int64_t e0, uint32_t bits) {
     uint64_t v = 0;

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_kernel(WgradArgs a) {
             if (has_drop) {
                 int64_t row = rb + m;
                 if (row >= r_end) row = r_end - 1;
-                kb = drop_bits8(drop, row * ldx + n0 + 16 * q + 8 * h);
+                kb = drop_bits8(drop, row, n0 + 16 * q + 8 * h, ldx);
             }
             xn[q] = raw_frag8<IO>(rx[q], valid, has_drop, kb, drop.keep_scale);
         }

@@ -428,7 +428,7 @@ class _LoraDeltaFn(torch.autograd.Function):
         mask = torch.empty(M, d, dtype=torch.uint8, device=xf.device) if (want_mask and p > 0) else None
         act = None
         if SAVE_ACTIVATIONS and any(ctx.needs_input_grad):      # training: z = dropout(x) A^T for the backward (see K1 / K2)
-            act = torch.empty(lib.vlpet_lora_saved_bytes(M, pk.tiles, io), dtype=torch.uint8, device=xf.device)
+            act = torch.empty(lib.vlpet_lora_saved_bytes(M, d, pk.tiles, io), dtype=torch.uint8, device=xf.device)
             rc = _timed("k3_fwd", M, lambda: lib.vlpet_lora_delta_fwd_save(
                 xf.data_ptr(), bf.data_ptr(), pk.buf.data_ptr(), _ptr(kf), float(p), int(seed), _ptr(mask), out.data_ptr(),
                 act.data_ptr(), M, d, pk.tiles, float(scaling), io, _stream()))
