@@ -776,7 +776,9 @@ bool pet_gate_bwd3_applies(const PetBwdArgs& a) {
     static const int force = [] { const char* e = getenv("VLPET_BWD3"); return e == nullptr ? -1 : atoi(e); }();
     if (force == 0) return false;
     if (!((a.flags & PET_GATE) && a.saved != nullptr && !drop_active(a.drop) && bwd3_rt_ok(a.RT))) return false;
-    return force == 1 || a.RT == 6;
+    // small M (a strong-scaled rank: a few thousand rows): both forms are latency chains of a handful of workgroups, and the
+    // two-pass one is the shorter (M = 3,500: 79 vs 88 us; M = 512: 74 vs 79 us; profiles/r02_kbench_two_pass_ab.txt)
+    return force == 1 || a.RT == 6 || a.M <= 4096;
 }
 
 template <typename IO, int RT, int RG>
