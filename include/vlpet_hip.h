@@ -130,6 +130,21 @@ int vlpet_adapter_gate_bwd_saved(int phases, const void* dy, const void* x1, con
                                  float delta_scale, float x2_scale, float gate_scale,
                                  int io_dtype, vlpet_stream_t stream);
 
+/* vlpet_adapter_gate_bwd_saved with an incoming residual-stream gradient:  dx1 = dx1_in + (gradient of the gate branch).
+ * x1 (the sublayer input) feeds both the gate and the sublayer tail LayerNorm(x1 + dropout(y))
+ * (my_transformers/modeling_bart.py:1196, 1259-1261); handing the tail's dx1 in here replaces the elementwise add
+ * autograd would launch for the two contributions.  The chain-split row kernel adds it in its epilogue (one more row
+ * stream of the gate-chain wave); the other forms run one extra pass.  dx1_in: [M, d] IO dtype, must not alias dx1.
+ * With phases, dx1 is complete after the call that carries bit 0 (previous split) or bit 1 (two-pass form). */
+int vlpet_adapter_gate_bwd_saved_acc(int phases, const void* dy, const void* x1, const void* x2, const void* saved,
+                                     const void* packed_a, const void* packed_g, const void* dx1_in, void* dx1, void* dx2,
+                                     float* dwd, float* dbd, float* dwu, float* dbu,
+                                     float* dwgd, float* dbgd, float* dwgu, float* dbgu,
+                                     int r, int rg, void* workspace, size_t workspace_bytes,
+                                     int64_t M, int d, int tiles, int gate_mode,
+                                     float delta_scale, float x2_scale, float gate_scale,
+                                     int io_dtype, vlpet_stream_t stream);
+
 /* ---- K2: parallel adapter (decoder cross-attention value path) ----------------------------
  * out = y + scale * up(gelu_new(down(x)))
  * replaces adapters/adapter_modeling.py:55-61 + adapters/adapter_controller.py:149-162 as called at

@@ -173,3 +173,54 @@ def test_k1_backward_transpose_read_wgrad_variant(monkeypatch):
     monkeypatch.setenv("VLPET_WGRAD_TR", "1")
     check(C.run_k1(torch.bfloat16, M=1000, d=768, r=96, rg=96, nh=4), torch.bfloat16)
     check(C.run_k1(torch.bfloat16, M=333, d=256, r=8, rg=16, nh=4), torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M", [1000, 8192 + 40])
+def test_k1_backward_accumulates_incoming_dx1(dtype, M):
+    """vlpet_adapter_gate_bwd_saved_acc: dx1 = dx1_in + gate-branch gradient, everything else unchanged.  M = 1000 takes
+    the two-pass form (one extra pass adds), M = 8232 the chain-split row kernel (adds in its epilogue, ragged last block)."""
+    import vlpet_amd.functional as F
+    from vlpet_amd import _lib
+    lib = _lib.load()
+    d, r, dev = 768, 96, "cuda"
+    g = torch.Generator(device=dev).manual_seed(11)
+    x1, x2, dy, dxin = (torch.randn(M, d, device=dev, generator=g).to(dtype) for _ in range(4))
+    mk = lambda *s: torch.randn(*s, device=dev, generator=g) * 0.05
+    W = [mk(r, d), mk(r), mk(d, r), mk(d), mk(r, d), mk(r), mk(d, r), mk(d)]
+    io, tiles = F._io_dtype(x2), F.rank_tiles(r)
+    pa = F.pack_pair([W[0]], [W[1]], W[2], W[3], io, tiles); pg = F.pack_pair([W[4]], [W[5]], W[6], W[7], io, tiles)
+    st = torch.cuda.current_stream().cuda_stream
+    nws = lib.vlpet_bwd_workspace_bytes(M, d, tiles, 1, io)
+    out = torch.empty_like(x2)
+    sv = torch.empty(lib.vlpet_saved_bytes(M, tiles, io), dtype=torch.uint8, device=dev)
+    assert lib.vlpet_adapter_gate_fwd_save(x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(), out.data_ptr(),
+                                           sv.data_ptr(), M, d, tiles, 1, 1.0, 1.0, 0.7, io, st) == 0
+    res = []
+    for acc in (False, True):
+        dx1 = torch.empty_like(x1); dx2 = torch.empty_like(x2)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        G = [torch.empty_like(w) for w in W]
+        common = [t.data_ptr() for t in G] + [r, r, ws.data_ptr(), nws, M, d, tiles, 1, 1.0, 1.0, 0.7, io, st]
+        if acc:
+            rc = lib.vlpet_adapter_gate_bwd_saved_acc(3, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(),
+                                                      pg.buf.data_ptr(), dxin.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), *common)
+        else:
+            rc = lib.vlpet_adapter_gate_bwd_saved(3, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(),
+                                                  pg.buf.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), *common)
+        assert rc == 0
+        torch.cuda.synchronize()
+        res.append([dx1.float(), dx2.float()] + [t.float() for t in G])
+    ref_dx1 = res[0][0] + dxin.float()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2          # bf16: the sum is rounded once in the kernel, twice in the reference
+    assert (res[1][0] - ref_dx1).abs().max().item() <= tol * ref_dx1.abs().max().item()
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert torch.equal(a, b)                            # dx2 and the eight weight / bias gradients are untouched
+    # aliasing dx1_in with dx1 is refused
+    dx1 = dxin.clone()
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    G = [torch.empty_like(w) for w in W]
+    rc = lib.vlpet_adapter_gate_bwd_saved_acc(3, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(),
+                                              pg.buf.data_ptr(), dx1.data_ptr(), dx1.data_ptr(), torch.empty_like(x2).data_ptr(),
+                                              *[t.data_ptr() for t in G], r, r, ws.data_ptr(), nws, M, d, tiles, 1, 1.0, 1.0, 0.7, io, st)
+    assert rc != 0

@@ -261,3 +261,44 @@ def test_apply_pet_wide_bottleneck(dtype, add, gs):
                 assert rel(p.grad, P[n].grad) <= (tol if dtype == torch.float32 else 2e-2), (n, split)
         finally:
             EP.SPLIT_WIDE_BOTTLENECK = False      # the default: fused 6-tile kernels
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_residual_gradient_handover_between_tail_and_k1(dtype):
+    """Encoder layer with the K1 -> K5 residual link on (the tail's dx1 is summed inside K1's backward kernel, no autograd
+    add) and off (plain autograd): same output, same gradients.  Rows = 5000: the chain-split row kernel's in-epilogue add."""
+    import copy
+    import vlpet_amd.host.bart as HB
+    torch.manual_seed(4)
+    cfg = HB.vlpet_config(encoder_layers=1, decoder_layers=1, vocab_size=300, dropout=0.0, attention_dropout=0.0,
+                          activation_dropout=0.0)
+    layer = HB.BartEncoderLayer(cfg)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.randn_like(p) * 0.03)
+    layer.cuda().train()
+    x = torch.randn(50, 100, 768, device="cuda").to(dtype)
+    dy = torch.randn(50, 100, 768, device="cuda").to(dtype)
+    import vlpet_amd.train as TR
+    if dtype == torch.bfloat16:
+        for p in layer.parameters():
+            if "adapter" not in "".join(n for n, q in layer.named_parameters() if q is p) and "gating" not in "".join(n for n, q in layer.named_parameters() if q is p) and "layer_norm" not in "".join(n for n, q in layer.named_parameters() if q is p):
+                p.data = p.data.to(dtype)
+    outs = []
+    for fuse in (True, False):
+        HB.FUSE_RESIDUAL_GRAD = fuse
+        try:
+            for p in layer.parameters():
+                p.grad = None
+            xi = x.clone().requires_grad_(True)
+            y = layer(xi)
+            y.backward(dy)
+            outs.append((y.detach().float(), xi.grad.float(), {n: p.grad.float().clone() for n, p in layer.named_parameters() if p.grad is not None}))
+        finally:
+            HB.FUSE_RESIDUAL_GRAD = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert (outs[0][1] - outs[1][1]).abs().max().item() <= tol * outs[1][1].abs().max().item()
+    for n in outs[1][2]:
+        a, b = outs[0][2][n], outs[1][2][n]
+        assert (a - b).abs().max().item() <= tol * max(b.abs().max().item(), 1e-6), n

@@ -266,7 +266,8 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
                    void* workspace, size_t workspace_bytes, int64_t M, int d, int tiles,
                    float s2, float sd, float gs, int flags, int io_dtype, vlpet_stream_t stream,
                    int phases = 3 /* bit0: row-parallel kernel, bit1: weight gradients */,
-                   const void* saved = nullptr /* vlpet_adapter_gate_fwd_save's block */) {
+                   const void* saved = nullptr /* vlpet_adapter_gate_fwd_save's block */,
+                   const void* dx1_in = nullptr /* gated K1: added to dxg (must not alias it) */) {
     int rc = check_common(M, d, tiles, io_dtype);
     if (rc) return rc;
     const bool gate = flags & PET_GATE;
@@ -283,7 +284,8 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
 
     PetBwdArgs b;
     b.dy = dy; b.xa = xa; b.res = res; b.xg = xg;
-    b.dxa = dxa; b.dxg = dxg;
+    b.dxa = dxa; b.dxg = dxg; b.dxg_in = nullptr;
+    if (dx1_in && (!gate || !aligned16(dx1_in) || dx1_in == dxg)) return VLPET_E_ALIGN;
     b.z_a = ws + w.z_a; b.dp_a = ws + w.dp_a;
     b.z_g = gate ? ws + w.z_g : nullptr; b.dp_g = gate ? ws + w.dp_g : nullptr;
     b.dh = gate ? ws + w.dh : nullptr; b.dq = gate ? ws + w.dq : nullptr;
@@ -305,12 +307,18 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     // two-pass form (pass 1: dpre only; pass 2: input gradients + weight gradients from recomputed dh / dq) unless the
     // caller needs the input gradients right after phase 1 (phases bit 2: weight gradients on a side stream)
     const bool two_pass = !(phases & 4) && pet_gate_bwd3_applies(b);
+    const bool rows2 = !two_pass && pet_gate_bwd2_applies(b);
     int gs3 = 0, ng3 = 0;
     if (phases & 1) {
+        if (rows2) b.dxg_in = dx1_in;                   // the chain-split row kernel adds it in its epilogue
         hipError_t e = two_pass ? launch_pet_gate_dz(b, io_dtype == VLPET_F32, (hipStream_t)stream)
-                     : pet_gate_bwd2_applies(b) ? launch_pet_gate_bwd2(b, io_dtype == VLPET_F32, (hipStream_t)stream)
-                                                : launch_pet_bwd(b, io_dtype == VLPET_F32, (hipStream_t)stream);
+                     : rows2 ? launch_pet_gate_bwd2(b, io_dtype == VLPET_F32, (hipStream_t)stream)
+                             : launch_pet_bwd(b, io_dtype == VLPET_F32, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
+        if (dx1_in && !two_pass && !rows2) {            // other row kernels: one more pass over dx1
+            e = launch_add_inplace(dxg, dx1_in, M * (int64_t)d, io_dtype == VLPET_F32, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     if (!(phases & 2)) return 0;
 
@@ -338,7 +346,11 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
         job(3, b.z_g, b.dq, false, 1.f, dwgu, rg, 1, rg, dbgu, nullptr);
         g.njobs = 4;
     }
-    if (two_pass) return herr(launch_pet_gate_cols(b, g, gs3, ng3, io_dtype == VLPET_F32, (hipStream_t)stream));
+    if (two_pass) {                                     // (dx1 is an output of pass 2 there)
+        hipError_t e = launch_pet_gate_cols(b, g, gs3, ng3, io_dtype == VLPET_F32, (hipStream_t)stream);
+        if (e == hipSuccess && dx1_in) e = launch_add_inplace(dxg, dx1_in, M * (int64_t)d, io_dtype == VLPET_F32, (hipStream_t)stream);
+        return herr(e);
+    }
     return herr(launch_wgrad(g, io_dtype == VLPET_F32, (hipStream_t)stream));
 }
 
@@ -395,6 +407,21 @@ extern "C" int vlpet_adapter_gate_bwd_saved(int phases, const void* dy, const vo
     return run_bwd(dy, x2, x2, x1, packed_a, packed_g, NO_DROP, dx2, dx1, dwd, dbd, dwu, dbu,
                    dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
                    x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream, phases & 7, saved);
+}
+
+extern "C" int vlpet_adapter_gate_bwd_saved_acc(int phases, const void* dy, const void* x1, const void* x2, const void* saved,
+                                                const void* packed_a, const void* packed_g, const void* dx1_in, void* dx1, void* dx2,
+                                                float* dwd, float* dbd, float* dwu, float* dbu,
+                                                float* dwgd, float* dbgd, float* dwgu, float* dbgu, int r, int rg,
+                                                void* workspace, size_t workspace_bytes, int64_t M, int d, int tiles,
+                                                int gate_mode, float delta_scale, float x2_scale, float gate_scale,
+                                                int io_dtype, vlpet_stream_t stream) {
+    int flags;
+    if (gate_flags(gate_mode, &flags)) return VLPET_E_SHAPE;
+    if (!dbd || !dbu || !saved || !dx1_in || !flags || (phases & 3) == 0) return VLPET_E_NULL;
+    return run_bwd(dy, x2, x2, x1, packed_a, packed_g, NO_DROP, dx2, dx1, dwd, dbd, dwu, dbu,
+                   dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
+                   x2_scale, delta_scale, gate_scale, flags, io_dtype, stream, phases & 7, saved, dx1_in);
 }
 
 extern "C" int vlpet_parallel_adapter_bwd(const void* dy, const void* x, const void* packed, void* dx,

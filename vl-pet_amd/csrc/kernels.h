@@ -52,6 +52,8 @@ struct PetBwdArgs {
     const void* xg;     // gate input
     void* dxa;          // K1: d/dx2 (includes the residual path); K2/K3: d/dx of the adapter branch only
     void* dxg;          // K1: d/dx1 of the gate branch
+    const void* dxg_in; // optional [M,d]: added to dxg (the residual-stream gradient of the sublayer tail: x1 feeds both the gate
+                        //   and the tail, and summing here saves autograd's separate add pass); may alias dxg
     // row-major side products consumed by the weight-gradient kernel (IO dtype)
     void* z_a; void* dp_a;      // [M, 32*RT] each
     void* z_g; void* dp_g;      // [M, 32*RT] each (gate)
@@ -208,6 +210,7 @@ struct AdamwArgs {
     const int32_t* slice_of;                       // optional [n]: parameter index of every element (per-parameter steps)
     const float* slice_bc;                         //   [n_slices][2]: 1 - b1^t, sqrt(1 - b2^t) per parameter; <= 0 = no grad this step
 };
+hipError_t launch_add_inplace(void* dst, const void* src, int64_t n, int io_fp32, hipStream_t stream);   // dst += src (IO dtype)
 hipError_t launch_sumsq(const float* g, int64_t n, float* partials, hipStream_t stream);
 hipError_t launch_adamw(const AdamwArgs& a, hipStream_t stream);
 int optim_blocks(int64_t n);

@@ -117,3 +117,28 @@ hipError_t launch_adamw(const AdamwArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(adamw_kernel<false>, dim3(optim_blocks(a.n)), dim3(OPT_THREADS), 0, stream, a);
     return hipGetLastError();
 }
+
+// dst += src over n IO-dtype elements (n % 8 == 0, 16-byte aligned): the fallback of the K1 backward's dx1 accumulation for
+// the kernel forms that do not add in their epilogue
+template <typename IO>
+__global__ __launch_bounds__(OPT_THREADS) void add_inplace_kernel(IO* dst, const IO* src, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n8; i += (int64_t)gridDim.x * OPT_THREADS) {
+        float a[8], b[8];
+        load8_f32(dst + 8 * i, a);
+        load8_f32(src + 8 * i, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[j];
+        store8_f32(dst + 8 * i, a);
+    }
+}
+hipError_t launch_add_inplace(void* dst, const void* src, int64_t n, int io_fp32, hipStream_t stream) {
+    const int64_t n8 = n / 8;
+    int64_t blocks = (n8 + OPT_THREADS - 1) / OPT_THREADS;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    if (io_fp32) hipLaunchKernelGGL(add_inplace_kernel<float>, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, stream,
+                                    reinterpret_cast<float*>(dst), reinterpret_cast<const float*>(src), n8);
+    else hipLaunchKernelGGL(add_inplace_kernel<__bf16>, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, stream,
+                            reinterpret_cast<__bf16*>(dst), reinterpret_cast<const __bf16*>(src), n8);
+    return hipGetLastError();
+}

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
     const uint8_t* dy = reinterpret_cast<const uint8_t*>(a.dy);
     uint8_t* DH = reinterpret_cast<uint8_t*>(a.dh);
     uint8_t* DQ = reinterpret_cast<uint8_t*>(a.dq);
+    const uint8_t* DXIN = reinterpret_cast<const uint8_t*>(a.dxg_in);     // optional: dx1 += the sublayer tail's residual gradient
 
     auto slot_w = [&](int j) { return smem + (size_t)j * L::W_B + (isA ? 0 : L::SEG_KB * 1024); };   // own segment
     auto slot_t0 = [&](int j) { return smem + L::ROW_OFF + (size_t)j * L::ROW_B; };
@@ -115,11 +116,12 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
         else glds_rows4(dy, rl, su * 128, slot_t1(su & 1), rg);
         return 4;
     };
-    // last-phase rows of block su: dh (chain A only) -> tile t0 of slot su % 3
+    // last-phase rows of block su: dh (chain A) -> tile t0 of slot su % 3; the incoming dx1 (chain G, optional) -> tile t1
     auto issue_last_rows = [&](int su) {
-        if (su >= S || !isA) return 0;
-        glds_rows4(DH, rl, su * 128, slot_t0(su % 3), rg);
-        return 4;
+        if (su >= S) return 0;
+        if (isA) { glds_rows4(DH, rl, su * 128, slot_t0(su % 3), rg); return 4; }
+        if (DXIN != nullptr) { glds_rows4(DXIN, rl, su * 128, slot_t1(su % 3), rg); return 4; }
+        return 0;
     };
 
 #ifdef VLPET_STAMPS
@@ -342,12 +344,14 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
 #pragma unroll
         for (int e = 0; e < G::E4; ++e) {
             float o8[8], dh8[8];
-            if (isA) tile_lane_vals8<IO>(tile, trow, h, e, dh8);
+            const bool add_in = !isA && DXIN != nullptr;
+            if (isA || add_in) tile_lane_vals8<IO>(tile, trow, h, e, dh8);        // A: dh;  G: the incoming dx1
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int i = 8 * e + j;
                 float v = ax[(i >> 4) % G::NV][i & 15];
                 if (isA) v += s2 * dh8[j];
+                else if (add_in) v += dh8[j];
                 o8[j] = v;
             }
             stage_lane_vals8<IO>(tile, trow, h, e, o8);

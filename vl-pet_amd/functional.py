@@ -213,11 +213,26 @@ def _finish(dests):
     return out
 
 
+class ResidualLink:
+    """Hand-over of the residual-stream gradient between the two ops that read the sublayer input x1: the gate of K1 and
+    the sublayer tail LayerNorm(x1 + dropout(y)) (my_transformers/modeling_bart.py:1196, 1259-1261).  Autograd would sum
+    their two contributions to d/dx1 with a separate elementwise pass over [M, d]; with a link the tail's backward (which
+    runs first: its output is downstream of K1's) parks its dx1 here and returns no gradient for x1, and K1's backward
+    adds it inside its kernel (vlpet_adapter_gate_bwd_saved_acc) and returns the sum.  Armed by K1's forward only when its
+    backward will take the hand-over (gated, saved-activation form)."""
+
+    __slots__ = ("armed", "dx1")
+
+    def __init__(self):
+        self.armed = False
+        self.dx1 = None
+
+
 class _AdapterGateFn(torch.autograd.Function):
     """K1.  inputs: x1, x2, then N_h down weights, N_h down biases, up w, up b, gate down w/b, gate up w/b."""
 
     @staticmethod
-    def forward(ctx, x1, x2, pk_a, pk_g, n_heads, gate_mode, delta_scale, x2_scale, gate_scale, *params):
+    def forward(ctx, x1, x2, pk_a, pk_g, n_heads, gate_mode, delta_scale, x2_scale, gate_scale, link, *params):
         lib = _lib.load()
         _need_cuda(x1, x2)
         d = x2.shape[-1]
@@ -242,6 +257,10 @@ class _AdapterGateFn(torch.autograd.Function):
                 io, _stream()))
         _lib.check(rc, "vlpet_adapter_gate_fwd")
         ctx.act = act
+        ctx.link = None
+        if link is not None and act is not None and gate_mode != GATE_NONE and x1.requires_grad:
+            link.armed = True                   # the tail that follows may park its dx1 for this op's backward
+            ctx.link = link
         ctx.save_for_backward(x1f if x1f is not None else x2f, x2f, *params)
         ctx.pk = (pk_a, pk_g)
         ctx.cfg = (n_heads, gate_mode, float(delta_scale), float(x2_scale), float(gate_scale), x2.shape,
@@ -281,7 +300,18 @@ class _AdapterGateFn(torch.autograd.Function):
         side = WGRAD_STREAM if all(s is not None for s in sinks) else None
         act = ctx.act
 
+        # the sublayer tail's residual-stream gradient, if it was handed over (ResidualLink): summed inside the kernel
+        dx1_in = None
+        if ctx.link is not None and ctx.link.dx1 is not None:
+            dx1_in, ctx.link.dx1 = ctx.link.dx1, None
+            if dx1_in.shape != x2f.shape or dx1_in.dtype != x2f.dtype or not dx1_in.is_contiguous():
+                dx1_in = dx1_in.reshape(x2f.shape).to(x2f.dtype).contiguous()
+        ctx.link = None
+
         def phase(ph, a):       # one or both halves of the backward, with or without the forward's saved activations
+            if act is not None and dx1_in is not None:
+                return lib.vlpet_adapter_gate_bwd_saved_acc(ph, a[0], a[1], a[2], act.data_ptr(), a[3], a[4], dx1_in.data_ptr(),
+                                                            *a[5:])
             if act is not None:
                 return lib.vlpet_adapter_gate_bwd_saved(ph, a[0], a[1], a[2], act.data_ptr(), *a[3:])
             return lib.vlpet_adapter_gate_bwd_phase(ph, *a)
@@ -324,19 +354,19 @@ class _AdapterGateFn(torch.autograd.Function):
             grads += _finish([(dwgd, s_gd, params[nh2 + 2]), (dbgd, s_gdb, params[nh2 + 3]),
                               (dwgu, s_gu, params[nh2 + 4]), (dbgu, s_gub, params[nh2 + 5])])
         gx1 = dx1.view(shp1) if gate else None
-        return (gx1, dx2.view(shp2), None, None, None, None, None, None, None, *grads)
+        return (gx1, dx2.view(shp2), None, None, None, None, None, None, None, None, *grads)
 
 
 def adapter_gate(x1, x2, down_w, down_b, up_w, up_b, gate_params, pk_a: PackedPair, pk_g: Optional[PackedPair],
-                 gate_mode=GATE_MUL, delta_scale=1.0, x2_scale=1.0, gate_scale=1.0):
+                 gate_mode=GATE_MUL, delta_scale=1.0, x2_scale=1.0, gate_scale=1.0, link: Optional[ResidualLink] = None):
     """Encoder granularity-controlled adapter (+ low-rank gate).  ``gate_params`` =
-    (gate_down_w, gate_down_b, gate_up_w, gate_up_b) or None."""
+    (gate_down_w, gate_down_b, gate_up_w, gate_up_b) or None.  ``link``: see ResidualLink."""
     params = list(down_w) + list(down_b) + [up_w, up_b]
     if gate_mode != GATE_NONE:
         params += list(gate_params)
     if x2.numel() == 0:
         return _empty_result(x2, params)
-    return _AdapterGateFn.apply(x1, x2, pk_a, pk_g, len(down_w), gate_mode, delta_scale, x2_scale, gate_scale, *params)
+    return _AdapterGateFn.apply(x1, x2, pk_a, pk_g, len(down_w), gate_mode, delta_scale, x2_scale, gate_scale, link, *params)
 
 
 class _ParallelAdapterFn(torch.autograd.Function):

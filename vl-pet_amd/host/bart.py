@@ -99,11 +99,27 @@ class HostLayerNorm(nn.LayerNorm):
         return F.layer_norm(x, self.normalized_shape, w, b, self.eps)
 
 
-def sublayer_tail(residual, h, norm, p, training):
+# K1's gate and the sublayer tail both read the sublayer input; with a link the tail's backward hands its d/dx1 to K1's
+# backward kernel instead of leaving the sum to an elementwise pass of autograd (functional.ResidualLink).  The CPU parity
+# harness of the test suite switches it off: its ops are plain autograd.
+FUSE_RESIDUAL_GRAD = True
+
+
+def _pet_then_tail(layer, which, residual, h, norm, p, training, config):
+    """``norm(residual + dropout(apply_pet(residual, h)))`` -- K1 followed by K5."""
+    if not FUSE_RESIDUAL_GRAD:
+        return sublayer_tail(residual, apply_pet(layer, which, residual, h, config), norm, p, training)
+    from ..functional import ResidualLink
+    link = ResidualLink()
+    y = apply_pet(layer, which, residual, h, config, link=link)
+    return sublayer_tail(residual, y, norm, p, training, link=link)
+
+
+def sublayer_tail(residual, h, norm, p, training, link=None):
     """K5: ``norm(residual + dropout(h))`` -- one fused HIP pass (vlpet_amd.tail); the parity / CPU-baseline harnesses
     swap this module attribute for an eager restatement."""
     from ..tail import sublayer_tail as _hip_tail
-    return _hip_tail(residual, h, norm, p, training)
+    return _hip_tail(residual, h, norm, p, training, link=link)
 
 
 def _linear(mod: nn.Linear, x):
@@ -113,6 +129,19 @@ def _linear(mod: nn.Linear, x):
     if b is not None and b.dtype != x.dtype:
         b = b.to(x.dtype)
     return F.linear(x, w, b)
+
+
+def _sdpa_ctx():
+    """Frozen-backbone attention = torch SDPA with its default backend choice; VLPET_SDPA = flash | efficient | math pins
+    one (an experiment switch for the host model, not part of the PET path)."""
+    import contextlib
+    import os
+    which = os.environ.get("VLPET_SDPA")
+    if not which:
+        return contextlib.nullcontext()
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+    return sdpa_kernel({"flash": SDPBackend.FLASH_ATTENTION, "efficient": SDPBackend.EFFICIENT_ATTENTION,
+                        "math": SDPBackend.MATH}[which])
 
 
 class BartAttention(nn.Module):
@@ -158,9 +187,10 @@ class BartAttention(nn.Module):
         k = _linear(self.k_proj, src)
         if kv is not None and self.attn_value_parallel_adapter is not None:
             v = self.attn_value_parallel_adapter(src, task, y=v)
-        out = F.scaled_dot_product_attention(self._shape(q, B), self._shape(k, B), self._shape(v, B),
-                                             attn_mask=attn_mask, is_causal=causal and attn_mask is None,
-                                             dropout_p=self.dropout if self.training else 0.0)
+        with _sdpa_ctx():
+            out = F.scaled_dot_product_attention(self._shape(q, B), self._shape(k, B), self._shape(v, B),
+                                                 attn_mask=attn_mask, is_causal=causal and attn_mask is None,
+                                                 dropout_p=self.dropout if self.training else 0.0)
         out = out.transpose(1, 2).reshape(B, L, self.embed_dim)
         return _linear(self.out_proj, out)
 
@@ -187,15 +217,16 @@ class BartEncoderLayer(nn.Module):
     def forward(self, hidden, attn_mask=None, task=None):
         residual = hidden
         h = self.self_attn(hidden, attn_mask=attn_mask, task=task)
-        if has_pet(self, "attn"):
-            h = apply_pet(self, "attn", residual, h, self.pet_config)             # K1
-        hidden = sublayer_tail(residual, h, self.self_attn_layer_norm, self.dropout, self.training)   # K5
+        if has_pet(self, "attn"):                                                   # K1 + K5
+            hidden = _pet_then_tail(self, "attn", residual, h, self.self_attn_layer_norm, self.dropout, self.training, self.pet_config)
+        else:
+            hidden = sublayer_tail(residual, h, self.self_attn_layer_norm, self.dropout, self.training)   # K5
         residual = hidden
         h = F.gelu(_linear(self.fc1, hidden))
         h = F.dropout(h, p=self.activation_dropout, training=self.training)
         h = _linear(self.fc2, h)
-        if has_pet(self, "ff"):
-            h = apply_pet(self, "ff", residual, h, self.pet_config)               # K1
+        if has_pet(self, "ff"):                                                     # K1 + K5
+            return _pet_then_tail(self, "ff", residual, h, self.final_layer_norm, self.dropout, self.training, self.pet_config)
         return sublayer_tail(residual, h, self.final_layer_norm, self.dropout, self.training)             # K5
 
 

@@ -26,11 +26,27 @@ from ..visual import Downsample, T5LayerNorm, VisualEmbedding
 from .bart import TASKS, _linear
 
 
-def sublayer_tail(residual, h, norm, p, training):
+# K1's gate and the sublayer tail both read the sublayer input; with a link the tail's backward hands its d/dx1 to K1's
+# backward kernel instead of leaving the sum to an elementwise pass of autograd (functional.ResidualLink).  The CPU parity
+# harness of the test suite switches it off: its ops are plain autograd.
+FUSE_RESIDUAL_GRAD = True
+
+
+def _pet_then_tail(layer, which, residual, h, norm, p, training, config):
+    """``norm(residual + dropout(apply_pet(residual, h)))`` -- K1 followed by K5."""
+    if not FUSE_RESIDUAL_GRAD:
+        return sublayer_tail(residual, apply_pet(layer, which, residual, h, config), norm, p, training)
+    from ..functional import ResidualLink
+    link = ResidualLink()
+    y = apply_pet(layer, which, residual, h, config, link=link)
+    return sublayer_tail(residual, y, norm, p, training, link=link)
+
+
+def sublayer_tail(residual, h, norm, p, training, link=None):
     """K5 (T5 form): ``residual + dropout(h)`` -- one fused HIP pass; harnesses swap this attribute for an eager
     restatement, exactly as for host.bart."""
     from ..tail import sublayer_tail as _hip_tail
-    return _hip_tail(residual, h, norm, p, training)
+    return _hip_tail(residual, h, norm, p, training, link=link)
 
 
 def vlt5_config(**over) -> SimpleNamespace:
@@ -163,8 +179,8 @@ class T5LayerSelfAttention(nn.Module):
 
     def forward(self, hidden, bias, task=None):
         y = self.SelfAttention(self.layer_norm(hidden), bias)
-        if not self.is_decoder and has_pet(self, "attn"):
-            y = apply_pet(self, "attn", hidden, y, self.config)                           # K1 (x1 = un-normalised stream)
+        if not self.is_decoder and has_pet(self, "attn"):                                 # K1 (x1 = un-normalised stream) + K5
+            return _pet_then_tail(self, "attn", hidden, y, None, self.p, self.training, self.config)
         return sublayer_tail(hidden, y, None, self.p, self.training)                      # K5
 
 
@@ -193,7 +209,7 @@ class T5LayerFF(nn.Module):
     def forward(self, hidden, task=None):
         y = self.DenseReluDense(self.layer_norm(hidden))
         if not self.is_decoder and has_pet(self, "ff"):
-            y = apply_pet(self, "ff", hidden, y, self.config)                             # K1
+            return _pet_then_tail(self, "ff", hidden, y, None, self.p, self.training, self.config)      # K1 + K5
         return sublayer_tail(hidden, y, None, self.p, self.training)
 
 

@@ -22,7 +22,7 @@ def _draw_seed() -> int:
 
 class _TailFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, x1, gamma, beta, eps, p, seed, norm, want_mask):
+    def forward(ctx, y, x1, gamma, beta, eps, p, seed, norm, want_mask, link=None):
         lib = _lib.load()
         _need_cuda(y, x1)
         d = y.shape[-1]
@@ -47,6 +47,7 @@ class _TailFn(torch.autograd.Function):
         _lib.check(rc, "vlpet_sublayer_tail_fwd")
         ctx.save_for_backward(h, mean, rstd, g32, gamma, beta)
         ctx.cfg = (float(p), seed, int(norm), y.shape, io)
+        ctx.link = link if (link is not None and link.armed) else None     # K1 upstream will add our dx1 in its kernel
         out = out.view(y.shape)
         if want_mask:
             ctx.mark_non_differentiable(mask)
@@ -81,11 +82,16 @@ class _TailFn(torch.autograd.Function):
                 dbeta = _grad_like(s[1], beta)
         dx1 = dx1.view(shape)
         dyv = dy.view(shape) if dy is not None else dx1
-        return dyv, dx1, dgamma, dbeta, None, None, None, None, None
+        gx1 = dx1
+        if ctx.link is not None:        # functional.ResidualLink: K1's backward (downstream of dy) returns the sum for x1
+            ctx.link.dx1 = dx1
+            gx1 = None
+            ctx.link = None
+        return dyv, gx1, dgamma, dbeta, None, None, None, None, None, None
 
 
 def sublayer_tail(x1: torch.Tensor, y: torch.Tensor, norm: Optional[torch.nn.Module], p: float = 0.0,
-                  training: bool = False, seed: Optional[int] = None, return_mask: bool = False):
+                  training: bool = False, seed: Optional[int] = None, return_mask: bool = False, link=None):
     """``norm(x1 + dropout(y, p))``; ``norm`` is an ``nn.LayerNorm`` (BART) or None (T5: plain residual add)."""
     p_eff = float(p) if training else 0.0
     if y.numel() == 0:
@@ -95,5 +101,5 @@ def sublayer_tail(x1: torch.Tensor, y: torch.Tensor, norm: Optional[torch.nn.Mod
     if seed is None:
         seed = _draw_seed() if p_eff > 0 else 0
     if norm is None:
-        return _TailFn.apply(y, x1, None, None, 0.0, p_eff, seed, 0, return_mask)
-    return _TailFn.apply(y, x1, norm.weight, norm.bias, norm.eps, p_eff, seed, 1, return_mask)
+        return _TailFn.apply(y, x1, None, None, 0.0, p_eff, seed, 0, return_mask, link)
+    return _TailFn.apply(y, x1, norm.weight, norm.bias, norm.eps, p_eff, seed, 1, return_mask, link)
