@@ -280,10 +280,9 @@ def test_residual_gradient_handover_between_tail_and_k1(dtype):
     x = torch.randn(50, 100, 768, device="cuda").to(dtype)
     dy = torch.randn(50, 100, 768, device="cuda").to(dtype)
     import vlpet_amd.train as TR
-    if dtype == torch.bfloat16:
-        for p in layer.parameters():
-            if "adapter" not in "".join(n for n, q in layer.named_parameters() if q is p) and "gating" not in "".join(n for n, q in layer.named_parameters() if q is p) and "layer_norm" not in "".join(n for n, q in layer.named_parameters() if q is p):
-                p.data = p.data.to(dtype)
+    for n, p in layer.named_parameters():          # the reference's trainable set for this layer; frozen weights in the IO dtype
+        p.requires_grad = ("adapter" in n) or ("gating" in n) or ("layer_norm" in n)
+    TR.cast_frozen(layer, dtype)
     outs = []
     for fuse in (True, False):
         HB.FUSE_RESIDUAL_GRAD = fuse

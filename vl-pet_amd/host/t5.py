@@ -29,7 +29,8 @@ from .bart import TASKS, _linear
 # K1's gate and the sublayer tail both read the sublayer input; with a link the tail's backward hands its d/dx1 to K1's
 # backward kernel instead of leaving the sum to an elementwise pass of autograd (functional.ResidualLink).  The CPU parity
 # harness of the test suite switches it off: its ops are plain autograd.
-FUSE_RESIDUAL_GRAD = True
+import os as _os
+FUSE_RESIDUAL_GRAD = _os.environ.get("VLPET_NO_LINK", "0") != "1"      # (VLPET_NO_LINK=1: plain autograd sums, for A/B)
 
 
 def _pet_then_tail(layer, which, residual, h, norm, p, training, config):
