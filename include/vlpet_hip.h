@@ -62,6 +62,13 @@ int vlpet_pack_pair(const void* const* wd_heads, const void* const* bd_heads, in
                     const void* wu, const void* bu, int r, int d, int tiles,
                     int param_dtype, int io_dtype, void* packed, vlpet_stream_t stream);
 
+/* n pairs of ONE geometry (same n_heads, r, d, tiles, dtypes; every pair with or without biases alike) in as few launches as
+ * possible (8 pairs per launch): wd_heads_flat / bd_heads_flat hold n * n_heads pointers (pair-major), wu / bu / packed n
+ * pointers.  What a trainer calls once per optimizer step for all its adapters instead of ~30 single packs. */
+int vlpet_pack_pairs(int n, const void* const* wd_heads_flat, const void* const* bd_heads_flat, int n_heads,
+                     const void* const* wu, const void* const* bu, int r, int d, int tiles,
+                     int param_dtype, int io_dtype, void* const* packed, vlpet_stream_t stream);
+
 /* ---- K1: encoder granularity-controlled adapter + gate ------------------------------------
  * out = ( x2_scale*x2 + delta_scale*up(gelu_new(down(x2))) ) (*|+) sigmoid(up_g(gelu_new(down_g(x1)))) * gate_scale
  * replaces my_transformers/modeling_bart.py:1147-1155,1195-1209,1256-1257 (attention sublayer),

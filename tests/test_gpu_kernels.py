@@ -224,3 +224,39 @@ def test_k1_backward_accumulates_incoming_dx1(dtype, M):
                                               pg.buf.data_ptr(), dx1.data_ptr(), dx1.data_ptr(), torch.empty_like(x2).data_ptr(),
                                               *[t.data_ptr() for t in G], r, r, ws.data_ptr(), nws, M, d, tiles, 1, 1.0, 1.0, 0.7, io, st)
     assert rc != 0
+
+
+def test_repack_all_matches_single_packs_and_makes_the_next_get_a_hit():
+    """functional.repack_all (vlpet_pack_pairs: several pairs per launch, into the existing buffers) == pack_pair byte for
+    byte, for every pair used in the step that just ended; pairs not used are left alone."""
+    import vlpet_amd.functional as F
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(5)
+    mk = lambda *s: torch.randn(*s, device=dev, generator=g) * 0.1
+    pairs = []
+    for nh, r, d in [(4, 96, 768)] * 11 + [(1, 96, 768)] * 3 + [(2, 16, 128)]:
+        rh = r // nh
+        pairs.append(([mk(rh, d) for _ in range(nh)], [mk(rh) for _ in range(nh)], mk(d, r), mk(d)))
+    caches = [F.PackCache() for _ in pairs]
+    stale = F.PackCache()
+    stale.get([mk(8, 64)], [mk(8)], mk(64, 8), mk(64), 1)                 # used two epochs ago: must not be touched
+    F.bump_weights_epoch()
+    for c, (dw, db, uw, ub) in zip(caches, pairs):
+        c.get(dw, db, uw, ub, 1)                                           # "forward" of the step
+    with torch.no_grad():                                                  # "optimizer": in-place update behind autograd's back
+        for dw, db, uw, ub in pairs:
+            for t in dw + db + [uw, ub]:
+                t.mul_(1.5).add_(0.01)
+                t._version  # (in-place ops bump versions; the fused optimizer does not -- both must work)
+    F.bump_weights_epoch()
+    stale_key = stale._key
+    n = F.repack_all()
+    assert n == len(pairs)
+    assert stale._key == stale_key
+    torch.cuda.synchronize()
+    for c, (dw, db, uw, ub) in zip(caches, pairs):
+        fresh = F.pack_pair(dw, db, uw, ub, 1)
+        buf_before = c._val.buf.data_ptr()
+        got = c.get(dw, db, uw, ub, 1)                                     # must be a hit: same buffer, no re-pack
+        assert got.buf.data_ptr() == buf_before
+        assert torch.equal(got.buf, fresh.buf)

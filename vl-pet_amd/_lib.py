@@ -25,6 +25,8 @@ SIGNATURES = {
     "vlpet_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vlpet_pack_pair": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_void_p, c_void_p]),
+    "vlpet_pack_pairs": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                 c_void_p, c_void_p]),
     "vlpet_adapter_gate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                        c_int, c_float, c_float, c_float, c_int, c_void_p]),
     "vlpet_saved_bytes": (c_size_t, [c_int64, c_int, c_int]),

@@ -66,6 +66,39 @@ extern "C" int vlpet_pack_pair(const void* const* wd_heads, const void* const* b
     return herr(launch_pack_pair(a, io_dtype == VLPET_F32 ? 2 : 1, (hipStream_t)stream));
 }
 
+extern "C" int vlpet_pack_pairs(int n, const void* const* wd_heads_flat, const void* const* bd_heads_flat, int n_heads,
+                                const void* const* wu, const void* const* bu, int r, int d, int tiles,
+                                int param_dtype, int io_dtype, void* const* packed, vlpet_stream_t stream) {
+    if (n <= 0) return 0;
+    if (!wd_heads_flat || !wu || !packed) return VLPET_E_NULL;
+    if (r <= 0 || d <= 0 || d % 64 != 0 || n_heads <= 0 || n_heads > VLPET_MAX_HEADS || r % n_heads != 0) return VLPET_E_SHAPE;
+    if (!tiles_ok(tiles) || r > 32 * tiles) return VLPET_E_RANK;
+    if (!dtype_ok(param_dtype) || !dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    for (int i0 = 0; i0 < n; i0 += VLPET_PACK_BATCH) {
+        PackBatch b;
+        b.n = n - i0 < VLPET_PACK_BATCH ? n - i0 : VLPET_PACK_BATCH;
+        for (int k = 0; k < b.n; ++k) {
+            PackArgs& a = b.p[k];
+            const int idx = i0 + k;
+            for (int i = 0; i < VLPET_MAX_HEADS; ++i) {
+                a.wd[i] = i < n_heads ? wd_heads_flat[(size_t)idx * n_heads + i] : nullptr;
+                a.bd[i] = (bd_heads_flat && i < n_heads) ? bd_heads_flat[(size_t)idx * n_heads + i] : nullptr;
+                if (i < n_heads && a.wd[i] == nullptr) return VLPET_E_NULL;
+            }
+            a.wu = wu[idx]; a.bu = bu ? bu[idx] : nullptr;
+            if (!a.wu || !packed[idx]) return VLPET_E_NULL;
+            if (!aligned16(packed[idx])) return VLPET_E_ALIGN;
+            a.n_heads = n_heads; a.rows_per_head = r / n_heads;
+            a.r = r; a.d = d; a.RT = tiles; a.src_bf16 = param_dtype == VLPET_BF16;
+            a.n_packs = 4;
+            a.out = reinterpret_cast<uint8_t*>(packed[idx]);
+        }
+        hipError_t e = launch_pack_pairs(b, io_dtype == VLPET_F32 ? 2 : 1, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
 static int check_common(int64_t M, int d, int tiles, int io_dtype) {
     if (M <= 0 || d <= 0 || d % 64 != 0) return VLPET_E_SHAPE;
     if (!tiles_ok(tiles)) return VLPET_E_RANK;

@@ -19,6 +19,9 @@ struct PackArgs {
     uint8_t* out;                      // packed pair (see pack_geom)
 };
 hipError_t launch_pack_pair(const PackArgs& a, int NS, hipStream_t stream);
+#define VLPET_PACK_BATCH 8
+struct PackBatch { PackArgs p[VLPET_PACK_BATCH]; int n; };      // pairs of one geometry (d, RT, n_packs, dtypes)
+hipError_t launch_pack_pairs(const PackBatch& b, int NS, hipStream_t stream);
 
 // flags
 #define PET_GATE 1        // chain G present: out = (res*s2 + sd*delta) (*|+) sigmoid(gate) * gs

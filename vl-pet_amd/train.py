@@ -451,6 +451,7 @@ class FusedAdamW:
                 self.bc_dev.data_ptr(), self.variant, 1, self.norm.data_ptr(), st)
             _lib.check(rc, "vlpet_adamw_step_sliced")
             VF.bump_weights_epoch()
+            VF.repack_all()        # the adapters' fragment packs for the next step: a few batched launches
             return
         rc = self.lib.vlpet_adamw_step(f.flat_p.data_ptr(), f.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                        self.decay.data_ptr(), n, self.partials.data_ptr(), self.nb, float(self.max_norm),
@@ -458,6 +459,7 @@ class FusedAdamW:
                                        self.betas[1], self.eps, self.wd, self.t, self.variant, 1, self.norm.data_ptr(), st)
         _lib.check(rc, "vlpet_adamw_step")
         VF.bump_weights_epoch()
+        VF.repack_all()            # the adapters' fragment packs for the next step: a few batched launches
 
 
 # Set by the test / CPU-baseline harness: factory(flat: FlatGrads, lr, max_norm) -> object with .step(lr).
