@@ -259,4 +259,7 @@ def test_repack_all_matches_single_packs_and_makes_the_next_get_a_hit():
         buf_before = c._val.buf.data_ptr()
         got = c.get(dw, db, uw, ub, 1)                                     # must be a hit: same buffer, no re-pack
         assert got.buf.data_ptr() == buf_before
-        assert torch.equal(got.buf, fresh.buf)
+        # the four packs + the two fp32 bias vectors; the buffer is rounded up to 256 bytes and the kernels leave the pad alone
+        written = 4 * (got.d // 16) * got.tiles * 1024 + 4 * (32 * got.tiles + got.d)
+        assert written <= got.buf.numel() < written + 256
+        assert torch.equal(got.buf[:written], fresh.buf[:written])

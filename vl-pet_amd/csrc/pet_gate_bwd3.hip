@@ -749,6 +749,438 @@ __global__ __launch_bounds__(NRG * 256) void pet_gate_cols_kernel(ColsArgs a) {
     }
 }
 
+// Accumulating MFMA with the accumulator pinned to the AGPR half of the register file.  The two-wave kernel below carries
+// 192 accumulator registers per wave; left to itself the register allocator keeps part of them in VGPRs / scratch and
+// shuttles them through the loop (measured: 219 spilled registers, ~90 scratch loads per tile).  Same-accumulator MFMAs
+// issued back to back need no wait states (exact vDst = SrcC overlap); nothing but the epilogue reads them otherwise.
+__device__ __forceinline__ void mfma32_acc(const bf16x8& a, const bf16x8& b, f32x16& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <int NS>
+__device__ __forceinline__ void mfma_ns_acc(const Frag<NS>& a, const Frag<NS>& b, f32x16& c) {
+    if constexpr (NS == 2) {
+        mfma32_acc(a.p[1], b.p[0], c);
+        mfma32_acc(a.p[0], b.p[1], c);
+    }
+    mfma32_acc(a.p[0], b.p[0], c);
+}
+
+// ================================================================================================== pass 2, two waves per tile
+// Same tile decomposition, but a row group is carried by TWO waves instead of four: the adapter-chain wave owns dWd and
+// dWu (+ h, dx2), the gate-chain wave dWgd and dWgu (+ g, dh / dq, dx1).  With four roles each wave sat idle through two of
+// the three phases of an iteration (the roles form a chain: projection -> h -> dh / dq -> dx2 / dWu / dWgu) and a
+// workgroup finished one tile per ~7 k cycles; with two roles a wave has work in every phase and a workgroup of four
+// waves (one per SIMD, the whole register file each: 192 accumulator registers + operands) carries two tiles at a time.
+template <typename IO, int RT, int NRG, int NBUF>
+__global__ __launch_bounds__(NRG * 128) void pet_gate_cols2_kernel(ColsArgs a) {
+    using G = Geo4<IO>;
+    using L = ColsLds<IO, NRG, NBUF>;
+    constexpr int IR = 32 * NRG;
+    constexpr int NS = G::NS, KT = 2 * RT, NV = G::NV, FE = G::FE, LW = G::LW;
+    constexpr int SEG_B = 4 * RT * 1024;
+    constexpr int PR = 32 * RT;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int b = blockIdx.x, xcd = b & 7, kq = b >> 3;
+    const int sg = kq % a.GS, unit = (kq / a.GS) * 8 + xcd;
+    const int rc = unit / a.NG, su = (unit % a.NG) * a.GS + sg;
+    if (rc >= a.wg.row_chunks) return;
+    const int64_t r_begin = (int64_t)rc * a.wg.rows_per_chunk;
+    if (r_begin >= a.M) return;
+    int64_t r_end = r_begin + a.wg.rows_per_chunk;
+    if (r_end > a.M) r_end = a.M;
+    const int n_it = (int)((r_end - r_begin + IR - 1) / IR);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave % NRG, chain = wave / NRG;                   // chain 0: adapter (A1 + A2), 1: gate (G1 + G2)
+    const bool isA = chain == 0;
+    const int m = lane & 31, h = lane >> 5;
+    const int lane16 = lane * 16;
+    const int d = a.d;
+    const PackGeom pg = pack_geom(RT, d, NS);
+
+    uint8_t* Wup = smem + (isA ? 0 : SEG_B);
+    uint8_t* Wdt = smem + 2 * SEG_B + (isA ? 0 : SEG_B);
+    uint8_t* rgb = smem + 4 * SEG_B + (size_t)rg * L::RG_B;
+    auto Tx2 = [&](int bf) { return rgb + (size_t)(0 * L::NBUF + bf) * L::TILE_B; };
+    auto Tdy = [&](int bf) { return rgb + (size_t)(1 * L::NBUF + bf) * L::TILE_B; };
+    auto Tx1 = [&](int bf) { return rgb + (size_t)(2 * L::NBUF + bf) * L::TILE_B; };
+    uint8_t* Tdh = rgb + (size_t)(3 * L::NBUF) * L::TILE_B;
+    uint8_t* Tdq = Tdh + L::TILE_B;
+    uint8_t* XHb = Tdq + L::TILE_B;
+    float* sbias = reinterpret_cast<float*>(smem + 4 * SEG_B + NRG * L::RG_B);
+
+    for (int k = wave; k < 16 * RT; k += 2 * NRG) {
+        const int blk = k / (4 * RT), piece = k % (4 * RT);
+        const uint8_t* pkx = (blk & 1) ? a.pk_g : a.pk_a;
+        const uint8_t* src = pkx + (int64_t)(blk < 2 ? 1 : 3) * pg.pack_bytes + (int64_t)su * SEG_B + (size_t)piece * 1024;
+        glds16(src + lane16, smem + (size_t)blk * SEG_B + (size_t)piece * 1024);
+    }
+    for (int i = tid; i < 2 * FE; i += NRG * 128) {
+        const uint8_t* pkx = i < FE ? a.pk_a : a.pk_g;
+        sbias[i] = reinterpret_cast<const float*>(pkx + pg.bias_off)[PR + su * FE + (i % FE)];
+    }
+
+    bf16x8 I0, I1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        I0[j] = (m == 8 * h + j) ? (__bf16)1.0f : (__bf16)0.0f;
+        I1[j] = (m == 16 + 8 * h + j) ? (__bf16)1.0f : (__bf16)0.0f;
+    }
+    // chain A: x tile = x2, P rows = dpre_a (job 0) and z_a (job 1); chain G: x tile = x1 (+ the dy tile), dpre_g (job 2), z_g (job 3)
+    const uint8_t* Xsrc = reinterpret_cast<const uint8_t*>(isA ? a.x2 : a.x1);
+    const uint8_t* Ysrc = reinterpret_cast<const uint8_t*>(a.dy);
+    const IO* Pdp = reinterpret_cast<const IO*>(isA ? a.dp_a : a.dp_g);
+    const IO* Pz = reinterpret_cast<const IO*>(isA ? a.z_a : a.z_g);
+    uint8_t* dxo = reinterpret_cast<uint8_t*>(isA ? a.dx2 : a.dx1);
+    const float s2 = a.s2, sd_ = a.sd, gs = a.gs;
+    const bool gate_add = (a.flags & PET_GATE_ADD) != 0;
+
+    f32x16 accD[RT][NV], accU[RT][NV];           // down-weight job (P = dpre), up-weight job (P = z)
+    float cspD[RT], cspU[RT], csxD[NV], csxU[NV];
+#pragma unroll
+    for (int ct = 0; ct < RT; ++ct) {
+        cspD[ct] = cspU[ct] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NV; ++nt) { accD[ct][nt] = zero16(); accU[ct][nt] = zero16(); }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NV; ++nt) csxD[nt] = csxU[nt] = 0.f;
+
+    uint32_t voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tr = 8 * i + (lane >> 3);
+        voff[i] = (uint32_t)tr * (uint32_t)(d * (int)sizeof(IO)) + (uint32_t)(((lane & 7) ^ swz(tr)) * 16);
+    }
+    auto load_tile = [&](const uint8_t* src, int64_t row0t, uint8_t* dst) {
+        if (row0t + 32 <= a.M) {
+            const uint8_t* base = src + row0t * d * (int64_t)sizeof(IO) + su * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(base + voff[i], dst + i * 1024);
+        } else {
+            const RowLanes rl = row_lanes<IO>(row0t, a.M, d, 0, lane);
+            glds_rows4(src, rl, su * 128, dst, 0);
+        }
+    };
+    auto issue_tiles = [&](int it) {                                 // A: x2;  G: x1 and dy
+        if (it >= n_it) return 0;
+        const int64_t row0t = r_begin + (int64_t)it * IR + 32 * rg;
+        if (isA) { load_tile(Xsrc, row0t, Tx2(it % NBUF)); return 4; }
+        load_tile(Xsrc, row0t, Tx1(it % NBUF));
+        load_tile(Ysrc, row0t, Tdy(it % NBUF));
+        return 8;
+    };
+    auto store_tile = [&](uint8_t* base_out, int64_t row0t, const uint8_t* tile) {
+        if (row0t + 32 <= a.M) {
+            uint8_t* base = base_out + row0t * d * (int64_t)sizeof(IO) + su * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(tile + ((size_t)(8 * i + (lane >> 3)) * 8 + (lane & 7)) * 16);
+                *reinterpret_cast<u32x4*>(base + voff[i]) = v;
+            }
+            return 4;
+        }
+        const RowLanes rl = row_lanes<IO>(row0t, a.M, d, 0, lane);
+        store_rows4(base_out, rl, su * 128, tile, 0, lane);
+        return rl.n_inst;
+    };
+    // P rows of the tile in registers, re-loaded IN PLACE for the next tile right after their last use (a second register set
+    // for the next iteration does not fit beside the 192 accumulator registers)
+    Frag<NS> pdp[KT], pz[KT];
+    auto load_p = [&](int it, const IO* P, Frag<NS>* dst) {
+        int64_t row = r_begin + (int64_t)it * IR + 32 * rg + m;
+        if (row >= r_end) row = r_end - 1;
+        const IO* p0 = P + row * (int64_t)PR + 8 * h;
+        const bool ok = r_begin + (int64_t)it * IR + 32 * rg + m < r_end;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) { const Frag<NS> f = load_frag8(p0 + 16 * ks); dst[ks] = ok ? f : zero_frag<NS>(); }
+    };
+    // down job: the column sums of P (= bias gradient of the down projection) are wanted; up job: those of X (dh / dq)
+    auto accumulate = [&](const Frag<NS>* xn, const Frag<NS>* pp, f32x16 (&acc)[RT][NV], float* csp, float* csx, auto want_p) {
+        constexpr bool WP = decltype(want_p)::value;
+        Frag<NS> xt[NV][2];
+#pragma unroll
+        for (int nt = 0; nt < NV; ++nt) {
+            const f32x16 t = transpose32<NS>(xn[2 * nt], xn[2 * nt + 1], I0, I1);
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { v[i] = t[i]; if constexpr (!WP) csx[nt] += t[i]; }
+            xt[nt][0] = frag_from_f32<NS>(v);
+            xt[nt][1] = frag_from_f32<NS>(v + 8);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct) {
+            const f32x16 t = transpose32<NS>(pp[2 * ct], pp[2 * ct + 1], I0, I1);
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { v[i] = t[i]; if constexpr (WP) csp[ct] += t[i]; }
+            const Frag<NS> pt0 = frag_from_f32<NS>(v), pt1 = frag_from_f32<NS>(v + 8);
+#pragma unroll
+            for (int nt = 0; nt < NV; ++nt) mfma_ns_acc<NS>(pt0, xt[nt][0], acc[ct][nt]);
+#pragma unroll
+            for (int nt = 0; nt < NV; ++nt) mfma_ns_acc<NS>(pt1, xt[nt][1], acc[ct][nt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto tile_frags = [&](const uint8_t* tile, bool valid, Frag<NS>* xn) {
+#pragma unroll
+        for (int u = 0; u < G::KU; ++u) {
+            const Frag<NS> f = tile_bfrag4<IO>(tile, m, h, u);
+            xn[u] = valid ? f : zero_frag<NS>();
+        }
+    };
+    auto project = [&](const uint8_t* w, const Frag<NS>* pp, f32x16* out) {
+        Frag<NS> cur[NV], nxt[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) cur[v] = wfrag<NS>(w, v * KT, lane);
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+            if (ks + 1 < KT) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) nxt[v] = wfrag<NS>(w, v * KT + ks + 1, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) out[v] = mfma_ns<NS>(cur[v], pp[ks], out[v]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < KT) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) cur[v] = nxt[v];
+            }
+        }
+    };
+
+#pragma unroll
+    for (int k = 0; k < NBUF - 1; ++k) issue_tiles(k);
+    load_p(0, Pdp, pdp);
+    load_p(0, Pz, pz);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const float* bb = sbias + (isA ? 0 : FE) + LW * h;
+    // one loop per chain (the two chains share nothing but the barriers): with both in one loop body every accumulator is a
+    // phi of the two branches at each phase and the register allocator copies / spills them
+    auto run = [&](auto chain_a) {
+    constexpr bool CA = decltype(chain_a)::value;
+    for (int it = 0; it < n_it; ++it) {
+        const int bf = it % NBUF;
+        const int64_t row0 = r_begin + (int64_t)it * IR + 32 * rg;
+        const bool valid = row0 + m < r_end;
+        const int n_tile = issue_tiles(it + NBUF - 1);
+        int n_store = 0;
+        Frag<1> gqp[NS == 1 ? LW / 8 : 1];
+        float gqf[NS == 1 ? 1 : LW];
+
+        // ================= phase 1: both up projections; A hands h over; the weight gradients that need no dh / dq; G's dx1
+        {
+            f32x16 au[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 tb = *reinterpret_cast<const f32x4*>(bb + 16 * v + 4 * q);
+                    au[v][4 * q] = tb[0]; au[v][4 * q + 1] = tb[1]; au[v][4 * q + 2] = tb[2]; au[v][4 * q + 3] = tb[3];
+                }
+            }
+            project(Wup, pz, au);
+            if constexpr (CA) {
+                const uint8_t* tx = Tx2(bf);
+#pragma unroll
+                for (int e = 0; e < G::E4; ++e) {
+                    float r8[8];
+                    tile_lane_vals8<IO>(tx, m, h, e, r8);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        f32x4 t;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int i = 8 * e + 4 * q + j;
+                            t[j] = s2 * r8[4 * q + j] + sd_ * au[(i >> 4) % NV][i & 15];
+                        }
+                        *reinterpret_cast<f32x4*>(XHb + (size_t)(2 * e + q) * 1024 + lane16) = t;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < LW; ++i) {
+                    const float gv = sigmoid_f(au[(i >> 4) % NV][i & 15]);
+                    if constexpr (NS == 1) gqp[i >> 3].p[0][i & 7] = (__bf16)gv; else gqf[i] = gv;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // B1: h is in the exchange buffer
+
+        // ================= phase 2: G: dh, dq of the tile;  A: dWd = dpre_a^T x2 (independent of dh)
+        if constexpr (CA) {
+            Frag<NS> xn[G::KU];
+            tile_frags(Tx2(bf), valid, xn);
+            accumulate(xn, pdp, accD, cspD, csxD, std::true_type{});
+        } else {
+            const uint8_t* ty = Tdy(bf);
+#pragma unroll
+            for (int e = 0; e < G::E4; ++e) {
+                float dy8[8], dh8[8], dq8[8], hx[8];
+                tile_lane_vals8<IO>(ty, m, h, e, dy8);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(XHb + (size_t)(2 * e + q) * 1024 + lane16);
+                    hx[4 * q] = t[0]; hx[4 * q + 1] = t[1]; hx[4 * q + 2] = t[2]; hx[4 * q + 3] = t[3];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float gt;
+                    if constexpr (NS == 1) gt = (float)gqp[e].p[0][j]; else gt = gqf[8 * e + j];
+                    const float dyp = gs * dy8[j];
+                    if (gate_add) {
+                        dh8[j] = dyp;
+                        dq8[j] = dyp * gt * (1.0f - gt);
+                    } else {
+                        dh8[j] = dyp * gt;
+                        dq8[j] = dh8[j] * hx[j] * (1.0f - gt);
+                    }
+                }
+                stage_lane_vals8<IO>(Tdh, m, h, e, dh8);
+                stage_lane_vals8<IO>(Tdq, m, h, e, dq8);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // B2: the dh / dq tiles are complete
+
+        // ================= phase 3: A: dx2, dWu;  G: dWgd, dx1, dWgu
+        if constexpr (CA) {
+            {
+                Frag<NS> xn[G::KU];
+                tile_frags(Tdh, valid, xn);
+                accumulate(xn, pz, accU, cspU, csxU, std::false_type{});
+            }
+            load_p(it + 1, Pz, pz);
+            f32x16 ax[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) ax[v] = zero16();
+            project(Wdt, pdp, ax);
+            load_p(it + 1, Pdp, pdp);
+            uint8_t* tile = Tx2(bf);
+#pragma unroll
+            for (int e = 0; e < G::E4; ++e) {
+                float o8[8], dh8[8];
+                tile_lane_vals8<IO>(Tdh, m, h, e, dh8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int i = 8 * e + j; o8[j] = ax[(i >> 4) % NV][i & 15] + s2 * dh8[j]; }
+                stage_lane_vals8<IO>(tile, m, h, e, o8);
+            }
+            n_store = store_tile(dxo, row0, tile);
+        } else {
+            {
+                Frag<NS> xn[G::KU];
+                tile_frags(Tdq, valid, xn);
+                accumulate(xn, pz, accU, cspU, csxU, std::false_type{});
+            }
+            load_p(it + 1, Pz, pz);
+            {
+                Frag<NS> xn[G::KU];
+                tile_frags(Tx1(bf), valid, xn);
+                accumulate(xn, pdp, accD, cspD, csxD, std::true_type{});
+            }
+            f32x16 ax[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) ax[v] = zero16();
+            project(Wdt, pdp, ax);
+            uint8_t* tile = Tx1(bf);
+#pragma unroll
+            for (int e = 0; e < G::E4; ++e) {
+                float o8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int i = 8 * e + j; o8[j] = ax[(i >> 4) % NV][i & 15]; }
+                stage_lane_vals8<IO>(tile, m, h, e, o8);
+            }
+            load_p(it + 1, Pdp, pdp);
+            n_store = store_tile(dxo, row0, tile);
+        }
+        // in order on vmcnt, oldest first: tiles of it+NBUF-1, z rows of it+1, dpre rows of it+1, output stores.  The next
+        // iteration needs the tiles of it+1 (this iteration's when NBUF = 2, the previous one's otherwise); the register loads
+        // are waited for by the compiler's own counters at their first use.
+        if constexpr (NBUF > 2) wait_vm(n_tile + 2 * KT * NS + n_store);
+        else wait_vm(2 * KT * NS + n_store);
+        __builtin_amdgcn_s_barrier();                                // B3
+    }
+
+    };
+    if (isA) run(std::true_type{}); else run(std::false_type{});
+
+    // ---- reduce the row groups (fixed order) and emit this chunk's partials: jobs 2*chain (down) and 2*chain + 1 (up)
+    constexpr int NVAL = RT * NV * 16 + RT + NV;
+    __syncthreads();
+    float* redD = reinterpret_cast<float*>(smem) + (size_t)(2 * chain) * NVAL * 64;
+    float* redU = redD + (size_t)NVAL * 64;
+    auto spill_out = [&](float* red, f32x16 (&acc)[RT][NV], float* csp, float* csx) {
+        int k = 0;
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < NV; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) red[(k++) * 64 + lane] = acc[ct][nt][i];
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct) red[(k++) * 64 + lane] = csp[ct];
+#pragma unroll
+        for (int nt = 0; nt < NV; ++nt) red[(k++) * 64 + lane] = csx[nt];
+    };
+    auto add_in = [&](const float* red, f32x16 (&acc)[RT][NV], float* csp, float* csx) {
+        int k = 0;
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < NV; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[ct][nt][i] += red[(k++) * 64 + lane];
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct) csp[ct] += red[(k++) * 64 + lane];
+#pragma unroll
+        for (int nt = 0; nt < NV; ++nt) csx[nt] += red[(k++) * 64 + lane];
+    };
+    auto emit = [&](int job, f32x16 (&acc)[RT][NV], float* csp, float* csx) {
+        const int xc = d, RC = a.wg.row_chunks, n0 = su * FE;
+        float* part = a.wg.partial + (int64_t)job * RC * ((int64_t)PR * xc + xc + PR);
+        float* tile = part + (int64_t)rc * PR * xc;
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < NV; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int crow = 32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    tile[(int64_t)crow * xc + n0 + 32 * nt + m] = acc[ct][nt][i];
+                }
+        float* psx = part + (int64_t)RC * PR * xc + (int64_t)rc * xc;
+#pragma unroll
+        for (int nt = 0; nt < NV; ++nt) {
+            const float v = csx[nt] + __shfl_xor(csx[nt], 32);
+            if (h == 0) psx[n0 + 32 * nt + m] = v;
+        }
+        if (su == 0) {
+            float* psp = part + (int64_t)RC * PR * xc + (int64_t)RC * xc + (int64_t)rc * PR;
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct) {
+                const float v = csp[ct] + __shfl_xor(csp[ct], 32);
+                if (h == 0) psp[32 * ct + m] = v;
+            }
+        }
+    };
+    if constexpr (NRG > 1) {
+        static_assert(NRG == 2, "two row groups per workgroup");
+        if (rg == 1) { spill_out(redD, accD, cspD, csxD); spill_out(redU, accU, cspU, csxU); }
+        __syncthreads();
+        if (rg == 0) { add_in(redD, accD, cspD, csxD); add_in(redU, accU, cspU, csxU); }
+    }
+    if (rg == 0) {
+        emit(2 * chain, accD, cspD, csxD);
+        emit(2 * chain + 1, accU, cspU, csxU);
+    }
+}
+
 // ================================================================================================== host side
 void gate_bwd3_plan(int64_t M, int d, int io_fp32, int* row_chunks, int64_t* rows_per_chunk, int* GS, int* NG) {
     const int S = d / (io_fp32 ? 32 : 64);
@@ -828,8 +1260,27 @@ static hipError_t launch_cols_cfg(const ColsArgs& c, hipStream_t stream) {
 // behind the tile prefetches; 4 waves (one per SIMD, no spill, P rows prefetched) take 189 us whether the tiles run one or
 // two iterations ahead, i.e. the pass is bound by the three-phase dependency chain of an iteration (~7k cycles per 32 rows),
 // not by memory.  Kept: the 4-wave shape (r > 32) and the 8-wave shape where it does not spill (r <= 32).
+template <typename IO, int RT, int NRG, int NBUF>
+static hipError_t launch_cols2_cfg(const ColsArgs& c, hipStream_t stream) {
+    const size_t lds = ColsLds<IO, NRG, NBUF>::bytes(RT);
+    auto kern = pet_gate_cols2_kernel<IO, RT, NRG, NBUF>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int units = c.NG * c.wg.row_chunks;
+    const unsigned grid = 8u * (unsigned)c.GS * (unsigned)((units + 7) / 8);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NRG * 128), lds, stream, c);
+    return hipGetLastError();
+}
+
 template <typename IO, int RT>
 static hipError_t launch_cols_one(const ColsArgs& c, hipStream_t stream) {
+    // VLPET_BWD3_FORM: 0 = four roles per row group (4 waves, one tile at a time); 1 (default for r <= 96) = two waves per row
+    // group, two row groups per workgroup
+    static const int form = [] { const char* e = getenv("VLPET_BWD3_FORM"); return e ? atoi(e) : 1; }();
+    if constexpr (RT == 3) {
+        if (form == 1) return launch_cols2_cfg<IO, RT, 2, 3>(c, stream);
+        if (form == 2) return launch_cols2_cfg<IO, RT, 2, 2>(c, stream);
+    }
     if constexpr (RT == 6) {
         return launch_cols_cfg<IO, RT, 1, 2, false>(c, stream);     // 96 KiB of weight fragments: room for two tile buffers
     } else if constexpr (RT == 1) {
