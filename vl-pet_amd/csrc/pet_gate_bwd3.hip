@@ -749,22 +749,6 @@ __global__ __launch_bounds__(NRG * 256) void pet_gate_cols_kernel(ColsArgs a) {
     }
 }
 
-// Accumulating MFMA with the accumulator pinned to the AGPR half of the register file.  The two-wave kernel below carries
-// 192 accumulator registers per wave; left to itself the register allocator keeps part of them in VGPRs / scratch and
-// shuttles them through the loop (measured: 219 spilled registers, ~90 scratch loads per tile).  Same-accumulator MFMAs
-// issued back to back need no wait states (exact vDst = SrcC overlap); nothing but the epilogue reads them otherwise.
-__device__ __forceinline__ void mfma32_acc(const bf16x8& a, const bf16x8& b, f32x16& c) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-template <int NS>
-__device__ __forceinline__ void mfma_ns_acc(const Frag<NS>& a, const Frag<NS>& b, f32x16& c) {
-    if constexpr (NS == 2) {
-        mfma32_acc(a.p[1], b.p[0], c);
-        mfma32_acc(a.p[0], b.p[1], c);
-    }
-    mfma32_acc(a.p[0], b.p[0], c);
-}
-
 // ================================================================================================== pass 2, two waves per tile
 // Same tile decomposition, but a row group is carried by TWO waves instead of four: the adapter-chain wave owns dWd and
 // dWu (+ h, dx2), the gate-chain wave dWgd and dWgu (+ g, dh / dq, dx1).  With four roles each wave sat idle through two of
@@ -897,12 +881,15 @@ __global__ __launch_bounds__(NRG * 128) void pet_gate_cols2_kernel(ColsArgs a) {
         for (int ks = 0; ks < KT; ++ks) { const Frag<NS> f = load_frag8(p0 + 16 * ks); dst[ks] = ok ? f : zero_frag<NS>(); }
     };
     // down job: the column sums of P (= bias gradient of the down projection) are wanted; up job: those of X (dh / dq)
-    auto accumulate = [&](const Frag<NS>* xn, const Frag<NS>* pp, f32x16 (&acc)[RT][NV], float* csp, float* csx, auto want_p) {
+    auto accumulate = [&](const uint8_t* tile, bool valid, const Frag<NS>* pp, f32x16 (&acc)[RT][NV], float* csp, float* csx, auto want_p) {
         constexpr bool WP = decltype(want_p)::value;
         Frag<NS> xt[NV][2];
 #pragma unroll
         for (int nt = 0; nt < NV; ++nt) {
-            const f32x16 t = transpose32<NS>(xn[2 * nt], xn[2 * nt + 1], I0, I1);
+            Frag<NS> x0 = tile_bfrag4<IO>(tile, m, h, 2 * nt), x1f = tile_bfrag4<IO>(tile, m, h, 2 * nt + 1);
+            x0 = valid ? x0 : zero_frag<NS>();
+            x1f = valid ? x1f : zero_frag<NS>();
+            const f32x16 t = transpose32<NS>(x0, x1f, I0, I1);
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) { v[i] = t[i]; if constexpr (!WP) csx[nt] += t[i]; }
@@ -918,17 +905,10 @@ __global__ __launch_bounds__(NRG * 128) void pet_gate_cols2_kernel(ColsArgs a) {
             for (int i = 0; i < 16; ++i) { v[i] = t[i]; if constexpr (WP) csp[ct] += t[i]; }
             const Frag<NS> pt0 = frag_from_f32<NS>(v), pt1 = frag_from_f32<NS>(v + 8);
 #pragma unroll
-            for (int nt = 0; nt < NV; ++nt) mfma_ns_acc<NS>(pt0, xt[nt][0], acc[ct][nt]);
+            for (int nt = 0; nt < NV; ++nt) acc[ct][nt] = mfma_ns<NS>(pt0, xt[nt][0], acc[ct][nt]);
 #pragma unroll
-            for (int nt = 0; nt < NV; ++nt) mfma_ns_acc<NS>(pt1, xt[nt][1], acc[ct][nt]);
+            for (int nt = 0; nt < NV; ++nt) acc[ct][nt] = mfma_ns<NS>(pt1, xt[nt][1], acc[ct][nt]);
             __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto tile_frags = [&](const uint8_t* tile, bool valid, Frag<NS>* xn) {
-#pragma unroll
-        for (int u = 0; u < G::KU; ++u) {
-            const Frag<NS> f = tile_bfrag4<IO>(tile, m, h, u);
-            xn[u] = valid ? f : zero_frag<NS>();
         }
     };
     auto project = [&](const uint8_t* w, const Frag<NS>* pp, f32x16* out) {
@@ -1014,11 +994,7 @@ __global__ __launch_bounds__(NRG * 128) void pet_gate_cols2_kernel(ColsArgs a) {
         __builtin_amdgcn_s_barrier();                                // B1: h is in the exchange buffer
 
         // ================= phase 2: G: dh, dq of the tile;  A: dWd = dpre_a^T x2 (independent of dh)
-        if constexpr (CA) {
-            Frag<NS> xn[G::KU];
-            tile_frags(Tx2(bf), valid, xn);
-            accumulate(xn, pdp, accD, cspD, csxD, std::true_type{});
-        } else {
+        if constexpr (CA) accumulate(Tx2(bf), valid, pdp, accD, cspD, csxD, std::true_type{}); else {
             const uint8_t* ty = Tdy(bf);
 #pragma unroll
             for (int e = 0; e < G::E4; ++e) {
@@ -1051,11 +1027,7 @@ __global__ __launch_bounds__(NRG * 128) void pet_gate_cols2_kernel(ColsArgs a) {
 
         // ================= phase 3: A: dx2, dWu;  G: dWgd, dx1, dWgu
         if constexpr (CA) {
-            {
-                Frag<NS> xn[G::KU];
-                tile_frags(Tdh, valid, xn);
-                accumulate(xn, pz, accU, cspU, csxU, std::false_type{});
-            }
+            accumulate(Tdh, valid, pz, accU, cspU, csxU, std::false_type{});
             load_p(it + 1, Pz, pz);
             f32x16 ax[NV];
 #pragma unroll
@@ -1073,17 +1045,9 @@ __global__ __launch_bounds__(NRG * 128) void pet_gate_cols2_kernel(ColsArgs a) {
             }
             n_store = store_tile(dxo, row0, tile);
         } else {
-            {
-                Frag<NS> xn[G::KU];
-                tile_frags(Tdq, valid, xn);
-                accumulate(xn, pz, accU, cspU, csxU, std::false_type{});
-            }
+            accumulate(Tdq, valid, pz, accU, cspU, csxU, std::false_type{});
             load_p(it + 1, Pz, pz);
-            {
-                Frag<NS> xn[G::KU];
-                tile_frags(Tx1(bf), valid, xn);
-                accumulate(xn, pdp, accD, cspD, csxD, std::true_type{});
-            }
+            accumulate(Tx1(bf), valid, pdp, accD, cspD, csxD, std::true_type{});
             f32x16 ax[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) ax[v] = zero16();
@@ -1275,11 +1239,11 @@ static hipError_t launch_cols2_cfg(const ColsArgs& c, hipStream_t stream) {
 template <typename IO, int RT>
 static hipError_t launch_cols_one(const ColsArgs& c, hipStream_t stream) {
     // VLPET_BWD3_FORM: 0 = four roles per row group (4 waves, one tile at a time); 1 (default for r <= 96) = two waves per row
-    // group, two row groups per workgroup
+    // group, two row groups per workgroup (198.8 -> 137.2 us at M = 28 k, 58.9 -> 55.0 at 3.5 k; profiles/r02_kbench_pass2_forms.txt)
     static const int form = [] { const char* e = getenv("VLPET_BWD3_FORM"); return e ? atoi(e) : 1; }();
     if constexpr (RT == 3) {
-        if (form == 1) return launch_cols2_cfg<IO, RT, 2, 3>(c, stream);
-        if (form == 2) return launch_cols2_cfg<IO, RT, 2, 2>(c, stream);
+        if (form == 1) return launch_cols2_cfg<IO, RT, 2, 2>(c, stream);
+        if (form == 2) return launch_cols2_cfg<IO, RT, 2, 3>(c, stream);
     }
     if constexpr (RT == 6) {
         return launch_cols_cfg<IO, RT, 1, 2, false>(c, stream);     // 96 KiB of weight fragments: room for two tile buffers
