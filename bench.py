@@ -304,6 +304,8 @@ def main():
         per_row = {"k1_fwd": 3 * d * esz, "k1_bwd_rows": 5 * d * esz, "k1_bwd_wgrad": 0, "k2_fwd": 3 * d * esz,
                    "k2_bwd": 3 * d * esz, "k3_fwd": 3 * d * esz, "k3_bwd": 3 * d * esz, "k5_fwd": 3 * d * esz,
                    "k5_bwd": 3 * d * esz}
+        d_ff = int(getattr(cfg, "encoder_ffn_dim", 0) or getattr(cfg, "d_ff", 0))
+        per_row.update({"ffn_act_fwd": 2 * d_ff * esz, "ffn_act_bwd": 3 * d_ff * esz})   # backbone FFN activation + dropout pass
         F_in = int(cfg.feat_dim)
         flops_per_row = {"k4_fwd": 2.0 * F_in * d, "k4_wgrad": 2.0 * F_in * d}
         kernels = {}

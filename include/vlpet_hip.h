@@ -255,6 +255,21 @@ int vlpet_sublayer_tail_bwd(const void* dout, const void* h_save, const float* m
                             const float* gamma, void* dx1, void* dy, float* dgb_partials, int64_t M, int d,
                             float p, uint64_t seed, int norm_mode, int io_dtype, vlpet_stream_t stream);
 
+/* ---- FFN activation + dropout (the backbone step between fc1 and fc2 of the sublayers K1 / K5 close) ----------
+ * out = dropout(act(x), p) as one pass; backward dx = dy * mask / (1 - p) * act'(x), mask regenerated from the seed
+ * (same counter-based generator as the sublayer tail; group of 8 consecutive elements = one Philox call).
+ * Replaces `activation_fn(fc1(x))` + `F.dropout(..., p=activation_dropout)` (my_transformers/modeling_bart.py:1264-1265,
+ * 1750-1756) and `F.relu` + `nn.Dropout` of T5DenseReluDense (my_transformers/modeling_t5.py:262-265).
+ *   act: VLPET_ACT_GELU (erf form), VLPET_ACT_GELU_NEW (tanh form), VLPET_ACT_RELU;  n: elements, multiple of 8;
+ *   keep_out: optional [n] uint8 export of the mask (tests), NULL otherwise. */
+#define VLPET_ACT_GELU 0
+#define VLPET_ACT_GELU_NEW 1
+#define VLPET_ACT_RELU 2
+int vlpet_act_dropout_fwd(const void* x, void* out, uint8_t* keep_out, int64_t n, int act, float p, uint64_t seed,
+                          int io_dtype, vlpet_stream_t stream);
+int vlpet_act_dropout_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, float p, uint64_t seed,
+                          int io_dtype, vlpet_stream_t stream);
+
 /* ---- Downsample (the step before K4) -------------------------------------------------------
  * AdaptiveMaxPool2d(s_in x s_in -> s_out x s_out) over the token grid of x [n_images, s_in*s_in, dim]
  * -> out [n_images, s_out*s_out, dim], with the cast to the compute dtype fused (in_dtype may be

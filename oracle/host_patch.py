@@ -64,6 +64,10 @@ def cpu_reference_ops():
             return O.t5_sublayer_tail(residual, hd)
         return O.bart_sublayer_tail(residual, hd, norm.weight, norm.bias, norm.eps)
 
+    def ffn_activation(x, act, p, training):                            # backbone FFN: activation, then dropout
+        y = {"gelu": F.gelu, "relu": F.relu, "gelu_new": O.gelu_new}[act](x)
+        return F.dropout(y, p=p, training=training)
+
     def downsample(self, inputs_tuple, out_dtype=None):
         hw = tuple(self.output_size)
         if len(inputs_tuple) == 4:
@@ -103,6 +107,8 @@ def cpu_reference_ops():
     HB.FUSE_RESIDUAL_GRAD = HT.FUSE_RESIDUAL_GRAD = False       # plain autograd on the checker path (no kernel-side hand-over)
     saved = (HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward,
              TR.CPU_OPTIMIZER_FACTORY, LoRALinearController.forward, HT.apply_pet, HT.sublayer_tail)
+    saved_act = (HB.ffn_activation, HT.ffn_activation)
+    HB.ffn_activation = HT.ffn_activation = ffn_activation
     HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward = \
         apply_pet, fused, visual, tail, downsample
     TR.CPU_OPTIMIZER_FACTORY = CpuAdamW
@@ -114,3 +120,4 @@ def cpu_reference_ops():
         (HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward,
          TR.CPU_OPTIMIZER_FACTORY, LoRALinearController.forward, HT.apply_pet, HT.sublayer_tail) = saved
         HB.FUSE_RESIDUAL_GRAD, HT.FUSE_RESIDUAL_GRAD = fuse_saved
+        HB.ffn_activation, HT.ffn_activation = saved_act

@@ -643,6 +643,38 @@ extern "C" int vlpet_sublayer_tail_bwd(const void* dout, const void* h_save, con
     return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
 }
 
+static int act_common(int64_t n, int act, float p, int io_dtype) {
+    if (n <= 0 || (n & 7) != 0) return VLPET_E_SHAPE;
+    if (act != VLPET_ACT_GELU && act != VLPET_ACT_GELU_NEW && act != VLPET_ACT_RELU) return VLPET_E_SHAPE;
+    if (!(p >= 0.0f && p < 1.0f)) return VLPET_E_SHAPE;
+    if (io_dtype != VLPET_F32 && io_dtype != VLPET_BF16) return VLPET_E_DTYPE;
+    return 0;
+}
+
+extern "C" int vlpet_act_dropout_fwd(const void* x, void* out, uint8_t* keep_out, int64_t n, int act, float p, uint64_t seed,
+                                     int io_dtype, vlpet_stream_t stream) {
+    int rc = act_common(n, act, p, io_dtype);
+    if (rc) return rc;
+    if (!x || !out) return VLPET_E_NULL;
+    if (!aligned16(x) || !aligned16(out)) return VLPET_E_ALIGN;
+    ActDropArgs a{};
+    a.x = x; a.dy = nullptr; a.out = out; a.keep_out = keep_out; a.n = n; a.act = act; a.thr = tail_thr(p);
+    a.keep_scale = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
+    return herr(launch_act_dropout(a, false, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_act_dropout_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, float p, uint64_t seed,
+                                     int io_dtype, vlpet_stream_t stream) {
+    int rc = act_common(n, act, p, io_dtype);
+    if (rc) return rc;
+    if (!dy || !x || !dx) return VLPET_E_NULL;
+    if (!aligned16(dy) || !aligned16(x) || !aligned16(dx)) return VLPET_E_ALIGN;
+    ActDropArgs a{};
+    a.x = x; a.dy = dy; a.out = dx; a.keep_out = nullptr; a.n = n; a.act = act; a.thr = tail_thr(p);
+    a.keep_scale = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
+    return herr(launch_act_dropout(a, true, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
 // ---- Downsample ---------------------------------------------------------------------------------------------
 extern "C" int vlpet_downsample_fwd(const void* x, void* out, int64_t n_images, int s_in, int s_out, int dim,
                                     int in_dtype, int out_dtype, vlpet_stream_t stream) {

@@ -238,3 +238,19 @@ inline int pick_row_groups(int64_t M, int max_rg, int min_rg) {
     return best;
 }
 
+// FFN activation + dropout of the backbone (actdrop.hip): out = dropout(act(x)) / dx = dy * mask * act'(x)
+#define VLPET_ACT_GELU 0        // erf form (F.gelu; BART)
+#define VLPET_ACT_GELU_NEW 1    // tanh form
+#define VLPET_ACT_RELU 2        // T5 DenseReluDense
+struct ActDropArgs {
+    const void* x;          // [n] pre-activation
+    const void* dy;         // backward: gradient of the output
+    void* out;              // forward: dropout(act(x)); backward: dx
+    uint8_t* keep_out;      // forward only: optional 0/1 export of the mask (tests)
+    int64_t n;              // elements, multiple of 8
+    int act;
+    uint32_t thr;           // drop iff 16-bit uniform < thr (0: no dropout)
+    float keep_scale;
+    uint64_t seed;
+};
+hipError_t launch_act_dropout(const ActDropArgs& a, bool bwd, int io_fp32, hipStream_t stream);

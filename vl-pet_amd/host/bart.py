@@ -123,6 +123,18 @@ def sublayer_tail(residual, h, norm, p, training, link=None):
     return _hip_tail(residual, h, norm, p, training, link=link)
 
 
+def ffn_activation(x, act, p, training):
+    """``dropout(act(fc1 output), p)`` of the feed-forward sublayer: one fused HIP pass (vlpet_amd.act); the parity /
+    CPU-baseline harnesses swap this module attribute for the eager pair."""
+    if EAGER_FFN_ACT:
+        return F.dropout(F.gelu(x) if act == "gelu" else F.relu(x), p=p, training=training)
+    from ..act import act_dropout
+    return act_dropout(x, act, p, training)
+
+
+EAGER_FFN_ACT = _os.environ.get("VLPET_EAGER_FFN_ACT", "0") == "1"     # A/B switch: the two elementwise torch passes instead
+
+
 def _linear(mod: nn.Linear, x):
     w, b = mod.weight, mod.bias             # (a trainable fp32 bias next to a frozen bf16 weight in LoRA runs)
     if w.dtype != x.dtype:
@@ -223,8 +235,7 @@ class BartEncoderLayer(nn.Module):
         else:
             hidden = sublayer_tail(residual, h, self.self_attn_layer_norm, self.dropout, self.training)   # K5
         residual = hidden
-        h = F.gelu(_linear(self.fc1, hidden))
-        h = F.dropout(h, p=self.activation_dropout, training=self.training)
+        h = ffn_activation(_linear(self.fc1, hidden), "gelu", self.activation_dropout, self.training)
         h = _linear(self.fc2, h)
         if has_pet(self, "ff"):                                                     # K1 + K5
             return _pet_then_tail(self, "ff", residual, h, self.final_layer_norm, self.dropout, self.training, self.pet_config)
@@ -255,8 +266,7 @@ class BartDecoderLayer(nn.Module):
         h = self.encoder_attn(hidden, kv=enc, attn_mask=enc_mask, task=task)      # K2 inside
         hidden = sublayer_tail(residual, h, self.encoder_attn_layer_norm, self.dropout, self.training)  # K5
         residual = hidden
-        h = F.gelu(_linear(self.fc1, hidden))
-        h = F.dropout(h, p=self.activation_dropout, training=self.training)
+        h = ffn_activation(_linear(self.fc1, hidden), "gelu", self.activation_dropout, self.training)
         h = _linear(self.fc2, h)
         return sublayer_tail(residual, h, self.final_layer_norm, self.dropout, self.training)             # K5
 

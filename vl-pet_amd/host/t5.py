@@ -43,6 +43,13 @@ def _pet_then_tail(layer, which, residual, h, norm, p, training, config):
     return sublayer_tail(residual, y, norm, p, training, link=link)
 
 
+def ffn_activation(x, act, p, training):
+    """``dropout(relu(wi output))`` of T5DenseReluDense as one fused HIP pass (vlpet_amd.act); harnesses swap this
+    attribute for the eager pair."""
+    from ..act import act_dropout
+    return act_dropout(x, act, p, training)
+
+
 def sublayer_tail(residual, h, norm, p, training, link=None):
     """K5 (T5 form): ``residual + dropout(h)`` -- one fused HIP pass; harnesses swap this attribute for an eager
     restatement, exactly as for host.bart."""
@@ -165,7 +172,7 @@ class T5DenseReluDense(nn.Module):
         self.dropout = config.dropout_rate
 
     def forward(self, x):
-        h = F.dropout(F.relu(_linear(self.wi, x)), p=self.dropout, training=self.training)
+        h = ffn_activation(_linear(self.wi, x), "relu", self.dropout, self.training)
         return _linear(self.wo, h)
 
 
