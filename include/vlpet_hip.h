@@ -270,6 +270,17 @@ int vlpet_act_dropout_fwd(const void* x, void* out, uint8_t* keep_out, int64_t n
 int vlpet_act_dropout_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, float p, uint64_t seed,
                           int io_dtype, vlpet_stream_t stream);
 
+/* ---- LM-head cross entropy (the loss of the training step; src/modeling_bart.py:1574-1586, src/modeling_t5.py:680-694) --
+ * CrossEntropyLoss(ignore_index=-100, reduction='none') on logits [N, V] stored with a row stride of ld elements
+ * (ld % 8 == 0, ld >= V; the caller pads the LM-head weight so that rows are 16-byte aligned; columns [V, ld) are ignored
+ * and get zero gradient).  labels: int64 [N], negative = ignored token (loss 0, zero gradient row).
+ * Forward: loss [N] fp32 and lse [N] fp32 (row log-sum-exp, kept for the backward).  Backward:
+ * dlogits[n, v] = dloss[n] * (exp(logits[n, v] - lse[n]) - [v == labels[n]]) in the IO dtype, [N, ld]. */
+int vlpet_ce_loss_fwd(const void* logits, const int64_t* labels, float* loss, float* lse, int64_t N, int V, int ld,
+                      int io_dtype, vlpet_stream_t stream);
+int vlpet_ce_loss_bwd(const void* logits, const int64_t* labels, const float* lse, const float* dloss, void* dlogits,
+                      int64_t N, int V, int ld, int io_dtype, vlpet_stream_t stream);
+
 /* ---- Downsample (the step before K4) -------------------------------------------------------
  * AdaptiveMaxPool2d(s_in x s_in -> s_out x s_out) over the token grid of x [n_images, s_in*s_in, dim]
  * -> out [n_images, s_out*s_out, dim], with the cast to the compute dtype fused (in_dtype may be

@@ -68,6 +68,13 @@ def cpu_reference_ops():
         y = {"gelu": F.gelu, "relu": F.relu, "gelu_new": O.gelu_new}[act](x)
         return F.dropout(y, p=p, training=training)
 
+    def lm_loss(h, weight, labels, bias=None):                          # LM head + CrossEntropyLoss(reduction='none')
+        logits = F.linear(h, weight.to(h.dtype))
+        if bias is not None:
+            logits = logits + bias.to(h.dtype)
+        loss = F.cross_entropy(logits.float().view(-1, logits.shape[-1]), labels.view(-1), ignore_index=-100, reduction="none")
+        return loss.view(labels.shape), logits
+
     def downsample(self, inputs_tuple, out_dtype=None):
         hw = tuple(self.output_size)
         if len(inputs_tuple) == 4:
@@ -107,8 +114,9 @@ def cpu_reference_ops():
     HB.FUSE_RESIDUAL_GRAD = HT.FUSE_RESIDUAL_GRAD = False       # plain autograd on the checker path (no kernel-side hand-over)
     saved = (HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward,
              TR.CPU_OPTIMIZER_FACTORY, LoRALinearController.forward, HT.apply_pet, HT.sublayer_tail)
-    saved_act = (HB.ffn_activation, HT.ffn_activation)
+    saved_act = (HB.ffn_activation, HT.ffn_activation, HB.lm_loss, HT.lm_loss)
     HB.ffn_activation = HT.ffn_activation = ffn_activation
+    HB.lm_loss = HT.lm_loss = lm_loss
     HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward = \
         apply_pet, fused, visual, tail, downsample
     TR.CPU_OPTIMIZER_FACTORY = CpuAdamW
@@ -120,4 +128,4 @@ def cpu_reference_ops():
         (HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward,
          TR.CPU_OPTIMIZER_FACTORY, LoRALinearController.forward, HT.apply_pet, HT.sublayer_tail) = saved
         HB.FUSE_RESIDUAL_GRAD, HT.FUSE_RESIDUAL_GRAD = fuse_saved
-        HB.ffn_activation, HT.ffn_activation = saved_act
+        HB.ffn_activation, HT.ffn_activation, HB.lm_loss, HT.lm_loss = saved_act

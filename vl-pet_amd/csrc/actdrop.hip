@@ -8,6 +8,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "rng.h"
+#include "vec8.h"
 
 template <int ACT> __device__ __forceinline__ float act_f(float x) {
     if constexpr (ACT == VLPET_ACT_RELU) return x > 0.f ? x : 0.f;
@@ -28,22 +29,6 @@ template <int ACT> __device__ __forceinline__ float act_df(float x) {
         return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
     }
 }
-
-template <typename IO> struct Vec8;
-template <> struct Vec8<__bf16> {
-    bf16x8 v;
-    __device__ __forceinline__ void load(const void* p, int64_t g) { v = reinterpret_cast<const bf16x8*>(p)[g]; }
-    __device__ __forceinline__ void store(void* p, int64_t g) const { reinterpret_cast<bf16x8*>(p)[g] = v; }
-    __device__ __forceinline__ float get(int j) const { return (float)v[j]; }
-    __device__ __forceinline__ void set(int j, float f) { v[j] = (__bf16)f; }
-};
-template <> struct Vec8<float> {
-    f32x4 a, b;
-    __device__ __forceinline__ void load(const void* p, int64_t g) { a = reinterpret_cast<const f32x4*>(p)[2 * g]; b = reinterpret_cast<const f32x4*>(p)[2 * g + 1]; }
-    __device__ __forceinline__ void store(void* p, int64_t g) const { reinterpret_cast<f32x4*>(p)[2 * g] = a; reinterpret_cast<f32x4*>(p)[2 * g + 1] = b; }
-    __device__ __forceinline__ float get(int j) const { return j < 4 ? a[j] : b[j - 4]; }
-    __device__ __forceinline__ void set(int j, float f) { if (j < 4) a[j] = f; else b[j - 4] = f; }
-};
 
 template <typename IO, int ACT, bool DROP, bool BWD>
 __global__ __launch_bounds__(256) void act_dropout_kernel(ActDropArgs a) {

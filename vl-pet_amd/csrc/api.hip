@@ -643,6 +643,36 @@ extern "C" int vlpet_sublayer_tail_bwd(const void* dout, const void* h_save, con
     return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
 }
 
+static int ce_common(int64_t N, int V, int ld, int io_dtype) {
+    if (N <= 0 || V <= 0 || ld < V || (ld & 7) != 0) return VLPET_E_SHAPE;
+    if (io_dtype != VLPET_F32 && io_dtype != VLPET_BF16) return VLPET_E_DTYPE;
+    return 0;
+}
+
+extern "C" int vlpet_ce_loss_fwd(const void* logits, const int64_t* labels, float* loss, float* lse, int64_t N, int V, int ld,
+                                 int io_dtype, vlpet_stream_t stream) {
+    int rc = ce_common(N, V, ld, io_dtype);
+    if (rc) return rc;
+    if (!logits || !labels || !loss || !lse) return VLPET_E_NULL;
+    if (!aligned16(logits)) return VLPET_E_ALIGN;
+    CeArgs a{};
+    a.logits = logits; a.labels = labels; a.loss = loss; a.lse = lse; a.dloss = nullptr; a.dlogits = nullptr;
+    a.N = N; a.V = V; a.ld = ld;
+    return herr(launch_ce(a, false, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_ce_loss_bwd(const void* logits, const int64_t* labels, const float* lse, const float* dloss, void* dlogits,
+                                 int64_t N, int V, int ld, int io_dtype, vlpet_stream_t stream) {
+    int rc = ce_common(N, V, ld, io_dtype);
+    if (rc) return rc;
+    if (!logits || !labels || !lse || !dloss || !dlogits) return VLPET_E_NULL;
+    if (!aligned16(logits) || !aligned16(dlogits)) return VLPET_E_ALIGN;
+    CeArgs a{};
+    a.logits = logits; a.labels = labels; a.loss = nullptr; a.lse = const_cast<float*>(lse); a.dloss = dloss; a.dlogits = dlogits;
+    a.N = N; a.V = V; a.ld = ld;
+    return herr(launch_ce(a, true, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
 static int act_common(int64_t n, int act, float p, int io_dtype) {
     if (n <= 0 || (n & 7) != 0) return VLPET_E_SHAPE;
     if (act != VLPET_ACT_GELU && act != VLPET_ACT_GELU_NEW && act != VLPET_ACT_RELU) return VLPET_E_SHAPE;

@@ -254,3 +254,16 @@ struct ActDropArgs {
     uint64_t seed;
 };
 hipError_t launch_act_dropout(const ActDropArgs& a, bool bwd, int io_fp32, hipStream_t stream);
+
+// token-level cross entropy over the LM-head logits (celoss.hip)
+struct CeArgs {
+    const void* logits;     // [N, ld] IO dtype, columns [0, V) valid
+    const int64_t* labels;  // [N]; < 0 = ignored
+    float* loss;            // forward: [N]
+    float* lse;             // [N] log-sum-exp of the row (written by the forward, read by the backward)
+    const float* dloss;     // backward: [N]
+    void* dlogits;          // backward: [N, ld]
+    int64_t N;
+    int V, ld;
+};
+hipError_t launch_ce(const CeArgs& a, bool bwd, int io_fp32, hipStream_t stream);

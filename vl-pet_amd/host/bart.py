@@ -135,6 +135,22 @@ def ffn_activation(x, act, p, training):
 EAGER_FFN_ACT = _os.environ.get("VLPET_EAGER_FFN_ACT", "0") == "1"     # A/B switch: the two elementwise torch passes instead
 
 
+def lm_loss(h, weight, labels, bias=None):
+    """LM head + per-token cross entropy (vlpet_amd.lmloss: library GEMM, then one fused HIP pass each way over the
+    logits); the parity / CPU-baseline harnesses swap this module attribute for the eager chain."""
+    if EAGER_LM_LOSS:
+        logits = F.linear(h, weight.to(h.dtype))
+        if bias is not None:
+            logits = logits + bias.to(h.dtype)
+        loss = F.cross_entropy(logits.float().view(-1, logits.shape[-1]), labels.view(-1), ignore_index=-100, reduction="none")
+        return loss.view(labels.shape), logits
+    from ..lmloss import lm_head_loss
+    return lm_head_loss(h, weight, labels, bias)
+
+
+EAGER_LM_LOSS = _os.environ.get("VLPET_EAGER_LM_LOSS", "0") == "1"       # A/B switch: torch's cast + log_softmax + nll chain
+
+
 def _linear(mod: nn.Linear, x):
     w, b = mod.weight, mod.bias             # (a trainable fp32 bias next to a frozen bf16 weight in LoRA runs)
     if w.dtype != x.dtype:
@@ -394,12 +410,18 @@ class VLBart(nn.Module):
             for t in m.tasks:
                 nn.init.zeros_(m.lora_Bs[t])
 
+    def _logits_bias(self):
+        """final_logits_bias (src/modeling_bart.py:1470, 1574) is a zero buffer unless a checkpoint carries one: checked once
+        per buffer version (one host sync), so the usual all-zero case adds no pass over the logits."""
+        b = self.final_logits_bias
+        key = (b.data_ptr(), b._version)
+        if getattr(self, "_bias_key", None) != key:
+            self._bias_key, self._bias_nonzero = key, bool(b.any())
+        return b if self._bias_nonzero else None
+
     def forward(self, input_ids, vis_inputs, labels, task, attention_mask=None, no_padding=False):
         cfg = self.config
         enc, mask = self.model.encoder(input_ids, vis_inputs, attention_mask, task, no_padding)
         dec_in = shift_tokens_right(labels, cfg.pad_token_id, cfg.decoder_start_token_id)
         h = self.model.decoder(dec_in, enc, mask, task)
-        logits = F.linear(h, self.model.shared.weight.to(h.dtype)) + self.final_logits_bias.to(h.dtype)
-        loss = F.cross_entropy(logits.float().view(-1, logits.shape[-1]), labels.view(-1), ignore_index=-100,
-                               reduction="none")
-        return loss.view(labels.shape), logits
+        return lm_loss(h, self.model.shared.weight, labels, self._logits_bias())

@@ -50,6 +50,12 @@ def ffn_activation(x, act, p, training):
     return act_dropout(x, act, p, training)
 
 
+def lm_loss(h, weight, labels, bias=None):
+    """LM head + per-token cross entropy (vlpet_amd.lmloss); harnesses swap this attribute for the eager chain."""
+    from ..lmloss import lm_head_loss
+    return lm_head_loss(h, weight, labels, bias)
+
+
 def sublayer_tail(residual, h, norm, p, training, link=None):
     """K5 (T5 form): ``residual + dropout(h)`` -- one fused HIP pass; harnesses swap this attribute for an eager
     restatement, exactly as for host.bart."""
@@ -351,7 +357,4 @@ class VLT5(nn.Module):
         enc, keep = self.encoder(input_ids, vis_inputs, attention_mask, task)
         dec_in = shift_right(labels, cfg.pad_token_id, cfg.decoder_start_token_id)
         h = self.decoder(dec_in, enc, keep, task) * (cfg.d_model ** -0.5)
-        logits = F.linear(h, self.shared.weight.to(h.dtype))
-        loss = F.cross_entropy(logits.float().view(-1, logits.shape[-1]), labels.view(-1), ignore_index=-100,
-                               reduction="none")
-        return loss.view(labels.shape), logits
+        return lm_loss(h, self.shared.weight, labels)
