@@ -306,6 +306,8 @@ def main():
                    "k5_bwd": 3 * d * esz}
         d_ff = int(getattr(cfg, "encoder_ffn_dim", 0) or getattr(cfg, "d_ff", 0))
         per_row.update({"ffn_act_fwd": 2 * d_ff * esz, "ffn_act_bwd": 3 * d_ff * esz})   # backbone FFN activation + dropout pass
+        # backbone attention on the short-sequence kernels: q, k, v read + o written / q, k, v, o, do read + dq, dk, dv written
+        per_row.update({"attn_fwd": 4 * d * esz, "attn_bwd": 8 * d * esz})
         V_head = int(cfg.vocab_size)
         per_row.update({"ce_fwd": V_head * esz, "ce_bwd": 2 * V_head * esz})              # LM-head loss: one read / read + write of the logits
         F_in = int(cfg.feat_dim)

@@ -281,6 +281,23 @@ int vlpet_ce_loss_fwd(const void* logits, const int64_t* labels, float* loss, fl
 int vlpet_ce_loss_bwd(const void* logits, const int64_t* labels, const float* lse, const float* dloss, void* dlogits,
                       int64_t N, int V, int ld, int io_dtype, vlpet_stream_t stream);
 
+/* ---- Short-sequence attention of the frozen backbone (my_transformers/modeling_bart.py:283-566, BartAttention.forward) ----
+ * o = dropout(softmax(scale * q k^T + mask), p) v per (batch, head), bf16, head dim 64, at most VLPET_ATTN_MAX_LEN keys and
+ * queries per sequence (the encoder's 20-40 text + 36 / 72 visual tokens; decoder self / cross attention).  One
+ * workgroup per (batch, head), everything on chip; HBM traffic = q, k, v read once, o written (see csrc/attn.hip).
+ *   q, o, dout, dq: [B, Lq, H, 64] contiguous;  k, v, dk, dv: [B, Lk, H, 64] contiguous (i.e. the [B, L, H*64] projection
+ *   outputs as they are: no head transpose);  key_mask: [B, Lk] uint8, 1 = attend, or NULL;  causal: key j visible to query
+ *   i iff j <= i + (Lk - Lq);  lse: [B, H, Lq] fp32 scratch written by the forward and read by the backward;
+ *   keep_out: optional [B, H, Lq, Lk] uint8 export of the dropout mask (tests), NULL otherwise.
+ * Dropout: element (b, h, i, j) is kept iff a hash of (seed, element index) >= p * 2^32; the backward regenerates it.
+ * A query row with no visible key yields zeros (the library path yields NaN there). */
+#define VLPET_ATTN_MAX_LEN 128
+int vlpet_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, void* o, float* lse, uint8_t* keep_out,
+                   int B, int H, int Lq, int Lk, int causal, float scale, float p, uint64_t seed, vlpet_stream_t stream);
+int vlpet_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                   const uint8_t* key_mask, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int causal,
+                   float scale, float p, uint64_t seed, vlpet_stream_t stream);
+
 /* ---- Downsample (the step before K4) -------------------------------------------------------
  * AdaptiveMaxPool2d(s_in x s_in -> s_out x s_out) over the token grid of x [n_images, s_in*s_in, dim]
  * -> out [n_images, s_out*s_out, dim], with the cast to the compute dtype fused (in_dtype may be

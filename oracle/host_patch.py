@@ -75,6 +75,13 @@ def cpu_reference_ops():
         loss = F.cross_entropy(logits.float().view(-1, logits.shape[-1]), labels.view(-1), ignore_index=-100, reduction="none")
         return loss.view(labels.shape), logits
 
+    def attention_core(q, k, v, num_heads, attn_mask, causal, p, training):   # backbone attention: the eager chain
+        B, Lq, E = q.shape
+        sh = lambda t: t.view(B, -1, num_heads, E // num_heads).transpose(1, 2)
+        out = F.scaled_dot_product_attention(sh(q), sh(k), sh(v), attn_mask=attn_mask, is_causal=causal and attn_mask is None,
+                                             dropout_p=p if training else 0.0)
+        return out.transpose(1, 2).reshape(B, Lq, E)
+
     def downsample(self, inputs_tuple, out_dtype=None):
         hw = tuple(self.output_size)
         if len(inputs_tuple) == 4:
@@ -114,6 +121,8 @@ def cpu_reference_ops():
     HB.FUSE_RESIDUAL_GRAD = HT.FUSE_RESIDUAL_GRAD = False       # plain autograd on the checker path (no kernel-side hand-over)
     saved = (HB.apply_pet, Adapter.fused, VisualEmbedding.forward, HB.sublayer_tail, Downsample.forward,
              TR.CPU_OPTIMIZER_FACTORY, LoRALinearController.forward, HT.apply_pet, HT.sublayer_tail)
+    saved_attn = HB.attention_core
+    HB.attention_core = attention_core
     saved_act = (HB.ffn_activation, HT.ffn_activation, HB.lm_loss, HT.lm_loss)
     HB.ffn_activation = HT.ffn_activation = ffn_activation
     HB.lm_loss = HT.lm_loss = lm_loss
@@ -129,3 +138,4 @@ def cpu_reference_ops():
          TR.CPU_OPTIMIZER_FACTORY, LoRALinearController.forward, HT.apply_pet, HT.sublayer_tail) = saved
         HB.FUSE_RESIDUAL_GRAD, HT.FUSE_RESIDUAL_GRAD = fuse_saved
         HB.ffn_activation, HT.ffn_activation, HB.lm_loss, HT.lm_loss = saved_act
+        HB.attention_core = saved_attn

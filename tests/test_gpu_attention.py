@@ -1,0 +1,116 @@
+"""Short-sequence attention (csrc/attn.hip, vlpet_amd.attention) against the eager chain of BartAttention.forward
+(my_transformers/modeling_bart.py:283-566: scores, mask, softmax, dropout, weighted sum) in fp32 on the same bf16 inputs,
+with the dropout mask the kernel applied exported so that forward and backward compare element for element."""
+import pytest
+import torch
+
+from gpu_cases import rel_err
+
+pytestmark = pytest.mark.gpu
+
+H = 12
+
+
+def _eager(q, k, v, key_mask, causal, keep, p):
+    B, Lq, _ = q.shape
+    Lk = k.shape[1]
+    sh = lambda t, L: t.view(B, L, H, 64).transpose(1, 2)
+    s = (sh(q, Lq) @ sh(k, Lk).transpose(-1, -2)) * 64 ** -0.5
+    if key_mask is not None:
+        s = s.masked_fill(~key_mask[:, None, None, :].bool(), float("-inf"))
+    if causal:
+        i = torch.arange(Lq)[:, None]; j = torch.arange(Lk)[None, :]
+        s = s.masked_fill(j > i + (Lk - Lq), float("-inf"))
+    pr = torch.softmax(s, -1)
+    if keep is not None:
+        pr = pr * keep.float() / (1.0 - p)
+    return (pr @ sh(v, Lk)).transpose(1, 2).reshape(B, Lq, H * 64)
+
+
+CASES = [  # B, Lq, Lk, causal, masked, p
+    (3, 56, 56, False, False, 0.0),
+    (3, 56, 56, False, True, 0.1),
+    (2, 92, 92, False, False, 0.1),
+    (2, 128, 128, False, True, 0.1),
+    (4, 5, 5, True, False, 0.1),
+    (4, 20, 20, True, False, 0.0),
+    (3, 5, 56, False, True, 0.1),
+    (2, 33, 97, False, False, 0.5),
+    (2, 1, 1, True, False, 0.0),
+]
+
+
+@pytest.mark.parametrize("B,Lq,Lk,causal,masked,p", CASES)
+def test_short_attention_matches_the_eager_chain(B, Lq, Lk, causal, masked, p):
+    from vlpet_amd.attention import short_attention
+    g = torch.Generator().manual_seed(Lq * 131 + Lk)
+    mk = lambda L: (torch.randn(B, L, H * 64, generator=g) * 1.5).bfloat16()
+    q, k, v, do = mk(Lq), mk(Lk), mk(Lk), mk(Lq)
+    key_mask = None
+    if masked:
+        key_mask = torch.rand(B, Lk, generator=g) > 0.25
+        key_mask[:, -1] = True                                  # (at least one key per row)
+    qg, kg, vg = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out = short_attention(qg, kg, vg, H, None if key_mask is None else key_mask.cuda(), causal, p, True, seed=99,
+                          return_mask=p > 0)
+    keep = None
+    if p > 0:
+        out, keep = out
+        keep = keep.cpu()
+        assert keep.shape == (B, H, Lq, Lk)
+        frac = float(keep.float().mean())
+        n = keep.numel()
+        assert abs(frac - (1 - p)) < 4.0 * (p * (1 - p) / n) ** 0.5 + 1e-3, frac
+    out.backward(do.cuda())
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref = _eager(qr, kr, vr, key_mask, causal, keep, p)
+    ref.backward(do.float())
+    tol = 2e-2                                                  # bf16 outputs and bf16 probabilities in the second product
+    def close(a, r):          # (a single visible key makes dq and dk exactly zero in the reference: absolute floor)
+        return float((a.float().cpu() - r).abs().max()) <= tol * max(float(r.abs().max()), 1e-2)
+    assert rel_err(out, ref) <= tol
+    assert close(qg.grad, qr.grad)
+    assert close(kg.grad, kr.grad)
+    assert close(vg.grad, vr.grad)
+
+
+def test_short_attention_mask_depends_on_seed_only_and_eval_has_no_dropout():
+    from vlpet_amd.attention import short_attention
+    q = torch.randn(2, 40, H * 64, device="cuda").bfloat16()
+    _, k1 = short_attention(q, q, q, H, p=0.1, training=True, seed=5, return_mask=True)
+    _, k2 = short_attention(q * 2, q, q, H, p=0.1, training=True, seed=5, return_mask=True)
+    _, k3 = short_attention(q, q, q, H, p=0.1, training=True, seed=6, return_mask=True)
+    assert torch.equal(k1, k2) and not torch.equal(k1, k3)
+    o1 = short_attention(q, q, q, H, p=0.1, training=False)
+    o2 = short_attention(q, q, q, H, p=0.0, training=True)
+    assert torch.equal(o1, o2)
+
+
+def test_fully_masked_row_gives_zeros():
+    from vlpet_amd.attention import short_attention
+    q = torch.randn(2, 8, H * 64, device="cuda").bfloat16().requires_grad_(True)
+    km = torch.ones(2, 8, dtype=torch.bool, device="cuda")
+    km[1] = False
+    o = short_attention(q, q, q, H, km)
+    assert float(o[1].abs().max()) == 0.0 and torch.isfinite(o).all()
+    o.sum().backward()
+    assert torch.isfinite(q.grad).all()
+
+
+def test_short_attention_argument_errors():
+    from vlpet_amd import _lib
+    from vlpet_amd.attention import short_attention, supported
+    q = torch.randn(2, 8, H * 64, device="cuda")
+    assert not supported(q, q, H)                                                   # fp32: library path
+    assert not supported(q.bfloat16().cpu(), q.bfloat16().cpu(), H)
+    assert not supported(torch.randn(1, 200, H * 64, device="cuda").bfloat16(), q.bfloat16(), H)
+    with pytest.raises(RuntimeError):
+        short_attention(q, q, q, H)
+    lib = _lib.load()
+    x = torch.randn(1, 8, 64, device="cuda").bfloat16(); l = torch.empty(8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    args = lambda Lq, Lk, p: (x.data_ptr(), x.data_ptr(), x.data_ptr(), None, x.data_ptr(), l.data_ptr(), None, 1, 1, Lq, Lk, 0, 0.125, p, 0, st)
+    assert lib.vlpet_attn_fwd(*args(129, 8, 0.0)) == -1
+    assert lib.vlpet_attn_fwd(*args(8, 0, 0.0)) == -1
+    assert lib.vlpet_attn_fwd(*args(8, 8, 1.0)) == -1
+    assert lib.vlpet_attn_fwd(None, x.data_ptr(), x.data_ptr(), None, x.data_ptr(), l.data_ptr(), None, 1, 1, 8, 8, 0, 0.125, 0.0, 0, st) == -5

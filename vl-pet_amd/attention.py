@@ -1,0 +1,80 @@
+"""Host glue of the short-sequence attention kernels (csrc/attn.hip): ``dropout(softmax(scale * q k^T + mask), p) v`` for
+the sequence lengths VL-PET trains on (at most 128 keys / queries, head dim 64, bf16), forward and backward on chip, one
+workgroup per (batch, head).
+
+Reference op chain replaced: BartAttention.forward (my_transformers/modeling_bart.py:283-566): bmm, mask add, softmax,
+F.dropout(p=attention_dropout), bmm, head transposes.  Tensors stay in the ``[B, L, H * 64]`` layout the projections
+produce (no head transpose / re-pack in either direction).  ``supported`` tells the caller whether a call fits; anything
+else (fp32 parity runs, long video sequences, additive biases) stays on the library path.  No CPU fallback."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .functional import _need_cuda, _ptr, _stream, _timed
+from .tail import _draw_seed
+
+MAX_LEN = 128
+HEAD_DIM = 64
+
+
+def supported(q: torch.Tensor, k: torch.Tensor, num_heads: int) -> bool:
+    return (q.is_cuda and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and q.shape[-1] == num_heads * HEAD_DIM
+            and q.shape[1] <= MAX_LEN and k.shape[1] <= MAX_LEN)
+
+
+class _AttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, key_mask, H, causal, scale, p, seed, want_mask):
+        lib = _lib.load()
+        _need_cuda(q, k, v)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, Lq, _ = q.shape
+        Lk = k.shape[1]
+        o = torch.empty_like(q)
+        lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+        keep = torch.empty(B, H, Lq, Lk, dtype=torch.uint8, device=q.device) if want_mask else None
+        rc = _timed("attn_fwd", B * Lq, lambda: lib.vlpet_attn_fwd(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(key_mask), o.data_ptr(), lse.data_ptr(), _ptr(keep),
+            B, H, Lq, Lk, int(causal), float(scale), float(p), seed, _stream()))
+        _lib.check(rc, "vlpet_attn_fwd")
+        ctx.save_for_backward(q, k, v, o, lse, key_mask)
+        ctx.cfg = (H, int(causal), float(scale), float(p), seed)
+        if want_mask:
+            ctx.mark_non_differentiable(keep)
+            return o, keep
+        return o
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        lib = _lib.load()
+        q, k, v, o, lse, key_mask = ctx.saved_tensors
+        H, causal, scale, p, seed = ctx.cfg
+        B, Lq, _ = q.shape
+        Lk = k.shape[1]
+        do = dout.contiguous()
+        if do.dtype != q.dtype:
+            do = do.to(q.dtype)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        rc = _timed("attn_bwd", B * Lq, lambda: lib.vlpet_attn_bwd(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), _ptr(key_mask),
+            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Lq, Lk, causal, scale, p, seed, _stream()))
+        _lib.check(rc, "vlpet_attn_bwd")
+        return dq, dk, dv, None, None, None, None, None, None, None
+
+
+def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, key_mask: Optional[torch.Tensor] = None,
+                    causal: bool = False, p: float = 0.0, training: bool = False, scale: Optional[float] = None, seed=None,
+                    return_mask: bool = False):
+    """q [B, Lq, H*64], k / v [B, Lk, H*64] (bf16) -> [B, Lq, H*64].  key_mask: [B, Lk] bool / uint8, True = attend."""
+    if not supported(q, k, num_heads):
+        raise RuntimeError("vl-pet_amd: short_attention needs bf16 CUDA tensors, head dim 64 and at most 128 keys / queries")
+    if key_mask is not None:
+        key_mask = key_mask.reshape(k.shape[0], k.shape[1]).to(torch.uint8).contiguous()
+    pe = float(p) if training else 0.0
+    if seed is None:
+        seed = _draw_seed() if pe > 0.0 else 0
+    return _AttnFn.apply(q, k, v, key_mask, num_heads, bool(causal), HEAD_DIM ** -0.5 if scale is None else float(scale),
+                         pe, int(seed), bool(return_mask))

@@ -643,6 +643,48 @@ extern "C" int vlpet_sublayer_tail_bwd(const void* dout, const void* h_save, con
     return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
 }
 
+static int attn_common(int B, int H, int Lq, int Lk, float p) {
+    if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || Lq > VLPET_ATTN_MAX_LEN || Lk > VLPET_ATTN_MAX_LEN) return VLPET_E_SHAPE;
+    if ((int64_t)B * H > 0x7fffffffLL) return VLPET_E_SHAPE;
+    if (!(p >= 0.0f && p < 1.0f)) return VLPET_E_SHAPE;
+    return 0;
+}
+static uint32_t attn_thr(float p) {
+    double t = (double)p * 4294967296.0 + 0.5;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
+extern "C" int vlpet_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, void* o, float* lse,
+                              uint8_t* keep_out, int B, int H, int Lq, int Lk, int causal, float scale, float p, uint64_t seed,
+                              vlpet_stream_t stream) {
+    int rc = attn_common(B, H, Lq, Lk, p);
+    if (rc) return rc;
+    if (!q || !k || !v || !o || !lse) return VLPET_E_NULL;
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o)) return VLPET_E_ALIGN;
+    AttnArgs a{};
+    a.q = (const __bf16*)q; a.k = (const __bf16*)k; a.v = (const __bf16*)v; a.o = (__bf16*)o; a.lse = lse;
+    a.key_mask = key_mask; a.keep_out = keep_out; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.causal = causal ? 1 : 0;
+    a.scale = scale; a.thr = attn_thr(p); a.inv_keep = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
+    return herr(launch_attn(a, false, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                              const uint8_t* key_mask, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int causal,
+                              float scale, float p, uint64_t seed, vlpet_stream_t stream) {
+    int rc = attn_common(B, H, Lq, Lk, p);
+    if (rc) return rc;
+    if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv) return VLPET_E_NULL;
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o) || !aligned16(dout) || !aligned16(dq) ||
+        !aligned16(dk) || !aligned16(dv)) return VLPET_E_ALIGN;
+    AttnArgs a{};
+    a.q = (const __bf16*)q; a.k = (const __bf16*)k; a.v = (const __bf16*)v; a.o = (__bf16*)const_cast<void*>(o);
+    a.lse = const_cast<float*>(lse); a.dout = (const __bf16*)dout; a.dq = (__bf16*)dq; a.dk = (__bf16*)dk; a.dv = (__bf16*)dv;
+    a.key_mask = key_mask; a.keep_out = nullptr; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.causal = causal ? 1 : 0;
+    a.scale = scale; a.thr = attn_thr(p); a.inv_keep = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
+    return herr(launch_attn(a, true, (hipStream_t)stream));
+}
+
 static int ce_common(int64_t N, int V, int ld, int io_dtype) {
     if (N <= 0 || V <= 0 || ld < V || (ld & 7) != 0) return VLPET_E_SHAPE;
     if (io_dtype != VLPET_F32 && io_dtype != VLPET_BF16) return VLPET_E_DTYPE;

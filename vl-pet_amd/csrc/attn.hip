@@ -1,0 +1,412 @@
+// Short-sequence multi-head attention of the frozen backbone (head dim 64, at most 128 keys and 128 queries per
+// sequence), forward and backward, for the shapes VL-PET trains on: S = 20-40 text + 36 / 72 visual tokens per sample and
+// hundreds of samples per step (encoder self-attention B x 12 heads x 56..92 tokens; decoder self / cross attention with
+// 2-20 queries).  my_transformers/modeling_bart.py:283-566 (BartAttention.forward: q k^T / sqrt(d), + mask, softmax,
+// dropout(p = attention_dropout), . v) computes this with bmm + softmax + dropout + bmm; the generic flash kernels the
+// library path dispatches to are built for long sequences (one 56-token sequence fills less than half of one of their
+// tiles) and took 22 % of the train step at configs[1].
+//
+// Here a workgroup owns one (batch, head) pair and everything stays on chip: K^T Q and V^T P as 32x32x16 MFMAs in the
+// "swapped" form (a lane owns a QUERY: its 16 accumulator registers of a tile are 16 keys, so the softmax over keys is a
+// reduction inside the lane plus one exchange with lane ^ 32), probabilities go straight from the accumulator registers
+// into the next MFMA's B operand, and the V^T / K^T / Q^T / dO^T operands come from row-major LDS images through
+// ds_read_b64_tr_b16.  HBM traffic = the algorithmic minimum: forward reads q, k, v once and writes o (+ 4 B per row of
+// log-sum-exp); backward reads q, k, v, o, do and writes dq, dk, dv.
+//
+// Backward, two phases per workgroup with everything recomputed from q, k, v and the saved log-sum-exp:
+//   phase K (a wave owns a 32-key tile, loops over the query blocks):  S = Q K^T and dP = dO V^T in the UNSWAPPED form (lane
+//     = key, registers = queries), P and dS elementwise, then dV^T += dO^T P, dK^T += Q^T dS (contraction over queries:
+//     B operand = the registers, A operand = transpose-read of the dO / Q image);
+//   phase Q (a wave owns a 32-query block, loops over the key tiles):  the swapped form again, dQ^T += K^T dS.
+// Dropout keeps element (b, h, i, j) iff hash32(row_key(b, h, i) + j * golden) >= p * 2^32: a function of the element index
+// and the call's seed only, so the three places that need the mask regenerate it.
+#include "common.h"
+#include "kernels.h"
+
+#define AT_LD 72                       // bf16 elements per LDS row: 64 + 8 of padding (144 B: 16-byte aligned, conflict-light)
+#define AT_ROW (AT_LD * 2)             // bytes
+#define AT_NW 4                        // waves per workgroup
+#define LOG2E 1.4426950408889634f
+
+typedef short v4s16_t __attribute__((ext_vector_type(4)));
+typedef short v8s16_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// per-row key of the dropout mask: rows are (b, h, i) triples
+__device__ __forceinline__ uint32_t row_key(uint64_t seed, int64_t row) {
+    return hash32((uint32_t)seed ^ (uint32_t)row) ^ hash32((uint32_t)(seed >> 32) + (uint32_t)((uint64_t)row >> 32));
+}
+__device__ __forceinline__ bool keep_elem(uint32_t rk, int j, uint32_t thr) { return hash32(rk + (uint32_t)j * 0x9E3779B9U) >= thr; }
+
+// A operand from a row-major LDS image: lane (c = lane & 31, hh = lane >> 5) gets column cb + c of rows
+// kb + 4 hh + {0..3} (slots 0..3) and kb + 8 + 4 hh + {0..3} (slots 4..7) -- the row order in which a 32x32 accumulator
+// tile hands its registers 8u .. 8u+7 to the next MFMA (accumulator register r of lane half hh is row (r & 3) + 8 (r >> 2) + 4 hh).
+__device__ __forceinline__ bf16x8 tr_acc_order(const uint8_t* img, int kb, int cb, int lane) {
+    const int g = lane >> 4, sl = lane & 15;
+    const uint8_t* p = img + (size_t)(kb + 4 * (g >> 1) + (sl >> 2)) * AT_ROW + (cb + 16 * (g & 1) + 4 * (sl & 3)) * 2;
+    typedef __attribute__((address_space(3))) v4s16_t lds_v4;
+    const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p));
+    const v4s16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 8 * AT_ROW));
+    const v8s16_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+// natural operand: row `row` of the image, 8 consecutive columns at 16 ks + 8 hh
+__device__ __forceinline__ bf16x8 nat_frag(const uint8_t* img, int row, int ks, int hh) {
+    return *reinterpret_cast<const bf16x8*>(img + (size_t)row * AT_ROW + (16 * ks + 8 * hh) * 2);
+}
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& t, int u) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (__bf16)t[8 * u + j];
+    return f;
+}
+// [rows_pad][64] bf16 rows of one (b, h) -> LDS image, rows >= n_rows zero
+__device__ __forceinline__ void stage_image(uint8_t* img, const __bf16* src, int64_t rs, int n_rows, int rows_pad, int tid, int nthreads) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int idx = tid; idx < rows_pad * 8; idx += nthreads) {
+        const int row = idx >> 3, pc = idx & 7;
+        u32x4 v = z;
+        if (row < n_rows) v = *reinterpret_cast<const u32x4*>(src + (int64_t)row * rs + pc * 8);
+        *reinterpret_cast<u32x4*>(img + (size_t)row * AT_ROW + pc * 16) = v;
+    }
+}
+// the same for several images at once with every global load in flight before the first LDS store (a plain per-piece
+// loop compiles to load -> wait -> store per trip: one memory latency per 4 KiB of image)
+template <int NIMG, int MAXP>
+__device__ __forceinline__ void stage_images(uint8_t* const* img, const __bf16* const* src, const int* n_rows, const int* rows_pad,
+                                             int64_t rs, int tid, int nthreads) {
+    u32x4 v[NIMG][MAXP];
+#pragma unroll
+    for (int g = 0; g < NIMG; ++g)
+#pragma unroll
+        for (int c = 0; c < MAXP; ++c) {
+            const int idx = tid + c * nthreads, row = idx >> 3, pc = idx & 7;
+            const int rr = row < n_rows[g] ? row : n_rows[g] - 1;
+            v[g][c] = *reinterpret_cast<const u32x4*>(src[g] + (int64_t)rr * rs + pc * 8);
+        }
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int g = 0; g < NIMG; ++g)
+#pragma unroll
+        for (int c = 0; c < MAXP; ++c) {
+            const int idx = tid + c * nthreads, row = idx >> 3, pc = idx & 7;
+            if (row < rows_pad[g]) *reinterpret_cast<u32x4*>(img[g] + (size_t)row * AT_ROW + pc * 16) = row < n_rows[g] ? v[g][c] : z;
+        }
+}
+// accumulator pair D[d][row] (two 32-wide d tiles; lane = row, registers = d) -> the wave's staging tile -> global rows
+__device__ __forceinline__ void store_rows_T(uint8_t* stg, const f32x16& t0, const f32x16& t1, __bf16* dst, int64_t rs,
+                                             int row0, int n_rows, int lane) {
+    const int m = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const f32x16& t = dt ? t1 : t0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+            bf16x4_t w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (__bf16)t[4 * q + e];
+            *reinterpret_cast<bf16x4_t*>(stg + (size_t)m * AT_ROW + (32 * dt + 8 * q + 4 * hh) * 2) = w;
+        }
+    }
+    // (same-wave LDS accesses are ordered: no barrier)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int idx = lane + 64 * c, row = idx >> 3, pc = idx & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (size_t)row * AT_ROW + pc * 16);
+        if (row0 + row < n_rows) *reinterpret_cast<u32x4*>(dst + (int64_t)(row0 + row) * rs + pc * 8) = v;
+    }
+}
+
+#define AT_FW 2                        // forward: waves per workgroup (each wave owns whole (batch, head) pairs: no barrier)
+
+struct AttnLds {
+    // forward, per wave: V image | staging tile;  backward, per workgroup: Q, dO, K, V images | staging x AT_NW | lse2, delta, row keys
+    __host__ __device__ static constexpr size_t fwd_wave_bytes(int Lkp) { return (size_t)Lkp * AT_ROW + (size_t)32 * AT_ROW; }
+    static size_t fwd_bytes(int Lkp) { return (size_t)AT_FW * fwd_wave_bytes(Lkp); }
+    static size_t bwd_bytes(int Lqp, int Lkp) {
+        return (size_t)2 * (Lqp + Lkp) * AT_ROW + (size_t)AT_NW * 32 * AT_ROW + (size_t)3 * Lqp * 4;
+    }
+};
+
+__device__ __forceinline__ bool key_ok(const AttnArgs& a, const uint8_t* km, int i, int key) {
+    if (key >= a.Lk) return false;
+    if (a.causal && key > i + (a.Lk - a.Lq)) return false;
+    if (km != nullptr && km[key] == 0) return false;
+    return true;
+}
+
+// Forward: a WAVE owns a (batch, head) pair -- its V image and staging tile are private, so nothing is synchronised and a
+// compute unit interleaves ~10 independent waves (the first version gave a pair to a 4-wave workgroup: half the waves had
+// no query block at S = 56, 354 registers kept it at one workgroup per CU, and every workgroup paid load -> barrier -> load
+// latencies in sequence: 208 us per call against 104 for the library kernel).
+template <int T>
+__global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.x * AT_FW + wave;
+    if (bh >= a.B * a.H) return;
+    const int b = bh / a.H, h = bh % a.H;
+    const int m = lane & 31, hh = lane >> 5;
+    constexpr int Lkp = 32 * T;
+    const int64_t rs = (int64_t)a.H * 64;
+    const __bf16* qb_ = a.q + (int64_t)b * a.Lq * rs + h * 64;
+    const __bf16* kb_ = a.k + (int64_t)b * a.Lk * rs + h * 64;
+    const __bf16* vb_ = a.v + (int64_t)b * a.Lk * rs + h * 64;
+    __bf16* ob_ = a.o + (int64_t)b * a.Lq * rs + h * 64;
+    const uint8_t* km = a.key_mask ? a.key_mask + (int64_t)b * a.Lk : nullptr;
+    uint8_t* Vs = smem + (size_t)wave * AttnLds::fwd_wave_bytes(Lkp);
+    uint8_t* stg = Vs + (size_t)Lkp * AT_ROW;
+
+    bf16x8 kf[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int j = 32 * t + m, jk = j < a.Lk ? j : a.Lk - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[t][ks] = *reinterpret_cast<const bf16x8*>(kb_ + (int64_t)jk * rs + 16 * ks + 8 * hh);
+    }
+    stage_image(Vs, vb_, rs, a.Lk, Lkp, lane, 64);
+
+    const float sc2 = a.scale * LOG2E;
+    const int NQB = (a.Lq + 31) >> 5;
+    for (int qb = 0; qb < NQB; ++qb) {
+        const int i = 32 * qb + m;
+        const int iq = i < a.Lq ? i : a.Lq - 1;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qb_ + (int64_t)iq * rs + 16 * ks + 8 * hh);
+        f32x16 st[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            st[t] = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) st[t] = mfma32(kf[t][ks], qf[ks], st[t]);
+        }
+        // ---- softmax over the keys of query i (this lane and lane ^ 32 hold them)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float s = key_ok(a, km, i, key) ? st[t][r] * sc2 : -INFINITY;
+                st[t][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (mx == -INFINITY) mx = 0.f;               // a row with no key to attend to: all-zero probabilities
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float p = exp2f(st[t][r] - mx); st[t][r] = p; sum += p; }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+        if (hh == 0 && i < a.Lq) a.lse[((int64_t)b * a.H + h) * a.Lq + i] = sum > 0.f ? mx + log2f(sum) : INFINITY;
+        // ---- dropout, probabilities -> B operands
+        const uint32_t rk = row_key(a.seed, ((int64_t)b * a.H + h) * a.Lq + iq);
+        f32x16 ot0 = zero16(), ot1 = zero16();
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float p = st[t][r] * inv;
+                if (a.thr != 0) {
+                    const bool kp = keep_elem(rk, key, a.thr);
+                    if (a.keep_out != nullptr && i < a.Lq && key < a.Lk)
+                        a.keep_out[(((int64_t)b * a.H + h) * a.Lq + i) * a.Lk + key] = kp ? 1 : 0;
+                    p = kp ? p * a.inv_keep : 0.f;
+                }
+                st[t][r] = p;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 pf = acc_frag(st[t], u);
+                ot0 = mfma32(tr_acc_order(Vs, 32 * t + 16 * u, 0, lane), pf, ot0);
+                ot1 = mfma32(tr_acc_order(Vs, 32 * t + 16 * u, 32, lane), pf, ot1);
+            }
+        }
+        store_rows_T(stg, ot0, ot1, ob_, rs, 32 * qb, a.Lq, lane);
+    }
+}
+
+// Backward: a workgroup owns a (batch, head) pair (the four images are shared by its waves).  Work units: one per key tile
+// (phase K: dK, dV of the tile) and one per query block (phase Q: dQ of the block), handed out round-robin, so that at
+// S = 56 (two tiles, two blocks) each of the four waves has exactly one and nothing is computed twice.
+__global__ __launch_bounds__(AT_NW * 64, 2) void attn_bwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, hh = lane >> 5;
+    const int Lkp = (a.Lk + 31) & ~31, T = Lkp >> 5;
+    const int Lqp = (a.Lq + 31) & ~31, NQB = Lqp >> 5;
+    const int64_t rs = (int64_t)a.H * 64;
+    const int64_t qoff = (int64_t)b * a.Lq * rs + h * 64, koff = (int64_t)b * a.Lk * rs + h * 64;
+    const uint8_t* km = a.key_mask ? a.key_mask + (int64_t)b * a.Lk : nullptr;
+    uint8_t* Qs = smem;
+    uint8_t* Ds = Qs + (size_t)Lqp * AT_ROW;                     // dO
+    uint8_t* Ks = Ds + (size_t)Lqp * AT_ROW;
+    uint8_t* Vs = Ks + (size_t)Lkp * AT_ROW;
+    uint8_t* stg = Vs + (size_t)Lkp * AT_ROW + (size_t)wave * 32 * AT_ROW;
+    float* lse2 = reinterpret_cast<float*>(Vs + (size_t)Lkp * AT_ROW + (size_t)AT_NW * 32 * AT_ROW);
+    float* dlt = lse2 + Lqp;
+    uint32_t* rks = reinterpret_cast<uint32_t*>(dlt + Lqp);
+
+    {
+        // delta[i] = sum_d dO[i][d] O[i][d]: four threads per row, 128 rows at most = two rows per thread quad; loads first
+        bf16x8 xo[2][2], xd[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int idx = tid + c * AT_NW * 64, row = idx >> 2, part = idx & 3;
+            const int rr = row < a.Lq ? row : a.Lq - 1;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                xo[c][e] = *reinterpret_cast<const bf16x8*>(a.o + qoff + (int64_t)rr * rs + 16 * part + 8 * e);
+                xd[c][e] = *reinterpret_cast<const bf16x8*>(a.dout + qoff + (int64_t)rr * rs + 16 * part + 8 * e);
+            }
+        }
+        uint8_t* const imgs[4] = {Qs, Ds, Ks, Vs};
+        const __bf16* const srcs[4] = {a.q + qoff, a.dout + qoff, a.k + koff, a.v + koff};
+        const int nr[4] = {a.Lq, a.Lq, a.Lk, a.Lk}, rp[4] = {Lqp, Lqp, Lkp, Lkp};
+        stage_images<4, 4>(imgs, srcs, nr, rp, rs, tid, AT_NW * 64);          // 128 rows x 8 pieces / 256 threads = 4 per image
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int idx = tid + c * AT_NW * 64, row = idx >> 2, part = idx & 3;
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += (float)xo[c][e][j] * (float)xd[c][e][j];
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if (part == 0 && row < Lqp) {
+                const bool live = row < a.Lq;
+                dlt[row] = live ? acc : 0.f;
+                lse2[row] = live ? a.lse[((int64_t)b * a.H + h) * a.Lq + row] : INFINITY;
+                rks[row] = row_key(a.seed, ((int64_t)b * a.H + h) * a.Lq + (live ? row : a.Lq - 1));
+            }
+        }
+    }
+    __syncthreads();
+
+    const float sc2 = a.scale * LOG2E;
+    for (int un = wave; un < T + NQB; un += AT_NW) {
+        if (un < T) {
+            // ============================================= phase K: key tile t (lane = key, registers = queries)
+            const int t = un;
+            const int key = 32 * t + m;
+            bf16x8 kf[4], vf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { kf[ks] = nat_frag(Ks, key, ks, hh); vf[ks] = nat_frag(Vs, key, ks, hh); }
+            f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
+            for (int qb = 0; qb < NQB; ++qb) {
+                f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s = mfma32(nat_frag(Qs, 32 * qb + m, ks, hh), kf[ks], s);        // D[query][key]
+                    dp = mfma32(nat_frag(Ds, 32 * qb + m, ks, hh), vf[ks], dp);
+                }
+                f32x16 pd, ds;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = 32 * qb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const bool ok = i < a.Lq && key_ok(a, km, i, key);
+                    const float p = ok ? exp2f(s[r] * sc2 - lse2[i]) : 0.f;
+                    float g = dp[r];
+                    float pdrop = p;
+                    if (a.thr != 0) {
+                        const bool kp = keep_elem(rks[i], key, a.thr);
+                        pdrop = kp ? p * a.inv_keep : 0.f;
+                        g = kp ? g * a.inv_keep : 0.f;
+                    }
+                    pd[r] = pdrop;
+                    ds[r] = p * (g - dlt[i]) * a.scale;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bf16x8 pf = acc_frag(pd, u), sf = acc_frag(ds, u);
+                    dv0 = mfma32(tr_acc_order(Ds, 32 * qb + 16 * u, 0, lane), pf, dv0);   // D[d][key] += dO^T P
+                    dv1 = mfma32(tr_acc_order(Ds, 32 * qb + 16 * u, 32, lane), pf, dv1);
+                    dk0 = mfma32(tr_acc_order(Qs, 32 * qb + 16 * u, 0, lane), sf, dk0);   // D[d][key] += Q^T dS
+                    dk1 = mfma32(tr_acc_order(Qs, 32 * qb + 16 * u, 32, lane), sf, dk1);
+                }
+            }
+            store_rows_T(stg, dv0, dv1, a.dv + koff, rs, 32 * t, a.Lk, lane);
+            store_rows_T(stg, dk0, dk1, a.dk + koff, rs, 32 * t, a.Lk, lane);
+        } else {
+            // ============================================= phase Q: query block qb (lane = query, registers = keys)
+            const int qb = un - T;
+            const int i = 32 * qb + m;
+            bf16x8 qf[4], df[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { qf[ks] = nat_frag(Qs, i, ks, hh); df[ks] = nat_frag(Ds, i, ks, hh); }
+            const float l2 = lse2[i], dl = dlt[i];
+            const uint32_t rk = rks[i];
+            f32x16 dq0 = zero16(), dq1 = zero16();
+            for (int t = 0; t < T; ++t) {
+                f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    s = mfma32(nat_frag(Ks, 32 * t + m, ks, hh), qf[ks], s);             // D[key][query]
+                    dp = mfma32(nat_frag(Vs, 32 * t + m, ks, hh), df[ks], dp);
+                }
+                f32x16 ds;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const bool ok = i < a.Lq && key_ok(a, km, i, key);
+                    const float p = ok ? exp2f(s[r] * sc2 - l2) : 0.f;
+                    float g = dp[r];
+                    if (a.thr != 0) g = keep_elem(rk, key, a.thr) ? g * a.inv_keep : 0.f;
+                    ds[r] = p * (g - dl) * a.scale;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bf16x8 sf = acc_frag(ds, u);
+                    dq0 = mfma32(tr_acc_order(Ks, 32 * t + 16 * u, 0, lane), sf, dq0);    // D[d][query] += K^T dS
+                    dq1 = mfma32(tr_acc_order(Ks, 32 * t + 16 * u, 32, lane), sf, dq1);
+                }
+            }
+            store_rows_T(stg, dq0, dq1, a.dq + qoff, rs, 32 * qb, a.Lq, lane);
+        }
+    }
+}
+
+size_t attn_lds_bytes(int Lq, int Lk, int bwd) {
+    const int Lqp = (Lq + 31) & ~31, Lkp = (Lk + 31) & ~31;
+    return bwd ? AttnLds::bwd_bytes(Lqp, Lkp) : AttnLds::fwd_bytes(Lkp);
+}
+
+template <int T>
+static hipError_t launch_attn_fwd_t(const AttnArgs& a, hipStream_t stream) {
+    const size_t lds = AttnLds::fwd_bytes(32 * T);
+    auto kern = attn_fwd_kernel<T>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const unsigned pairs = (unsigned)(a.B * a.H);
+    hipLaunchKernelGGL(kern, dim3((pairs + AT_FW - 1) / AT_FW), dim3(AT_FW * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_attn(const AttnArgs& a, bool bwd, hipStream_t stream) {
+    if (!bwd) {
+        switch ((a.Lk + 31) >> 5) {
+            case 1: return launch_attn_fwd_t<1>(a, stream);
+            case 2: return launch_attn_fwd_t<2>(a, stream);
+            case 3: return launch_attn_fwd_t<3>(a, stream);
+            case 4: return launch_attn_fwd_t<4>(a, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    const size_t lds = attn_lds_bytes(a.Lq, a.Lk, 1);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(a.B * a.H)), dim3(AT_NW * 64), lds, stream, a);
+    return hipGetLastError();
+}

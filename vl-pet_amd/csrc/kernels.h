@@ -267,3 +267,21 @@ struct CeArgs {
     int V, ld;
 };
 hipError_t launch_ce(const CeArgs& a, bool bwd, int io_fp32, hipStream_t stream);
+
+// short-sequence attention of the backbone (attn.hip): bf16, head dim 64, Lq, Lk <= 128; tensors [B, L, H, 64] contiguous
+struct AttnArgs {
+    const __bf16* q; const __bf16* k; const __bf16* v;
+    __bf16* o;              // forward output; backward: the forward's output (read)
+    float* lse;             // [B, H, Lq] log2-domain log-sum-exp of the scaled scores (written fwd, read bwd)
+    const __bf16* dout;     // backward
+    __bf16* dq; __bf16* dk; __bf16* dv;
+    const uint8_t* key_mask;   // [B, Lk] 1 = attend, or nullptr
+    uint8_t* keep_out;      // forward only: optional [B, H, Lq, Lk] export of the dropout mask (tests)
+    int B, H, Lq, Lk, causal;
+    float scale;
+    uint32_t thr;           // drop iff hash < thr (p * 2^32); 0 = no dropout
+    float inv_keep;
+    uint64_t seed;
+};
+size_t attn_lds_bytes(int Lq, int Lk, int bwd);
+hipError_t launch_attn(const AttnArgs& a, bool bwd, hipStream_t stream);

@@ -173,6 +173,28 @@ def _sdpa_ctx():
                         "math": SDPBackend.MATH}[which])
 
 
+def attention_core(q, k, v, num_heads, attn_mask, causal, p, training):
+    """``dropout(softmax(q k^T / sqrt(d) + mask), p) v`` on the projection outputs ``[B, L, H * d]``.  Sequences of at most
+    128 tokens in bf16 with head dim 64 (every image-text shape) run on vlpet_amd.attention's on-chip kernels; anything
+    else (fp32 parity runs, the 664-token video encoder, non-boolean masks) on torch's SDPA.  The parity / CPU-baseline
+    harnesses swap this module attribute for the eager chain."""
+    from .. import attention as A
+    B, Lq, E = q.shape
+    boolean_key_mask = attn_mask is None or (attn_mask.dtype == torch.bool and attn_mask.dim() == 4
+                                             and attn_mask.shape[1] == 1 and attn_mask.shape[2] == 1)
+    if not EAGER_ATTENTION and boolean_key_mask and A.supported(q, k, num_heads):
+        km = None if attn_mask is None else attn_mask[:, 0, 0, :]
+        return A.short_attention(q, k, v, num_heads, km, causal and attn_mask is None, p, training)
+    sh = lambda t: t.view(B, -1, num_heads, E // num_heads).transpose(1, 2)
+    with _sdpa_ctx():
+        out = F.scaled_dot_product_attention(sh(q), sh(k), sh(v), attn_mask=attn_mask, is_causal=causal and attn_mask is None,
+                                             dropout_p=p if training else 0.0)
+    return out.transpose(1, 2).reshape(B, Lq, E)
+
+
+EAGER_ATTENTION = _os.environ.get("VLPET_EAGER_ATTENTION", "0") == "1"   # A/B switch: the library (SDPA) path for every shape
+
+
 class BartAttention(nn.Module):
     """Multi-head attention; optional LoRA on q/v (my_transformers/modeling_bart.py:738-879) and optional
     value-parallel adapter on the cross-attention value (:283-566, use at :427-430)."""
@@ -216,11 +238,7 @@ class BartAttention(nn.Module):
         k = _linear(self.k_proj, src)
         if kv is not None and self.attn_value_parallel_adapter is not None:
             v = self.attn_value_parallel_adapter(src, task, y=v)
-        with _sdpa_ctx():
-            out = F.scaled_dot_product_attention(self._shape(q, B), self._shape(k, B), self._shape(v, B),
-                                                 attn_mask=attn_mask, is_causal=causal and attn_mask is None,
-                                                 dropout_p=self.dropout if self.training else 0.0)
-        out = out.transpose(1, 2).reshape(B, L, self.embed_dim)
+        out = attention_core(q, k, v, self.num_heads, attn_mask, causal, self.dropout, self.training)
         return _linear(self.out_proj, out)
 
 
