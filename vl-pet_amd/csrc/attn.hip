@@ -20,6 +20,7 @@
 //   phase Q (a wave owns a 32-query block, loops over the key tiles):  the swapped form again, dQ^T += K^T dS.
 // Dropout keeps element (b, h, i, j) iff hash32(row_key(b, h, i) + j * golden) >= p * 2^32: a function of the element index
 // and the call's seed only, so the three places that need the mask regenerate it.
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -30,6 +31,8 @@
 
 typedef short v4s16_t __attribute__((ext_vector_type(4)));
 typedef short v8s16_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32: arguments here are <= 0 or -inf
 
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -96,7 +99,9 @@ __device__ __forceinline__ void stage_images(uint8_t* const* img, const __bf16* 
             if (row < rows_pad[g]) *reinterpret_cast<u32x4*>(img[g] + (size_t)row * AT_ROW + pc * 16) = row < n_rows[g] ? v[g][c] : z;
         }
 }
-// accumulator pair D[d][row] (two 32-wide d tiles; lane = row, registers = d) -> the wave's staging tile -> global rows
+// accumulator pair D[d][row] (two 32-wide d tiles; lane = row, registers = d) -> global rows, one d tile at a time through the
+// wave's 32 x 64 B staging tile (80-byte rows)
+#define AT_SROW 80
 __device__ __forceinline__ void store_rows_T(uint8_t* stg, const f32x16& t0, const f32x16& t1, __bf16* dst, int64_t rs,
                                              int row0, int n_rows, int lane) {
     const int m = lane & 31, hh = lane >> 5;
@@ -109,26 +114,26 @@ __device__ __forceinline__ void store_rows_T(uint8_t* stg, const f32x16& t0, con
             bf16x4_t w;
 #pragma unroll
             for (int e = 0; e < 4; ++e) w[e] = (__bf16)t[4 * q + e];
-            *reinterpret_cast<bf16x4_t*>(stg + (size_t)m * AT_ROW + (32 * dt + 8 * q + 4 * hh) * 2) = w;
+            *reinterpret_cast<bf16x4_t*>(stg + (size_t)m * AT_SROW + (8 * q + 4 * hh) * 2) = w;
         }
-    }
-    // (same-wave LDS accesses are ordered: no barrier)
+        // (same-wave LDS accesses are ordered: no barrier)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int idx = lane + 64 * c, row = idx >> 3, pc = idx & 7;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (size_t)row * AT_ROW + pc * 16);
-        if (row0 + row < n_rows) *reinterpret_cast<u32x4*>(dst + (int64_t)(row0 + row) * rs + pc * 8) = v;
+        for (int c = 0; c < 2; ++c) {
+            const int idx = lane + 64 * c, row = idx >> 2, pc = idx & 3;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (size_t)row * AT_SROW + pc * 16);
+            if (row0 + row < n_rows) *reinterpret_cast<u32x4*>(dst + (int64_t)(row0 + row) * rs + 32 * dt + pc * 8) = v;
+        }
     }
 }
 
 #define AT_FW 2                        // forward: waves per workgroup (each wave owns whole (batch, head) pairs: no barrier)
 
 struct AttnLds {
-    // forward, per wave: V image | staging tile;  backward, per workgroup: Q, dO, K, V images | staging x AT_NW | lse2, delta, row keys
-    __host__ __device__ static constexpr size_t fwd_wave_bytes(int Lkp) { return (size_t)Lkp * AT_ROW + (size_t)32 * AT_ROW; }
+    // forward, per wave: V image | staging tile;  backward, per workgroup: Q, dO, K, V images | staging x AT_NW | per-row {lse2, delta, row key}
+    __host__ __device__ static constexpr size_t fwd_wave_bytes(int Lkp) { return (size_t)Lkp * AT_ROW + (size_t)32 * AT_SROW; }
     static size_t fwd_bytes(int Lkp) { return (size_t)AT_FW * fwd_wave_bytes(Lkp); }
     static size_t bwd_bytes(int Lqp, int Lkp) {
-        return (size_t)2 * (Lqp + Lkp) * AT_ROW + (size_t)AT_NW * 32 * AT_ROW + (size_t)3 * Lqp * 4;
+        return (size_t)2 * (Lqp + Lkp) * AT_ROW + (size_t)AT_NW * 32 * AT_SROW + (size_t)Lqp * 16;
     }
 };
 
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
 #pragma unroll
         for (int t = 0; t < T; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float p = exp2f(st[t][r] - mx); st[t][r] = p; sum += p; }
+            for (int r = 0; r < 16; ++r) { const float p = fast_exp2(st[t][r] - mx); st[t][r] = p; sum += p; }
         }
         sum += __shfl_xor(sum, 32);
         const float inv = sum > 0.f ? 1.0f / sum : 0.f;
@@ -239,7 +244,8 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
 // Backward: a workgroup owns a (batch, head) pair (the four images are shared by its waves).  Work units: one per key tile
 // (phase K: dK, dV of the tile) and one per query block (phase Q: dQ of the block), handed out round-robin, so that at
 // S = 56 (two tiles, two blocks) each of the four waves has exactly one and nothing is computed twice.
-__global__ __launch_bounds__(AT_NW * 64, 2) void attn_bwd_kernel(AttnArgs a) {
+template <int OCC>
+__global__ __launch_bounds__(AT_NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -253,10 +259,8 @@ __global__ __launch_bounds__(AT_NW * 64, 2) void attn_bwd_kernel(AttnArgs a) {
     uint8_t* Ds = Qs + (size_t)Lqp * AT_ROW;                     // dO
     uint8_t* Ks = Ds + (size_t)Lqp * AT_ROW;
     uint8_t* Vs = Ks + (size_t)Lkp * AT_ROW;
-    uint8_t* stg = Vs + (size_t)Lkp * AT_ROW + (size_t)wave * 32 * AT_ROW;
-    float* lse2 = reinterpret_cast<float*>(Vs + (size_t)Lkp * AT_ROW + (size_t)AT_NW * 32 * AT_ROW);
-    float* dlt = lse2 + Lqp;
-    uint32_t* rks = reinterpret_cast<uint32_t*>(dlt + Lqp);
+    uint8_t* stg = Vs + (size_t)Lkp * AT_ROW + (size_t)wave * 32 * AT_SROW;
+    f32x4* rowv = reinterpret_cast<f32x4*>(Vs + (size_t)Lkp * AT_ROW + (size_t)AT_NW * 32 * AT_SROW);   // per query row: {lse2, delta, row key, -}
 
     {
         // delta[i] = sum_d dO[i][d] O[i][d]: four threads per row, 128 rows at most = two rows per thread quad; loads first
@@ -287,9 +291,12 @@ __global__ __launch_bounds__(AT_NW * 64, 2) void attn_bwd_kernel(AttnArgs a) {
             acc += __shfl_xor(acc, 2);
             if (part == 0 && row < Lqp) {
                 const bool live = row < a.Lq;
-                dlt[row] = live ? acc : 0.f;
-                lse2[row] = live ? a.lse[((int64_t)b * a.H + h) * a.Lq + row] : INFINITY;
-                rks[row] = row_key(a.seed, ((int64_t)b * a.H + h) * a.Lq + (live ? row : a.Lq - 1));
+                f32x4 rv;
+                rv[0] = live ? a.lse[((int64_t)b * a.H + h) * a.Lq + row] : INFINITY;
+                rv[1] = live ? acc : 0.f;
+                rv[2] = __uint_as_float(row_key(a.seed, ((int64_t)b * a.H + h) * a.Lq + (live ? row : a.Lq - 1)));
+                rv[3] = 0.f;
+                rowv[row] = rv;
             }
         }
     }
@@ -316,17 +323,18 @@ __global__ __launch_bounds__(AT_NW * 64, 2) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = 32 * qb + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const bool ok = i < a.Lq && key_ok(a, km, i, key);
-                    const float p = ok ? exp2f(s[r] * sc2 - lse2[i]) : 0.f;
+                    const f32x4 rv = rowv[i];                                        // (rows >= Lq: lse2 = +inf -> p = 0)
+                    const bool ok = key_ok(a, km, i, key);
+                    const float p = ok ? fast_exp2(s[r] * sc2 - rv[0]) : 0.f;
                     float g = dp[r];
                     float pdrop = p;
                     if (a.thr != 0) {
-                        const bool kp = keep_elem(rks[i], key, a.thr);
+                        const bool kp = keep_elem(__float_as_uint(rv[2]), key, a.thr);
                         pdrop = kp ? p * a.inv_keep : 0.f;
                         g = kp ? g * a.inv_keep : 0.f;
                     }
                     pd[r] = pdrop;
-                    ds[r] = p * (g - dlt[i]) * a.scale;
+                    ds[r] = p * (g - rv[1]) * a.scale;
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -346,8 +354,9 @@ __global__ __launch_bounds__(AT_NW * 64, 2) void attn_bwd_kernel(AttnArgs a) {
             bf16x8 qf[4], df[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { qf[ks] = nat_frag(Qs, i, ks, hh); df[ks] = nat_frag(Ds, i, ks, hh); }
-            const float l2 = lse2[i], dl = dlt[i];
-            const uint32_t rk = rks[i];
+            const f32x4 rvq = rowv[i];
+            const float l2 = rvq[0], dl = rvq[1];
+            const uint32_t rk = __float_as_uint(rvq[2]);
             f32x16 dq0 = zero16(), dq1 = zero16();
             for (int t = 0; t < T; ++t) {
                 f32x16 s = zero16(), dp = zero16();
@@ -360,8 +369,8 @@ __global__ __launch_bounds__(AT_NW * 64, 2) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const bool ok = i < a.Lq && key_ok(a, km, i, key);
-                    const float p = ok ? exp2f(s[r] * sc2 - l2) : 0.f;
+                    const bool ok = key_ok(a, km, i, key);
+                    const float p = ok ? fast_exp2(s[r] * sc2 - l2) : 0.f;
                     float g = dp[r];
                     if (a.thr != 0) g = keep_elem(rk, key, a.thr) ? g * a.inv_keep : 0.f;
                     ds[r] = p * (g - dl) * a.scale;
@@ -405,8 +414,12 @@ hipError_t launch_attn(const AttnArgs& a, bool bwd, hipStream_t stream) {
         }
     }
     const size_t lds = attn_lds_bytes(a.Lq, a.Lk, 1);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const int occ_env = [] { const char* e = getenv("VLPET_ATTN_OCC"); return e ? atoi(e) : 0; }();
+    const bool occ3 = occ_env == 3;      // (3 spills 40 registers and measured slower: 166 vs 151 us at B = 500, S = 56)
+    const void* kern = occ3 ? reinterpret_cast<const void*>(attn_bwd_kernel<3>) : reinterpret_cast<const void*>(attn_bwd_kernel<2>);
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(a.B * a.H)), dim3(AT_NW * 64), lds, stream, a);
+    if (occ3) hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3((unsigned)(a.B * a.H)), dim3(AT_NW * 64), lds, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3((unsigned)(a.B * a.H)), dim3(AT_NW * 64), lds, stream, a);
     return hipGetLastError();
 }
