@@ -10,7 +10,7 @@
 // No LDS transpose, no strided global access.  The next 32-row block is loaded while the current one
 // is in the MFMAs (register double buffer).  Row-chunk partials are written to a workspace and summed
 // by wgrad_finalize (deterministic: no atomics).
-#include "common.h"
+#include "pet16.h"      // common.h + glds16
 #include <cstdlib>
 #include <type_traits>
 #include "kernels.h"
@@ -21,11 +21,14 @@ size_t wgrad_workspace_bytes(int njobs, int RT, int xcols_max, int row_chunks) {
 }
 
 void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* rows_per_chunk) {
-    const int slices = xcols_max / 64;
+    // The streaming kernel's workgroups are (job, 256-column slab, row chunk); the row chunks are what the partial-sum
+    // workspace (and the finalize pass) scales with, so the plan takes as few as fill the chip: by default one workgroup
+    // per CU (VLPET_WGRAD_WGS overrides; the 64-column-slice kernels of the fp32 / masked paths get 4x as many workgroups
+    // from the same plan).
+    const int slabs = (xcols_max + 255) / 256;
     int64_t blocks128 = (M + 127) / 128;
-    // 768 workgroups = three per CU in a single round (measured best of 256..2048 at M = 28k; VLPET_WGRAD_WGS overrides)
-    static const int64_t target = [] { const char* e = getenv("VLPET_WGRAD_WGS"); return e ? (int64_t)atoi(e) : (int64_t)768; }();
-    int64_t rc = (target + (int64_t)slices * njobs - 1) / ((int64_t)slices * njobs);
+    static const int64_t target = [] { const char* e = getenv("VLPET_WGRAD_WGS"); return e ? (int64_t)atoi(e) : (int64_t)256; }();
+    int64_t rc = (target + (int64_t)slabs * njobs / 2) / ((int64_t)slabs * njobs);
     if (rc < 1) rc = 1;
     if (rc > blocks128) rc = blocks128;
     int64_t per = (blocks128 + rc - 1) / rc;          // 128-row blocks per chunk
@@ -462,75 +465,337 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_tr_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 streaming form (round 3): the op is a split-K GEMM with a 4-byte-per-flop appetite -- at M = 28 k the four jobs of
+// a K1 call read 172 MB and do 16.5 GFLOP, i.e. HBM-bound by a factor of 4 -- so the kernel is built as a stream:
+//   * a workgroup owns (job, 256-column slab of X, row chunk); wave w owns 64 columns of the slab and ALL 32*RT columns of
+//     P: no cross-wave reduction at the end, the P tile is fetched once per workgroup (a quarter of the L2 -> LDS traffic
+//     of the 64-column slices above), X rows arrive as 512 contiguous bytes per row;
+//   * every tile travels global -> LDS by global_load_lds (no staging registers) into an NSTG-deep ring, NSTG - 1 steps
+//     of 32 rows in flight per wave (counted vmcnt; one s_barrier per step for the shared P tile);
+//   * operands come out of the row-major tiles with ds_read_b64_tr_b16 (tr_operand above).  The 128-byte rows of the X
+//     sub-tiles are swizzled on the SOURCE side (16-byte slot ^= 4 for rows with bit 1 set) so that the four rows a
+//     32-lane group reads fall into four different 64-byte bank windows; the 64 / 192-byte rows of P do so natively,
+//     the 128 / 384-byte ones (even RT) get the same swizzle.
+// Partials and finalize as above (same workspace layout); rows past the end of the chunk are zeroed in LDS.
+// The LDS reads of the streaming kernel are inline asm: hipcc orders every LDS read it can see behind ALL outstanding
+// global_load_lds of the wave (s_waitcnt vmcnt(0) before the first ds_read of a step -- which would wait for the stages just
+// requested and serialise the ring).  The counted vmcnt of the stage is issued by hand (wgs_wait), and so is the lgkmcnt
+// before the MFMAs (tr_fence ties the operand registers to the wait so that no MFMA is scheduled above it).
+typedef int v2i32 __attribute__((ext_vector_type(2)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+struct TrOp { v2i32 lo, hi; };
+template <int OFF_LO, int OFF_HI>
+__device__ __forceinline__ void tr_read(TrOp& o, uint32_t lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(o.lo) : "v"(lds_addr), "n"(OFF_LO) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(o.hi) : "v"(lds_addr), "n"(OFF_HI) : "memory");
+}
+__device__ __forceinline__ void tr_fence(TrOp& a) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.lo), "+v"(a.hi) :: "memory");
+}
+__device__ __forceinline__ void tr_tie(TrOp& a) {            // no instruction: the operand is only usable after the preceding fence
+    asm volatile("" : "+v"(a.lo), "+v"(a.hi) :: "memory");
+}
+__device__ __forceinline__ bf16x8 tr_val(const TrOp& a) {
+    const v4i32 r = {a.lo[0], a.lo[1], a.hi[0], a.hi[1]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int N> __device__ __forceinline__ void wgs_wait_n() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter on gfx950");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+// at most `pending` later stages (NI instructions each) may still be in flight
+template <int NI, int MAXP>
+__device__ __forceinline__ void wgs_wait(int pending) {
+    if (pending <= 0) wgs_wait_n<0>();
+    else if (pending == 1 || MAXP == 1) wgs_wait_n<NI>();
+    else if (pending == 2 || MAXP == 2) wgs_wait_n<2 * NI>();
+    else wgs_wait_n<3 * NI>();
+}
+
+template <int RT> struct WgsGeo {
+    static constexpr int PB = 64 * RT;                 // bytes of a P row
+    static constexpr int NPR = PB / 16;                // 16-byte slots per P row
+    static constexpr int NPI = 2 * RT;                 // 1 KiB pieces of a 32-row P tile
+    static constexpr int PPW = (NPI + 3) / 4;          // pieces per wave (the last ones may be padding)
+    static constexpr int PT_B = PPW * 4 * 1024;        // P region of a stage
+    static constexpr int XT_B = 32 * 128;              // one wave's X sub-tile
+    static constexpr int STG_B = PT_B + 4 * XT_B;
+    static constexpr int NI = PPW + 4;                 // global_load_lds instructions per wave and stage
+    static constexpr bool PSWZ = (RT % 2) == 0;
+};
+
+template <int RT, int NSTG>
+__global__ __launch_bounds__(VLPET_THREADS, (RT <= 3 ? 2 : 1)) void wgrad_stream_kernel(WgradArgs a) {
+    using GEO = WgsGeo<RT>;
+    constexpr int PR = 32 * RT;
+    constexpr int PB = GEO::PB, NPR = GEO::NPR, PPW = GEO::PPW, NI = GEO::NI;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const WgId wg = wg_decode(a, a.nslice);            // nslice = 256-column slabs of the widest job
+    if (!wg.ok) return;
+    const int jb = wg.job;
+    // one batch of scalar loads for everything the prologue needs (dependent kernel-argument loads cost ~1.5 us each)
+    const uint8_t* P = reinterpret_cast<const uint8_t*>(a.job[jb].P);
+    const uint8_t* X = reinterpret_cast<const uint8_t*>(a.job[jb].X);
+    const int ldp_ = a.job[jb].ldp, ldx_ = a.job[jb].ldx;
+    const int xc = a.job[jb].xcols;
+    const int64_t rpc_ = a.rows_per_chunk, M_ = a.M;
+    asm volatile("" :: "s"(P), "s"(X), "s"(ldp_), "s"(ldx_), "s"(xc), "s"(rpc_), "s"(M_));
+    const int64_t ldpb = (int64_t)ldp_ * 2, ldxb = (int64_t)ldx_ * 2;
+    if (wg.slice * 256 >= xc) return;
+    const int rc = wg.rc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    const int n0 = wg.slice * 256 + wave * 64;
+    const bool active = n0 < xc;                       // wave-uniform
+    const bool want_csp = wg.slice == 0 && wave == 0;
+    const int64_t r_begin = (int64_t)rc * rpc_;
+    int64_t r_end = r_begin + rpc_;
+    if (r_end > M_) r_end = M_;
+    const int nsteps = r_end > r_begin ? (int)((r_end - r_begin + 31) >> 5) : 0;
+
+    // per-lane source geometry of the stage pieces
+    const int xrow = lane >> 3;                                                   // + 8 i
+    const int xsrc = (((lane & 7) ^ (4 * ((lane >> 4) & 1))) * 16) + (active ? n0 : 0) * 2;
+    int prow[PPW], psrc[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int q = 64 * (wave + 4 * j) + lane;
+        prow[j] = q / NPR;
+        int slot = q % NPR;
+        if (GEO::PSWZ) slot ^= 4 * ((prow[j] >> 1) & 1);
+        psrc[j] = slot * 16;
+    }
+    auto issue = [&](int s) {
+        const int64_t rb = r_begin + 32 * (int64_t)s;
+        uint8_t* st = smem + (size_t)(s % NSTG) * GEO::STG_B;
+#ifdef VLPET_WGRAD_EXP
+        if (!(a.RT & 0x400))
+#endif
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            int64_t row = rb + prow[j];
+            if (row >= r_end) row = r_end - 1;
+            glds16(P + row * ldpb + psrc[j], st + (size_t)(wave + 4 * j) * 1024);
+        }
+        uint8_t* sx_ = st + GEO::PT_B + (size_t)wave * GEO::XT_B;
+#ifdef VLPET_WGRAD_EXP
+        if (!(a.RT & 0x800))
+#endif
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t row = rb + 8 * i + xrow;
+            if (row >= r_end) row = r_end - 1;
+            glds16(X + row * ldxb + xsrc, sx_ + i * 1024);
+        }
+    };
+
+    // per-lane LDS byte addresses of the transpose reads (k-step 0, rows 8h + (sl >> 2); the k-step and the +4 rows of the
+    // second read are instruction offsets): lane (g = lane >> 4, sl = lane & 15) supplies 8 bytes of row .. at column
+    // bytes 32 (g & 1) + 8 (sl & 3) of the 64-byte tile column ct / nt, XOR-swizzled by bit 1 of the row where the tile is
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    uint32_t xa[2], pa[RT];
+    {
+        const int g = lane >> 4, sl = lane & 15;
+        const int row = 8 * (g >> 1) + (sl >> 2), bit = (row >> 1) & 1, lp = 32 * (g & 1) + 8 * (sl & 3);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            xa[nt] = (uint32_t)(GEO::PT_B + wave * GEO::XT_B + row * 128 + 64 * (nt ^ bit) + lp);
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct)
+            pa[ct] = (uint32_t)(row * PB + 64 * (GEO::PSWZ ? (ct ^ bit) : ct) + lp);
+    }
+
+    f32x16 acc[RT][2];
+    f32x16 sx = zero16(), sp = zero16();
+#pragma unroll
+    for (int ct = 0; ct < RT; ++ct) { acc[ct][0] = zero16(); acc[ct][1] = zero16(); }
+    bf16x8 erow[RT > 2 ? RT : 2];
+#pragma unroll
+    for (int t = 0; t < (RT > 2 ? RT : 2); ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) erow[t][j] = (m == t) ? (__bf16)1.0f : (__bf16)0.0f;
+
+#pragma unroll
+    for (int s = 0; s < NSTG - 1; ++s)
+        if (s < nsteps) issue(s);
+
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+        int pending = nsteps - 1 - s;
+        if (pending > NSTG - 2) pending = NSTG - 2;
+        wgs_wait<NI, NSTG - 2>(pending);
+        uint8_t* st = smem + (size_t)(s % NSTG) * GEO::STG_B;
+        uint8_t* tx = st + GEO::PT_B + (size_t)wave * GEO::XT_B;
+        const int valid = (int)(r_end - (r_begin + 32 * (int64_t)s));            // rows of this step that exist
+        const bool tail = valid < 32;
+        if (tail) {                                                               // own X pieces have landed: zero the missing rows
+            const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (8 * i + xrow >= valid) *reinterpret_cast<u32x4*>(tx + (size_t)i * 1024 + lane * 16) = z;
+        }
+        __builtin_amdgcn_s_barrier();
+        if (s + NSTG - 1 < nsteps) issue(s + NSTG - 1);
+        if (tail) {                                                               // everybody's P pieces have landed
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            for (int q = tid; q < 32 * NPR; q += VLPET_THREADS)
+                if (q / NPR >= valid) *reinterpret_cast<u32x4*>(st + (size_t)q * 16) = z;
+            __syncthreads();
+        }
+#ifdef VLPET_WGRAD_EXP
+        if (a.RT & 0x200) continue;                  // experiment: the stream without the products
+#endif
+        if (active) {
+            const uint32_t sb = lds0 + (uint32_t)((s % NSTG) * GEO::STG_B);
+            TrOp bx[2][2], ap[2][RT];
+            auto reads = [&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
+                tr_read<16 * ks * 128, (16 * ks + 4) * 128>(bx[ks][0], sb + xa[0]);
+                tr_read<16 * ks * 128, (16 * ks + 4) * 128>(bx[ks][1], sb + xa[1]);
+#pragma unroll
+                for (int ct = 0; ct < RT; ++ct) tr_read<16 * ks * PB, (16 * ks + 4) * PB>(ap[ks][ct], sb + pa[ct]);
+            };
+            auto products = [&](int ks, bool fenced_first) {
+                if (!fenced_first) tr_tie(bx[ks][0]);
+                tr_tie(bx[ks][1]);
+                const bf16x8 b0 = tr_val(bx[ks][0]), b1 = tr_val(bx[ks][1]);
+                sx = mfma32(erow[0], b0, sx);
+                sx = mfma32(erow[1], b1, sx);
+#pragma unroll
+                for (int ct = 0; ct < RT; ++ct) {
+                    tr_tie(ap[ks][ct]);
+                    const bf16x8 av = tr_val(ap[ks][ct]);
+                    acc[ct][0] = mfma32(av, b0, acc[ct][0]);
+                    acc[ct][1] = mfma32(av, b1, acc[ct][1]);
+                    if (want_csp) sp = mfma32(erow[ct], av, sp);
+                }
+            };
+            if constexpr (RT <= 3) {                 // both k-steps' operands requested before the first product
+                reads(std::integral_constant<int, 0>{});
+                reads(std::integral_constant<int, 1>{});
+                tr_fence(bx[0][0]);
+                products(0, true);
+                products(1, false);
+            } else {                                 // 12 accumulator tiles: one k-step's operands at a time
+                reads(std::integral_constant<int, 0>{});
+                tr_fence(bx[0][0]);
+                products(0, true);
+                reads(std::integral_constant<int, 1>{});
+                tr_fence(bx[1][0]);
+                products(1, true);
+            }
+        }
+    }
+
+    if (!active) return;
+#ifdef VLPET_WGRAD_EXP
+    if ((a.RT & 0x100) && acc[0][0][0] != 123.456f) return;      // experiment: no partial stores
+    a.RT &= 0xff;
+#endif
+    const WgradLayout L = wgrad_layout(a);
+    float* part = a.partial + L.off[jb];
+    float* tile = part + (int64_t)rc * PR * xc;
+#pragma unroll
+    for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int crow = 32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h;
+                tile[(int64_t)crow * xc + n0 + 32 * nt + m] = acc[ct][nt][i];
+            }
+    float* psx = part + (int64_t)a.row_chunks * PR * xc + (int64_t)rc * xc;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+        if (h == 0) psx[n0 + 32 * nt + m] = sx[nt];
+    if (want_csp) {
+        float* psp = part + (int64_t)a.row_chunks * PR * xc + (int64_t)a.row_chunks * xc + (int64_t)rc * PR;
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct)
+            if (h == 0) psp[32 * ct + m] = sp[ct];
+    }
+}
+
 // sum the row-chunk partials, apply the scale, drop the rank padding, write in the parameter's layout.
 // A block owns a [32 c x 64 n] tile: reads run along n (the contiguous axis of the partials, 8 independent sums per
 // thread in flight), writes are contiguous in the OUTPUT layout -- along n for [r, d] gradients, and through an LDS
 // transpose along c for the transposed [d, r] ones (a direct store there scatters 4-byte writes r*4 bytes apart and
 // cost 32 us per launch).  The last blocks of a job sum the bias-gradient partials.
-__host__ __device__ inline int finalize_tiles(int PR, int xcols) { return (PR / 32) * (xcols / 64); }
+// Round 3: a block owns a [16 c x 64 n] tile, ONE float4 per thread, and keeps up to 16 row-chunk loads in flight
+// (the first version walked 4 chunks per trip with 144 blocks: 23 us for a 19 MB reduction, all of it exposed latency).
+__host__ __device__ inline int finalize_tiles(int PR, int xcols) { return (PR / 16) * (xcols / 64); }
 
-__global__ __launch_bounds__(256) void wgrad_finalize_kernel(WgradArgs a) {
-    __shared__ float tile[32][65];
-    const WgradJob& J = a.job[blockIdx.y];
-    const int PR = 32 * a.RT;
-    const WgradLayout L = wgrad_layout(a);
-    const float* part = a.partial + L.off[blockIdx.y];
-    const int xc = J.xcols, R = J.out_rows, RC = a.row_chunks;
-    const int ntile = finalize_tiles(PR, xc);
+// The kernel's own arguments are a compact per-job record filled on the host: the first version indexed WgradArgs and
+// rebuilt the workspace layout on the device -- six DEPENDENT scalar loads from the kernel-argument segment before the first
+// partial was requested, ~13 us of the kernel's 21 (an empty kernel with the same preamble took 19 us, one that returns at
+// the top 5 us; profiles/r02_wgrad_stream_probes.md).  Here a block issues one batch of scalar loads, then every row-chunk
+// load of its tile, then the sum.
+struct FinJob {
+    const float* part;      // this job's partial block
+    float* out;
+    float* colsum_x;
+    float* colsum_p;
+    int xcols, out_rows, ldo, transposed;
+    float scale;
+    int ntile;
+};
+struct FinArgs {
+    FinJob job[4];
+    int RC, PR;
+};
+
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(FinArgs a) {
+    __shared__ float tile[16][65];
+    const FinJob J = a.job[blockIdx.y];
+    const int PR = a.PR, RC = a.RC;
+    const float* part = J.part;
+    const int xc = J.xcols, R = J.out_rows;
+    const int ntile = J.ntile;
     const int t = threadIdx.x;
     if ((int)blockIdx.x < ntile) {
-        const int c0 = 32 * ((int)blockIdx.x / (xc / 64)), n0 = 64 * ((int)blockIdx.x % (xc / 64));
-        // thread -> two float4 of the tile: e4 = t + 256 k, row cc = e4 / 16, columns 4 (e4 % 16) .. +3
-        f32x4 s[2];
-        s[0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[1] = s[0];
-        // four row chunks per trip, 16-byte loads: 8 independent loads in flight per thread (one 4-byte load per element
-        // and one chunk per trip was 16 serial global latencies: 27 us for a 19 MB reduction)
+        const int c0 = 16 * ((int)blockIdx.x / (xc / 64)), n0 = 64 * ((int)blockIdx.x % (xc / 64));
+        if (c0 >= R) return;                                     // rank padding: nothing to write
+        const int cc = t >> 4, nn = 4 * (t & 15);
+        const float* p0 = part + (int64_t)(c0 + cc) * xc + n0 + nn;
+        const int64_t cstride = (int64_t)PR * xc;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
         int rc = 0;
-        for (; rc + 4 <= RC; rc += 4) {
-            f32x4 v[4][2];
+        for (; rc + 16 <= RC; rc += 16) {
+            f32x4 v[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float* p = part + ((int64_t)(rc + q) * PR + c0) * xc + n0;
+            for (int q = 0; q < 16; ++q) v[q] = *reinterpret_cast<const f32x4*>(p0 + (rc + q) * cstride);
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int e4 = t + 256 * k;
-                    v[q][k] = *reinterpret_cast<const f32x4*>(p + (int64_t)(e4 >> 4) * xc + 4 * (e4 & 15));
-                }
+            for (int q = 0; q < 16; ++q) s += v[q];             // chunk order kept
+        }
+        if (rc < RC) {
+            f32x4 v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int r2 = rc + q < RC ? rc + q : RC - 1;
+                v[q] = *reinterpret_cast<const f32x4*>(p0 + r2 * cstride);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { s[0] += v[q][0]; s[1] += v[q][1]; }       // chunk order kept
+            for (int q = 0; q < 16; ++q)
+                if (rc + q < RC) s += v[q];
         }
-        for (; rc < RC; ++rc) {
-            const float* p = part + ((int64_t)rc * PR + c0) * xc + n0;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int e4 = t + 256 * k;
-                s[k] += *reinterpret_cast<const f32x4*>(p + (int64_t)(e4 >> 4) * xc + 4 * (e4 & 15));
-            }
-        }
+        s = s * J.scale;
         if (!J.transposed) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int e4 = t + 256 * k, cc = e4 >> 4, nn = 4 * (e4 & 15);
-                if (c0 + cc < R) {
-                    float* o = J.out + (int64_t)(c0 + cc) * J.ldo + n0 + nn;
-                    const f32x4 r4 = s[k] * J.scale;
-                    if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) *reinterpret_cast<f32x4*>(o) = r4;     // (a gradient view in the
-                    else { o[0] = r4[0]; o[1] = r4[1]; o[2] = r4[2]; o[3] = r4[3]; }                       // flat buffer may sit at any 4-byte offset)
-                }
+            if (c0 + cc < R) {
+                float* o = J.out + (int64_t)(c0 + cc) * J.ldo + n0 + nn;
+                if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) *reinterpret_cast<f32x4*>(o) = s;     // (a gradient view in the
+                else { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; }                           // flat buffer may sit at any 4-byte offset)
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int e4 = t + 256 * k, cc = e4 >> 4, nn = 4 * (e4 & 15);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) tile[cc][nn + j] = s[k][j] * J.scale;
-            }
+            for (int j = 0; j < 4; ++j) tile[cc][nn + j] = s[j];
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int e = t + 256 * k, nn = e >> 5, cc = e & 31;      // c fastest: contiguous in out[n * ldo + c]
-                if (c0 + cc < R) J.out[(int64_t)(n0 + nn) * J.ldo + c0 + cc] = tile[cc][nn];
+            for (int k = 0; k < 4; ++k) {
+                const int e = t + 256 * k, n2 = e >> 4, c2 = e & 15;      // c fastest: contiguous in out[n * ldo + c]
+                if (c0 + c2 < R) J.out[(int64_t)(n0 + n2) * J.ldo + c0 + c2] = tile[c2][n2];
             }
         }
         return;
@@ -540,7 +805,15 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(WgradArgs a) {
         if (J.colsum_x != nullptr) {
             const float* p = part + (int64_t)RC * PR * xc;
             float sum = 0.f;
-            for (int rc = 0; rc < RC; ++rc) sum += p[(int64_t)rc * xc + gid];
+            int rc = 0;
+            for (; rc + 8 <= RC; rc += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = p[(int64_t)(rc + q) * xc + gid];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sum += v[q];
+            }
+            for (; rc < RC; ++rc) sum += p[(int64_t)rc * xc + gid];
             J.colsum_x[gid] = sum * J.scale;
         }
     } else if (gid < xc + R) {
@@ -548,15 +821,35 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(WgradArgs a) {
             const int c = (int)(gid - xc);
             const float* p = part + (int64_t)RC * PR * xc + (int64_t)RC * xc;
             float sum = 0.f;
-            for (int rc = 0; rc < RC; ++rc) sum += p[(int64_t)rc * PR + c];
+            int rc = 0;
+            for (; rc + 8 <= RC; rc += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = p[(int64_t)(rc + q) * PR + c];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sum += v[q];
+            }
+            for (; rc < RC; ++rc) sum += p[(int64_t)rc * PR + c];
             J.colsum_p[c] = sum;
         }
     }
 }
 
 static hipError_t launch_finalize(const WgradArgs& a, int RT, int xmax, int rmax, hipStream_t stream) {
-    const int blocks = finalize_tiles(32 * RT, xmax) + (xmax + rmax + 255) / 256;   // tiles of every job fit: xcols <= xmax
-    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)blocks, a.njobs), dim3(256), 0, stream, a);
+    const int PR = 32 * RT;
+    const int blocks = finalize_tiles(PR, xmax) + (xmax + rmax + 255) / 256;   // tiles of every job fit: xcols <= xmax
+    const WgradLayout L = wgrad_layout(a);
+    FinArgs f{};
+    f.RC = a.row_chunks; f.PR = PR;
+    for (int j = 0; j < a.njobs; ++j) {
+        const WgradJob& J = a.job[j];
+        FinJob& F = f.job[j];
+        F.part = a.partial + L.off[j];
+        F.out = J.out; F.colsum_x = J.colsum_x; F.colsum_p = J.colsum_p;
+        F.xcols = J.xcols; F.out_rows = J.out_rows; F.ldo = J.ldo; F.transposed = J.transposed;
+        F.scale = J.scale; F.ntile = finalize_tiles(PR, J.xcols);
+    }
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)blocks, a.njobs), dim3(256), 0, stream, f);
     return hipGetLastError();
 }
 
@@ -585,6 +878,29 @@ static hipError_t launch_one(const WgradArgs& a, hipStream_t stream) {
     // profiles/r02_kbench_wgrad_variants.txt).  VLPET_WGRAD_TR=0 selects the identity-transpose kernel.
     static const bool use_tr = [] { const char* e = getenv("VLPET_WGRAD_TR"); return e == nullptr || atoi(e) != 0; }();
     hipError_t e;
+    // bf16, no dropout mask: the streaming kernel (256-column slabs, LDS-DMA ring).  VLPET_WGRAD_STREAM=0 falls back to the
+    // per-wave transpose-read kernel below (A/B).
+    static const bool use_stream = [] { const char* e = getenv("VLPET_WGRAD_STREAM"); return e == nullptr || atoi(e) != 0; }();
+    if constexpr (std::is_same<IO, __bf16>::value) {
+        if (plain && use_stream) {
+            // ring depth: 3 stages (72 KiB at RT = 3: two workgroups per CU); VLPET_WGRAD_NSTG=4 for A/B (one per CU, one more stage in flight)
+            static const int nstg = [] { const char* e = getenv("VLPET_WGRAD_NSTG"); return e ? atoi(e) : 3; }();
+            WgradArgs b = a; b.nslice = (xmax + 255) / 256;
+#ifdef VLPET_WGRAD_EXP
+            { const char* e2 = getenv("VLPET_WGS_MODE"); if (e2) b.RT |= atoi(e2) << 8; }
+#endif
+            auto go = [&](auto kern, int NSTG) -> hipError_t {
+                const size_t lds = (size_t)NSTG * WgsGeo<RT>::STG_B;
+                hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e2 != hipSuccess) return e2;
+                hipLaunchKernelGGL(kern, dim3(wg_grid(b, b.nslice)), dim3(VLPET_THREADS), lds, stream, b);
+                return hipGetLastError();
+            };
+            e = nstg == 4 ? go(wgrad_stream_kernel<RT, 4>, 4) : go(wgrad_stream_kernel<RT, 3>, 3);
+            if (e != hipSuccess) return e;
+            return launch_finalize(a, RT, xmax, rmax, stream);
+        }
+    }
     if constexpr (std::is_same<IO, __bf16>::value && RT <= 3) {
         if (plain && use_tr) {
             const size_t tiles = (size_t)4 * 2 * 32 * (64 * RT + 128);
