@@ -17,8 +17,12 @@ class KernelTimer:
     """Optional HIP-event bracketing of individual launches (bench.py's live roofline measurement).
     Events are recorded on the stream the kernels are enqueued on (torch's current stream)."""
 
-    def __init__(self):
+    def __init__(self, names=None):
         self.records = []      # (name, rows, start_event, end_event)
+        self.names = None if names is None else frozenset(names)     # bracket only these launch groups (None: all)
+
+    def wants(self, name):
+        return self.names is None or name in self.names
 
     def bracket(self, name, rows, fn):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -52,7 +56,7 @@ WGRAD_STREAM: Optional["torch.cuda.Stream"] = None
 
 
 def _timed(name, rows, fn):
-    if TIMER is None:
+    if TIMER is None or not TIMER.wants(name):
         return fn()
     return TIMER.bracket(name, rows, fn)
 
@@ -383,7 +387,7 @@ class _AdapterGateFn(torch.autograd.Function):
                     rc = _timed("k1_bwd_wgrad", M, lambda: phase(2 | 4, sargs))
                 for t in (x1f, x2f, dyf, ws, pk_a.buf) + ((pk_g.buf,) if gate else ()) + ((act,) if act is not None else ()):
                     t.record_stream(side)        # the caching allocator must not recycle them under the side stream
-        elif TIMER is None:
+        elif TIMER is None or not TIMER.wants("k1_bwd_rows"):
             rc = phase(3, args)
         else:       # same work, the two halves bracketed separately
             rc = TIMER.bracket("k1_bwd_rows", M, lambda: phase(1, args))
