@@ -211,6 +211,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to exercise the DP path on a 1-GPU box")
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="K1 weight gradients on a side stream (measured 5 %% SLOWER on one MI355X: the step is GPU-bound)")
+    ap.add_argument("--gemm-table", default="on", choices=["on", "off", "tune"],
+                    help="TunableOp table for the backbone's library GEMMs: on = use vl-pet_amd/tuning/tunableop_gfx950.csv, "
+                         "tune = measure this run's shapes into gpurun_out/tunableop_gfx950_new.csv (slow), off = library defaults")
     ap.add_argument("--kernel-table", default="after", choices=["after", "inline", "off"],
                     help="where the per-kernel table is measured: a separate pass after the timed region (default; the timed "
                          "region brackets only the roofline's op), inline (every launch bracketed inside the timed region), off")
@@ -253,6 +256,18 @@ def main():
     import vlpet_amd.train as TR
     from vlpet_amd import _lib
     _lib.load()     # fail loudly before anything is timed
+    gemm_table = None
+    if args.gemm_table != "off":     # library-GEMM solution selection for the frozen backbone (TunableOp; train.use_tuned_gemms)
+        if args.gemm_table == "tune":
+            new_table = os.path.join(ROOT, "gpurun_out", "tunableop_gfx950_new.csv")
+            os.makedirs(os.path.dirname(new_table), exist_ok=True)
+            if not os.path.exists(new_table) and os.path.exists(TR.TUNED_GEMMS):       # start from the committed table
+                import shutil
+                shutil.copyfile(TR.TUNED_GEMMS, new_table)
+            TR.use_tuned_gemms(new_table, tune=True)
+            gemm_table = "tuning (gpurun_out/tunableop_gfx950_new.csv)"
+        elif TR.use_tuned_gemms():
+            gemm_table = os.path.relpath(TR.TUNED_GEMMS, ROOT)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(1234)      # same initial state on every rank: no parameter broadcast needed
@@ -392,7 +407,7 @@ def main():
                        ("per_gpu_task_batch" if args.scaling == "weak" else "global_task_batch"): per_task,
                        "enc_rows_per_step_rank0": enc_rows, "trainable_params": n_train, "parallelism": f"dp{n_ranks}",
                        "backend": args.backend if n_ranks > 1 else None},
-            "roofline": roof, "kernels": kernels,
+            "roofline": roof, "kernels": kernels, "backbone_gemm_table": gemm_table,
             "kernel_table": {"after": "roofline op bracketed inside the timed region; the other launch groups in one step per task after it",
                              "inline": "every launch group bracketed inside the timed region", "off": "roofline op only"}[args.kernel_table],
         }

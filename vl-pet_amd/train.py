@@ -22,6 +22,7 @@ No per-step barrier.
 from __future__ import annotations
 
 import math
+import os
 import random
 from typing import Dict, List, Optional, Sequence
 
@@ -379,6 +380,25 @@ class FlatGrads:
 
 
 NO_DECAY = ("bias", "LayerNorm.weight")     # trainer_base.py:635 (substring rule; BART's *_layer_norm.weight DOES decay)
+
+
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "tunableop_gfx950.csv")
+
+
+def use_tuned_gemms(path: Optional[str] = None, tune: bool = False) -> bool:
+    """Library-GEMM solution selection for the frozen backbone (the q/k/v/o, FFN and LM-head products stay plain
+    hipBLASLt / rocBLAS GEMMs): PyTorch's TunableOp with the table measured on an MI355X for the shapes of the
+    benchmark's four task batches (``tuning/tunableop_gfx950.csv``; 22,017 -> 22,566 samples/s on the same box).
+    ``tune=True`` measures missing shapes on first use and appends them (minutes per run).  The table carries the
+    library versions it was measured with; TunableOp ignores it when they differ.  Returns whether it is active."""
+    import torch.cuda.tunable as tunable
+    path = path or TUNED_GEMMS
+    if not tune and not os.path.exists(path):
+        return False
+    tunable.set_filename(path, insert_device_ordinal=False)     # the same table for every rank of a node
+    tunable.enable(True)
+    tunable.tuning_enable(bool(tune))
+    return True
 
 
 def lr_at(step: int, base_lr: float, warmup_steps: int, total_steps: int) -> float:
