@@ -76,11 +76,34 @@ def cpu_baseline(budget_s=18.0, warm=2, batch=4):
         # every host core and, because batch-4 eager ops stop scaling long before a server's core
         # count, 16 threads as well: the faster of the two is the reported baseline, both are in `thread_sweep`
         sweep = {}
-        for nt in sorted({ncores, min(16, ncores)}):
+        skipped = {}
+
+        def probe_chain():                               # a config-0-sized K1 chain: milliseconds at a sane thread count
+            gp = torch.Generator().manual_seed(3)
+            xs = [torch.randn(224, 768, generator=gp) for _ in range(3)]
+            ws = [torch.randn(96, 768, generator=gp) * 0.05, torch.zeros(96), torch.randn(768, 96, generator=gp) * 0.05, torch.zeros(768)] * 2
+            O.k1_fwd_bwd(xs[0], xs[1], *ws, xs[2], n_heads=4)
+            t = time.perf_counter()
+            for _ in range(3):
+                O.k1_fwd_bwd(xs[0], xs[1], *ws, xs[2], n_heads=4)
+            return (time.perf_counter() - t) / 3
+        base_probe = base_step = None
+        for nt in sorted({ncores, min(16, ncores)}):     # 16 threads first: it bounds what the all-core leg may cost
             torch.set_num_threads(nt)
+            pr = probe_chain()
+            if base_probe is None:
+                base_probe = pr
+            elif pr > 4.0 * base_probe:                  # oversubscribed: a full step would take minutes (285 s on a 256-thread host)
+                skipped[nt] = f"skipped: the config-0 K1 chain is {pr / base_probe:.0f}x slower than at {min(16, ncores)} threads"
+                print(f"[bench cpu_baseline] {nt} threads: {skipped[nt]}", file=sys.stderr, flush=True)
+                continue
             t0 = time.perf_counter()
             tr.step(b)                                   # warm-up (also the probe: a pathological thread count shows here)
             probe = time.perf_counter() - t0
+            if base_step is not None and probe > 5.0 * base_step:
+                sweep[nt] = (batch / probe, 1, probe)
+                print(f"[bench cpu_baseline] {nt} threads: 1 step in {probe:.1f} s (not repeated)", file=sys.stderr, flush=True)
+                continue
             if probe < 2.0:
                 for _ in range(warm - 1):
                     tr.step(b)
@@ -91,6 +114,8 @@ def cpu_baseline(budget_s=18.0, warm=2, batch=4):
                 steps += 1
             dt = time.perf_counter() - t0
             sweep[nt] = (batch * steps / dt, steps, dt)
+            if base_step is None:
+                base_step = dt / steps
             print(f"[bench cpu_baseline] {nt} threads: {steps} steps in {dt:.1f} s", file=sys.stderr, flush=True)
         best = max(sweep, key=lambda k: sweep[k][0])
         rate, steps, dt = sweep[best]
@@ -141,7 +166,7 @@ def cpu_baseline(budget_s=18.0, warm=2, batch=4):
     chains = {k: round(v, 4) for k, v in chains.items()}
     return dict(value=round(rate, 3), unit="samples/s", cores=best, host_cores=ncores,
                 cpu_model=cpu_model_name(), kind="port",
-                thread_sweep={str(k): round(v[0], 3) for k, v in sweep.items()},
+                thread_sweep=dict({str(k): round(v[0], 3) for k, v in sweep.items()}, **{str(k): v for k, v in skipped.items()}),
                 sample=f"configs[0]: BART-base VL-PET-large r=96, VQA batch {batch}, S=20+36, fp32, full train step "
                        f"(fwd+bwd+clip+AdamW) through oracle/vlpet_oracle.py on the host CPU, {warm} warm-up + "
                        f"{steps} timed steps ({dt:.1f} s)",

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""K1 forward (training form) and backward rows kernel only, at the sizes given: a quick A/B target for alternative builds
+(VLPET_LIB=...).  usage: k1bench.py tag M [M ...]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import vlpet_amd.functional as F
+from vlpet_amd import _lib
+from kbench import timeit
+
+def run(M, tag):
+    dt, r, d, dev = torch.bfloat16, 96, 768, "cuda"
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(0)
+    x1 = torch.randn(M, d, device=dev, generator=g).to(dt); x2 = torch.randn(M, d, device=dev, generator=g).to(dt)
+    dy = torch.randn(M, d, device=dev, generator=g).to(dt)
+    mk = lambda *s: torch.randn(*s, device=dev, generator=g) * 0.05
+    wd, bd, wu, bu = mk(r, d), mk(r), mk(d, r), mk(d)
+    wgd, bgd, wgu, bgu = mk(r, d), mk(r), mk(d, r), mk(d)
+    io = F._io_dtype(x2); tiles = F.rank_tiles(r)
+    pa = F.pack_pair([wd], [bd], wu, bu, io, tiles); pg = F.pack_pair([wgd], [bgd], wgu, bgu, io, tiles)
+    out = torch.empty_like(x2)
+    st = torch.cuda.current_stream().cuda_stream
+    nws = lib.vlpet_bwd_workspace_bytes(M, d, tiles, 1, io)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    G = [torch.empty(r, d, **f32), torch.empty(r, **f32), torch.empty(d, r, **f32), torch.empty(d, **f32),
+         torch.empty(r, d, **f32), torch.empty(r, **f32), torch.empty(d, r, **f32), torch.empty(d, **f32)]
+    dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+    nsv = lib.vlpet_saved_bytes(M, tiles, io)
+    sv = torch.empty(nsv, dtype=torch.uint8, device=dev)
+    def fwd_save():
+        rc = lib.vlpet_adapter_gate_fwd_save(x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(), out.data_ptr(),
+                                             sv.data_ptr(), M, d, tiles, 1, 1.0, 1.0, 1.0, io, st); assert rc == 0
+    def bwd_saved(ph):
+        def f():
+            rc = lib.vlpet_adapter_gate_bwd_saved(ph, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(),
+                                                  dx1.data_ptr(), dx2.data_ptr(), *[t.data_ptr() for t in G], r, r, ws.data_ptr(), nws,
+                                                  M, d, tiles, 1, 1.0, 1.0, 1.0, io, st); assert rc == 0
+        return f
+    fwd_save()
+    res = []
+    for rep in range(2):
+        res.append((timeit(fwd_save, iters=60, warm=5), timeit(bwd_saved(1 | 4), iters=60, warm=5), timeit(bwd_saved(2 | 4), iters=60, warm=5)))
+    f, b, w = (min(x[i] for x in res) for i in range(3))
+    print(f"k1bench {tag:10s} M={M:6d}: fwd+save {f:6.1f} us   bwd rows {b:6.1f} us   wgrad+fin {w:6.1f} us   bwd op {b + w:6.1f} us "
+          f"(op frac {5 * d * M * 2 / (b + w) / 1e3 / 8000:.3f})", flush=True)
+
+if __name__ == "__main__":
+    tag = sys.argv[1]
+    for M in [int(a) for a in sys.argv[2:]] or [28000]:
+        run(M, tag)
