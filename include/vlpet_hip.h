@@ -297,6 +297,16 @@ int vlpet_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* k
 int vlpet_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                    const uint8_t* key_mask, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int causal,
                    float scale, float p, uint64_t seed, vlpet_stream_t stream);
+/* The same with explicit row strides (in elements, multiples of 8, >= H*64) for q / dq (ld_q) and k, v / dk, dv (ld_kv): the
+ * columns of a fused [B, L, 3*H*64] q|k|v projection output (and of its gradient) are read / written in place, so the frozen
+ * q_proj / k_proj / v_proj of a self-attention (my_transformers/modeling_bart.py:791-811) run as ONE library GEMM each way and
+ * autograd has no three input gradients to sum.  o, dout and lse keep the dense layout. */
+int vlpet_attn_fwd_ld(const void* q, const void* k, const void* v, const uint8_t* key_mask, void* o, float* lse, uint8_t* keep_out,
+                      int B, int H, int Lq, int Lk, int ld_q, int ld_kv, int causal, float scale, float p, uint64_t seed,
+                      vlpet_stream_t stream);
+int vlpet_attn_bwd_ld(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                      const uint8_t* key_mask, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int ld_q, int ld_kv,
+                      int causal, float scale, float p, uint64_t seed, vlpet_stream_t stream);
 
 /* ---- Downsample (the step before K4) -------------------------------------------------------
  * AdaptiveMaxPool2d(s_in x s_in -> s_out x s_out) over the token grid of x [n_images, s_in*s_in, dim]

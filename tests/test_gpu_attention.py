@@ -114,3 +114,62 @@ def test_short_attention_argument_errors():
     assert lib.vlpet_attn_fwd(*args(8, 0, 0.0)) == -1
     assert lib.vlpet_attn_fwd(*args(8, 8, 1.0)) == -1
     assert lib.vlpet_attn_fwd(None, x.data_ptr(), x.data_ptr(), None, x.data_ptr(), l.data_ptr(), None, 1, 1, 8, 8, 0, 0.125, 0.0, 0, st) == -5
+
+
+@pytest.mark.parametrize("B,L,causal,masked,p", [(3, 56, False, True, 0.1), (2, 92, False, False, 0.0), (4, 5, True, False, 0.1),
+                                                 (2, 128, False, True, 0.1)])
+def test_fused_qkv_form_is_the_same_kernel_on_column_blocks(B, L, causal, masked, p):
+    """vlpet_attn_{fwd,bwd}_ld on the q | k | v columns of one [B, L, 3E] buffer == the dense entry points on three tensors
+    (same seed -> same dropout pattern): outputs and the three input gradients bit for bit."""
+    from vlpet_amd.attention import short_attention, short_self_attention
+    E = H * 64
+    g = torch.Generator().manual_seed(L)
+    qkv = (torch.randn(B, L, 3 * E, generator=g) * 1.5).bfloat16().cuda()
+    do = (torch.randn(B, L, E, generator=g)).bfloat16().cuda()
+    km = None
+    if masked:
+        km = (torch.rand(B, L, generator=g) > 0.25)
+        km[:, -1] = True
+        km = km.cuda()
+    a = qkv.clone().requires_grad_(True)
+    o1 = short_self_attention(a, H, km, causal, p, True, seed=7)
+    o1.backward(do)
+    q, k, v = (qkv[..., i * E:(i + 1) * E].clone().requires_grad_(True) for i in range(3))
+    o2 = short_attention(q, k, v, H, km, causal, p, True, seed=7)
+    o2.backward(do)
+    assert torch.equal(o1, o2)
+    for i, t in enumerate((q, k, v)):
+        assert torch.equal(a.grad[..., i * E:(i + 1) * E], t.grad), "qkv"[i]
+
+
+def test_self_attention_module_fused_projection_equals_separate_projections():
+    """BartAttention with frozen projections: the fused [E -> 3E] GEMM + column-block attention against the three separate
+    projections (VLPET_NO_FUSED_QKV path), eval mode (no dropout), bf16: output and input gradient within bf16 GEMM rounding."""
+    import vlpet_amd.host.bart as HB
+    cfg = HB.vlpet_config()
+    torch.manual_seed(3)
+    att = HB.BartAttention(cfg, 768, 12, 0.1).cuda().to(torch.bfloat16).eval()
+    for p_ in att.parameters():
+        p_.requires_grad_(False)
+    x = (torch.randn(5, 56, 768, device="cuda") * 0.7).bfloat16()
+    mask = torch.ones(5, 1, 1, 56, dtype=torch.bool, device="cuda")
+    mask[:, :, :, -7:] = False
+    res = []
+    for fuse in (True, False):
+        HB.FUSE_QKV = fuse
+        xi = x.clone().requires_grad_(True)
+        y = att(xi, attn_mask=mask)
+        y.float().square().sum().backward()
+        res.append((y.float(), xi.grad.float()))
+    HB.FUSE_QKV = True
+    assert hasattr(att, "_qkv_cache")
+    assert rel_err(res[0][0], res[1][0]) < 1e-2 and rel_err(res[0][1], res[1][1]) < 2e-2
+    # the cache follows the source weights
+    with torch.no_grad():
+        att.k_proj.weight.mul_(0.5)
+    xi = x.clone()
+    y2 = att(xi, attn_mask=mask)
+    HB.FUSE_QKV = False
+    y3 = att(xi, attn_mask=mask)
+    HB.FUSE_QKV = True
+    assert rel_err(y2.float(), y3.float()) < 1e-2

@@ -65,6 +65,66 @@ class _AttnFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None, None, None
 
 
+class _AttnQkvFn(torch.autograd.Function):
+    """Self-attention on a fused projection output ``qkv [B, L, 3*E]`` (columns q | k | v): the kernels read the three column
+    blocks in place (row stride 3E) and the backward writes dq | dk | dv into ONE ``[B, L, 3E]`` gradient, which the fused
+    projection's dgrad GEMM consumes directly."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_mask, H, causal, scale, p, seed):
+        lib = _lib.load()
+        _need_cuda(qkv)
+        qkv = qkv.contiguous()
+        B, L, E3 = qkv.shape
+        E = E3 // 3
+        o = torch.empty(B, L, E, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(B, H, L, dtype=torch.float32, device=qkv.device)
+        base, esz = qkv.data_ptr(), qkv.element_size()
+        rc = _timed("attn_fwd", B * L, lambda: lib.vlpet_attn_fwd_ld(
+            base, base + E * esz, base + 2 * E * esz, _ptr(key_mask), o.data_ptr(), lse.data_ptr(), None,
+            B, H, L, L, E3, E3, int(causal), float(scale), float(p), seed, _stream()))
+        _lib.check(rc, "vlpet_attn_fwd_ld")
+        ctx.save_for_backward(qkv, o, lse, key_mask)
+        ctx.cfg = (H, int(causal), float(scale), float(p), seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        qkv, o, lse, key_mask = ctx.saved_tensors
+        H, causal, scale, p, seed = ctx.cfg
+        B, L, E3 = qkv.shape
+        E = E3 // 3
+        do = dout.contiguous()
+        if do.dtype != qkv.dtype:
+            do = do.to(qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        base, dbase, esz = qkv.data_ptr(), dqkv.data_ptr(), qkv.element_size()
+        rc = _timed("attn_bwd", B * L, lambda: lib.vlpet_attn_bwd_ld(
+            base, base + E * esz, base + 2 * E * esz, o.data_ptr(), do.data_ptr(), lse.data_ptr(), _ptr(key_mask),
+            dbase, dbase + E * esz, dbase + 2 * E * esz, B, H, L, L, E3, E3, causal, scale, p, seed, _stream()))
+        _lib.check(rc, "vlpet_attn_bwd_ld")
+        return dqkv, None, None, None, None, None, None
+
+
+def supported_qkv(qkv: torch.Tensor, num_heads: int) -> bool:
+    return (qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and qkv.shape[-1] == 3 * num_heads * HEAD_DIM
+            and qkv.shape[1] <= MAX_LEN)
+
+
+def short_self_attention(qkv: torch.Tensor, num_heads: int, key_mask: Optional[torch.Tensor] = None, causal: bool = False,
+                         p: float = 0.0, training: bool = False, scale: Optional[float] = None, seed=None):
+    """qkv [B, L, 3*H*64] (bf16; the output of one fused q|k|v projection) -> [B, L, H*64]."""
+    if not supported_qkv(qkv, num_heads):
+        raise RuntimeError("vl-pet_amd: short_self_attention needs a bf16 CUDA [B, L, 3*H*64] tensor with L <= 128")
+    if key_mask is not None:
+        key_mask = key_mask.reshape(qkv.shape[0], qkv.shape[1]).to(torch.uint8).contiguous()
+    pe = float(p) if training else 0.0
+    if seed is None:
+        seed = _draw_seed() if pe > 0.0 else 0
+    return _AttnQkvFn.apply(qkv, key_mask, num_heads, bool(causal), HEAD_DIM ** -0.5 if scale is None else float(scale), pe, int(seed))
+
+
 def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, key_mask: Optional[torch.Tensor] = None,
                     causal: bool = False, p: float = 0.0, training: bool = False, scale: Optional[float] = None, seed=None,
                     return_mask: bool = False):

@@ -7,7 +7,7 @@
 #include <stdio.h>
 #include <vector>
 
-#define VLPET_VERSION 200      // round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form
+#define VLPET_VERSION 210      // round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -655,34 +655,54 @@ static uint32_t attn_thr(float p) {
     return (uint32_t)t;
 }
 
-extern "C" int vlpet_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, void* o, float* lse,
-                              uint8_t* keep_out, int B, int H, int Lq, int Lk, int causal, float scale, float p, uint64_t seed,
-                              vlpet_stream_t stream) {
+static int attn_ld_ok(int H, int ld_q, int ld_kv) {
+    return ld_q >= H * 64 && ld_kv >= H * 64 && ld_q % 8 == 0 && ld_kv % 8 == 0;
+}
+
+extern "C" int vlpet_attn_fwd_ld(const void* q, const void* k, const void* v, const uint8_t* key_mask, void* o, float* lse,
+                                 uint8_t* keep_out, int B, int H, int Lq, int Lk, int ld_q, int ld_kv, int causal, float scale,
+                                 float p, uint64_t seed, vlpet_stream_t stream) {
     int rc = attn_common(B, H, Lq, Lk, p);
     if (rc) return rc;
+    if (!attn_ld_ok(H, ld_q, ld_kv)) return VLPET_E_SHAPE;
     if (!q || !k || !v || !o || !lse) return VLPET_E_NULL;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o)) return VLPET_E_ALIGN;
     AttnArgs a{};
+    a.ld_q = ld_q; a.ld_kv = ld_kv;
     a.q = (const __bf16*)q; a.k = (const __bf16*)k; a.v = (const __bf16*)v; a.o = (__bf16*)o; a.lse = lse;
     a.key_mask = key_mask; a.keep_out = keep_out; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.causal = causal ? 1 : 0;
     a.scale = scale; a.thr = attn_thr(p); a.inv_keep = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
     return herr(launch_attn(a, false, (hipStream_t)stream));
 }
 
-extern "C" int vlpet_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                              const uint8_t* key_mask, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int causal,
-                              float scale, float p, uint64_t seed, vlpet_stream_t stream) {
+extern "C" int vlpet_attn_fwd(const void* q, const void* k, const void* v, const uint8_t* key_mask, void* o, float* lse,
+                              uint8_t* keep_out, int B, int H, int Lq, int Lk, int causal, float scale, float p, uint64_t seed,
+                              vlpet_stream_t stream) {
+    return vlpet_attn_fwd_ld(q, k, v, key_mask, o, lse, keep_out, B, H, Lq, Lk, H * 64, H * 64, causal, scale, p, seed, stream);
+}
+
+extern "C" int vlpet_attn_bwd_ld(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                                 const uint8_t* key_mask, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int ld_q,
+                                 int ld_kv, int causal, float scale, float p, uint64_t seed, vlpet_stream_t stream) {
     int rc = attn_common(B, H, Lq, Lk, p);
     if (rc) return rc;
+    if (!attn_ld_ok(H, ld_q, ld_kv)) return VLPET_E_SHAPE;
     if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv) return VLPET_E_NULL;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o) || !aligned16(dout) || !aligned16(dq) ||
         !aligned16(dk) || !aligned16(dv)) return VLPET_E_ALIGN;
     AttnArgs a{};
+    a.ld_q = ld_q; a.ld_kv = ld_kv;
     a.q = (const __bf16*)q; a.k = (const __bf16*)k; a.v = (const __bf16*)v; a.o = (__bf16*)const_cast<void*>(o);
     a.lse = const_cast<float*>(lse); a.dout = (const __bf16*)dout; a.dq = (__bf16*)dq; a.dk = (__bf16*)dk; a.dv = (__bf16*)dv;
     a.key_mask = key_mask; a.keep_out = nullptr; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.causal = causal ? 1 : 0;
     a.scale = scale; a.thr = attn_thr(p); a.inv_keep = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
     return herr(launch_attn(a, true, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                              const uint8_t* key_mask, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int causal,
+                              float scale, float p, uint64_t seed, vlpet_stream_t stream) {
+    return vlpet_attn_bwd_ld(q, k, v, o, dout, lse, key_mask, dq, dk, dv, B, H, Lq, Lk, H * 64, H * 64, causal, scale, p, seed, stream);
 }
 
 static int ce_common(int64_t N, int V, int ld, int io_dtype) {

@@ -80,7 +80,7 @@ __device__ __forceinline__ void stage_image(uint8_t* img, const __bf16* src, int
 // loop compiles to load -> wait -> store per trip: one memory latency per 4 KiB of image)
 template <int NIMG, int MAXP>
 __device__ __forceinline__ void stage_images(uint8_t* const* img, const __bf16* const* src, const int* n_rows, const int* rows_pad,
-                                             int64_t rs, int tid, int nthreads) {
+                                             const int64_t* rs, int tid, int nthreads) {
     u32x4 v[NIMG][MAXP];
 #pragma unroll
     for (int g = 0; g < NIMG; ++g)
@@ -88,7 +88,7 @@ __device__ __forceinline__ void stage_images(uint8_t* const* img, const __bf16* 
         for (int c = 0; c < MAXP; ++c) {
             const int idx = tid + c * nthreads, row = idx >> 3, pc = idx & 7;
             const int rr = row < n_rows[g] ? row : n_rows[g] - 1;
-            v[g][c] = *reinterpret_cast<const u32x4*>(src[g] + (int64_t)rr * rs + pc * 8);
+            v[g][c] = *reinterpret_cast<const u32x4*>(src[g] + (int64_t)rr * rs[g] + pc * 8);
         }
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -157,10 +157,10 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
     const int b = bh / a.H, h = bh % a.H;
     const int m = lane & 31, hh = lane >> 5;
     constexpr int Lkp = 32 * T;
-    const int64_t rs = (int64_t)a.H * 64;
-    const __bf16* qb_ = a.q + (int64_t)b * a.Lq * rs + h * 64;
-    const __bf16* kb_ = a.k + (int64_t)b * a.Lk * rs + h * 64;
-    const __bf16* vb_ = a.v + (int64_t)b * a.Lk * rs + h * 64;
+    const int64_t rs = (int64_t)a.H * 64, rq = a.ld_q, rk = a.ld_kv;
+    const __bf16* qb_ = a.q + (int64_t)b * a.Lq * rq + h * 64;
+    const __bf16* kb_ = a.k + (int64_t)b * a.Lk * rk + h * 64;
+    const __bf16* vb_ = a.v + (int64_t)b * a.Lk * rk + h * 64;
     __bf16* ob_ = a.o + (int64_t)b * a.Lq * rs + h * 64;
     const uint8_t* km = a.key_mask ? a.key_mask + (int64_t)b * a.Lk : nullptr;
     uint8_t* Vs = smem + (size_t)wave * AttnLds::fwd_wave_bytes(Lkp);
@@ -171,9 +171,9 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
     for (int t = 0; t < T; ++t) {
         const int j = 32 * t + m, jk = j < a.Lk ? j : a.Lk - 1;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) kf[t][ks] = *reinterpret_cast<const bf16x8*>(kb_ + (int64_t)jk * rs + 16 * ks + 8 * hh);
+        for (int ks = 0; ks < 4; ++ks) kf[t][ks] = *reinterpret_cast<const bf16x8*>(kb_ + (int64_t)jk * rk + 16 * ks + 8 * hh);
     }
-    stage_image(Vs, vb_, rs, a.Lk, Lkp, lane, 64);
+    stage_image(Vs, vb_, rk, a.Lk, Lkp, lane, 64);
 
     const float sc2 = a.scale * LOG2E;
     const int NQB = (a.Lq + 31) >> 5;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
         const int iq = i < a.Lq ? i : a.Lq - 1;
         bf16x8 qf[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qb_ + (int64_t)iq * rs + 16 * ks + 8 * hh);
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qb_ + (int64_t)iq * rq + 16 * ks + 8 * hh);
         f32x16 st[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -252,8 +252,9 @@ __global__ __launch_bounds__(AT_NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
     const int m = lane & 31, hh = lane >> 5;
     const int Lkp = (a.Lk + 31) & ~31, T = Lkp >> 5;
     const int Lqp = (a.Lq + 31) & ~31, NQB = Lqp >> 5;
-    const int64_t rs = (int64_t)a.H * 64;
-    const int64_t qoff = (int64_t)b * a.Lq * rs + h * 64, koff = (int64_t)b * a.Lk * rs + h * 64;
+    const int64_t rs = (int64_t)a.H * 64, rq = a.ld_q, rk = a.ld_kv;
+    const int64_t ooff = (int64_t)b * a.Lq * rs + h * 64;                                            // o, dout
+    const int64_t qoff = (int64_t)b * a.Lq * rq + h * 64, koff = (int64_t)b * a.Lk * rk + h * 64;    // q / dq, k v / dk dv
     const uint8_t* km = a.key_mask ? a.key_mask + (int64_t)b * a.Lk : nullptr;
     uint8_t* Qs = smem;
     uint8_t* Ds = Qs + (size_t)Lqp * AT_ROW;                     // dO
@@ -271,14 +272,15 @@ __global__ __launch_bounds__(AT_NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
             const int rr = row < a.Lq ? row : a.Lq - 1;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                xo[c][e] = *reinterpret_cast<const bf16x8*>(a.o + qoff + (int64_t)rr * rs + 16 * part + 8 * e);
-                xd[c][e] = *reinterpret_cast<const bf16x8*>(a.dout + qoff + (int64_t)rr * rs + 16 * part + 8 * e);
+                xo[c][e] = *reinterpret_cast<const bf16x8*>(a.o + ooff + (int64_t)rr * rs + 16 * part + 8 * e);
+                xd[c][e] = *reinterpret_cast<const bf16x8*>(a.dout + ooff + (int64_t)rr * rs + 16 * part + 8 * e);
             }
         }
         uint8_t* const imgs[4] = {Qs, Ds, Ks, Vs};
-        const __bf16* const srcs[4] = {a.q + qoff, a.dout + qoff, a.k + koff, a.v + koff};
+        const __bf16* const srcs[4] = {a.q + qoff, a.dout + ooff, a.k + koff, a.v + koff};
         const int nr[4] = {a.Lq, a.Lq, a.Lk, a.Lk}, rp[4] = {Lqp, Lqp, Lkp, Lkp};
-        stage_images<4, 4>(imgs, srcs, nr, rp, rs, tid, AT_NW * 64);          // 128 rows x 8 pieces / 256 threads = 4 per image
+        const int64_t rss[4] = {rq, rs, rk, rk};
+        stage_images<4, 4>(imgs, srcs, nr, rp, rss, tid, AT_NW * 64);          // 128 rows x 8 pieces / 256 threads = 4 per image
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int idx = tid + c * AT_NW * 64, row = idx >> 2, part = idx & 3;
@@ -345,8 +347,8 @@ __global__ __launch_bounds__(AT_NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
                     dk1 = mfma32(tr_acc_order(Qs, 32 * qb + 16 * u, 32, lane), sf, dk1);
                 }
             }
-            store_rows_T(stg, dv0, dv1, a.dv + koff, rs, 32 * t, a.Lk, lane);
-            store_rows_T(stg, dk0, dk1, a.dk + koff, rs, 32 * t, a.Lk, lane);
+            store_rows_T(stg, dv0, dv1, a.dv + koff, rk, 32 * t, a.Lk, lane);
+            store_rows_T(stg, dk0, dk1, a.dk + koff, rk, 32 * t, a.Lk, lane);
         } else {
             // ============================================= phase Q: query block qb (lane = query, registers = keys)
             const int qb = un - T;
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(AT_NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
                     dq1 = mfma32(tr_acc_order(Ks, 32 * t + 16 * u, 32, lane), sf, dq1);
                 }
             }
-            store_rows_T(stg, dq0, dq1, a.dq + qoff, rs, 32 * qb, a.Lq, lane);
+            store_rows_T(stg, dq0, dq1, a.dq + qoff, rq, 32 * qb, a.Lq, lane);
         }
     }
 }

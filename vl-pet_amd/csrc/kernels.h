@@ -278,6 +278,8 @@ struct AttnArgs {
     const uint8_t* key_mask;   // [B, Lk] 1 = attend, or nullptr
     uint8_t* keep_out;      // forward only: optional [B, H, Lq, Lk] export of the dropout mask (tests)
     int B, H, Lq, Lk, causal;
+    int ld_q, ld_kv;        // row stride (elements) of q / dq and of k, v / dk, dv: H*64 for separate projection outputs, 3*H*64
+                            // for the columns of a fused [B, L, 3*H*64] q|k|v buffer (o and dout are always H*64 wide)
     float scale;
     uint32_t thr;           // drop iff hash < thr (p * 2^32); 0 = no dropout
     float inv_keep;

@@ -193,6 +193,7 @@ def attention_core(q, k, v, num_heads, attn_mask, causal, p, training):
 
 
 EAGER_ATTENTION = _os.environ.get("VLPET_EAGER_ATTENTION", "0") == "1"   # A/B switch: the library (SDPA) path for every shape
+FUSE_QKV = _os.environ.get("VLPET_NO_FUSED_QKV", "0") != "1"              # A/B switch: separate q / k / v projections in self-attention
 
 
 class BartAttention(nn.Module):
@@ -226,9 +227,37 @@ class BartAttention(nn.Module):
     def _shape(self, t, B):
         return t.view(B, -1, self.num_heads, self.head_dim).transpose(1, 2)
 
+    def _fused_qkv(self, dtype):
+        """The frozen q | k | v projections of a self-attention as one [3E, E] weight (a derived cache keyed on the three
+        modules' tensors: rebuilt when any of them changes; never a parameter, the state dict keeps q_proj / k_proj / v_proj)."""
+        mods = (self.q_proj, self.k_proj, self.v_proj)
+        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods) + (dtype,)
+        c = getattr(self, "_qkv_cache", None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                w = torch.cat([m.weight.to(dtype) for m in mods], 0).contiguous()
+                b = torch.cat([m.bias.to(dtype) for m in mods], 0).contiguous()
+            c = (key, w, b)
+            self._qkv_cache = c
+        return c[1], c[2]
+
     def forward(self, hidden, kv=None, attn_mask=None, causal=False, task=None):
         B, L, _ = hidden.shape
         src = hidden if kv is None else kv
+        if kv is None and FUSE_QKV and not self.use_lora and not EAGER_ATTENTION:
+            # self-attention with frozen projections: one [E -> 3E] GEMM each way, the attention kernels read / write the
+            # q | k | v column blocks in place (one input gradient instead of three that autograd would have to sum)
+            from .. import attention as A
+            frozen = not any(t.requires_grad for m in (self.q_proj, self.k_proj, self.v_proj) for t in (m.weight, m.bias))
+            boolean_key_mask = attn_mask is None or (attn_mask.dtype == torch.bool and attn_mask.dim() == 4
+                                                     and attn_mask.shape[1] == 1 and attn_mask.shape[2] == 1)
+            if (frozen and boolean_key_mask and hidden.is_cuda and hidden.dtype == torch.bfloat16 and L <= A.MAX_LEN
+                    and self.head_dim == A.HEAD_DIM):
+                w, b = self._fused_qkv(hidden.dtype)
+                qkv = F.linear(hidden, w, b)
+                km = None if attn_mask is None else attn_mask[:, 0, 0, :]
+                out = A.short_self_attention(qkv, self.num_heads, km, causal and attn_mask is None, self.dropout, self.training)
+                return _linear(self.out_proj, out)
         if self.use_lora:
             q = self.q_proj(hidden, task)
             v = self.v_proj(src, task)
