@@ -36,7 +36,7 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # with rocprofv3 --pmc in its own run at ONE size (M = 28,000, bf16, r = 96) -- bench.py scales them by the run's rows per
 # launch, so for the other task shapes they are an extrapolation (labelled as such in the line).
 PMC_TRAFFIC = {"source": "profiles/r02_pmc_traffic_k1_bwd.md", "measured_at_rows": 28000,
-               "bytes_per_row": {"k1_bwd_rows": 11881.0, "k1_bwd_op": 20264.0}}
+               "bytes_per_row": {"k1_bwd_rows": 11881.0, "k1_bwd_op": 20432.0}}
 IMAGE_TASKS = ["vqa", "gqa", "nlvr", "caption"]
 VIDEO_TASKS = ["tvqa", "how2qa", "tvc", "yc2c"]
 
