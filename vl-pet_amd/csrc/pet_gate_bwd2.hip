@@ -99,29 +99,46 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
     const int lane16 = lane * 16;
     const uint32_t wv_off = (uint32_t)(rg * 1024 + lane16);
 
-    // weight pieces of stage st (own segment): middle a -> pack 1 (up), middle b -> pack 2 (up_t), last -> pack 3 (down_t)
-    auto issue_w = [&](int st) {
-        if (st >= NST) return;
+    // weight pieces of stage st: middle a -> pack 1 (up), middle b -> pack 2 (up_t), last -> pack 3 (down_t).  `both` = the
+    // segments of BOTH chains (the loading wave of the phase, see below); otherwise the own segment (prologue)
+    auto issue_w = [&](int st, bool both) {
+        if (st >= NST) return 0;
         int pack, ss;
         if (st < 2 * S) { ss = st >> 1; pack = (st & 1) ? 2 : 1; } else { ss = st - 2 * S; pack = 3; }
-        const uint8_t* src = pk + (int64_t)pack * pg.pack_bytes + (int64_t)ss * L::SEG_KB * 1024;
-        uint8_t* dst = slot_w(st & 1) + rg * 1024;
+        const int64_t so = (int64_t)pack * pg.pack_bytes + (int64_t)ss * L::SEG_KB * 1024;
+        uint8_t* slot = smem + (size_t)(st & 1) * L::W_B;
+        int n = 0;
 #pragma unroll
-        for (int j = 0; j < PW; ++j) glds16(src + (wv_off + j * RG * 1024), dst + j * RG * 1024);
+        for (int c = 0; c < 2; ++c) {
+            if (!both && c != chain) continue;
+            const uint8_t* src = (c == 0 ? a.pk_a : a.pk_g) + so;
+            uint8_t* dst = slot + (size_t)c * L::SEG_KB * 1024 + rg * 1024;
+#pragma unroll
+            for (int j = 0; j < PW; ++j) glds16(src + (wv_off + j * RG * 1024), dst + j * RG * 1024);
+            n += PW;
+        }
+        return n;
     };
-    // middle-phase rows of block su: res (chain A) / dy (chain G) -> tile t0 / t1 of slot su & 1
-    auto issue_mid_rows = [&](int su) {
+    // Who issues the LDS-DMA of a phase.  Cycle stamps (profiles/r02_stamps_k1_bwd_rows.txt): in the middle phase the gate-chain
+    // wave is the pole of every feature block (9.2 k cycles, of which 1.26 k issuing its seven pieces behind the adapter-chain
+    // waves' in the memory pipe) while the adapter-chain wave idles 2.2 k cycles at the barriers; in the last phase it is the
+    // other way round.  So the wave with the slack loads for both chains of its row group: chain A in the middle phase,
+    // chain G in the last phase; the pole wave issues no loads at all (its data is covered by the loader's vmcnt + the barrier).
+    // middle-phase rows of block su: res -> tile t0, dy -> tile t1 of slot su & 1
+    auto issue_mid_rows = [&](int su, bool both) {
         if (su >= S) return 0;
-        if (isA) glds_rows4(res, rl, su * 128, slot_t0(su & 1), rg);
-        else glds_rows4(dy, rl, su * 128, slot_t1(su & 1), rg);
-        return 4;
+        int n = 0;
+        if (both || isA) { glds_rows4(res, rl, su * 128, slot_t0(su & 1), rg); n += 4; }
+        if (both || !isA) { glds_rows4(dy, rl, su * 128, slot_t1(su & 1), rg); n += 4; }
+        return n;
     };
-    // last-phase rows of block su: dh (chain A) -> tile t0 of slot su % 3; the incoming dx1 (chain G, optional) -> tile t1
-    auto issue_last_rows = [&](int su) {
+    // last-phase rows of block su: dh -> tile t0 of slot su % 3; the incoming dx1 (optional) -> tile t1
+    auto issue_last_rows = [&](int su, bool both) {
         if (su >= S) return 0;
-        if (isA) { glds_rows4(DH, rl, su * 128, slot_t0(su % 3), rg); return 4; }
-        if (DXIN != nullptr) { glds_rows4(DXIN, rl, su * 128, slot_t1(su % 3), rg); return 4; }
-        return 0;
+        int n = 0;
+        if (both || isA) { glds_rows4(DH, rl, su * 128, slot_t0(su % 3), rg); n += 4; }
+        if ((both || !isA) && DXIN != nullptr) { glds_rows4(DXIN, rl, su * 128, slot_t1(su % 3), rg); n += 4; }
+        return n;
     };
 
 #ifdef VLPET_STAMPS
@@ -129,8 +146,8 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
 #endif
     B2STAMP(0);
     // ---- prologue: weights of stage 0, rows of block 0, biases, saved activations
-    issue_w(0);
-    issue_mid_rows(0);
+    issue_w(0, false);
+    issue_mid_rows(0, false);
     copy_bias<RG * 128>(sb, reinterpret_cast<const float*>(a.pk_a + pg.bias_off), nb, tid);
     copy_bias<RG * 128>(sb + nb, reinterpret_cast<const float*>(a.pk_g + pg.bias_off), nb, tid);
     Frag<NS> z[KT];
@@ -171,8 +188,8 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
         f32x16 au[G::NV];
         {
             if (su == 5) B2STAMP(8);
-            issue_w(st + 1);
-            const int nrows = issue_mid_rows(su + 1);
+            int nrows = rl.n_inst;                  // chain G: only its dq stores of the previous block may still be in flight
+            if (isA) { issue_w(st + 1, true); nrows = issue_mid_rows(su + 1, true); }
             if (su == 5) B2STAMP(9);
             const uint8_t* w = slot_w(st & 1);
 #pragma unroll
@@ -217,7 +234,7 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
         }
         // ================= stage b: elementwise backward of the own half, then the contraction over features
         {
-            issue_w(st + 1);
+            if (isA) issue_w(st + 1, true);
             const uint8_t* w = slot_w(st & 1);
             uint8_t* t0 = slot_t0(su & 1);
             uint8_t* t1 = slot_t1(su & 1);
@@ -291,8 +308,8 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
 
     // ---- the dh rows of the last phase: this wave's own stores must have completed; start their stream, then dpre
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    issue_last_rows(0);
-    issue_last_rows(1);
+    issue_last_rows(0, false);
+    issue_last_rows(1, false);
     const int ldz = 32 * RT;
     Frag<NS> dp[KT];
     {
@@ -318,8 +335,8 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
     uint8_t* dxo = reinterpret_cast<uint8_t*>(isA ? a.dxa : a.dxg);
     for (int su = 0; su < S; ++su, ++st) {
         if (su == 5) B2STAMP(24);
-        issue_w(st + 1);
-        const int nrows = issue_last_rows(su + 2);
+        int nrows = 0;
+        if (!isA) { issue_w(st + 1, true); nrows = issue_last_rows(su + 2, true); }
         if (su == 5) B2STAMP(25);
         const uint8_t* w = slot_w(st & 1);
         uint8_t* tile = isA ? slot_t0(su % 3) : slot_t1(su % 3);
