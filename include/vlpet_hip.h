@@ -233,6 +233,45 @@ int vlpet_visproj_wgrad(const void* dpre, const void* feats, float* dw, float* d
                         void* workspace, size_t workspace_bytes,
                         int64_t M, int feat_dim, int d_out, int io_dtype, vlpet_stream_t stream);
 
+/* ---- f4: low-rank visual projector -------------------------------------------------------------
+ * LowRankVisualEmbedding (src/modeling_bart.py:195-334), the feature branch:
+ *     fe  = up(gelu_new(cat_i down_i(feats)))                                    (:278-284)
+ *     fe *= sigmoid(gup(gelu_new(gdown(feats))))  [+ fe  with gate_residual]      (:286-295)
+ *     out = LayerNorm(fe) + r        (r = position branch + order embeddings)     (:298-299, 324-325)
+ * as the K1 kernels in a rectangular form: both chains read the same [M, feat_dim] feature rows
+ * (one LDS tile per stage), the down phase runs over feat_dim, the up phase over d_out, no residual
+ * term, and -- the features being data -- no input gradients.  feat_dim % 64 == 0, d_out % 64 == 0,
+ * tiles 1 or 3 (r, r_g <= 96, both chains padded to the same tile count).
+ *
+ * vlpet_lowrank_pack replaces the module's raw parameters (visual_projector_multihead_down[i].weight
+ * [r/n_heads, feat_dim] / .bias, visual_projector_multihead_up.weight [d_out, r] / .bias; same for the
+ * gate pair) by one fragment-ordered buffer per pair: a square pair pack at d_out (up side + biases)
+ * followed by a down-only pack at feat_dim.  Re-pack after every optimizer step, as for K1.
+ *
+ * packed_g == NULL selects the ungated projector (the gate chain then runs with multiplier 0, offset 1
+ * on packed_a, and the gate's weight gradients are neither computed nor written).
+ * saved: vlpet_saved_bytes(M, tiles, io_dtype) bytes, written by the forward, read by the backward.
+ * Weight gradients: fp32, overwritten; dwd [r, feat_dim], dbd [r], dwu [d_out, r], dbu [d_out] (gate alike). */
+size_t vlpet_lowrank_packed_bytes(int tiles, int feat_dim, int d_out, int io_dtype);
+int vlpet_lowrank_pack(const void* const* wd_heads, const void* const* bd_heads, int n_heads,
+                       const void* wu, const void* bu, int r, int feat_dim, int d_out, int tiles,
+                       int param_dtype, int io_dtype, void* packed, vlpet_stream_t stream);
+int vlpet_lowrank_gate_fwd(const void* feats, const void* packed_a, const void* packed_g, void* fe,
+                           void* saved, int64_t M, int feat_dim, int d_out, int tiles, int gate_residual,
+                           int io_dtype, vlpet_stream_t stream);
+size_t vlpet_lowrank_bwd_workspace_bytes(int64_t M, int feat_dim, int d_out, int tiles, int io_dtype);
+int vlpet_lowrank_gate_bwd(const void* dfe, const void* feats, const void* saved, const void* packed_a,
+                           const void* packed_g, float* dwd, float* dbd, float* dwu, float* dbu,
+                           float* dwgd, float* dbgd, float* dwgu, float* dbgu, int r, int rg,
+                           void* workspace, size_t workspace_bytes, int64_t M, int feat_dim, int d_out,
+                           int tiles, int gate_residual, int io_dtype, vlpet_stream_t stream);
+/* out = LayerNorm(y) * gamma + beta + r, one pass (the K5 kernel with the residual joining after the norm;
+ * src/modeling_bart.py:298-299 then :324-325).  mean / rstd [M] are saved for the backward, which is
+ * vlpet_sublayer_tail_bwd(dout, h_save = y, ..., p = 0, norm_mode = 1): its dx1 is d/dy; d/dr is dout. */
+int vlpet_norm_residual_fwd(const void* y, const void* r, const float* gamma, const float* beta, void* out,
+                            float* mean, float* rstd, int64_t M, int d, float eps, int io_dtype,
+                            vlpet_stream_t stream);
+
 /* ---- K5: sublayer tail ----------------------------------------------------------------------
  * The step right after K1 (and after every decoder sublayer):
  *     norm_mode 1:  out = LayerNorm(x1 + dropout(y)) * gamma + beta

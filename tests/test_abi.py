@@ -71,3 +71,30 @@ def test_product_package_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_lowrank_projector_argument_errors_without_gpu():
+    """f4 entry points (include/vlpet_hip.h, LowRankVisualEmbedding): shapes, ranks, NULLs and alignment are rejected
+    before any launch; the size queries are pure host arithmetic."""
+    from vlpet_amd import _lib
+    lib = _lib.load()
+    assert lib.vlpet_version() >= 220
+    n = lib.vlpet_lowrank_packed_bytes(3, 2048, 768, 1)
+    assert n % 256 == 0 and n > (2048 // 16) * 3 * 1024          # at least the feat_dim-wide down fragments
+    assert lib.vlpet_lowrank_packed_bytes(3, 2048, 768, 0) > n   # fp32 IO: hi/lo split, twice the fragments
+    assert lib.vlpet_lowrank_packed_bytes(6, 2048, 768, 1) == 0 and lib.vlpet_lowrank_packed_bytes(3, 100, 768, 1) == 0
+    assert lib.vlpet_lowrank_bwd_workspace_bytes(1024, 2048, 768, 3, 1) > 2 * 1024 * 768 * 2
+    assert lib.vlpet_lowrank_bwd_workspace_bytes(0, 2048, 768, 3, 1) == 0
+    fwd = lib.vlpet_lowrank_gate_fwd
+    assert fwd(None, None, None, None, None, 0, 2048, 768, 3, 0, 1, None) == -1       # M
+    assert fwd(None, None, None, None, None, 16, 2000, 768, 3, 0, 1, None) == -1      # feat_dim % 64
+    assert fwd(None, None, None, None, None, 16, 2048, 768, 6, 0, 1, None) == -2      # r > 96 has no rows kernel
+    assert fwd(None, None, None, None, None, 16, 2048, 768, 3, 0, 7, None) == -6
+    assert fwd(None, None, None, None, None, 16, 2048, 768, 3, 0, 1, None) == -5
+    assert fwd(16, 16, None, 24, None, 16, 2048, 768, 3, 0, 1, None) == -3            # misaligned output
+    bwd = lib.vlpet_lowrank_gate_bwd
+    assert bwd(*([None] * 13), 96, 96, None, 0, 16, 2048, 768, 3, 0, 1, None) == -5
+    assert bwd(*([16] * 13), 97, 96, 16, 0, 16, 2048, 768, 3, 0, 1, None) == -2       # r beyond the padded rank
+    assert bwd(*([16] * 13), 96, 96, 16, 0, 16, 2048, 768, 3, 0, 1, None) == -4       # workspace too small (VLPET_E_WORKSPACE)
+    assert lib.vlpet_norm_residual_fwd(None, None, None, None, None, None, None, 16, 768, 1e-5, 1, None) == -5
+    assert lib.vlpet_norm_residual_fwd(16, 16, 16, 16, 16, 16, 16, 16, 770, 1e-5, 1, None) == -1

@@ -69,6 +69,12 @@ SIGNATURES = {
     "vlpet_visproj_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "vlpet_visproj_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "vlpet_visproj_wgrad": (c_int, [c_void_p] * 5 + [c_size_t, c_int64, c_int, c_int, c_int, c_void_p]),
+    "vlpet_lowrank_packed_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "vlpet_lowrank_pack": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
+    "vlpet_lowrank_gate_fwd": (c_int, [c_void_p] * 5 + [c_int64] + [c_int] * 5 + [c_void_p]),
+    "vlpet_lowrank_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
+    "vlpet_lowrank_gate_bwd": (c_int, [c_void_p] * 13 + [c_int, c_int, c_void_p, c_size_t, c_int64] + [c_int] * 5 + [c_void_p]),
+    "vlpet_norm_residual_fwd": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_float, c_int, c_void_p]),
     "vlpet_rowgate_partials": (c_int, [c_int64]),
     "vlpet_row_dot": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
     "vlpet_row_affine": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p]),

@@ -7,7 +7,7 @@
 #include <stdio.h>
 #include <vector>
 
-#define VLPET_VERSION 210      // round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients
+#define VLPET_VERSION 220      // round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -161,6 +161,7 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
     a.save = saved; a.save_stride = (int64_t)saved_stride(M, tiles, io_dtype);
     a.dbg = 0;
     a.dbg_ts = nullptr;
+    a.d_in = 0; a.pk_a_dn = nullptr; a.pk_g_dn = nullptr; a.gm = 1.f; a.go = 0.f;
 #ifdef VLPET_DEBUG      // ablation bits / cycle stamps: debug builds only (function-static device buffer, synchronises, prints)
     { const char* e = getenv("VLPET_DBG"); a.dbg = e ? atoi(e) : 0; }
     if (a.dbg & 16) {     // debug only: per-phase timestamps of wave 0 of every block, printed at the next call
@@ -331,6 +332,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     }
     b.M = M; b.d = d; b.RT = tiles;
     b.s2 = s2; b.sd = sd; b.gs = gs; b.flags = flags;
+    b.gm = 1.f; b.go = 0.f;
     if (saved && !aligned16(saved)) return VLPET_E_ALIGN;
     b.saved = saved; b.saved_stride = (int64_t)saved_stride(M, tiles, io_dtype);
     if (saved) {        // z comes from the forward; the rows kernel does not write it
@@ -590,6 +592,170 @@ extern "C" int vlpet_visproj_wgrad(const void* dpre, const void* feats, float* d
     return 0;
 }
 
+// ------------------------------------------------------------------ f4: low-rank visual projector
+// LowRankVisualEmbedding (src/modeling_bart.py:195-334):  fe = up(gelu_new(cat_i down_i(feats))) [* (sigmoid(gup(gelu_new(gdown(feats)))) (+ 1))]
+// One packed buffer per projection pair: [square pair pack at d_out: up, up_t, biases (down slots zero)] [down-only pack at feat_dim].
+static inline bool lowrank_dims_ok(int feat_dim, int d_out) {
+    return feat_dim > 0 && feat_dim % 64 == 0 && d_out > 0 && d_out % 64 == 0;
+}
+static inline size_t lowrank_sq_bytes(int tiles, int d_out, int NS) { return align256((size_t)pack_geom(tiles, d_out, NS).total_bytes); }
+static inline size_t lowrank_dn_bytes(int tiles, int feat_dim, int NS) {
+    return align256((size_t)(feat_dim / 16) * tiles * NS * 1024 + (size_t)(32 * tiles + feat_dim) * 4);
+}
+extern "C" size_t vlpet_lowrank_packed_bytes(int tiles, int feat_dim, int d_out, int io_dtype) {
+    if (!(tiles == 1 || tiles == 3) || !lowrank_dims_ok(feat_dim, d_out)) return 0;
+    const int NS = io_dtype == VLPET_F32 ? 2 : 1;
+    return lowrank_sq_bytes(tiles, d_out, NS) + lowrank_dn_bytes(tiles, feat_dim, NS);
+}
+
+extern "C" int vlpet_lowrank_pack(const void* const* wd_heads, const void* const* bd_heads, int n_heads,
+                                  const void* wu, const void* bu, int r, int feat_dim, int d_out, int tiles,
+                                  int param_dtype, int io_dtype, void* packed, vlpet_stream_t stream) {
+    if (!wd_heads || !wu || !packed) return VLPET_E_NULL;
+    if (!lowrank_dims_ok(feat_dim, d_out) || r <= 0 || n_heads <= 0 || n_heads > VLPET_MAX_HEADS || r % n_heads != 0) return VLPET_E_SHAPE;
+    if (!(tiles == 1 || tiles == 3) || r > 32 * tiles) return VLPET_E_RANK;
+    if (!dtype_ok(param_dtype) || !dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    if (!aligned16(packed)) return VLPET_E_ALIGN;
+    const int NS = io_dtype == VLPET_F32 ? 2 : 1;
+    PackArgs a;
+    for (int i = 0; i < VLPET_MAX_HEADS; ++i) {
+        a.wd[i] = nullptr;
+        a.bd[i] = (bd_heads && i < n_heads) ? bd_heads[i] : nullptr;
+        if (i < n_heads && wd_heads[i] == nullptr) return VLPET_E_NULL;
+    }
+    a.n_heads = n_heads; a.rows_per_head = r / n_heads;
+    a.r = r; a.RT = tiles; a.src_bf16 = param_dtype == VLPET_BF16;
+    // (i) the up side at d_out: up / up_t fragments and both biases; no down weight (its slots come out zero)
+    a.wu = wu; a.bu = bu; a.d = d_out; a.n_packs = 4;
+    a.out = reinterpret_cast<uint8_t*>(packed);
+    hipError_t e = launch_pack_pair(a, NS, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    // (ii) the down side at feat_dim: down fragments only
+    for (int i = 0; i < n_heads; ++i) a.wd[i] = wd_heads[i];
+    a.wu = nullptr; a.bu = nullptr; a.d = feat_dim; a.n_packs = 1;
+    a.out = reinterpret_cast<uint8_t*>(packed) + lowrank_sq_bytes(tiles, d_out, NS);
+    return herr(launch_pack_pair(a, NS, (hipStream_t)stream));
+}
+
+static int lowrank_common(int64_t M, int feat_dim, int d_out, int tiles, int io_dtype) {
+    if (M <= 0 || !lowrank_dims_ok(feat_dim, d_out)) return VLPET_E_SHAPE;
+    if (io_dtype == VLPET_F32 && (feat_dim % 32 != 0)) return VLPET_E_SHAPE;
+    if (!(tiles == 1 || tiles == 3)) return VLPET_E_RANK;
+    if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    return 0;
+}
+
+// packed_g == NULL: ungated projector (the gate chain runs on packed_a with multiplier 0, offset 1).
+// gate_residual: 1 = fe + fe*gate (use_visual_projector_residual_connection), 0 = fe*gate.
+extern "C" int vlpet_lowrank_gate_fwd(const void* feats, const void* packed_a, const void* packed_g, void* fe,
+                                      void* saved, int64_t M, int feat_dim, int d_out, int tiles, int gate_residual,
+                                      int io_dtype, vlpet_stream_t stream) {
+    int rc = lowrank_common(M, feat_dim, d_out, tiles, io_dtype);
+    if (rc) return rc;
+    if (!feats || !packed_a || !fe) return VLPET_E_NULL;
+    if (!aligned16(feats) || !aligned16(packed_a) || !aligned16(fe) || (packed_g && !aligned16(packed_g)) ||
+        (saved && !aligned16(saved))) return VLPET_E_ALIGN;
+    const int NS = io_dtype == VLPET_F32 ? 2 : 1;
+    const size_t sq = lowrank_sq_bytes(tiles, d_out, NS);
+    const bool gated = packed_g != nullptr;
+    const uint8_t* pa = reinterpret_cast<const uint8_t*>(packed_a);
+    const uint8_t* pgt = gated ? reinterpret_cast<const uint8_t*>(packed_g) : pa;
+    PetFwdArgs a;
+    a.xa = feats; a.res = nullptr; a.xg = feats; a.out = fe;
+    a.pk_a = pa; a.pk_g = pgt;
+    a.pk_a_dn = pa + sq; a.pk_g_dn = pgt + sq;
+    a.drop = NO_DROP;
+    a.M = M; a.d = d_out; a.d_in = feat_dim; a.RT = tiles;
+    a.s2 = 0.f; a.sd = 1.f; a.gs = 1.f; a.flags = PET_GATE;
+    a.gm = gated ? 1.f : 0.f; a.go = gated ? (gate_residual ? 1.f : 0.f) : 1.f;
+    a.save = saved; a.save_stride = (int64_t)saved_stride(M, tiles, io_dtype);
+    a.dbg = 0; a.dbg_ts = nullptr;
+    return herr(launch_pet_lowrank_fwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
+struct LowrankWs { size_t dp_a, dp_g, dh, dq, partial, total; int row_chunks; int64_t rows_per_chunk; };
+static LowrankWs lowrank_ws(int64_t M, int feat_dim, int d_out, int tiles, int io_dtype) {
+    LowrankWs w{};
+    const size_t esz = io_dtype == VLPET_F32 ? 4 : 2;
+    const size_t side = align256((size_t)M * 32 * tiles * esz), wide = align256((size_t)M * d_out * esz);
+    size_t o = 0;
+    w.dp_a = o; o += side; w.dp_g = o; o += side; w.dh = o; o += wide; w.dq = o; o += wide;
+    const int xmax = feat_dim > d_out ? feat_dim : d_out;
+    wgrad_plan(M, 4, xmax, &w.row_chunks, &w.rows_per_chunk);
+    w.partial = o; o += align256(wgrad_workspace_bytes(4, tiles, xmax, w.row_chunks));
+    w.total = o;
+    return w;
+}
+extern "C" size_t vlpet_lowrank_bwd_workspace_bytes(int64_t M, int feat_dim, int d_out, int tiles, int io_dtype) {
+    if (lowrank_common(M, feat_dim, d_out, tiles, io_dtype)) return 0;
+    return lowrank_ws(M, feat_dim, d_out, tiles, io_dtype).total;
+}
+
+// dfe = d loss / d fe ([M, d_out]); `saved` = the forward's block.  Weight gradients (fp32, overwritten): dwd [r, feat_dim],
+// dbd [r], dwu [d_out, r], dbu [d_out] and the gate's four (ignored and may be NULL when packed_g == NULL).
+extern "C" int vlpet_lowrank_gate_bwd(const void* dfe, const void* feats, const void* saved, const void* packed_a,
+                                      const void* packed_g, float* dwd, float* dbd, float* dwu, float* dbu,
+                                      float* dwgd, float* dbgd, float* dwgu, float* dbgu, int r, int rg,
+                                      void* workspace, size_t workspace_bytes, int64_t M, int feat_dim, int d_out,
+                                      int tiles, int gate_residual, int io_dtype, vlpet_stream_t stream) {
+    int rc = lowrank_common(M, feat_dim, d_out, tiles, io_dtype);
+    if (rc) return rc;
+    const bool gated = packed_g != nullptr;
+    if (!dfe || !feats || !saved || !packed_a || !dwd || !dbd || !dwu || !dbu || !workspace) return VLPET_E_NULL;
+    if (gated && (!dwgd || !dbgd || !dwgu || !dbgu)) return VLPET_E_NULL;
+    if (r <= 0 || r > 32 * tiles || (gated && (rg <= 0 || rg > 32 * tiles))) return VLPET_E_RANK;
+    if (!aligned16(dfe) || !aligned16(feats) || !aligned16(saved) || !aligned16(packed_a) || !aligned16(workspace) ||
+        (gated && !aligned16(packed_g))) return VLPET_E_ALIGN;
+    const LowrankWs w = lowrank_ws(M, feat_dim, d_out, tiles, io_dtype);
+    if (workspace_bytes < w.total) return VLPET_E_WORKSPACE;
+    uint8_t* ws = reinterpret_cast<uint8_t*>(workspace);
+    const uint8_t* sv = reinterpret_cast<const uint8_t*>(saved);
+    PetBwdArgs b;
+    b.dy = dfe; b.xa = feats; b.res = nullptr; b.xg = feats;
+    b.dxa = nullptr; b.dxg = nullptr; b.dxg_in = nullptr;
+    b.saved = saved; b.saved_stride = (int64_t)saved_stride(M, tiles, io_dtype);
+    b.z_a = const_cast<uint8_t*>(sv); b.z_g = const_cast<uint8_t*>(sv) + 2 * b.saved_stride;
+    b.dp_a = ws + w.dp_a; b.dp_g = ws + w.dp_g; b.dh = ws + w.dh; b.dq = ws + w.dq;
+    b.pk_a = reinterpret_cast<const uint8_t*>(packed_a);
+    b.pk_g = gated ? reinterpret_cast<const uint8_t*>(packed_g) : b.pk_a;
+    b.drop = NO_DROP;
+    b.M = M; b.d = d_out; b.RT = tiles;
+    b.s2 = 0.f; b.sd = 1.f; b.gs = 1.f; b.flags = PET_GATE;
+    b.gm = gated ? 1.f : 0.f; b.go = gated ? (gate_residual ? 1.f : 0.f) : 1.f;
+    hipError_t e = launch_pet_lowrank_bwd(b, io_dtype == VLPET_F32, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+
+    WgradArgs g{};
+    g.M = M; g.RT = tiles; g.row_chunks = w.row_chunks; g.rows_per_chunk = w.rows_per_chunk;
+    g.partial = reinterpret_cast<float*>(ws + w.partial);
+    const int ldp = 32 * tiles;
+    auto job = [&](int i, const void* P, const void* X, int xw, float* out, int ldo, int transposed, int out_rows,
+                   float* csx, float* csp) {
+        WgradJob& J = g.job[i];
+        J.P = P; J.ldp = ldp; J.pcols = ldp;
+        J.X = X; J.ldx = xw; J.xcols = xw;
+        J.drop = NO_DROP; J.has_drop = 0;
+        J.scale = 1.f; J.out = out; J.ldo = ldo; J.transposed = transposed; J.out_rows = out_rows;
+        J.colsum_x = csx; J.colsum_p = csp;
+    };
+    job(0, b.dp_a, feats, feat_dim, dwd, feat_dim, 0, r, nullptr, dbd);     // dWd[c,k] = sum_m dpre[m,c] feats[m,k]
+    job(1, b.z_a, b.dh, d_out, dwu, r, 1, r, dbu, nullptr);                  // dWu[f,c] = sum_m dh[m,f] z[m,c]
+    g.njobs = 2;
+    if (gated) {
+        job(2, b.dp_g, feats, feat_dim, dwgd, feat_dim, 0, rg, nullptr, dbgd);
+        job(3, b.z_g, b.dq, d_out, dwgu, rg, 1, rg, dbgu, nullptr);
+        g.njobs = 4;
+    }
+    return herr(launch_wgrad(g, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
+// out = LayerNorm(y) * gamma + beta + r   (visual_projector_layer_norm, then the position / order-embedding term:
+// src/modeling_bart.py:298-299, 324-325).  Backward: vlpet_sublayer_tail_bwd with h_save = y, p = 0 (its dx1 is d/dy;
+// d/dr is dout itself).
+extern "C" int vlpet_norm_residual_fwd(const void* y, const void* r, const float* gamma, const float* beta, void* out,
+                                       float* mean, float* rstd, int64_t M, int d, float eps, int io_dtype,
+                                       vlpet_stream_t stream);
+
 // ---- K5 sublayer tail -------------------------------------------------------------------------------------
 static int tail_common(int64_t M, int d, float p, int io_dtype) {
     if (M <= 0 || d <= 0 || d % 8 != 0) return VLPET_E_SHAPE;
@@ -621,6 +787,20 @@ extern "C" int vlpet_sublayer_tail_fwd(const void* y, const void* x1, const floa
     a.y = y; a.x1 = x1; a.out = out; a.h = h_save; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd;
     a.keep_out = keep_out; a.dgb = nullptr; a.M = M; a.d = d; a.eps = eps; a.thr = tail_thr(p);
     a.keep_scale = 1.0f / (1.0f - p); a.seed = seed; a.norm = norm_mode;
+    return herr(launch_tail(a, io_dtype == VLPET_F32, false, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_norm_residual_fwd(const void* y, const void* r, const float* gamma, const float* beta, void* out,
+                                       float* mean, float* rstd, int64_t M, int d, float eps, int io_dtype,
+                                       vlpet_stream_t stream) {
+    int rc = tail_common(M, d, 0.f, io_dtype);
+    if (rc) return rc;
+    if (!y || !r || !out || !gamma || !mean || !rstd) return VLPET_E_NULL;
+    if (!aligned16(y) || !aligned16(r) || !aligned16(out)) return VLPET_E_ALIGN;
+    TailArgs a{};
+    a.y = y; a.x1 = r; a.out = out; a.h = nullptr; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd;
+    a.keep_out = nullptr; a.dgb = nullptr; a.M = M; a.d = d; a.eps = eps; a.thr = 0; a.keep_scale = 1.f; a.seed = 0;
+    a.norm = 1; a.post = 1;
     return herr(launch_tail(a, io_dtype == VLPET_F32, false, (hipStream_t)stream));
 }
 

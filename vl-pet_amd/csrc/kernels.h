@@ -44,9 +44,17 @@ struct PetFwdArgs {
     int64_t save_stride;   //   tensors at save + k*save_stride bytes: z_a, gelu'(pre_a), z_g, gelu'(pre_g)
     int dbg;               // ablation bits (env VLPET_DBG; 0 in production): 1 no weight stream, 2 no row loads, 8 no stores, 16 timestamps
     unsigned long long* dbg_ts;   // [blocks][8] s_memtime stamps of wave 0 (only when dbg & 16)
+    // low-rank visual projector (LowRankVisualEmbedding, src/modeling_bart.py:195-334): both chains read the SAME
+    // [M, d_in] input (xa), the output is d wide; down weights come from separate down-only packs of width d_in
+    int d_in;                  // 0: square form (input width = d)
+    const uint8_t* pk_a_dn;    // down pack (n_packs = 1 form) of chain A at width d_in
+    const uint8_t* pk_g_dn;    // same, chain G
+    float gm, go;              // gate value = gm * sigmoid(.) + go  (gated: gm = 1, go = 1 with use_visual_projector_residual_connection
+                               //   else 0; ungated projector: gm = 0, go = 1)
 };
 hipError_t launch_pet_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream);
 hipError_t launch_pet_gate_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream);   // PET_GATE only
+hipError_t launch_pet_lowrank_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream);   // low-rank visual projector form (d_in != d)
 
 struct PetBwdArgs {
     const void* dy;     // [M,d]
@@ -70,11 +78,13 @@ struct PetBwdArgs {
     int d, RT;
     float s2, sd, gs;
     int flags;
+    float gm, go;           // low-rank visual projector: gate value = gm * sigmoid(.) + go (unused otherwise)
 };
 hipError_t launch_pet_bwd(const PetBwdArgs& a, int io_fp32, hipStream_t stream);
 // chain-split form of the same (pet_gate_bwd2.hip): gated K1 with saved activations
 bool pet_gate_bwd2_applies(const PetBwdArgs& a);
 hipError_t launch_pet_gate_bwd2(const PetBwdArgs& a, int io_fp32, hipStream_t stream);
+hipError_t launch_pet_lowrank_bwd(const PetBwdArgs& a, int io_fp32, hipStream_t stream);   // low-rank visual projector form: dh, dq, dpre only
 
 // Weight gradients:  Out[c, n] = scale * sum_m P[m, c] * X[m, n]   (P skinny, X wide), plus the
 // column sums of X (bias of the "up" side) and of P (bias of the "down" side).
@@ -163,6 +173,9 @@ struct TailArgs {
     float keep_scale;       // 1 / (1 - p)
     uint64_t seed;
     int norm;
+    int post;               // 1: out = LayerNorm(dropout(y)) + x1  (x1 is added AFTER the norm: the visual projectors' position /
+                            //    order-embedding term, src/modeling_bart.py:298-299, 324-325); forward only -- the backward of
+                            //    that form is the plain one with h = y (dx1 := d/dy, the caller passes dout on as d/dx1)
 };
 hipError_t launch_tail(const TailArgs& a, int io_fp32, bool bwd, hipStream_t stream);
 int tail_blocks(int64_t M);

@@ -10,13 +10,13 @@ __device__ __forceinline__ float ld_src(const void* p, int64_t idx, int bf16_src
     return bf16_src ? (float)reinterpret_cast<const __bf16*>(p)[idx] : reinterpret_cast<const float*>(p)[idx];
 }
 __device__ __forceinline__ float fetch_down(const PackArgs& a, int c, int k) {
-    if (c >= a.r) return 0.f;
+    if (c >= a.r || a.wd[0] == nullptr) return 0.f;      // (no down weight: the up-side pack of the low-rank visual projector)
     int head = c / a.rows_per_head;
     int cc = c - head * a.rows_per_head;
     return ld_src(a.wd[head], (int64_t)cc * a.d + k, a.src_bf16);
 }
 __device__ __forceinline__ float fetch_up(const PackArgs& a, int f, int c) {
-    if (c >= a.r) return 0.f;
+    if (c >= a.r || a.wu == nullptr) return 0.f;
     return ld_src(a.wu, (int64_t)f * a.r + c, a.src_bf16);
 }
 

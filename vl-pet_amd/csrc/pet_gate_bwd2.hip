@@ -54,7 +54,10 @@ __device__ unsigned long long g_b2_ts[64];
 #define B2STAMP(k) do { } while (0)
 #endif
 
-template <typename IO, int RT, int RG>
+// LR = low-rank visual projector form (LowRankVisualEmbedding, autograd of src/modeling_bart.py:278-295): d is the OUTPUT
+// width; no residual term (res is never read), gate value sigmoid(.) + go, and no input gradients -- the features are data --
+// so the kernel ends after dpre (the weight-gradient kernel then contracts dpre with the [M, d_in] features itself).
+template <typename IO, int RT, int RG, bool LR = false>
 __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
     using G = Geo4<IO>;
     using L = Bwd2Lds<IO, RT, RG>;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
     auto xslot = [&](int writer_chain) { return xbuf + (size_t)writer_chain * L::TILE_B + (size_t)rg * (XH * 256); };
     float* sb = reinterpret_cast<float*>(smem + L::BIAS_OFF);
     const int nb = 32 * RT + d;
-    const int NST = 3 * S;                          // stages: 2S middle (a, b alternating) + S last
+    const int NST = LR ? 2 * S : 3 * S;             // stages: 2S middle (a, b alternating) + S last (none in the LR form)
 
     const RowLanes rl = row_lanes<IO>(row0_wave, a.M, d, rg, lane);
     const int lane16 = lane * 16;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
     auto issue_mid_rows = [&](int su, bool both) {
         if (su >= S) return 0;
         int n = 0;
-        if (both || isA) { glds_rows4(res, rl, su * 128, slot_t0(su & 1), rg); n += 4; }
+        if constexpr (!LR) { if (both || isA) { glds_rows4(res, rl, su * 128, slot_t0(su & 1), rg); n += 4; } }
         if (both || !isA) { glds_rows4(dy, rl, su * 128, slot_t1(su & 1), rg); n += 4; }
         return n;
     };
@@ -176,6 +179,8 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
     // ---- middle phase
     const float* bu = sb + (isA ? 0 : nb) + 32 * RT + G::LW * h;
     const float s2 = a.s2, sd_ = a.sd, gs = a.gs;
+    float gm = 1.f, go = 0.f;
+    if constexpr (LR) { gm = a.gm; go = a.go; }
     const bool gate_add = (a.flags & PET_GATE_ADD) != 0;
     f32x16 dz[RT];
 #pragma unroll
@@ -245,7 +250,12 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
                 for (int ee = 0; ee < EH; ++ee) {
                     const int e = e0 + ee;
                     float r8[8], dy8[8], dh8[8], dq8[8], ox[8];
-                    tile_lane_vals8<IO>(t0, trow, h, e, r8);
+                    if constexpr (LR) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) r8[j] = 0.f;      // (t0 is only the staging tile of dh here)
+                    } else {
+                        tile_lane_vals8<IO>(t0, trow, h, e, r8);
+                    }
                     tile_lane_vals8<IO>(t1, trow, h, e, dy8);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
@@ -263,9 +273,14 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
                             dh8[j] = dyp;
                             dq8[j] = dyp * gt * (1.0f - gt);
                         } else {
-                            const float hv = s2 * r8[j] + sd_ * aAv;
-                            dh8[j] = dyp * gt;
-                            dq8[j] = dh8[j] * hv * (1.0f - gt);
+                            if constexpr (LR) {         // out = sd*aA * (gm*gt + go)
+                                dh8[j] = dyp * (gm * gt + go);
+                                dq8[j] = dyp * (sd_ * aAv) * gm * gt * (1.0f - gt);
+                            } else {
+                                const float hv = s2 * r8[j] + sd_ * aAv;
+                                dh8[j] = dyp * gt;
+                                dq8[j] = dh8[j] * hv * (1.0f - gt);
+                            }
                         }
                     }
                     stage_lane_vals8<IO>(t0, trow, h, e, dh8);
@@ -308,8 +323,10 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
 
     // ---- the dh rows of the last phase: this wave's own stores must have completed; start their stream, then dpre
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    issue_last_rows(0, false);
-    issue_last_rows(1, false);
+    if constexpr (!LR) {
+        issue_last_rows(0, false);
+        issue_last_rows(1, false);
+    }
     const int ldz = 32 * RT;
     Frag<NS> dp[KT];
     {
@@ -327,6 +344,7 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
             }
         }
     }
+    if constexpr (LR) return;                       // no input gradients in the low-rank projector form
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                   // (slot 2 was the exchange buffer: every wave is past its last read)
 
@@ -384,11 +402,11 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
     B2STAMP(4);
 }
 
-template <typename IO, int RT, int RG>
+template <typename IO, int RT, int RG, bool LR = false>
 static hipError_t launch_one(const PetBwdArgs& a, hipStream_t stream) {
     using L = Bwd2Lds<IO, RT, RG>;
     const size_t lds = L::bytes(a.d);
-    auto kern = pet_gate_bwd2_kernel<IO, RT, RG>;
+    auto kern = pet_gate_bwd2_kernel<IO, RT, RG, LR>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -434,5 +452,21 @@ bool pet_gate_bwd2_applies(const PetBwdArgs& a) {
 hipError_t launch_pet_gate_bwd2(const PetBwdArgs& a, int io_fp32, hipStream_t stream) {
     if (a.RT == 1) return io_fp32 ? launch_rt<float, 1>(a, stream) : launch_rt<__bf16, 1>(a, stream);
     if (a.RT == 3) return io_fp32 ? launch_rt<float, 3>(a, stream) : launch_rt<__bf16, 3>(a, stream);
+    return hipErrorInvalidValue;
+}
+
+// low-rank visual projector form: saved activations, multiplicative gate, r, r_g <= 96
+template <typename IO, int RT>
+static hipError_t launch_lr(const PetBwdArgs& a, hipStream_t stream) {
+    switch (pick_row_groups(a.M, 4, 2)) {
+        case 4: return launch_one<IO, RT, 4, true>(a, stream);
+        case 3: if constexpr ((4 * RT) % 3 == 0) return launch_one<IO, RT, 3, true>(a, stream);   // (else: falls through)
+        default: return launch_one<IO, RT, 2, true>(a, stream);
+    }
+}
+hipError_t launch_pet_lowrank_bwd(const PetBwdArgs& a, int io_fp32, hipStream_t stream) {
+    if (!a.saved || !(a.flags & PET_GATE) || (a.flags & PET_GATE_ADD) || drop_active(a.drop)) return hipErrorInvalidValue;
+    if (a.RT == 1) return io_fp32 ? launch_lr<float, 1>(a, stream) : launch_lr<__bf16, 1>(a, stream);
+    if (a.RT == 3) return io_fp32 ? launch_lr<float, 3>(a, stream) : launch_lr<__bf16, 3>(a, stream);
     return hipErrorInvalidValue;
 }

@@ -41,8 +41,12 @@ struct GateLds {
     static size_t bytes(int d) { return (size_t)BIAS_OFF + (size_t)2 * (32 * RT + d) * 4; }
 };
 
-template <typename IO, int RT, bool GATE_ADD, int RG, bool LD>
+// LR = low-rank visual projector form (LowRankVisualEmbedding, src/modeling_bart.py:278-295): both chains read the same
+// [M, d_in] feature rows (one LDS tile per stage instead of two), the down phase runs d_in / FE stages on the separate
+// down-only packs, the up phase d / FE stages; no residual term; the gate value is sigmoid(.) + go.  Loader-wave form only.
+template <typename IO, int RT, bool GATE_ADD, int RG, bool LD, bool LR = false>
 __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(PetFwdArgs a) {
+    static_assert(!LR || LD, "the low-rank projector form exists with loader waves only");
     using G = Geo4<IO>;
     using L = GateLds<IO, RT, RG>;
     constexpr int NS = G::NS;
@@ -57,16 +61,19 @@ __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(Pe
     const int trow = 32 * rg + m;
     const int d = a.d;
     const int64_t row0_wave = (int64_t)blockIdx.x * (RG * 32) + rg * 32;
-    const int S = d / G::FE;
+    const int SU = d / G::FE;                                // up-phase stages (output feature blocks)
+    const int S = LR ? a.d_in / G::FE : SU;                  // down-phase stages (input feature blocks)
     const PackGeom pg = pack_geom(RT, d, NS);
     const uint8_t* pkA = a.pk_a;
     const uint8_t* pkG = a.pk_g;
+    const uint8_t* pkAd = LR ? a.pk_a_dn : a.pk_a;           // down-phase weights (LR: down-only packs of width d_in)
+    const uint8_t* pkGd = LR ? a.pk_g_dn : a.pk_g;
     const uint8_t* xin = reinterpret_cast<const uint8_t*>(isA ? a.xa : a.xg);
     const uint8_t* res = reinterpret_cast<const uint8_t*>(a.res);
     uint8_t* out = reinterpret_cast<uint8_t*>(a.out);
 
     auto slot_w = [&](int j) { return smem + (size_t)j * L::W_B; };
-    auto slot_d = [&](int j) { return smem + L::ROW_OFF + (size_t)j * 2 * L::TILE_B + (isA ? 0 : L::TILE_B); };
+    auto slot_d = [&](int j) { return smem + L::ROW_OFF + (size_t)j * 2 * L::TILE_B + ((isA || LR) ? 0 : L::TILE_B); };
     // up-phase use of the row area, placed by when each down-phase slot was last read (slot (S-1)%3 at stage S-1,
     // (S-2)%3 at S-2, S%3 at S-3): three residual tiles (block b in tile b%3) in slots S%3, S%3, (S+1)%3 and the two
     // gate-exchange buffers (block b in buffer b&1, 16 bytes per lane and piece: 8 bf16 or 4 fp32 values) in the second
@@ -79,10 +86,11 @@ __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(Pe
 
     const RowLanes rl = row_lanes<IO>(row0_wave, a.M, d, rg, lane);
     const int lane16 = lane * 16;
+    constexpr bool no_res = LR;          // compile-time: a runtime test here changes the register allocation of the K1 builds
 
     // ---- weight pieces of stage t (1 KiB each, piece k of [A segment | G segment]); returns how many this wave issued
     auto issue_w = [&](int t) -> int {
-        if (LD || t > 2 * S) return 0;
+        if (LD || t > S + SU) return 0;
         uint8_t* dst = slot_w(t & 1);
         int n = 0;
         for (int k = wave; k < 2 * L::SEG_KB; k += NW) {
@@ -92,7 +100,7 @@ __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(Pe
             if (t < S) woff = (int64_t)t * L::SEG_KB * 1024;
             else {
                 const int su = segA ? t - S - 1 : t - S;
-                if (su < 0 || su >= S) continue;
+                if (su < 0 || su >= SU) continue;
                 woff = pg.pack_bytes + (int64_t)su * L::SEG_KB * 1024;
             }
             glds16((segA ? pkA : pkG) + woff + (size_t)kk * 1024 + lane16, dst + (size_t)k * 1024);
@@ -107,7 +115,7 @@ __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(Pe
             glds_rows4(xin, rl, (t + 2) * 128, slot_d((t + 2) % 3), rg);
             return 4;
         }
-        if (isA && t >= S && t < 2 * S) {        // residual block su = t - S, consumed at stage t + 1
+        if (isA && !no_res && t >= S && t < S + SU) {        // residual block su = t - S, consumed at stage t + 1
             const int su = t - S;
             glds_rows4(res, rl, su * 128, slot_res(su % 3), rg);
             return 4;
@@ -132,26 +140,30 @@ __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(Pe
         if (wave >= NW) {
             const uint8_t* x2p = reinterpret_cast<const uint8_t*>(a.xa);
             const uint8_t* x1p = reinterpret_cast<const uint8_t*>(a.xg);
+            // LR: the input rows are d_in wide (rl addresses the d-wide output / residual rows)
+            RowLanes rli_lr;
+            if constexpr (LR) rli_lr = row_lanes<IO>(row0_wave, a.M, a.d_in, rg, lane);
+            const RowLanes& rli = LR ? rli_lr : rl;
             auto ld_w = [&](int t) {
-                if (t > 2 * S) return;
+                if (t > S + SU) return;
                 uint8_t* dst = slot_w(t & 1);
                 for (int k = rg; k < 2 * L::SEG_KB; k += RG) {
                     const bool segA = k < L::SEG_KB;
                     const int kk = segA ? k : k - L::SEG_KB;
-                    int64_t woff;
-                    if (t < S) woff = (int64_t)t * L::SEG_KB * 1024;
+                    const uint8_t* src;
+                    if (t < S) src = (segA ? pkAd : pkGd) + (int64_t)t * L::SEG_KB * 1024;
                     else {
                         const int su = segA ? t - S - 1 : t - S;
-                        if (su < 0 || su >= S) continue;
-                        woff = pg.pack_bytes + (int64_t)su * L::SEG_KB * 1024;
+                        if (su < 0 || su >= SU) continue;
+                        src = (segA ? pkA : pkG) + pg.pack_bytes + (int64_t)su * L::SEG_KB * 1024;
                     }
-                    glds16((segA ? pkA : pkG) + woff + (size_t)kk * 1024 + lane16, dst + (size_t)k * 1024);
+                    glds16(src + (size_t)kk * 1024 + lane16, dst + (size_t)k * 1024);
                 }
             };
-            auto ld_rows = [&](int t2) {        // down-phase rows of stage t2, both chains of this row group
+            auto ld_rows = [&](int t2) {        // down-phase rows of stage t2, both chains of this row group (LR: one shared tile)
                 uint8_t* base = smem + L::ROW_OFF + (size_t)(t2 % 3) * 2 * L::TILE_B;
-                glds_rows4(x2p, rl, t2 * 128, base, rg);
-                glds_rows4(x1p, rl, t2 * 128, base + L::TILE_B, rg);
+                glds_rows4(x2p, rli, t2 * 128, base, rg);
+                if constexpr (!LR) glds_rows4(x1p, rli, t2 * 128, base + L::TILE_B, rg);
             };
             ld_w(0);
             ld_rows(0);
@@ -159,12 +171,12 @@ __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(Pe
             __syncthreads();
             // residual block b goes out at stage S+b-1 and is consumed at S+b+1: like the down-phase rows, the newest
             // row pieces stay in flight across the barrier (only the weights have a prefetch distance of one stage)
-            for (int t = 0; t <= 2 * S; ++t) {
+            for (int t = 0; t <= S + SU; ++t) {
                 ld_w(t + 1);
                 int nrows = 0;
                 const int b = t - S + 1;
-                if (t + 2 < S) { ld_rows(t + 2); nrows = 8; }
-                else if (b >= 0 && b < S) { glds_rows4(res, rl, b * 128, slot_res(b % 3), rg); nrows = 4; }
+                if (t + 2 < S) { ld_rows(t + 2); nrows = LR ? 4 : 8; }
+                else if (!no_res && b >= 0 && b < SU) { glds_rows4(res, rl, b * 128, slot_res(b % 3), rg); nrows = 4; }
                 wait_vm(nrows);
                 __builtin_amdgcn_s_barrier();
             }
@@ -267,14 +279,16 @@ __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(Pe
     const float* bu = sb + (isA ? 0 : nb) + 32 * RT + G::LW * h;
     const float gs = a.gs;
     const float s2g = a.s2 * gs, sdg = a.sd * gs;      // gate scale folded into the linear part
-    for (; t <= 2 * S; ++t) {
+    float gm = 1.f, go = 0.f;
+    if constexpr (LR) { gm = a.gm; go = a.go; }
+    for (; t <= S + SU; ++t) {
         if (t == S + 5 && (a.dbg & 32)) stamp(5);      // VLPET_DBG & 32: stage stamps from the up phase instead
         issue_w(t + 1);
         const int nrows = issue_rows(t);
         (void)nrows;
         const int su = isA ? t - S - 1 : t - S;
         int n_after = 0;                                // vector-memory operations allowed to stay in flight
-        if (su >= 0 && su < S) {
+        if (su >= 0 && su < SU) {
             const uint8_t* w = slot_w(t & 1) + (isA ? 0 : L::SEG_KB * 1024);
             f32x16 au[G::NV];
 #pragma unroll
@@ -328,7 +342,12 @@ __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(Pe
                 uint8_t* tr = slot_res(su % 3);
                 const uint8_t* xb = slot_x(su & 1);
                 float r[G::LW], o[G::LW], gv[G::LW];
-                tile_lane_vals4<IO>(tr, trow, h, r);
+                if constexpr (no_res) {
+#pragma unroll
+                    for (int i = 0; i < G::LW; ++i) r[i] = 0.f;       // the tile is only the staging area of the output here
+                } else {
+                    tile_lane_vals4<IO>(tr, trow, h, r);
+                }
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     if constexpr (NS == 1) {
@@ -344,7 +363,8 @@ __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(Pe
 #pragma unroll
                 for (int i = 0; i < G::LW; ++i) {
                     const float lin = s2g * r[i] + sdg * au[i >> 4][i & 15];
-                    o[i] = GATE_ADD ? lin + gs * gv[i] : lin * gv[i];
+                    if constexpr (LR) o[i] = lin * (gm * gv[i] + go);  // scale / offset applied in fp32, after the IO-precision exchange
+                    else o[i] = GATE_ADD ? lin + gs * gv[i] : lin * gv[i];
                 }
                 stage_lane_vals4<IO>(tr, trow, h, o);
                 store_rows4(out, rl, su * 128, tr, rg, lane);
@@ -359,11 +379,11 @@ __global__ __launch_bounds__((LD ? 3 : 2) * RG * 64) void pet_gate_fwd_kernel(Pe
     stamp(4);
 }
 
-template <typename IO, int RT, bool GATE_ADD, int RG, bool LD>
+template <typename IO, int RT, bool GATE_ADD, int RG, bool LD, bool LR = false>
 static hipError_t launch_one(const PetFwdArgs& a, hipStream_t stream) {
     using L = GateLds<IO, RT, RG>;
     const size_t lds = L::bytes(a.d);
-    auto kern = pet_gate_fwd_kernel<IO, RT, GATE_ADD, RG, LD>;
+    auto kern = pet_gate_fwd_kernel<IO, RT, GATE_ADD, RG, LD, LR>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -405,4 +425,18 @@ static hipError_t launch_io(const PetFwdArgs& a, hipStream_t stream) {
 
 hipError_t launch_pet_gate_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream) {
     return io_fp32 ? launch_io<float>(a, stream) : launch_io<__bf16>(a, stream);
+}
+
+// low-rank visual projector form (PetFwdArgs::d_in, pk_a_dn, pk_g_dn, go): r, r_g <= 96, multiplicative gate
+template <typename IO, int RT>
+static hipError_t launch_lr(const PetFwdArgs& a, hipStream_t stream) {
+    static_assert(GateLds<IO, RT, 4>::BIAS_OFF + 8 * 1024 <= 160 * 1024, "loader-wave form must fit");
+    return a.M <= 256 * 64 ? launch_one<IO, RT, false, 2, true, true>(a, stream)
+                           : launch_one<IO, RT, false, 4, true, true>(a, stream);
+}
+hipError_t launch_pet_lowrank_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream) {
+    if (a.d_in <= 0 || !a.pk_a_dn || !a.pk_g_dn || (a.flags & PET_GATE_ADD)) return hipErrorInvalidValue;
+    if (a.RT == 1) return io_fp32 ? launch_lr<float, 1>(a, stream) : launch_lr<__bf16, 1>(a, stream);
+    if (a.RT == 3) return io_fp32 ? launch_lr<float, 3>(a, stream) : launch_lr<__bf16, 3>(a, stream);
+    return hipErrorInvalidValue;
 }

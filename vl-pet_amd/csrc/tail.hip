@@ -22,8 +22,11 @@
 
 constexpr int TAIL_WAVES = 4;
 
-template <typename IO, int NP, bool NORM>
+// POST (NORM only): out = LayerNorm(dropout(y)) + x1 -- the residual joins AFTER the norm (visual projectors:
+// src/modeling_bart.py:298-299 then :324-325); statistics and the saved pre-norm tensor are those of dropout(y) alone.
+template <typename IO, int NP, bool NORM, bool POST = false>
 __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
+    static_assert(!POST || NORM, "post-norm residual needs the norm");
     using P = Piece<IO>;
     constexpr int E = P::E;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -69,6 +72,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
         u32x4 ny[NP], nx[NP];
         load_row(row + rstride, ny, nx);
         float h[NP][E];
+        float xpost[POST ? NP : 1][E];
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -77,6 +81,10 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
                 float vy[E], vx[E];
                 P::from_raw(cy[k], vy);
                 P::from_raw(cx[k], vx);
+                if constexpr (POST) {
+#pragma unroll
+                    for (int j = 0; j < E; ++j) { xpost[k][j] = vx[j]; vx[j] = 0.f; }
+                }
                 uint32_t bits = 0xffu;
                 if (thr) {
                     const int64_t e0 = row * d + (int64_t)p * E;
@@ -116,6 +124,10 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
                     float o[E];
 #pragma unroll
                     for (int j = 0; j < E; ++j) o[j] = (h[k][j] - mean) * rstd * gam[k][j] + bet[k][j];
+                    if constexpr (POST) {
+#pragma unroll
+                        for (int j = 0; j < E; ++j) o[j] += xpost[k][j];
+                    }
                     P::store(out + rb + p * 16, o);
                 }
             }
@@ -277,6 +289,9 @@ template <typename IO, int NP, bool NORM>
 static hipError_t launch_np(const TailArgs& a, bool bwd, hipStream_t stream) {
     const int blocks = tail_blocks(a.M);
     if (bwd) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, NORM>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+    else if (NORM && a.post) {
+        if constexpr (NORM) hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, true, true>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+    }
     else hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, NORM>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
     return hipGetLastError();
 }
@@ -294,6 +309,7 @@ static hipError_t launch_io(const TailArgs& a, bool bwd, hipStream_t stream) {
 }
 
 hipError_t launch_tail(const TailArgs& a, int io_fp32, bool bwd, hipStream_t stream) {
+    if (a.post && (!a.norm || bwd)) return hipErrorInvalidValue;      // forward-only form of the norm path
     if (a.norm) return io_fp32 ? launch_io<float, true>(a, bwd, stream) : launch_io<__bf16, true>(a, bwd, stream);
     return io_fp32 ? launch_io<float, false>(a, bwd, stream) : launch_io<__bf16, false>(a, bwd, stream);
 }
