@@ -626,14 +626,17 @@ def golden_vlbart_tiny(tag="vlbart_tiny_d64", seed=7, lora=False, kind="bart", v
 
 
 # ------------------------------------------------------------------ LowRankVisualEmbedding
-def golden_lowrank_vis(tag, gated, d=64, feat_dim=128, r=16, nh=4, rg=8, B=2, N=6, seed=10):
-    """LowRankVisualEmbedding (src/modeling_bart.py:195-334), plain and with the low-rank gate."""
+def golden_lowrank_vis(tag, gated, d=64, feat_dim=128, r=16, nh=4, rg=8, B=2, N=6, seed=10, residual=False):
+    """LowRankVisualEmbedding (src/modeling_bart.py:195-334), plain, with the low-rank gate, and with the gate in its
+    ``fe + fe * gate`` form (``--use_visual_projector_residual_connection``, :292-293)."""
     import torch.nn as nn
     flags = list(VLPET_LARGE_FLAGS) + ["--feat_dim", str(feat_dim), "--visual_projector_down_dim", str(r),
                                        "--visual_projector_multihead_num_head", str(nh),
                                        "--visual_projector_gating_down_dim", str(rg)]
     if gated:
         flags.append("--use_visual_projector_gating_large_x_lowrank")
+    if residual:
+        flags.append("--use_visual_projector_residual_connection")
     config, args = make_config("bart", flags, d_model=d, heads=4, ffn=4 * d)
     config.feat_dim = int(feat_dim); config.pos_dim = 4
     config.vis_use_transformer = False
@@ -657,7 +660,8 @@ def golden_lowrank_vis(tag, gated, d=64, feat_dim=128, r=16, nh=4, rg=8, B=2, N=
     out.backward(dy)
     arrs = {"sd::" + k: T(v) for k, v in ve.state_dict().items()}
     arrs.update({"grad::" + n: T(p.grad) for n, p in ve.named_parameters() if p.grad is not None})
-    save(tag, meta=np.array([d, feat_dim, r, nh, rg, B, N, int(gated)]), feats=T(feats), pos=T(pos), out=T(out), dy=T(dy), **arrs)
+    save(tag, meta=np.array([d, feat_dim, r, nh, rg, B, N, int(gated)] + ([1] if residual else [])), feats=T(feats), pos=T(pos),
+         out=T(out), dy=T(dy), **arrs)
 
 
 # -------------------------------------------------------- trainable-name lists
@@ -688,6 +692,8 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "lowrank":
         golden_lowrank_vis("lowrank_vis_d64", gated=False)
         golden_lowrank_vis("lowrank_vis_gated_d64", gated=True)
+        # the fe + fe * gate form; a second bottleneck geometry (r = 24 over 3 heads, r_g = 32, 3 x 11 rows)
+        golden_lowrank_vis("lowrank_vis_gated_res_d64", gated=True, residual=True, r=24, nh=3, rg=32, B=3, N=11, seed=12)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "video":
         golden_vlbart_tiny("vlbart_tiny_video_d64", seed=11, video=True)
@@ -739,6 +745,8 @@ def main():
     golden_vlbart_tiny("vlt5_tiny_d64", seed=9, kind="t5")
     golden_lowrank_vis("lowrank_vis_d64", gated=False)
     golden_lowrank_vis("lowrank_vis_gated_d64", gated=True)
+    # the fe + fe * gate form; a second bottleneck geometry (r = 24 over 3 heads, r_g = 32, 3 x 11 rows)
+    golden_lowrank_vis("lowrank_vis_gated_res_d64", gated=True, residual=True, r=24, nh=3, rg=32, B=3, N=11, seed=12)
     golden_vlbart_tiny("vlbart_tiny_video_d64", seed=11, video=True)
 
 

@@ -1,0 +1,251 @@
+"""GPU: f4, the low-rank visual projector (LowRankVisualEmbedding, src/modeling_bart.py:195-334) on the HIP path --
+rectangular K1 kernels (feat_dim-wide input, d_model-wide output), weight-gradient kernels, K5 kernel with the residual
+after the norm -- against the reference-generated fixtures (plain, gated, gated with the residual connection) and against
+the oracle at the real geometry (2048 -> 96 -> 768; the video config's 512-wide features) up to the bench's row count.
+
+Tolerances (max |got - ref| / max |ref| per tensor, tests/gpu_cases.rel_err): fp32 IO 1e-3 (products are 3-term bf16
+hi/lo splits, not fp32 arithmetic); bf16 IO 2e-2 on the output and 5e-2 on parameter gradients.  Bias gradients are also
+checked element by element (REL_EL below), which a per-tensor norm would hide for small-magnitude columns."""
+import ctypes
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+sys.path.insert(0, os.path.dirname(__file__))
+from gpu_cases import rel_err  # noqa: E402
+from oracle import vlpet_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+TOL = {torch.float32: (1e-3, 1e-3), torch.bfloat16: (2e-2, 5e-2)}      # (output, parameter gradients)
+
+
+def rel_el(got, ref, floor=0.02):
+    """element-wise |got - ref| / (|ref| + floor * max|ref|): every column is held to its own magnitude"""
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    return float(((got - ref).abs() / (ref.abs() + floor * ref.abs().max().clamp_min(1e-12))).max())
+
+
+def make_cfg(d, F_, r, nh, rg, gated, residual):
+    return SimpleNamespace(d_model=d, feat_dim=F_, pos_dim=4, n_images=2, use_vis_order_embedding=True,
+                           use_vis_layer_norm=True, individual_vis_layer_norm=True, visual_projector_down_dim=r,
+                           visual_projector_multihead_num_head=nh, visual_projector_gating_down_dim=rg,
+                           use_visual_projector_gating_large_x_lowrank=bool(gated),
+                           use_visual_projector_residual_connection=bool(residual))
+
+
+def oracle_run(ve, table, nh, gated, residual, feats, pos, dy):
+    """oracle forward + backward on fp32 CPU copies of the module's parameters; returns (out, {name: grad})"""
+    P = {n: p.detach().float().cpu().clone().requires_grad_(True) for n, p in ve.named_parameters()}
+    gate = None
+    if gated:
+        gate = dict(down_w=P["visual_projector_gating_large_x_down.weight"], down_b=P["visual_projector_gating_large_x_down.bias"],
+                    up_w=P["visual_projector_gating_large_x_up.weight"], up_b=P["visual_projector_gating_large_x_up.bias"])
+    out = O.lowrank_visual_embedding(
+        feats.float().cpu(), pos.float().cpu(),
+        [P[f"visual_projector_multihead_down.{i}.weight"] for i in range(nh)],
+        [P[f"visual_projector_multihead_down.{i}.bias"] for i in range(nh)],
+        P["visual_projector_multihead_up.weight"], P["visual_projector_multihead_up.bias"],
+        P["visual_projector_layer_norm.weight"], P["visual_projector_layer_norm.bias"],
+        P["absolute_vis_pos_embedding.0.weight"], P["absolute_vis_pos_embedding.0.bias"],
+        P["absolute_vis_pos_embedding.1.weight"], P["absolute_vis_pos_embedding.1.bias"],
+        P["img_order_embedding.weight"], P["obj_order_embedding.weight"], gate=gate, gate_residual=residual)
+    out.backward(dy.float().cpu())
+    return out.detach(), {n: p.grad for n, p in P.items()}
+
+
+@pytest.mark.parametrize("name", ["lowrank_vis_d64", "lowrank_vis_gated_d64", "lowrank_vis_gated_res_d64"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lowrank_visual_embedding_fixture(name, dtype):
+    """The drop-in module against the reference-generated fixtures (tests/golden/make_goldens.py, `lowrank`): output and every
+    parameter gradient, state dict loaded with strict=True.  12 / 12 / 33 rows: partial 32-row groups."""
+    from vlpet_amd.visual import LowRankVisualEmbedding
+    z = np.load(os.path.join(G, name + ".npz"))
+    d, F_, r, nh, rg, B, N, gated = [int(v) for v in z["meta"][:8]]
+    residual = len(z["meta"]) > 8 and bool(int(z["meta"][8]))
+    table = nn.Embedding(200, d)
+    ve = LowRankVisualEmbedding(make_cfg(d, F_, r, nh, rg, gated, residual), table)
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    ve.load_state_dict(sd, strict=True)
+    ve.cuda()
+    out = ve(torch.from_numpy(z["feats"]).cuda().to(dtype), torch.from_numpy(z["pos"]).cuda())
+    t_out, t_g = TOL[dtype]
+    assert out.dtype == dtype and tuple(out.shape) == (B, N, d)
+    assert rel_err(out, torch.from_numpy(z["out"])) <= t_out
+    out.backward(torch.from_numpy(z["dy"]).cuda().to(dtype))
+    for n, p in ve.named_parameters():
+        if "obj_order" in n:
+            continue
+        assert p.grad is not None, n
+        assert rel_err(p.grad, torch.from_numpy(z["grad::" + n])) <= t_g, n
+
+
+FORMS = {"plain": (False, False), "gated": (True, False), "gated_res": (True, True)}
+
+
+@pytest.mark.parametrize("form", list(FORMS))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("F_,r,nh,rg", [(2048, 96, 4, 96), (512, 64, 2, 48)])
+def test_lowrank_real_geometry_vs_oracle(form, dtype, F_, r, nh, rg):
+    """2048 -> 96 -> 768 (image-text features) and 512 -> 64 / 48 -> 768 (clip-vit video features, bottlenecks below the
+    padded rank) against the oracle; 37 x 36 = 1332 rows = ten 128-row workgroups + 52 rows."""
+    from vlpet_amd.visual import LowRankVisualEmbedding
+    gated, residual = FORMS[form]
+    torch.manual_seed(11)
+    B, N, d = 37, 36, 768
+    table = nn.Embedding(300, d)
+    ve = LowRankVisualEmbedding(make_cfg(d, F_, r, nh, rg, gated, residual), table)
+    with torch.no_grad():
+        for p in ve.parameters():
+            p.add_(torch.randn_like(p) * 0.03)
+    feats = torch.randn(B, N, F_).to(dtype)
+    pos = torch.rand(B, N, 4)
+    dy = torch.randn(B, N, d).to(dtype)
+    ref_out, ref_g = oracle_run(ve, table, nh, gated, residual, feats, pos, dy)
+    ve.cuda()
+    out = ve(feats.cuda(), pos.cuda())
+    t_out, t_g = TOL[dtype]
+    assert rel_err(out, ref_out) <= t_out
+    out.backward(dy.cuda())
+    for n, p in ve.named_parameters():
+        if "obj_order" in n:
+            continue
+        assert rel_err(p.grad, ref_g[n]) <= t_g, n
+    # bias and LayerNorm gradients element by element (column sums: a wrong column hides under a per-tensor norm)
+    el_tol = 5 * t_g
+    for n in ["visual_projector_multihead_up.bias", "visual_projector_layer_norm.weight", "visual_projector_layer_norm.bias"] + \
+             [f"visual_projector_multihead_down.{i}.bias" for i in range(nh)] + \
+             (["visual_projector_gating_large_x_down.bias", "visual_projector_gating_large_x_up.bias"] if gated else []):
+        assert rel_el(dict(ve.named_parameters())[n].grad, ref_g[n]) <= el_tol, n
+
+
+def _abi_pack(lib, F, down_w, down_b, up_w, up_b, io, tiles):
+    n = len(down_w)
+    rh, feat_dim = down_w[0].shape
+    d = up_w.shape[0]
+    buf = torch.empty(lib.vlpet_lowrank_packed_bytes(tiles, feat_dim, d, io), dtype=torch.uint8, device="cuda")
+    aw = (ctypes.c_void_p * n)(*[w.data_ptr() for w in down_w])
+    ab = (ctypes.c_void_p * n)(*[b.data_ptr() for b in down_b])
+    rc = lib.vlpet_lowrank_pack(aw, ab, n, up_w.data_ptr(), up_b.data_ptr(), rh * n, feat_dim, d, tiles, F._param_dtype(up_w), io,
+                                buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
+    return buf
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 2e-2)])
+def test_lowrank_c_abi_forward_forms(dtype, tol):
+    """vlpet_lowrank_pack / vlpet_lowrank_gate_fwd called directly (no autograd glue): the pre-norm product `fe` of the
+    three forms -- packed_g NULL = up(gelu_new(down(x))); gate_residual 0 / 1 -- against the fp32 op chain of
+    src/modeling_bart.py:278-295, with and without the saved block (inference form)."""
+    from vlpet_amd import _lib, functional as F
+    lib = _lib.load()
+    torch.manual_seed(5)
+    M, Fd, d, r, rg, nh = 333, 512, 768, 96, 32, 4
+    io = F._io_dtype(torch.empty(0, dtype=dtype))
+    x = torch.randn(M, Fd).to(dtype).cuda()
+    wd = [(torch.randn(r // nh, Fd) * 0.04).cuda() for _ in range(nh)]
+    bd = [(torch.randn(r // nh) * 0.1).cuda() for _ in range(nh)]
+    wu, bu = (torch.randn(d, r) * 0.1).cuda(), (torch.randn(d) * 0.1).cuda()
+    gwd, gbd = [(torch.randn(rg, Fd) * 0.04).cuda()], [(torch.randn(rg) * 0.1).cuda()]
+    gwu, gbu = (torch.randn(d, rg) * 0.1).cuda(), (torch.randn(d) * 0.1).cuda()
+    pa = _abi_pack(lib, F, wd, bd, wu, bu, io, 3)
+    pg = _abi_pack(lib, F, gwd, gbd, gwu, gbu, io, 3)          # r_g = 32 padded to the adapter chain's three tiles
+    xf = x.float()
+    u = torch.nn.functional.linear(O.gelu_new(torch.cat([torch.nn.functional.linear(xf, w, b) for w, b in zip(wd, bd)], -1)), wu, bu)
+    g = torch.sigmoid(torch.nn.functional.linear(O.gelu_new(torch.nn.functional.linear(xf, gwd[0], gbd[0])), gwu, gbu))
+    st = torch.cuda.current_stream().cuda_stream
+    for packed_g, residual, ref in ((None, 0, u), (pg, 0, u * g), (pg, 1, u + u * g)):
+        for with_saved in (False, True):
+            fe = torch.empty(M, d, dtype=dtype, device="cuda")
+            saved = torch.empty(lib.vlpet_saved_bytes(M, 3, io), dtype=torch.uint8, device="cuda") if with_saved else None
+            rc = lib.vlpet_lowrank_gate_fwd(x.data_ptr(), pa.data_ptr(), packed_g.data_ptr() if packed_g is not None else None,
+                                            fe.data_ptr(), saved.data_ptr() if saved is not None else None, M, Fd, d, 3, residual,
+                                            io, st)
+            assert rc == 0, rc
+            assert rel_err(fe, ref) <= tol, (packed_g is not None, residual, with_saved)
+
+
+def test_lowrank_norm_residual_abi():
+    """vlpet_norm_residual_fwd: LayerNorm(y) * gamma + beta + r in one pass (statistics of y alone), fp32 and bf16."""
+    from vlpet_amd import _lib, functional as F
+    lib = _lib.load()
+    torch.manual_seed(6)
+    M, d = 1001, 768
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+        y, r = (torch.randn(M, d) * 2 + 0.5).to(dtype).cuda(), torch.randn(M, d).to(dtype).cuda()
+        gam, bet = (torch.rand(d) + 0.5).cuda(), torch.randn(d).cuda()
+        out = torch.empty_like(y)
+        mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+        rc = lib.vlpet_norm_residual_fwd(y.data_ptr(), r.data_ptr(), gam.data_ptr(), bet.data_ptr(), out.data_ptr(), mean.data_ptr(),
+                                         rstd.data_ptr(), M, d, 1e-5, F._io_dtype(y), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, rc
+        ref = torch.nn.functional.layer_norm(y.float(), (d,), gam, bet, 1e-5) + r.float()
+        assert rel_err(out, ref) <= tol
+        assert rel_err(mean, y.float().mean(-1)) <= 1e-5
+        assert rel_err(rstd, (y.float().var(-1, unbiased=False) + 1e-5).rsqrt()) <= 1e-5
+
+
+def test_lowrank_full_bench_rows_bf16():
+    """The bench's average visual row count (M_v = 18,700 > 16,384: the 128-row workgroup form, 147 workgroups, ragged tail)
+    at 2048 -> 96 -> 768, gated, bf16, against the oracle."""
+    from vlpet_amd.visual import LowRankVisualEmbedding
+    torch.manual_seed(21)
+    B, N, F_, d, r, nh, rg = 425, 44, 2048, 768, 96, 4, 96            # 18,700 rows
+    table = nn.Embedding(300, d)
+    ve = LowRankVisualEmbedding(make_cfg(d, F_, r, nh, rg, True, False), table)
+    with torch.no_grad():
+        for p in ve.parameters():
+            p.add_(torch.randn_like(p) * 0.03)
+    feats = torch.randn(B, N, F_).bfloat16()
+    pos = torch.rand(B, N, 4)
+    dy = torch.randn(B, N, d).bfloat16()
+    ref_out, ref_g = oracle_run(ve, table, nh, True, False, feats, pos, dy)
+    ve.cuda()
+    out = ve(feats.cuda(), pos.cuda())
+    assert rel_err(out, ref_out) <= 2e-2
+    out.backward(dy.cuda())
+    for n, p in ve.named_parameters():
+        if "obj_order" not in n:
+            assert rel_err(p.grad, ref_g[n]) <= 5e-2, n
+
+
+def test_lowrank_repack_after_weight_change_and_inference_form():
+    """The pack cache follows in-place parameter updates (Tensor._version) and the fused optimizer's epoch; under no_grad the
+    forward allocates no saved block; a zero-row batch launches nothing and stays connected to the parameters."""
+    from vlpet_amd import functional as F
+    from vlpet_amd.visual import LowRankVisualEmbedding
+    torch.manual_seed(8)
+    d, F_, r, nh, rg = 128, 256, 32, 2, 16
+    table = nn.Embedding(100, d)
+    ve = LowRankVisualEmbedding(make_cfg(d, F_, r, nh, rg, True, True), table).cuda()
+    feats, pos = torch.randn(3, 7, F_).cuda(), torch.rand(3, 7, 4).cuda()
+    with torch.no_grad():
+        a = ve(feats, pos)
+        ve.visual_projector_multihead_up.weight.mul_(0.5)          # in place: bumps _version
+        b = ve(feats, pos)
+        assert not torch.allclose(a, b)
+        raw = ve.visual_projector_gating_large_x_up.bias.data      # behind autograd's back, as the fused AdamW writes
+        raw.view(-1).add_(3.0)
+        F.bump_weights_epoch()
+        c = ve(feats, pos)
+        assert not torch.allclose(b, c)
+    ref_out, _ = oracle_run(ve, table, nh, True, True, feats, pos, torch.zeros(3, 7, d))
+    assert rel_err(c, ref_out) <= 1e-3
+    e = ve(feats[:0], pos[:0])
+    assert tuple(e.shape) == (0, 7, d)
+    e.sum().backward()
+    assert ve.visual_projector_multihead_up.weight.grad is not None
+    assert float(ve.visual_projector_multihead_up.weight.grad.abs().max()) == 0.0
+
+
+def test_lowrank_rejects_wide_bottleneck():
+    """r > 96 has no rectangular rows kernel: an explicit refusal, not a fallback."""
+    from vlpet_amd.visual import LowRankVisualEmbedding
+    ve = LowRankVisualEmbedding(make_cfg(128, 256, 128, 4, 16, True, False), nn.Embedding(50, 128)).cuda()
+    with pytest.raises(NotImplementedError):
+        ve(torch.randn(2, 5, 256).cuda(), torch.rand(2, 5, 4).cuda())

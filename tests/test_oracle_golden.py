@@ -165,11 +165,13 @@ def test_downsample_golden():
     assert torch.equal(i2, t("yi2")) and torch.equal(o2, t("yo2"))
 
 
-@pytest.mark.parametrize("name", ["lowrank_vis_d64", "lowrank_vis_gated_d64"])
+@pytest.mark.parametrize("name", ["lowrank_vis_d64", "lowrank_vis_gated_d64", "lowrank_vis_gated_res_d64"])
 def test_lowrank_visual_embedding_golden(name):
-    """oracle.lowrank_visual_embedding against the reference's LowRankVisualEmbedding (src/modeling_bart.py:195-334)."""
+    """oracle.lowrank_visual_embedding against the reference's LowRankVisualEmbedding (src/modeling_bart.py:195-334):
+    plain, gated (fe * gate) and gated with --use_visual_projector_residual_connection (fe + fe * gate, :292-293)."""
     g = load(name)
-    d, F_, r, nh, rg, B, N, gated = [int(v) for v in g["meta"]]
+    d, F_, r, nh, rg, B, N, gated = [int(v) for v in g["meta"][:8]]
+    residual = len(g["meta"]) > 8 and bool(int(g["meta"][8]))
     P = {k[4:]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith("sd::") and "obj_order" not in k}
     table = g["sd::obj_order_embedding.weight"].clone().requires_grad_(True)
     gate = None
@@ -183,7 +185,7 @@ def test_lowrank_visual_embedding_golden(name):
         P["visual_projector_layer_norm.weight"], P["visual_projector_layer_norm.bias"],
         P["absolute_vis_pos_embedding.0.weight"], P["absolute_vis_pos_embedding.0.bias"],
         P["absolute_vis_pos_embedding.1.weight"], P["absolute_vis_pos_embedding.1.bias"],
-        P["img_order_embedding.weight"], table, gate=gate)
+        P["img_order_embedding.weight"], table, gate=gate, gate_residual=residual)
     close(out, g["out"])
     out.backward(g["dy"])
     for k, v in g.items():

@@ -132,11 +132,12 @@ class LowRankVisualEmbedding(nn.Module):
     optional low-rank sigmoid gate on the features, plus the position / order-embedding terms of ``VisualEmbedding``.
     Same constructor, forward signature and state-dict keys as the reference.
 
-    No launch script of the reference enables it (``--use_lowrank_visual_projector`` is an ablation flag), so it is a
-    composition rather than a dedicated kernel: the feat_dim -> r down projections are plain library GEMMs, and the
-    r -> d_model up projection + LayerNorm + residual add run on the K4 HIP kernel (csrc/visproj.hip) with the
-    bottleneck zero-padded to a multiple of 64.  The gated form (``use_visual_projector_gating_large_x_lowrank``)
-    needs the product before the norm and is expressed with library GEMMs + elementwise ops."""
+    No launch script of the reference enables it (``--use_lowrank_visual_projector`` is an ablation flag).  The feature
+    branch -- both low-rank chains over the feat_dim-wide features, the gate product, LayerNorm and the post-norm add of
+    the position / order-embedding term -- runs on the HIP path (vl-pet_amd/lowrank.py: the K1 kernels in their
+    rectangular form, the weight-gradient kernels, the K5 kernel with the residual after the norm), plain and gated,
+    for bottlenecks up to 96 and feat_dim / d_model multiples of 64.  The 5-wide position branch and the two embedding
+    lookups stay library ops, as in ``VisualEmbedding``."""
 
     def __init__(self, config, obj_order_embedding: nn.Embedding):
         super().__init__()
@@ -166,11 +167,6 @@ class LowRankVisualEmbedding(nn.Module):
     def forward(self, feats, pos, img_order_ids=None, obj_order_ids=None):
         B, N, _ = feats.shape
         assert pos.shape == (B, N, 4)
-        dt = feats.dtype
-
-        def lin(m, x):
-            return F.linear(x, m.weight.to(x.dtype), m.bias.to(x.dtype))
-        z = self.visual_projector_non_linear(torch.cat([lin(m, feats) for m in self.visual_projector_multihead_down], dim=-1))
         pos = pos.float()
         pos5 = torch.cat([pos, self.get_area(pos).unsqueeze(2)], dim=2)
         pl, pn = self.absolute_vis_pos_embedding[0], self.absolute_vis_pos_embedding[1]
@@ -184,20 +180,14 @@ class LowRankVisualEmbedding(nn.Module):
             obj_order_ids = self.obj_order_embedding.num_embeddings - obj_order_ids - 1
             R = R + self.img_order_embedding(img_order_ids).float() + self.obj_order_embedding(obj_order_ids).float()
         R = R.expand(B, N, R.shape[-1])
-        up, ln = self.visual_projector_multihead_up, self.visual_projector_layer_norm
-        if hasattr(self, "visual_projector_gating_large_x_down"):
-            fe = lin(up, z)
-            g = torch.sigmoid(lin(self.visual_projector_gating_large_x_up,
-                                  self.gating_non_linear(lin(self.visual_projector_gating_large_x_down, feats))))
-            fe = fe + fe * g if getattr(self.config, "use_visual_projector_residual_connection", False) else fe * g
-            return F.layer_norm(fe.float(), (fe.shape[-1],), ln.weight.float(), ln.bias.float(), ln.eps).to(dt) + R.to(dt)
-        from types import SimpleNamespace
-        from .visproj import VisProjPackCache, visproj
-        r = z.shape[-1]
-        rp = (r + 63) // 64 * 64
-        zp = F.pad(z, (0, rp - r)).contiguous()
-        wp = F.pad(up.weight, (0, rp - r)).contiguous()          # zero columns: the padding contributes nothing
-        if not hasattr(self, "_vis_cache"):
-            self._vis_cache = VisProjPackCache()
-        return visproj(zp, R, SimpleNamespace(weight=wp, bias=up.bias), ln, self._vis_cache, False)
-
+        from .lowrank import LowRankPackCache, lowrank_project
+        if not hasattr(self, "_lr_caches"):
+            self._lr_caches = (LowRankPackCache(), LowRankPackCache())
+        gated = hasattr(self, "visual_projector_gating_large_x_down")
+        return lowrank_project(
+            feats, R, list(self.visual_projector_multihead_down), self.visual_projector_multihead_up,
+            self.visual_projector_layer_norm,
+            self.visual_projector_gating_large_x_down if gated else None,
+            self.visual_projector_gating_large_x_up if gated else None,
+            bool(getattr(self.config, "use_visual_projector_residual_connection", False)),
+            self._lr_caches[0], self._lr_caches[1])
