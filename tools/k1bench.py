@@ -40,6 +40,23 @@ def run(M, tag):
                                                   M, d, tiles, 1, 1.0, 1.0, 1.0, io, st); assert rc == 0
         return f
     fwd_save()
+    if os.environ.get("K1BENCH_COLD"):
+        # cold mode: the repeated call's inputs are otherwise hits of the 256 MB Infinity Cache left by the previous iteration, which a
+        # training step never sees (third session).  Before every timed call a read-modify-write over 1 GiB.
+        evict = torch.zeros(1 << 28, dtype=torch.float32, device=dev)
+        def cold(fn, iters=15):
+            ts = []
+            for _ in range(iters):
+                evict.add_(1.0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            ts.sort()
+            return ts[len(ts) // 2]
+        f, b, w, op = cold(fwd_save), cold(bwd_saved(1 | 4)), cold(bwd_saved(2 | 4)), cold(bwd_saved(3))
+        print(f"k1bench {tag:10s} M={M:6d} COLD: fwd+save {f:6.1f} us   bwd rows {b:6.1f} us   wgrad+fin (dh, dq cold too) {w:6.1f} us   "
+              f"whole op in one call (phases 3; VLPET_BWD3 applies) {op:6.1f} us (op frac {5 * d * M * 2 / op / 1e3 / 8000:.3f})", flush=True)
+        return
     res = []
     for rep in range(2):
         res.append((timeit(fwd_save, iters=60, warm=5), timeit(bwd_saved(1 | 4), iters=60, warm=5), timeit(bwd_saved(2 | 4), iters=60, warm=5)))

@@ -30,6 +30,18 @@ void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* r
     static const int64_t target = [] { const char* e = getenv("VLPET_WGRAD_WGS"); return e ? (int64_t)atoi(e) : (int64_t)256; }();
     int64_t rc = (target + (int64_t)slabs * njobs / 2) / ((int64_t)slabs * njobs);
     if (rc < 1) rc = 1;
+    // ... and never more row chunks than put ONE workgroup on every CU of an XCD: the grid is numbered XCD-aware (wg_grid:
+    // 8 x nslice x ceil(groups / 8), groups = chunks x jobs), so one chunk too many adds a whole group row -- with 4 jobs and 3
+    // slabs 21 chunks are 84 groups = 33 workgroups on four of the 32-CU XCDs, and the CU that carries two of them finishes
+    // late: cold-input timings (tools/k1bench.py K1BENCH_COLD=1, profiles/r02_wgrad_cold_crossover.txt) jump by 25-40 %
+    // exactly where the plan says 21 (M = 24,000: 94.6 us, 31,616: 116.9) against 20 (28,000: 82.9, 33,200: 93.4).
+    // Applies to the default target only (an explicit VLPET_WGRAD_WGS is taken as given).
+    static const bool explicit_target = getenv("VLPET_WGRAD_WGS") != nullptr;
+    if (!explicit_target) {
+        const int64_t per_xcd = 32 / (slabs < 32 ? slabs : 32);              // (job, chunk) groups per XCD at one workgroup per CU
+        const int64_t rc_max = per_xcd > 0 ? (8 * per_xcd) / njobs : 1;
+        if (rc_max >= 1 && rc > rc_max) rc = rc_max;
+    }
     if (rc > blocks128) rc = blocks128;
     int64_t per = (blocks128 + rc - 1) / rc;          // 128-row blocks per chunk
     rc = (blocks128 + per - 1) / per;
