@@ -39,6 +39,18 @@ __device__ __forceinline__ f32x4 mfma16_ns(const Frag<NS>& a, const Frag<NS>& b,
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gmem_cv*)gsrc, (lmem_v*)lds_wave_base, 16, 0, 0);
 }
+// the same for data that ONE workgroup reads ONCE (activation rows): cache-policy bits of the build (aux 2 = nt; MI355X_MICROARCH.md
+// "nt-weights": issue -> landed -18 % for a stream a single CU reads once, -6 % end to end when every CU re-reads it -- so never on
+// the packed weights).  Measured here (profiles/r02_k1bench_nt_row_loads.txt, r02_bench_instep_nt_row_loads_ab.txt): with cold inputs
+// K1 forward 70.6 -> 57.9 us, backward rows 97.0 -> 85.5, weight gradients 84.6 -> 60.9 at M = 28,000 (warm, i.e. a microbenchmark
+// re-reading its own previous iteration from the Infinity Cache, 3-10 % slower); in the training step 23.3 k -> 23.7 k samples/s.
+// -DVLPET_ROW_AUX=0 builds the default-policy variant for A/B.
+#ifndef VLPET_ROW_AUX
+#define VLPET_ROW_AUX 2
+#endif
+__device__ __forceinline__ void glds16_row(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gmem_cv*)gsrc, (lmem_v*)lds_wave_base, 16, 0, VLPET_ROW_AUX);
+}
 
 // ---- row tiles: [rows][8 slots of 16 B]; slot = piece ^ swz(row), swizzle applied on the SOURCE side
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }

@@ -125,7 +125,7 @@ __device__ __forceinline__ RowLanes row_lanes(int64_t row0_wave, int64_t M, int 
 __device__ __forceinline__ void glds_rows4(const uint8_t* base, const RowLanes& rl, int so, uint8_t* tile, int wave) {
     uint8_t* dst = tile + (size_t)(32 * wave) * 128;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(base + rl.off[i] + so, dst + i * 1024);
+    for (int i = 0; i < 4; ++i) glds16_row(base + rl.off[i] + so, dst + i * 1024);
 }
 // the wave's rows of `tile` (slot order) -> whole-line stores
 __device__ __forceinline__ void store_rows4(uint8_t* base, const RowLanes& rl, int so, const uint8_t* tile,

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
                 const int k = (i - NWP) / 4, q = (i - NWP) % 4;
                 const uint8_t* base = k ? P.r1 : P.r0;
                 uint8_t* dst = k ? P.d1 : P.d0;
-                if (base) glds16(base + rl.off[q], dst + q * 1024);
+                if (base) glds16_row(base + rl.off[q], dst + q * 1024);
             }
         }
     };

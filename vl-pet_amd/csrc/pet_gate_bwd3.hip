@@ -443,7 +443,7 @@ __global__ __launch_bounds__(NRG * 256) void pet_gate_cols_kernel(ColsArgs a) {
         if (row0t + 32 <= a.M) {
             const uint8_t* base = Xsrc + row0t * d * (int64_t)sizeof(IO) + su * 128;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) glds16(base + voff[i], dst + i * 1024);
+            for (int i = 0; i < 4; ++i) glds16_row(base + voff[i], dst + i * 1024);
         } else {
             const RowLanes rl = row_lanes<IO>(row0t, a.M, d, 0, lane);
             glds_rows4(Xsrc, rl, su * 128, dst, 0);
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(NRG * 128) void pet_gate_cols2_kernel(ColsArgs a) {
         if (row0t + 32 <= a.M) {
             const uint8_t* base = src + row0t * d * (int64_t)sizeof(IO) + su * 128;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) glds16(base + voff[i], dst + i * 1024);
+            for (int i = 0; i < 4; ++i) glds16_row(base + voff[i], dst + i * 1024);
         } else {
             const RowLanes rl = row_lanes<IO>(row0t, a.M, d, 0, lane);
             glds_rows4(src, rl, su * 128, dst, 0);

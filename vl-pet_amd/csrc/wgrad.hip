@@ -600,7 +600,7 @@ __global__ __launch_bounds__(VLPET_THREADS, (RT <= 3 ? 2 : 1)) void wgrad_stream
         for (int i = 0; i < 4; ++i) {
             int64_t row = rb + 8 * i + xrow;
             if (row >= r_end) row = r_end - 1;
-            glds16(X + row * ldxb + xsrc, sx_ + i * 1024);
+            glds16_row(X + row * ldxb + xsrc, sx_ + i * 1024);
         }
     };
 
