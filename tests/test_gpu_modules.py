@@ -301,3 +301,52 @@ def test_residual_gradient_handover_between_tail_and_k1(dtype):
     for n in outs[1][2]:
         a, b = outs[0][2][n], outs[1][2][n]
         assert (a - b).abs().max().item() <= tol * max(b.abs().max().item(), 1e-6), n
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("which", ["encoder", "decoder"])
+def test_gemm_gradient_handover(which, p_drop):
+    """The dgrad GEMM of a sublayer's first frozen projection accumulates onto the gradient K1 / K5 / K2 parked
+    (functional.linear_acc, host/bart.py _first_linear) -- against plain autograd sums (FUSE_GEMM_GRAD off): same output,
+    same gradients for the layer input, the encoder output and every trainable parameter.  p_drop = 0 is the case where the
+    tail's dy and dx1 are one tensor (the consumer must not accumulate in place)."""
+    import vlpet_amd.host.bart as HB
+    import vlpet_amd.train as TR
+    torch.manual_seed(11)
+    dtype = torch.bfloat16
+    cfg = HB.vlpet_config(encoder_layers=1, decoder_layers=1, vocab_size=300, dropout=p_drop, attention_dropout=p_drop,
+                          activation_dropout=p_drop)
+    layer = HB.BartEncoderLayer(cfg) if which == "encoder" else HB.BartDecoderLayer(cfg)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.randn_like(p) * 0.03)
+    layer.cuda().train()
+    for n, p in layer.named_parameters():
+        p.requires_grad = ("adapter" in n) or ("gating" in n) or ("layer_norm" in n)
+    TR.cast_frozen(layer, dtype)
+    B, L, S = 40, 20, 56
+    x = torch.randn(B, S if which == "encoder" else L, 768, device="cuda").to(dtype)
+    enc = torch.randn(B, S, 768, device="cuda").to(dtype)
+    dy = torch.randn_like(x)
+    outs = []
+    for fuse in (True, False):
+        HB.FUSE_GEMM_GRAD = fuse
+        try:
+            for p in layer.parameters():
+                p.grad = None
+            torch.manual_seed(5)                    # the dropout seeds of the kernels are drawn from torch's generator
+            xi, ei = x.clone().requires_grad_(True), enc.clone().requires_grad_(True)
+            y = layer(xi) if which == "encoder" else layer(xi, ei, task="vqa")
+            y.backward(dy)
+            g = {n: p.grad.float().clone() for n, p in layer.named_parameters() if p.grad is not None}
+            g["<input>"] = xi.grad.float()
+            if which == "decoder":
+                g["<encoder output>"] = ei.grad.float()
+            outs.append((y.detach().float(), g))
+        finally:
+            HB.FUSE_GEMM_GRAD = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1].keys() == outs[1][1].keys() and len(outs[0][1]) > 2
+    for n in outs[1][1]:
+        a, b = outs[0][1][n], outs[1][1][n]
+        assert (a - b).abs().max().item() <= 2e-2 * max(b.abs().max().item(), 1e-6), n

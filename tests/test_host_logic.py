@@ -141,3 +141,78 @@ def test_per_task_parameter_detection():
         names = TR.trainable_names(m, cfg)
         ps = dict(m.named_parameters())
         assert TR._has_per_task_params(names, [ps[n] for n in names]) is expect
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# functional.linear_acc: the dgrad GEMM of a frozen projection accumulates onto a parked gradient (pure torch: runs on CPU)
+
+def _park_op():
+    """A stand-in for K1 / K5 / K2: reads x and y = proj(x), parks its d/dx in the link when that is armed."""
+    import torch
+
+    class Park(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, y, link, shared):
+            ctx.link = link if (link is not None and link.armed) else None
+            ctx.shared = shared
+            ctx.save_for_backward(x, y)
+            return y * x.sum(-1, keepdim=True) + 3.0 * x[..., : y.shape[-1]]
+
+        @staticmethod
+        def backward(ctx, g):
+            x, y = ctx.saved_tensors
+            dy = g * x.sum(-1, keepdim=True)
+            dx = (g * y).sum(-1, keepdim=True).expand_as(x).clone()
+            dx[..., : y.shape[-1]] += 3.0 * g
+            if ctx.link is not None:
+                ctx.link.dx1, ctx.link.shared = dx, ctx.shared
+                return None, dy, None, None
+            return dx, dy, None, None
+    return Park
+
+
+@pytest.mark.parametrize("n_proj", [1, 2])
+@pytest.mark.parametrize("shared", [False, True])
+def test_linear_acc_accumulates_onto_parked_gradient(n_proj, shared):
+    import torch
+    import vlpet_amd.functional as VF
+    torch.manual_seed(0)
+    Park = _park_op()
+    lins = [torch.nn.Linear(12, 8).requires_grad_(False) for _ in range(n_proj)]
+    x0 = torch.randn(3, 5, 12)
+    g = torch.randn(3, 5, 8)
+
+    def run(linked):
+        x = x0.clone().requires_grad_(True)
+        link = VF.ResidualLink() if linked else None
+        ys = VF.linear_acc(x, link, *lins) if linked else tuple(l(x) for l in lins)
+        ys = ys if isinstance(ys, tuple) else (ys,)
+        if linked:
+            assert link.armed
+        out = Park.apply(x, ys[0], link, shared)
+        for y in ys[1:]:
+            out = out + y.tanh()
+        out.backward(g)
+        if linked:
+            assert link.dx1 is None         # taken
+        return out.detach(), x.grad
+
+    (o1, g1), (o0, g0) = run(True), run(False)
+    assert torch.equal(o1, o0)
+    assert torch.allclose(g1, g0, rtol=1e-5, atol=1e-6)
+
+
+def test_linear_acc_without_a_park_and_without_grad():
+    import torch
+    import vlpet_amd.functional as VF
+    lin = torch.nn.Linear(6, 4).requires_grad_(False)
+    x = torch.randn(7, 6, requires_grad=True)
+    link = VF.ResidualLink()
+    y = VF.linear_acc(x, link, lin)         # armed, nobody parks: the plain dgrad
+    y.sum().backward()
+    assert torch.allclose(x.grad, lin.weight.sum(0).expand(7, 6))
+    link = VF.ResidualLink()
+    VF.linear_acc(x.detach(), link, lin)
+    assert not link.armed                   # nothing to hand over when the input needs no gradient
+    with pytest.raises(RuntimeError):
+        VF.linear_acc(x, None, torch.nn.Linear(6, 4))      # trainable projections are refused

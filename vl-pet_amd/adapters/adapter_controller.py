@@ -66,7 +66,9 @@ class AdapterController(nn.Module):
             for p in self.get_adapter(task).parameters():
                 p.requires_grad = False
 
-    def forward(self, inputs, task, y=None):
+    def forward(self, inputs, task, y=None, link=None):
+        # (`link`, not in the reference's signature: functional.parallel_adapter -- the frozen projection that made `y`
+        #  from `inputs` takes over the adapter's input gradient; only when the adapter reads `inputs` itself)
         adapter = self.get_adapter(self.get_task(task))
         z = self.pre_layer_norm(inputs) if self.add_layer_norm_before_adapter else inputs
         scale = float(self.config.scaling_factor) if self.config.use_scaling_factor else 1.0
@@ -78,4 +80,6 @@ class AdapterController(nn.Module):
             if scale != 1.0:
                 outputs = scale * outputs
             return self.post_layer_norm(outputs) + residual
-        return adapter.fused(z, residual, scale)
+        if link is None or z is not inputs:
+            return adapter.fused(z, residual, scale)
+        return adapter.fused(z, residual, scale, link=link)

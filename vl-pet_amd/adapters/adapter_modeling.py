@@ -32,13 +32,13 @@ class Adapter(nn.Module):
         return self._pack.get([self.down_sampler.weight], [self.down_sampler.bias], self.up_sampler.weight,
                               self.up_sampler.bias, io_dtype)
 
-    def fused(self, x, residual, scale=1.0):
-        """residual + scale * adapter(x) in one kernel (K2)."""
+    def fused(self, x, residual, scale=1.0, link=None):
+        """residual + scale * adapter(x) in one kernel (K2).  ``link``: functional.parallel_adapter."""
         if self.track_z:
             raise NotImplementedError("track_z needs the [M,r] bottleneck materialised; the fused path never writes it")
         pk = self.packed(VF._io_dtype(x))
         return VF.parallel_adapter(x, residual, self.down_sampler.weight, self.down_sampler.bias,
-                                   self.up_sampler.weight, self.up_sampler.bias, pk, scale)
+                                   self.up_sampler.weight, self.up_sampler.bias, pk, scale, link=link)
 
     def forward(self, x):
         # bare adapter output (no residual): K1 kernel with gate off and x2_scale = 0

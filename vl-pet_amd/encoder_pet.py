@@ -116,7 +116,7 @@ def has_pet(module: nn.Module, which: str) -> bool:
     return getattr(module, _names(which)["down"], None) is not None
 
 
-def apply_pet(module: nn.Module, which: str, x1: torch.Tensor, x2: torch.Tensor, config, link=None) -> torch.Tensor:
+def apply_pet(module: nn.Module, which: str, x1: torch.Tensor, x2: torch.Tensor, config, link=None, out_link=None) -> torch.Tensor:
     """y = ((x2*s2 + sd*up(gelu_new(cat_i down_i(x2)))) (*|+) sigmoid(up_g(gelu_new(down_g(x1))))) * gs
 
     x1 = sublayer input ("residual"), x2 = frozen attention / FFN output; the caller then does
@@ -147,7 +147,8 @@ def apply_pet(module: nn.Module, which: str, x1: torch.Tensor, x2: torch.Tensor,
         x1 = x1.to(x2.dtype)
     if gate and tiles == 6 and SPLIT_WIDE_BOTTLENECK:
         return _apply_pet_split(module, which, x1, x2, dws, dbs, up, gdown, gup, mode, sd, s2, gs, io)
-    y = VF.adapter_gate(x1, x2, dws, dbs, up.weight, up.bias, gp, pk_a, pk_g, mode, sd, s2, gs if gate else 1.0, link=link)
+    y = VF.adapter_gate(x1, x2, dws, dbs, up.weight, up.bias, gp, pk_a, pk_g, mode, sd, s2, gs if gate else 1.0, link=link,
+                        out_link=out_link if x1.dim() == x2.dim() else None)
     if gate:
         return y
     # same precedence as the reference's elif chain (large > small > middleX > middleY)

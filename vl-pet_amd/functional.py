@@ -4,9 +4,11 @@ HIP library is unavailable; there is deliberately no eager fallback."""
 from __future__ import annotations
 
 import ctypes
+import math
 from typing import List, Optional, Sequence
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 
@@ -282,18 +284,87 @@ class ResidualLink:
     adds it inside its kernel (vlpet_adapter_gate_bwd_saved_acc) and returns the sum.  Armed by K1's forward only when its
     backward will take the hand-over (gated, saved-activation form)."""
 
-    __slots__ = ("armed", "dx1")
+    __slots__ = ("armed", "dx1", "shared")
 
     def __init__(self):
         self.armed = False
         self.dx1 = None
+        self.shared = False        # the parked tensor is also somebody else's gradient: a consumer must not write into it
+
+
+class _LinearAccFn(torch.autograd.Function):
+    """``n`` frozen projections of ONE input (``x -> x W_i^T + b_i``) whose input gradient starts from a parked one.
+
+    The input of a sublayer's first GEMM is read by a second op further down (the gate of K1, the sublayer tail's
+    residual add, the value-parallel adapter of K2: my_transformers/modeling_bart.py:1147-1155, 1259-1261, 427-430), and
+    autograd sums the two input gradients with an elementwise pass over ``[M, d]``.  That other op is downstream of this
+    GEMM's output, so its backward always runs first: it parks its gradient in the ``ResidualLink`` this forward armed and
+    returns none, and the dgrad GEMM here accumulates onto it (``C += dY W``, beta = 1 in the library GEMM's epilogue) --
+    one gradient for x, no add kernel.  Weights and biases are frozen (no gradient is produced for them)."""
+
+    @staticmethod
+    def forward(ctx, x, link, *wb):
+        n = len(wb) // 2
+        ws, bs = wb[:n], wb[n:]
+        ctx.link = None
+        if link is not None and ctx.needs_input_grad[0]:
+            link.armed = True
+            ctx.link = link
+        ctx.save_for_backward(*ws)
+        ctx.xshape = x.shape
+        outs = tuple(F.linear(x, w, b) for w, b in zip(ws, bs))
+        return outs if n > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *dys):
+        ws = ctx.saved_tensors
+        link, ctx.link = ctx.link, None
+        base = None
+        shared = False
+        if link is not None:
+            base, link.dx1, shared = link.dx1, None, link.shared
+            link.shared = False
+        K = ctx.xshape[-1]
+        acc = None
+        if base is not None:
+            if base.dtype == ws[0].dtype and base.is_contiguous() and base.numel() == math.prod(ctx.xshape):
+                acc = base.view(-1, K)
+                if shared:
+                    acc = acc.clone()
+            else:                       # (never on the product path: kept correct rather than fast)
+                acc = base.reshape(-1, K).to(ws[0].dtype).contiguous()
+        for dy, w in zip(dys, ws):
+            if dy is None:
+                continue
+            dy2 = dy.reshape(-1, dy.shape[-1])
+            if dy2.dtype != w.dtype:
+                dy2 = dy2.to(w.dtype)
+            if acc is None:
+                acc = dy2 @ w
+            else:
+                acc.addmm_(dy2, w)
+        dx = acc.view(ctx.xshape) if acc is not None else None
+        return (dx, None) + (None,) * (2 * len(ws))
+
+
+def linear_acc(x: torch.Tensor, link: Optional[ResidualLink], *mods):
+    """``F.linear`` of ``x`` through each of ``mods`` (``nn.Linear``-like, or ``(weight, bias)`` pairs), frozen, with the
+    input gradient accumulated onto whatever the op sharing ``link`` parks (see _LinearAccFn).  One result per module."""
+    ws, bs = [], []
+    for m in mods:
+        w, b = (m.weight, m.bias) if hasattr(m, "weight") else m
+        if w.requires_grad or (b is not None and b.requires_grad):
+            raise RuntimeError("vl-pet_amd: linear_acc is for frozen projections")
+        ws.append(w if w.dtype == x.dtype else w.to(x.dtype))
+        bs.append(b if b is None or b.dtype == x.dtype else b.to(x.dtype))
+    return _LinearAccFn.apply(x, link, *ws, *bs)
 
 
 class _AdapterGateFn(torch.autograd.Function):
     """K1.  inputs: x1, x2, then N_h down weights, N_h down biases, up w, up b, gate down w/b, gate up w/b."""
 
     @staticmethod
-    def forward(ctx, x1, x2, pk_a, pk_g, n_heads, gate_mode, delta_scale, x2_scale, gate_scale, link, *params):
+    def forward(ctx, x1, x2, pk_a, pk_g, n_heads, gate_mode, delta_scale, x2_scale, gate_scale, link, out_link, *params):
         lib = _lib.load()
         _need_cuda(x1, x2)
         d = x2.shape[-1]
@@ -322,6 +393,8 @@ class _AdapterGateFn(torch.autograd.Function):
         if link is not None and act is not None and gate_mode != GATE_NONE and x1.requires_grad:
             link.armed = True                   # the tail that follows may park its dx1 for this op's backward
             ctx.link = link
+        # the other direction: the sublayer's first GEMM (upstream of x2) armed `out_link` -- this backward parks d/dx1 there
+        ctx.out_link = out_link if (out_link is not None and out_link.armed and gate_mode != GATE_NONE) else None
         ctx.save_for_backward(x1f if x1f is not None else x2f, x2f, *params)
         ctx.pk = (pk_a, pk_g)
         ctx.cfg = (n_heads, gate_mode, float(delta_scale), float(x2_scale), float(gate_scale), x2.shape,
@@ -415,28 +488,36 @@ class _AdapterGateFn(torch.autograd.Function):
             grads += _finish([(dwgd, s_gd, params[nh2 + 2]), (dbgd, s_gdb, params[nh2 + 3]),
                               (dwgu, s_gu, params[nh2 + 4]), (dbgu, s_gub, params[nh2 + 5])])
         gx1 = dx1.view(shp1) if gate else None
-        return (gx1, dx2.view(shp2), None, None, None, None, None, None, None, None, *grads)
+        if ctx.out_link is not None:        # the dgrad GEMM of the sublayer's first projection accumulates onto it (_LinearAccFn)
+            ctx.out_link.dx1, ctx.out_link.shared = gx1, False
+            gx1 = None
+            ctx.out_link = None
+        return (gx1, dx2.view(shp2), None, None, None, None, None, None, None, None, None, *grads)
 
 
 def adapter_gate(x1, x2, down_w, down_b, up_w, up_b, gate_params, pk_a: PackedPair, pk_g: Optional[PackedPair],
-                 gate_mode=GATE_MUL, delta_scale=1.0, x2_scale=1.0, gate_scale=1.0, link: Optional[ResidualLink] = None):
+                 gate_mode=GATE_MUL, delta_scale=1.0, x2_scale=1.0, gate_scale=1.0, link: Optional[ResidualLink] = None,
+                 out_link: Optional[ResidualLink] = None):
     """Encoder granularity-controlled adapter (+ low-rank gate).  ``gate_params`` =
-    (gate_down_w, gate_down_b, gate_up_w, gate_up_b) or None.  ``link``: see ResidualLink."""
+    (gate_down_w, gate_down_b, gate_up_w, gate_up_b) or None.  ``link``: see ResidualLink (the tail's d/dx1 comes in);
+    ``out_link``: armed by the sublayer's first GEMM (linear_acc) -- this op's d/dx1 goes out through it."""
     params = list(down_w) + list(down_b) + [up_w, up_b]
     if gate_mode != GATE_NONE:
         params += list(gate_params)
     if x2.numel() == 0:
         return _empty_result(x2, params)
-    return _AdapterGateFn.apply(x1, x2, pk_a, pk_g, len(down_w), gate_mode, delta_scale, x2_scale, gate_scale, link, *params)
+    return _AdapterGateFn.apply(x1, x2, pk_a, pk_g, len(down_w), gate_mode, delta_scale, x2_scale, gate_scale, link, out_link,
+                                *params)
 
 
 class _ParallelAdapterFn(torch.autograd.Function):
     """K2: out = y + scale * up(gelu_new(down(x)))."""
 
     @staticmethod
-    def forward(ctx, x, y, pk, scale, wd, bd, wu, bu):
+    def forward(ctx, x, y, pk, scale, link, wd, bd, wu, bu):
         lib = _lib.load()
         _need_cuda(x, y)
+        ctx.link = link if (link is not None and link.armed and ctx.needs_input_grad[0]) else None
         d = x.shape[-1]
         io = _io_dtype(x)
         xf, yf = _flat(x, d), _flat(y, d)
@@ -486,13 +567,19 @@ class _ParallelAdapterFn(torch.autograd.Function):
         _lib.check(rc, "vlpet_parallel_adapter_bwd")
         gw = _finish([(dwd, s0, wd), (dbd, s1, bd), (dwu, s2, wu)])
         gbu = _finish([(dbu, s3, bu)])[0] if bu is not None else None
-        return (dx.view(ctx.shape), dy, None, None, *gw, gbu)
+        gx = dx.view(ctx.shape)
+        if ctx.link is not None:        # the projection that made `y` from the same `x` accumulates its dgrad onto dx (_LinearAccFn)
+            ctx.link.dx1, ctx.link.shared = gx, False
+            gx = None
+            ctx.link = None
+        return (gx, dy, None, None, None, *gw, gbu)
 
 
-def parallel_adapter(x, y, wd, bd, wu, bu, pk: PackedPair, scale: float = 1.0):
+def parallel_adapter(x, y, wd, bd, wu, bu, pk: PackedPair, scale: float = 1.0, link: Optional[ResidualLink] = None):
+    """``link``: armed by the frozen projection that produced ``y`` from the same ``x`` (linear_acc); d/dx is parked there."""
     if x.numel() == 0:
         return _empty_result(y, [wd, bd, wu, bu])
-    return _ParallelAdapterFn.apply(x, y, pk, scale, wd, bd, wu, bu)
+    return _ParallelAdapterFn.apply(x, y, pk, scale, link, wd, bd, wu, bu)
 
 
 class _LoraDeltaFn(torch.autograd.Function):

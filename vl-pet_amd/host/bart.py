@@ -106,14 +106,43 @@ import os as _os
 FUSE_RESIDUAL_GRAD = _os.environ.get("VLPET_NO_LINK", "0") != "1"      # (VLPET_NO_LINK=1: plain autograd sums, for A/B)
 
 
-def _pet_then_tail(layer, which, residual, h, norm, p, training, config):
-    """``norm(residual + dropout(apply_pet(residual, h)))`` -- K1 followed by K5."""
+def _pet_then_tail(layer, which, residual, h, norm, p, training, config, gemm_link=None):
+    """``norm(residual + dropout(apply_pet(residual, h)))`` -- K1 followed by K5.  ``gemm_link``: the link the sublayer's first
+    projection armed (_first_linear): K1's d/dresidual (which already holds the tail's) goes out through it."""
     if not FUSE_RESIDUAL_GRAD:
         return sublayer_tail(residual, apply_pet(layer, which, residual, h, config), norm, p, training)
     from ..functional import ResidualLink
     link = ResidualLink()
-    y = apply_pet(layer, which, residual, h, config, link=link)
+    y = apply_pet(layer, which, residual, h, config, link=link, out_link=gemm_link)
     return sublayer_tail(residual, y, norm, p, training, link=link)
+
+
+# The same hand-over one op further: the input of a sublayer is also the input of its first frozen projection (q|k|v, q_proj,
+# fc1), whose dgrad GEMM accumulates onto the gradient K1 / the tail parked (functional.linear_acc: beta = 1 in the GEMM
+# epilogue) instead of autograd adding two [M, d] tensors; in the cross-attention, k_proj / v_proj and the value-parallel
+# adapter (K2) all read the encoder output: one gradient per decoder layer instead of three.
+FUSE_GEMM_GRAD = _os.environ.get("VLPET_NO_GEMM_LINK", "0") != "1"       # (VLPET_NO_GEMM_LINK=1: autograd's adds, for A/B)
+
+
+def _frozen(*mods) -> bool:
+    return all(isinstance(m, nn.Linear) for m in mods) and not any(
+        t is not None and t.requires_grad for m in mods for t in (m.weight, m.bias))
+
+
+def _new_gemm_link(x):
+    """A link for the first projection of a sublayer whose input is ``x``, or None when nothing would use it."""
+    if not (FUSE_RESIDUAL_GRAD and FUSE_GEMM_GRAD) or not x.requires_grad or not torch.is_grad_enabled():
+        return None
+    from ..functional import ResidualLink
+    return ResidualLink()
+
+
+def _first_linear(mod, x, link):
+    """``mod(x)`` for the first projection of a sublayer; with a link and a frozen ``nn.Linear``: functional.linear_acc."""
+    if link is not None and _frozen(mod):
+        from ..functional import linear_acc
+        return linear_acc(x, link, mod)
+    return _linear(mod, x)
 
 
 def sublayer_tail(residual, h, norm, p, training, link=None):
@@ -121,6 +150,14 @@ def sublayer_tail(residual, h, norm, p, training, link=None):
     swap this module attribute for an eager restatement."""
     from ..tail import sublayer_tail as _hip_tail
     return _hip_tail(residual, h, norm, p, training, link=link)
+
+
+def _tail_linked(residual, h, norm, p, training, link):
+    """K5 whose d/dresidual goes to the sublayer's first dgrad GEMM when that armed ``link`` (the swapped-in eager tail of
+    the parity harness takes no link: it is only ever called without one)."""
+    if link is None or not link.armed:
+        return sublayer_tail(residual, h, norm, p, training)
+    return sublayer_tail(residual, h, norm, p, training, link=link)
 
 
 def ffn_activation(x, act, p, training):
@@ -241,7 +278,8 @@ class BartAttention(nn.Module):
             self._qkv_cache = c
         return c[1], c[2]
 
-    def forward(self, hidden, kv=None, attn_mask=None, causal=False, task=None):
+    def forward(self, hidden, kv=None, attn_mask=None, causal=False, task=None, in_link=None):
+        """``in_link``: see _first_linear -- armed by the projection of ``hidden`` (q|k|v or q_proj) when that is frozen."""
         B, L, _ = hidden.shape
         src = hidden if kv is None else kv
         if kv is None and FUSE_QKV and not self.use_lora and not EAGER_ATTENTION:
@@ -254,17 +292,31 @@ class BartAttention(nn.Module):
             if (frozen and boolean_key_mask and hidden.is_cuda and hidden.dtype == torch.bfloat16 and L <= A.MAX_LEN
                     and self.head_dim == A.HEAD_DIM):
                 w, b = self._fused_qkv(hidden.dtype)
-                qkv = F.linear(hidden, w, b)
+                if in_link is not None:
+                    from ..functional import linear_acc
+                    qkv = linear_acc(hidden, in_link, (w, b))
+                else:
+                    qkv = F.linear(hidden, w, b)
                 km = None if attn_mask is None else attn_mask[:, 0, 0, :]
                 out = A.short_self_attention(qkv, self.num_heads, km, causal and attn_mask is None, self.dropout, self.training)
                 return _linear(self.out_proj, out)
         if self.use_lora:
             q = self.q_proj(hidden, task)
             v = self.v_proj(src, task)
+            k = _linear(self.k_proj, src)
         else:
-            q = _linear(self.q_proj, hidden)
+            # (self-attention off the fused path: hidden feeds three projections -- only q_proj takes the sublayer's link)
+            q = _first_linear(self.q_proj, hidden, in_link)
+            kv_link = _new_gemm_link(src) if (kv is not None and _frozen(self.k_proj, self.v_proj)) else None
+            if kv_link is not None:
+                from ..functional import linear_acc
+                k, v = linear_acc(src, kv_link, self.k_proj, self.v_proj)      # one gradient for the encoder output, K2's included
+                if self.attn_value_parallel_adapter is not None:
+                    v = self.attn_value_parallel_adapter(src, task, y=v, link=kv_link)
+                out = attention_core(q, k, v, self.num_heads, attn_mask, causal, self.dropout, self.training)
+                return _linear(self.out_proj, out)
             v = _linear(self.v_proj, src)
-        k = _linear(self.k_proj, src)
+            k = _linear(self.k_proj, src)
         if kv is not None and self.attn_value_parallel_adapter is not None:
             v = self.attn_value_parallel_adapter(src, task, y=v)
         out = attention_core(q, k, v, self.num_heads, attn_mask, causal, self.dropout, self.training)
@@ -292,17 +344,21 @@ class BartEncoderLayer(nn.Module):
 
     def forward(self, hidden, attn_mask=None, task=None):
         residual = hidden
-        h = self.self_attn(hidden, attn_mask=attn_mask, task=task)
+        gl = _new_gemm_link(hidden)
+        h = self.self_attn(hidden, attn_mask=attn_mask, task=task, in_link=gl)
         if has_pet(self, "attn"):                                                   # K1 + K5
-            hidden = _pet_then_tail(self, "attn", residual, h, self.self_attn_layer_norm, self.dropout, self.training, self.pet_config)
+            hidden = _pet_then_tail(self, "attn", residual, h, self.self_attn_layer_norm, self.dropout, self.training,
+                                    self.pet_config, gemm_link=gl)
         else:
-            hidden = sublayer_tail(residual, h, self.self_attn_layer_norm, self.dropout, self.training)   # K5
+            hidden = _tail_linked(residual, h, self.self_attn_layer_norm, self.dropout, self.training, gl)   # K5
         residual = hidden
-        h = ffn_activation(_linear(self.fc1, hidden), "gelu", self.activation_dropout, self.training)
+        gl = _new_gemm_link(hidden)
+        h = ffn_activation(_first_linear(self.fc1, hidden, gl), "gelu", self.activation_dropout, self.training)
         h = _linear(self.fc2, h)
         if has_pet(self, "ff"):                                                     # K1 + K5
-            return _pet_then_tail(self, "ff", residual, h, self.final_layer_norm, self.dropout, self.training, self.pet_config)
-        return sublayer_tail(residual, h, self.final_layer_norm, self.dropout, self.training)             # K5
+            return _pet_then_tail(self, "ff", residual, h, self.final_layer_norm, self.dropout, self.training, self.pet_config,
+                                  gemm_link=gl)
+        return _tail_linked(residual, h, self.final_layer_norm, self.dropout, self.training, gl)             # K5
 
 
 class BartDecoderLayer(nn.Module):
@@ -323,15 +379,18 @@ class BartDecoderLayer(nn.Module):
 
     def forward(self, hidden, enc, enc_mask=None, task=None):
         residual = hidden
-        h = self.self_attn(hidden, causal=True, task=task)
-        hidden = sublayer_tail(residual, h, self.self_attn_layer_norm, self.dropout, self.training)   # K5
+        gl = _new_gemm_link(hidden)
+        h = self.self_attn(hidden, causal=True, task=task, in_link=gl)
+        hidden = _tail_linked(residual, h, self.self_attn_layer_norm, self.dropout, self.training, gl)   # K5
         residual = hidden
-        h = self.encoder_attn(hidden, kv=enc, attn_mask=enc_mask, task=task)      # K2 inside
-        hidden = sublayer_tail(residual, h, self.encoder_attn_layer_norm, self.dropout, self.training)  # K5
+        gl = _new_gemm_link(hidden)
+        h = self.encoder_attn(hidden, kv=enc, attn_mask=enc_mask, task=task, in_link=gl)      # K2 inside
+        hidden = _tail_linked(residual, h, self.encoder_attn_layer_norm, self.dropout, self.training, gl)  # K5
         residual = hidden
-        h = ffn_activation(_linear(self.fc1, hidden), "gelu", self.activation_dropout, self.training)
+        gl = _new_gemm_link(hidden)
+        h = ffn_activation(_first_linear(self.fc1, hidden, gl), "gelu", self.activation_dropout, self.training)
         h = _linear(self.fc2, h)
-        return sublayer_tail(residual, h, self.final_layer_norm, self.dropout, self.training)             # K5
+        return _tail_linked(residual, h, self.final_layer_norm, self.dropout, self.training, gl)             # K5
 
 
 class LearnedPositionalEmbedding(nn.Embedding):

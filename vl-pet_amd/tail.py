@@ -47,7 +47,7 @@ class _TailFn(torch.autograd.Function):
         _lib.check(rc, "vlpet_sublayer_tail_fwd")
         ctx.save_for_backward(h, mean, rstd, g32, gamma, beta)
         ctx.cfg = (float(p), seed, int(norm), y.shape, io)
-        ctx.link = link if (link is not None and link.armed) else None     # K1 upstream will add our dx1 in its kernel
+        ctx.link = link if (link is not None and link.armed) else None     # the op that armed it (K1, or a linear_acc GEMM) sums our dx1 into its own
         out = out.view(y.shape)
         if want_mask:
             ctx.mark_non_differentiable(mask)
@@ -83,8 +83,9 @@ class _TailFn(torch.autograd.Function):
         dx1 = dx1.view(shape)
         dyv = dy.view(shape) if dy is not None else dx1
         gx1 = dx1
-        if ctx.link is not None:        # functional.ResidualLink: K1's backward (downstream of dy) returns the sum for x1
+        if ctx.link is not None:        # functional.ResidualLink: K1's backward / the sublayer's first dgrad GEMM returns the sum for x1
             ctx.link.dx1 = dx1
+            ctx.link.shared = dy is None        # without dropout dy IS dx1: a consumer must not accumulate into it in place
             gx1 = None
             ctx.link = None
         return dyv, gx1, dgamma, dbeta, None, None, None, None, None, None
