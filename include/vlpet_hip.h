@@ -293,6 +293,12 @@ int vlpet_sublayer_tail_fwd(const void* y, const void* x1, const float* gamma, c
 int vlpet_sublayer_tail_bwd(const void* dout, const void* h_save, const float* mean, const float* rstd,
                             const float* gamma, void* dx1, void* dy, float* dgb_partials, int64_t M, int d,
                             float p, uint64_t seed, int norm_mode, int io_dtype, vlpet_stream_t stream);
+/* The LayerNorm parameter gradients of that backward (autograd of `self_attn_layer_norm` / `final_layer_norm`,
+ * my_transformers/modeling_bart.py:1261, 1377): dgamma [d], dbeta [d] (fp32, OVERWRITTEN; either may be NULL) = the sum of
+ * the n_partials = vlpet_sublayer_tail_partials(M) rows of dgb_partials.  One launch; the caller may point dgamma / dbeta
+ * straight at the parameters' slots of its flat gradient buffer. */
+int vlpet_sublayer_tail_reduce(const float* dgb_partials, int n_partials, int d, float* dgamma, float* dbeta,
+                               vlpet_stream_t stream);
 
 /* ---- FFN activation + dropout (the backbone step between fc1 and fc2 of the sublayers K1 / K5 close) ----------
  * out = dropout(act(x), p) as one pass; backward dx = dy * mask / (1 - p) * act'(x), mask regenerated from the seed

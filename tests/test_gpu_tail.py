@@ -59,7 +59,7 @@ def _run(M, d, dtype, p, norm=True, seed=1234):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,d", [(1, 64), (37, 768), (1000, 768), (130, 1024), (5, 2048)])
+@pytest.mark.parametrize("M,d", [(1, 64), (37, 768), (1000, 768), (130, 1024), (5, 2048), (3111, 768)])
 def test_tail_layernorm_no_dropout(M, d, dtype):
     mask = _run(M, d, dtype, 0.0)
     assert bool((mask == 1).all())
@@ -97,3 +97,27 @@ def test_tail_inference_path_saves_nothing():
         out = sublayer_tail(x1.cuda().bfloat16(), y.cuda().bfloat16(), ln, p=0.1, training=False)
     ref = O.bart_sublayer_tail(x1, y, torch.ones(768), torch.zeros(768))
     assert _rel(out, ref) <= 1e-2
+
+
+def test_tail_frozen_layernorm_copy_is_cached_and_follows_the_parameter():
+    """A frozen LayerNorm kept in bf16: its fp32 copy for the kernel is made once (cached on the parameter) and remade when
+    the parameter changes in place."""
+    from vlpet_amd.tail import sublayer_tail
+    torch.manual_seed(0)
+    d = 256
+    ln = torch.nn.LayerNorm(d).cuda().to(torch.bfloat16).requires_grad_(False)
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.1 * torch.randn(d)); ln.bias.copy_(0.1 * torch.randn(d))
+    x1 = torch.randn(50, d, device="cuda", dtype=torch.bfloat16)
+    y = torch.randn(50, d, device="cuda", dtype=torch.bfloat16)
+    ref = lambda: torch.nn.functional.layer_norm((x1 + y).float(), (d,), ln.weight.float(), ln.bias.float(), ln.eps)
+    o1 = sublayer_tail(x1, y, ln, p=0.0, training=False)
+    c1 = ln.weight._vlpet_f32[1]
+    o2 = sublayer_tail(x1, y, ln, p=0.0, training=False)
+    assert ln.weight._vlpet_f32[1] is c1 and torch.equal(o1, o2)
+    assert _rel(o1, ref().cpu()) <= 1e-2
+    with torch.no_grad():
+        ln.weight.mul_(2.0); ln.bias.add_(1.0)
+    o3 = sublayer_tail(x1, y, ln, p=0.0, training=False)
+    assert ln.weight._vlpet_f32[1] is not c1
+    assert _rel(o3, ref().cpu()) <= 1e-2

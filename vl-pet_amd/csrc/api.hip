@@ -7,7 +7,7 @@
 #include <stdio.h>
 #include <vector>
 
-#define VLPET_VERSION 220      // round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
+#define VLPET_VERSION 221      // 221: vlpet_sublayer_tail_reduce;  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -772,6 +772,13 @@ static uint32_t tail_thr(float p) {
 }
 
 extern "C" int vlpet_sublayer_tail_partials(int64_t M) { return M > 0 ? tail_blocks(M) : 0; }
+
+extern "C" int vlpet_sublayer_tail_reduce(const float* dgb_partials, int n_partials, int d, float* dgamma, float* dbeta,
+                                          vlpet_stream_t stream) {
+    if (n_partials <= 0 || d <= 0) return VLPET_E_SHAPE;
+    if (!dgb_partials || (!dgamma && !dbeta)) return VLPET_E_NULL;
+    return herr(launch_tail_reduce(dgb_partials, n_partials, d, dgamma, dbeta, (hipStream_t)stream));
+}
 
 extern "C" int vlpet_sublayer_tail_fwd(const void* y, const void* x1, const float* gamma, const float* beta, void* out,
                                        void* h_save, float* mean, float* rstd, uint8_t* keep_out, int64_t M, int d,

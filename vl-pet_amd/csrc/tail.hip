@@ -279,6 +279,42 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
     }
 }
 
+// Sum of the backward's per-workgroup partials [nb][2][d] into dgamma [d] / dbeta [d] (OVERWRITTEN; either may be null):
+// a workgroup owns 64 consecutive columns of the [2 d] row, its 16 waves take every 16th partial row (a wave reads 256
+// contiguous bytes per row), LDS combines the waves.  One launch instead of a library reduction plus autograd's adds.
+__global__ __launch_bounds__(1024) void tail_reduce_kernel(const float* __restrict__ part, int nb, int d,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float acc[16][64];
+    const int c = threadIdx.x & 63, s = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    const int w = 2 * d;
+    float v = 0.f;
+    if (col < w) {
+        const float* src = part + col;
+        int r = s;
+        for (; r + 48 < nb; r += 64) {
+            const float a0 = src[(size_t)r * w], a1 = src[(size_t)(r + 16) * w], a2 = src[(size_t)(r + 32) * w],
+                        a3 = src[(size_t)(r + 48) * w];
+            v += (a0 + a1) + (a2 + a3);
+        }
+        for (; r < nb; r += 16) v += src[(size_t)r * w];
+    }
+    acc[s][c] = v;
+    __syncthreads();
+    if (s == 0 && col < w) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += acc[k][c];
+        if (col < d) { if (dgamma) dgamma[col] = t; }
+        else if (dbeta) dbeta[col - d] = t;
+    }
+}
+
+hipError_t launch_tail_reduce(const float* part, int nb, int d, float* dgamma, float* dbeta, hipStream_t stream) {
+    hipLaunchKernelGGL(tail_reduce_kernel, dim3((2 * d + 63) / 64), dim3(1024), 0, stream, part, nb, d, dgamma, dbeta);
+    return hipGetLastError();
+}
+
 int tail_blocks(int64_t M) {
     const int64_t need = (M + TAIL_WAVES - 1) / TAIL_WAVES;
     static const int64_t cap = [] { const char* e = getenv("VLPET_TAIL_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)(256 * 3); }();   // 3 workgroups of 4 waves per CU (with the row prefetch: best of 256 .. 2048; fewer partial sums)

@@ -13,11 +13,29 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .functional import _flat, _grad_like, _io_dtype, _need_cuda, _ptr, _stream, _timed
+from .functional import _finish, _flat, _grad_dest, _grad_like, _io_dtype, _need_cuda, _ptr, _stream, _timed
 
 
 def _draw_seed() -> int:
     return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+def _f32_frozen(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """fp32 contiguous copy of a LayerNorm parameter for the kernels.  A frozen parameter kept in the IO dtype (the decoder's
+    LayerNorms of a bf16 run) is converted once and the copy cached on the parameter, keyed on its storage and version --
+    not once per forward (two conversion launches per sublayer tail)."""
+    if t is None:
+        return None
+    if t.dtype == torch.float32:
+        return t.detach().contiguous()
+    if t.requires_grad:
+        return t.detach().float().contiguous()
+    key = (t.data_ptr(), t._version, t.dtype)
+    c = getattr(t, "_vlpet_f32", None)
+    if c is None or c[0] != key:
+        c = (key, t.detach().float().contiguous())
+        t._vlpet_f32 = c
+    return c[1]
 
 
 class _TailFn(torch.autograd.Function):
@@ -36,8 +54,7 @@ class _TailFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=y.device)
         h = mean = rstd = g32 = b32 = None
         if norm:
-            g32 = gamma.detach().float().contiguous()
-            b32 = beta.detach().float().contiguous() if beta is not None else None
+            g32, b32 = _f32_frozen(gamma), _f32_frozen(beta)
             mean, rstd = torch.empty(M, **f32), torch.empty(M, **f32)
             h = torch.empty_like(yf) if need_bwd else None
         mask = torch.empty(M, d, dtype=torch.uint8, device=y.device) if want_mask else None
@@ -75,11 +92,18 @@ class _TailFn(torch.autograd.Function):
         _lib.check(rc, "vlpet_sublayer_tail_bwd")
         dgamma = dbeta = None
         if train_ln:
-            s = part.sum(0)
-            if ctx.needs_input_grad[2]:
-                dgamma = _grad_like(s[0], gamma)
-            if beta is not None and ctx.needs_input_grad[3]:
-                dbeta = _grad_like(s[1], beta)
+            # one launch sums the partials, straight into the parameters' slots of the trainer's flat gradient buffer when it
+            # offers them (functional._grad_dest: then autograd gets None and runs no accumulate kernel)
+            want_g = bool(ctx.needs_input_grad[2])
+            want_b = beta is not None and bool(ctx.needs_input_grad[3])
+            (tg, sg) = _grad_dest(gamma, (d,)) if want_g else (None, None)
+            (tb, sb) = _grad_dest(beta, (d,)) if want_b else (None, None)
+            rc = lib.vlpet_sublayer_tail_reduce(part.data_ptr(), part.shape[0], d, _ptr(tg), _ptr(tb), _stream())
+            _lib.check(rc, "vlpet_sublayer_tail_reduce")
+            if want_g:
+                dgamma = _finish([(tg, sg, gamma)])[0]
+            if want_b:
+                dbeta = _finish([(tb, sb, beta)])[0]
         dx1 = dx1.view(shape)
         dyv = dy.view(shape) if dy is not None else dx1
         gx1 = dx1
