@@ -299,6 +299,11 @@ int vlpet_sublayer_tail_bwd(const void* dout, const void* h_save, const float* m
  * straight at the parameters' slots of its flat gradient buffer. */
 int vlpet_sublayer_tail_reduce(const float* dgb_partials, int n_partials, int d, float* dgamma, float* dbeta,
                                vlpet_stream_t stream);
+/* LayerNorm backward from the NORMALISED rows: xhat [M, d] (IO dtype) and rstd [M] as vlpet_visproj_fwd saves them
+ * (autograd of `feat_embedding`'s LayerNorm, src/modeling_bart.py:157, 171).  dx [M, d] = gradient of the pre-norm rows,
+ * dgb_partials as above (NULL when the LayerNorm is frozen); one pass over [M, d]. */
+int vlpet_layernorm_bwd_xhat(const void* dout, const void* xhat, const float* rstd, const float* gamma, void* dx,
+                             float* dgb_partials, int64_t M, int d, int io_dtype, vlpet_stream_t stream);
 
 /* ---- FFN activation + dropout (the backbone step between fc1 and fc2 of the sublayers K1 / K5 close) ----------
  * out = dropout(act(x), p) as one pass; backward dx = dy * mask / (1 - p) * act'(x), mask regenerated from the seed

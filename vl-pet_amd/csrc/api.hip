@@ -7,7 +7,7 @@
 #include <stdio.h>
 #include <vector>
 
-#define VLPET_VERSION 221      // 221: vlpet_sublayer_tail_reduce;  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
+#define VLPET_VERSION 221      // 221: vlpet_sublayer_tail_reduce, vlpet_layernorm_bwd_xhat;  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -772,6 +772,21 @@ static uint32_t tail_thr(float p) {
 }
 
 extern "C" int vlpet_sublayer_tail_partials(int64_t M) { return M > 0 ? tail_blocks(M) : 0; }
+
+// LayerNorm backward from the normalised rows (K4 saves xhat and rstd, not the pre-norm rows): the tail's backward kernel
+// with `h` = xhat.  dx [M, d] = d/d(pre-norm); dgb_partials as in vlpet_sublayer_tail_bwd (or NULL).
+extern "C" int vlpet_layernorm_bwd_xhat(const void* dout, const void* xhat, const float* rstd, const float* gamma, void* dx,
+                                        float* dgb_partials, int64_t M, int d, int io_dtype, vlpet_stream_t stream) {
+    int rc = tail_common(M, d, 0.f, io_dtype);
+    if (rc) return rc;
+    if (!dout || !xhat || !rstd || !gamma || !dx) return VLPET_E_NULL;
+    if (!aligned16(dout) || !aligned16(xhat) || !aligned16(dx)) return VLPET_E_ALIGN;
+    TailArgs a{};
+    a.out = const_cast<void*>(dout); a.h = const_cast<void*>(xhat); a.mean = nullptr; a.rstd = const_cast<float*>(rstd);
+    a.gamma = gamma; a.x1 = dx; a.y = nullptr; a.dgb = dgb_partials; a.M = M; a.d = d; a.thr = 0; a.keep_scale = 1.f;
+    a.norm = 1; a.h_xhat = 1;
+    return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
+}
 
 extern "C" int vlpet_sublayer_tail_reduce(const float* dgb_partials, int n_partials, int d, float* dgamma, float* dbeta,
                                           vlpet_stream_t stream) {

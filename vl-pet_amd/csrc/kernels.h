@@ -176,6 +176,7 @@ struct TailArgs {
     int post;               // 1: out = LayerNorm(dropout(y)) + x1  (x1 is added AFTER the norm: the visual projectors' position /
                             //    order-embedding term, src/modeling_bart.py:298-299, 324-325); forward only -- the backward of
                             //    that form is the plain one with h = y (dx1 := d/dy, the caller passes dout on as d/dx1)
+    int h_xhat;             // bwd, norm = 1: `h` holds the normalised rows xhat (what K4's forward saves), `mean` is not read
 };
 hipError_t launch_tail(const TailArgs& a, int io_fp32, bool bwd, hipStream_t stream);
 int tail_blocks(int64_t M);

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
     auto load_row = [&](int64_t r, u32x4 (&rd)[NP], u32x4 (&rh)[NORM ? NP : 1], float& mu, float& rs) {
         if (r >= a.M) r = a.M - 1;                  // next row of this wave, requested one row ahead (see the forward)
         const int64_t o = r * d * (int64_t)sizeof(IO);
-        if constexpr (NORM) { mu = a.mean[r]; rs = a.rstd[r]; }
+        if constexpr (NORM) { mu = a.h_xhat ? 0.f : a.mean[r]; rs = a.rstd[r]; }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = lane + 64 * k;
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
         float g[NP][E], xh[NORM ? NP : 1][E];
         float s1 = 0.f, s2 = 0.f;
         const float mean = cmean, rstd = crstd;
+        const float rin = a.h_xhat ? 1.f : rstd;            // (rows already normalised: K4's saved xhat)
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = lane + 64 * k;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
                     P::from_raw(ch[k], vh);
 #pragma unroll
                     for (int j = 0; j < E; ++j) {
-                        xh[k][j] = (vh[j] - mean) * rstd;
+                        xh[k][j] = (vh[j] - mean) * rin;
                         g[k][j] = vd[j] * gam[k][j];
                         s1 += g[k][j];
                         s2 += g[k][j] * xh[k][j];

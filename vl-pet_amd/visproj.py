@@ -48,8 +48,8 @@ class _VisProjFn(torch.autograd.Function):
         out = torch.empty(M, d_out, dtype=feats.dtype, device=feats.device)
         xhat = torch.empty_like(out)
         rstd = torch.empty(M, dtype=torch.float32, device=feats.device)
-        g32 = gamma.detach().float().contiguous()
-        b32 = beta.detach().float().contiguous() if beta is not None else None
+        from .tail import _f32_frozen
+        g32, b32 = _f32_frozen(gamma), _f32_frozen(beta)
         rc = _timed("k4_fwd", M, lambda: lib.vlpet_visproj_fwd(
             ff.data_ptr(), packed.data_ptr(), g32.data_ptr(), _ptr(b32), _ptr(Rf), out.data_ptr(), xhat.data_ptr(),
             rstd.data_ptr(), M, F, d_out, float(eps), int(bool(rms)), io, _stream()))
@@ -66,18 +66,34 @@ class _VisProjFn(torch.autograd.Function):
         M, F = ff.shape
         d_out = w.shape[0]
         io = _io_dtype(ff)
-        dyf = _flat(dy, d_out).float()
-        xh = xhat.float()
-        g = dyf * gamma.float()
-        c2 = (g * xh).mean(dim=1, keepdim=True)
-        if rms:
+        s_g = s_be = None
+        if rms:         # T5's RMS norm: library ops (one call per step on [M_v, d])
+            dyf = _flat(dy, d_out).float()
+            xh = xhat.float()
+            g = dyf * gamma.float()
+            c2 = (g * xh).mean(dim=1, keepdim=True)
             dpre = (g - xh * c2) * rstd[:, None]
-        else:
-            c1 = g.mean(dim=1, keepdim=True)
-            dpre = (g - c1 - xh * c2) * rstd[:, None]
-        dgamma = (dyf * xh).sum(0)
-        dbeta = dyf.sum(0) if has_beta else None
-        dpre_io = dpre.to(ff.dtype).contiguous()
+            dgamma = (dyf * xh).sum(0)
+            dbeta = None
+            dpre_io = dpre.to(ff.dtype).contiguous()
+        else:           # LayerNorm: K5's backward kernel on the saved xhat, its partial sums reduced into the gradient slots
+            from .tail import _f32_frozen
+            dyc = _flat(dy, d_out)
+            if dyc.dtype != ff.dtype:
+                dyc = dyc.to(ff.dtype)
+            dpre_io = torch.empty_like(xhat)
+            train_ln = ctx.needs_input_grad[4] or (has_beta and ctx.needs_input_grad[5])
+            part = torch.empty(lib.vlpet_sublayer_tail_partials(M), 2, d_out, dtype=torch.float32, device=ff.device) if train_ln else None
+            rc = _timed("k4_ln_bwd", M, lambda: lib.vlpet_layernorm_bwd_xhat(
+                dyc.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), _f32_frozen(gamma).data_ptr(), dpre_io.data_ptr(), _ptr(part),
+                M, d_out, io, _stream()))
+            _lib.check(rc, "vlpet_layernorm_bwd_xhat")
+            dgamma = dbeta = None
+            if train_ln:
+                (dgamma, s_g) = _grad_dest(gamma, (d_out,))
+                (dbeta, s_be) = _grad_dest(beta, (d_out,)) if has_beta else (None, None)
+                rc = lib.vlpet_sublayer_tail_reduce(part.data_ptr(), part.shape[0], d_out, dgamma.data_ptr(), _ptr(dbeta), _stream())
+                _lib.check(rc, "vlpet_sublayer_tail_reduce")
         (dw, s_w), (db, s_b) = _grad_dest(w, (d_out, F)), _grad_dest(b, (d_out,))
         nws = lib.vlpet_visproj_wgrad_workspace_bytes(M, F, d_out)
         ws = torch.empty(nws, dtype=torch.uint8, device=ff.device)
@@ -89,8 +105,13 @@ class _VisProjFn(torch.autograd.Function):
         gw, gb = _finish([(dw, s_w, w), (db, s_b, b)])
         # the CLIP features of K4 carry no gradient; the low-rank projector's bottleneck activations do (library GEMM)
         dfeats = (dpre_io @ w.detach().to(dpre_io.dtype)).view(*lead, F) if ctx.needs_input_grad[0] else None
-        return (dfeats, dR, gw, gb, _grad_like(dgamma, gamma),
-                _grad_like(dbeta, beta) if has_beta else None, None, None, None)
+        if rms or dgamma is None:
+            gg = _grad_like(dgamma, gamma) if dgamma is not None else None
+            gbe = None
+        else:
+            gg = _finish([(dgamma, s_g, gamma)])[0]
+            gbe = _finish([(dbeta, s_be, beta)])[0] if has_beta else None
+        return (dfeats, dR, gw, gb, gg, gbe, None, None, None)
 
 
 def visproj(feats, R, linear: torch.nn.Linear, norm: torch.nn.Module, cache: VisProjPackCache, rms: bool):
