@@ -10,23 +10,44 @@
 #include "rng.h"
 #include "vec8.h"
 
+// The pass is as much instruction-bound as memory-bound (an element has ~30 VALU slots at the HBM rate), so the
+// transcendental forms are the cheap ones: one v_exp_f32 and one v_rcp_f32 per element.
+//   erf form:  Phi(x) = 1 - h (x >= 0), h (x < 0),  h = 0.5 * poly(t) * exp(-x^2 / 2),  t = 1 / (1 + p |x| / sqrt(2))
+//              (Abramowitz & Stegun 7.1.26: |error of erf| <= 1.5e-7), and the same exponential is the density of the derivative;
+//   tanh form: 0.5 (1 + tanh(u)) = 1 / (1 + exp(-2 u)).
+struct GeluParts { float cdf, e; };           // Phi(x) and exp(-x^2 / 2)
+__device__ __forceinline__ GeluParts gelu_erf_parts(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.7071067811865476f, ax, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-0.5f * 1.4426950408889634f * x * x);
+    float q = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    q = __builtin_fmaf(q, t, 1.421413741f);
+    q = __builtin_fmaf(q, t, -0.284496736f);
+    q = __builtin_fmaf(q, t, 0.254829592f);
+    const float h = 0.5f * q * t * e;
+    return {x >= 0.f ? 1.0f - h : h, e};
+}
+__device__ __forceinline__ float sigmoid_fast(float v) {      // 1 / (1 + exp(-v)); exp overflow -> 1 / inf = 0
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+
 template <int ACT> __device__ __forceinline__ float act_f(float x) {
     if constexpr (ACT == VLPET_ACT_RELU) return x > 0.f ? x : 0.f;
     else if constexpr (ACT == VLPET_ACT_GELU_NEW) {
         const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-        return 0.5f * x * (1.0f + tanhf(u));
-    } else return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+        return x * sigmoid_fast(2.0f * u);
+    } else return x * gelu_erf_parts(x).cdf;
 }
 template <int ACT> __device__ __forceinline__ float act_df(float x) {
     if constexpr (ACT == VLPET_ACT_RELU) return x > 0.f ? 1.f : 0.f;
     else if constexpr (ACT == VLPET_ACT_GELU_NEW) {
         const float x2 = x * x;
         const float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
-        const float t = tanhf(u);
-        return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 0.134145f * x2);
+        const float sg = sigmoid_fast(2.0f * u);              // = 0.5 (1 + tanh u);  1 - tanh^2 u = 4 sg (1 - sg)
+        return sg + x * 2.0f * sg * (1.0f - sg) * 0.7978845608028654f * (1.0f + 0.134145f * x2);
     } else {
-        const float cdf = 0.5f * (1.0f + erff(x * 0.7071067811865476f));
-        return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+        const GeluParts g = gelu_erf_parts(x);
+        return g.cdf + x * 0.3989422804014327f * g.e;
     }
 }
 
@@ -34,28 +55,40 @@ template <typename IO, int ACT, bool DROP, bool BWD>
 __global__ __launch_bounds__(256) void act_dropout_kernel(ActDropArgs a) {
     const int64_t groups = a.n >> 3;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
-        Vec8<IO> x, o;
-        x.load(a.x, g);
-        uint32_t bits = 0xffu;
-        if constexpr (DROP) bits = keep8(g, a.seed, a.thr);
+    // two groups per thread and iteration, both loads (four in the backward) issued before the arithmetic of either
+    for (int64_t g0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g0 < groups; g0 += 2 * stride) {
+        const int64_t g1 = g0 + stride;
+        const bool two = g1 < groups;
+        Vec8<IO> x[2], dy[2];
+        x[0].load(a.x, g0);
+        if (two) x[1].load(a.x, g1);
         if constexpr (BWD) {
-            Vec8<IO> dy;
-            dy.load(a.dy, g);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float k = ((bits >> j) & 1u) ? a.keep_scale : 0.f;
-                o.set(j, dy.get(j) * k * act_df<ACT>(x.get(j)));
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float k = ((bits >> j) & 1u) ? a.keep_scale : 0.f;
-                o.set(j, act_f<ACT>(x.get(j)) * k);
-            }
-            if (a.keep_out != nullptr) drop_export8(a.keep_out, g << 3, bits);
+            dy[0].load(a.dy, g0);
+            if (two) dy[1].load(a.dy, g1);
         }
-        o.store(a.out, g);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const int64_t g = u == 0 ? g0 : g1;
+            Vec8<IO> o;
+            uint32_t bits = 0xffu;
+            if constexpr (DROP) bits = keep8(g, a.seed, a.thr);
+            if constexpr (BWD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float k = ((bits >> j) & 1u) ? a.keep_scale : 0.f;
+                    o.set(j, dy[u].get(j) * k * act_df<ACT>(x[u].get(j)));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float k = ((bits >> j) & 1u) ? a.keep_scale : 0.f;
+                    o.set(j, act_f<ACT>(x[u].get(j)) * k);
+                }
+                if (a.keep_out != nullptr) drop_export8(a.keep_out, g << 3, bits);
+            }
+            o.store(a.out, g);
+        }
     }
 }
 
