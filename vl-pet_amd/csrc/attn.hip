@@ -310,37 +310,39 @@ __global__ __launch_bounds__(AT_NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
             // ============================================= phase K: key tile t (lane = key, registers = queries)
             const int t = un;
             const int key = 32 * t + m;
-            bf16x8 kf[4], vf[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { kf[ks] = nat_frag(Ks, key, ks, hh); vf[ks] = nat_frag(Vs, key, ks, hh); }
             f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
             for (int qb = 0; qb < NQB; ++qb) {
                 f32x16 s = zero16(), dp = zero16();
+                // Register diet (three waves per SIMD without scratch): the key / value fragments are re-read from LDS per query
+                // block (the opaque copy of the row index keeps the compiler from hoisting them out of the loop), and P / dS
+                // overwrite S / dP in place.
+                int keyr = key;
+                if constexpr (OCC >= 3) asm volatile("" : "+v"(keyr));      // (two waves per SIMD: registers to spare, let them be hoisted)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    s = mfma32(nat_frag(Qs, 32 * qb + m, ks, hh), kf[ks], s);        // D[query][key]
-                    dp = mfma32(nat_frag(Ds, 32 * qb + m, ks, hh), vf[ks], dp);
+                    s = mfma32(nat_frag(Qs, 32 * qb + m, ks, hh), nat_frag(Ks, keyr, ks, hh), s);        // D[query][key]
+                    dp = mfma32(nat_frag(Ds, 32 * qb + m, ks, hh), nat_frag(Vs, keyr, ks, hh), dp);
                 }
-                f32x16 pd, ds;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = 32 * qb + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const f32x4 rv = rowv[i];                                        // (rows >= Lq: lse2 = +inf -> p = 0)
+                    const float* rp = reinterpret_cast<const float*>(rowv + i);      // {lse2, delta, row key}; rows >= Lq: lse2 = +inf -> p = 0
+                    const float lse2 = rp[0], delta = rp[1];
                     const bool ok = key_ok(a, km, i, key);
-                    const float p = ok ? fast_exp2(s[r] * sc2 - rv[0]) : 0.f;
+                    const float p = ok ? fast_exp2(s[r] * sc2 - lse2) : 0.f;
                     float g = dp[r];
                     float pdrop = p;
                     if (a.thr != 0) {
-                        const bool kp = keep_elem(__float_as_uint(rv[2]), key, a.thr);
+                        const bool kp = keep_elem(__float_as_uint(rp[2]), key, a.thr);
                         pdrop = kp ? p * a.inv_keep : 0.f;
                         g = kp ? g * a.inv_keep : 0.f;
                     }
-                    pd[r] = pdrop;
-                    ds[r] = p * (g - rv[1]) * a.scale;
+                    s[r] = pdrop;
+                    dp[r] = p * (g - delta) * a.scale;
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const bf16x8 pf = acc_frag(pd, u), sf = acc_frag(ds, u);
+                    const bf16x8 pf = acc_frag(s, u), sf = acc_frag(dp, u);
                     dv0 = mfma32(tr_acc_order(Ds, 32 * qb + 16 * u, 0, lane), pf, dv0);   // D[d][key] += dO^T P
                     dv1 = mfma32(tr_acc_order(Ds, 32 * qb + 16 * u, 32, lane), pf, dv1);
                     dk0 = mfma32(tr_acc_order(Qs, 32 * qb + 16 * u, 0, lane), sf, dk0);   // D[d][key] += Q^T dS
@@ -367,7 +369,6 @@ __global__ __launch_bounds__(AT_NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
                     s = mfma32(nat_frag(Ks, 32 * t + m, ks, hh), qf[ks], s);             // D[key][query]
                     dp = mfma32(nat_frag(Vs, 32 * t + m, ks, hh), df[ks], dp);
                 }
-                f32x16 ds;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -375,11 +376,11 @@ __global__ __launch_bounds__(AT_NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
                     const float p = ok ? fast_exp2(s[r] * sc2 - l2) : 0.f;
                     float g = dp[r];
                     if (a.thr != 0) g = keep_elem(rk, key, a.thr) ? g * a.inv_keep : 0.f;
-                    ds[r] = p * (g - dl) * a.scale;
+                    dp[r] = p * (g - dl) * a.scale;          // dS in place of dP
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const bf16x8 sf = acc_frag(ds, u);
+                    const bf16x8 sf = acc_frag(dp, u);
                     dq0 = mfma32(tr_acc_order(Ks, 32 * t + 16 * u, 0, lane), sf, dq0);    // D[d][query] += K^T dS
                     dq1 = mfma32(tr_acc_order(Ks, 32 * t + 16 * u, 32, lane), sf, dq1);
                 }
@@ -416,8 +417,11 @@ hipError_t launch_attn(const AttnArgs& a, bool bwd, hipStream_t stream) {
         }
     }
     const size_t lds = attn_lds_bytes(a.Lq, a.Lk, 1);
+    // Three waves per SIMD (168 registers, one spilled) whenever three workgroups fit the CU's LDS -- sequences of at most 64
+    // tokens: the memory phase of a pair then overlaps the compute phase of two others (142 -> 114 us at B = 500, S = 56);
+    // longer sequences (two workgroups per CU by LDS either way) keep the 171-register build.  VLPET_ATTN_OCC = 2 | 3 forces one.
     static const int occ_env = [] { const char* e = getenv("VLPET_ATTN_OCC"); return e ? atoi(e) : 0; }();
-    const bool occ3 = occ_env == 3;      // (3 spills 40 registers and measured slower: 166 vs 151 us at B = 500, S = 56)
+    const bool occ3 = occ_env == 3 || (occ_env != 2 && 3 * (lds + 512) <= (size_t)160 * 1024);
     const void* kern = occ3 ? reinterpret_cast<const void*>(attn_bwd_kernel<3>) : reinterpret_cast<const void*>(attn_bwd_kernel<2>);
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
