@@ -363,7 +363,8 @@ def main():
         # K5 fwd reads y, x1, writes out; K5 bwd reads dout, writes dx1, dy (the saved pre-norm sum is extra traffic)
         per_row = {"k1_fwd": 3 * d * esz, "k1_bwd_rows": 5 * d * esz, "k1_bwd_wgrad": 0, "k2_fwd": 3 * d * esz,
                    "k2_bwd": 3 * d * esz, "k3_fwd": 3 * d * esz, "k3_bwd": 3 * d * esz, "k5_fwd": 3 * d * esz,
-                   "k5_bwd": 3 * d * esz, "k4_ln_bwd": 3 * d * esz}      # (K4's LayerNorm backward: dout, xhat read, dpre written)
+                   "k5_bwd": 3 * d * esz, "k4_ln_bwd": 3 * d * esz,
+                   "rms_fwd": 2 * d * esz, "rms_bwd": 3 * d * esz}      # (K4's LayerNorm backward: dout, xhat read, dpre written)
         d_ff = int(getattr(cfg, "encoder_ffn_dim", 0) or getattr(cfg, "d_ff", 0))
         per_row.update({"ffn_act_fwd": 2 * d_ff * esz, "ffn_act_bwd": 3 * d_ff * esz})   # backbone FFN activation + dropout pass
         # backbone attention on the short-sequence kernels: q, k, v read + o written / q, k, v, o, do read + dq, dk, dv written

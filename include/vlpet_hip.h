@@ -302,6 +302,14 @@ int vlpet_sublayer_tail_reduce(const float* dgb_partials, int n_partials, int d,
 /* LayerNorm backward from the NORMALISED rows: xhat [M, d] (IO dtype) and rstd [M] as vlpet_visproj_fwd saves them
  * (autograd of `feat_embedding`'s LayerNorm, src/modeling_bart.py:157, 171).  dx [M, d] = gradient of the pre-norm rows,
  * dgb_partials as above (NULL when the LayerNorm is frozen); one pass over [M, d]. */
+/* T5LayerNorm (my_transformers/modeling_t5.py:235-252; the RMS norm in front of every T5 sublayer, :366, :782, and the final
+ * norms): out = x * rsqrt(mean(x^2) + eps) * gamma, statistics in fp32, one pass each way over [M, d].  rstd [M] is saved by the
+ * forward; the backward writes dx [M, d] and, when dgb_partials is non-NULL, the partial sums of dgamma in the layout of
+ * vlpet_sublayer_tail_bwd (reduce with vlpet_sublayer_tail_reduce(partials, n, d, dgamma, NULL)). */
+int vlpet_rmsnorm_fwd(const void* x, const float* gamma, void* out, float* rstd, int64_t M, int d, float eps, int io_dtype,
+                      vlpet_stream_t stream);
+int vlpet_rmsnorm_bwd(const void* dout, const void* x, const float* rstd, const float* gamma, void* dx, float* dgb_partials,
+                      int64_t M, int d, int io_dtype, vlpet_stream_t stream);
 int vlpet_layernorm_bwd_xhat(const void* dout, const void* xhat, const float* rstd, const float* gamma, void* dx,
                              float* dgb_partials, int64_t M, int d, int io_dtype, vlpet_stream_t stream);
 

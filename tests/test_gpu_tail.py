@@ -121,3 +121,39 @@ def test_tail_frozen_layernorm_copy_is_cached_and_follows_the_parameter():
     o3 = sublayer_tail(x1, y, ln, p=0.0, training=False)
     assert ln.weight._vlpet_f32[1] is not c1
     assert _rel(o3, ref().cpu()) <= 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,d", [(1, 64), (37, 768), (3111, 768), (130, 1024)])
+def test_rms_norm_matches_the_eager_t5_layer_norm(M, d, dtype):
+    """vlpet_rmsnorm_{fwd,bwd} (T5LayerNorm, my_transformers/modeling_t5.py:235-252) against the fp32 eager form: output,
+    input gradient and weight gradient."""
+    from vlpet_amd.tail import rms_norm
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(M, d, generator=g) * 1.5 + 0.2).to(dtype).float()
+    w = 1.0 + 0.2 * torch.randn(d, generator=g)
+    dout = torch.randn(M, d, generator=g).to(dtype).float()
+    X = x.to("cuda", dtype).requires_grad_(True)
+    W = w.cuda().requires_grad_(True)
+    out = rms_norm(X, W, 1e-6)
+    assert out.dtype == dtype
+    out.backward(dout.to("cuda", dtype))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = wr * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6))
+    ref.backward(dout)
+    tol = TOL[dtype]
+    assert _rel(out, ref.detach()) <= tol
+    assert _rel(X.grad, xr.grad) <= tol
+    assert _rel(W.grad, wr.grad) <= tol
+
+
+def test_t5_layer_norm_module_uses_the_hip_path_and_keeps_the_activation_dtype():
+    from vlpet_amd.visual import T5LayerNorm
+    ln = T5LayerNorm(256).cuda()                          # fp32 master weight next to bf16 activations
+    x = torch.randn(9, 5, 256, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    y = ln(x)
+    assert y.dtype == torch.bfloat16 and y.shape == x.shape
+    y.float().sum().backward()
+    assert ln.weight.grad is not None and ln.weight.grad.dtype == torch.float32 and x.grad.dtype == torch.bfloat16
+    ref = (x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6)) * ln.weight.float()
+    assert _rel(y.detach(), ref.detach().cpu()) <= 1e-2

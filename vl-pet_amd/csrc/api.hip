@@ -7,7 +7,7 @@
 #include <stdio.h>
 #include <vector>
 
-#define VLPET_VERSION 221      // 221: vlpet_sublayer_tail_reduce, vlpet_layernorm_bwd_xhat;  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
+#define VLPET_VERSION 221      // 221: vlpet_sublayer_tail_reduce, vlpet_layernorm_bwd_xhat, vlpet_rmsnorm_{fwd,bwd};  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -785,6 +785,33 @@ extern "C" int vlpet_layernorm_bwd_xhat(const void* dout, const void* xhat, cons
     a.out = const_cast<void*>(dout); a.h = const_cast<void*>(xhat); a.mean = nullptr; a.rstd = const_cast<float*>(rstd);
     a.gamma = gamma; a.x1 = dx; a.y = nullptr; a.dgb = dgb_partials; a.M = M; a.d = d; a.thr = 0; a.keep_scale = 1.f;
     a.norm = 1; a.h_xhat = 1;
+    return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
+}
+
+// T5's RMS norm (my_transformers/modeling_t5.py:235-252: x * rsqrt(mean(x^2) + eps) * weight) as one pass each way on the tail
+// kernels: forward out = rmsnorm(x) * gamma, rstd [M] saved; backward dx from (dout, x, rstd, gamma) + the dgamma partials.
+extern "C" int vlpet_rmsnorm_fwd(const void* x, const float* gamma, void* out, float* rstd, int64_t M, int d, float eps,
+                                 int io_dtype, vlpet_stream_t stream) {
+    int rc = tail_common(M, d, 0.f, io_dtype);
+    if (rc) return rc;
+    if (!x || !gamma || !out || !rstd) return VLPET_E_NULL;
+    if (!aligned16(x) || !aligned16(out)) return VLPET_E_ALIGN;
+    TailArgs a{};
+    a.y = nullptr; a.x1 = x; a.out = out; a.h = nullptr; a.gamma = gamma; a.beta = nullptr; a.mean = nullptr; a.rstd = rstd;
+    a.keep_out = nullptr; a.dgb = nullptr; a.M = M; a.d = d; a.eps = eps; a.thr = 0; a.keep_scale = 1.f; a.norm = 1; a.rms = 1;
+    return herr(launch_tail(a, io_dtype == VLPET_F32, false, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_rmsnorm_bwd(const void* dout, const void* x, const float* rstd, const float* gamma, void* dx,
+                                 float* dgb_partials, int64_t M, int d, int io_dtype, vlpet_stream_t stream) {
+    int rc = tail_common(M, d, 0.f, io_dtype);
+    if (rc) return rc;
+    if (!dout || !x || !rstd || !gamma || !dx) return VLPET_E_NULL;
+    if (!aligned16(dout) || !aligned16(x) || !aligned16(dx)) return VLPET_E_ALIGN;
+    TailArgs a{};
+    a.out = const_cast<void*>(dout); a.h = const_cast<void*>(x); a.mean = nullptr; a.rstd = const_cast<float*>(rstd);
+    a.gamma = gamma; a.x1 = dx; a.y = nullptr; a.dgb = dgb_partials; a.M = M; a.d = d; a.thr = 0; a.keep_scale = 1.f;
+    a.norm = 1; a.rms = 1;
     return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
 }
 

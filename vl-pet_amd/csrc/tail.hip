@@ -60,7 +60,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = lane + 64 * k;
-            if (p < pieces) { ry[k] = P::load_raw(y + o + p * 16); rx[k] = P::load_raw(x1 + o + p * 16); }
+            if (p < pieces) { if (y) ry[k] = P::load_raw(y + o + p * 16); rx[k] = P::load_raw(x1 + o + p * 16); }
         }
     };
     {
@@ -79,7 +79,11 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
             const int p = lane + 64 * k;
             if (p < pieces) {
                 float vy[E], vx[E];
-                P::from_raw(cy[k], vy);
+                if (y) P::from_raw(cy[k], vy);
+                else {
+#pragma unroll
+                    for (int j = 0; j < E; ++j) vy[j] = 0.f;
+                }
                 P::from_raw(cx[k], vx);
                 if constexpr (POST) {
 #pragma unroll
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
             }
         }
         if constexpr (NORM) {
-            const float mean = wave_sum(s) * inv_d;
+            const float mean = a.rms ? 0.f : wave_sum(s) * inv_d;
             float q = 0.f;
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
                 }
             }
             const float rstd = rsqrtf(wave_sum(q) * inv_d + a.eps);
-            if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+            if (lane == 0) { if (a.mean) a.mean[row] = mean; a.rstd[row] = rstd; }
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int p = lane + 64 * k;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
     auto load_row = [&](int64_t r, u32x4 (&rd)[NP], u32x4 (&rh)[NORM ? NP : 1], float& mu, float& rs) {
         if (r >= a.M) r = a.M - 1;                  // next row of this wave, requested one row ahead (see the forward)
         const int64_t o = r * d * (int64_t)sizeof(IO);
-        if constexpr (NORM) { mu = a.h_xhat ? 0.f : a.mean[r]; rs = a.rstd[r]; }
+        if constexpr (NORM) { mu = (a.h_xhat || a.rms) ? 0.f : a.mean[r]; rs = a.rstd[r]; }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = lane + 64 * k;
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
             }
         }
         if constexpr (NORM) {
-            const float c1 = wave_sum(s1) * inv_d, c2 = wave_sum(s2) * inv_d;
+            const float c1 = a.rms ? 0.f : wave_sum(s1) * inv_d, c2 = wave_sum(s2) * inv_d;
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 if (lane + 64 * k < pieces) {

@@ -128,3 +128,56 @@ def sublayer_tail(x1: torch.Tensor, y: torch.Tensor, norm: Optional[torch.nn.Mod
     if norm is None:
         return _TailFn.apply(y, x1, None, None, 0.0, p_eff, seed, 0, return_mask, link)
     return _TailFn.apply(y, x1, norm.weight, norm.bias, norm.eps, p_eff, seed, 1, return_mask, link)
+
+
+class _RmsNormFn(torch.autograd.Function):
+    """T5LayerNorm on the tail kernels (vlpet_rmsnorm_{fwd,bwd}): ``x * rsqrt(mean(x^2) + eps) * weight``, statistics in fp32,
+    result in x's dtype; one pass each way instead of the eight / ten elementwise and reduction passes of the eager form."""
+
+    @staticmethod
+    def forward(ctx, x, weight, eps):
+        lib = _lib.load()
+        _need_cuda(x)
+        d = x.shape[-1]
+        io = _io_dtype(x)
+        xf = _flat(x, d)
+        M = xf.shape[0]
+        out = torch.empty_like(xf)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        g32 = _f32_frozen(weight)
+        rc = _timed("rms_fwd", M, lambda: lib.vlpet_rmsnorm_fwd(xf.data_ptr(), g32.data_ptr(), out.data_ptr(), rstd.data_ptr(),
+                                                                M, d, float(eps), io, _stream()))
+        _lib.check(rc, "vlpet_rmsnorm_fwd")
+        ctx.save_for_backward(xf, rstd, g32, weight)
+        ctx.cfg = (x.shape, io)
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        xf, rstd, g32, weight = ctx.saved_tensors
+        shape, io = ctx.cfg
+        M, d = xf.shape
+        df = _flat(dout, d)
+        if df.dtype != xf.dtype:
+            df = df.to(xf.dtype)
+        dx = torch.empty_like(xf)
+        train = bool(ctx.needs_input_grad[1])
+        part = torch.empty(lib.vlpet_sublayer_tail_partials(M), 2, d, dtype=torch.float32, device=xf.device) if train else None
+        rc = _timed("rms_bwd", M, lambda: lib.vlpet_rmsnorm_bwd(df.data_ptr(), xf.data_ptr(), rstd.data_ptr(), g32.data_ptr(),
+                                                                dx.data_ptr(), _ptr(part), M, d, io, _stream()))
+        _lib.check(rc, "vlpet_rmsnorm_bwd")
+        dgamma = None
+        if train:
+            (tg, sg) = _grad_dest(weight, (d,))
+            rc = lib.vlpet_sublayer_tail_reduce(part.data_ptr(), part.shape[0], d, tg.data_ptr(), None, _stream())
+            _lib.check(rc, "vlpet_sublayer_tail_reduce")
+            dgamma = _finish([(tg, sg, weight)])[0]
+        return dx.view(shape), dgamma, None
+
+
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """T5's RMS norm of ``x [..., d]`` (d % 8 == 0, bf16 or fp32 CUDA tensor) on the HIP path."""
+    if x.numel() == 0:
+        return x * weight.to(x.dtype)
+    return _RmsNormFn.apply(x, weight, eps)

@@ -16,6 +16,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+import os as _os
+EAGER_RMS_NORM = _os.environ.get("VLPET_EAGER_RMS_NORM", "0") == "1"
+
+
 class T5LayerNorm(nn.Module):
     """RMS norm without bias (my_transformers/modeling_t5.py:235-252)."""
 
@@ -25,9 +29,16 @@ class T5LayerNorm(nn.Module):
         self.variance_epsilon = eps
 
     def forward(self, x):
-        var = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
-        x = x * torch.rsqrt(var + self.variance_epsilon)
-        return self.weight.to(x.dtype) * x.to(self.weight.dtype if self.weight.dtype != torch.float32 else x.dtype)
+        if x.is_cuda and not EAGER_RMS_NORM and x.shape[-1] % 8 == 0 and x.dtype in (torch.bfloat16, torch.float32):
+            from .tail import rms_norm
+            return rms_norm(x, self.weight, self.variance_epsilon)       # one HIP pass each way (csrc/tail.hip, rms mode)
+        # eager form (CPU tensors of the parity harness; VLPET_EAGER_RMS_NORM=1 for A/B): statistics and scaling in fp32, result in the activation dtype (the reference casts the normalised rows to the
+        # weight's half dtype, :248-251; here the weight may be an fp32 master next to bf16 activations -- a bf16 row times an
+        # fp32 tensor silently promoted the whole encoder to fp32 before this line said otherwise)
+        xf = x.to(torch.float32)
+        var = xf.pow(2).mean(-1, keepdim=True)
+        y = self.weight.to(torch.float32) * (xf * torch.rsqrt(var + self.variance_epsilon))
+        return y.to(x.dtype)
 
 
 class Downsample(nn.Module):
