@@ -310,6 +310,10 @@ int vlpet_rmsnorm_fwd(const void* x, const float* gamma, void* out, float* rstd,
                       vlpet_stream_t stream);
 int vlpet_rmsnorm_bwd(const void* dout, const void* x, const float* rstd, const float* gamma, void* dx, float* dgb_partials,
                       int64_t M, int d, int io_dtype, vlpet_stream_t stream);
+/* out [n] (fp32, OVERWRITTEN) = column sums of x [M, n] (IO dtype): the gradient of a trainable Linear bias -- the reference's LoRA
+ * runs train every bias (src/trainer_base.py `unfreeze "bias"` rule; autograd's dy.sum(0) of my_transformers/modeling_bart.py:791-811).
+ * workspace: vlpet_sublayer_tail_partials(M) * n floats.  n % 16 == 0, n <= 4096 (bf16) / 2048 (fp32).  Two launches. */
+int vlpet_colsum(const void* x, int64_t M, int n, float* workspace, float* out, int io_dtype, vlpet_stream_t stream);
 int vlpet_layernorm_bwd_xhat(const void* dout, const void* xhat, const float* rstd, const float* gamma, void* dx,
                              float* dgb_partials, int64_t M, int d, int io_dtype, vlpet_stream_t stream);
 

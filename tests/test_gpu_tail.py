@@ -157,3 +157,33 @@ def test_t5_layer_norm_module_uses_the_hip_path_and_keeps_the_activation_dtype()
     assert ln.weight.grad is not None and ln.weight.grad.dtype == torch.float32 and x.grad.dtype == torch.bfloat16
     ref = (x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6)) * ln.weight.float()
     assert _rel(y.detach(), ref.detach().cpu()) <= 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,n", [(1, 64), (37, 768), (3111, 768), (501, 3072), (20000, 768)])
+def test_linear_with_trainable_bias_matches_autograd(M, n, dtype):
+    """vlpet_colsum behind functional.linear_train_bias (frozen weight, trainable fp32 bias -- the LoRA runs' bias rule):
+    output, input gradient and bias gradient against F.linear's autograd in fp32."""
+    import vlpet_amd.functional as VF
+    g = torch.Generator().manual_seed(21)
+    k = 96
+    x = torch.randn(M, k, generator=g).to(dtype).float()
+    w = (torch.randn(n, k, generator=g) * 0.1).to(dtype).float()
+    b = torch.randn(n, generator=g)
+    dy = torch.randn(M, n, generator=g).to(dtype).float()
+    X = x.to("cuda", dtype).requires_grad_(True)
+    W = w.to("cuda", dtype)
+    B = b.cuda().requires_grad_(True)
+    if dtype == torch.float32 and n > 2048:             # beyond the row kernels' width in fp32: the caller keeps autograd's sum
+        assert not VF.linear_train_bias_ok(X, W, B)
+        return
+    assert VF.linear_train_bias_ok(X, W, B)
+    out = VF.linear_train_bias(X, W, B)
+    out.backward(dy.to("cuda", dtype))
+    xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.linear(xr, w, br)
+    ref.backward(dy)
+    tol = TOL[dtype]
+    assert _rel(out, ref.detach()) <= tol
+    assert _rel(X.grad, xr.grad) <= tol
+    assert B.grad.dtype == torch.float32 and _rel(B.grad, br.grad) <= (1e-5 if dtype == torch.float32 else 2e-3)

@@ -7,7 +7,7 @@
 #include <stdio.h>
 #include <vector>
 
-#define VLPET_VERSION 221      // 221: vlpet_sublayer_tail_reduce, vlpet_layernorm_bwd_xhat, vlpet_rmsnorm_{fwd,bwd};  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
+#define VLPET_VERSION 221      // 221: vlpet_sublayer_tail_reduce, vlpet_layernorm_bwd_xhat, vlpet_rmsnorm_{fwd,bwd}, vlpet_colsum;  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -813,6 +813,17 @@ extern "C" int vlpet_rmsnorm_bwd(const void* dout, const void* x, const float* r
     a.gamma = gamma; a.x1 = dx; a.y = nullptr; a.dgb = dgb_partials; a.M = M; a.d = d; a.thr = 0; a.keep_scale = 1.f;
     a.norm = 1; a.rms = 1;
     return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
+}
+
+// Column sums of x [M, n] in fp32 (OVERWRITTEN): the gradient of a trainable bias (dy.sum(0)).  workspace: at least
+// vlpet_sublayer_tail_partials(M) * n floats.  n % 16 == 0.
+extern "C" int vlpet_colsum(const void* x, int64_t M, int n, float* workspace, float* out, int io_dtype, vlpet_stream_t stream) {
+    if (M <= 0 || n <= 0 || n % 16 != 0) return VLPET_E_SHAPE;
+    if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    if (n / (io_dtype == VLPET_F32 ? 4 : 8) > 8 * 64) return VLPET_E_SHAPE;
+    if (!x || !workspace || !out) return VLPET_E_NULL;
+    if (!aligned16(x)) return VLPET_E_ALIGN;
+    return herr(launch_colsum(x, M, n, workspace, out, io_dtype == VLPET_F32, (hipStream_t)stream));
 }
 
 extern "C" int vlpet_sublayer_tail_reduce(const float* dgb_partials, int n_partials, int d, float* dgamma, float* dbeta,

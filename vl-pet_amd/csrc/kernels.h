@@ -183,6 +183,7 @@ struct TailArgs {
 hipError_t launch_tail(const TailArgs& a, int io_fp32, bool bwd, hipStream_t stream);
 int tail_blocks(int64_t M);
 hipError_t launch_tail_reduce(const float* part, int nb, int d, float* dgamma, float* dbeta, hipStream_t stream);
+hipError_t launch_colsum(const void* x, int64_t M, int n, float* part, float* out, int io_fp32, hipStream_t stream);
 
 // Downsample (adaptive max pool over the token grid), downsample.hip
 struct PoolArgs {

@@ -315,6 +315,89 @@ __global__ __launch_bounds__(1024) void tail_reduce_kernel(const float* __restri
     }
 }
 
+// Column sums of x [M, n] (the gradient of a trainable Linear bias: autograd's dy.sum(0), the LoRA runs train every bias,
+// my_transformers/modeling_bart.py:791-811 with lora/controller.py): pass 1 = per-workgroup partial sums [blocks][n] (a wave owns
+// a row, lanes own 16-byte pieces, the next row requested before the current one is added), pass 2 = tail_reduce_kernel over
+// the partials viewed as [blocks][2 * (n / 2)].
+template <typename IO, int NP>
+__global__ __launch_bounds__(TAIL_WAVES * 64) void colsum_partial_kernel(const void* __restrict__ xin, int64_t M, int n,
+                                                                         float* __restrict__ part) {
+    using P = Piece<IO>;
+    constexpr int E = P::E;
+    __shared__ float acc[TAIL_WAVES][64 * 8];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pieces = n / E;
+    const uint8_t* x = reinterpret_cast<const uint8_t*>(xin);
+    const int64_t rstride = (int64_t)gridDim.x * TAIL_WAVES;
+    float s[NP][E];
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+        for (int j = 0; j < E; ++j) s[k][j] = 0.f;
+    u32x4 cur[NP];
+    auto load_row = [&](int64_t r, u32x4 (&rd)[NP]) {
+        if (r >= M) r = M - 1;
+        const int64_t o = r * n * (int64_t)sizeof(IO);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { const int p = lane + 64 * k; if (p < pieces) rd[k] = P::load_raw(x + o + p * 16); }
+    };
+    const int64_t r0 = (int64_t)blockIdx.x * TAIL_WAVES + wave;
+    if (r0 < M) load_row(r0, cur);
+    for (int64_t row = r0; row < M; row += rstride) {
+        u32x4 nxt[NP];
+        load_row(row + rstride, nxt);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if (lane + 64 * k < pieces) {
+                float v[E];
+                P::from_raw(cur[k], v);
+#pragma unroll
+                for (int j = 0; j < E; ++j) s[k][j] += v[j];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) cur[k] = nxt[k];
+    }
+    float* dst = part + (size_t)blockIdx.x * n;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int p = lane + 64 * k;
+#pragma unroll
+        for (int j = 0; j < E; ++j) acc[wave][lane * 8 + j] = s[k][j];
+        __syncthreads();
+        if (wave == 0 && p < pieces) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < TAIL_WAVES; ++w) t += acc[w][lane * 8 + j];
+                dst[p * E + j] = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename IO>
+static hipError_t launch_colsum_io(const void* x, int64_t M, int n, float* part, int blocks, hipStream_t stream) {
+    const int np = (n / Piece<IO>::E + 63) / 64;
+    const dim3 g(blocks), b(TAIL_WAVES * 64);
+    if (np <= 1) hipLaunchKernelGGL((colsum_partial_kernel<IO, 1>), g, b, 0, stream, x, M, n, part);
+    else if (np <= 2) hipLaunchKernelGGL((colsum_partial_kernel<IO, 2>), g, b, 0, stream, x, M, n, part);
+    else if (np <= 4) hipLaunchKernelGGL((colsum_partial_kernel<IO, 4>), g, b, 0, stream, x, M, n, part);
+    else if (np <= 8) hipLaunchKernelGGL((colsum_partial_kernel<IO, 8>), g, b, 0, stream, x, M, n, part);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// out [n] (fp32, OVERWRITTEN) = column sums of x [M, n]; part = workspace of tail_blocks(M) * n floats
+hipError_t launch_colsum(const void* x, int64_t M, int n, float* part, float* out, int io_fp32, hipStream_t stream) {
+    const int blocks = tail_blocks(M);
+    hipError_t e = io_fp32 ? launch_colsum_io<float>(x, M, n, part, blocks, stream) : launch_colsum_io<__bf16>(x, M, n, part, blocks, stream);
+    if (e != hipSuccess) return e;
+    return launch_tail_reduce(part, blocks, n / 2, out, out + n / 2, stream);
+}
+
 hipError_t launch_tail_reduce(const float* part, int nb, int d, float* dgamma, float* dbeta, hipStream_t stream) {
     hipLaunchKernelGGL(tail_reduce_kernel, dim3((2 * d + 63) / 64), dim3(1024), 0, stream, part, nb, d, dgamma, dbeta);
     return hipGetLastError();

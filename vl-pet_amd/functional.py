@@ -347,6 +347,48 @@ class _LinearAccFn(torch.autograd.Function):
         return (dx, None) + (None,) * (2 * len(ws))
 
 
+class _LinearTrainBiasFn(torch.autograd.Function):
+    """``x W^T + b`` with a FROZEN weight and a TRAINABLE bias (the reference's LoRA runs unfreeze every bias next to the frozen
+    projections): the bias gradient = column sums of dy through vlpet_colsum (two HIP launches, fp32, straight into the
+    parameter's slot of the flat gradient buffer when the trainer offers one) instead of autograd's bf16 ``sum(0)`` + cast +
+    accumulate."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(w, b)
+        return F.linear(x, w, b if b.dtype == x.dtype else b.to(x.dtype))
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        w, b = ctx.saved_tensors
+        n = dy.shape[-1]
+        dy2 = _flat(dy, n)
+        if dy2.dtype != w.dtype:
+            dy2 = dy2.to(w.dtype)
+        dx = (dy2 @ w).view(*dy.shape[:-1], w.shape[1]) if ctx.needs_input_grad[0] else None
+        db = None
+        if ctx.needs_input_grad[2]:
+            M = dy2.shape[0]
+            (t, sink) = _grad_dest(b, (n,))
+            ws = torch.empty(lib.vlpet_sublayer_tail_partials(M) * n, dtype=torch.float32, device=dy2.device)
+            rc = lib.vlpet_colsum(dy2.data_ptr(), M, n, ws.data_ptr(), t.data_ptr(), _io_dtype(dy2), _stream())
+            _lib.check(rc, "vlpet_colsum")
+            db = _finish([(t, sink, b)])[0]
+        return dx, None, db
+
+
+def linear_train_bias_ok(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> bool:
+    """Whether ``linear_train_bias`` applies: CUDA bf16 / fp32 activations, frozen weight in that dtype, trainable bias."""
+    return (b is not None and b.requires_grad and not w.requires_grad and x.is_cuda and w.dtype == x.dtype
+            and x.dtype in (torch.bfloat16, torch.float32) and w.shape[0] % 16 == 0 and w.shape[0] <= (4096 if x.dtype == torch.bfloat16 else 2048)
+            and x.numel() > 0 and torch.is_grad_enabled())
+
+
+def linear_train_bias(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return _LinearTrainBiasFn.apply(x, w, b)
+
+
 def linear_acc(x: torch.Tensor, link: Optional[ResidualLink], *mods):
     """``F.linear`` of ``x`` through each of ``mods`` (``nn.Linear``-like, or ``(weight, bias)`` pairs), frozen, with the
     input gradient accumulated onto whatever the op sharing ``link`` parks (see _LinearAccFn).  One result per module."""

@@ -192,6 +192,10 @@ def _linear(mod: nn.Linear, x):
     w, b = mod.weight, mod.bias             # (a trainable fp32 bias next to a frozen bf16 weight in LoRA runs)
     if w.dtype != x.dtype:
         w = w.to(x.dtype)
+    if FUSE_BIAS_GRAD and b is not None and b.requires_grad:
+        from ..functional import linear_train_bias, linear_train_bias_ok
+        if linear_train_bias_ok(x, w, b):
+            return linear_train_bias(x, w, b)             # bias gradient = column sums of dy on the HIP path
     if b is not None and b.dtype != x.dtype:
         b = b.to(x.dtype)
     return F.linear(x, w, b)
@@ -229,6 +233,7 @@ def attention_core(q, k, v, num_heads, attn_mask, causal, p, training):
     return out.transpose(1, 2).reshape(B, Lq, E)
 
 
+FUSE_BIAS_GRAD = _os.environ.get("VLPET_NO_BIAS_GRAD_KERNEL", "0") != "1"    # A/B switch: autograd's sum(0) for trainable biases
 EAGER_ATTENTION = _os.environ.get("VLPET_EAGER_ATTENTION", "0") == "1"   # A/B switch: the library (SDPA) path for every shape
 FUSE_QKV = _os.environ.get("VLPET_NO_FUSED_QKV", "0") != "1"              # A/B switch: separate q / k / v projections in self-attention
 

@@ -64,9 +64,12 @@ class LoRALinearController(nn.Linear, LoRALayer):
         w, b = self.weight, self.bias
         if w.dtype != x.dtype:
             w = w.to(x.dtype)
-        if b is not None and b.dtype != x.dtype:      # the bias trains (fp32 master) next to the frozen bf16 weight
-            b = b.to(x.dtype)
-        base = F.linear(x, w, b)
+        if VF.linear_train_bias_ok(x, w, b):          # the bias trains (fp32 master) next to the frozen bf16 weight
+            base = VF.linear_train_bias(x, w, b)
+        else:
+            if b is not None and b.dtype != x.dtype:
+                b = b.to(x.dtype)
+            base = F.linear(x, w, b)
         if self.r <= 0:
             return base
         A, B = self.lora_As[task], self.lora_Bs[task]
