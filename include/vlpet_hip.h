@@ -305,11 +305,13 @@ int vlpet_sublayer_tail_reduce(const float* dgb_partials, int n_partials, int d,
 /* T5LayerNorm (my_transformers/modeling_t5.py:235-252; the RMS norm in front of every T5 sublayer, :366, :782, and the final
  * norms): out = x * rsqrt(mean(x^2) + eps) * gamma, statistics in fp32, one pass each way over [M, d].  rstd [M] is saved by the
  * forward; the backward writes dx [M, d] and, when dgb_partials is non-NULL, the partial sums of dgamma in the layout of
- * vlpet_sublayer_tail_bwd (reduce with vlpet_sublayer_tail_reduce(partials, n, d, dgamma, NULL)). */
+ * vlpet_sublayer_tail_bwd (reduce with vlpet_sublayer_tail_reduce(partials, n, d, dgamma, NULL)).  dx_in: optional [M, d], added
+ * to dx -- the gradient of the other reader of x (a pre-norm sublayer's residual add, :408, and K1's gate input), so that
+ * autograd has one gradient for the stream instead of two to add; may alias dx. */
 int vlpet_rmsnorm_fwd(const void* x, const float* gamma, void* out, float* rstd, int64_t M, int d, float eps, int io_dtype,
                       vlpet_stream_t stream);
-int vlpet_rmsnorm_bwd(const void* dout, const void* x, const float* rstd, const float* gamma, void* dx, float* dgb_partials,
-                      int64_t M, int d, int io_dtype, vlpet_stream_t stream);
+int vlpet_rmsnorm_bwd(const void* dout, const void* x, const float* rstd, const float* gamma, const void* dx_in, void* dx,
+                      float* dgb_partials, int64_t M, int d, int io_dtype, vlpet_stream_t stream);
 /* out [n] (fp32, OVERWRITTEN) = column sums of x [M, n] (IO dtype): the gradient of a trainable Linear bias -- the reference's LoRA
  * runs train every bias (src/trainer_base.py `unfreeze "bias"` rule; autograd's dy.sum(0) of my_transformers/modeling_bart.py:791-811).
  * workspace: vlpet_sublayer_tail_partials(M) * n floats.  n % 16 == 0, n <= 4096 (bf16) / 2048 (fp32).  Two launches. */

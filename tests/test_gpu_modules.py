@@ -350,3 +350,49 @@ def test_gemm_gradient_handover(which, p_drop):
     for n in outs[1][1]:
         a, b = outs[0][1][n], outs[1][1][n]
         assert (a - b).abs().max().item() <= 2e-2 * max(b.abs().max().item(), 1e-6), n
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("which", ["encoder", "decoder"])
+def test_t5_norm_gradient_handover(which, p_drop):
+    """T5 block with the residual-stream hand-over into the RMS norm's backward kernel (host/t5.py FUSE_NORM_GRAD) against
+    plain autograd sums: same output, same gradients for the block input, the encoder output and every trainable parameter."""
+    import vlpet_amd.host.t5 as HT
+    import vlpet_amd.train as TR
+    torch.manual_seed(13)
+    dtype = torch.bfloat16
+    cfg = HT.vlt5_config(num_layers=1, num_decoder_layers=1, vocab_size=300, dropout_rate=p_drop)
+    blk = HT.T5Block(cfg, which == "decoder", True)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn_like(p) * 0.03)
+    blk.cuda().train()
+    for n, p in blk.named_parameters():
+        p.requires_grad = ("adapter" in n) or ("gating" in n) or ("layer_norm" in n and which == "encoder")
+    TR.cast_frozen(blk, dtype)
+    B, L, S = 24, 20, 56
+    x = torch.randn(B, S if which == "encoder" else L, 768, device="cuda").to(dtype)
+    enc = torch.randn(B, S, 768, device="cuda").to(dtype)
+    dy = torch.randn_like(x)
+    outs = []
+    for fuse in (True, False):
+        HT.FUSE_NORM_GRAD = fuse
+        try:
+            for p in blk.parameters():
+                p.grad = None
+            torch.manual_seed(5)
+            xi, ei = x.clone().requires_grad_(True), enc.clone().requires_grad_(True)
+            y = blk(xi, None) if which == "encoder" else blk(xi, None, enc=ei, cross_bias=None, task="vqa")
+            y.backward(dy)
+            g = {n: p.grad.float().clone() for n, p in blk.named_parameters() if p.grad is not None}
+            g["<input>"] = xi.grad.float()
+            if which == "decoder":
+                g["<encoder output>"] = ei.grad.float()
+            outs.append((y.detach().float(), g))
+        finally:
+            HT.FUSE_NORM_GRAD = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1].keys() == outs[1][1].keys() and len(outs[0][1]) > 2
+    for n in outs[1][1]:
+        a, b = outs[0][1][n], outs[1][1][n]
+        assert (a - b).abs().max().item() <= 2e-2 * max(b.abs().max().item(), 1e-6), n

@@ -96,7 +96,7 @@ SIGNATURES = {
     "vlpet_layernorm_bwd_xhat": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_void_p]),
     "vlpet_colsum": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "vlpet_rmsnorm_fwd": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_float, c_int, c_void_p]),
-    "vlpet_rmsnorm_bwd": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_void_p]),
+    "vlpet_rmsnorm_bwd": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p]),
     "vlpet_attn_fwd": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_float, c_float, c_uint64, c_void_p]),
     "vlpet_attn_bwd": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_float, c_float, c_uint64, c_void_p]),
     "vlpet_attn_fwd_ld": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_float, c_uint64, c_void_p]),

@@ -802,16 +802,16 @@ extern "C" int vlpet_rmsnorm_fwd(const void* x, const float* gamma, void* out, f
     return herr(launch_tail(a, io_dtype == VLPET_F32, false, (hipStream_t)stream));
 }
 
-extern "C" int vlpet_rmsnorm_bwd(const void* dout, const void* x, const float* rstd, const float* gamma, void* dx,
-                                 float* dgb_partials, int64_t M, int d, int io_dtype, vlpet_stream_t stream) {
+extern "C" int vlpet_rmsnorm_bwd(const void* dout, const void* x, const float* rstd, const float* gamma, const void* dx_in,
+                                 void* dx, float* dgb_partials, int64_t M, int d, int io_dtype, vlpet_stream_t stream) {
     int rc = tail_common(M, d, 0.f, io_dtype);
     if (rc) return rc;
     if (!dout || !x || !rstd || !gamma || !dx) return VLPET_E_NULL;
-    if (!aligned16(dout) || !aligned16(x) || !aligned16(dx)) return VLPET_E_ALIGN;
+    if (!aligned16(dout) || !aligned16(x) || !aligned16(dx) || (dx_in && !aligned16(dx_in))) return VLPET_E_ALIGN;
     TailArgs a{};
     a.out = const_cast<void*>(dout); a.h = const_cast<void*>(x); a.mean = nullptr; a.rstd = const_cast<float*>(rstd);
     a.gamma = gamma; a.x1 = dx; a.y = nullptr; a.dgb = dgb_partials; a.M = M; a.d = d; a.thr = 0; a.keep_scale = 1.f;
-    a.norm = 1; a.rms = 1;
+    a.norm = 1; a.rms = 1; a.dres = dx_in;
     return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
 }
 

@@ -176,9 +176,10 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
     uint8_t* dy = reinterpret_cast<uint8_t*>(const_cast<void*>(a.y));
     const float inv_d = 1.0f / (float)d;
     const int64_t rstride = (int64_t)gridDim.x * TAIL_WAVES;
-    u32x4 cd[NP], ch[NORM ? NP : 1];
+    const uint8_t* dres = reinterpret_cast<const uint8_t*>(a.dres);
+    u32x4 cd[NP], ch[NORM ? NP : 1], cr[NP];
     float cmean = 0.f, crstd = 1.f;
-    auto load_row = [&](int64_t r, u32x4 (&rd)[NP], u32x4 (&rh)[NORM ? NP : 1], float& mu, float& rs) {
+    auto load_row = [&](int64_t r, u32x4 (&rd)[NP], u32x4 (&rh)[NORM ? NP : 1], u32x4 (&rr)[NP], float& mu, float& rs) {
         if (r >= a.M) r = a.M - 1;                  // next row of this wave, requested one row ahead (see the forward)
         const int64_t o = r * d * (int64_t)sizeof(IO);
         if constexpr (NORM) { mu = (a.h_xhat || a.rms) ? 0.f : a.mean[r]; rs = a.rstd[r]; }
@@ -188,18 +189,19 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
             if (p < pieces) {
                 rd[k] = P::load_raw(dout + o + p * 16);
                 if constexpr (NORM) rh[k] = P::load_raw(hs + o + p * 16);
+                if (dres) rr[k] = P::load_raw(dres + o + p * 16);
             }
         }
     };
     {
         const int64_t r0 = (int64_t)blockIdx.x * TAIL_WAVES + wave;
-        if (r0 < a.M) load_row(r0, cd, ch, cmean, crstd);
+        if (r0 < a.M) load_row(r0, cd, ch, cr, cmean, crstd);
     }
     for (int64_t row = (int64_t)blockIdx.x * TAIL_WAVES + wave; row < a.M; row += rstride) {
         const int64_t rb = row * d * (int64_t)sizeof(IO);
-        u32x4 nd[NP], nh[NORM ? NP : 1];
+        u32x4 nd[NP], nh[NORM ? NP : 1], nr[NP];
         float nmean = 0.f, nrstd = 1.f;
-        load_row(row + rstride, nd, nh, nmean, nrstd);
+        load_row(row + rstride, nd, nh, nr, nmean, nrstd);
         float g[NP][E], xh[NORM ? NP : 1][E];
         float s1 = 0.f, s2 = 0.f;
         const float mean = cmean, rstd = crstd;
@@ -238,6 +240,17 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
                 }
             }
         }
+        if (dres) {                                  // the parked gradient of the other reader of this input
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if (lane + 64 * k < pieces) {
+                    float vr[E];
+                    P::from_raw(cr[k], vr);
+#pragma unroll
+                    for (int j = 0; j < E; ++j) g[k][j] += vr[j];
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = lane + 64 * k;
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < NP; ++k) { cd[k] = nd[k]; if constexpr (NORM) ch[k] = nh[k]; }
+        for (int k = 0; k < NP; ++k) { cd[k] = nd[k]; if constexpr (NORM) ch[k] = nh[k]; cr[k] = nr[k]; }
         cmean = nmean; crstd = nrstd;
     }
     if constexpr (NORM) {

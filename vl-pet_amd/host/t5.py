@@ -33,14 +33,38 @@ import os as _os
 FUSE_RESIDUAL_GRAD = _os.environ.get("VLPET_NO_LINK", "0") != "1"      # (VLPET_NO_LINK=1: plain autograd sums, for A/B)
 
 
-def _pet_then_tail(layer, which, residual, h, norm, p, training, config):
-    """``norm(residual + dropout(apply_pet(residual, h)))`` -- K1 followed by K5."""
+def _pet_then_tail(layer, which, residual, h, norm, p, training, config, norm_link=None):
+    """``norm(residual + dropout(apply_pet(residual, h)))`` -- K1 followed by K5.  ``norm_link``: armed by the sublayer's RMS norm
+    (which read ``residual`` first): K1's d/dresidual -- the tail's included -- goes out through it."""
     if not FUSE_RESIDUAL_GRAD:
         return sublayer_tail(residual, apply_pet(layer, which, residual, h, config), norm, p, training)
     from ..functional import ResidualLink
     link = ResidualLink()
-    y = apply_pet(layer, which, residual, h, config, link=link)
+    y = apply_pet(layer, which, residual, h, config, link=link, out_link=norm_link)
     return sublayer_tail(residual, y, norm, p, training, link=link)
+
+
+# The pre-norm residual stream of a T5 sublayer is read by the RMS norm in front of it and by the tail's add behind it (and by
+# K1's gate in the encoder): the later reader parks its gradient and the norm's backward kernel adds it (tail.rms_norm's link) --
+# one gradient for the stream, no elementwise add by autograd (my_transformers/modeling_t5.py:366, 408; :782, 824).
+FUSE_NORM_GRAD = _os.environ.get("VLPET_NO_NORM_LINK", "0") != "1"     # (VLPET_NO_NORM_LINK=1: autograd's adds, for A/B)
+
+
+def _new_norm_link(x):
+    if not (FUSE_RESIDUAL_GRAD and FUSE_NORM_GRAD) or not x.is_cuda or not x.requires_grad or not torch.is_grad_enabled():
+        return None
+    from ..functional import ResidualLink
+    return ResidualLink()
+
+
+def _normed(norm, hidden, link):
+    return norm(hidden) if link is None else norm(hidden, link=link)
+
+
+def _tail_linked(hidden, y, p, training, link):
+    if link is None or not link.armed:
+        return sublayer_tail(hidden, y, None, p, training)
+    return sublayer_tail(hidden, y, None, p, training, link=link)
 
 
 def ffn_activation(x, act, p, training):
@@ -192,10 +216,11 @@ class T5LayerSelfAttention(nn.Module):
             build_pet(self, config, config.d_model, ("attn",))
 
     def forward(self, hidden, bias, task=None):
-        y = self.SelfAttention(self.layer_norm(hidden), bias)
+        nl = _new_norm_link(hidden)
+        y = self.SelfAttention(_normed(self.layer_norm, hidden, nl), bias)
         if not self.is_decoder and has_pet(self, "attn"):                                 # K1 (x1 = un-normalised stream) + K5
-            return _pet_then_tail(self, "attn", hidden, y, None, self.p, self.training, self.config)
-        return sublayer_tail(hidden, y, None, self.p, self.training)                      # K5
+            return _pet_then_tail(self, "attn", hidden, y, None, self.p, self.training, self.config, norm_link=nl)
+        return _tail_linked(hidden, y, self.p, self.training, nl)                         # K5
 
 
 class T5LayerCrossAttention(nn.Module):
@@ -207,8 +232,9 @@ class T5LayerCrossAttention(nn.Module):
         self.layer_norm = T5LayerNorm(config.d_model, eps=config.layer_norm_epsilon)
 
     def forward(self, hidden, enc, bias, task=None):
-        y = self.EncDecAttention(self.layer_norm(hidden), bias, kv=enc, task=task)
-        return sublayer_tail(hidden, y, None, self.p, self.training)
+        nl = _new_norm_link(hidden)
+        y = self.EncDecAttention(_normed(self.layer_norm, hidden, nl), bias, kv=enc, task=task)
+        return _tail_linked(hidden, y, self.p, self.training, nl)
 
 
 class T5LayerFF(nn.Module):
@@ -221,10 +247,11 @@ class T5LayerFF(nn.Module):
             build_pet(self, config, config.d_model, ("ff",))
 
     def forward(self, hidden, task=None):
-        y = self.DenseReluDense(self.layer_norm(hidden))
+        nl = _new_norm_link(hidden)
+        y = self.DenseReluDense(_normed(self.layer_norm, hidden, nl))
         if not self.is_decoder and has_pet(self, "ff"):
-            return _pet_then_tail(self, "ff", hidden, y, None, self.p, self.training, self.config)      # K1 + K5
-        return sublayer_tail(hidden, y, None, self.p, self.training)
+            return _pet_then_tail(self, "ff", hidden, y, None, self.p, self.training, self.config, norm_link=nl)      # K1 + K5
+        return _tail_linked(hidden, y, self.p, self.training, nl)
 
 
 class T5Block(nn.Module):

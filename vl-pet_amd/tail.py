@@ -135,9 +135,13 @@ class _RmsNormFn(torch.autograd.Function):
     result in x's dtype; one pass each way instead of the eight / ten elementwise and reduction passes of the eager form."""
 
     @staticmethod
-    def forward(ctx, x, weight, eps):
+    def forward(ctx, x, weight, eps, link=None):
         lib = _lib.load()
         _need_cuda(x)
+        ctx.link = None
+        if link is not None and ctx.needs_input_grad[0]:
+            link.armed = True               # the other reader of x (the tail / K1, downstream) parks its d/dx here
+            ctx.link = link
         d = x.shape[-1]
         io = _io_dtype(x)
         xf = _flat(x, d)
@@ -162,10 +166,17 @@ class _RmsNormFn(torch.autograd.Function):
         if df.dtype != xf.dtype:
             df = df.to(xf.dtype)
         dx = torch.empty_like(xf)
+        dx_in = None
+        if ctx.link is not None:
+            dx_in, ctx.link.dx1 = ctx.link.dx1, None
+            ctx.link.shared = False
+            ctx.link = None
+            if dx_in is not None and (dx_in.dtype != xf.dtype or dx_in.numel() != xf.numel() or not dx_in.is_contiguous()):
+                dx_in = dx_in.reshape(xf.shape).to(xf.dtype).contiguous()
         train = bool(ctx.needs_input_grad[1])
         part = torch.empty(lib.vlpet_sublayer_tail_partials(M), 2, d, dtype=torch.float32, device=xf.device) if train else None
         rc = _timed("rms_bwd", M, lambda: lib.vlpet_rmsnorm_bwd(df.data_ptr(), xf.data_ptr(), rstd.data_ptr(), g32.data_ptr(),
-                                                                dx.data_ptr(), _ptr(part), M, d, io, _stream()))
+                                                                _ptr(dx_in), dx.data_ptr(), _ptr(part), M, d, io, _stream()))
         _lib.check(rc, "vlpet_rmsnorm_bwd")
         dgamma = None
         if train:
@@ -173,11 +184,13 @@ class _RmsNormFn(torch.autograd.Function):
             rc = lib.vlpet_sublayer_tail_reduce(part.data_ptr(), part.shape[0], d, tg.data_ptr(), None, _stream())
             _lib.check(rc, "vlpet_sublayer_tail_reduce")
             dgamma = _finish([(tg, sg, weight)])[0]
-        return dx.view(shape), dgamma, None
+        return dx.view(shape), dgamma, None, None
 
 
-def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
-    """T5's RMS norm of ``x [..., d]`` (d % 8 == 0, bf16 or fp32 CUDA tensor) on the HIP path."""
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float, link=None) -> torch.Tensor:
+    """T5's RMS norm of ``x [..., d]`` (d % 8 == 0, bf16 or fp32 CUDA tensor) on the HIP path.  ``link``
+    (functional.ResidualLink): armed here; the op that also reads ``x`` further down parks its gradient and this backward adds it
+    inside the kernel."""
     if x.numel() == 0:
         return x * weight.to(x.dtype)
-    return _RmsNormFn.apply(x, weight, eps)
+    return _RmsNormFn.apply(x, weight, eps, link)

@@ -28,10 +28,11 @@ class T5LayerNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(hidden_size))
         self.variance_epsilon = eps
 
-    def forward(self, x):
+    def forward(self, x, link=None):
+        """``link`` (not in the reference's signature): see vlpet_amd.tail.rms_norm; ignored on the eager path."""
         if x.is_cuda and not EAGER_RMS_NORM and x.shape[-1] % 8 == 0 and x.dtype in (torch.bfloat16, torch.float32):
             from .tail import rms_norm
-            return rms_norm(x, self.weight, self.variance_epsilon)       # one HIP pass each way (csrc/tail.hip, rms mode)
+            return rms_norm(x, self.weight, self.variance_epsilon, link)  # one HIP pass each way (csrc/tail.hip, rms mode)
         # eager form (CPU tensors of the parity harness; VLPET_EAGER_RMS_NORM=1 for A/B): statistics and scaling in fp32, result in the activation dtype (the reference casts the normalised rows to the
         # weight's half dtype, :248-251; here the weight may be an fp32 master next to bf16 activations -- a bf16 row times an
         # fp32 tensor silently promoted the whole encoder to fp32 before this line said otherwise)
