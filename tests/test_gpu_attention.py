@@ -31,6 +31,8 @@ CASES = [  # B, Lq, Lk, causal, masked, p
     (3, 56, 56, False, False, 0.0),
     (3, 56, 56, False, True, 0.1),
     (2, 92, 92, False, False, 0.1),
+    (3, 76, 76, False, True, 0.1),        # six units: the six-wave backward
+    (2, 70, 40, False, True, 0.0),        # five units
     (2, 128, 128, False, True, 0.1),
     (4, 5, 5, True, False, 0.1),
     (4, 20, 20, True, False, 0.0),
@@ -173,3 +175,24 @@ def test_self_attention_module_fused_projection_equals_separate_projections():
     y3 = att(xi, attn_mask=mask)
     HB.FUSE_QKV = True
     assert rel_err(y2.float(), y3.float()) < 1e-2
+
+
+def test_six_wave_backward_variant_matches_the_default(monkeypatch):
+    """The six-wave form of the backward (VLPET_ATTN_NW=6; measured slower, kept for A/B) is read once per process, so it is
+    exercised in a child process: same gradients as the default for a six-unit shape."""
+    import os, subprocess, sys
+    code = (
+        "import torch; from vlpet_amd.attention import short_attention\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "mk = lambda L: (torch.randn(3, L, 768, generator=g) * 0.5).cuda().bfloat16().requires_grad_(True)\n"
+        "q, k, v = mk(76), mk(76), mk(76); do = torch.randn(3, 76, 768, generator=g).cuda().bfloat16()\n"
+        "o = short_attention(q, k, v, 12, p=0.1, training=True, seed=11); o.backward(do)\n"
+        "print(' '.join(f'{float(t.grad.float().abs().sum()):.6e}' for t in (q, k, v)))\n")
+    outs = []
+    for nw in ("4", "6"):
+        env = dict(os.environ, VLPET_ATTN_NW=nw)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([float(x) for x in r.stdout.strip().splitlines()[-1].split()])
+    for a, b in zip(*outs):
+        assert abs(a - b) <= 1e-3 * abs(b)

@@ -133,7 +133,10 @@ struct AttnLds {
     __host__ __device__ static constexpr size_t fwd_wave_bytes(int Lkp) { return (size_t)Lkp * AT_ROW + (size_t)32 * AT_SROW; }
     static size_t fwd_bytes(int Lkp) { return (size_t)AT_FW * fwd_wave_bytes(Lkp); }
     static size_t bwd_bytes(int Lqp, int Lkp) {
-        return (size_t)2 * (Lqp + Lkp) * AT_ROW + (size_t)AT_NW * 32 * AT_SROW + (size_t)Lqp * 16;
+        return bwd_bytes_nw(Lqp, Lkp, AT_NW);
+    }
+    static size_t bwd_bytes_nw(int Lqp, int Lkp, int nw) {
+        return (size_t)2 * (Lqp + Lkp) * AT_ROW + (size_t)nw * 32 * AT_SROW + (size_t)Lqp * 16;
     }
 };
 
@@ -244,8 +247,10 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
 // Backward: a workgroup owns a (batch, head) pair (the four images are shared by its waves).  Work units: one per key tile
 // (phase K: dK, dV of the tile) and one per query block (phase Q: dQ of the block), handed out round-robin, so that at
 // S = 56 (two tiles, two blocks) each of the four waves has exactly one and nothing is computed twice.
-template <int OCC>
-__global__ __launch_bounds__(AT_NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
+// NW = waves per workgroup: 4, or 6 for sequences of 65-96 tokens (three key tiles + three query blocks = six units: one round
+// instead of a full one and a half-empty one; two 6-wave workgroups per CU = three waves per SIMD, the OCC = 3 register budget)
+template <int OCC, int NW = AT_NW>
+__global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -261,14 +266,14 @@ __global__ __launch_bounds__(AT_NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
     uint8_t* Ks = Ds + (size_t)Lqp * AT_ROW;
     uint8_t* Vs = Ks + (size_t)Lkp * AT_ROW;
     uint8_t* stg = Vs + (size_t)Lkp * AT_ROW + (size_t)wave * 32 * AT_SROW;
-    f32x4* rowv = reinterpret_cast<f32x4*>(Vs + (size_t)Lkp * AT_ROW + (size_t)AT_NW * 32 * AT_SROW);   // per query row: {lse2, delta, row key, -}
+    f32x4* rowv = reinterpret_cast<f32x4*>(Vs + (size_t)Lkp * AT_ROW + (size_t)NW * 32 * AT_SROW);   // per query row: {lse2, delta, row key, -}
 
     {
         // delta[i] = sum_d dO[i][d] O[i][d]: four threads per row, 128 rows at most = two rows per thread quad; loads first
         bf16x8 xo[2][2], xd[2][2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int idx = tid + c * AT_NW * 64, row = idx >> 2, part = idx & 3;
+            const int idx = tid + c * NW * 64, row = idx >> 2, part = idx & 3;
             const int rr = row < a.Lq ? row : a.Lq - 1;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -280,10 +285,10 @@ __global__ __launch_bounds__(AT_NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
         const __bf16* const srcs[4] = {a.q + qoff, a.dout + ooff, a.k + koff, a.v + koff};
         const int nr[4] = {a.Lq, a.Lq, a.Lk, a.Lk}, rp[4] = {Lqp, Lqp, Lkp, Lkp};
         const int64_t rss[4] = {rq, rs, rk, rk};
-        stage_images<4, 4>(imgs, srcs, nr, rp, rss, tid, AT_NW * 64);          // 128 rows x 8 pieces / 256 threads = 4 per image
+        stage_images<4, (NW == 6 ? 3 : 4)>(imgs, srcs, nr, rp, rss, tid, NW * 64);          // 128 rows x 8 pieces / 256 threads = 4 per image
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int idx = tid + c * AT_NW * 64, row = idx >> 2, part = idx & 3;
+            const int idx = tid + c * NW * 64, row = idx >> 2, part = idx & 3;
             float acc = 0.f;
 #pragma unroll
             for (int e = 0; e < 2; ++e)
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(AT_NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
     __syncthreads();
 
     const float sc2 = a.scale * LOG2E;
-    for (int un = wave; un < T + NQB; un += AT_NW) {
+    for (int un = wave; un < T + NQB; un += NW) {
         if (un < T) {
             // ============================================= phase K: key tile t (lane = key, registers = queries)
             const int t = un;
@@ -416,11 +421,26 @@ hipError_t launch_attn(const AttnArgs& a, bool bwd, hipStream_t stream) {
             default: return hipErrorInvalidValue;
         }
     }
+    const int Lqp = (a.Lq + 31) & ~31, Lkp = (a.Lk + 31) & ~31;
+    const int units = (Lqp >> 5) + (Lkp >> 5);
+    static const int occ_env = [] { const char* e = getenv("VLPET_ATTN_OCC"); return e ? atoi(e) : 0; }();
+    static const int nw_env = [] { const char* e = getenv("VLPET_ATTN_NW"); return e ? atoi(e) : 0; }();
+    // Five or six units (sequences of 65-96 tokens) on six waves, one unit each, two such workgroups per CU (three waves per SIMD on
+    // the 168-register build) instead of four waves taking a full round and a half-empty one: parity-green and SLOWER (238 vs 203 us
+    // at B = 416, S = 76; 97 vs 92 at B = 166, S = 92, profiles/r02_attnbench2_s4_six_waves.txt) -- the workgroup still stages, waits,
+    // computes and stores in sequence, and the longer compute phase was not what bounded it.  Kept behind VLPET_ATTN_NW=6 for A/B.
+    const size_t lds6 = AttnLds::bwd_bytes_nw(Lqp, Lkp, 6);
+    if (nw_env == 6 && (units == 5 || units == 6) && 2 * (lds6 + 512) <= (size_t)160 * 1024) {
+        auto k6 = attn_bwd_kernel<3, 6>;
+        hipError_t e6 = hipFuncSetAttribute(reinterpret_cast<const void*>(k6), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
+        if (e6 != hipSuccess) return e6;
+        hipLaunchKernelGGL(k6, dim3((unsigned)(a.B * a.H)), dim3(6 * 64), lds6, stream, a);
+        return hipGetLastError();
+    }
     const size_t lds = attn_lds_bytes(a.Lq, a.Lk, 1);
     // Three waves per SIMD (168 registers, one spilled) whenever three workgroups fit the CU's LDS -- sequences of at most 64
     // tokens: the memory phase of a pair then overlaps the compute phase of two others (142 -> 114 us at B = 500, S = 56);
     // longer sequences (two workgroups per CU by LDS either way) keep the 171-register build.  VLPET_ATTN_OCC = 2 | 3 forces one.
-    static const int occ_env = [] { const char* e = getenv("VLPET_ATTN_OCC"); return e ? atoi(e) : 0; }();
     const bool occ3 = occ_env == 3 || (occ_env != 2 && 3 * (lds + 512) <= (size_t)160 * 1024);
     const void* kern = occ3 ? reinterpret_cast<const void*>(attn_bwd_kernel<3>) : reinterpret_cast<const void*>(attn_bwd_kernel<2>);
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
