@@ -185,9 +185,24 @@ class T5Attention(nn.Module):
     def forward(self, hidden, bias, kv=None, task=None):
         B, Lq, _ = hidden.shape
         src = hidden if kv is None else kv
-        q, k, v = _linear(self.q, hidden), _linear(self.k, src), _linear(self.v, src)
-        if kv is not None and self.attn_value_parallel_adapter is not None:
-            v = self.attn_value_parallel_adapter(src, task, y=v)                          # K2
+        fused = (FUSE_RESIDUAL_GRAD and FUSE_NORM_GRAD and hidden.is_cuda and torch.is_grad_enabled() and src.requires_grad
+                 and not any(m.weight.requires_grad for m in (self.q, self.k, self.v)))
+        if fused:
+            # the projections that read one tensor are ONE autograd node whose dgrad GEMMs accumulate into one gradient
+            # (functional.linear_acc): q | k | v of a self-attention; k | v of a cross-attention, onto K2's parked d/dsrc
+            from ..functional import ResidualLink, linear_acc
+            if kv is None:
+                q, k, v = linear_acc(hidden, None, self.q, self.k, self.v)
+            else:
+                q = _linear(self.q, hidden)
+                kv_link = ResidualLink() if self.attn_value_parallel_adapter is not None else None
+                k, v = linear_acc(src, kv_link, self.k, self.v)
+                if self.attn_value_parallel_adapter is not None:
+                    v = self.attn_value_parallel_adapter(src, task, y=v, link=kv_link)    # K2
+        else:
+            q, k, v = _linear(self.q, hidden), _linear(self.k, src), _linear(self.v, src)
+            if kv is not None and self.attn_value_parallel_adapter is not None:
+                v = self.attn_value_parallel_adapter(src, task, y=v)                      # K2
         mask = None if bias is None else bias.to(q.dtype)
         out = F.scaled_dot_product_attention(self._shape(q, B), self._shape(k, B), self._shape(v, B), attn_mask=mask,
                                              dropout_p=self.dropout if self.training else 0.0, scale=1.0)
