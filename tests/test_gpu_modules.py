@@ -396,3 +396,41 @@ def test_t5_norm_gradient_handover(which, p_drop):
     for n in outs[1][1]:
         a, b = outs[0][1][n], outs[1][1][n]
         assert (a - b).abs().max().item() <= 2e-2 * max(b.abs().max().item(), 1e-6), n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("training", [False, True])
+def test_lora_base_dgrad_takes_over_the_delta_gradient(dtype, training):
+    """LoRA projection with a frozen weight and a trainable bias (the LoRA runs' parameter rule): K3's d/dx handed to the base
+    projection's dgrad GEMM (lora/controller.py LINK_DELTA_GRAD) against autograd's add -- output, d/dx, dA, dB, dbias."""
+    import vlpet_amd.lora.controller as LC
+    from vlpet_amd.lora import LoraConfig, LoRALinearController
+    torch.manual_seed(2)
+    d, r = 768, 64
+    lin = LoRALinearController(d, d, config=LoraConfig(lora_dim=r, lora_alpha=32, tasks=["vqa"]), bias=True).cuda()
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(d, d) * 0.03); lin.bias.copy_(torch.randn(d) * 0.1)
+        lin.lora_As["vqa"].copy_(torch.randn(r, d) * 0.05); lin.lora_Bs["vqa"].copy_(torch.randn(d, r) * 0.05)
+    lin.weight.requires_grad = False
+    lin.weight.data = lin.weight.data.to(dtype)
+    lin.train(training)
+    x0 = torch.randn(700, d, device="cuda").to(dtype)
+    dy = torch.randn(700, d, device="cuda").to(dtype)
+    outs = []
+    for on in (True, False):
+        LC.LINK_DELTA_GRAD = on
+        try:
+            for p in lin.parameters():
+                p.grad = None
+            torch.manual_seed(7)
+            x = x0.clone().requires_grad_(True)
+            out = lin(x, "vqa")
+            out.backward(dy)
+            outs.append((out.detach().float(), x.grad.float(), lin.lora_As["vqa"].grad.float().clone(),
+                         lin.lora_Bs["vqa"].grad.float().clone(), lin.bias.grad.float().clone()))
+        finally:
+            LC.LINK_DELTA_GRAD = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert (a - b).abs().max().item() <= tol * max(b.abs().max().item(), 1e-6)

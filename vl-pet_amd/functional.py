@@ -354,7 +354,11 @@ class _LinearTrainBiasFn(torch.autograd.Function):
     accumulate."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, link=None):
+        ctx.link = None
+        if link is not None and ctx.needs_input_grad[0]:
+            link.armed = True           # K3's delta on this projection (same x, downstream of this output) parks its d/dx
+            ctx.link = link
         ctx.save_for_backward(w, b)
         return F.linear(x, w, b if b.dtype == x.dtype else b.to(x.dtype))
 
@@ -366,7 +370,19 @@ class _LinearTrainBiasFn(torch.autograd.Function):
         dy2 = _flat(dy, n)
         if dy2.dtype != w.dtype:
             dy2 = dy2.to(w.dtype)
-        dx = (dy2 @ w).view(*dy.shape[:-1], w.shape[1]) if ctx.needs_input_grad[0] else None
+        dx = None
+        link, ctx.link = ctx.link, None
+        if ctx.needs_input_grad[0]:
+            base = None
+            if link is not None:
+                base, link.dx1, shared = link.dx1, None, link.shared
+                link.shared = False
+                if base is not None and (shared or base.dtype != w.dtype or not base.is_contiguous()):
+                    base = base.to(w.dtype).contiguous().clone() if shared else base.to(w.dtype).contiguous()
+            if base is not None:
+                dx = base.view(-1, w.shape[1]).addmm_(dy2, w).view(*dy.shape[:-1], w.shape[1])      # C += dY W in the GEMM epilogue
+            else:
+                dx = (dy2 @ w).view(*dy.shape[:-1], w.shape[1])
         db = None
         if ctx.needs_input_grad[2]:
             M = dy2.shape[0]
@@ -375,7 +391,7 @@ class _LinearTrainBiasFn(torch.autograd.Function):
             rc = lib.vlpet_colsum(dy2.data_ptr(), M, n, ws.data_ptr(), t.data_ptr(), _io_dtype(dy2), _stream())
             _lib.check(rc, "vlpet_colsum")
             db = _finish([(t, sink, b)])[0]
-        return dx, None, db
+        return dx, None, db, None
 
 
 def linear_train_bias_ok(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> bool:
@@ -385,8 +401,9 @@ def linear_train_bias_ok(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Ten
             and x.numel() > 0 and torch.is_grad_enabled())
 
 
-def linear_train_bias(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    return _LinearTrainBiasFn.apply(x, w, b)
+def linear_train_bias(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, link: Optional["ResidualLink"] = None) -> torch.Tensor:
+    """``link``: shared with the K3 delta applied on top of this projection (lora_delta(..., link=link))."""
+    return _LinearTrainBiasFn.apply(x, w, b, link)
 
 
 def linear_acc(x: torch.Tensor, link: Optional[ResidualLink], *mods):
@@ -632,7 +649,9 @@ class _LoraDeltaFn(torch.autograd.Function):
     ``keep`` given -> that explicit 0/1 mask.  ``want_mask``: also return the applied mask (parity tests)."""
 
     @staticmethod
-    def forward(ctx, x, base, pk, scaling, keep, p, seed, want_mask, lora_a, lora_b):
+    def forward(ctx, x, base, pk, scaling, keep, p, seed, want_mask, lora_a, lora_b, link=None):
+        # (`link`: armed by the frozen projection that produced `base` from the same x -- its dgrad GEMM takes over d/dx)
+        ctx.link = link if (link is not None and link.armed and ctx.needs_input_grad[0]) else None
         lib = _lib.load()
         _need_cuda(x, base)
         d = x.shape[-1]
@@ -693,13 +712,18 @@ class _LoraDeltaFn(torch.autograd.Function):
                 db.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, scaling, io, _stream()))
         ctx.act = None
         _lib.check(rc, "vlpet_lora_delta_bwd")
-        return (dx.view(shape), dy, None, None, None, None, None, None, *_finish([(da, s0, lora_a), (db, s1, lora_b)]))
+        gx = dx.view(shape)
+        if ctx.link is not None:
+            ctx.link.dx1, ctx.link.shared = gx, False
+            gx = None
+            ctx.link = None
+        return (gx, dy, None, None, None, None, None, None, *_finish([(da, s0, lora_a), (db, s1, lora_b)]), None)
 
 
 def lora_delta(x, base, lora_a, lora_b, pk: PackedPair, scaling: float, keep=None, p: float = 0.0, seed: int = 0,
-               return_mask: bool = False):
+               return_mask: bool = False, link: Optional["ResidualLink"] = None):
     """``base + scaling * (dropout(x, p) @ A^T @ B^T)``.  ``keep`` (uint8 [.., d]) overrides the generator's mask."""
     if x.numel() == 0:
         out = _empty_result(base, [lora_a, lora_b])
         return (out, torch.empty(x.shape, dtype=torch.uint8, device=x.device)) if return_mask else out
-    return _LoraDeltaFn.apply(x, base, pk, scaling, keep, p, seed, return_mask, lora_a, lora_b)
+    return _LoraDeltaFn.apply(x, base, pk, scaling, keep, p, seed, return_mask, lora_a, lora_b, link)

@@ -9,6 +9,9 @@ from .layers import LoRALayer
 from .. import functional as VF
 from ..tail import _draw_seed
 
+import os as _os
+LINK_DELTA_GRAD = _os.environ.get("VLPET_NO_LORA_LINK", "0") != "1"      # (VLPET_NO_LORA_LINK=1: autograd adds the two d/dx, for A/B)
+
 
 class LoRALinearController(nn.Linear, LoRALayer):
     """``F.linear(x, W, b) + (dropout(x) @ A[task].T @ B[task].T) * alpha/r``.
@@ -64,8 +67,11 @@ class LoRALinearController(nn.Linear, LoRALayer):
         w, b = self.weight, self.bias
         if w.dtype != x.dtype:
             w = w.to(x.dtype)
+        link = None
         if VF.linear_train_bias_ok(x, w, b):          # the bias trains (fp32 master) next to the frozen bf16 weight
-            base = VF.linear_train_bias(x, w, b)
+            if self.r > 0 and LINK_DELTA_GRAD and x.requires_grad:
+                link = VF.ResidualLink()              # K3's d/dx is taken over by this projection's dgrad GEMM (no autograd add)
+            base = VF.linear_train_bias(x, w, b, link)
         else:
             if b is not None and b.dtype != x.dtype:
                 b = b.to(x.dtype)
@@ -79,4 +85,4 @@ class LoRALinearController(nn.Linear, LoRALayer):
         # from torch's CPU generator so torch.manual_seed makes a run repeatable); the backward regenerates the mask
         p = float(self.lora_dropout_p) if self.training else 0.0
         seed = _draw_seed() if p > 0.0 else 0
-        return VF.lora_delta(x, base, A, B, pk, self.scaling, None, p, seed)
+        return VF.lora_delta(x, base, A, B, pk, self.scaling, None, p, seed, link=link)
