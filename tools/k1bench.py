@@ -53,16 +53,18 @@ def run(M, tag):
                 ts.append(e0.elapsed_time(e1) * 1e3)
             ts.sort()
             return ts[len(ts) // 2]
-        f, b, w, op = cold(fwd_save), cold(bwd_saved(1 | 4)), cold(bwd_saved(2 | 4)), cold(bwd_saved(3))
-        print(f"k1bench {tag:10s} M={M:6d} COLD: fwd+save {f:6.1f} us   bwd rows {b:6.1f} us   wgrad+fin (dh, dq cold too) {w:6.1f} us   "
-              f"whole op in one call (phases 3; VLPET_BWD3 applies) {op:6.1f} us (op frac {5 * d * M * 2 / op / 1e3 / 8000:.3f})", flush=True)
+        f, b, w, p1, p2, op = cold(fwd_save), cold(bwd_saved(1 | 4)), cold(bwd_saved(2 | 4)), cold(bwd_saved(1)), cold(bwd_saved(2)), cold(bwd_saved(3))
+        print(f"k1bench {tag:10s} M={M:6d} COLD: fwd+save {f:6.1f} us | previous split: rows {b:6.1f} + wgrad+fin (dh, dq cold too) {w:6.1f} us | "
+              f"default: pass 1 {p1:6.1f}, pass 2 + fin {p2:6.1f}, whole op in one call {op:6.1f} us (op frac {5 * d * M * 2 / op / 1e3 / 8000:.3f})", flush=True)
         return
     res = []
     for rep in range(2):
-        res.append((timeit(fwd_save, iters=60, warm=5), timeit(bwd_saved(1 | 4), iters=60, warm=5), timeit(bwd_saved(2 | 4), iters=60, warm=5)))
-    f, b, w = (min(x[i] for x in res) for i in range(3))
-    print(f"k1bench {tag:10s} M={M:6d}: fwd+save {f:6.1f} us   bwd rows {b:6.1f} us   wgrad+fin {w:6.1f} us   bwd op {b + w:6.1f} us "
-          f"(op frac {5 * d * M * 2 / (b + w) / 1e3 / 8000:.3f})", flush=True)
+        res.append((timeit(fwd_save, iters=60, warm=5), timeit(bwd_saved(1 | 4), iters=60, warm=5), timeit(bwd_saved(2 | 4), iters=60, warm=5),
+                    timeit(bwd_saved(1), iters=60, warm=5), timeit(bwd_saved(2), iters=60, warm=5), timeit(bwd_saved(3), iters=60, warm=5)))
+    f, b, w, p1, p2, op = (min(x[i] for x in res) for i in range(6))
+    frac = lambda t: 5 * d * M * 2 / t / 1e3 / 8000
+    print(f"k1bench {tag:10s} M={M:6d}: fwd+save {f:6.1f} us | previous split: rows {b:6.1f} + wgrad+fin {w:6.1f} = {b + w:6.1f} us (op frac {frac(b + w):.3f}) | "
+          f"default: pass 1 {p1:6.1f} + pass 2 + fin {p2:6.1f} us, whole op {op:6.1f} us (op frac {frac(op):.3f})", flush=True)
 
 if __name__ == "__main__":
     tag = sys.argv[1]

@@ -280,6 +280,9 @@ static BwdWs bwd_ws(int64_t M, int d, int tiles, bool gate, int io_dtype) {
         int rc3, gs3, ng3; int64_t rpc3;
         gate_bwd3_plan(M, d, io_dtype == VLPET_F32, &rc3, &rpc3, &gs3, &ng3);
         if (rc3 > chunks) chunks = rc3;
+        int rc4; int64_t rpc4;                          // ... and the column-parallel pass of pet_cols.hip
+        k1_cols_plan(M, d, &rc4, &rpc4);
+        if (rc4 > chunks) chunks = rc4;
     }
     w.partial = o;
     o += align256(wgrad_workspace_bytes(njobs, tiles, d, chunks));
@@ -341,7 +344,10 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     }
     // two-pass form (pass 1: dpre only; pass 2: input gradients + weight gradients from recomputed dh / dq) unless the
     // caller needs the input gradients right after phase 1 (phases bit 2: weight gradients on a side stream)
-    const bool two_pass = !(phases & 4) && pet_gate_bwd3_applies(b);
+    // bf16, r <= 96: pass 1 (dpre) + the column-parallel pass of pet_cols.hip (input gradients + the four weight gradients from
+    // one read of dy, x1, x2) -- unless the caller needs the input gradients right after phase 1
+    const bool cols4 = !(phases & 4) && k1_cols_applies(b, io_dtype == VLPET_F32);
+    const bool two_pass = cols4 || (!(phases & 4) && pet_gate_bwd3_applies(b));
     const bool rows2 = !two_pass && pet_gate_bwd2_applies(b);
     int gs3 = 0, ng3 = 0;
     if (phases & 1) {
@@ -359,7 +365,8 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
 
     WgradArgs g{};
     g.M = M; g.RT = tiles; g.row_chunks = w.row_chunks; g.rows_per_chunk = w.rows_per_chunk;
-    if (two_pass) gate_bwd3_plan(M, d, io_dtype == VLPET_F32, &g.row_chunks, &g.rows_per_chunk, &gs3, &ng3);
+    if (cols4) k1_cols_plan(M, d, &g.row_chunks, &g.rows_per_chunk);
+    else if (two_pass) gate_bwd3_plan(M, d, io_dtype == VLPET_F32, &g.row_chunks, &g.rows_per_chunk, &gs3, &ng3);
     g.partial = reinterpret_cast<float*>(ws + w.partial);
     const int ldp = 32 * tiles;
     auto job = [&](int i, const void* P, const void* X, bool dropped, float scale, float* out, int ldo,
@@ -380,6 +387,20 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
         job(2, b.dp_g, xg, false, 1.f, dwgd, d, 0, rg, nullptr, dbgd);
         job(3, b.z_g, b.dq, false, 1.f, dwgu, rg, 1, rg, dbgu, nullptr);
         g.njobs = 4;
+    }
+    if (cols4) {
+        ColzArgs c{};
+        c.dy = dy; c.x1 = xg; c.x2 = res; c.dxin = dx1_in;
+        c.z_a = b.z_a; c.z_g = b.z_g; c.dp_a = b.dp_a; c.dp_g = b.dp_g;
+        c.dx1 = dxg; c.dx2 = dxa;
+        c.pk_a = b.pk_a; c.pk_g = b.pk_g;
+        c.M = M; c.d = d; c.s2 = s2; c.sd = sd; c.gs = gs; c.flags = flags;
+        c.row_chunks = g.row_chunks; c.rows_per_chunk = g.rows_per_chunk;
+        const WgradLayout L = wgrad_layout(g);
+        for (int j = 0; j < 4; ++j) c.part[j] = g.partial + L.off[j];
+        hipError_t e = launch_k1_cols(c, tiles, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+        return herr(launch_wgrad_finalize(g, (hipStream_t)stream));
     }
     if (two_pass) {                                     // (dx1 is an output of pass 2 there)
         hipError_t e = launch_pet_gate_cols(b, g, gs3, ng3, io_dtype == VLPET_F32, (hipStream_t)stream);

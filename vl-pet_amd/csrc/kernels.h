@@ -137,6 +137,26 @@ void gate_bwd3_plan(int64_t M, int d, int io_fp32, int* row_chunks, int64_t* row
 hipError_t launch_pet_gate_dz(const PetBwdArgs& a, int io_fp32, hipStream_t stream);
 hipError_t launch_pet_gate_cols(const PetBwdArgs& a, const WgradArgs& g, int GS, int NG, int io_fp32, hipStream_t stream);
 
+// Column-parallel pass 2 of the gated K1 backward, round-3 form (pet_cols.hip): weights resident in registers, row tensors streamed
+// once; bf16, saved activations, r <= 96.  Partials in the workspace layout of the weight-gradient kernels (wgrad_layout).
+struct ColzArgs {
+    const void* dy; const void* x1; const void* x2;      // [M, d] bf16
+    const void* dxin;                                    // optional [M, d]: added to dx1
+    const void* z_a; const void* z_g;                    // the forward's saved z          [M, 32*RT]
+    const void* dp_a; const void* dp_g;                  // pass 1's dpre                  [M, 32*RT]
+    void* dx1; void* dx2;
+    const uint8_t* pk_a; const uint8_t* pk_g;
+    int64_t M;
+    int d;
+    float s2, sd, gs;
+    int flags;
+    int row_chunks; int64_t rows_per_chunk;              // rows_per_chunk % 32 == 0
+    float* part[4];                                      // per job (0 dWd, 1 dWu, 2 dWgd, 3 dWgu): [RC][32RT][d] tiles, [RC][d] column sums of X, [RC][32RT] of P
+};
+void k1_cols_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk);
+bool k1_cols_applies(const PetBwdArgs& a, int io_fp32);
+hipError_t launch_k1_cols(const ColzArgs& c, int RT, hipStream_t stream);
+
 // K4: out = LN(feats . W^T + b) * gamma + beta (+ R); optionally stores xhat and rstd for the backward
 struct VisprojArgs {
     const void* feats;      // [M, F]  IO dtype
