@@ -41,7 +41,6 @@ template <int RT> struct ColzGeo {
     static constexpr int PT_B = 32 * PB;                // one bottleneck tile
     static constexpr int X_B = 6 * 4096;                // dy, x2, x1: two pair tiles [32 rows x 128 B] each
     static constexpr int STG_B = X_B + 4 * PT_B;        // + z_a, z_g, dpre_a, dpre_g
-    static constexpr int NI = 6 + 2 * RT;               // global_load_lds instructions per wave and stage
     static constexpr int DQ_B = 2 * 4096;
     static constexpr int BIAS_B = 2 * 128 * 4;
     static constexpr size_t lds(int nstg) { return (size_t)nstg * STG_B + DQ_B + BIAS_B; }
@@ -58,9 +57,30 @@ template <int OFF> __device__ __forceinline__ void lds_read16(u32x4& o, uint32_t
 template <int OFF> __device__ __forceinline__ void lds_write16(uint32_t addr, const u32x4& v) {
     asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");
 }
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+template <int OFF> __device__ __forceinline__ void lds_read8(u32x2& o, uint32_t addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(o) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void lds_write8(uint32_t addr, const u32x2& v) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
 __device__ __forceinline__ void lgkm_fence(u32x4& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) :: "memory"); }
 __device__ __forceinline__ void lgkm_tie(u32x4& a) { asm volatile("" : "+v"(a) :: "memory"); }
 __device__ __forceinline__ bf16x8 as_bf(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+// transpose read with separate addresses for the two 4-row halves (their rows carry different swizzles)
+template <int OFF> __device__ __forceinline__ void tr_read2(TrOp& o, uint32_t alo, uint32_t ahi) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(o.lo) : "v"(alo), "n"(OFF) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(o.hi) : "v"(ahi), "n"(OFF) : "memory");
+}
+// LDS images (all swizzles are applied on the SOURCE side of the global_load_lds: slot = 16-byte unit of a row):
+//   row tiles [32 rows x 128 B]: slot ^= fsw(row), fsw = (q & 1) << 2 | q >> 1 with q = (row >> 1) & 7 -- bit 2 alternates every two
+//     rows (the four rows of a transpose read fall into four 64-byte bank windows), the other two bits make the 16 rows of a
+//     ds_read_b128 lane group distinct (the row-per-lane reads of dy, x2, dh);
+//   bottleneck tiles [32 rows x 64*RT B]: slot ^= (row >> 2) & 3 -- the four rows of a transpose read share it (their native
+//     conflict-free pattern is kept), the rows 4 apart of a ds_read_b128 lane group (B fragments, lane = row) do not.
+__device__ __forceinline__ int fsw(int row) { const int q = (row >> 1) & 7; return ((q & 1) << 2) | (q >> 1); }
+__device__ __forceinline__ int gsw(int row) { return (row >> 2) & 3; }
 
 // at most n vector-memory operations of this wave still in flight (n is wave-uniform)
 __device__ __forceinline__ void vm_wait(int n) {
@@ -90,12 +110,14 @@ __device__ __forceinline__ float sigm(float x) {
 }
 
 template <int RT, int NSTG, bool ADD, bool HAS_IN>
-__global__ __launch_bounds__(256, 1) void k1_cols_kernel(ColzArgs a) {
+__global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
     using GEO = ColzGeo<RT>;
-    constexpr int KT = GEO::KT, PB = GEO::PB, PT_B = GEO::PT_B, X_B = GEO::X_B, STG_B = GEO::STG_B, NI = GEO::NI;
+    constexpr int KT = GEO::KT, PB = GEO::PB, PT_B = GEO::PT_B, X_B = GEO::X_B, STG_B = GEO::STG_B;
     constexpr int DQ_OFF = NSTG * STG_B, BIAS_OFF = DQ_OFF + GEO::DQ_B;
     constexpr int PR = 32 * RT;
-    constexpr int NL = HAS_IN ? 2 : 0;                  // register loads (dx1_in) per step
+    constexpr int NL = HAS_IN ? 2 : 0;                  // register loads (dx1_in) per step of a role-D wave
+    constexpr int NW = 3 + RT;                          // global_load_lds instructions per wave and stage
+    constexpr int GRP = RT == 1 ? 2 : 3;                // B fragments requested per batch of a projection
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     // ---- which (column block, row chunk): the column blocks of a row chunk share an XCD (they re-read the same bottleneck rows)
@@ -104,7 +126,8 @@ __global__ __launch_bounds__(256, 1) void k1_cols_kernel(ColzArgs a) {
     const int cb = bq % NCB;
     const int rc = (bq / NCB) * 8 + (blockIdx.x & 7);
     if (rc >= a.row_chunks) return;
-    const int tid = threadIdx.x, lane = tid & 63, wc = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 2, wc = wave & 3;          // waves w and w + 4 share a SIMD: the up side and the down side of a column quarter
     const int pp = wc >> 1, nt = wc & 1;
     const int m = lane & 31, h = lane >> 5;
     const int64_t ld2 = (int64_t)d * 2;
@@ -113,50 +136,54 @@ __global__ __launch_bounds__(256, 1) void k1_cols_kernel(ColzArgs a) {
     int64_t r_end = r_begin + a.rows_per_chunk;
     if (r_end > a.M) r_end = a.M;
     const int nsteps = r_end > r_begin ? (int)((r_end - r_begin + 31) >> 5) : 0;
-    const uint8_t* DY = reinterpret_cast<const uint8_t*>(a.dy);
-    const uint8_t* X1 = reinterpret_cast<const uint8_t*>(a.x1);
-    const uint8_t* X2 = reinterpret_cast<const uint8_t*>(a.x2);
-    const uint8_t* DXIN = reinterpret_cast<const uint8_t*>(a.dxin);
 
-    // ---- resident weights: A fragments of this wave's 32 columns.  Wu / Wgu from the "up" packs (slot = W[f][16ks + 8hh + j]),
-    // Wd / Wgd transposed from the "down_t" packs (slot = W[16ks + 8hh + j][f]).  MFMA row i stands for column c0 + 16*((i>>2)&1)
-    // + 4*(i>>3) + (i&3), so that a lane (m, h) ends with the 16 CONTIGUOUS columns c0 + 16h .. +15 of row m; in the packs' own
-    // numbering (tests/packing_spec.py f_of4) that row is lane (i&3) | (nt << 2) | (i>>3 << 3) of n-tile v = (i>>2)&1.
-    bf16x8 wU[KT], wGU[KT], wD[KT], wGD[KT];
-    {
-        const PackGeom pg = pack_geom(RT, d, 1);
-        const int i = m, v = (i >> 2) & 1, ip = (i & 3) | (nt << 2) | ((i >> 3) << 3);
-        const int64_t off = (int64_t)(2 * cb + pp) * (4 * RT * 1024) + (int64_t)(v * KT) * 1024 + (ip + 32 * h) * 16;
-#pragma unroll
-        for (int ks = 0; ks < KT; ++ks) {
-            wU[ks] = *reinterpret_cast<const bf16x8*>(a.pk_a + pg.pack_bytes + off + ks * 1024);
-            wGU[ks] = *reinterpret_cast<const bf16x8*>(a.pk_g + pg.pack_bytes + off + ks * 1024);
-            wD[ks] = *reinterpret_cast<const bf16x8*>(a.pk_a + 3 * pg.pack_bytes + off + ks * 1024);
-            wGD[ks] = *reinterpret_cast<const bf16x8*>(a.pk_g + 3 * pg.pack_bytes + off + ks * 1024);
-        }
-        // up-side biases of the workgroup's 128 columns -> LDS (fp32)
+    // up-side biases of the workgroup's 128 columns -> LDS (fp32)
+    const PackGeom pg = pack_geom(RT, d, 1);
+    if (tid < 256) {
         float* sbias = reinterpret_cast<float*>(smem + BIAS_OFF);
         const uint8_t* pk = tid < 128 ? a.pk_a : a.pk_g;
         sbias[tid] = reinterpret_cast<const float*>(pk + pg.bias_off)[PR + 128 * cb + (tid & 127)];
     }
-
-    // ---- per-lane source geometry of the stage pieces: wave w loads rows 8w .. 8w+7 of both pair tiles of the three row
-    // tensors (6 instructions) and 2*RT of the 8*RT one-KiB pieces of the bottleneck tiles
-    const int xrow = 8 * wc + (lane >> 3);
-    const uint32_t xcol = (uint32_t)((128 * cb) * 2 + (((lane & 7) ^ (4 * ((xrow >> 1) & 1))) * 16));
-    const uint32_t xoff = (uint32_t)xrow * (uint32_t)ld2 + xcol;          // (32 rows x d*2 bytes: far below 4 GiB)
-    const uint32_t xdst = (uint32_t)(wc * 1024);
-    const uint8_t* pbase[2 * RT]; uint32_t poff[2 * RT]; uint32_t pdst[2 * RT];
+    // resident weights: A fragments of this wave's 32 columns.  Role U: Wu / Wgu from the "up" packs (slot = W[f][16ks + 8hh + j]);
+    // role D: Wd / Wgd transposed from the "down_t" packs (slot = W[16ks + 8hh + j][f]).  MFMA row i stands for column c0 +
+    // 16*((i>>2)&1) + 4*(i>>3) + (i&3), so that a lane (m, h) ends with the 16 CONTIGUOUS columns c0 + 16h .. +15 of row m; in the
+    // packs' own numbering (tests/packing_spec.py f_of4) that row is lane (i&3) | (nt << 2) | (i>>3 << 3) of n-tile v = (i>>2)&1.
+    bf16x8 wA[KT], wG[KT];
+    {
+        const int i = m, v = (i >> 2) & 1, ip = (i & 3) | (nt << 2) | ((i >> 3) << 3);
+        const int64_t off = (int64_t)(role == 0 ? 1 : 3) * pg.pack_bytes + (int64_t)(2 * cb + pp) * (4 * RT * 1024)
+                          + (int64_t)(v * KT) * 1024 + (ip + 32 * h) * 16;
 #pragma unroll
-    for (int j = 0; j < 2 * RT; ++j) {
-        const int q = wc + 4 * j, t = q / KT, piece = q % KT;            // wave-uniform
+        for (int ks = 0; ks < KT; ++ks) {
+            wA[ks] = *reinterpret_cast<const bf16x8*>(a.pk_a + off + ks * 1024);
+            wG[ks] = *reinterpret_cast<const bf16x8*>(a.pk_g + off + ks * 1024);
+        }
+    }
+
+    // ---- the stage pieces (1 KiB each) of this wave: pieces q = wave, wave + 8, wave + 16 are 8 rows of a pair tile of a row
+    // tensor (tensor q / 8, pair (q / 4) % 2, rows 8 (q % 4) ..), pieces q' = wave + 8 j < 8 RT belong to the bottleneck tiles
+    // (tensor q' / KT, piece q' % KT of the 32 contiguous rows)
+    const uint8_t* xbase[3]; uint32_t xdst[3];
+    const int xrow = 8 * (wave & 3) + (lane >> 3);
+    const uint32_t xoff = (uint32_t)xrow * (uint32_t)ld2
+                        + (uint32_t)((128 * cb + 64 * (wave >> 2)) * 2 + (((lane & 7) ^ fsw(xrow)) * 16));
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        xbase[t] = reinterpret_cast<const uint8_t*>(t == 0 ? a.dy : t == 1 ? a.x2 : a.x1);
+        xdst[t] = (uint32_t)((t * 2 + (wave >> 2)) * 4096 + (wave & 3) * 1024);
+    }
+    const uint8_t* pbase[RT]; uint32_t pdst[RT], poff[RT]; int prow[RT];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+        const int q = wave + 8 * j, t = q / KT, piece = q % KT;
+        const int sig = piece * 64 + lane;                                // LDS slot of this lane inside the tile
+        prow[j] = sig / (PB / 16);
         pbase[j] = reinterpret_cast<const uint8_t*>(t == 0 ? a.z_a : t == 1 ? a.z_g : t == 2 ? a.dp_a : a.dp_g);
-        poff[j] = (uint32_t)(piece * 1024 + lane * 16);
+        poff[j] = (uint32_t)(prow[j] * PB + ((sig % (PB / 16)) ^ gsw(prow[j])) * 16);
         pdst[j] = (uint32_t)(X_B + t * PT_B + piece * 1024);
     }
-    // a wave-uniform pointer the compiler must treat as a fresh scalar: keeps "scalar base + 32-bit lane offset" addressing (with
-    // the lane offsets visible as loop invariants hipcc hoists one 64-bit per-lane address per stream out of the loop -- 18
-    // registers it then spills and reloads in front of every request)
+    // a wave-uniform pointer the compiler must treat as a fresh scalar: keeps the per-lane part of an address a 32-bit loop
+    // invariant (otherwise hipcc hoists one 64-bit per-lane address per stream out of the loop and spills them)
     auto sbase = [](const uint8_t* p) {
         const uint64_t u = reinterpret_cast<uint64_t>(p);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
@@ -165,251 +192,283 @@ __global__ __launch_bounds__(256, 1) void k1_cols_kernel(ColzArgs a) {
     auto issue = [&](int s) {
         const int64_t rb = r_begin + 32 * (int64_t)s;
         uint8_t* st = smem + (size_t)(s % NSTG) * STG_B;
-        if (rb + 32 <= r_end) {                                           // scalar base + 32-bit lane offset
-            const int64_t ro = rb * ld2;
-            const uint8_t* b0 = sbase(DY + ro); const uint8_t* b1 = sbase(X2 + ro); const uint8_t* b2 = sbase(X1 + ro);
-            glds16_row(b0 + xoff, st + xdst);         glds16_row(b0 + 128 + xoff, st + xdst + 4096);
-            glds16_row(b1 + xoff, st + xdst + 8192);  glds16_row(b1 + 128 + xoff, st + xdst + 12288);
-            glds16_row(b2 + xoff, st + xdst + 16384); glds16_row(b2 + 128 + xoff, st + xdst + 20480);
+        if (rb + 32 <= r_end) {
 #pragma unroll
-            for (int j = 0; j < 2 * RT; ++j) glds16(sbase(pbase[j] + rb * PB) + poff[j], st + pdst[j]);
-        } else {                                                          // last step of the chunk: rows past the end re-read the last row
-            int64_t row = rb + xrow;
-            if (row >= r_end) row = r_end - 1;
-            const int64_t ro = row * ld2 + (int64_t)xcol;
-            glds16_row(DY + ro, st + xdst);         glds16_row(DY + ro + 128, st + xdst + 4096);
-            glds16_row(X2 + ro, st + xdst + 8192);  glds16_row(X2 + ro + 128, st + xdst + 12288);
-            glds16_row(X1 + ro, st + xdst + 16384); glds16_row(X1 + ro + 128, st + xdst + 20480);
+            for (int t = 0; t < 3; ++t) glds16_row(sbase(xbase[t] + rb * ld2) + xoff, st + xdst[t]);
 #pragma unroll
-            for (int j = 0; j < 2 * RT; ++j) {
-                int64_t prow = rb + (int)(poff[j] / PB);
-                if (prow >= r_end) prow = r_end - 1;
-                glds16(pbase[j] + prow * PB + (int)(poff[j] % PB), st + pdst[j]);
-            }
+            for (int j = 0; j < RT; ++j) glds16(sbase(pbase[j] + rb * PB) + poff[j], st + pdst[j]);
+        } else {                                        // last step of the chunk: rows past the end re-read the last row
+            const int last = (int)(r_end - rb) - 1;
+            const uint32_t xo = xoff - (uint32_t)(xrow > last ? xrow - last : 0) * (uint32_t)ld2;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) glds16_row(sbase(xbase[t] + rb * ld2) + xo, st + xdst[t]);
+#pragma unroll
+            for (int j = 0; j < RT; ++j)
+                glds16(sbase(pbase[j] + rb * PB) + poff[j] - (uint32_t)(prow[j] > last ? prow[j] - last : 0) * PB, st + pdst[j]);
         }
     };
 
     // ---- per-lane LDS byte addresses (relative to the stage base)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
-    uint32_t a_xtr, a_xcl, a_ptr, a_pbf;
+    uint32_t a_xtr[2], a_ptr[2], a_xcl[2], a_pbf[2];
     {
         const int g4 = lane >> 4, sl = lane & 15;
-        const int trow = 8 * (g4 >> 1) + (sl >> 2), tbit = (trow >> 1) & 1, lp = 32 * (g4 & 1) + 8 * (sl & 3);
-        a_xtr = (uint32_t)(pp * 4096 + trow * 128 + 64 * (nt ^ tbit) + lp);                      // transpose reads of a row tile
-        a_ptr = (uint32_t)(X_B + trow * PB + lp);                                                //   ... of a bottleneck tile (+ 64 ct)
-        a_xcl = (uint32_t)(pp * 4096 + m * 128 + (((4 * nt + 2 * h) ^ (4 * ((m >> 1) & 1))) * 16));  // the lane's 16 columns of row m (32 B)
-        a_pbf = (uint32_t)(X_B + m * PB + 16 * h);                                               // B fragment of row m (+ 32 ks)
-    }
-    const uint32_t a_bias = lds0 + (uint32_t)(BIAS_OFF + (32 * wc + 16 * h) * 4);
-    const uint32_t a_dqtr = lds0 + (uint32_t)DQ_OFF + a_xtr, a_dqcl = lds0 + (uint32_t)DQ_OFF + a_xcl;
-
-    f32x16 accU[RT], accGU[RT], accD[RT], accGD[RT];   // this wave's [32*RT x 32 columns] slices of dWu, dWgu, dWd, dWgd
-    // column sums by ones-row MFMAs: slot k lives in MFMA row (k & 3) + 8 * (k >> 2) = register k of the lanes h = 0.
-    // slots 0 / 1: dh / dq;  slots 2 + ct / 2 + RT + ct: dpre_a / dpre_g (one wave per row chunk)
-    f32x16 sx = zero16();
+        const int trow = 8 * (g4 >> 1) + (sl >> 2);                       // first row of this lane's transpose reads (second: + 4)
+        const int tslot = 2 * (g4 & 1) + ((sl & 3) >> 1), thalf = 8 * (sl & 1);      // 8 bytes at slot 4 nt / 4 ct + tslot
 #pragma unroll
-    for (int ct = 0; ct < RT; ++ct) { accU[ct] = zero16(); accGU[ct] = zero16(); accD[ct] = zero16(); accGD[ct] = zero16(); }
+        for (int hi = 0; hi < 2; ++hi) {
+            const int r = trow + 4 * hi;
+            a_xtr[hi] = (uint32_t)(pp * 4096 + r * 128 + (((4 * nt + tslot) ^ fsw(r)) * 16) + thalf);   // row tiles
+            a_ptr[hi] = (uint32_t)(X_B + r * PB + ((tslot ^ gsw(r)) * 16) + thalf);                      // bottleneck tiles (+ 64 ct)
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            a_xcl[k] = (uint32_t)(pp * 4096 + m * 128 + (((4 * nt + 2 * h + k) ^ fsw(m)) * 16));        // columns 8k .. 8k+7 of the lane's 16 (row m)
+            a_pbf[k] = (uint32_t)(X_B + m * PB + (((2 * k + h) ^ gsw(m)) * 16));                         // B fragment of row m, k-step 2j + k (+ 64 j)
+        }
+    }
     auto ones_row = [&](int k) {          // A fragment whose row (slot k) is all ones: D[row][n] = column sums of the B operand
-        const uint32_t w = (m == (k & 3) + 8 * (k >> 2)) ? 0x3f803f80u : 0u;
+        int mm = m;
+        asm volatile("" : "+v"(mm));      // (rebuilt at every use: as loop invariants the fragments cost four registers per slot)
+        const uint32_t w = (mm == (k & 3) + 8 * (k >> 2)) ? 0x3f803f80u : 0u;
         const u32x4 v = {w, w, w, w};
         return __builtin_bit_cast(bf16x8, v);
     };
-    const bool want_csp = cb == 0 && wc == 0;            // wave-uniform: the down-side bias sums, once per row chunk
-    const float s2 = a.s2, sd = a.sd;
-
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // weights in registers, biases in LDS
-    if (nsteps > 0) issue(0);
-    if (nsteps > 1) issue(1);
-
+    const int RC = a.row_chunks;
+    const int col = c0 + m;
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     using X2O = std::integral_constant<int, 8192>; using X1O = std::integral_constant<int, 16384>;
 
-#pragma unroll 1
-    for (int s = 0; s < nsteps; ++s) {
-        const int64_t rb = r_begin + 32 * (int64_t)s;
-        const int valid = (int)(r_end - rb) < 32 ? (int)(r_end - rb) : 32;
-        const bool tail = valid < 32;
+    // this row chunk's accumulators: role U: dWu, dWgu;  role D: dWd, dWgd  ([32*RT x 32 columns] each), and the column sums by
+    // ones-row MFMAs (slot k = MFMA row (k & 3) + 8 (k >> 2) = register k of the lanes h = 0): U: slots 0 / 1 = dh / dq;
+    // slots 2 + ct / 2 + RT + ct = dpre_a / dpre_g (one U wave per row chunk)
+    f32x16 accA[RT], accG[RT], sx = zero16();
+#pragma unroll
+    for (int ct = 0; ct < RT; ++ct) { accA[ct] = zero16(); accG[ct] = zero16(); }
+
+    // ---- the step frame shared by the roles: wait for the own pieces of stage s, barrier, request stage s + 2, zero the
+    // bottleneck rows past the end in the last step.  `extra` = this wave's OTHER vector-memory operations younger than its
+    // requests of stage s (role D: the stores of step s - 1 and the dx1_in loads of step s).
+    auto step_top = [&](int s, int extra) {
         const bool has1 = s + 1 < nsteps, has2 = s + 2 < nsteps;
-        const uint32_t sb = lds0 + (uint32_t)((s % NSTG) * STG_B);
-        const bool row_ok = m < valid;
-        // byte offset of this lane's 16 columns of its row, relative to row rb (rows past the end: the last row)
-        const uint32_t rowoff = (uint32_t)(row_ok ? m : valid - 1) * (uint32_t)ld2 + (uint32_t)((c0 + 16 * h) * 2);
-        // Order of this wave's vector-memory operations: ... G(s+1) S(s-1) | L(s) [wait for G(s)] G(s+2) ... [wait for L(s)] ... S(s)
-        // (G = the stage requests, L = the dx1_in register loads, S = the four output stores), all counted by hand.
-        u32x4 din0 = {0u, 0u, 0u, 0u}, din1 = {0u, 0u, 0u, 0u};
-        if constexpr (HAS_IN) {                                           // the incoming dx1 rows of this step, straight to registers
-            const uint8_t* bp = sbase(DXIN + rb * ld2);
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(din0) : "v"(rowoff), "s"(bp) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(din1) : "v"(rowoff), "s"(bp) : "memory");
-        }
-        vm_wait((has1 ? NI : 0) + (s > 0 ? 4 : 0) + NL);
+        vm_wait((has1 ? NW : 0) + extra);
         __builtin_amdgcn_s_barrier();                                     // stage s has landed for every wave; stage s - 1 is free
         if (has2) issue(s + 2);
-        if (tail) {                                                       // zero the bottleneck rows past the end (their products must vanish)
+        const int valid = (int)(r_end - (r_begin + 32 * (int64_t)s));
+        if (valid < 32) {                                                 // zero the bottleneck rows past the end (their products must vanish)
             const u32x4 z = {0u, 0u, 0u, 0u};
             uint8_t* pt = smem + (size_t)(s % NSTG) * STG_B + X_B;
-            for (int q = tid; q < 4 * 32 * (PB / 16); q += 256) {
+            for (int q = tid; q < 4 * 32 * (PB / 16); q += 512) {
                 const int rr = (q / (PB / 16)) & 31;
                 if (rr >= valid) *reinterpret_cast<u32x4*>(pt + (size_t)q * 16) = z;
             }
             __syncthreads();
         }
-
-        // projection of one chain: acc += W (resident A fragments) . B fragments of bottleneck tile T (lane = row)
-        auto project = [&](auto TC, const bf16x8* w, f32x16& acc) {
-            constexpr int T = decltype(TC)::value;
-            u32x4 bf[KT];
-            sfor<KT>([&](auto K) { lds_read16<T * PT_B + 32 * K.value>(bf[K.value], sb + a_pbf); });
+    };
+    // projection: acc += W (resident A fragments) . B fragments of bottleneck tile T (lane = row), GRP k-steps per batch
+    auto project = [&](uint32_t sb, auto TC, const bf16x8* w, f32x16& acc) {
+        constexpr int T = decltype(TC)::value;
+        sfor<KT / GRP>([&](auto G) {
+            u32x4 bf[GRP];
+            sfor<GRP>([&](auto K) {
+                constexpr int ks = G.value * GRP + K.value;
+                lds_read16<T * PT_B + 64 * (ks >> 1)>(bf[K.value], sb + a_pbf[ks & 1]);
+            });
             lgkm_fence(bf[0]);
 #pragma unroll
-            for (int k = 0; k < KT; ++k) { if (k) lgkm_tie(bf[k]); acc = mfma32(w[k], as_bf(bf[k]), acc); }
-        };
-        auto load_bias = [&](auto OC, f32x16& acc) {
-            u32x4 bb[4];
-            sfor<4>([&](auto Q) { lds_read16<decltype(OC)::value + 16 * Q.value>(bb[Q.value], a_bias); });
-            lgkm_fence(bb[0]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q) lgkm_tie(bb[q]);
-#pragma unroll
-                for (int w = 0; w < 4; ++w) acc[4 * q + w] = __uint_as_float(bb[q][w]);
-            }
-        };
-        // weight-gradient products of one job: acc[ct] += P^T (tile TP) . X (row tile at xaddr + XO), both 16-row k-steps
-        auto wg_products = [&](auto TPC, auto XOC, uint32_t xaddr, f32x16* acc, int srow) {
-            constexpr int TP = decltype(TPC)::value, XO = decltype(XOC)::value;
-            TrOp bx[2], ap[2][RT];
-            sfor<2>([&](auto KS) {
-                constexpr int ks = KS.value;
-                tr_read<XO + ks * 16 * 128, XO + (ks * 16 + 4) * 128>(bx[ks], xaddr);
-                sfor<RT>([&](auto CT) {
-                    tr_read<TP * PT_B + 64 * CT.value + ks * 16 * PB, TP * PT_B + 64 * CT.value + (ks * 16 + 4) * PB>(ap[ks][CT.value], sb + a_ptr);
-                });
-            });
-            tr_fence(bx[0]);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (ks) tr_tie(bx[ks]);
-                const bf16x8 vx = tr_val(bx[ks]);
-                if (srow >= 0) sx = mfma32(ones_row(srow), vx, sx);
-#pragma unroll
-                for (int ct = 0; ct < RT; ++ct) { tr_tie(ap[ks][ct]); acc[ct] = mfma32(tr_val(ap[ks][ct]), vx, acc[ct]); }
-            }
-        };
-
-        // ---- both up projections of the step's rows (accumulators start at the biases)
-        f32x16 aA, aG;
-        load_bias(I0{}, aA);
-        project(I0{}, wU, aA);
-        load_bias(std::integral_constant<int, 512>{}, aG);
-        project(I1{}, wGU, aG);
-        // ---- dh, dq (this lane: 16 columns of its row) -> the tiles the row contractions read; dh replaces dy in place
-        u32x4 dhp[2];
-        const float gsr = row_ok ? a.gs : 0.f;                            // rows past the end: dh = dq = 0
-        sfor<2>([&](auto C) {
-            constexpr int c = C.value;
-            u32x4 dyv, x2v;
-            lds_read16<16 * c>(dyv, sb + a_xcl);
-            lds_read16<8192 + 16 * c>(x2v, sb + a_xcl);
-            lgkm_fence(dyv); lgkm_tie(x2v);
-            float dh[8], dq[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = 8 * c + j;
-                const float gt = sigm(aG[e]);
-                const float dyp = gsr * bf_at(dyv, j);
-                if constexpr (ADD) {
-                    dh[j] = dyp;
-                    dq[j] = dyp * gt * (1.0f - gt);
-                } else {
-                    const float hv = s2 * bf_at(x2v, j) + sd * aA[e];
-                    dh[j] = dyp * gt;
-                    dq[j] = dh[j] * hv * (1.0f - gt);
-                }
-            }
-            dhp[c] = pack8(dh);
-            const u32x4 dqp = pack8(dq);
-            lds_write16<16 * c>(sb + a_xcl, dhp[c]);
-            lds_write16<16 * c>(a_dqcl, dqp);
+            for (int k = 0; k < GRP; ++k) { if (k) lgkm_tie(bf[k]); acc = mfma32(w[G.value * GRP + k], as_bf(bf[k]), acc); }
         });
-        // ---- down side: dWd += dpre_a^T x2, dWgd += dpre_g^T x1 (+ their bias sums in one wave per row chunk), both projections
-        wg_products(I2{}, X2O{}, sb + a_xtr, accD, -1);
-        wg_products(I3{}, X1O{}, sb + a_xtr, accGD, -1);
-        if (want_csp) {                                                   // its own block (inside the products it would make every accumulator a phi)
-            sfor<2>([&](auto KS) {
-                constexpr int ks = KS.value;
-                sfor<2>([&](auto TT) {
-                    TrOp ap[RT];
-                    sfor<RT>([&](auto CT) {
-                        tr_read<(2 + TT.value) * PT_B + 64 * CT.value + ks * 16 * PB, (2 + TT.value) * PT_B + 64 * CT.value + (ks * 16 + 4) * PB>(ap[CT.value], sb + a_ptr);
-                    });
-                    tr_fence(ap[0]);
+    };
+    // weight-gradient products of one job: acc[ct] += P^T (tile TP) . X (row tile at xaddr + XO); one 16-row k-step at a time
+    // (4 operands = 16 registers in flight)
+    auto wg_products = [&](uint32_t sb, auto TPC, auto XOC, uint32_t xlo, uint32_t xhi, f32x16* acc, int slot) {
+        constexpr int TP = decltype(TPC)::value, XO = decltype(XOC)::value;
+        sfor<2>([&](auto KS) {
+            constexpr int ks = KS.value;
+            TrOp bx, ap[RT];
+            tr_read2<XO + ks * 16 * 128>(bx, xlo, xhi);
+            sfor<RT>([&](auto CT) { tr_read2<TP * PT_B + 64 * CT.value + ks * 16 * PB>(ap[CT.value], sb + a_ptr[0], sb + a_ptr[1]); });
+            tr_fence(bx);
+            const bf16x8 vx = tr_val(bx);
+            if (slot >= 0) sx = mfma32(ones_row(slot), vx, sx);
 #pragma unroll
-                    for (int ct = 0; ct < RT; ++ct) {
-                        if (ct) tr_tie(ap[ct]);
-                        sx = mfma32(ones_row(2 + TT.value * RT + ct), tr_val(ap[ct]), sx);
-                    }
-                });
-            });
-        }
-        f32x16 p2 = zero16(), p1 = zero16();
-        project(I2{}, wD, p2);
-        project(I3{}, wGD, p1);
-        // ---- dx2 = s2*dh + p2, dx1 = p1 (+ dx1_in): 32 bytes per lane and tensor
-        if constexpr (HAS_IN) {                                           // the dx1_in loads precede this step's stage requests
-            if (has2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(din0), "+v"(din1) : "n"(NI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(din0), "+v"(din1) :: "memory");
-        }
-        {
-            uint8_t* q2 = const_cast<uint8_t*>(sbase(reinterpret_cast<const uint8_t*>(a.dx2) + rb * ld2)) + rowoff;
-            uint8_t* q1 = const_cast<uint8_t*>(sbase(reinterpret_cast<const uint8_t*>(a.dx1) + rb * ld2)) + rowoff;
+            for (int ct = 0; ct < RT; ++ct) { tr_tie(ap[ct]); acc[ct] = mfma32(tr_val(ap[ct]), vx, acc[ct]); }
+        });
+    };
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // weights in registers, biases in LDS
+    if (nsteps > 0) issue(0);
+    if (nsteps > 1) issue(1);
+
+    if (role == 0) {
+        // ================================================================ role U: up projections, dh / dq, dWu, dWgu, their bias sums
+        const float s2 = a.s2, sd = a.sd;
+        const bool want_csp = cb == 0 && wc == 0;       // the down-side bias sums (column sums of dpre_a, dpre_g): one wave per row chunk
+        const uint32_t a_bias = lds0 + (uint32_t)(BIAS_OFF + (32 * wc + 16 * h) * 4);
+        const uint32_t dq0 = lds0 + (uint32_t)DQ_OFF;
+#pragma unroll 1
+        for (int s = 0; s < nsteps; ++s) {
+            const int valid = (int)(r_end - (r_begin + 32 * (int64_t)s));
+            const uint32_t sb = lds0 + (uint32_t)((s % NSTG) * STG_B);
+            step_top(s, 0);
+            auto load_bias = [&](auto OC, f32x16& acc) {
+                u32x4 bb[4];
+                sfor<4>([&](auto Q) { lds_read16<decltype(OC)::value + 16 * Q.value>(bb[Q.value], a_bias); });
+                lgkm_fence(bb[0]);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const u32x4 din = c == 0 ? din0 : din1;
-                float o2[8], o1[8];
+                for (int q = 0; q < 4; ++q) {
+                    if (q) lgkm_tie(bb[q]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    o2[j] = s2 * bf_at(dhp[c], j) + p2[8 * c + j];      // (the bf16-rounded dh, as the weight gradients see it)
-                    o1[j] = p1[8 * c + j] + bf_at(din, j);               // (zeros without dx1_in)
+                    for (int w = 0; w < 4; ++w) acc[4 * q + w] = __uint_as_float(bb[q][w]);
                 }
-                const u32x4 v2 = pack8(o2), v1 = pack8(o1);
+            };
+            {
+                f32x16 aA, aG;                                            // both up projections, starting at the biases
+                load_bias(I0{}, aA);
+                project(sb, I0{}, wA, aA);
+                load_bias(std::integral_constant<int, 512>{}, aG);
+                project(sb, I1{}, wG, aG);
+                const float gsr = m < valid ? a.gs : 0.f;                 // rows past the end: dh = dq = 0
+                sfor<4>([&](auto C) {                                     // 4 columns at a time (a small live set): dy, x2 in, dh, dq out
+                    constexpr int c = C.value;
+                    u32x2 dyv, x2v;
+                    lds_read8<8 * (c & 1)>(dyv, sb + a_xcl[c >> 1]);
+                    lds_read8<8192 + 8 * (c & 1)>(x2v, sb + a_xcl[c >> 1]);
+                    // (the wait also pins this chunk's share of the projections behind the previous chunk's stores: hipcc would
+                    //  otherwise start all 16 sigmoids at once and keep their temporaries live)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dyv), "+v"(x2v), "+v"(aG[4 * c]), "+v"(aG[4 * c + 1]), "+v"(aG[4 * c + 2]), "+v"(aG[4 * c + 3]) :: "memory");
+                    float dh[4], dq[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * c + j;
+                        const float gt = sigm(aG[e]);
+                        const float dyp = gsr * ((j & 1) ? bf_hi(dyv[j >> 1]) : bf_lo(dyv[j >> 1]));
+                        if constexpr (ADD) {
+                            dh[j] = dyp;
+                            dq[j] = dyp * gt * (1.0f - gt);
+                        } else {
+                            const float hv = s2 * ((j & 1) ? bf_hi(x2v[j >> 1]) : bf_lo(x2v[j >> 1])) + sd * aA[e];
+                            dh[j] = dyp * gt;
+                            dq[j] = dh[j] * hv * (1.0f - gt);
+                        }
+                    }
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                    const bf16x4 th = {(__bf16)dh[0], (__bf16)dh[1], (__bf16)dh[2], (__bf16)dh[3]};
+                    const bf16x4 tq = {(__bf16)dq[0], (__bf16)dq[1], (__bf16)dq[2], (__bf16)dq[3]};
+                    lds_write8<8 * (c & 1)>(sb + a_xcl[c >> 1], __builtin_bit_cast(u32x2, th));      // dh replaces dy in place
+                    lds_write8<8 * (c & 1)>(dq0 + a_xcl[c >> 1], __builtin_bit_cast(u32x2, tq));
+                });
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                 // dh is visible to the D wave of these columns
+            wg_products(sb, I0{}, I0{}, sb + a_xtr[0], sb + a_xtr[1], accA, 0);
+            wg_products(sb, I1{}, I0{}, dq0 + a_xtr[0], dq0 + a_xtr[1], accG, 1);
+            if (want_csp) {                                               // its own block (inside the products it would make every accumulator a phi)
+                sfor<2>([&](auto KS) {
+                    constexpr int ks = KS.value;
+                    sfor<2>([&](auto TT) {
+                        TrOp ap[RT];
+                        sfor<RT>([&](auto CT) {
+                            tr_read2<(2 + TT.value) * PT_B + 64 * CT.value + ks * 16 * PB>(ap[CT.value], sb + a_ptr[0], sb + a_ptr[1]);
+                        });
+                        tr_fence(ap[0]);
+#pragma unroll
+                        for (int ct = 0; ct < RT; ++ct) {
+                            if (ct) tr_tie(ap[ct]);
+                            sx = mfma32(ones_row(2 + TT.value * RT + ct), tr_val(ap[ct]), sx);
+                        }
+                    });
+                });
+            }
+        }
+        if (h == 0) {
+            a.part[1][(int64_t)RC * PR * d + (int64_t)rc * d + col] = sx[0];
+            a.part[3][(int64_t)RC * PR * d + (int64_t)rc * d + col] = sx[1];
+            if (want_csp) {
+                float* psa = a.part[0] + (int64_t)RC * PR * d + (int64_t)RC * d + (int64_t)rc * PR;
+                float* psg = a.part[2] + (int64_t)RC * PR * d + (int64_t)RC * d + (int64_t)rc * PR;
+#pragma unroll
+                for (int ct = 0; ct < RT; ++ct) { psa[32 * ct + m] = sx[2 + ct]; psg[32 * ct + m] = sx[2 + RT + ct]; }
+            }
+        }
+    } else {
+        // ================================================================ role D: dWd, dWgd (+ bias sums), input gradients
+        const uint8_t* DXIN = reinterpret_cast<const uint8_t*>(a.dxin);
+        const float s2 = a.s2;
+#pragma unroll 1
+        for (int s = 0; s < nsteps; ++s) {
+            const int64_t rb = r_begin + 32 * (int64_t)s;
+            const int valid = (int)(r_end - rb) < 32 ? (int)(r_end - rb) : 32;
+            const bool has2 = s + 2 < nsteps;
+            const uint32_t sb = lds0 + (uint32_t)((s % NSTG) * STG_B);
+            const bool row_ok = m < valid;
+            // byte offset of this lane's 16 columns of its row, relative to row rb (rows past the end: the last row)
+            const uint32_t rowoff = (uint32_t)(row_ok ? m : valid - 1) * (uint32_t)ld2 + (uint32_t)((c0 + 16 * h) * 2);
+            // Order of this wave's vector-memory operations: ... G(s+1) S(s-1) | L(s) [wait for G(s)] G(s+2) ... [wait for L(s)] ... S(s)
+            // (G = its stage requests, L = the dx1_in register loads, S = the four output stores), all counted by hand.
+            u32x4 din0, din1;
+            if constexpr (HAS_IN) {                                       // the incoming dx1 rows of this step, straight to registers
+                const uint8_t* bp = sbase(DXIN + rb * ld2);
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(din0) : "v"(rowoff), "s"(bp) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(din1) : "v"(rowoff), "s"(bp) : "memory");
+            }
+            step_top(s, (s > 0 ? 4 : 0) + NL);
+            wg_products(sb, I2{}, X2O{}, sb + a_xtr[0], sb + a_xtr[1], accA, -1);
+            wg_products(sb, I3{}, X1O{}, sb + a_xtr[0], sb + a_xtr[1], accG, -1);
+            // both input-gradient projections before the hand-off (role U is busy with the elementwise stage meanwhile)
+            f32x16 p2 = zero16(), p1 = zero16();
+            project(sb, I2{}, wA, p2);
+            project(sb, I3{}, wG, p1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                 // the U wave of these columns has written dh
+            // ---- dx2 = s2*dh + Wd^T dpre_a, dx1 = Wgd^T dpre_g (+ dx1_in): 32 bytes per lane and tensor
+            {
+                u32x4 dh0, dh1;
+                lds_read16<0>(dh0, sb + a_xcl[0]); lds_read16<0>(dh1, sb + a_xcl[1]);
+                lgkm_fence(dh0); lgkm_tie(dh1);
+                float o[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[e] = s2 * bf_at(e < 8 ? dh0 : dh1, e & 7) + p2[e];
+                const u32x4 v0 = pack8(o), v1 = pack8(o + 8);
                 if (row_ok) {
-                    reinterpret_cast<u32x4*>(q2)[c] = v2;
-                    reinterpret_cast<u32x4*>(q1)[c] = v1;
+                    uint8_t* q2 = const_cast<uint8_t*>(sbase(reinterpret_cast<const uint8_t*>(a.dx2) + rb * ld2)) + rowoff;
+                    reinterpret_cast<u32x4*>(q2)[0] = v0;
+                    reinterpret_cast<u32x4*>(q2)[1] = v1;
+                }
+            }
+            {
+                float o[16];
+                if constexpr (HAS_IN) {                                   // the dx1_in loads precede this step's requests and the dx2 stores
+                    vm_wait((has2 ? NW : 0) + 2);
+                    asm volatile("" : "+v"(din0), "+v"(din1) :: "memory");
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[e] = p1[e] + bf_at(e < 8 ? din0 : din1, e & 7);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[e] = p1[e];
+                }
+                const u32x4 v0 = pack8(o), v1 = pack8(o + 8);
+                if (row_ok) {
+                    uint8_t* q1 = const_cast<uint8_t*>(sbase(reinterpret_cast<const uint8_t*>(a.dx1) + rb * ld2)) + rowoff;
+                    reinterpret_cast<u32x4*>(q1)[0] = v0;
+                    reinterpret_cast<u32x4*>(q1)[1] = v1;
                 }
             }
         }
-        // ---- up side: dWu += z_a^T dh, dWgu += z_g^T dq and the column sums of dh, dq (this wave's own tile columns: its
-        // ds_writes above are ordered before these reads by the lgkmcnt waits in between)
-        wg_products(I0{}, I0{}, sb + a_xtr, accU, 0);
-        wg_products(I1{}, I0{}, a_dqtr, accGU, 1);
     }
-
     // ---- this row chunk's partial sums, in wgrad.hip's workspace layout (wgrad_finalize_kernel sums the chunks)
-    const int RC = a.row_chunks;
-    const int col = c0 + m;
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-        float* t = a.part[jb] + (int64_t)rc * PR * d;
-        const f32x16* acc = jb == 0 ? accD : jb == 1 ? accU : jb == 2 ? accGD : accGU;
+    {
+        float* tA = a.part[role == 0 ? 1 : 0] + (int64_t)rc * PR * d;
+        float* tG = a.part[role == 0 ? 3 : 2] + (int64_t)rc * PR * d;
 #pragma unroll
         for (int ct = 0; ct < RT; ++ct)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int crow = 32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h;
-                t[(int64_t)crow * d + col] = acc[ct][i];
+                tA[(int64_t)crow * d + col] = accA[ct][i];
+                tG[(int64_t)crow * d + col] = accG[ct][i];
             }
-    }
-    if (h == 0) {
-        a.part[1][(int64_t)RC * PR * d + (int64_t)rc * d + col] = sx[0];
-        a.part[3][(int64_t)RC * PR * d + (int64_t)rc * d + col] = sx[1];
-        if (want_csp) {
-            float* psa = a.part[0] + (int64_t)RC * PR * d + (int64_t)RC * d + (int64_t)rc * PR;
-            float* psg = a.part[2] + (int64_t)RC * PR * d + (int64_t)RC * d + (int64_t)rc * PR;
-#pragma unroll
-            for (int ct = 0; ct < RT; ++ct) { psa[32 * ct + m] = sx[2 + ct]; psg[32 * ct + m] = sx[2 + RT + ct]; }
-        }
     }
 }
 
@@ -441,7 +500,7 @@ static hipError_t launch_cols_cfg(const ColzArgs& c, hipStream_t stream) {
     if (e != hipSuccess) return e;
     const int ncb = c.d / 128;
     const unsigned grid = 8u * (unsigned)ncb * (unsigned)((c.row_chunks + 7) / 8);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, c);
     return hipGetLastError();
 }
 template <int RT>
