@@ -234,6 +234,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--buckets", type=int, default=3)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to exercise the DP path on a 1-GPU box")
+    ap.add_argument("--k1-previous-split", action="store_true",
+                    help="A/B: the round-2 form of the gated K1 backward (row kernel + streaming weight gradients) instead of pass 1 + column-parallel pass")
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="K1 weight gradients on a side stream (measured 5 %% SLOWER on one MI355X: the step is GPU-bound)")
     ap.add_argument("--gemm-table", default="on", choices=["on", "off", "tune"],
@@ -321,7 +323,8 @@ def main():
     # Live HIP-event brackets inside the timed region: only the launches of the roofline's op (every bracket is two marker
     # packets on the launch stream; bracketing all ~150 launches of a step cost the step a few percent).  The full per-kernel
     # table comes from a separate pass after the timed region (--kernel-table inline restores the old behaviour).
-    dom_names = ("k3_bwd", "k3_fwd") if args.model == "lora" else ("k1_bwd_rows", "k1_bwd_wgrad")
+    dom_names = ("k3_bwd", "k3_fwd") if args.model == "lora" else ("k1_bwd_rows", "k1_bwd_wgrad", "k1_bwd_fin")
+    VF.K1_BWD_PREVIOUS_SPLIT = bool(args.k1_previous_split)
     VF.TIMER = VF.KernelTimer(None if args.kernel_table == "inline" else dom_names)
     t0 = time.perf_counter()
     samples = 0
@@ -361,7 +364,14 @@ def main():
         # algorithmic bytes per row: K1 fwd reads x1, x2, writes y; K1 bwd (the whole op: rows kernel + weight
         # gradients) reads dy, x1, x2, writes dx1, dx2; K2 / K3 fwd read x, y|base, write out; K2 / K3 bwd read dy, x, write dx;
         # K5 fwd reads y, x1, writes out; K5 bwd reads dout, writes dx1, dy (the saved pre-norm sum is extra traffic)
-        per_row = {"k1_fwd": 3 * d * esz, "k1_bwd_rows": 5 * d * esz, "k1_bwd_wgrad": 0, "k2_fwd": 3 * d * esz,
+        # Form of the gated K1 backward at this shape (vlpet_adapter_gate_bwd_form): 2 = pass 1 (pet_gate_dz_kernel: reads dy, x2,
+        # writes only the [M, r] dpre) + the column-parallel pass (k1_cols_kernel: reads dy, x1, x2, writes dx1, dx2 and the
+        # weight-gradient partials) + the finalize launch; otherwise rows kernel + weight-gradient kernels as in round 2.
+        k1_tiles = 6 if args.model == "t5" else 3
+        k1_form = VF._lib.load().vlpet_adapter_gate_bwd_form(28000, d, k1_tiles, 1 if dtype == torch.bfloat16 else 0)
+        two_pass = k1_form == 2 and not args.k1_previous_split
+        per_row = {"k1_fwd": 3 * d * esz, "k1_bwd_rows": (2 if two_pass else 5) * d * esz, "k1_bwd_wgrad": (5 if two_pass else 0) * d * esz,
+                   "k1_bwd_fin": 0, "k2_fwd": 3 * d * esz,
                    "k2_bwd": 3 * d * esz, "k3_fwd": 3 * d * esz, "k3_bwd": 3 * d * esz, "k5_fwd": 3 * d * esz,
                    "k5_bwd": 3 * d * esz, "k4_ln_bwd": 3 * d * esz,
                    "rms_fwd": 2 * d * esz, "rms_bwd": 3 * d * esz}      # (K4's LayerNorm backward: dout, xhat read, dpre written)
@@ -389,22 +399,24 @@ def main():
         # the K1 backward as ONE op (rows kernel + weight-gradient kernels): SURVEY 8d's 5*d*b per row over their summed time
         if "k1_bwd_rows" in agg and "k1_bwd_wgrad" in agg:
             a, w = agg["k1_bwd_rows"], agg["k1_bwd_wgrad"]
-            op_us = a["total_us"] + w["total_us"]
-            gbps = per_row["k1_bwd_rows"] * a["rows"] / op_us / 1e3
+            op_us = a["total_us"] + w["total_us"] + (agg["k1_bwd_fin"]["total_us"] if "k1_bwd_fin" in agg else 0.0)
+            gbps = 5 * d * esz * a["rows"] / op_us / 1e3
             kernels["k1_bwd_op"] = dict(launches=a["launches"], avg_us=round(op_us / a["launches"], 2),
                                         total_ms=round(op_us / 1e3, 3), algorithmic_GBps=round(gbps, 1),
                                         hbm_frac=round(gbps / HBM_PEAK_GBS, 4),
-                                        note="rows kernel + weight-gradient kernels of one K1 backward, 5*d*b per row")
+                                        note=("pass 1 + column-parallel pass + finalize of one K1 backward, 5*d*b per row" if two_pass
+                                              else "rows kernel + weight-gradient kernels of one K1 backward, 5*d*b per row"))
         # dominant HIP kernel of the hot path by time
         if args.model == "lora":
             dom = "k3_bwd" if "k3_bwd" in agg else "k3_fwd"
         else:
-            dom = "k1_bwd_rows" if "k1_bwd_rows" in agg else "k1_fwd"
+            dom = ("k1_bwd_wgrad" if two_pass and "k1_bwd_wgrad" in agg else "k1_bwd_rows") if "k1_bwd_rows" in agg else "k1_fwd"
         a = agg[dom]
         achieved = per_row[dom] * a["rows"] / a["total_us"] / 1e3     # GB/s
         tiles = 6 if args.model == "t5" else 3
         kname = {"k1_bwd_rows": (f"pet_gate_bwd2_kernel<{args.dtype},{tiles}>" if tiles <= 3
                                  else f"pet_bwd_kernel<{args.dtype},{tiles},gate>"),
+                 "k1_bwd_wgrad": f"k1_cols_kernel<{tiles}> (column-parallel pass of the K1 backward: reads dy, x1, x2, writes dx1, dx2)",
                  "k1_fwd": f"pet_gate_fwd_kernel<{args.dtype},{tiles}>",
                  "k3_bwd": f"pet_bwd_kernel<{args.dtype},act_id> + wgrad_kernel (one K3 backward)",
                  "k3_fwd": f"pet_fwd_kernel<{args.dtype},act_id>"}[dom]
@@ -418,7 +430,7 @@ def main():
                     avg_launch_us=round(a["total_us"] / a["launches"], 2),
                     avg_rows_per_launch=round(a["rows"] / a["launches"], 1),
                     algorithmic_bytes_per_row=per_row[dom])
-        if "k1_bwd_op" in kernels and dom == "k1_bwd_rows":
+        if "k1_bwd_op" in kernels and dom in ("k1_bwd_rows", "k1_bwd_wgrad"):
             roof["op_frac"] = kernels["k1_bwd_op"]["hbm_frac"]          # the same bytes over rows + weight-gradient time
             roof["op_avg_us"] = kernels["k1_bwd_op"]["avg_us"]
             if traffic:

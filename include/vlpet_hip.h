@@ -120,13 +120,20 @@ int vlpet_adapter_gate_bwd_phase(int phases, const void* dy, const void* x1, con
                                  float delta_scale, float x2_scale, float gate_scale,
                                  int io_dtype, vlpet_stream_t stream);
 
+/* Which form vlpet_adapter_gate_bwd_saved takes for this shape: 2 = pass 1 + the column-parallel pass of csrc/pet_cols.hip
+ * (bf16, r, r_g <= 96, d % 128 == 0), 1 = pass 1 + the older column-parallel pass (csrc/pet_gate_bwd3.hip: r = 192, fp32 small M),
+ * 0 = row kernel + weight-gradient kernels; < 0: bad arguments.  (What a bench labels its kernel brackets with.) */
+int vlpet_adapter_gate_bwd_form(int64_t M, int d, int tiles, int io_dtype);
+
 /* vlpet_adapter_gate_bwd_phase with the activations saved by vlpet_adapter_gate_fwd_save (x1 is
  * still an argument because the gate's down-weight gradient contracts it).
- * For r, r_g <= 96 this runs as TWO PASSES that move every [M, d] tensor once each (csrc/pet_gate_bwd3.hip):
+ * It runs as TWO PASSES that move every [M, d] tensor once each (csrc/pet_gate_bwd3.hip pass 1, csrc/pet_cols.hip pass 2):
  * phases bit 0 = pass 1 (row-parallel: dpre of both chains into the workspace, no [M, d] output),
  * bit 1 = pass 2 (column-parallel: dx1, dx2 AND the eight weight / bias gradients from recomputed dh / dq).  A caller that
  * needs dx1 / dx2 right after bit 0 (weight gradients on another stream) adds bit 2 to BOTH calls: the previous split
- * (bit 0: dx1, dx2 + [M, d] side products; bit 1: weight gradients from them).  phases = 3 is the full call either way. */
+ * (bit 0: dx1, dx2 + [M, d] side products; bit 1: weight gradients from them).  phases = 3 is the full call either way.
+ * For event brackets around single kernels (form 2 only): bit 3 with bit 1 = pass 2 WITHOUT the finalize launch (the row-chunk
+ * partial sums stay in the workspace), bit 4 alone = the finalize launch only. */
 int vlpet_adapter_gate_bwd_saved(int phases, const void* dy, const void* x1, const void* x2, const void* saved,
                                  const void* packed_a, const void* packed_g,
                                  void* dx1, void* dx2,

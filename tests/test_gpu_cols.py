@@ -1,0 +1,107 @@
+"""Gated K1 backward in its round-3 form: pass 1 (dpre) + the column-parallel pass of csrc/pet_cols.hip (bf16, r <= 96).
+Parity against the CPU oracle (autograd of my_transformers/modeling_bart.py:1147-1155,1195-1209) through the product path,
+at ragged and full sizes, for both gate forms, r <= 32 (one tile), unequal ranks and the T5 script's scales; the dx1_in
+form against an explicit add; the previous split (ABI phases bit 2) kept under test as the A/B reference."""
+import pytest
+import torch
+
+import gpu_cases as C
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-2          # BASELINE.json: 1e-2 for bf16 IO (max-abs error over max-abs reference, per tensor)
+
+
+def _check(errs):
+    bad = {k: v for k, v in errs.items() if not (v <= TOL)}
+    assert not bad, errs
+
+
+def test_form_query():
+    from vlpet_amd import _lib
+    lib = _lib.load()
+    assert lib.vlpet_adapter_gate_bwd_form(28000, 768, 3, _lib.VLPET_BF16) == 2       # column-parallel pass
+    assert lib.vlpet_adapter_gate_bwd_form(28000, 768, 1, _lib.VLPET_BF16) == 2
+    assert lib.vlpet_adapter_gate_bwd_form(28000, 768, 6, _lib.VLPET_BF16) == 1       # r = 192: the older two-pass form
+    assert lib.vlpet_adapter_gate_bwd_form(28000, 768, 3, _lib.VLPET_F32) == 0        # fp32 (parity mode): rows + weight gradients
+    assert lib.vlpet_adapter_gate_bwd_form(28000, 64, 3, _lib.VLPET_BF16) != 2        # d % 128 != 0
+    assert lib.vlpet_adapter_gate_bwd_form(0, 768, 3, _lib.VLPET_BF16) < 0
+
+
+@pytest.mark.parametrize("kw", [
+    dict(M=32), dict(M=33), dict(M=224), dict(M=1000), dict(M=3500), dict(M=2100, gate_scale=0.3, delta_scale=0.5, x2_scale=0.7),
+    dict(M=1000, gate_mode=2), dict(M=777, r=8, rg=8, nh=4), dict(M=1000, r=96, rg=32, nh=4), dict(M=640, d=256, r=32, rg=16, nh=4),
+    dict(M=8232), dict(M=28000), dict(M=31616),
+], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_k1_two_pass_bf16_vs_oracle(kw):
+    ce = {}
+    _check(C.run_k1(torch.bfloat16, col_errs=ce, **kw))
+    assert max(ce.values()) <= 5e-2, ce          # bias gradients element by element (sums over all M rows of bf16-rounded terms)
+
+
+def _abi_case(M, dtype=torch.bfloat16, seed=11, gate_mode=1):
+    import vlpet_amd.functional as F
+    from vlpet_amd import _lib
+    lib = _lib.load()
+    d, r, dev = 768, 96, "cuda"
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x1, x2, dy, dxin = (torch.randn(M, d, device=dev, generator=g).to(dtype) for _ in range(4))
+    mk = lambda *s: torch.randn(*s, device=dev, generator=g) * 0.05
+    W = [mk(r, d), mk(r), mk(d, r), mk(d), mk(r, d), mk(r), mk(d, r), mk(d)]
+    io, tiles = F._io_dtype(x2), F.rank_tiles(r)
+    pa = F.pack_pair([W[0]], [W[1]], W[2], W[3], io, tiles); pg = F.pack_pair([W[4]], [W[5]], W[6], W[7], io, tiles)
+    st = torch.cuda.current_stream().cuda_stream
+    nws = lib.vlpet_bwd_workspace_bytes(M, d, tiles, 1, io)
+    out = torch.empty_like(x2)
+    sv = torch.empty(lib.vlpet_saved_bytes(M, tiles, io), dtype=torch.uint8, device=dev)
+    assert lib.vlpet_adapter_gate_fwd_save(x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(), out.data_ptr(),
+                                           sv.data_ptr(), M, d, tiles, gate_mode, 1.0, 1.0, 0.7, io, st) == 0
+
+    def run(phases_list, acc):
+        dx1 = torch.zeros_like(x1); dx2 = torch.zeros_like(x2)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        G = [torch.zeros_like(w) for w in W]
+        common = [t.data_ptr() for t in G] + [r, r, ws.data_ptr(), nws, M, d, tiles, gate_mode, 1.0, 1.0, 0.7, io, st]
+        for ph in phases_list:
+            if acc:
+                rc = lib.vlpet_adapter_gate_bwd_saved_acc(ph, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(),
+                                                          pg.buf.data_ptr(), dxin.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), *common)
+            else:
+                rc = lib.vlpet_adapter_gate_bwd_saved(ph, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(),
+                                                      pg.buf.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), *common)
+            assert rc == 0
+        torch.cuda.synchronize()
+        return [dx1.float(), dx2.float()] + [t.float() for t in G]
+    return run, dxin
+
+
+@pytest.mark.parametrize("M", [96, 8232, 28000])
+def test_incoming_dx1_travels_with_the_stage(M):
+    """vlpet_adapter_gate_bwd_saved_acc on the column-parallel pass: dx1 = dx1_in + gate-branch gradient; the other nine
+    outputs are bit-identical to the plain call (M = 8232, 28000: several steps per row chunk, ragged last step)."""
+    run, dxin = _abi_case(M)
+    plain, acc = run([3], False), run([3], True)
+    ref = plain[0] + dxin.float()
+    assert (acc[0] - ref).abs().max().item() <= TOL * ref.abs().max().item()
+    for a, b in zip(plain[1:], acc[1:]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("gate_mode", [1, 2])
+def test_kernel_brackets_and_previous_split_agree(gate_mode):
+    """phases 1, 2|8, 16 (pass 1, pass 2 without finalize, finalize: what the bench brackets) == phases 3; and the previous
+    split (phases bit 2: row kernel + streaming weight gradients) agrees with the two-pass form within the bf16 tolerance."""
+    run, _ = _abi_case(5000, gate_mode=gate_mode)
+    whole, parts, prev = run([3], False), run([1, 2 | 8, 16], False), run([1 | 4, 2 | 4], False)
+    for a, b in zip(whole, parts):
+        assert torch.equal(a, b)
+    for a, b in zip(whole, prev):
+        assert (a - b).abs().max().item() <= TOL * b.abs().max().item()
+
+
+def test_module_path_can_run_the_previous_split():
+    import vlpet_amd.functional as F
+    F.K1_BWD_PREVIOUS_SPLIT = True
+    try:
+        _check(C.run_k1(torch.bfloat16, M=1500))
+    finally:
+        F.K1_BWD_PREVIOUS_SPLIT = False

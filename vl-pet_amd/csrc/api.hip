@@ -7,7 +7,8 @@
 #include <stdio.h>
 #include <vector>
 
-#define VLPET_VERSION 221      // 221: vlpet_sublayer_tail_reduce, vlpet_layernorm_bwd_xhat, vlpet_rmsnorm_{fwd,bwd}, vlpet_colsum;  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
+#define VLPET_VERSION 300      // 300: column-parallel K1 backward pass (pet_cols.hip), phases bits 3 / 4, vlpet_adapter_gate_bwd_form;
+#define VLPET_VERSION_R2 221      // 221: vlpet_sublayer_tail_reduce, vlpet_layernorm_bwd_xhat, vlpet_rmsnorm_{fwd,bwd}, vlpet_colsum;  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -302,7 +303,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
                    float* dwgd, float* dbgd, float* dwgu, float* dbgu, int r, int rg,
                    void* workspace, size_t workspace_bytes, int64_t M, int d, int tiles,
                    float s2, float sd, float gs, int flags, int io_dtype, vlpet_stream_t stream,
-                   int phases = 3 /* bit0: row-parallel kernel, bit1: weight gradients */,
+                   int phases = 3 /* bit0: row-parallel kernel, bit1: weight gradients; bit3: skip the finalize of bit1, bit4: finalize only */,
                    const void* saved = nullptr /* vlpet_adapter_gate_fwd_save's block */,
                    const void* dx1_in = nullptr /* gated K1: added to dxg (must not alias it) */) {
     int rc = check_common(M, d, tiles, io_dtype);
@@ -361,7 +362,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
             if (e != hipSuccess) return (int)e;
         }
     }
-    if (!(phases & 2)) return 0;
+    if (!(phases & (2 | 16))) return 0;
 
     WgradArgs g{};
     g.M = M; g.RT = tiles; g.row_chunks = w.row_chunks; g.rows_per_chunk = w.rows_per_chunk;
@@ -398,16 +399,29 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
         c.row_chunks = g.row_chunks; c.rows_per_chunk = g.rows_per_chunk;
         const WgradLayout L = wgrad_layout(g);
         for (int j = 0; j < 4; ++j) c.part[j] = g.partial + L.off[j];
-        hipError_t e = launch_k1_cols(c, tiles, (hipStream_t)stream);
-        if (e != hipSuccess) return (int)e;
+        if (phases & 2) {
+            hipError_t e = launch_k1_cols(c, tiles, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
+        if ((phases & 8) && !(phases & 16)) return 0;       // (the partial sums stay in the workspace)
         return herr(launch_wgrad_finalize(g, (hipStream_t)stream));
     }
+    if (!(phases & 2)) return 0;                            // (bits 3 / 4 split the column-parallel form only)
     if (two_pass) {                                     // (dx1 is an output of pass 2 there)
         hipError_t e = launch_pet_gate_cols(b, g, gs3, ng3, io_dtype == VLPET_F32, (hipStream_t)stream);
         if (e == hipSuccess && dx1_in) e = launch_add_inplace(dxg, dx1_in, M * (int64_t)d, io_dtype == VLPET_F32, (hipStream_t)stream);
         return herr(e);
     }
     return herr(launch_wgrad(g, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_adapter_gate_bwd_form(int64_t M, int d, int tiles, int io_dtype) {
+    if (check_common(M, d, tiles, io_dtype)) return -1;
+    PetBwdArgs b{};
+    b.M = M; b.d = d; b.RT = tiles; b.flags = PET_GATE; b.saved = &b; b.drop = NO_DROP;
+    if (k1_cols_applies(b, io_dtype == VLPET_F32)) return 2;
+    if (pet_gate_bwd3_applies(b)) return 1;
+    return 0;
 }
 
 extern "C" int vlpet_adapter_gate_bwd(const void* dy, const void* x1, const void* x2,
@@ -459,10 +473,10 @@ extern "C" int vlpet_adapter_gate_bwd_saved(int phases, const void* dy, const vo
                                             int io_dtype, vlpet_stream_t stream) {
     int flags;
     if (gate_flags(gate_mode, &flags)) return VLPET_E_SHAPE;
-    if (!dbd || !dbu || !saved || (phases & 3) == 0) return VLPET_E_NULL;
+    if (!dbd || !dbu || !saved || (phases & 19) == 0) return VLPET_E_NULL;
     return run_bwd(dy, x2, x2, x1, packed_a, packed_g, NO_DROP, dx2, dx1, dwd, dbd, dwu, dbu,
                    dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
-                   x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream, phases & 7, saved);
+                   x2_scale, delta_scale, flags ? gate_scale : 1.f, flags, io_dtype, stream, phases & 31, saved);
 }
 
 extern "C" int vlpet_adapter_gate_bwd_saved_acc(int phases, const void* dy, const void* x1, const void* x2, const void* saved,
@@ -474,10 +488,10 @@ extern "C" int vlpet_adapter_gate_bwd_saved_acc(int phases, const void* dy, cons
                                                 int io_dtype, vlpet_stream_t stream) {
     int flags;
     if (gate_flags(gate_mode, &flags)) return VLPET_E_SHAPE;
-    if (!dbd || !dbu || !saved || !dx1_in || !flags || (phases & 3) == 0) return VLPET_E_NULL;
+    if (!dbd || !dbu || !saved || !dx1_in || !flags || (phases & 19) == 0) return VLPET_E_NULL;
     return run_bwd(dy, x2, x2, x1, packed_a, packed_g, NO_DROP, dx2, dx1, dwd, dbd, dwu, dbu,
                    dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
-                   x2_scale, delta_scale, gate_scale, flags, io_dtype, stream, phases & 7, saved, dx1_in);
+                   x2_scale, delta_scale, gate_scale, flags, io_dtype, stream, phases & 31, saved, dx1_in);
 }
 
 extern "C" int vlpet_parallel_adapter_bwd(const void* dy, const void* x, const void* packed, void* dx,

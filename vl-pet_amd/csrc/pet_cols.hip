@@ -35,15 +35,16 @@
 #include "kernels.h"
 #include "trread.h"
 
-template <int RT> struct ColzGeo {
+template <int RT, bool HAS_IN = false> struct ColzGeo {
     static constexpr int KT = 2 * RT;
     static constexpr int PB = 64 * RT;                  // bytes of a bottleneck row
     static constexpr int PT_B = 32 * PB;                // one bottleneck tile
-    static constexpr int X_B = 6 * 4096;                // dy, x2, x1: two pair tiles [32 rows x 128 B] each
+    static constexpr int NX = HAS_IN ? 4 : 3;           // row tensors of a stage: dy, x2, x1 (+ the incoming dx1)
+    static constexpr int X_B = NX * 2 * 4096;           // two pair tiles [32 rows x 128 B] each
     static constexpr int STG_B = X_B + 4 * PT_B;        // + z_a, z_g, dpre_a, dpre_g
     static constexpr int DQ_B = 2 * 4096;
     static constexpr int BIAS_B = 2 * 128 * 4;
-    static constexpr size_t lds(int nstg) { return (size_t)nstg * STG_B + DQ_B + BIAS_B; }
+    static constexpr size_t lds(int nstg) { return (size_t)nstg * STG_B + 2 * 8192 + DQ_B + BIAS_B; }    // ring, dh (x2), dq, biases
 };
 
 template <typename F, int... I>
@@ -111,12 +112,11 @@ __device__ __forceinline__ float sigm(float x) {
 
 template <int RT, int NSTG, bool ADD, bool HAS_IN>
 __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
-    using GEO = ColzGeo<RT>;
-    constexpr int KT = GEO::KT, PB = GEO::PB, PT_B = GEO::PT_B, X_B = GEO::X_B, STG_B = GEO::STG_B;
-    constexpr int DQ_OFF = NSTG * STG_B, BIAS_OFF = DQ_OFF + GEO::DQ_B;
+    using GEO = ColzGeo<RT, HAS_IN>;
+    constexpr int KT = GEO::KT, PB = GEO::PB, PT_B = GEO::PT_B, X_B = GEO::X_B, STG_B = GEO::STG_B, NX = GEO::NX;
+    constexpr int DH_OFF = NSTG * STG_B, DQ_OFF = DH_OFF + 2 * 8192, BIAS_OFF = DQ_OFF + GEO::DQ_B;
     constexpr int PR = 32 * RT;
-    constexpr int NL = HAS_IN ? 2 : 0;                  // register loads (dx1_in) per step of a role-D wave
-    constexpr int NW = 3 + RT;                          // global_load_lds instructions per wave and stage
+    constexpr int NW = NX + RT;                         // global_load_lds instructions per wave and stage
     constexpr int GRP = RT == 1 ? 2 : 3;                // B fragments requested per batch of a projection
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
@@ -163,13 +163,13 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
     // ---- the stage pieces (1 KiB each) of this wave: pieces q = wave, wave + 8, wave + 16 are 8 rows of a pair tile of a row
     // tensor (tensor q / 8, pair (q / 4) % 2, rows 8 (q % 4) ..), pieces q' = wave + 8 j < 8 RT belong to the bottleneck tiles
     // (tensor q' / KT, piece q' % KT of the 32 contiguous rows)
-    const uint8_t* xbase[3]; uint32_t xdst[3];
+    const uint8_t* xbase[NX]; uint32_t xdst[NX];
     const int xrow = 8 * (wave & 3) + (lane >> 3);
     const uint32_t xoff = (uint32_t)xrow * (uint32_t)ld2
                         + (uint32_t)((128 * cb + 64 * (wave >> 2)) * 2 + (((lane & 7) ^ fsw(xrow)) * 16));
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        xbase[t] = reinterpret_cast<const uint8_t*>(t == 0 ? a.dy : t == 1 ? a.x2 : a.x1);
+    for (int t = 0; t < NX; ++t) {
+        xbase[t] = reinterpret_cast<const uint8_t*>(t == 0 ? a.dy : t == 1 ? a.x2 : t == 2 ? a.x1 : a.dxin);
         xdst[t] = (uint32_t)((t * 2 + (wave >> 2)) * 4096 + (wave & 3) * 1024);
     }
     const uint8_t* pbase[RT]; uint32_t pdst[RT], poff[RT]; int prow[RT];
@@ -194,14 +194,14 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
         uint8_t* st = smem + (size_t)(s % NSTG) * STG_B;
         if (rb + 32 <= r_end) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) glds16_row(sbase(xbase[t] + rb * ld2) + xoff, st + xdst[t]);
+            for (int t = 0; t < NX; ++t) glds16_row(sbase(xbase[t] + rb * ld2) + xoff, st + xdst[t]);
 #pragma unroll
             for (int j = 0; j < RT; ++j) glds16(sbase(pbase[j] + rb * PB) + poff[j], st + pdst[j]);
         } else {                                        // last step of the chunk: rows past the end re-read the last row
             const int last = (int)(r_end - rb) - 1;
             const uint32_t xo = xoff - (uint32_t)(xrow > last ? xrow - last : 0) * (uint32_t)ld2;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) glds16_row(sbase(xbase[t] + rb * ld2) + xo, st + xdst[t]);
+            for (int t = 0; t < NX; ++t) glds16_row(sbase(xbase[t] + rb * ld2) + xo, st + xdst[t]);
 #pragma unroll
             for (int j = 0; j < RT; ++j)
                 glds16(sbase(pbase[j] + rb * PB) + poff[j] - (uint32_t)(prow[j] > last ? prow[j] - last : 0) * PB, st + pdst[j]);
@@ -247,14 +247,15 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
 #pragma unroll
     for (int ct = 0; ct < RT; ++ct) { accA[ct] = zero16(); accG[ct] = zero16(); }
 
-    // ---- the step frame shared by the roles: wait for the own pieces of stage s, barrier, request stage s + 2, zero the
+    // ---- the step frame shared by the roles: wait for the own pieces of stage s, barrier, request stage s + NSTG - 1, zero the
     // bottleneck rows past the end in the last step.  `extra` = this wave's OTHER vector-memory operations younger than its
-    // requests of stage s (role D: the stores of step s - 1 and the dx1_in loads of step s).
+    // requests of stage s (role D: output stores and dx1_in loads).
     auto step_top = [&](int s, int extra) {
-        const bool has1 = s + 1 < nsteps, has2 = s + 2 < nsteps;
-        vm_wait((has1 ? NW : 0) + extra);
+        int ahead = nsteps - 1 - s;                                       // stages already requested beyond s
+        if (ahead > NSTG - 2) ahead = NSTG - 2;
+        vm_wait(ahead * NW + extra);
         __builtin_amdgcn_s_barrier();                                     // stage s has landed for every wave; stage s - 1 is free
-        if (has2) issue(s + 2);
+        if (s + NSTG - 1 < nsteps) issue(s + NSTG - 1);
         const int valid = (int)(r_end - (r_begin + 32 * (int64_t)s));
         if (valid < 32) {                                                 // zero the bottleneck rows past the end (their products must vanish)
             const u32x4 z = {0u, 0u, 0u, 0u};
@@ -280,8 +281,8 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
             for (int k = 0; k < GRP; ++k) { if (k) lgkm_tie(bf[k]); acc = mfma32(w[G.value * GRP + k], as_bf(bf[k]), acc); }
         });
     };
-    // weight-gradient products of one job: acc[ct] += P^T (tile TP) . X (row tile at xaddr + XO); one 16-row k-step at a time
-    // (4 operands = 16 registers in flight)
+    // weight-gradient products of one job: acc[ct] += P^T (tile TP) . X (row tile at xlo / xhi + XO); one 16-row k-step at a
+    // time (4 operands = 16 registers in flight)
     auto wg_products = [&](uint32_t sb, auto TPC, auto XOC, uint32_t xlo, uint32_t xhi, f32x16* acc, int slot) {
         constexpr int TP = decltype(TPC)::value, XO = decltype(XOC)::value;
         sfor<2>([&](auto KS) {
@@ -298,11 +299,15 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
     };
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // weights in registers, biases in LDS
-    if (nsteps > 0) issue(0);
-    if (nsteps > 1) issue(1);
+#pragma unroll
+    for (int s0 = 0; s0 < NSTG - 1; ++s0)
+        if (s0 < nsteps) issue(s0);
 
+    // The only hand-off between the roles is the dh tile (U -> D, for dx2 = s2*dh + ..).  It is double-buffered OUTSIDE the
+    // ring and consumed one step late: D finishes the input gradients of step s - 1 at the start of step s, so the one barrier
+    // of a step (the stage hand-over) also orders that hand-off and the two roles never wait for each other inside a step.
     if (role == 0) {
-        // ================================================================ role U: up projections, dh / dq, dWu, dWgu, their bias sums
+        // ================================================================ role U: up projections, dh / dq, dWu, dWgu, all bias sums
         const float s2 = a.s2, sd = a.sd;
         const bool want_csp = cb == 0 && wc == 0;       // the down-side bias sums (column sums of dpre_a, dpre_g): one wave per row chunk
         const uint32_t a_bias = lds0 + (uint32_t)(BIAS_OFF + (32 * wc + 16 * h) * 4);
@@ -311,6 +316,7 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
         for (int s = 0; s < nsteps; ++s) {
             const int valid = (int)(r_end - (r_begin + 32 * (int64_t)s));
             const uint32_t sb = lds0 + (uint32_t)((s % NSTG) * STG_B);
+            const uint32_t dh0 = lds0 + (uint32_t)(DH_OFF + (s & 1) * 8192);
             step_top(s, 0);
             auto load_bias = [&](auto OC, f32x16& acc) {
                 u32x4 bb[4];
@@ -356,13 +362,13 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
                     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
                     const bf16x4 th = {(__bf16)dh[0], (__bf16)dh[1], (__bf16)dh[2], (__bf16)dh[3]};
                     const bf16x4 tq = {(__bf16)dq[0], (__bf16)dq[1], (__bf16)dq[2], (__bf16)dq[3]};
-                    lds_write8<8 * (c & 1)>(sb + a_xcl[c >> 1], __builtin_bit_cast(u32x2, th));      // dh replaces dy in place
+                    lds_write8<8 * (c & 1)>(dh0 + a_xcl[c >> 1], __builtin_bit_cast(u32x2, th));
                     lds_write8<8 * (c & 1)>(dq0 + a_xcl[c >> 1], __builtin_bit_cast(u32x2, tq));
                 });
             }
+            // this wave's own columns of dh, dq: its writes above are ordered before these reads by the waits in between
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                 // dh is visible to the D wave of these columns
-            wg_products(sb, I0{}, I0{}, sb + a_xtr[0], sb + a_xtr[1], accA, 0);
+            wg_products(sb, I0{}, I0{}, dh0 + a_xtr[0], dh0 + a_xtr[1], accA, 0);
             wg_products(sb, I1{}, I0{}, dq0 + a_xtr[0], dq0 + a_xtr[1], accG, 1);
             if (want_csp) {                                               // its own block (inside the products it would make every accumulator a phi)
                 sfor<2>([&](auto KS) {
@@ -381,7 +387,9 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
                     });
                 });
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (every LDS access of this step is complete at the next barrier)
         }
+        __builtin_amdgcn_s_barrier();                                     // the last dh tile is visible to role D
         if (h == 0) {
             a.part[1][(int64_t)RC * PR * d + (int64_t)rc * d + col] = sx[0];
             a.part[3][(int64_t)RC * PR * d + (int64_t)rc * d + col] = sx[1];
@@ -393,43 +401,28 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
             }
         }
     } else {
-        // ================================================================ role D: dWd, dWgd (+ bias sums), input gradients
-        const uint8_t* DXIN = reinterpret_cast<const uint8_t*>(a.dxin);
+        // ================================================================ role D: dWd, dWgd, input gradients (one step late)
         const float s2 = a.s2;
-#pragma unroll 1
-        for (int s = 0; s < nsteps; ++s) {
-            const int64_t rb = r_begin + 32 * (int64_t)s;
+        f32x16 p2 = zero16(), p1 = zero16();            // Wd^T dpre_a, Wgd^T dpre_g of the PREVIOUS step's rows
+        // Order of this wave's vector-memory operations around step s: ... S(s-2) | [wait for G(s)] G(s+NSTG-1) S(s-1) ...
+        // (G = its stage requests, S = the four output stores of a step's rows).  The incoming dx1 rows travel with the stage (a
+        // fourth row tensor) and wait in registers for a step: register loads next to the LDS-DMA queue are not an option -- hidden
+        // in asm, hipcc copies their destination registers before the data lands; visible, it drains the queue for them.
+        u32x4 dinA = {0u, 0u, 0u, 0u}, dinB = {0u, 0u, 0u, 0u};           // dx1_in of the previous step's rows (this lane's 16 columns)
+        auto finish = [&](int sp, const u32x4& din0, const u32x4& din1) {   // input gradients of step sp (its dh tile is complete)
+            const int64_t rb = r_begin + 32 * (int64_t)sp;
             const int valid = (int)(r_end - rb) < 32 ? (int)(r_end - rb) : 32;
-            const bool has2 = s + 2 < nsteps;
-            const uint32_t sb = lds0 + (uint32_t)((s % NSTG) * STG_B);
             const bool row_ok = m < valid;
             // byte offset of this lane's 16 columns of its row, relative to row rb (rows past the end: the last row)
             const uint32_t rowoff = (uint32_t)(row_ok ? m : valid - 1) * (uint32_t)ld2 + (uint32_t)((c0 + 16 * h) * 2);
-            // Order of this wave's vector-memory operations: ... G(s+1) S(s-1) | L(s) [wait for G(s)] G(s+2) ... [wait for L(s)] ... S(s)
-            // (G = its stage requests, L = the dx1_in register loads, S = the four output stores), all counted by hand.
-            u32x4 din0, din1;
-            if constexpr (HAS_IN) {                                       // the incoming dx1 rows of this step, straight to registers
-                const uint8_t* bp = sbase(DXIN + rb * ld2);
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(din0) : "v"(rowoff), "s"(bp) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(din1) : "v"(rowoff), "s"(bp) : "memory");
-            }
-            step_top(s, (s > 0 ? 4 : 0) + NL);
-            wg_products(sb, I2{}, X2O{}, sb + a_xtr[0], sb + a_xtr[1], accA, -1);
-            wg_products(sb, I3{}, X1O{}, sb + a_xtr[0], sb + a_xtr[1], accG, -1);
-            // both input-gradient projections before the hand-off (role U is busy with the elementwise stage meanwhile)
-            f32x16 p2 = zero16(), p1 = zero16();
-            project(sb, I2{}, wA, p2);
-            project(sb, I3{}, wG, p1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                 // the U wave of these columns has written dh
-            // ---- dx2 = s2*dh + Wd^T dpre_a, dx1 = Wgd^T dpre_g (+ dx1_in): 32 bytes per lane and tensor
+            const uint32_t dh0 = lds0 + (uint32_t)(DH_OFF + (sp & 1) * 8192);
+            u32x4 dhv0, dhv1;
+            lds_read16<0>(dhv0, dh0 + a_xcl[0]); lds_read16<0>(dhv1, dh0 + a_xcl[1]);
+            lgkm_fence(dhv0); lgkm_tie(dhv1);
             {
-                u32x4 dh0, dh1;
-                lds_read16<0>(dh0, sb + a_xcl[0]); lds_read16<0>(dh1, sb + a_xcl[1]);
-                lgkm_fence(dh0); lgkm_tie(dh1);
                 float o[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) o[e] = s2 * bf_at(e < 8 ? dh0 : dh1, e & 7) + p2[e];
+                for (int e = 0; e < 16; ++e) o[e] = s2 * bf_at(e < 8 ? dhv0 : dhv1, e & 7) + p2[e];
                 const u32x4 v0 = pack8(o), v1 = pack8(o + 8);
                 if (row_ok) {
                     uint8_t* q2 = const_cast<uint8_t*>(sbase(reinterpret_cast<const uint8_t*>(a.dx2) + rb * ld2)) + rowoff;
@@ -439,9 +432,7 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
             }
             {
                 float o[16];
-                if constexpr (HAS_IN) {                                   // the dx1_in loads precede this step's requests and the dx2 stores
-                    vm_wait((has2 ? NW : 0) + 2);
-                    asm volatile("" : "+v"(din0), "+v"(din1) :: "memory");
+                if constexpr (HAS_IN) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) o[e] = p1[e] + bf_at(e < 8 ? din0 : din1, e & 7);
                 } else {
@@ -455,7 +446,25 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
                     reinterpret_cast<u32x4*>(q1)[1] = v1;
                 }
             }
+        };
+#pragma unroll 1
+        for (int s = 0; s < nsteps; ++s) {
+            const uint32_t sb = lds0 + (uint32_t)((s % NSTG) * STG_B);
+            step_top(s, s >= 2 ? 4 : 0);
+            if (s > 0) finish(s - 1, dinA, dinB);
+            if constexpr (HAS_IN) {
+                lds_read16<3 * 8192>(dinA, sb + a_xcl[0]); lds_read16<3 * 8192>(dinB, sb + a_xcl[1]);
+                lgkm_fence(dinA); lgkm_tie(dinB);
+            }
+            wg_products(sb, I2{}, X2O{}, sb + a_xtr[0], sb + a_xtr[1], accA, -1);
+            wg_products(sb, I3{}, X1O{}, sb + a_xtr[0], sb + a_xtr[1], accG, -1);
+            p2 = zero16(); p1 = zero16();
+            project(sb, I2{}, wA, p2);
+            project(sb, I3{}, wG, p1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        __builtin_amdgcn_s_barrier();                                     // role U has written the last dh tile
+        if (nsteps > 0) finish(nsteps - 1, dinA, dinB);
     }
     // ---- this row chunk's partial sums, in wgrad.hip's workspace layout (wgrad_finalize_kernel sums the chunks)
     {
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
 // Row chunks: (d / 128) column blocks x chunks workgroups, at most 32 per XCD (one per CU: the ring takes the LDS), i.e. at most
 // 8 * floor(32 / NCB) chunks; a chunk is a multiple of 32 rows.
 void k1_cols_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk) {
-    const int ncb = d / 128;
+    const int ncb = d >= 128 ? d / 128 : 1;             // (d < 128: the form does not apply; the plan only sizes workspaces)
     int64_t rc = 8 * (32 / (ncb < 32 ? ncb : 32));
     const int64_t blocks32 = (M + 31) / 32;
     if (rc > blocks32) rc = blocks32;
@@ -493,8 +502,8 @@ bool k1_cols_applies(const PetBwdArgs& a, int io_fp32) {
 
 template <int RT, bool ADD, bool HAS_IN>
 static hipError_t launch_cols_cfg(const ColzArgs& c, hipStream_t stream) {
-    constexpr int NSTG = 3;
-    const size_t lds = ColzGeo<RT>::lds(NSTG);
+    constexpr int NSTG = RT <= 1 ? 3 : 2;               // (r = 96: two 48-KiB stages + the dh / dq tiles = 121 KiB)
+    const size_t lds = ColzGeo<RT, HAS_IN>::lds(NSTG);
     auto kern = k1_cols_kernel<RT, NSTG, ADD, HAS_IN>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

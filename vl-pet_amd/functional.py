@@ -140,6 +140,9 @@ def pack_pair(down_w: Sequence[torch.Tensor], down_b: Optional[Sequence[torch.Te
 # keep the gated forward's bottleneck activations for the backward (vlpet_adapter_gate_fwd_save / _bwd_saved); False = the
 # backward recomputes them from x1, x2 (no extra memory between forward and backward)
 SAVE_ACTIVATIONS = True
+# A/B switch for benches and tests: True = the round-2 split of the gated K1 backward (row kernel that also writes dh / dq +
+# streaming weight-gradient kernel, ABI phases bit 2) instead of pass 1 + the column-parallel pass
+K1_BWD_PREVIOUS_SPLIT = False
 
 WEIGHTS_EPOCH = 0
 
@@ -519,11 +522,20 @@ class _AdapterGateFn(torch.autograd.Function):
                     rc = _timed("k1_bwd_wgrad", M, lambda: phase(2 | 4, sargs))
                 for t in (x1f, x2f, dyf, ws, pk_a.buf) + ((pk_g.buf,) if gate else ()) + ((act,) if act is not None else ()):
                     t.record_stream(side)        # the caching allocator must not recycle them under the side stream
+        elif K1_BWD_PREVIOUS_SPLIT:
+            rc = _timed("k1_bwd_rows", M, lambda: phase(1 | 4, args))
+            if rc == 0:
+                rc = _timed("k1_bwd_wgrad", M, lambda: phase(2 | 4, args))
         elif TIMER is None or not TIMER.wants("k1_bwd_rows"):
             rc = phase(3, args)
-        else:       # same work, the two halves bracketed separately
+        else:       # same work, its kernels bracketed separately
             rc = TIMER.bracket("k1_bwd_rows", M, lambda: phase(1, args))
-            if rc == 0:
+            two_pass = act is not None and lib.vlpet_adapter_gate_bwd_form(M, d, pk_a.tiles, io) == 2
+            if rc == 0 and two_pass:        # (pass 2 and the finalize launch of the column-parallel form)
+                rc = TIMER.bracket("k1_bwd_wgrad", M, lambda: phase(2 | 8, args))
+                if rc == 0:
+                    rc = TIMER.bracket("k1_bwd_fin", M, lambda: phase(16, args))
+            elif rc == 0:
                 rc = TIMER.bracket("k1_bwd_wgrad", M, lambda: phase(2, args))
         ctx.act = None
         _lib.check(rc, "vlpet_adapter_gate_bwd")
