@@ -234,6 +234,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--buckets", type=int, default=3)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to exercise the DP path on a 1-GPU box")
+    ap.add_argument("--pad-mask", action="store_true",
+                    help="build and apply the reference's default attention mask input_ids.ne(pad) every step (the synthetic rows have "
+                         "no pad tokens, so the default run tells the host to skip it)")
     ap.add_argument("--k1-previous-split", action="store_true",
                     help="A/B: the round-2 form of the gated K1 backward (row kernel + streaming weight gradients) instead of pass 1 + column-parallel pass")
     ap.add_argument("--overlap-wgrad", action="store_true",
@@ -311,7 +314,7 @@ def main():
             return gb
         return gb // n_ranks + (1 if rank < gb % n_ranks else 0)       # strong: partition the global task batch
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    batches = {t: TR.synthetic_batch(t, rank_batch(t), cfg, dev, gen) for t in tasks}
+    batches = {t: TR.synthetic_batch(t, rank_batch(t), cfg, dev, gen, no_padding=not args.pad_mask) for t in tasks}
     order = [tasks[i % len(tasks)] for i in range(args.warmup + args.steps)]
 
     for i in range(args.warmup):
@@ -353,6 +356,31 @@ def main():
         s = torch.tensor([samples], device=dev, dtype=torch.float64)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         samples = int(s.item())
+    # The reference's task batch is GLOBAL (multitask.py:682-695): with N > 1 ranks the same job is the strong-scaled one (the batch
+    # partitioned across the ranks, a few thousand encoder rows per rank).  The weak line above keeps the per-GPU work fixed, as
+    # the contract asks; the strong-scaled throughput of the same N ranks is measured right after it and reported beside it.
+    strong = None
+    if n_ranks > 1 and args.scaling == "weak":
+        sb = {t: TR.synthetic_batch(t, TR.TASK_BATCH[t](args.batch) // n_ranks + (1 if rank < TR.TASK_BATCH[t](args.batch) % n_ranks else 0),
+                                    cfg, dev, gen, no_padding=not args.pad_mask) for t in tasks}
+        for t_ in tasks:                              # new shapes: one untimed step per task
+            tr.step(sb[t_])
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_s = 0
+        for i in range(args.steps):
+            b = sb[tasks[i % len(tasks)]]
+            tr.step(b)
+            n_s += b["input_ids"].shape[0]
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        dts = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(dts, op=dist.ReduceOp.MAX)
+        ns = torch.tensor([n_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(ns, op=dist.ReduceOp.SUM)
+        strong = {"value": round(float(ns.item()) / float(dts.item()), 2), "unit": "samples/s", "scaling": "strong",
+                  "ms_per_step": round(float(dts.item()) / args.steps * 1e3, 3), "steps": args.steps,
+                  "global_task_batch": {t: TR.TASK_BATCH[t](args.batch) for t in tasks},
+                  "note": "same ranks, the reference's global task batch partitioned across them (timed after the weak region)"}
 
     if rank == 0:
         esz = 2 if dtype == torch.bfloat16 else 4
@@ -446,6 +474,8 @@ def main():
                        "enc_rows_per_step_rank0": enc_rows, "trainable_params": n_train, "parallelism": f"dp{n_ranks}",
                        "backend": args.backend if n_ranks > 1 else None},
             "roofline": roof, "kernels": kernels, "backbone_gemm_table": gemm_table,
+            **({"strong_scaling": strong} if strong is not None else {}),
+            **({"attention_mask": "default input_ids.ne(pad) mask built and applied every step (--pad-mask)"} if args.pad_mask else {}),
             "kernel_table": {"after": "roofline op bracketed inside the timed region; the other launch groups in one step per task after it",
                              "inline": "every launch group bracketed inside the timed region", "off": "roofline op only"}[args.kernel_table],
         }

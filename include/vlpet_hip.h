@@ -125,6 +125,10 @@ int vlpet_adapter_gate_bwd_phase(int phases, const void* dy, const void* x1, con
  * 0 = row kernel + weight-gradient kernels; < 0: bad arguments.  (What a bench labels its kernel brackets with.) */
 int vlpet_adapter_gate_bwd_form(int64_t M, int d, int tiles, int io_dtype);
 
+/* 1 for a diagnosis build (make DEBUG=1): the only builds whose kernels' experiment switches (csrc/tuning.h) can be set from
+ * VLPET_* environment variables, read once at load time.  The product library (0) reads nothing from the environment. */
+int vlpet_debug_build(void);
+
 /* vlpet_adapter_gate_bwd_phase with the activations saved by vlpet_adapter_gate_fwd_save (x1 is
  * still an argument because the gate's down-weight gradient contracts it).
  * It runs as TWO PASSES that move every [M, d] tensor once each (csrc/pet_gate_bwd3.hip pass 1, csrc/pet_cols.hip pass 2):

@@ -181,6 +181,9 @@ def test_six_wave_backward_variant_matches_the_default(monkeypatch):
     """The six-wave form of the backward (VLPET_ATTN_NW=6; measured slower, kept for A/B) is read once per process, so it is
     exercised in a child process: same gradients as the default for a six-unit shape."""
     import os, subprocess, sys
+    from vlpet_amd import _lib
+    if not _lib.load().vlpet_debug_build():
+        pytest.skip("experiment switches are compiled out of the product library (make DEBUG=1 for the A/B build)")
     code = (
         "import torch; from vlpet_amd.attention import short_attention\n"
         "g = torch.Generator().manual_seed(3)\n"

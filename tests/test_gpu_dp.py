@@ -119,3 +119,54 @@ def test_rccl_collectives_on_one_rank(tmp_path):
         if p.requires_grad:
             ref = p.detach().cpu()
             assert float((got[n] - ref).abs().max() / ref.abs().max().clamp_min(1e-3)) <= 2e-2, n
+
+
+def _rccl2_worker(rank, world, port, out):
+    import vlpet_amd.train as TR
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    cfg, model = _cfg_model()
+    model.cuda()
+    tr = TR.Trainer(model, cfg, lr=1e-2, total_steps=10, warmup_ratio=0.1, world_size=world, n_buckets=3)
+    for b in _batches(cfg, 8):
+        tr.step({k: (v.cuda() if torch.is_tensor(v) else tuple(t.cuda() for t in v) if k == "vis_inputs" else v)
+                 for k, v in _shard_cpu(b, rank, world).items()})
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({n: p.detach().cpu() for n, p in model.named_parameters() if p.requires_grad}, out)
+    dist.destroy_process_group()
+
+
+def _shard_cpu(b, rank, world):
+    out = {}
+    for k, v in b.items():
+        if torch.is_tensor(v):
+            out[k] = v.chunk(world)[rank]
+        elif k == "vis_inputs":
+            out[k] = tuple(t.chunk(world)[rank] for t in v)
+        else:
+            out[k] = v
+    return out
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: real RCCL buckets over xGMI (the 1-GPU test box skips)")
+def test_rccl_two_ranks_equal_one_rank(tmp_path):
+    """Two ranks on two GPUs over RCCL (backend "nccl"), half the batch each: the bucketed asynchronous all-reduce of the flat
+    trainable gradients + the fused optimizer's 1/world scaling land on the parameters of one rank with the whole batch.
+    The first multi-GPU box that runs `pytest -m gpu` exercises the real collectives; one-GPU boxes skip."""
+    import vlpet_amd.train as TR
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "rccl2.pt")
+    mp.spawn(_rccl2_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    cfg, model = _cfg_model()
+    model.cuda()
+    tr = TR.Trainer(model, cfg, lr=1e-2, total_steps=10, warmup_ratio=0.1)
+    for b in _batches(cfg, 8):
+        tr.step(_shard(b, 0, 1))
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            ref = p.detach().cpu()
+            assert float((got[n] - ref).abs().max() / ref.abs().max().clamp_min(1e-3)) <= 2e-2, n

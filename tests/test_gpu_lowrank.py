@@ -22,7 +22,12 @@ from oracle import vlpet_oracle as O  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
-TOL = {torch.float32: (1e-3, 1e-3), torch.bfloat16: (2e-2, 5e-2)}      # (output, parameter gradients)
+# BASELINE.json's bounds (max-abs error over max-abs reference per tensor): 1e-3 fp32 / 1e-2 bf16, output and parameter gradients.
+# Measured on MI355X (round 3, pytest -s prints them): bf16 output 4.1-5.7e-3, parameter gradients <= 5e-3 per tensor.
+TOL = {torch.float32: (1e-3, 1e-3), torch.bfloat16: (1e-2, 1e-2)}
+# ... and the bias / LayerNorm gradients additionally element by element against each column's own magnitude (rel_el): a column sum
+# over 1,332 rows of terms rounded to bf16 three times (dh, dq, dpre) -- measured <= 6.2e-2 in bf16, <= 2e-3 in fp32
+EL_TOL = {torch.float32: 5e-3, torch.bfloat16: 1e-1}
 
 
 def rel_el(got, ref, floor=0.02):
@@ -110,14 +115,16 @@ def test_lowrank_real_geometry_vs_oracle(form, dtype, F_, r, nh, rg):
     ve.cuda()
     out = ve(feats.cuda(), pos.cuda())
     t_out, t_g = TOL[dtype]
+    print(f"[measured] lowrank {form} {F_}->{r}/{rg} {dtype}: out {rel_err(out, ref_out):.2e}")
     assert rel_err(out, ref_out) <= t_out
     out.backward(dy.cuda())
     for n, p in ve.named_parameters():
         if "obj_order" in n:
             continue
+        print(f"[measured]    d{n} {rel_err(p.grad, ref_g[n]):.2e}")
         assert rel_err(p.grad, ref_g[n]) <= t_g, n
     # bias and LayerNorm gradients element by element (column sums: a wrong column hides under a per-tensor norm)
-    el_tol = 5 * t_g
+    el_tol = EL_TOL[dtype]
     for n in ["visual_projector_multihead_up.bias", "visual_projector_layer_norm.weight", "visual_projector_layer_norm.bias"] + \
              [f"visual_projector_multihead_down.{i}.bias" for i in range(nh)] + \
              (["visual_projector_gating_large_x_down.bias", "visual_projector_gating_large_x_up.bias"] if gated else []):
@@ -207,11 +214,13 @@ def test_lowrank_full_bench_rows_bf16():
     ref_out, ref_g = oracle_run(ve, table, nh, True, False, feats, pos, dy)
     ve.cuda()
     out = ve(feats.cuda(), pos.cuda())
-    assert rel_err(out, ref_out) <= 2e-2
+    print(f"[measured] lowrank M={B * N} bf16: out {rel_err(out, ref_out):.2e}")
+    assert rel_err(out, ref_out) <= 1e-2
     out.backward(dy.cuda())
     for n, p in ve.named_parameters():
         if "obj_order" not in n:
-            assert rel_err(p.grad, ref_g[n]) <= 5e-2, n
+            print(f"[measured]    d{n} {rel_err(p.grad, ref_g[n]):.2e}")
+            assert rel_err(p.grad, ref_g[n]) <= 1e-2, (n, rel_err(p.grad, ref_g[n]))
 
 
 def test_lowrank_repack_after_weight_change_and_inference_form():

@@ -258,7 +258,7 @@ def test_apply_pet_wide_bottleneck(dtype, add, gs):
             assert rel(y, ref.detach()) <= tol, ("y", split)
             assert rel(X1.grad, x1r.grad) <= tol and rel(X2.grad, x2r.grad) <= tol, ("dx", split)
             for n, p in m.named_parameters():
-                assert rel(p.grad, P[n].grad) <= (tol if dtype == torch.float32 else 2e-2), (n, split)
+                assert rel(p.grad, P[n].grad) <= tol, (n, split, rel(p.grad, P[n].grad))
         finally:
             EP.SPLIT_WIDE_BOTTLENECK = False      # the default: fused 6-tile kernels
 

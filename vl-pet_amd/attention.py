@@ -35,7 +35,8 @@ class _AttnFn(torch.autograd.Function):
         Lk = k.shape[1]
         o = torch.empty_like(q)
         lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
-        keep = torch.empty(B, H, Lq, Lk, dtype=torch.uint8, device=q.device) if want_mask else None
+        # (the kernel writes the mask only when it drops something: without dropout every element is kept)
+        keep = torch.ones(B, H, Lq, Lk, dtype=torch.uint8, device=q.device) if want_mask else None
         rc = _timed("attn_fwd", B * Lq, lambda: lib.vlpet_attn_fwd(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(key_mask), o.data_ptr(), lse.data_ptr(), _ptr(keep),
             B, H, Lq, Lk, int(causal), float(scale), float(p), seed, _stream()))

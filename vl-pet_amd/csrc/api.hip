@@ -15,6 +15,7 @@ static inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 static inline int herr(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 
 extern "C" int vlpet_version(void) { return VLPET_VERSION; }
+extern "C" int vlpet_debug_build(void) { return VLPET_IS_DEBUG_BUILD; }
 
 extern "C" const char* vlpet_error_string(int code) {
     switch (code) {
@@ -164,7 +165,7 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
     a.dbg_ts = nullptr;
     a.d_in = 0; a.pk_a_dn = nullptr; a.pk_g_dn = nullptr; a.gm = 1.f; a.go = 0.f;
 #ifdef VLPET_DEBUG      // ablation bits / cycle stamps: debug builds only (function-static device buffer, synchronises, prints)
-    { const char* e = getenv("VLPET_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = vlpet_tuning().dbg;
     if (a.dbg & 16) {     // debug only: per-phase timestamps of wave 0 of every block, printed at the next call
         static unsigned long long* dev = nullptr;
         static int nblk = 0;

@@ -423,8 +423,8 @@ hipError_t launch_attn(const AttnArgs& a, bool bwd, hipStream_t stream) {
     }
     const int Lqp = (a.Lq + 31) & ~31, Lkp = (a.Lk + 31) & ~31;
     const int units = (Lqp >> 5) + (Lkp >> 5);
-    static const int occ_env = [] { const char* e = getenv("VLPET_ATTN_OCC"); return e ? atoi(e) : 0; }();
-    static const int nw_env = [] { const char* e = getenv("VLPET_ATTN_NW"); return e ? atoi(e) : 0; }();
+    const int occ_env = vlpet_tuning().attn_occ;
+    const int nw_env = vlpet_tuning().attn_nw;
     // Five or six units (sequences of 65-96 tokens) on six waves, one unit each, two such workgroups per CU (three waves per SIMD on
     // the 168-register build) instead of four waves taking a full round and a half-empty one: parity-green and SLOWER (238 vs 203 us
     // at B = 416, S = 76; 97 vs 92 at B = 166, S = 92, profiles/r02_attnbench2_s4_six_waves.txt) -- the workgroup still stages, waits,

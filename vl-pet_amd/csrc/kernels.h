@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "rng.h"
+#include "tuning.h"
 
 #define VLPET_MAX_HEADS 16
 
@@ -264,10 +265,7 @@ int optim_blocks(int64_t n);
 // two rounds of 96 rows instead of two of 128); at M = 15,272 it is 2 (239 workgroups in one round instead of
 // 120 CUs working and 136 idle).
 inline int pick_row_groups(int64_t M, int max_rg, int min_rg) {
-    if (const char* e = getenv("VLPET_RG")) {          // experiments: force the workgroup size
-        const int rg = atoi(e);
-        if (rg >= min_rg && rg <= max_rg) return rg;
-    }
+    if (const int rg = vlpet_tuning().rg; rg >= min_rg && rg <= max_rg && rg > 0) return rg;       // (diagnosis builds only)
     int best = max_rg;
     int64_t best_cost = -1;
     for (int rg = max_rg; rg >= min_rg; --rg) {

@@ -639,7 +639,7 @@ static hipError_t launch_one(const PetBwdArgs& a, hipStream_t stream) {
     const int blocks = (int)((a.M + rows - 1) / rows);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), lds, stream, a);
 #ifdef VLPET_STAMPS
-    if (const char* e = getenv("VLPET_DBG"); e && (atoi(e) & 16) && GATE) {
+    if ((vlpet_tuning().dbg & 16) && GATE) {
         (void)hipDeviceSynchronize();
         unsigned long long t[64];
         (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_bwd_ts), sizeof(t));

@@ -80,7 +80,6 @@ __global__ __launch_bounds__(RG * 128) void pet_gate_bwd2_kernel(PetBwdArgs a) {
     const int64_t grow = row_ok ? grow_raw : a.M - 1;
     const int S = d / G::FE;
     const PackGeom pg = pack_geom(RT, d, NS);
-    const uint8_t* pk = isA ? a.pk_a : a.pk_g;                  // this chain's packed pair
     const uint8_t* res = reinterpret_cast<const uint8_t*>(a.res);
     const uint8_t* dy = reinterpret_cast<const uint8_t*>(a.dy);
     uint8_t* DH = reinterpret_cast<uint8_t*>(a.dh);
@@ -414,9 +413,9 @@ static hipError_t launch_one(const PetBwdArgs& a, hipStream_t stream) {
     const int blocks = (int)((a.M + rows - 1) / rows);
 #ifdef VLPET_STAMPS
     PetBwdArgs b = a;
-    { const char* e = getenv("VLPET_DBG"); if (e && (atoi(e) & 128)) b.flags |= 1 << 20; }
+    if (vlpet_tuning().dbg & 128) b.flags |= 1 << 20;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(RG * 128), lds, stream, b);
-    if (const char* e = getenv("VLPET_DBG"); e && (atoi(e) & 16)) {
+    if (vlpet_tuning().dbg & 16) {
         (void)hipDeviceSynchronize();
         unsigned long long t[64];
         (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_b2_ts), sizeof(t));
@@ -444,8 +443,7 @@ static hipError_t launch_rt(const PetBwdArgs& a, hipStream_t stream) {
 
 // true when this form applies: gated K1, saved activations, r <= 96, every dimension it was written for
 bool pet_gate_bwd2_applies(const PetBwdArgs& a) {
-    static const bool off = [] { const char* e = getenv("VLPET_BWD2"); return e != nullptr && atoi(e) == 0; }();
-    if (off) return false;
+    if (vlpet_tuning().bwd2 == 0) return false;
     return (a.flags & PET_GATE) && a.saved != nullptr && !drop_active(a.drop) && (a.RT == 1 || a.RT == 3);
 }
 

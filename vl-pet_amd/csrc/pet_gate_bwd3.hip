@@ -1152,7 +1152,7 @@ void gate_bwd3_plan(int64_t M, int d, int io_fp32, int* row_chunks, int64_t* row
     for (int g = 1; g <= 8 && g <= S; ++g) if (S % g == 0) gs = g;   // feature blocks that share an XCD's L2
     const int ng = S / gs;
     // one workgroup (512 threads, ~130 KiB of LDS) per CU and 32 CUs per XCD: floor(32 / gs) groups per XCD
-    static const int target_units = [] { const char* e = getenv("VLPET_BWD3_UNITS"); return e ? atoi(e) : 0; }();
+    const int target_units = vlpet_tuning().bwd3_units;
     const int units = target_units > 0 ? target_units : 8 * (32 / gs);
     int64_t rc = units / ng;
     if (rc < 1) rc = 1;
@@ -1169,7 +1169,7 @@ static inline bool bwd3_rt_ok(int RT) { return RT == 1 || RT == 3 || RT == 6; }
 // MI355X despite its 11 units of traffic (164 us vs 234 us at M = 28,000): pass 2 is latency-chain bound (see launch_cols_one).
 // VLPET_BWD3 = 1 / 0 forces it on / off for every supported rank.
 bool pet_gate_bwd3_applies(const PetBwdArgs& a) {
-    static const int force = [] { const char* e = getenv("VLPET_BWD3"); return e == nullptr ? -1 : atoi(e); }();
+    const int force = vlpet_tuning().bwd3;
     if (force == 0) return false;
     if (!((a.flags & PET_GATE) && a.saved != nullptr && !drop_active(a.drop) && bwd3_rt_ok(a.RT))) return false;
     // small M (a strong-scaled rank: a few thousand rows): both forms are latency chains of a handful of workgroups, and the
@@ -1240,7 +1240,7 @@ template <typename IO, int RT>
 static hipError_t launch_cols_one(const ColsArgs& c, hipStream_t stream) {
     // VLPET_BWD3_FORM: 0 = four roles per row group (4 waves, one tile at a time); 1 (default for r <= 96) = two waves per row
     // group, two row groups per workgroup (198.8 -> 137.2 us at M = 28 k, 58.9 -> 55.0 at 3.5 k; profiles/r02_kbench_pass2_forms.txt)
-    static const int form = [] { const char* e = getenv("VLPET_BWD3_FORM"); return e ? atoi(e) : 1; }();
+    const int form = vlpet_tuning().bwd3_form;
     if constexpr (RT == 3) {
         if (form == 1) return launch_cols2_cfg<IO, RT, 2, 2>(c, stream);
         if (form == 2) return launch_cols2_cfg<IO, RT, 2, 3>(c, stream);

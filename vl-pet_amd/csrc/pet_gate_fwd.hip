@@ -402,7 +402,7 @@ static hipError_t launch_rt(const PetFwdArgs& a, hipStream_t stream) {
         // 96-row workgroups -- 9 waves, uneven over the 4 SIMDs -- are the slowest form at every size, and two rounds of
         // 128 rows beat three of 64); the backward rows kernel follows pick_row_groups' cost model
         int rg = a.M <= 256 * 64 ? 2 : 4;
-        static const int rg_env = [] { const char* e = getenv("VLPET_RG"); return e ? atoi(e) : 0; }();   // (A/B override, read once)
+        const int rg_env = vlpet_tuning().rg;     // (A/B override: diagnosis builds only)
         if (rg_env >= 2 && rg_env <= 4) rg = rg_env;
         switch (rg) {
             case 4: return add ? launch_one<IO, RT, true, 4, true>(a, stream) : launch_one<IO, RT, false, 4, true>(a, stream);

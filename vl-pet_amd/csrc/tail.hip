@@ -418,7 +418,7 @@ hipError_t launch_tail_reduce(const float* part, int nb, int d, float* dgamma, f
 
 int tail_blocks(int64_t M) {
     const int64_t need = (M + TAIL_WAVES - 1) / TAIL_WAVES;
-    static const int64_t cap = [] { const char* e = getenv("VLPET_TAIL_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)(256 * 3); }();   // 3 workgroups of 4 waves per CU (with the row prefetch: best of 256 .. 2048; fewer partial sums)
+    const int64_t cap = 256 * 3;   // 3 workgroups of 4 waves per CU (with the row prefetch: best of 256 .. 2048; fewer partial sums)
     return (int)(need < cap ? need : cap);
 }
 

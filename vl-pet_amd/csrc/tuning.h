@@ -1,0 +1,42 @@
+// Experiment switches of the kernels (alternative kernels / plans kept for A/B measurements).
+// The product library reads NOTHING from the environment: every switch below is a constant.  Only a diagnosis build
+// (make DEBUG=1: -DVLPET_DEBUG, what tools/ uses for same-box A/Bs and what the tests of the alternatives ask for via
+// vlpet_debug_build()) fills the table from VLPET_* variables, once, when the library is loaded.
+#pragma once
+#include <cstdlib>
+
+struct VlpetTuning {
+    int rg = 0;             // VLPET_RG: force the row groups per workgroup of the row kernels (0: pick_row_groups)
+    int bwd2 = 1;           // VLPET_BWD2=0: single-wave row kernel instead of the chain-split one
+    int bwd3 = -1;          // VLPET_BWD3=1|0: older two-pass form always / never (-1: r = 192 and M <= 4096)
+    int bwd3_units = 0;     // VLPET_BWD3_UNITS: row chunks of the older pass 2
+    int bwd3_form = 1;      // VLPET_BWD3_FORM: 0 = four-role form of the older pass 2
+    int k4_waves4 = 0;      // VLPET_K4_WAVES4=1: the 4-wave K4 forward
+    int wgrad_wgs = 0;      // VLPET_WGRAD_WGS: workgroup target of the weight-gradient plan (0: one per CU, XCD-bounded)
+    int wgrad_tr = 1;       // VLPET_WGRAD_TR=0: identity-transpose weight-gradient kernel
+    int wgrad_stream = 1;   // VLPET_WGRAD_STREAM=0: per-wave transpose-read kernel instead of the streaming one
+    int wgrad_nstg = 3;     // VLPET_WGRAD_NSTG=4: ring depth of the streaming kernel
+    int wgs_mode = 0;       // VLPET_WGS_MODE: ablation bits of the streaming kernel (needs -DVLPET_WGRAD_EXP as well)
+    int attn_occ = 0;       // VLPET_ATTN_OCC=2|3: waves per SIMD of the attention backward (0: by shape)
+    int attn_nw = 0;        // VLPET_ATTN_NW=6: six-wave attention backward
+    int dbg = 0;            // VLPET_DBG: ablation / stamp bits
+};
+
+#ifdef VLPET_DEBUG
+inline const VlpetTuning& vlpet_tuning() {
+    static const VlpetTuning t = [] {
+        VlpetTuning v;
+        auto rd = [](const char* n, int& dst) { if (const char* e = getenv(n)) dst = atoi(e); };
+        rd("VLPET_RG", v.rg); rd("VLPET_BWD2", v.bwd2); rd("VLPET_BWD3", v.bwd3); rd("VLPET_BWD3_UNITS", v.bwd3_units);
+        rd("VLPET_BWD3_FORM", v.bwd3_form); rd("VLPET_K4_WAVES4", v.k4_waves4); rd("VLPET_WGRAD_WGS", v.wgrad_wgs);
+        rd("VLPET_WGRAD_TR", v.wgrad_tr); rd("VLPET_WGRAD_STREAM", v.wgrad_stream); rd("VLPET_WGRAD_NSTG", v.wgrad_nstg);
+        rd("VLPET_WGS_MODE", v.wgs_mode); rd("VLPET_ATTN_OCC", v.attn_occ); rd("VLPET_ATTN_NW", v.attn_nw); rd("VLPET_DBG", v.dbg);
+        return v;
+    }();
+    return t;
+}
+#define VLPET_IS_DEBUG_BUILD 1
+#else
+inline const VlpetTuning& vlpet_tuning() { static const VlpetTuning t{}; return t; }
+#define VLPET_IS_DEBUG_BUILD 0
+#endif

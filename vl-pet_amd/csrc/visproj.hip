@@ -432,7 +432,7 @@ static hipError_t launch_io(const VisprojArgs& a, hipStream_t stream) {
         case 64: return launch_nct<IO, 2>(a, stream);
         case 128: return launch_nct<IO, 4>(a, stream);
         case 768: {
-            static const bool old_form = [] { const char* e = getenv("VLPET_K4_WAVES4"); return e != nullptr && atoi(e) != 0; }();
+            const bool old_form = vlpet_tuning().k4_waves4 != 0;
             return old_form ? launch_nct<IO, 24>(a, stream) : launch_nct2<IO, 24>(a, stream);      // (VLPET_K4_WAVES4=1: A/B)
         }
         default: return hipErrorInvalidValue;

@@ -27,7 +27,7 @@ void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* r
     // from the same plan).
     const int slabs = (xcols_max + 255) / 256;
     int64_t blocks128 = (M + 127) / 128;
-    static const int64_t target = [] { const char* e = getenv("VLPET_WGRAD_WGS"); return e ? (int64_t)atoi(e) : (int64_t)256; }();
+    const int64_t target = vlpet_tuning().wgrad_wgs > 0 ? vlpet_tuning().wgrad_wgs : 256;
     int64_t rc = (target + (int64_t)slabs * njobs / 2) / ((int64_t)slabs * njobs);
     if (rc < 1) rc = 1;
     // ... and never more row chunks than put ONE workgroup on every CU of an XCD: the grid is numbered XCD-aware (wg_grid:
@@ -36,7 +36,7 @@ void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* r
     // late: cold-input timings (tools/k1bench.py K1BENCH_COLD=1, profiles/r02_wgrad_cold_crossover.txt) jump by 25-40 %
     // exactly where the plan says 21 (M = 24,000: 94.6 us, 31,616: 116.9) against 20 (28,000: 82.9, 33,200: 93.4).
     // Applies to the default target only (an explicit VLPET_WGRAD_WGS is taken as given).
-    static const bool explicit_target = getenv("VLPET_WGRAD_WGS") != nullptr;
+    const bool explicit_target = vlpet_tuning().wgrad_wgs > 0;
     if (!explicit_target) {
         const int64_t per_xcd = 32 / (slabs < 32 ? slabs : 32);              // (job, chunk) groups per XCD at one workgroup per CU
         const int64_t rc_max = per_xcd > 0 ? (8 * per_xcd) / njobs : 1;
@@ -858,18 +858,18 @@ static hipError_t launch_one(const WgradArgs& a, hipStream_t stream) {
     // transposes, no fp32 -> bf16 re-conversion).  Round 2, after the XCD-aware numbering: 83.0 vs 86.7 us at M = 28 k,
     // and in the bench 96.6 vs 104.3 us per K1 call, 235 vs 279 us for the K4 weight gradient (16,415 vs 16,319 samples/s;
     // profiles/r02_kbench_wgrad_variants.txt).  VLPET_WGRAD_TR=0 selects the identity-transpose kernel.
-    static const bool use_tr = [] { const char* e = getenv("VLPET_WGRAD_TR"); return e == nullptr || atoi(e) != 0; }();
+    const bool use_tr = vlpet_tuning().wgrad_tr != 0;
     hipError_t e;
     // bf16, no dropout mask: the streaming kernel (256-column slabs, LDS-DMA ring).  VLPET_WGRAD_STREAM=0 falls back to the
     // per-wave transpose-read kernel below (A/B).
-    static const bool use_stream = [] { const char* e = getenv("VLPET_WGRAD_STREAM"); return e == nullptr || atoi(e) != 0; }();
+    const bool use_stream = vlpet_tuning().wgrad_stream != 0;
     if constexpr (std::is_same<IO, __bf16>::value) {
         if (plain && use_stream) {
             // ring depth: 3 stages (72 KiB at RT = 3: two workgroups per CU); VLPET_WGRAD_NSTG=4 for A/B (one per CU, one more stage in flight)
-            static const int nstg = [] { const char* e = getenv("VLPET_WGRAD_NSTG"); return e ? atoi(e) : 3; }();
+            const int nstg = vlpet_tuning().wgrad_nstg;
             WgradArgs b = a; b.nslice = (xmax + 255) / 256;
 #ifdef VLPET_WGRAD_EXP
-            { const char* e2 = getenv("VLPET_WGS_MODE"); if (e2) b.RT |= atoi(e2) << 8; }
+            b.RT |= vlpet_tuning().wgs_mode << 8;
 #endif
             auto go = [&](auto kern, int NSTG) -> hipError_t {
                 const size_t lds = (size_t)NSTG * WgsGeo<RT>::STG_B;

@@ -104,7 +104,7 @@ def cast_frozen(model: nn.Module, dtype: torch.dtype):
 
 
 # ------------------------------------------------------------------ synthetic data
-def synthetic_batch(task: str, batch: int, config, device, gen: torch.Generator, feat_dtype=torch.float32):
+def synthetic_batch(task: str, batch: int, config, device, gen: torch.Generator, feat_dtype=torch.float32, no_padding: bool = True):
     """Synthetic CLIP-feature + token batch with the reference loaders' shapes:
     RN101 grid 7x7 = 49 features of 2048, zero boxes, fixed-length text, short targets."""
     V = config.vocab_size - 200
@@ -116,7 +116,7 @@ def synthetic_batch(task: str, batch: int, config, device, gen: torch.Generator,
         # [B, 64, feat_dim = 512] frame features, zero boxes (multitask_video.py:738; video/video_model.py:34-36)
         feats = torch.randn(batch, VIDEO_FRAMES, int(config.feat_dim), device=device, generator=gen, dtype=feat_dtype)
         boxes = torch.zeros(batch, VIDEO_FRAMES, 4, device=device, dtype=feat_dtype)
-        return dict(task=task, input_ids=ids, vis_inputs=(feats, boxes), labels=labels, scores=None, no_padding=True)
+        return dict(task=task, input_ids=ids, vis_inputs=(feats, boxes), labels=labels, scores=None, no_padding=no_padding)
     if task == "nlvr":
         feats = torch.randn(batch, 2 * n_grid, int(config.feat_dim), device=device, generator=gen, dtype=feat_dtype)
         boxes = torch.zeros(batch, 2 * n_grid, 4, device=device, dtype=feat_dtype)
@@ -127,9 +127,11 @@ def synthetic_batch(task: str, batch: int, config, device, gen: torch.Generator,
         feats = torch.randn(batch, n_grid, int(config.feat_dim), device=device, generator=gen, dtype=feat_dtype)
         boxes = torch.zeros(batch, n_grid, 4, device=device, dtype=feat_dtype)
         vis = (feats, boxes)
-    # ids are drawn from [5, V): no pad token (id 1) occurs, every row has the full length
+    # ids are drawn from [5, V): no pad token (id 1) occurs, every row has the full length.  no_padding = True tells the host
+    # that (it then skips building the all-ones input_ids.ne(pad) mask); False = the reference's default path, which builds
+    # and applies the mask every step (src/modeling_bart.py:817-818, 995-996)
     return dict(task=task, input_ids=ids, vis_inputs=vis, labels=labels,
-                scores=torch.ones(batch, device=device), no_padding=True)
+                scores=torch.ones(batch, device=device), no_padding=no_padding)
 
 
 def epoch_task_order(tasks: Sequence[str], steps_per_task: Dict[str, int], epoch: int) -> List[str]:
@@ -442,7 +444,11 @@ class FusedAdamW:
                 so[a:b] = k
             self.slice_of = so.to(dev)
             self.steps = [0] * len(flat.slices)
-            self.bc_host = torch.zeros(len(flat.slices), 2, dtype=torch.float32).pin_memory()
+            # the per-parameter bias corrections travel host -> device every step through a small ring of pinned buffers: the
+            # copy is asynchronous and the trainer never syncs with the GPU, so a single staging buffer could be rewritten by the
+            # host (one step ahead) before the previous step's DMA had read it; each slot's event says when it is free again
+            self._bc_ring = [torch.zeros(len(flat.slices), 2, dtype=torch.float32).pin_memory() for _ in range(4)]
+            self._bc_free = [None] * len(self._bc_ring)
             self.bc_dev = torch.zeros(len(flat.slices), 2, dtype=torch.float32, device=dev)
 
     def step(self, lr: Optional[float] = None):
@@ -456,14 +462,21 @@ class FusedAdamW:
         _lib.check(rc, "vlpet_grad_sumsq")
         if self.sliced:
             b1, b2 = self.betas
+            slot = self.t % len(self._bc_ring)
+            if self._bc_free[slot] is not None:
+                self._bc_free[slot].synchronize()       # (only ever waits when the host is a whole ring ahead of the GPU)
+            bc_host = self._bc_ring[slot]
             for k, on in enumerate(f.active()):
                 if on:
                     self.steps[k] += 1
-                    self.bc_host[k, 0] = 1.0 - b1 ** self.steps[k]
-                    self.bc_host[k, 1] = math.sqrt(1.0 - b2 ** self.steps[k])
+                    bc_host[k, 0] = 1.0 - b1 ** self.steps[k]
+                    bc_host[k, 1] = math.sqrt(1.0 - b2 ** self.steps[k])
                 else:
-                    self.bc_host[k, 0] = -1.0
-            self.bc_dev.copy_(self.bc_host, non_blocking=True)
+                    bc_host[k, 0] = -1.0
+            self.bc_dev.copy_(bc_host, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._bc_free[slot] = ev
             rc = self.lib.vlpet_adamw_step_sliced(
                 f.flat_p.data_ptr(), f.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.decay.data_ptr(), n,
                 self.partials.data_ptr(), self.nb, float(self.max_norm), 1.0 / f.world_size,
