@@ -110,6 +110,16 @@ __device__ __forceinline__ float sigm(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+#ifndef VLPET_COLS_GRP
+#define VLPET_COLS_GRP 6
+#endif
+#ifndef VLPET_COLS_WGBOTH
+#define VLPET_COLS_WGBOTH 1
+#endif
+#ifndef VLPET_COLS_EWAHEAD
+#define VLPET_COLS_EWAHEAD 1
+#endif
+
 template <int RT, int NSTG, bool ADD, bool HAS_IN>
 __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
     using GEO = ColzGeo<RT, HAS_IN>;
@@ -117,7 +127,11 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
     constexpr int DH_OFF = NSTG * STG_B, DQ_OFF = DH_OFF + 2 * 8192, BIAS_OFF = DQ_OFF + GEO::DQ_B;
     constexpr int PR = 32 * RT;
     constexpr int NW = NX + RT;                         // global_load_lds instructions per wave and stage
-    constexpr int GRP = RT == 1 ? 2 : 3;                // B fragments requested per batch of a projection
+    // LDS round trips are what a step's instruction stream waits for (a wave alone covers none of them), so operands are
+    // requested in batches as large as the registers allow and each batch is waited for once:
+    constexpr int GRP = VLPET_COLS_GRP < KT ? (KT % VLPET_COLS_GRP == 0 ? VLPET_COLS_GRP : KT) : KT;   // B fragments per batch of a projection
+    constexpr bool WG_BOTH = VLPET_COLS_WGBOTH != 0;    // both 16-row k-steps of a weight-gradient job in one batch
+    constexpr bool EW_AHEAD = VLPET_COLS_EWAHEAD != 0;  // all dy / x2 pieces of the elementwise stage requested at once
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     // ---- which (column block, row chunk): the column blocks of a row chunk share an XCD (they re-read the same bottleneck rows)
@@ -285,17 +299,35 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
     // time (4 operands = 16 registers in flight)
     auto wg_products = [&](uint32_t sb, auto TPC, auto XOC, uint32_t xlo, uint32_t xhi, f32x16* acc, int slot) {
         constexpr int TP = decltype(TPC)::value, XO = decltype(XOC)::value;
-        sfor<2>([&](auto KS) {
-            constexpr int ks = KS.value;
-            TrOp bx, ap[RT];
-            tr_read2<XO + ks * 16 * 128>(bx, xlo, xhi);
-            sfor<RT>([&](auto CT) { tr_read2<TP * PT_B + 64 * CT.value + ks * 16 * PB>(ap[CT.value], sb + a_ptr[0], sb + a_ptr[1]); });
-            tr_fence(bx);
-            const bf16x8 vx = tr_val(bx);
-            if (slot >= 0) sx = mfma32(ones_row(slot), vx, sx);
+        if constexpr (WG_BOTH) {
+            TrOp bx[2], ap[2][RT];
+            sfor<2>([&](auto KS) {
+                constexpr int ks = KS.value;
+                tr_read2<XO + ks * 16 * 128>(bx[ks], xlo, xhi);
+                sfor<RT>([&](auto CT) { tr_read2<TP * PT_B + 64 * CT.value + ks * 16 * PB>(ap[ks][CT.value], sb + a_ptr[0], sb + a_ptr[1]); });
+            });
+            tr_fence(bx[0]);
 #pragma unroll
-            for (int ct = 0; ct < RT; ++ct) { tr_tie(ap[ct]); acc[ct] = mfma32(tr_val(ap[ct]), vx, acc[ct]); }
-        });
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks) tr_tie(bx[ks]);
+                const bf16x8 vx = tr_val(bx[ks]);
+                if (slot >= 0) sx = mfma32(ones_row(slot), vx, sx);
+#pragma unroll
+                for (int ct = 0; ct < RT; ++ct) { tr_tie(ap[ks][ct]); acc[ct] = mfma32(tr_val(ap[ks][ct]), vx, acc[ct]); }
+            }
+        } else {
+            sfor<2>([&](auto KS) {
+                constexpr int ks = KS.value;
+                TrOp bx, ap[RT];
+                tr_read2<XO + ks * 16 * 128>(bx, xlo, xhi);
+                sfor<RT>([&](auto CT) { tr_read2<TP * PT_B + 64 * CT.value + ks * 16 * PB>(ap[CT.value], sb + a_ptr[0], sb + a_ptr[1]); });
+                tr_fence(bx);
+                const bf16x8 vx = tr_val(bx);
+                if (slot >= 0) sx = mfma32(ones_row(slot), vx, sx);
+#pragma unroll
+                for (int ct = 0; ct < RT; ++ct) { tr_tie(ap[ct]); acc[ct] = mfma32(tr_val(ap[ct]), vx, acc[ct]); }
+            });
+        }
     };
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // weights in registers, biases in LDS
@@ -318,43 +350,66 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
             const uint32_t sb = lds0 + (uint32_t)((s % NSTG) * STG_B);
             const uint32_t dh0 = lds0 + (uint32_t)(DH_OFF + (s & 1) * 8192);
             step_top(s, 0);
-            auto load_bias = [&](auto OC, f32x16& acc) {
-                u32x4 bb[4];
+            // up projection of one chain, starting at its bias: the bias values and the first batch of B fragments are one LDS batch
+            auto project_up = [&](auto TC, auto OC, const bf16x8* w, f32x16& acc) {
+                constexpr int T = decltype(TC)::value;
+                u32x4 bb[4], bf0[GRP];
                 sfor<4>([&](auto Q) { lds_read16<decltype(OC)::value + 16 * Q.value>(bb[Q.value], a_bias); });
+                sfor<GRP>([&](auto K) { lds_read16<T * PT_B + 64 * (K.value >> 1)>(bf0[K.value], sb + a_pbf[K.value & 1]); });
                 lgkm_fence(bb[0]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (q) lgkm_tie(bb[q]);
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) acc[4 * q + w] = __uint_as_float(bb[q][w]);
+                    for (int w2 = 0; w2 < 4; ++w2) acc[4 * q + w2] = __uint_as_float(bb[q][w2]);
                 }
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) { lgkm_tie(bf0[k]); acc = mfma32(w[k], as_bf(bf0[k]), acc); }
+                sfor<KT / GRP - 1>([&](auto G) {
+                    u32x4 bf[GRP];
+                    sfor<GRP>([&](auto K) {
+                        constexpr int ks = (G.value + 1) * GRP + K.value;
+                        lds_read16<T * PT_B + 64 * (ks >> 1)>(bf[K.value], sb + a_pbf[ks & 1]);
+                    });
+                    lgkm_fence(bf[0]);
+#pragma unroll
+                    for (int k = 0; k < GRP; ++k) { if (k) lgkm_tie(bf[k]); acc = mfma32(w[(G.value + 1) * GRP + k], as_bf(bf[k]), acc); }
+                });
             };
             {
-                f32x16 aA, aG;                                            // both up projections, starting at the biases
-                load_bias(I0{}, aA);
-                project(sb, I0{}, wA, aA);
-                load_bias(std::integral_constant<int, 512>{}, aG);
-                project(sb, I1{}, wG, aG);
+                f32x16 aA, aG;                                            // both up projections
+                project_up(I0{}, I0{}, wA, aA);
+                project_up(I1{}, std::integral_constant<int, 512>{}, wG, aG);
                 const float gsr = m < valid ? a.gs : 0.f;                 // rows past the end: dh = dq = 0
+                u32x2 dyv[4], x2v[4];
+                if constexpr (EW_AHEAD) {                                 // (requested while the projections' MFMAs run)
+                    sfor<4>([&](auto C) {
+                        lds_read8<8 * (C.value & 1)>(dyv[C.value], sb + a_xcl[C.value >> 1]);
+                        lds_read8<8192 + 8 * (C.value & 1)>(x2v[C.value], sb + a_xcl[C.value >> 1]);
+                    });
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dyv[0]), "+v"(x2v[0]), "+v"(dyv[1]), "+v"(x2v[1]), "+v"(dyv[2]), "+v"(x2v[2]), "+v"(dyv[3]), "+v"(x2v[3]) :: "memory");
+                }
                 sfor<4>([&](auto C) {                                     // 4 columns at a time (a small live set): dy, x2 in, dh, dq out
                     constexpr int c = C.value;
-                    u32x2 dyv, x2v;
-                    lds_read8<8 * (c & 1)>(dyv, sb + a_xcl[c >> 1]);
-                    lds_read8<8192 + 8 * (c & 1)>(x2v, sb + a_xcl[c >> 1]);
-                    // (the wait also pins this chunk's share of the projections behind the previous chunk's stores: hipcc would
+                    if constexpr (!EW_AHEAD) {
+                        lds_read8<8 * (c & 1)>(dyv[c], sb + a_xcl[c >> 1]);
+                        lds_read8<8192 + 8 * (c & 1)>(x2v[c], sb + a_xcl[c >> 1]);
+                    }
+                    // (the statement also pins this chunk's share of the projections behind the previous chunk's stores: hipcc would
                     //  otherwise start all 16 sigmoids at once and keep their temporaries live)
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dyv), "+v"(x2v), "+v"(aG[4 * c]), "+v"(aG[4 * c + 1]), "+v"(aG[4 * c + 2]), "+v"(aG[4 * c + 3]) :: "memory");
+                    if constexpr (EW_AHEAD) asm volatile("" : "+v"(dyv[c]), "+v"(x2v[c]), "+v"(aG[4 * c]), "+v"(aG[4 * c + 1]), "+v"(aG[4 * c + 2]), "+v"(aG[4 * c + 3]) :: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dyv[c]), "+v"(x2v[c]), "+v"(aG[4 * c]), "+v"(aG[4 * c + 1]), "+v"(aG[4 * c + 2]), "+v"(aG[4 * c + 3]) :: "memory");
                     float dh[4], dq[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int e = 4 * c + j;
                         const float gt = sigm(aG[e]);
-                        const float dyp = gsr * ((j & 1) ? bf_hi(dyv[j >> 1]) : bf_lo(dyv[j >> 1]));
+                        const float dyp = gsr * ((j & 1) ? bf_hi(dyv[c][j >> 1]) : bf_lo(dyv[c][j >> 1]));
                         if constexpr (ADD) {
                             dh[j] = dyp;
                             dq[j] = dyp * gt * (1.0f - gt);
                         } else {
-                            const float hv = s2 * ((j & 1) ? bf_hi(x2v[j >> 1]) : bf_lo(x2v[j >> 1])) + sd * aA[e];
+                            const float hv = s2 * ((j & 1) ? bf_hi(x2v[c][j >> 1]) : bf_lo(x2v[c][j >> 1])) + sd * aA[e];
                             dh[j] = dyp * gt;
                             dq[j] = dh[j] * hv * (1.0f - gt);
                         }
