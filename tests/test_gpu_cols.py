@@ -21,7 +21,7 @@ def test_form_query():
     lib = _lib.load()
     assert lib.vlpet_adapter_gate_bwd_form(28000, 768, 3, _lib.VLPET_BF16) == 2       # column-parallel pass
     assert lib.vlpet_adapter_gate_bwd_form(28000, 768, 1, _lib.VLPET_BF16) == 2
-    assert lib.vlpet_adapter_gate_bwd_form(28000, 768, 6, _lib.VLPET_BF16) == 1       # r = 192: the older two-pass form
+    assert lib.vlpet_adapter_gate_bwd_form(28000, 768, 6, _lib.VLPET_BF16) == 2       # r = 192: pet_cols6.hip
     assert lib.vlpet_adapter_gate_bwd_form(28000, 768, 3, _lib.VLPET_F32) == 0        # fp32 (parity mode): rows + weight gradients
     assert lib.vlpet_adapter_gate_bwd_form(28000, 64, 3, _lib.VLPET_BF16) != 2        # d % 128 != 0
     assert lib.vlpet_adapter_gate_bwd_form(0, 768, 3, _lib.VLPET_BF16) < 0
@@ -31,6 +31,10 @@ def test_form_query():
     dict(M=32), dict(M=33), dict(M=224), dict(M=1000), dict(M=3500), dict(M=2100, gate_scale=0.3, delta_scale=0.5, x2_scale=0.7),
     dict(M=1000, gate_mode=2), dict(M=777, r=8, rg=8, nh=4), dict(M=1000, r=96, rg=32, nh=4), dict(M=640, d=256, r=32, rg=16, nh=4),
     dict(M=8232), dict(M=28000), dict(M=31616),
+    # six tiles (csrc/pet_cols6.hip): the T5 script's r = r_g = 192 with its scales, unequal ranks, the additive gate
+    dict(M=32, r=192, rg=192, nh=4, delta_scale=4.0, x2_scale=0.5, gate_scale=0.3), dict(M=1000, r=192, rg=192, nh=4, delta_scale=4.0, x2_scale=0.5, gate_scale=0.3),
+    dict(M=999, r=192, rg=192, nh=4, gate_mode=2, gate_scale=0.3), dict(M=1000, r=192, rg=128, nh=4), dict(M=1000, r=128, rg=192, nh=4),
+    dict(M=4321, r=160, rg=192, nh=4),
 ], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
 def test_k1_two_pass_bf16_vs_oracle(kw):
     ce = {}
@@ -38,11 +42,11 @@ def test_k1_two_pass_bf16_vs_oracle(kw):
     assert max(ce.values()) <= 5e-2, ce          # bias gradients element by element (sums over all M rows of bf16-rounded terms)
 
 
-def _abi_case(M, dtype=torch.bfloat16, seed=11, gate_mode=1):
+def _abi_case(M, dtype=torch.bfloat16, seed=11, gate_mode=1, r=96):
     import vlpet_amd.functional as F
     from vlpet_amd import _lib
     lib = _lib.load()
-    d, r, dev = 768, 96, "cuda"
+    d, dev = 768, "cuda"
     g = torch.Generator(device=dev).manual_seed(seed)
     x1, x2, dy, dxin = (torch.randn(M, d, device=dev, generator=g).to(dtype) for _ in range(4))
     mk = lambda *s: torch.randn(*s, device=dev, generator=g) * 0.05
@@ -74,11 +78,11 @@ def _abi_case(M, dtype=torch.bfloat16, seed=11, gate_mode=1):
     return run, dxin
 
 
-@pytest.mark.parametrize("M", [96, 8232, 28000])
-def test_incoming_dx1_travels_with_the_stage(M):
+@pytest.mark.parametrize("M,r", [(96, 96), (8232, 96), (28000, 96), (8232, 192), (16800, 192)])
+def test_incoming_dx1_travels_with_the_stage(M, r):
     """vlpet_adapter_gate_bwd_saved_acc on the column-parallel pass: dx1 = dx1_in + gate-branch gradient; the other nine
-    outputs are bit-identical to the plain call (M = 8232, 28000: several steps per row chunk, ragged last step)."""
-    run, dxin = _abi_case(M)
+    outputs are bit-identical to the plain call (M >= 8232: several steps per row chunk, ragged last step; r = 192: pet_cols6)."""
+    run, dxin = _abi_case(M, r=r)
     plain, acc = run([3], False), run([3], True)
     ref = plain[0] + dxin.float()
     assert (acc[0] - ref).abs().max().item() <= TOL * ref.abs().max().item()

@@ -11,6 +11,10 @@ cases = [dict(M=224), dict(M=32), dict(M=1000), dict(M=3500), dict(M=1000, gate_
          dict(M=1000, r=96, rg=32, nh=4), dict(M=2100, gate_scale=0.3, delta_scale=0.5, x2_scale=0.7), dict(M=28000), dict(M=33200)]
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
     cases = cases[:4]
+if len(sys.argv) > 1 and sys.argv[1] == "r192":      # the T5 script's rank: six tiles (csrc/pet_cols6.hip)
+    T5 = dict(r=192, rg=192, nh=4, delta_scale=4.0, x2_scale=0.5, gate_scale=0.3)
+    cases = [dict(M=32, **T5), dict(M=100, **T5), dict(M=1000, **T5), dict(M=2100, **T5), dict(M=999, gate_mode=2, **T5),
+             dict(M=1000, r=192, rg=128, nh=4), dict(M=1000, r=128, rg=192, nh=4), dict(M=16800, **T5)]
 bad = 0
 for kw in cases:
     ce = {}

@@ -10,7 +10,7 @@ from vlpet_amd import _lib
 from kbench import timeit
 
 def run(M, tag):
-    dt, r, d, dev = torch.bfloat16, 96, 768, "cuda"
+    dt, r, d, dev = torch.bfloat16, int(os.environ.get("K1BENCH_R", "96")), 768, "cuda"
     lib = _lib.load()
     g = torch.Generator(device=dev).manual_seed(0)
     x1 = torch.randn(M, d, device=dev, generator=g).to(dt); x2 = torch.randn(M, d, device=dev, generator=g).to(dt)

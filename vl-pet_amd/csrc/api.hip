@@ -285,6 +285,8 @@ static BwdWs bwd_ws(int64_t M, int d, int tiles, bool gate, int io_dtype) {
         int rc4; int64_t rpc4;                          // ... and the column-parallel pass of pet_cols.hip
         k1_cols_plan(M, d, &rc4, &rpc4);
         if (rc4 > chunks) chunks = rc4;
+        k1_cols6_plan(M, d, &rc4, &rpc4);
+        if (rc4 > chunks) chunks = rc4;
     }
     w.partial = o;
     o += align256(wgrad_workspace_bytes(njobs, tiles, d, chunks));
@@ -348,7 +350,8 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     // caller needs the input gradients right after phase 1 (phases bit 2: weight gradients on a side stream)
     // bf16, r <= 96: pass 1 (dpre) + the column-parallel pass of pet_cols.hip (input gradients + the four weight gradients from
     // one read of dy, x1, x2) -- unless the caller needs the input gradients right after phase 1
-    const bool cols4 = !(phases & 4) && k1_cols_applies(b, io_dtype == VLPET_F32);
+    const bool cols6 = !(phases & 4) && k1_cols6_applies(b, io_dtype == VLPET_F32);
+    const bool cols4 = cols6 || (!(phases & 4) && k1_cols_applies(b, io_dtype == VLPET_F32));
     const bool two_pass = cols4 || (!(phases & 4) && pet_gate_bwd3_applies(b));
     const bool rows2 = !two_pass && pet_gate_bwd2_applies(b);
     int gs3 = 0, ng3 = 0;
@@ -367,7 +370,8 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
 
     WgradArgs g{};
     g.M = M; g.RT = tiles; g.row_chunks = w.row_chunks; g.rows_per_chunk = w.rows_per_chunk;
-    if (cols4) k1_cols_plan(M, d, &g.row_chunks, &g.rows_per_chunk);
+    if (cols6) k1_cols6_plan(M, d, &g.row_chunks, &g.rows_per_chunk);
+    else if (cols4) k1_cols_plan(M, d, &g.row_chunks, &g.rows_per_chunk);
     else if (two_pass) gate_bwd3_plan(M, d, io_dtype == VLPET_F32, &g.row_chunks, &g.rows_per_chunk, &gs3, &ng3);
     g.partial = reinterpret_cast<float*>(ws + w.partial);
     const int ldp = 32 * tiles;
@@ -401,7 +405,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
         const WgradLayout L = wgrad_layout(g);
         for (int j = 0; j < 4; ++j) c.part[j] = g.partial + L.off[j];
         if (phases & 2) {
-            hipError_t e = launch_k1_cols(c, tiles, (hipStream_t)stream);
+            hipError_t e = cols6 ? launch_k1_cols6(c, (hipStream_t)stream) : launch_k1_cols(c, tiles, (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
         }
         if ((phases & 8) && !(phases & 16)) return 0;       // (the partial sums stay in the workspace)
@@ -420,7 +424,7 @@ extern "C" int vlpet_adapter_gate_bwd_form(int64_t M, int d, int tiles, int io_d
     if (check_common(M, d, tiles, io_dtype)) return -1;
     PetBwdArgs b{};
     b.M = M; b.d = d; b.RT = tiles; b.flags = PET_GATE; b.saved = &b; b.drop = NO_DROP;
-    if (k1_cols_applies(b, io_dtype == VLPET_F32)) return 2;
+    if (k1_cols_applies(b, io_dtype == VLPET_F32) || k1_cols6_applies(b, io_dtype == VLPET_F32)) return 2;
     if (pet_gate_bwd3_applies(b)) return 1;
     return 0;
 }

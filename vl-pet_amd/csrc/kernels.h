@@ -157,6 +157,10 @@ struct ColzArgs {
 void k1_cols_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk);
 bool k1_cols_applies(const PetBwdArgs& a, int io_fp32);
 hipError_t launch_k1_cols(const ColzArgs& c, int RT, hipStream_t stream);
+// the same pass for six tiles (r = 192; pet_cols6.hip: four roles per column quarter, 64-column workgroups)
+void k1_cols6_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk);
+bool k1_cols6_applies(const PetBwdArgs& a, int io_fp32);
+hipError_t launch_k1_cols6(const ColzArgs& c, hipStream_t stream);
 
 // K4: out = LN(feats . W^T + b) * gamma + beta (+ R); optionally stores xhat and rstd for the backward
 struct VisprojArgs {
