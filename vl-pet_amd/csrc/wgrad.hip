@@ -494,7 +494,13 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_tr_kernel(WgradArgs a) {
 // global_load_lds of the wave (s_waitcnt vmcnt(0) before the first ds_read of a step -- which would wait for the stages just
 // requested and serialise the ring).  The counted vmcnt of the stage is issued by hand (wgs_wait), and so is the lgkmcnt
 // before the MFMAs (tr_fence ties the operand registers to the wait so that no MFMA is scheduled above it).
-#include "trread.h"
+// Dropout on X (the LoRA down-projection gradient, K3): when the job carries the packed mask the forward left behind
+// (DropSpec::bits, 1 bit per element), the DROPB instantiation brings each wave's 32 rows x 8 mask bytes along with the stage
+// (one more 4-byte global_load_lds per lane: lane = (row, parity) owns the dword of the groups of its parity, drop_pos order)
+// and clears the dropped elements of its own X sub-tile in LDS before the transpose reads; 1 / (1 - p) is applied to the sums
+// by the finalize kernel.  Round 3: the mask had forced this job onto the per-wave register kernel (46 us per call in the
+// LoRA step against 25 for the stream).
+#include "cols_common.h"
 
 template <int RT> struct WgsGeo {
     static constexpr int PB = 64 * RT;                 // bytes of a P row
@@ -508,11 +514,12 @@ template <int RT> struct WgsGeo {
     static constexpr bool PSWZ = (RT % 2) == 0;
 };
 
-template <int RT, int NSTG>
+template <int RT, int NSTG, bool DROPB>
 __global__ __launch_bounds__(VLPET_THREADS, (RT <= 3 ? 2 : 1)) void wgrad_stream_kernel(WgradArgs a) {
     using GEO = WgsGeo<RT>;
     constexpr int PR = 32 * RT;
-    constexpr int PB = GEO::PB, NPR = GEO::NPR, PPW = GEO::PPW, NI = GEO::NI;
+    constexpr int PB = GEO::PB, NPR = GEO::NPR, PPW = GEO::PPW, NI = GEO::NI + (DROPB ? 1 : 0);
+    constexpr int STG = GEO::STG_B + (DROPB ? 4 * 256 : 0);      // + the four waves' mask words
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const WgId wg = wg_decode(a, a.nslice);            // nslice = 256-column slabs of the widest job
@@ -524,7 +531,9 @@ __global__ __launch_bounds__(VLPET_THREADS, (RT <= 3 ? 2 : 1)) void wgrad_stream
     const int ldp_ = a.job[jb].ldp, ldx_ = a.job[jb].ldx;
     const int xc = a.job[jb].xcols;
     const int64_t rpc_ = a.rows_per_chunk, M_ = a.M;
-    asm volatile("" :: "s"(P), "s"(X), "s"(ldp_), "s"(ldx_), "s"(xc), "s"(rpc_), "s"(M_));
+    const bool dropj = DROPB && a.job[jb].has_drop != 0;
+    const uint8_t* mbits = dropj ? a.job[jb].drop.bits : P;      // jobs without a mask fetch a dummy word: one vmcnt count for all
+    asm volatile("" :: "s"(P), "s"(X), "s"(ldp_), "s"(ldx_), "s"(xc), "s"(rpc_), "s"(M_), "s"(mbits));
     const int64_t ldpb = (int64_t)ldp_ * 2, ldxb = (int64_t)ldx_ * 2;
     if (wg.slice * 256 >= xc) return;
     const int rc = wg.rc;
@@ -550,9 +559,16 @@ __global__ __launch_bounds__(VLPET_THREADS, (RT <= 3 ? 2 : 1)) void wgrad_stream
         if (GEO::PSWZ) slot ^= 4 * ((prow[j] >> 1) & 1);
         psrc[j] = slot * 16;
     }
+    const int64_t ldm = dropj ? (int64_t)(ldx_ >> 3) : 0;
+    const int msrc = dropj ? ((active ? n0 : 0) >> 3) + 4 * (lane & 1) : 0;
     auto issue = [&](int s) {
         const int64_t rb = r_begin + 32 * (int64_t)s;
-        uint8_t* st = smem + (size_t)(s % NSTG) * GEO::STG_B;
+        uint8_t* st = smem + (size_t)(s % NSTG) * STG;
+        if constexpr (DROPB) {
+            int64_t row = rb + (lane >> 1);
+            if (row >= r_end) row = r_end - 1;
+            __builtin_amdgcn_global_load_lds((gmem_cv*)(mbits + row * ldm + msrc), (lmem_v*)(st + GEO::STG_B + wave * 256), 4, 0, 0);
+        }
 #ifdef VLPET_WGRAD_EXP
         if (!(a.RT & 0x400))
 #endif
@@ -609,8 +625,30 @@ __global__ __launch_bounds__(VLPET_THREADS, (RT <= 3 ? 2 : 1)) void wgrad_stream
         int pending = nsteps - 1 - s;
         if (pending > NSTG - 2) pending = NSTG - 2;
         wgs_wait<NI, NSTG - 2>(pending);
-        uint8_t* st = smem + (size_t)(s % NSTG) * GEO::STG_B;
+        uint8_t* st = smem + (size_t)(s % NSTG) * STG;
         uint8_t* tx = st + GEO::PT_B + (size_t)wave * GEO::XT_B;
+        if constexpr (DROPB) {
+            if (dropj && active) {                   // own X pieces and mask words have landed: clear the dropped elements
+                const uint32_t sb = lds0 + (uint32_t)((s % NSTG) * STG);
+                const int row = lane >> 1, b = (row >> 1) & 1;
+                uint32_t kw;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(kw) : "v"(sb + (uint32_t)(GEO::STG_B + wave * 256 + lane * 4)) : "memory");
+                if (b) kw = (kw >> 16) | (kw << 16);             // rows with the slot ^ 4 swizzle: LDS slot t holds group t ^ 2
+                const uint32_t xb = sb + (uint32_t)(GEO::PT_B + wave * GEO::XT_B + row * 128 + 16 * (lane & 1));
+                u32x4 v[4];
+                lds_read16<0>(v[0], xb); lds_read16<32>(v[1], xb); lds_read16<64>(v[2], xb); lds_read16<96>(v[3], xb);
+                lgkm_fence(v[0]); lgkm_tie(v[1]); lgkm_tie(v[2]); lgkm_tie(v[3]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int lo = ((int)(kw << (31 - (8 * t + 2 * q)))) >> 31;
+                        const int hi = ((int)(kw << (31 - (8 * t + 2 * q + 1)))) >> 31;
+                        v[t][q] &= __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x07060100u);
+                    }
+                lds_write16<0>(xb, v[0]); lds_write16<32>(xb, v[1]); lds_write16<64>(xb, v[2]); lds_write16<96>(xb, v[3]);
+            }
+        }
         const int valid = (int)(r_end - (r_begin + 32 * (int64_t)s));            // rows of this step that exist
         const bool tail = valid < 32;
         if (tail) {                                                               // own X pieces have landed: zero the missing rows
@@ -631,7 +669,7 @@ __global__ __launch_bounds__(VLPET_THREADS, (RT <= 3 ? 2 : 1)) void wgrad_stream
         if (a.RT & 0x200) continue;                  // experiment: the stream without the products
 #endif
         if (active) {
-            const uint32_t sb = lds0 + (uint32_t)((s % NSTG) * GEO::STG_B);
+            const uint32_t sb = lds0 + (uint32_t)((s % NSTG) * STG);
             TrOp bx[2][2], ap[2][RT];
             auto reads = [&](auto ksc) {
                 constexpr int ks = decltype(ksc)::value;
@@ -817,7 +855,7 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(FinArgs a) {
     }
 }
 
-static hipError_t launch_finalize(const WgradArgs& a, int RT, int xmax, int rmax, hipStream_t stream) {
+static hipError_t launch_finalize(const WgradArgs& a, int RT, int xmax, int rmax, hipStream_t stream, bool mask_unscaled = false) {
     const int PR = 32 * RT;
     const int blocks = finalize_tiles(PR, xmax) + (xmax + rmax + 255) / 256;   // tiles of every job fit: xcols <= xmax
     const WgradLayout L = wgrad_layout(a);
@@ -830,6 +868,7 @@ static hipError_t launch_finalize(const WgradArgs& a, int RT, int xmax, int rmax
         F.out = J.out; F.colsum_x = J.colsum_x; F.colsum_p = J.colsum_p;
         F.xcols = J.xcols; F.out_rows = J.out_rows; F.ldo = J.ldo; F.transposed = J.transposed;
         F.scale = J.scale; F.ntile = finalize_tiles(PR, J.xcols);
+        if (mask_unscaled && J.has_drop) F.scale *= J.drop.keep_scale;      // the streaming kernel only clears the dropped elements
     }
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)blocks, a.njobs), dim3(256), 0, stream, f);
     return hipGetLastError();
@@ -849,10 +888,17 @@ static hipError_t launch_one(const WgradArgs& a, hipStream_t stream) {
     constexpr int NV = RT * 2 * 16 + RT + 2;
     int xmax = 0, rmax = 0;
     bool plain = true;                       // no dropout mask on X, 16-byte aligned rows: the transpose-read path applies
+    bool streamable = true, masked = false;  // the streaming kernel also takes a mask if it is the forward's packed one
     for (int j = 0; j < a.njobs; ++j) {
-        if (a.job[j].xcols > xmax) xmax = a.job[j].xcols;
-        if (a.job[j].out_rows > rmax) rmax = a.job[j].out_rows;
-        if (a.job[j].has_drop || a.job[j].ldp % 8 != 0 || a.job[j].ldx % 8 != 0) plain = false;
+        const WgradJob& J = a.job[j];
+        if (J.xcols > xmax) xmax = J.xcols;
+        if (J.out_rows > rmax) rmax = J.out_rows;
+        if (J.ldp % 8 != 0 || J.ldx % 8 != 0) plain = streamable = false;
+        if (J.has_drop) {
+            plain = false;
+            masked = true;
+            if (J.drop.bits == nullptr || J.drop.keep != nullptr || J.colsum_x != nullptr || J.ldx % 64 != 0) streamable = false;
+        }
     }
     // bf16, r <= 96, no dropout mask: the LDS transpose-read kernel (ds_read_b64_tr_b16 operands, no identity-MFMA
     // transposes, no fp32 -> bf16 re-conversion).  Round 2, after the XCD-aware numbering: 83.0 vs 86.7 us at M = 28 k,
@@ -864,7 +910,7 @@ static hipError_t launch_one(const WgradArgs& a, hipStream_t stream) {
     // per-wave transpose-read kernel below (A/B).
     const bool use_stream = vlpet_tuning().wgrad_stream != 0;
     if constexpr (std::is_same<IO, __bf16>::value) {
-        if (plain && use_stream) {
+        if (streamable && use_stream) {
             // ring depth: 3 stages (72 KiB at RT = 3: two workgroups per CU); VLPET_WGRAD_NSTG=4 for A/B (one per CU, one more stage in flight)
             const int nstg = vlpet_tuning().wgrad_nstg;
             WgradArgs b = a; b.nslice = (xmax + 255) / 256;
@@ -872,15 +918,16 @@ static hipError_t launch_one(const WgradArgs& a, hipStream_t stream) {
             b.RT |= vlpet_tuning().wgs_mode << 8;
 #endif
             auto go = [&](auto kern, int NSTG) -> hipError_t {
-                const size_t lds = (size_t)NSTG * WgsGeo<RT>::STG_B;
+                const size_t lds = (size_t)NSTG * (WgsGeo<RT>::STG_B + (masked ? 1024 : 0));
                 hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e2 != hipSuccess) return e2;
                 hipLaunchKernelGGL(kern, dim3(wg_grid(b, b.nslice)), dim3(VLPET_THREADS), lds, stream, b);
                 return hipGetLastError();
             };
-            e = nstg == 4 ? go(wgrad_stream_kernel<RT, 4>, 4) : go(wgrad_stream_kernel<RT, 3>, 3);
+            if (masked) e = go(wgrad_stream_kernel<RT, 3, true>, 3);
+            else e = nstg == 4 ? go(wgrad_stream_kernel<RT, 4, false>, 4) : go(wgrad_stream_kernel<RT, 3, false>, 3);
             if (e != hipSuccess) return e;
-            return launch_finalize(a, RT, xmax, rmax, stream);
+            return launch_finalize(a, RT, xmax, rmax, stream, masked);
         }
     }
     if constexpr (std::is_same<IO, __bf16>::value && RT <= 3) {
