@@ -102,10 +102,28 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
     auto stamp = [&](int k) {      // debug timestamps (thread 0 of each block), see api.hip VLPET_DBG & 16
         if ((a.dbg & 16) && tid == 0 && blockIdx.x < 4096) a.dbg_ts[blockIdx.x * 8 + k] = __builtin_readcyclecounter();
     };
+    // packed keep flags of the lane's KU 8-element groups of down stage s (byte u <-> features s*FE + 16u + 8h ..)
+    auto gen_stage = [&](int s) -> uint32_t {
+        uint32_t w = 0;
+        if constexpr (DROP) {
+            const bool live = row0_wave + m < a.M;
+            const int64_t grow = live ? row0_wave + m : a.M - 1;
+#pragma unroll
+            for (int u = 0; u < G::KU; ++u) {
+                const int f0 = s * G::FE + 16 * u + 8 * h;
+                const uint32_t kb = drop_bits8(a.drop, grow, f0, d);
+                if (a.drop.keep_out != nullptr && live) drop_export8(a.drop.keep_out, grow * d + f0, kb);
+                w |= kb << (8 * u);
+            }
+        }
+        return w;
+    };
+    uint32_t kbw_next = 0;
     stamp(0);
     issue_w(0);
     issue_rows(0);
     issue_rows(1);
+    if constexpr (DROP) kbw_next = gen_stage(0);
     {   // biases -> LDS: [bdA(32RT) | buA(d) | bdG(32RT) | buG(d)]
         const float* ba = reinterpret_cast<const float*>(a.pk_a + pg.bias_off);
         for (int i = tid; i < nb; i += WAVES * 64) sb[i] = ba[i];
@@ -127,6 +145,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
         for (int ct = 0; ct < RT; ++ct) accG[ct] = zero16();
     }
     bf16x8 xkeep[KEEP ? SKEEP : 1][4];            // the lane's 64 bytes of every x2 stage (KEEP only)
+    uint32_t kbw = 0;
     auto down_stage = [&](int s) {
         if (s == 5) stamp(5);
         issue_w(s + 1);
@@ -142,24 +161,21 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
         // k-step u (counted lgkmcnt waits; <= 8 fragment reads in flight), so LDS and the matrix pipe overlap.
         // (One burst of all 40 reads made hipcc emit lgkmcnt(0) before the first MFMA: reads, then MFMAs.)
         Frag<NS> bA[G::KU], bG[GATE ? G::KU : 1], wa[G::KU][RT], wg[GATE ? G::KU : 1][RT];
-        uint32_t kbw = 0;
+        if constexpr (DROP) kbw = kbw_next;
         auto load_u = [&](int u) {
             bA[u] = tile_bfrag4<IO>(ta, trow, h, u);
-            if constexpr (DROP) {
-                const bool live = row0_wave + m < a.M;
-                const int64_t grow = live ? row0_wave + m : a.M - 1;
-                const int f0 = s * G::FE + 16 * u + 8 * h;
-                const uint32_t kb = drop_bits8(a.drop, grow, f0, d);
-                if (a.drop.keep_out != nullptr && live) drop_export8(a.drop.keep_out, grow * d + f0, kb);
-                kbw |= kb << (8 * u);                    // packed mask of this lane's KU groups of the stage (training form)
-                float v[8];
+            if constexpr (DROP) {                        // clear the dropped elements (1 / (1 - p) is applied to the sums)
+                const uint32_t kb = kbw >> (8 * u);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    v[j] = (float)bA[u].p[0][j];
-                    if constexpr (NS == 2) v[j] += (float)bA[u].p[1][j];
-                    v[j] = ((kb >> j) & 1u) ? v[j] * a.drop.keep_scale : 0.f;
+                for (int ns = 0; ns < NS; ++ns) {
+                    u32x4 t = __builtin_bit_cast(u32x4, bA[u].p[ns]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int lo = ((int)(kb << (31 - 2 * q))) >> 31, hi = ((int)(kb << (30 - 2 * q))) >> 31;
+                        t[q] &= __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x07060100u);
+                    }
+                    bA[u].p[ns] = __builtin_bit_cast(bf16x8, t);
                 }
-                bA[u] = frag_from_f32<NS>(v);
             }
 #pragma unroll
             for (int ct = 0; ct < RT; ++ct) wa[u][ct] = wfrag<NS>(w, u * RT + ct, lane);
@@ -187,6 +203,10 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
         mfma_u(G::KU - 1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (DROP) {
+            // the next stage's keep flags are generated here, behind this stage's MFMAs and in front of the wait for its rows:
+            // the generator depends on (seed, element index) only, so its ~100 VALU instructions per group fill the time the
+            // wave would spend waiting (round 3; before, they sat between the LDS read and the MFMA of every k-step)
+            if (s + 1 < S) kbw_next = gen_stage(s + 1);
             // the lane's KU mask bytes of this stage are contiguous in the packed layout (rng.h drop_pos): one store
             if (a.drop.bits_out != nullptr && row0_wave + m < a.M) {
                 uint8_t* bp = a.drop.bits_out + (row0_wave + m) * (int64_t)(d >> 3) + drop_pos((s * G::FE + 8 * h) >> 3);
@@ -207,6 +227,10 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
         s = SKEEP;
     } else {
         for (; s < S; ++s) down_stage(s);
+    }
+    if constexpr (DROP) {                        // dropout's 1 / (1 - p): once on the sums instead of on every kept element
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct) accA[ct] *= a.drop.keep_scale;
     }
 
     stamp(2);

@@ -13,8 +13,11 @@ __device__ __forceinline__ void philox7(uint32_t c0, uint32_t c1, uint32_t k0, u
     uint32_t c2 = 0x5bd1e995u, c3 = 0x2545f491u;
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 64-bit product per multiplier (v_mad_u64_u32) instead of a v_mul_hi_u32 / v_mul_lo_u32 pair: the 32-bit integer
+        // multiplies are the slow VALU ops of the generator (28 -> 14 per group of 8 elements)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
