@@ -136,6 +136,9 @@ hipError_t launch_wgrad(const WgradArgs& a, int io_fp32, hipStream_t stream);
 bool pet_gate_bwd3_applies(const PetBwdArgs& a);
 void gate_bwd3_plan(int64_t M, int d, int io_fp32, int* row_chunks, int64_t* rows_per_chunk, int* GS, int* NG);
 hipError_t launch_pet_gate_dz(const PetBwdArgs& a, int io_fp32, hipStream_t stream);
+// the same pass with the stage's features split over the two waves of a row group (pet_dz2.hip; bf16, r <= 96)
+bool k1_dz2_applies(const PetBwdArgs& a, int io_fp32);
+hipError_t launch_k1_dz2(const PetBwdArgs& a, hipStream_t stream);
 hipError_t launch_pet_gate_cols(const PetBwdArgs& a, const WgradArgs& g, int GS, int NG, int io_fp32, hipStream_t stream);
 
 // Column-parallel pass 2 of the gated K1 backward, round-3 form (pet_cols.hip): weights resident in registers, row tensors streamed

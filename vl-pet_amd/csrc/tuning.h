@@ -19,6 +19,7 @@ struct VlpetTuning {
     int wgs_mode = 0;       // VLPET_WGS_MODE: ablation bits of the streaming kernel (needs -DVLPET_WGRAD_EXP as well)
     int attn_occ = 0;       // VLPET_ATTN_OCC=2|3: waves per SIMD of the attention backward (0: by shape)
     int attn_nw = 0;        // VLPET_ATTN_NW=6: six-wave attention backward
+    int dz2 = 1;            // VLPET_DZ2=0: chain-split pass 1 of the K1 backward (pet_gate_dz_kernel) instead of the feature-split one
     int dbg = 0;            // VLPET_DBG: ablation / stamp bits
 };
 
@@ -30,7 +31,7 @@ inline const VlpetTuning& vlpet_tuning() {
         rd("VLPET_RG", v.rg); rd("VLPET_BWD2", v.bwd2); rd("VLPET_BWD3", v.bwd3); rd("VLPET_BWD3_UNITS", v.bwd3_units);
         rd("VLPET_BWD3_FORM", v.bwd3_form); rd("VLPET_K4_WAVES4", v.k4_waves4); rd("VLPET_WGRAD_WGS", v.wgrad_wgs);
         rd("VLPET_WGRAD_TR", v.wgrad_tr); rd("VLPET_WGRAD_STREAM", v.wgrad_stream); rd("VLPET_WGRAD_NSTG", v.wgrad_nstg);
-        rd("VLPET_WGS_MODE", v.wgs_mode); rd("VLPET_ATTN_OCC", v.attn_occ); rd("VLPET_ATTN_NW", v.attn_nw); rd("VLPET_DBG", v.dbg);
+        rd("VLPET_WGS_MODE", v.wgs_mode); rd("VLPET_ATTN_OCC", v.attn_occ); rd("VLPET_ATTN_NW", v.attn_nw); rd("VLPET_DBG", v.dbg); rd("VLPET_DZ2", v.dz2);
         return v;
     }();
     return t;
