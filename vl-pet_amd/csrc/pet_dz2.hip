@@ -23,6 +23,9 @@
 #define VLPET_DZ2_AW1 2     // stages the weight / row requests run ahead at RT = 1 (LDS allows it); RT = 3: 1 / 1
 #define VLPET_DZ2_AX1 2
 #endif
+#ifndef VLPET_DZ2_SPREAD
+#define VLPET_DZ2_SPREAD 1
+#endif
 template <int RT> struct Dz2Geo {
     static constexpr int AW = RT == 1 ? VLPET_DZ2_AW1 : 1, AX = RT == 1 ? VLPET_DZ2_AX1 : 1;
     static constexpr int NWS = AW + 2, NXS = AX + 1;   // slots (a stage's weight image is used for two steps)
@@ -43,6 +46,7 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
     constexpr int KT = 2 * RT;
     constexpr int PB = GEO::PB, NPS = GEO::NPS, WT_B = GEO::WT_B, XT_B = GEO::XT_B, WS_B = GEO::WS_B, XS_B = GEO::XS_B;
     constexpr int X_OFF = GEO::X_OFF, AW = GEO::AW, AX = GEO::AX, NWS = GEO::NWS, NXS = GEO::NXS;
+    constexpr bool SPREAD = VLPET_DZ2_SPREAD != 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,14 +114,12 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
 #pragma unroll
         for (int j = 0; j < RT; ++j) glds16(sbase(wbase[j] + (int64_t)s * (4 * RT * 1024)) + woff[j], st + wdst[j]);
     };
-    auto issue_x = [&](int s) {
+    auto issue_x1 = [&](int s, int j) {
         uint8_t* st = smem + X_OFF + (size_t)(s % NXS) * XS_B;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            glds16_row(sbase(dyp + s * 128) + xoff[j], st + xdst[j]);
-            glds16_row(sbase(x2p + s * 128) + xoff[j], st + XT_B + xdst[j]);
-        }
+        glds16_row(sbase(dyp + s * 128) + xoff[j], st + xdst[j]);
+        glds16_row(sbase(x2p + s * 128) + xoff[j], st + XT_B + xdst[j]);
     };
+    auto issue_x = [&](int s) { issue_x1(s, 0); issue_x1(s, 1); };
 
     // ---- per-lane LDS byte addresses (relative to the stage base)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
@@ -176,7 +178,9 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
         const uint32_t xb = lds0 + (uint32_t)(X_OFF + (s % NXS) * XS_B);
         f32x16 aA, aG;
         project_up(sb, std::integral_constant<int, 0>{}, zA, aA, (s * 64) * 4);
+        if (SPREAD && s + AX < S) issue_x1(s + AX, 0);     // the row requests of the stage ahead are spread over the step: up front,
         project_up(sb, std::integral_constant<int, 1>{}, zG, aG, (d + s * 64) * 4);
+        if (SPREAD && s + AX < S) issue_x1(s + AX, 1);     // all 56 pieces of a workgroup queue at the texture path at once (~1 k cycles of blocked issue)
 #ifdef VLPET_DZ2_STAMPS
         asm volatile("s_nop 0" : "+v"(aG[15]), "+v"(aA[15]));
 #endif
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
         __builtin_amdgcn_s_barrier();
         DZ2_STAMP(1)
         if (s + AW < S) issue_w(s + AW);
-        if (s + AX < S) issue_x(s + AX);
+        if (!SPREAD && s + AX < S) issue_x(s + AX);
     };
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // z in registers, biases in LDS
