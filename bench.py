@@ -35,8 +35,13 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # HBM-side bytes per row of the K1 backward from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
 # with rocprofv3 --pmc in its own run at ONE size (M = 28,000, bf16, r = 96) -- bench.py scales them by the run's rows per
 # launch, so for the other task shapes they are an extrapolation (labelled as such in the line).
-PMC_TRAFFIC = {"source": "profiles/r02_pmc_traffic_k1_bwd.md", "measured_at_rows": 28000,
-               "bytes_per_row": {"k1_bwd_rows": 11881.0, "k1_bwd_op": 20432.0}}
+# Two tables: the two-pass form (round 3: pass 1 + column-parallel pass + finalize) and the previous split (--k1-previous-split).
+PMC_TRAFFIC_FORMS = {
+    "two_pass": {"source": "profiles/r03_pmc_traffic_k1_bwd.md", "measured_at_rows": 28000,
+                 "bytes_per_row": {"k1_bwd_rows": 4217.0, "k1_bwd_wgrad": 10083.0, "k1_bwd_op": 16000.0}},
+    "previous_split": {"source": "profiles/r02_pmc_traffic_k1_bwd.md", "measured_at_rows": 28000,
+                       "bytes_per_row": {"k1_bwd_rows": 11881.0, "k1_bwd_op": 20432.0}},
+}
 IMAGE_TASKS = ["vqa", "gqa", "nlvr", "caption"]
 VIDEO_TASKS = ["tvqa", "how2qa", "tvc", "yc2c"]
 
@@ -392,7 +397,7 @@ def main():
         # algorithmic bytes per row: K1 fwd reads x1, x2, writes y; K1 bwd (the whole op: rows kernel + weight
         # gradients) reads dy, x1, x2, writes dx1, dx2; K2 / K3 fwd read x, y|base, write out; K2 / K3 bwd read dy, x, write dx;
         # K5 fwd reads y, x1, writes out; K5 bwd reads dout, writes dx1, dy (the saved pre-norm sum is extra traffic)
-        # Form of the gated K1 backward at this shape (vlpet_adapter_gate_bwd_form): 2 = pass 1 (pet_gate_dz_kernel: reads dy, x2,
+        # Form of the gated K1 backward at this shape (vlpet_adapter_gate_bwd_form): 2 = pass 1 (k1_dz2_kernel / pet_gate_dz_kernel: reads dy, x2,
         # writes only the [M, r] dpre) + the column-parallel pass (k1_cols_kernel: reads dy, x1, x2, writes dx1, dx2 and the
         # weight-gradient partials) + the finalize launch; otherwise rows kernel + weight-gradient kernels as in round 2.
         k1_tiles = 6 if args.model == "t5" else 3
@@ -446,9 +451,10 @@ def main():
                                  else f"pet_bwd_kernel<{args.dtype},{tiles},gate>"),
                  "k1_bwd_wgrad": f"k1_cols_kernel<{tiles}> (column-parallel pass of the K1 backward: reads dy, x1, x2, writes dx1, dx2)",
                  "k1_fwd": f"pet_gate_fwd_kernel<{args.dtype},{tiles}>",
-                 "k3_bwd": f"pet_bwd_kernel<{args.dtype},act_id> + wgrad_kernel (one K3 backward)",
+                 "k3_bwd": f"pet_bwd_kernel<{args.dtype},act_id> + wgrad_stream_kernel (one K3 backward)",
                  "k3_fwd": f"pet_fwd_kernel<{args.dtype},act_id>"}[dom]
         traffic = None
+        PMC_TRAFFIC = PMC_TRAFFIC_FORMS["two_pass" if (args.model != "lora" and two_pass) else "previous_split"]
         if dom in PMC_TRAFFIC["bytes_per_row"] and args.dtype == "bf16" and args.model == "bart":
             traffic = round(PMC_TRAFFIC["bytes_per_row"][dom] * a["rows"] / a["launches"])
         roof = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
