@@ -31,6 +31,8 @@ def test_form_query():
     dict(M=32), dict(M=33), dict(M=224), dict(M=1000), dict(M=3500), dict(M=2100, gate_scale=0.3, delta_scale=0.5, x2_scale=0.7),
     dict(M=1000, gate_mode=2), dict(M=777, r=8, rg=8, nh=4), dict(M=1000, r=96, rg=32, nh=4), dict(M=640, d=256, r=32, rg=16, nh=4),
     dict(M=8232), dict(M=28000), dict(M=31616),
+    # workgroup boundaries of pass 1 (128 rows) and of a pass-2 step (32 rows), one row, other widths (one / eight column blocks)
+    dict(M=1), dict(M=127), dict(M=129), dict(M=257, d=128, r=16, rg=16, nh=4), dict(M=5000, d=1024), dict(M=3000, d=1024, r=192, rg=192, nh=4, gate_scale=0.3),
     # six tiles (csrc/pet_cols6.hip): the T5 script's r = r_g = 192 with its scales, unequal ranks, the additive gate
     dict(M=32, r=192, rg=192, nh=4, delta_scale=4.0, x2_scale=0.5, gate_scale=0.3), dict(M=1000, r=192, rg=192, nh=4, delta_scale=4.0, x2_scale=0.5, gate_scale=0.3),
     dict(M=999, r=192, rg=192, nh=4, gate_mode=2, gate_scale=0.3), dict(M=1000, r=192, rg=128, nh=4), dict(M=1000, r=128, rg=192, nh=4),
