@@ -107,3 +107,25 @@ def test_cross_entropy_argument_errors():
     assert lib.vlpet_ce_loss_fwd(x.data_ptr(), lab.data_ptr(), out.data_ptr(), out.data_ptr(), 4, 12, 12, _lib.VLPET_F32, st) == -1   # ld % 8
     assert lib.vlpet_ce_loss_fwd(x.data_ptr(), None, out.data_ptr(), out.data_ptr(), 4, 16, 16, _lib.VLPET_F32, st) == -5
     assert lib.vlpet_ce_loss_fwd(x.data_ptr(), lab.data_ptr(), out.data_ptr(), out.data_ptr(), 4, 16, 16, 7, st) == -6
+
+
+def test_out_of_range_label_raises_and_empty_batch_is_empty():
+    """ADVICE round 2: a label outside [0, V) other than -100 used to be treated like ignore_index (F.cross_entropy asserts);
+    the first batch per vocabulary is now validated on the host.  N == 0 returns an empty loss instead of a shape error."""
+    import vlpet_amd.lmloss as L
+    V = 40
+    lg = torch.randn(6, V, device="cuda", dtype=torch.bfloat16)
+    old = L.CHECK_LABELS
+    L.CHECK_LABELS = "always"
+    try:
+        with pytest.raises(IndexError):
+            L.cross_entropy_rows(lg, torch.tensor([1, 2, V, 3, -100, 0], device="cuda"), V)
+        with pytest.raises(IndexError):
+            L.cross_entropy_rows(lg, torch.tensor([1, 2, -7, 3, -100, 0], device="cuda"), V)
+        ok = L.cross_entropy_rows(lg, torch.tensor([1, 2, V - 1, 3, -100, 0], device="cuda"), V)
+        assert ok.shape == (6,) and float(ok[4]) == 0.0
+    finally:
+        L.CHECK_LABELS = old
+    e = L.cross_entropy_rows(lg[:0].requires_grad_(True), torch.zeros(0, dtype=torch.long, device="cuda"), V)
+    assert e.shape == (0,) and e.dtype == torch.float32
+    e.sum().backward()

@@ -354,8 +354,11 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
 }
 
 bool k1_dz2_applies(const PetBwdArgs& a, int io_fp32) {
-    return !io_fp32 && (a.flags & PET_GATE) && a.saved != nullptr && !drop_active(a.drop) && (a.RT == 1 || a.RT == 3) &&
-           a.d % 64 == 0 && a.d >= 64;
+    if (io_fp32 || !(a.flags & PET_GATE) || a.saved == nullptr || drop_active(a.drop) || a.d % 64 != 0 || a.d < 64) return false;
+    // (the up-side biases of every feature sit in LDS next to the rings: very wide models go to pet_gate_dz_kernel)
+    if (a.RT == 1) return Dz2Geo<1>::bytes(a.d) <= (size_t)160 * 1024;
+    if (a.RT == 3) return Dz2Geo<3>::bytes(a.d) <= (size_t)160 * 1024;
+    return false;
 }
 
 template <int RT>

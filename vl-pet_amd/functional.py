@@ -145,11 +145,25 @@ SAVE_ACTIVATIONS = True
 K1_BWD_PREVIOUS_SPLIT = False
 
 WEIGHTS_EPOCH = 0
+# Part of the keys of the derived copies of FROZEN tensors (fused q|k|v weight, padded LM head, fp32 LayerNorm copies, the
+# logits-bias flag).  Those keys also carry (data_ptr, Tensor._version), but ``p.data`` has its own version counter: in-place
+# edits through ``.data`` (``m.weight.data.normal_()``, ``p.data.copy_()`` in hand-written checkpoint loaders) or through raw
+# pointers are invisible to them.  ``invalidate_caches()`` is the explicit way out; the hosts call it from a
+# ``load_state_dict`` post-hook.  (Not bumped by optimizer steps: frozen tensors do not change there.)
+FROZEN_EPOCH = 0
 
 
 def bump_weights_epoch():
     global WEIGHTS_EPOCH
     WEIGHTS_EPOCH += 1
+
+
+def invalidate_caches():
+    """Drop every derived copy of a parameter (weight packs and the caches of frozen tensors): call after changing weights in
+    a way autograd's version counters do not see (``.data`` edits, raw-pointer writes, custom checkpoint loaders)."""
+    global FROZEN_EPOCH
+    FROZEN_EPOCH += 1
+    bump_weights_epoch()
 
 
 _PACK_CACHES = None       # weak set of the PackCache objects that packed parameters directly (see repack_all)

@@ -28,6 +28,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import functional as VF
 from ..adapters import AdapterConfig, AdapterController
 from ..encoder_pet import apply_pet, build_pet, has_pet
 from ..lora import LoRALinearController, LoraConfig
@@ -273,7 +274,7 @@ class BartAttention(nn.Module):
         """The frozen q | k | v projections of a self-attention as one [3E, E] weight (a derived cache keyed on the three
         modules' tensors: rebuilt when any of them changes; never a parameter, the state dict keeps q_proj / k_proj / v_proj)."""
         mods = (self.q_proj, self.k_proj, self.v_proj)
-        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods) + (dtype,)
+        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods) + (dtype, VF.FROZEN_EPOCH)
         c = getattr(self, "_qkv_cache", None)
         if c is None or c[0] != key:
             with torch.no_grad():
@@ -505,6 +506,8 @@ class VLBart(nn.Module):
         self.model = VLBartModel(config)
         self.register_buffer("final_logits_bias", torch.zeros(1, config.vocab_size))
         self.apply(self._init_weights)
+        # derived copies of frozen tensors (fused q|k|v, padded LM head, fp32 norms) must not outlive a checkpoint load
+        self.register_load_state_dict_post_hook(lambda module, incompatible: VF.invalidate_caches())
 
     def _init_weights(self, m):
         # my_transformers/modeling_bart.py:1819-1828: every Linear (adapters included) ~ N(0, 0.02), zero bias
@@ -525,7 +528,7 @@ class VLBart(nn.Module):
         """final_logits_bias (src/modeling_bart.py:1470, 1574) is a zero buffer unless a checkpoint carries one: checked once
         per buffer version (one host sync), so the usual all-zero case adds no pass over the logits."""
         b = self.final_logits_bias
-        key = (b.data_ptr(), b._version)
+        key = (b.data_ptr(), b._version, VF.FROZEN_EPOCH)
         if getattr(self, "_bias_key", None) != key:
             self._bias_key, self._bias_nonzero = key, bool(b.any())
         return b if self._bias_nonzero else None

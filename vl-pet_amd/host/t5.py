@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import functional as VF
 from ..adapters import AdapterConfig, AdapterController
 from ..encoder_pet import apply_pet, build_pet, has_pet
 from ..visual import Downsample, T5LayerNorm, VisualEmbedding
@@ -373,6 +374,7 @@ class VLT5(nn.Module):
         self.encoder = JointEncoder(config, self.shared)
         self.decoder = T5Decoder(config, self.shared)
         self.apply(self._init_weights)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: VF.invalidate_caches())   # (see host/bart.py)
 
     def _init_weights(self, m):
         # my_transformers/modeling_t5.py:1026-1066: T5's Mesh-TensorFlow rules for its own layers; adapter / gate

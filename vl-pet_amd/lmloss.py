@@ -17,6 +17,11 @@ from . import _lib
 from .functional import _io_dtype, _need_cuda, _stream, _timed
 
 
+def _frozen_epoch():
+    from . import functional as _VF
+    return _VF.FROZEN_EPOCH
+
+
 class _CeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, V):
@@ -57,7 +62,30 @@ def cross_entropy_rows(logits: torch.Tensor, labels: torch.Tensor, V: Optional[i
     V = logits.shape[1] if V is None else int(V)
     if logits.shape[1] % 8 != 0:
         raise RuntimeError("vl-pet_amd: logits row stride must be a multiple of 8 (use lm_head_loss, which pads the head)")
-    return _CeFn.apply(logits, labels.reshape(-1), V)
+    labels = labels.reshape(-1)
+    if logits.shape[0] == 0:                         # an empty batch has an empty loss (F.cross_entropy, reduction 'none')
+        return logits.new_zeros(0, dtype=torch.float32) + 0.0 * logits.float().sum()
+    _check_labels_once(labels, V)
+    return _CeFn.apply(logits, labels, V)
+
+
+# The kernel treats a label outside [0, V) like ignore_index (loss 0, no gradient); F.cross_entropy raises a device assert for
+# it.  A tokenizer / vocabulary mismatch would otherwise train silently on fewer tokens, so the first batch of every (V, label
+# dtype) is validated on the host (one synchronisation per process and vocabulary); CHECK_LABELS = "always" checks every call.
+CHECK_LABELS = "once"
+_CHECKED = set()
+
+
+def _check_labels_once(labels: torch.Tensor, V: int):
+    if CHECK_LABELS == "never":
+        return
+    key = (V, labels.dtype, labels.device.type)
+    if CHECK_LABELS == "once" and key in _CHECKED:
+        return
+    bad = (labels >= V) | ((labels < 0) & (labels != -100))
+    if bool(bad.any()):
+        raise IndexError(f"vl-pet_amd: label {int(labels[bad][0])} outside [0, {V}) (and not ignore_index -100)")
+    _CHECKED.add(key)
 
 
 def _padded_head(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -69,7 +97,7 @@ def _padded_head(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     if weight.requires_grad:
         w = weight.to(dtype)
         return w if Vp == V else torch.cat([w, w.new_zeros(Vp - V, d)], 0)
-    key = (weight.data_ptr(), weight._version, dtype, tuple(weight.shape))
+    key = (weight.data_ptr(), weight._version, dtype, tuple(weight.shape), _frozen_epoch())
     hit = getattr(weight, "_vlpet_padded_head", None)              # lives and dies with the parameter object
     if hit is not None and hit[0] == key:
         return hit[1]

@@ -16,6 +16,11 @@ from . import _lib
 from .functional import _finish, _flat, _grad_dest, _grad_like, _io_dtype, _need_cuda, _ptr, _stream, _timed
 
 
+def _frozen_epoch():
+    from . import functional as _VF
+    return _VF.FROZEN_EPOCH
+
+
 def _draw_seed() -> int:
     return int(torch.empty((), dtype=torch.int64).random_().item())
 
@@ -30,7 +35,7 @@ def _f32_frozen(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
         return t.detach().contiguous()
     if t.requires_grad:
         return t.detach().float().contiguous()
-    key = (t.data_ptr(), t._version, t.dtype)
+    key = (t.data_ptr(), t._version, t.dtype, _frozen_epoch())
     c = getattr(t, "_vlpet_f32", None)
     if c is None or c[0] != key:
         c = (key, t.detach().float().contiguous())
