@@ -267,6 +267,12 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
 #pragma unroll
     for (int s0 = 0; s0 < NSTG - 1; ++s0)
         if (s0 < nsteps) issue(s0);
+#ifdef VLPET_COLS_STAMPS      // diagnosis build: wall-clock time per phase, summed over the steps, printed by one wave of each side
+    uint64_t tacc[5] = {0, 0, 0, 0, 0}, tlast = wall_clock64();
+#define COLS_STAMP(k) { const uint64_t tn = wall_clock64(); tacc[k] += tn - tlast; tlast = tn; }
+#else
+#define COLS_STAMP(k)
+#endif
 
     // The only hand-off between the roles is the dh tile (U -> D, for dx2 = s2*dh + ..).  It is double-buffered OUTSIDE the
     // ring and consumed one step late: D finishes the input gradients of step s - 1 at the start of step s, so the one barrier
@@ -274,7 +280,16 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
     if (role == 0) {
         // ================================================================ role U: up projections, dh / dq, dWu, dWgu, all bias sums
         const float s2 = a.s2, sd = a.sd;
-        const bool want_csp = cb == 0 && wc == 0;       // the down-side bias sums (column sums of dpre_a, dpre_g): one wave per row chunk
+        // the down-side bias sums (column sums of the 2 RT bottleneck tiles dpre_a / dpre_g, needed once per row chunk): tile k goes
+        // to the up-side wave number w = wc * NCB + cb of the row chunk's workgroups with k = w (mod 4 NCB) -- at d = 768 one tile
+        // for wave 0 of each of the six column blocks (all twelve products on ONE wave made its workgroup the last to finish)
+        int csp_tile[2] = {-1, -1};
+        {
+            const int w = wc * NCB + cb;
+            if (w < 2 * RT) csp_tile[0] = w;
+            if (w + 4 * NCB < 2 * RT) csp_tile[1] = w + 4 * NCB;
+        }
+        const bool want_csp = csp_tile[0] >= 0;
         const uint32_t a_bias = lds0 + (uint32_t)(BIAS_OFF + (32 * wc + 16 * h) * 4);
         const uint32_t dq0 = lds0 + (uint32_t)DQ_OFF;
 #pragma unroll 1
@@ -282,7 +297,9 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
             const int valid = (int)(r_end - (r_begin + 32 * (int64_t)s));
             const uint32_t sb = lds0 + (uint32_t)((s % NSTG) * STG_B);
             const uint32_t dh0 = lds0 + (uint32_t)(DH_OFF + (s & 1) * 8192);
+            COLS_STAMP(4)
             step_top(s, 0);
+            COLS_STAMP(0)
             // up projection of one chain, starting at its bias: the bias values and the first batch of B fragments are one LDS batch
             auto project_up = [&](auto TC, auto OC, const bf16x8* w, f32x16& acc) {
                 constexpr int T = decltype(TC)::value;
@@ -313,6 +330,10 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
                 f32x16 aA, aG;                                            // both up projections
                 project_up(I0{}, I0{}, wA, aA);
                 project_up(I1{}, std::integral_constant<int, 512>{}, wG, aG);
+#ifdef VLPET_COLS_STAMPS
+                asm volatile("s_nop 0" : "+v"(aA[15]), "+v"(aG[15]));
+#endif
+                COLS_STAMP(1)
                 const float gsr = m < valid ? a.gs : 0.f;                 // rows past the end: dh = dq = 0
                 u32x2 dyv[4], x2v[4];
                 if constexpr (EW_AHEAD) {                                 // (requested while the projections' MFMAs run)
@@ -356,36 +377,47 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
             }
             // this wave's own columns of dh, dq: its writes above are ordered before these reads by the waits in between
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            COLS_STAMP(2)
             wg_products(sb, I0{}, I0{}, dh0 + a_xtr[0], dh0 + a_xtr[1], accA, 0);
             wg_products(sb, I1{}, I0{}, dq0 + a_xtr[0], dq0 + a_xtr[1], accG, 1);
             if (want_csp) {                                               // its own block (inside the products it would make every accumulator a phi)
-                sfor<2>([&](auto KS) {
-                    constexpr int ks = KS.value;
-                    sfor<2>([&](auto TT) {
-                        TrOp ap[RT];
-                        sfor<RT>([&](auto CT) {
-                            tr_read2<(2 + TT.value) * PT_B + 64 * CT.value + ks * 16 * PB>(ap[CT.value], sb + a_ptr[0], sb + a_ptr[1]);
-                        });
-                        tr_fence(ap[0]);
 #pragma unroll
-                        for (int ct = 0; ct < RT; ++ct) {
-                            if (ct) tr_tie(ap[ct]);
-                            sx = mfma32(ones_row(2 + TT.value * RT + ct), tr_val(ap[ct]), sx);
-                        }
-                    });
-                });
+                for (int j = 0; j < 2; ++j) {
+                    const int k = csp_tile[j];
+                    if (k < 0) break;
+                    const uint32_t off = (uint32_t)((2 + k / RT) * PT_B + 64 * (k % RT));    // tile dpre_a / dpre_g, c-tile k % RT
+                    TrOp ap[2];
+                    tr_read2<0>(ap[0], sb + a_ptr[0] + off, sb + a_ptr[1] + off);
+                    tr_read2<16 * PB>(ap[1], sb + a_ptr[0] + off, sb + a_ptr[1] + off);
+                    tr_fence(ap[0]);
+                    sx = mfma32(ones_row(2 + j), tr_val(ap[0]), sx);
+                    tr_tie(ap[1]);
+                    sx = mfma32(ones_row(2 + j), tr_val(ap[1]), sx);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (every LDS access of this step is complete at the next barrier)
+#ifdef VLPET_COLS_STAMPS
+            asm volatile("s_nop 0" : "+v"(accA[RT - 1][15]), "+v"(accG[RT - 1][15]));
+#endif
+            COLS_STAMP(3)
         }
+#ifdef VLPET_COLS_STAMPS
+        if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 101))
+            printf("cols stamps U blk %d (10 ns units, %d steps): top %llu up %llu ew %llu wgrad %llu other %llu\n", (int)blockIdx.x, nsteps,
+                   (unsigned long long)tacc[0], (unsigned long long)tacc[1], (unsigned long long)tacc[2], (unsigned long long)tacc[3], (unsigned long long)tacc[4]);
+#endif
         __builtin_amdgcn_s_barrier();                                     // the last dh tile is visible to role D
         if (h == 0) {
             a.part[1][(int64_t)RC * PR * d + (int64_t)rc * d + col] = sx[0];
             a.part[3][(int64_t)RC * PR * d + (int64_t)rc * d + col] = sx[1];
             if (want_csp) {
-                float* psa = a.part[0] + (int64_t)RC * PR * d + (int64_t)RC * d + (int64_t)rc * PR;
-                float* psg = a.part[2] + (int64_t)RC * PR * d + (int64_t)RC * d + (int64_t)rc * PR;
 #pragma unroll
-                for (int ct = 0; ct < RT; ++ct) { psa[32 * ct + m] = sx[2 + ct]; psg[32 * ct + m] = sx[2 + RT + ct]; }
+                for (int j = 0; j < 2; ++j) {
+                    const int k = csp_tile[j];
+                    if (k < 0) break;
+                    float* ps = a.part[k / RT == 0 ? 0 : 2] + (int64_t)RC * PR * d + (int64_t)RC * d + (int64_t)rc * PR;
+                    ps[32 * (k % RT) + m] = sx[2 + j];
+                }
             }
         }
     } else {
@@ -438,19 +470,35 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
 #pragma unroll 1
         for (int s = 0; s < nsteps; ++s) {
             const uint32_t sb = lds0 + (uint32_t)((s % NSTG) * STG_B);
+            COLS_STAMP(4)
             step_top(s, s >= 2 ? 4 : 0);
+            COLS_STAMP(0)
             if (s > 0) finish(s - 1, dinA, dinB);
+            COLS_STAMP(1)
             if constexpr (HAS_IN) {
                 lds_read16<3 * 8192>(dinA, sb + a_xcl[0]); lds_read16<3 * 8192>(dinB, sb + a_xcl[1]);
                 lgkm_fence(dinA); lgkm_tie(dinB);
             }
             wg_products(sb, I2{}, X2O{}, sb + a_xtr[0], sb + a_xtr[1], accA, -1);
             wg_products(sb, I3{}, X1O{}, sb + a_xtr[0], sb + a_xtr[1], accG, -1);
+#ifdef VLPET_COLS_STAMPS
+            asm volatile("s_nop 0" : "+v"(accA[RT - 1][15]), "+v"(accG[RT - 1][15]));
+#endif
+            COLS_STAMP(2)
             p2 = zero16(); p1 = zero16();
             project(sb, I2{}, wA, p2);
             project(sb, I3{}, wG, p1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef VLPET_COLS_STAMPS
+            asm volatile("s_nop 0" : "+v"(p1[15]), "+v"(p2[15]));
+#endif
+            COLS_STAMP(3)
         }
+#ifdef VLPET_COLS_STAMPS
+        if (lane == 0 && wave == 4 && (blockIdx.x == 0 || blockIdx.x == 101))
+            printf("cols stamps D blk %d (10 ns units, %d steps): top %llu finish %llu wgrad %llu project %llu other %llu\n", (int)blockIdx.x, nsteps,
+                   (unsigned long long)tacc[0], (unsigned long long)tacc[1], (unsigned long long)tacc[2], (unsigned long long)tacc[3], (unsigned long long)tacc[4]);
+#endif
         __builtin_amdgcn_s_barrier();                                     // role U has written the last dh tile
         if (nsteps > 0) finish(nsteps - 1, dinA, dinB);
     }
