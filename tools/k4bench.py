@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""K4 (visual projection: Linear(2048 -> 768) + LayerNorm) at the bench's visual-row count: forward and weight gradient through
+the C ABI, HIP events, plus the same GEMM through the library for reference.  usage: k4bench.py [tag] [M...]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import vlpet_amd.functional as F
+from vlpet_amd import _lib
+from vlpet_amd.visproj import VisProjPackCache
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "k4"
+Ms = [int(a) for a in sys.argv[2:]] or [18700]
+lib = _lib.load()
+dev, dt, Fd, d = "cuda", torch.bfloat16, 2048, 768
+st = torch.cuda.current_stream().cuda_stream
+
+
+def timed(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+for M in Ms:
+    g = torch.Generator(device=dev).manual_seed(0)
+    feats = torch.randn(M, Fd, device=dev, generator=g).to(dt)
+    lin = torch.nn.Linear(Fd, d).to(dev)
+    gamma = torch.ones(d, device=dev); beta = torch.zeros(d, device=dev)
+    packed = VisProjPackCache().get(lin.weight, lin.bias, 1)
+    out = torch.empty(M, d, dtype=dt, device=dev); xhat = torch.empty_like(out); rstd = torch.empty(M, device=dev)
+    dpre = torch.randn(M, d, device=dev, generator=g).to(dt)
+    dw = torch.empty(d, Fd, device=dev); db = torch.empty(d, device=dev)
+    nws = lib.vlpet_visproj_wgrad_workspace_bytes(M, Fd, d); ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+
+    def fwd():
+        rc = lib.vlpet_visproj_fwd(feats.data_ptr(), packed.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 0, out.data_ptr(),
+                                   xhat.data_ptr(), rstd.data_ptr(), M, Fd, d, 1e-5, 0, 1, st); assert rc == 0
+
+    def wgrad():
+        rc = lib.vlpet_visproj_wgrad(dpre.data_ptr(), feats.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, M, Fd, d, 1, st)
+        assert rc == 0
+
+    wb = lin.weight.detach().to(dt)
+    t_f, t_w = timed(fwd), timed(wgrad)
+    t_lf = timed(lambda: torch.nn.functional.linear(feats, wb))
+    t_lw = timed(lambda: dpre.t() @ feats)
+    fl = 2.0 * M * Fd * d
+    # parity of the two against the library results (bf16 tolerance)
+    fwd(); wgrad(); torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm((feats.float() @ lin.weight.float().t() + lin.bias.float()), (d,), gamma, beta, 1e-5)
+    e_f = float((out.float() - ref).abs().max() / ref.abs().max())
+    refw = dpre.float().t() @ feats.float()
+    e_w = float((dw - refw).abs().max() / refw.abs().max())
+    print(f"k4bench {tag:8s} M={M:6d}: fwd {t_f:7.1f} us ({fl / t_f / 1e6:6.0f} TFLOP/s, frac {fl / t_f / 1e6 / 2500:.3f}, err {e_f:.1e})   "
+          f"wgrad {t_w:7.1f} us ({fl / t_w / 1e6:6.0f} TFLOP/s, frac {fl / t_w / 1e6 / 2500:.3f}, err {e_w:.1e})   | library GEMMs alone: "
+          f"fwd {t_lf:6.1f} us, wgrad {t_lw:6.1f} us", flush=True)

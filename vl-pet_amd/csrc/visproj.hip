@@ -224,6 +224,15 @@ __global__ __launch_bounds__(WAVES * 64) void visproj_fwd_kernel(VisprojArgs a) 
 // same rows per workgroup, same weight bytes per MFMA (the fragment stream is shared by the eight waves, the row
 // tile by the two halves of a row group), the LayerNorm statistics cross the two halves through LDS (two exchanges:
 // mean, then centred variance -- the reference's two-pass order).
+#ifndef VLPET_K4_GB
+#define VLPET_K4_GB 3
+#endif
+#ifndef VLPET_K4_ABL
+#define VLPET_K4_ABL 0
+#endif
+#ifndef VLPET_K4_SPLIT_ISSUE
+#define VLPET_K4_SPLIT_ISSUE 0
+#endif
 template <typename IO, int NCT>
 struct VisLds2 {
     static constexpr int NS = Geo4<IO>::NS;
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(512) void visproj_fwd2_kernel(VisprojArgs a) {
     constexpr int NS = G::NS;
     constexpr int WAVES = L::WAVES, RGN = L::RGN;
     constexpr int NCW = NCT / L::CH;             // accumulator tiles per wave
-    constexpr int GB = NCW < 6 ? NCW : 6;        // A fragments read per LDS burst
+    constexpr int GB = NCW % VLPET_K4_GB == 0 ? VLPET_K4_GB : 1;      // A fragments per LDS burst (double-buffered)
     static_assert(NCW % GB == 0, "burst must divide the tiles of a wave");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
@@ -276,13 +285,24 @@ __global__ __launch_bounds__(512) void visproj_fwd2_kernel(VisprojArgs a) {
         if (q1 >= Q) return;
         const uint8_t* src0 = a.pk + (int64_t)q1 * L::WSUB_B;
         uint8_t* dst = slot_w(q1 % L::NW);
-        for (int k = wave; k < KBW; k += WAVES) glds16(src0 + (size_t)k * 1024 + lane16, dst + (size_t)k * 1024);
+        if constexpr (L::NW >= 4 && VLPET_K4_SPLIT_ISSUE) {
+            // the weight pieces are requested by the column-half-1 waves only, the row pieces by the column-half-0 waves: the two
+            // waves of a SIMD then stall in their requests at different times instead of together (the matrix pipe idled through both)
+            if (ch == 1)
+                for (int k = rgi; k < KBW; k += RGN) glds16(src0 + (size_t)k * 1024 + lane16, dst + (size_t)k * 1024);
+        } else {
+            for (int k = wave; k < KBW; k += WAVES) glds16(src0 + (size_t)k * 1024 + lane16, dst + (size_t)k * 1024);
+        }
     };
     const int npw = wave < KBW ? (KBW - wave + WAVES - 1) / WAVES : 0;     // weight pieces this wave issues per sub-stage
     const int nrow = ch == 0 ? 4 : 0;                                        // row pieces this wave issues per stage
 
+    constexpr bool PAIRS = L::NW >= 4;            // (fp32 IO: two 48-KiB weight slots, one sub-stage per barrier as before)
+    if constexpr (PAIRS) { issue_w(0); issue_w(1); }
+    else {
 #pragma unroll
-    for (int q0 = 0; q0 < L::NW - 1; ++q0) issue_w(q0);
+        for (int q0 = 0; q0 < L::NW - 1; ++q0) issue_w(q0);
+    }
     issue_rows(0);
     issue_rows(1);
     {
@@ -298,6 +318,55 @@ __global__ __launch_bounds__(512) void visproj_fwd2_kernel(VisprojArgs a) {
     f32x16 acc[NCW];
 #pragma unroll
     for (int ct = 0; ct < NCW; ++ct) acc[ct] = zero16();
+    // Round 3: the loop walks PAIRS of 16-feature sub-stages -- one counted wait and one barrier per 32 features instead of per
+    // 16, and the A fragments of the pair form one chain of bursts (the next burst is requested before the MFMAs of the current
+    // one), so that only the first burst of a pair waits for its LDS round trip.  Before: 2 x [6 reads, wait, 6 MFMAs], wait,
+    // barrier per sub-stage = 1.7 k cycles for 0.77 k cycles of MFMA issue per SIMD, at any M (a latency chain of 128 links).
+    static_assert(G::KU % 2 == 0, "pairs of sub-stages inside a row stage");
+    constexpr int NB = NCW / GB;                  // bursts per sub-stage
+    if constexpr (PAIRS) {
+    for (int q = 0; q < Q; q += 2) {
+        const int s = q / G::KU, u = q % G::KU;
+#if VLPET_K4_ABL != 2          // (ablation builds: 1 = the stream without the products, 2 = the products without the stream)
+        issue_w(q + 2);
+        issue_w(q + 3);
+#endif
+        const bool rows_now = u == 0 && s + 2 < S;
+#if VLPET_K4_ABL != 2
+        if (u == 0) issue_rows(s + 2);
+#endif
+        const uint8_t* w0 = slot_w(q % L::NW);
+        const uint8_t* w1 = slot_w((q + 1) % L::NW);
+        const Frag<NS> b0 = tile_bfrag4<IO>(slot_t(s % 3), trow, h, u);
+        const Frag<NS> b1 = tile_bfrag4<IO>(slot_t(s % 3), trow, h, u + 1);
+#if VLPET_K4_ABL != 1
+        {
+            Frag<NS> wa[2][GB];
+#pragma unroll
+            for (int i = 0; i < GB; ++i) wa[0][i] = wfrag<NS>(w0, ch * NCW + i, lane);
+#pragma unroll
+            for (int t = 0; t < 2 * NB; ++t) {
+                if (t + 1 < 2 * NB) {
+                    const uint8_t* wn = (t + 1 < NB) ? w0 : w1;
+#pragma unroll
+                    for (int i = 0; i < GB; ++i) wa[(t + 1) & 1][i] = wfrag<NS>(wn, ch * NCW + ((t + 1) % NB) * GB + i, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < GB; ++i) acc[(t % NB) * GB + i] = mfma_ns<NS>(wa[t & 1][i], t < NB ? b0 : b1, acc[(t % NB) * GB + i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
+        acc[0][0] += (float)b0.p[0][0] + (float)b1.p[0][0] + (float)w0[lane] + (float)w1[lane];
+#endif
+        // this wave's requests in program order: W(q+2) W(q+3) [rows(s+2)]: the next pair's weights must have landed; the
+        // rows of the stage after next may stay in flight
+        wait_vm(rows_now ? nrow : 0);
+        __builtin_amdgcn_s_barrier();
+    }
+    } else {
+    constexpr int GB1 = NCW < 6 ? NCW : 6;
     for (int q = 0; q < Q; ++q) {
         const int s = q / G::KU, u = q % G::KU;
         issue_w(q + L::NW - 1);
@@ -305,13 +374,13 @@ __global__ __launch_bounds__(512) void visproj_fwd2_kernel(VisprojArgs a) {
         const uint8_t* w = slot_w(q % L::NW);
         const Frag<NS> b = tile_bfrag4<IO>(slot_t(s % 3), trow, h, u);
 #pragma unroll
-        for (int g0 = 0; g0 < NCW; g0 += GB) {
-            Frag<NS> wa[GB];
+        for (int g0 = 0; g0 < NCW; g0 += GB1) {
+            Frag<NS> wa[GB1];
 #pragma unroll
-            for (int i = 0; i < GB; ++i) wa[i] = wfrag<NS>(w, ch * NCW + g0 + i, lane);
+            for (int i = 0; i < GB1; ++i) wa[i] = wfrag<NS>(w, ch * NCW + g0 + i, lane);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < GB; ++i) acc[g0 + i] = mfma_ns<NS>(wa[i], b, acc[g0 + i]);
+            for (int i = 0; i < GB1; ++i) acc[g0 + i] = mfma_ns<NS>(wa[i], b, acc[g0 + i]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // (see visproj_fwd_kernel: what may stay in flight while the next sub-stage's weights and rows must have landed)
@@ -322,6 +391,8 @@ __global__ __launch_bounds__(512) void visproj_fwd2_kernel(VisprojArgs a) {
             wait_vm(keep);
         }
         __builtin_amdgcn_s_barrier();
+    }
+
     }
 
     // ---- bias, LayerNorm statistics: this wave holds half of the row (lane + partner lane^32), the partner wave the rest
