@@ -85,3 +85,23 @@ def test_k4_real_shape_vs_oracle(dtype, tol):
            ve.img_order_embedding.weight]
     for a, b in zip(got, ref[:9]):
         assert rel_err(a.grad, b.grad) <= tol
+
+
+@pytest.mark.parametrize("M,F,d", [(1, 256, 384), (31, 256, 384), (33, 512, 768), (4097, 2048, 768), (18700, 2048, 768)])
+def test_k4_weight_gradient_tiled_gemm(M, F, d):
+    """vlpet_visproj_wgrad in its round-3 form (csrc/visproj_wgrad.hip: [384 x 256] tiles, split-K over row chunks) against
+    fp32 matmuls of the same bf16 inputs: dW = dpre^T feats, db = column sums of dpre; one row, ragged last steps, one tile."""
+    from vlpet_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    dpre = torch.randn(M, d, device="cuda", generator=g).to(torch.bfloat16)
+    feats = torch.randn(M, F, device="cuda", generator=g).to(torch.bfloat16)
+    dw = torch.full((d, F), float("nan"), device="cuda"); db = torch.full((d,), float("nan"), device="cuda")
+    nws = lib.vlpet_visproj_wgrad_workspace_bytes(M, F, d)
+    ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+    rc = lib.vlpet_visproj_wgrad(dpre.data_ptr(), feats.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, M, F, d,
+                                 _lib.VLPET_BF16, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    ref_w = dpre.float().t() @ feats.float()
+    ref_b = dpre.float().sum(0)
+    assert rel_err(dw, ref_w) <= 1e-4 and rel_err(db, ref_b) <= 1e-4      # exact products of bf16 inputs, fp32 sums

@@ -599,7 +599,12 @@ extern "C" size_t vlpet_visproj_wgrad_workspace_bytes(int64_t M, int feat_dim, i
     if (M <= 0 || feat_dim <= 0 || d_out <= 0) return 0;
     int RT, pcols, rc; int64_t rpc;
     visproj_wgrad_plan(M, feat_dim, d_out, &RT, &pcols, &rc, &rpc);
-    return align256(wgrad_workspace_bytes(4, RT, feat_dim, rc));
+    size_t n = wgrad_workspace_bytes(4, RT, feat_dim, rc);
+    if (k4_wgrad2_applies(M, feat_dim, d_out, 0)) {                 // (dtype-independent size: the larger of the two forms)
+        const size_t n2 = k4_wgrad2_workspace_bytes(M, feat_dim, d_out);
+        if (n2 > n) n = n2;
+    }
+    return align256(n);
 }
 
 extern "C" int vlpet_visproj_wgrad(const void* dpre, const void* feats, float* dw, float* db, void* workspace,
@@ -609,6 +614,10 @@ extern "C" int vlpet_visproj_wgrad(const void* dpre, const void* feats, float* d
     if (M <= 0 || d_out % 32 != 0 || feat_dim <= 0 || feat_dim % 64 != 0) return VLPET_E_SHAPE;
     if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
     if (!aligned16(dpre) || !aligned16(feats) || !aligned16(workspace)) return VLPET_E_ALIGN;
+    if (vlpet_tuning().k4_wgrad2 != 0 && k4_wgrad2_applies(M, feat_dim, d_out, io_dtype == VLPET_F32)) {   // tiled split-K GEMM (round 3)
+        if (workspace_bytes < k4_wgrad2_workspace_bytes(M, feat_dim, d_out)) return VLPET_E_WORKSPACE;
+        return herr(launch_k4_wgrad2(dpre, feats, dw, db, workspace, M, feat_dim, d_out, (hipStream_t)stream));
+    }
     int RT, pcols, rc; int64_t rpc;
     visproj_wgrad_plan(M, feat_dim, d_out, &RT, &pcols, &rc, &rpc);
     if (workspace_bytes < wgrad_workspace_bytes(4, RT, feat_dim, rc)) return VLPET_E_WORKSPACE;

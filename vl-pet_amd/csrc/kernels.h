@@ -130,6 +130,11 @@ size_t wgrad_workspace_bytes(int njobs, int RT, int xcols_max, int row_chunks);
 hipError_t launch_wgrad_finalize(const WgradArgs& a, hipStream_t stream);      // sums the row-chunk partials into the outputs
 void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* rows_per_chunk);
 hipError_t launch_wgrad(const WgradArgs& a, int io_fp32, hipStream_t stream);
+// K4 weight gradient as a tiled split-K GEMM (visproj_wgrad.hip; bf16, F % 256 == 0, d_out % 384 == 0)
+bool k4_wgrad2_applies(int64_t M, int F, int d_out, int io_fp32);
+size_t k4_wgrad2_workspace_bytes(int64_t M, int F, int d_out);
+hipError_t launch_k4_wgrad2(const void* dpre, const void* feats, float* dw, float* db, void* workspace, int64_t M, int F, int d_out,
+                            hipStream_t stream);
 
 // Two-pass gated K1 backward (pet_gate_bwd3.hip): pass 1 writes dpre only, pass 2 (column-parallel) recomputes dh / dq per
 // feature block and produces the input gradients and the four weight gradients.
