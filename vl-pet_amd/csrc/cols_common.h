@@ -70,3 +70,20 @@ __device__ __forceinline__ float sigm(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+
+// Workgroup -> (group, member) map of the column-parallel passes.  A group = the U workgroups that re-read the same bottleneck
+// rows (the column blocks of a row chunk); block b runs on XCD b % 8, and a group's members should share an XCD's L2.  Each XCD
+// has 32 CUs = G = 32 / U whole groups (slots j = b / 8 < U * G); the 32 - U * G CUs per XCD that are left over take the
+// members of a few more groups, spread over the XCDs (those groups re-read their bottleneck rows through several L2s -- a few
+// MB -- but at d = 768 they turn 240 busy CUs into 252: two more row chunks, one step less per workgroup).
+__host__ __device__ inline int cols_groups_max(int U) { const int G = 32 / U; return 8 * G + ((32 - U * G) * 8) / U; }
+__host__ __device__ inline void cols_decode(int b, int U, int& group, int& member) {
+    const int G = 32 / U, main = U * G, x = b & 7, j = b >> 3;
+    if (j < main) { member = j % U; group = (j / U) * 8 + x; }
+    else { const int l = (j - main) * 8 + x; group = 8 * G + l / U; member = l % U; }
+}
+__host__ __device__ inline unsigned cols_grid(int U, int ngroups) {
+    const int G = 32 / U;
+    if (ngroups <= 8 * G) return 8u * (unsigned)U * (unsigned)((ngroups + 7) / 8);
+    return 8u * (unsigned)(U * G + ((ngroups - 8 * G) * U + 7) / 8);
+}

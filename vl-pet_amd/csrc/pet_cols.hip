@@ -69,9 +69,8 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
 
     // ---- which (column block, row chunk): the column blocks of a row chunk share an XCD (they re-read the same bottleneck rows)
     const int d = a.d, NCB = d >> 7;
-    const int bq = blockIdx.x >> 3;
-    const int cb = bq % NCB;
-    const int rc = (bq / NCB) * 8 + (blockIdx.x & 7);
+    int rc, cb;
+    cols_decode((int)blockIdx.x, NCB, rc, cb);
     if (rc >= a.row_chunks) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int role = wave >> 2, wc = wave & 3;          // waves w and w + 4 share a SIMD: the up side and the down side of a column quarter
@@ -521,7 +520,7 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
 // 8 * floor(32 / NCB) chunks; a chunk is a multiple of 32 rows.
 void k1_cols_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk) {
     const int ncb = d >= 128 ? d / 128 : 1;             // (d < 128: the form does not apply; the plan only sizes workspaces)
-    int64_t rc = 8 * (32 / (ncb < 32 ? ncb : 32));
+    int64_t rc = cols_groups_max(ncb < 32 ? ncb : 32);
     const int64_t blocks32 = (M + 31) / 32;
     if (rc > blocks32) rc = blocks32;
     if (rc < 1) rc = 1;
@@ -544,7 +543,7 @@ static hipError_t launch_cols_cfg(const ColzArgs& c, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int ncb = c.d / 128;
-    const unsigned grid = 8u * (unsigned)ncb * (unsigned)((c.row_chunks + 7) / 8);
+    const unsigned grid = cols_grid(ncb, c.row_chunks);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, c);
     return hipGetLastError();
 }

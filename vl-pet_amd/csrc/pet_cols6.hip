@@ -39,10 +39,10 @@ __global__ __launch_bounds__(512, 2) void k1_cols6_kernel(ColzArgs a) {
     // ---- which (column block, row chunk).  Groups = (row chunk, half of the column blocks): the column blocks of a group share
     // an XCD (block b runs on XCD b % 8) and with it the L2 copies of the bottleneck rows they all re-read
     const int d = a.d, NCB = d >> 6, CBH = NCB >> 1;
-    const int bq = blockIdx.x >> 3;
-    const int grp = (bq / CBH) * 8 + (blockIdx.x & 7);
+    int grp, mem;
+    cols_decode((int)blockIdx.x, CBH, grp, mem);
     if (grp >= 2 * a.row_chunks) return;
-    const int rc = grp >> 1, cb = (grp & 1) * CBH + bq % CBH;
+    const int rc = grp >> 1, cb = (grp & 1) * CBH + mem;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = wave & 1, side = (wave >> 1) & 1, kind = wave >> 2;   // column quarter, U / D, E / W  (waves w, w + 4 share a SIMD)
     const int m = lane & 31, h = lane >> 5;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void k1_cols6_kernel(ColzArgs a) {
 // most 32 workgroups (one per CU) there: 8 * floor(32 / (d / 128)) groups = half as many row chunks.
 void k1_cols6_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk) {
     const int cbh = d >= 128 ? d / 128 : 1;
-    int64_t rc = 8 * (32 / (cbh < 32 ? cbh : 32)) / 2;
+    int64_t rc = cols_groups_max(cbh < 32 ? cbh : 32) / 2;
     const int64_t blocks32 = (M + 31) / 32;
     if (rc > blocks32) rc = blocks32;
     if (rc < 1) rc = 1;
@@ -420,7 +420,7 @@ static hipError_t launch_cols6_cfg(const ColzArgs& c, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int cbh = c.d / 128;
-    const unsigned grid = 8u * (unsigned)cbh * (unsigned)((2 * c.row_chunks + 7) / 8);
+    const unsigned grid = cols_grid(cbh, 2 * c.row_chunks);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, c);
     return hipGetLastError();
 }
