@@ -278,6 +278,11 @@ static BwdWs bwd_ws(int64_t M, int d, int tiles, bool gate, int io_dtype) {
     const int njobs = gate ? 4 : 2;
     wgrad_plan(M, njobs, d, &w.row_chunks, &w.rows_per_chunk);
     int chunks = w.row_chunks;
+    if (!gate && d % 128 == 0) {                        // the two-pass form without a gate (pet_cols_ng.hip) cuts the rows its own way
+        int rcn; int64_t rpcn;
+        ng_cols_plan(M, d, &rcn, &rpcn);
+        if (rcn > chunks) chunks = rcn;
+    }
     if (gate) {     // the two-pass gated backward (pet_gate_bwd3.hip) cuts the rows differently: room for either plan
         int rc3, gs3, ng3; int64_t rpc3;
         gate_bwd3_plan(M, d, io_dtype == VLPET_F32, &rc3, &rpc3, &gs3, &ng3);
@@ -354,7 +359,26 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     const bool cols4 = cols6 || (!(phases & 4) && k1_cols_applies(b, io_dtype == VLPET_F32));
     const bool two_pass = cols4 || (!(phases & 4) && pet_gate_bwd3_applies(b));
     const bool rows2 = !two_pass && pet_gate_bwd2_applies(b);
+    // without a gate (K2, adapter-only K1, K3 without dropout), bf16, saved activations, whole call: pass 1 (dpre) + the
+    // column-parallel pass of pet_cols_ng.hip (dx and both weight gradients from one read of dy and x)
+    const bool ng2 = !gate && phases == 3 && vlpet_tuning().ng2 != 0 && ng_two_pass_applies(b, io_dtype == VLPET_F32);
     int gs3 = 0, ng3 = 0;
+    if (ng2) {
+        WgradArgs g{};
+        g.M = M; g.RT = tiles; g.njobs = 2;
+        ng_cols_plan(M, d, &g.row_chunks, &g.rows_per_chunk);
+        g.partial = reinterpret_cast<float*>(ws + w.partial);
+        const int ldp = 32 * tiles;
+        WgradJob& J0 = g.job[0];                        // dWd[c,k] = sum_m dpre[m,c] x[m,k];  dbd = column sums of dpre
+        J0.P = b.dp_a; J0.ldp = ldp; J0.pcols = ldp; J0.X = xa; J0.ldx = d; J0.xcols = d; J0.drop = NO_DROP; J0.has_drop = 0;
+        J0.scale = 1.f; J0.out = dwd; J0.ldo = d; J0.transposed = 0; J0.out_rows = r; J0.colsum_x = nullptr; J0.colsum_p = dbd;
+        WgradJob& J1 = g.job[1];                        // dWu[f,c] = sd * sum_m dy[m,f] z[m,c];  dbu = sd * column sums of dy
+        J1.P = b.z_a; J1.ldp = ldp; J1.pcols = ldp; J1.X = dy; J1.ldx = d; J1.xcols = d; J1.drop = NO_DROP; J1.has_drop = 0;
+        J1.scale = sd; J1.out = dwu; J1.ldo = r; J1.transposed = 1; J1.out_rows = r; J1.colsum_x = dbu; J1.colsum_p = nullptr;
+        hipError_t e = launch_ng_two_pass(b, g, 3, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+        return herr(launch_wgrad_finalize(g, (hipStream_t)stream));
+    }
     if (phases & 1) {
         if (rows2) b.dxg_in = dx1_in;                   // the chain-split row kernel adds it in its epilogue
         const bool dz2 = two_pass && vlpet_tuning().dz2 != 0 && k1_dz2_applies(b, io_dtype == VLPET_F32);

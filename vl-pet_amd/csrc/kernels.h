@@ -130,6 +130,10 @@ size_t wgrad_workspace_bytes(int njobs, int RT, int xcols_max, int row_chunks);
 hipError_t launch_wgrad_finalize(const WgradArgs& a, hipStream_t stream);      // sums the row-chunk partials into the outputs
 void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* rows_per_chunk);
 hipError_t launch_wgrad(const WgradArgs& a, int io_fp32, hipStream_t stream);
+// Backward without a gate (K2, adapter-only K1, K3 without dropout) in two passes (pet_cols_ng.hip; bf16, r <= 96, saved activations)
+bool ng_two_pass_applies(const PetBwdArgs& a, int io_fp32);
+void ng_cols_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk);
+hipError_t launch_ng_two_pass(const PetBwdArgs& b, const WgradArgs& g, int passes, hipStream_t stream);
 // K4 weight gradient as a tiled split-K GEMM (visproj_wgrad.hip; bf16, F % 256 == 0, d_out % 384 == 0)
 bool k4_wgrad2_applies(int64_t M, int F, int d_out, int io_fp32);
 size_t k4_wgrad2_workspace_bytes(int64_t M, int F, int d_out);
