@@ -1,0 +1,34 @@
+"""Backward WITHOUT a gate in its round-3 two-pass form (csrc/pet_cols_ng.hip: bf16, r <= 96, the forward's saved activations) --
+K2 (adapters/adapter_modeling.py:55-61), the adapter-only K1 of the small / middle gate scripts, K3 without dropout -- against
+the CPU oracle through the product path: one row, the 32-row step and 128-row workgroup boundaries, other widths and ranks,
+a scale, the identity activation; full size."""
+import pytest
+import torch
+
+import gpu_cases as C
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-2          # BASELINE.json: 1e-2 for bf16 IO
+
+
+def _check(errs):
+    bad = {k: v for k, v in errs.items() if k != "keep_frac" and not (v <= TOL)}
+    assert not bad, errs
+
+
+@pytest.mark.parametrize("kw", [dict(M=1), dict(M=31), dict(M=33), dict(M=127), dict(M=129), dict(M=777, r=8), dict(M=1000, r=32),
+                                dict(M=640, d=256, r=16), dict(M=3000, d=1024), dict(M=5000, scale=0.25), dict(M=28000), dict(M=46648)],
+                         ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_k2_two_pass_vs_oracle(kw):
+    _check(C.run_k2(torch.bfloat16, **kw))
+
+
+@pytest.mark.parametrize("kw", [dict(M=130), dict(M=1000, delta_scale=0.5, x2_scale=0.7), dict(M=777, r=8, rg=8, nh=4), dict(M=15272)],
+                         ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_k1_adapter_only_two_pass_vs_oracle(kw):
+    _check(C.run_k1(torch.bfloat16, gate_mode=0, **kw))
+
+
+@pytest.mark.parametrize("M,r", [(200, 8), (2500, 64), (28000, 64)])
+def test_k3_without_dropout_two_pass_vs_oracle(M, r):
+    _check(C.run_k3(torch.bfloat16, M=M, r=r, p=0.0))
