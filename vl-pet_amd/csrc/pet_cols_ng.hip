@@ -33,14 +33,15 @@ template <int RT> struct NgDzGeo {
     static constexpr int WT_B = 64 * PB;               // the Wu block of a stage [64 f x 32*RT c]
     static constexpr int XT_B = 128 * 128;             // the dy tile
     static constexpr int STG_B = WT_B + XT_B;
-    static constexpr int NSTG = 4;
     static constexpr int NWW = (4 * RT + 7) / 8;       // weight pieces per wave (the last ones may be missing)
 };
 
-template <int RT>
+// NSTG = 4: one workgroup per CU, three stages ahead (M <= 32,768: one round of 128-row workgroups on 256 CUs);
+// NSTG = 2: 56 KiB of LDS, two workgroups per CU (96 registers allow it): up to 65,536 rows in one round
+template <int RT, int NSTG>
 __global__ __launch_bounds__(512, 2) void ng_dz_kernel(NgArgs a) {
     using GEO = NgDzGeo<RT>;
-    constexpr int PB = GEO::PB, NPS = GEO::NPS, WT_B = GEO::WT_B, STG_B = GEO::STG_B, NSTG = GEO::NSTG, NWW = GEO::NWW;
+    constexpr int PB = GEO::PB, NPS = GEO::NPS, WT_B = GEO::WT_B, STG_B = GEO::STG_B, NWW = GEO::NWW;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = wave & 3, fh = wave >> 2;
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void ng_cols_kernel(NgArgs a) {
 bool ng_two_pass_applies(const PetBwdArgs& a, int io_fp32) {
     if (io_fp32 || (a.flags & PET_GATE) || a.saved == nullptr || drop_active(a.drop)) return false;
     if (!(a.RT == 1 || a.RT == 3) || a.d % 128 != 0 || a.d / 128 > 32) return false;
-    return (size_t)NgDzGeo<3>::NSTG * NgDzGeo<3>::STG_B <= (size_t)160 * 1024;
+    return true;
 }
 void ng_cols_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk) {
     const int ncb = d >= 128 ? d / 128 : 1;
@@ -433,10 +434,14 @@ void ng_cols_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk) {
 template <int RT>
 static hipError_t launch_ng_rt(const NgArgs& a, int passes, hipStream_t stream) {
     if (passes & 1) {
-        const size_t lds = (size_t)NgDzGeo<RT>::NSTG * NgDzGeo<RT>::STG_B;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ng_dz_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const bool two_per_cu = a.M > 128 * 256;        // more 128-row workgroups than CUs: the two-slot form, two per CU
+        const size_t lds = (size_t)(two_per_cu ? 2 : 4) * NgDzGeo<RT>::STG_B;
+        const void* kern = two_per_cu ? reinterpret_cast<const void*>(ng_dz_kernel<RT, 2>) : reinterpret_cast<const void*>(ng_dz_kernel<RT, 4>);
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(ng_dz_kernel<RT>, dim3((unsigned)((a.M + 127) / 128)), dim3(512), lds, stream, a);
+        const dim3 grid((unsigned)((a.M + 127) / 128));
+        if (two_per_cu) hipLaunchKernelGGL((ng_dz_kernel<RT, 2>), grid, dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((ng_dz_kernel<RT, 4>), grid, dim3(512), lds, stream, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
