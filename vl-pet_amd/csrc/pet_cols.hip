@@ -9,15 +9,14 @@
 //     dh = gs*dy*g,  dq = dh*h*(1-g),  h = s2*x2 + sd*(bu + Wu z_a),  g = sigmoid(bgu + Wgu z_g)     (f by f)
 //     dWu[f,c] = sd * sum_m dh[m,f] z_a[m,c]     dWgu[f,c] = sum_m dq[m,f] z_g[m,c]
 //     dWd[c,f] = sum_m dpre_a[m,c] x2[m,f]       dWgd[c,f] = sum_m dpre_g[m,c] x1[m,f]
-// so a workgroup owns 128 columns and a chunk of rows; each of its four waves owns 32 columns (one MFMA tile), keeps ITS
-// slice of the four weights (4 x 32 x r: 96 registers at r = 96) and its [r x 32] slices of the four weight gradients
-// (192 accumulator registers) in registers for the whole launch -- one wave per SIMD, the whole 512-entry register file --
-// and streams rows 32 at a time: reads dy, x1, x2 once, writes dx1, dx2 once (5 units = the op's algorithmic traffic), plus
-// the four [M, 32*RT] bottleneck tensors (z_a, z_g, dpre_a, dpre_g), which the d/128 column blocks of a row chunk re-read
-// through the L2 of one XCD.  Row chunks are any multiple of 32 rows: no round quantisation.  (A two-roles-per-SIMD form --
-// up side and down side on two waves of 256 registers -- was built first: 48 weights + 96 accumulators + 16 column sums per
-// wave leave hipcc 60-80 registers short in the loop, and a spill there is a scratch access on the vmcnt queue that the
-// counted waits below do not know about.)
+// so a workgroup owns 128 columns and a chunk of rows; a column quarter (32 columns = one MFMA tile) belongs to TWO waves of
+// one SIMD: the up side keeps Wu / Wgu of those columns (48 registers at r = 96) and the dWu / dWgu accumulators (96), the down
+// side Wd^T / Wgd^T and the dWd / dWgd accumulators, for the whole launch.  Rows stream by 32 at a time: dy, x1, x2 are read
+// once, dx1, dx2 written once (5 units = the op's algorithmic traffic), plus the four [M, 32*RT] bottleneck tensors (z_a, z_g,
+// dpre_a, dpre_g), which the d/128 column blocks of a row chunk re-read through the L2 of one XCD.  Row chunks are any multiple
+// of 32 rows: no round quantisation.  (The first build put both sides on one wave per SIMD with the whole register file: hipcc
+// spilled 360 registers in its loop; with the roles split, every accumulator and weight is live in exactly one loop and the
+// kernel fits 254 registers without a spill.)
 //
 // Per 32-row step and wave (r = 96): a_A = bu + Wu z_a, a_G = bgu + Wgu z_g (12 MFMAs), elementwise dh, dq -> LDS tiles,
 // p2 = Wd^T dpre_a, p1 = Wgd^T dpre_g (12), dWd += dpre_a^T x2, dWgd += dpre_g^T x1 (12), dx2 = s2*dh + p2 and
