@@ -371,7 +371,8 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
         const int ldp = 32 * tiles;
         WgradJob& J0 = g.job[0];                        // dWd[c,k] = sum_m dpre[m,c] x[m,k];  dbd = column sums of dpre
         J0.P = b.dp_a; J0.ldp = ldp; J0.pcols = ldp; J0.X = xa; J0.ldx = d; J0.xcols = d; J0.drop = NO_DROP; J0.has_drop = 0;
-        J0.scale = 1.f; J0.out = dwd; J0.ldo = d; J0.transposed = 0; J0.out_rows = r; J0.colsum_x = nullptr; J0.colsum_p = dbd;
+        J0.scale = drop_active(b.drop) ? b.drop.keep_scale : 1.f;      // (dropout: the kernel clears the dropped x, 1 / (1 - p) here)
+        J0.out = dwd; J0.ldo = d; J0.transposed = 0; J0.out_rows = r; J0.colsum_x = nullptr; J0.colsum_p = dbd;
         WgradJob& J1 = g.job[1];                        // dWu[f,c] = sd * sum_m dy[m,f] z[m,c];  dbu = sd * column sums of dy
         J1.P = b.z_a; J1.ldp = ldp; J1.pcols = ldp; J1.X = dy; J1.ldx = d; J1.xcols = d; J1.drop = NO_DROP; J1.has_drop = 0;
         J1.scale = sd; J1.out = dwu; J1.ldo = r; J1.transposed = 1; J1.out_rows = r; J1.colsum_x = dbu; J1.colsum_p = nullptr;

@@ -23,6 +23,7 @@ struct NgArgs {
     int64_t M;
     int d;
     float sd;
+    const uint8_t* bits; float ks;                                      // K3 dropout on x: the forward's packed mask [M, d/8] (rng.h drop_pos) and 1 / (1 - p)
     int row_chunks; int64_t rows_per_chunk;
     float* part[2];                                                     // job 0: dWd (+ column sums of dpre), job 1: dWu (+ column sums of dy)
 };
@@ -178,14 +179,19 @@ __global__ __launch_bounds__(512, 2) void ng_dz_kernel(NgArgs a) {
 template <int RT> struct NgColGeo {
     static constexpr int KT = 2 * RT, PB = 64 * RT, PT_B = 32 * PB;
     static constexpr int X_B = 2 * 2 * 4096;           // dy, x: two pair tiles [32 rows x 128 B] each
-    static constexpr int STG_B = X_B + 2 * PT_B;       // + z, dpre
+    static constexpr int MASK_OFF = X_B + 2 * PT_B;    // + z, dpre, then (DROP) 32 rows x 16 mask bytes of the 128 columns
+    static constexpr int STG_B = MASK_OFF + 1024;
     static constexpr int NSTG = 3;
 };
 
-template <int RT>
+// DROP (K3 with dropout): x enters the op as dropout(x) = x * mask / (1 - p), so dWd (= dA) sees the masked x and dx = mask / (1 - p) *
+// Wd^T dpre.  The 16 mask bytes per row of the workgroup's 128 columns travel with the stage (one more request of the last wave);
+// every down-side wave clears the dropped elements of ITS 32 columns of the x tile in LDS before its transpose reads (nobody else
+// reads them) and masks its 16 outputs per row; 1 / (1 - p) goes into dx directly and into dWd through the finalize scale.
+template <int RT, bool DROP>
 __global__ __launch_bounds__(512, 2) void ng_cols_kernel(NgArgs a) {
     using GEO = NgColGeo<RT>;
-    constexpr int KT = GEO::KT, PB = GEO::PB, PT_B = GEO::PT_B, X_B = GEO::X_B, STG_B = GEO::STG_B, NSTG = GEO::NSTG;
+    constexpr int KT = GEO::KT, PB = GEO::PB, PT_B = GEO::PT_B, X_B = GEO::X_B, STG_B = GEO::STG_B, NSTG = GEO::NSTG, MASK_OFF = GEO::MASK_OFF;
     constexpr int PR = 32 * RT;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
@@ -232,7 +238,8 @@ __global__ __launch_bounds__(512, 2) void ng_cols_kernel(NgArgs a) {
         pdst[j] = (uint32_t)(X_B + t * PT_B + piece * 1024);
         if (q < 4 * RT) npj = j + 1;
     }
-    const int NW = 2 + npj;
+    const bool mask_wave = DROP && wave == 7;
+    const int NW = 2 + npj + (mask_wave ? 1 : 0);
     auto sbase = [](const uint8_t* p) {
         const uint64_t u = reinterpret_cast<uint64_t>(p);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
@@ -252,6 +259,12 @@ __global__ __launch_bounds__(512, 2) void ng_cols_kernel(NgArgs a) {
         for (int j = 0; j < NPJ; ++j)
             if (j < npj)
                 glds16(sbase(pbase[j] + rb * PB) + poff[j] - (uint32_t)(prow[j] > last ? prow[j] - last : 0) * PB, st + pdst[j]);
+        if constexpr (DROP) {
+            if (mask_wave) {                            // lane -> row lane & 31 (both halves of the wave bring the same 512 bytes)
+                const int mr = (lane & 31) > last ? last : (lane & 31);
+                glds16(sbase(a.bits + rb * (int64_t)(d >> 3) + 16 * cb) + (uint32_t)mr * (uint32_t)(d >> 3), st + MASK_OFF);
+            }
+        }
     };
 
     // ---- per-lane LDS byte addresses (relative to the stage base)
@@ -377,6 +390,31 @@ __global__ __launch_bounds__(512, 2) void ng_cols_kernel(NgArgs a) {
             step_top(s, s >= 1 ? 2 : 0);                // (its two output stores of the previous step may stay in flight)
             const int64_t rb = r_begin + 32 * (int64_t)s;
             const int valid = (int)(r_end - rb) < 32 ? (int)(r_end - rb) : 32;
+            uint32_t mlo = 0xffffffffu, mhi = 0xffffffffu;                 // row m's keep flags of this wave's pair of 64 columns
+            if constexpr (DROP) {
+                // this lane clears row lane >> 1, groups 4 nt + 2 (lane & 1) + {0, 1} of the pair tile (two 16-byte slots)
+                const int xr = lane >> 1, par = lane & 1;
+                u32x2 mk;
+                lds_read8<0>(mk, sb + (uint32_t)(MASK_OFF + xr * 16 + 8 * pp));
+                u32x4 v0, v1;
+                const uint32_t xa0 = sb + (uint32_t)(8192 + pp * 4096 + xr * 128 + (((4 * nt + 2 * par) ^ fsw(xr)) * 16));
+                const uint32_t xa1 = sb + (uint32_t)(8192 + pp * 4096 + xr * 128 + (((4 * nt + 2 * par + 1) ^ fsw(xr)) * 16));
+                lds_read16<0>(v0, xa0); lds_read16<0>(v1, xa1);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mk), "+v"(v0), "+v"(v1) :: "memory");
+                const uint32_t k0 = mk[0] >> (8 * (2 * nt + par)), k1 = mk[1] >> (8 * (2 * nt + par));   // even group, odd group
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int l0 = ((int)(k0 << (31 - 2 * q))) >> 31, h0 = ((int)(k0 << (30 - 2 * q))) >> 31;
+                    const int l1 = ((int)(k1 << (31 - 2 * q))) >> 31, h1 = ((int)(k1 << (30 - 2 * q))) >> 31;
+                    v0[q] &= __builtin_amdgcn_perm((uint32_t)h0, (uint32_t)l0, 0x07060100u);
+                    v1[q] &= __builtin_amdgcn_perm((uint32_t)h1, (uint32_t)l1, 0x07060100u);
+                }
+                lds_write16<0>(xa0, v0); lds_write16<0>(xa1, v1);
+                u32x2 mo;                                                 // ... and the flags of its own 16 output columns of row m
+                lds_read8<0>(mo, sb + (uint32_t)(MASK_OFF + m * 16 + 8 * pp));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mo) :: "memory");
+                mlo = mo[0] >> (8 * (2 * nt + h)); mhi = mo[1] >> (8 * (2 * nt + h));
+            }
             wg_products(sb, I1{}, I1{}, -1);
             f32x16 p2 = zero16();
             {
@@ -389,7 +427,10 @@ __global__ __launch_bounds__(512, 2) void ng_cols_kernel(NgArgs a) {
             {
                 float o[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) o[e] = p2[e];
+                for (int e = 0; e < 16; ++e) {
+                    if constexpr (DROP) o[e] = (((e < 8 ? mlo : mhi) >> (e & 7)) & 1u) ? p2[e] * a.ks : 0.f;
+                    else o[e] = p2[e];
+                }
                 const u32x4 v0 = pack8(o), v1 = pack8(o + 8);
                 if (m < valid) {
                     const uint32_t rowoff = (uint32_t)m * (uint32_t)ld2 + (uint32_t)((c0 + 16 * h) * 2);
@@ -416,7 +457,9 @@ __global__ __launch_bounds__(512, 2) void ng_cols_kernel(NgArgs a) {
 
 // ================================================================================================== host side
 bool ng_two_pass_applies(const PetBwdArgs& a, int io_fp32) {
-    if (io_fp32 || (a.flags & PET_GATE) || a.saved == nullptr || drop_active(a.drop)) return false;
+    if (io_fp32 || (a.flags & PET_GATE) || a.saved == nullptr) return false;
+    // dropout (K3): only with the forward's packed mask (the training form), never an explicit byte mask or the generator
+    if (drop_active(a.drop) && (a.drop.bits == nullptr || a.drop.keep != nullptr || !(a.flags & PET_ACT_IDENTITY))) return false;
     if (!(a.RT == 1 || a.RT == 3) || a.d % 128 != 0 || a.d / 128 > 32) return false;
     return true;
 }
@@ -447,9 +490,13 @@ static hipError_t launch_ng_rt(const NgArgs& a, int passes, hipStream_t stream) 
     }
     if (passes & 2) {
         const size_t lds = (size_t)NgColGeo<RT>::NSTG * NgColGeo<RT>::STG_B;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ng_cols_kernel<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const bool drop = a.bits != nullptr;
+        const void* kern = drop ? reinterpret_cast<const void*>(ng_cols_kernel<RT, true>) : reinterpret_cast<const void*>(ng_cols_kernel<RT, false>);
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(ng_cols_kernel<RT>, dim3(cols_grid(a.d / 128, a.row_chunks)), dim3(512), lds, stream, a);
+        const dim3 grid(cols_grid(a.d / 128, a.row_chunks));
+        if (drop) hipLaunchKernelGGL((ng_cols_kernel<RT, true>), grid, dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((ng_cols_kernel<RT, false>), grid, dim3(512), lds, stream, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -463,6 +510,7 @@ hipError_t launch_ng_two_pass(const PetBwdArgs& b, const WgradArgs& g, int passe
     a.gp = (b.flags & PET_ACT_IDENTITY) ? nullptr : reinterpret_cast<const uint8_t*>(b.saved) + b.saved_stride;
     a.dp = b.dp_a; a.dx = b.dxa; a.pk = b.pk_a;
     a.M = b.M; a.d = b.d; a.sd = b.sd;
+    a.bits = drop_active(b.drop) ? b.drop.bits : nullptr; a.ks = drop_active(b.drop) ? b.drop.keep_scale : 1.f;
     a.row_chunks = g.row_chunks; a.rows_per_chunk = g.rows_per_chunk;
     const WgradLayout L = wgrad_layout(g);
     a.part[0] = g.partial + L.off[0]; a.part[1] = g.partial + L.off[1];
