@@ -451,7 +451,7 @@ def main():
                                  else f"pet_bwd_kernel<{args.dtype},{tiles},gate>"),
                  "k1_bwd_wgrad": f"k1_cols_kernel<{tiles}> (column-parallel pass of the K1 backward: reads dy, x1, x2, writes dx1, dx2)",
                  "k1_fwd": f"pet_gate_fwd_kernel<{args.dtype},{tiles}>",
-                 "k3_bwd": f"pet_bwd_kernel<{args.dtype},act_id> + wgrad_stream_kernel (one K3 backward)",
+                 "k3_bwd": f"ng_dz_kernel + ng_cols_kernel<drop> + wgrad_finalize_kernel (one K3 backward, two-pass form of csrc/pet_cols_ng.hip)",
                  "k3_fwd": f"pet_fwd_kernel<{args.dtype},act_id>"}[dom]
         traffic = None
         PMC_TRAFFIC = PMC_TRAFFIC_FORMS["two_pass" if (args.model != "lora" and two_pass) else "previous_split"]
