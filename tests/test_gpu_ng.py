@@ -17,7 +17,8 @@ def _check(errs):
 
 
 @pytest.mark.parametrize("kw", [dict(M=1), dict(M=31), dict(M=33), dict(M=127), dict(M=129), dict(M=777, r=8), dict(M=1000, r=32),
-                                dict(M=640, d=256, r=16), dict(M=3000, d=1024), dict(M=5000, scale=0.25), dict(M=28000), dict(M=46648)],
+                                dict(M=640, d=256, r=16), dict(M=3000, d=1024), dict(M=5000, scale=0.25), dict(M=28000), dict(M=46648),
+                                dict(M=100, r=192), dict(M=2100, r=192), dict(M=16800, r=192), dict(M=1000, r=128)],   # six tiles
                          ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
 def test_k2_two_pass_vs_oracle(kw):
     _check(C.run_k2(torch.bfloat16, **kw))
@@ -29,6 +30,8 @@ def test_k1_adapter_only_two_pass_vs_oracle(kw):
     _check(C.run_k1(torch.bfloat16, gate_mode=0, **kw))
 
 
-@pytest.mark.parametrize("M,r", [(200, 8), (2500, 64), (28000, 64)])
-def test_k3_without_dropout_two_pass_vs_oracle(M, r):
-    _check(C.run_k3(torch.bfloat16, M=M, r=r, p=0.0))
+@pytest.mark.parametrize("M,r,p", [(200, 8, 0.0), (2500, 64, 0.0), (28000, 64, 0.0), (333, 8, 0.1), (2500, 64, 0.1), (28000, 64, 0.1), (2500, 128, 0.1),
+                                   (28000, 128, 0.1)])
+def test_k3_two_pass_vs_oracle(M, r, p):
+    """p > 0: the training form with the forward's packed mask (the oracle gets the exported mask); r = 128: six tiles."""
+    _check(C.run_k3(torch.bfloat16, M=M, r=r, p=p))

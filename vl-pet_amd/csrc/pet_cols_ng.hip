@@ -1,6 +1,6 @@
 // Backward of the adapter WITHOUT a gate (K2: adapters/adapter_modeling.py:55-61 + adapter_controller.py:149-162; the
 // adapter-only K1 of the small / middle gate scripts; K3 when it runs without dropout) in the two-pass shape of the gated K1
-// backward (pet_dz2.hip + pet_cols.hip), bf16, r <= 96, with the forward's saved z / act'(pre):
+// backward (pet_dz2.hip + pet_cols.hip), bf16, r <= 192, with the forward's saved z / act'(pre):
 //     dz[m,c]   = sd * sum_f Wu[f,c] dy[m,f]          dpre = dz * act'(pre)                       (pass 1, row-parallel)
 //     dx[m,k]   = sum_c Wd[c,k] dpre[m,c]                                                        (pass 2, column-parallel)
 //     dWu[f,c]  = sd * sum_m dy[m,f] z[m,c]      dbu = sd * sum_m dy         dWd[c,k] = sum_m dpre[m,c] x[m,k]      dbd = sum_m dpre
@@ -460,7 +460,7 @@ bool ng_two_pass_applies(const PetBwdArgs& a, int io_fp32) {
     if (io_fp32 || (a.flags & PET_GATE) || a.saved == nullptr) return false;
     // dropout (K3): only with the forward's packed mask (the training form), never an explicit byte mask or the generator
     if (drop_active(a.drop) && (a.drop.bits == nullptr || a.drop.keep != nullptr || !(a.flags & PET_ACT_IDENTITY))) return false;
-    if (!(a.RT == 1 || a.RT == 3) || a.d % 128 != 0 || a.d / 128 > 32) return false;
+    if (!(a.RT == 1 || a.RT == 3 || a.RT == 6) || a.d % 128 != 0 || a.d / 128 > 32) return false;
     return true;
 }
 void ng_cols_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk) {
@@ -477,14 +477,15 @@ void ng_cols_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk) {
 template <int RT>
 static hipError_t launch_ng_rt(const NgArgs& a, int passes, hipStream_t stream) {
     if (passes & 1) {
-        const bool two_per_cu = a.M > 128 * 256;        // more 128-row workgroups than CUs: the two-slot form, two per CU
-        const size_t lds = (size_t)(two_per_cu ? 2 : 4) * NgDzGeo<RT>::STG_B;
-        const void* kern = two_per_cu ? reinterpret_cast<const void*>(ng_dz_kernel<RT, 2>) : reinterpret_cast<const void*>(ng_dz_kernel<RT, 4>);
+        const bool two_per_cu = RT <= 3 && a.M > 128 * 256;   // more 128-row workgroups than CUs: the two-slot form, two per CU (96 registers)
+        constexpr int NSTG1 = RT <= 3 ? 4 : 3;          // (six tiles: 40-KiB stages)
+        const size_t lds = (size_t)(two_per_cu ? 2 : NSTG1) * NgDzGeo<RT>::STG_B;
+        const void* kern = two_per_cu ? reinterpret_cast<const void*>(ng_dz_kernel<RT, 2>) : reinterpret_cast<const void*>(ng_dz_kernel<RT, NSTG1>);
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         const dim3 grid((unsigned)((a.M + 127) / 128));
         if (two_per_cu) hipLaunchKernelGGL((ng_dz_kernel<RT, 2>), grid, dim3(512), lds, stream, a);
-        else hipLaunchKernelGGL((ng_dz_kernel<RT, 4>), grid, dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((ng_dz_kernel<RT, NSTG1>), grid, dim3(512), lds, stream, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -514,5 +515,5 @@ hipError_t launch_ng_two_pass(const PetBwdArgs& b, const WgradArgs& g, int passe
     a.row_chunks = g.row_chunks; a.rows_per_chunk = g.rows_per_chunk;
     const WgradLayout L = wgrad_layout(g);
     a.part[0] = g.partial + L.off[0]; a.part[1] = g.partial + L.off[1];
-    return b.RT == 1 ? launch_ng_rt<1>(a, passes, stream) : launch_ng_rt<3>(a, passes, stream);
+    return b.RT == 1 ? launch_ng_rt<1>(a, passes, stream) : b.RT == 3 ? launch_ng_rt<3>(a, passes, stream) : launch_ng_rt<6>(a, passes, stream);
 }
