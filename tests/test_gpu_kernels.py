@@ -107,8 +107,12 @@ def test_k1_saved_and_recompute_backward_agree(dtype):
                                               M, d, tiles, 1, 1.0, 1.0, 1.0, io, st) == 0
         torch.cuda.synchronize()
         res.append([out.float(), dx1.float(), dx2.float()] + [t.float() for t in gp])
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][0], res[2][0])    # the forward's output does not depend on saving
     tol = 1e-4 if dtype == torch.float32 else 1e-2
+    assert torch.equal(res[1][0], res[2][0])         # the same forward kernels twice
+    if dtype == torch.float32:                       # fp32: saving and plain form are one kernel -- the output does not depend on saving
+        assert torch.equal(res[0][0], res[1][0])
+    else:                                            # bf16: the training form runs the two-pass forward (pet_fwd2p.hip), the plain form the one-kernel forward
+        assert (res[0][0] - res[1][0]).abs().max().item() <= tol * res[0][0].abs().max().item()
     for other in (res[1], res[2]):
         for a, b in zip(res[0][1:], other[1:]):
             assert (a - b).abs().max().item() <= tol * max(a.abs().max().item(), 1e-6)

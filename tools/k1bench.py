@@ -40,6 +40,11 @@ def run(M, tag):
                                                   M, d, tiles, 1, 1.0, 1.0, 1.0, io, st); assert rc == 0
         return f
     fwd_save()
+    if os.environ.get("K1BENCH_FWD_ONLY"):      # forward only (A/B of forward forms: VLPET_LIB=<debug build> VLPET_FWD2P=0|1|2|3)
+        f = min(timeit(fwd_save, iters=60, warm=5) for _ in range(2))
+        nb = 3 * d * M * 2
+        print(f"k1bench {tag:10s} M={M:6d} r={r:3d}: fwd+save {f:6.1f} us (frac of 8 TB/s on 3*d*b per row: {nb / f / 1e3 / 8000:.3f})", flush=True)
+        return
     if os.environ.get("K1BENCH_COLD"):
         # cold mode: the repeated call's inputs are otherwise hits of the 256 MB Infinity Cache left by the previous iteration, which a
         # training step never sees (third session).  Before every timed call a read-modify-write over 1 GiB.

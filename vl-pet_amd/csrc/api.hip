@@ -189,6 +189,9 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
         a.dbg_ts = dev;
     }
 #endif
+    // training form, bf16: two passes with the weights resident in registers where that form is the faster one
+    if (const int f2 = vlpet_tuning().fwd2p; f2 != 0 && k1_fwd2p_applies(a, io_dtype == VLPET_F32) && (f2 > 0 || k1_fwd2p_preferred(a)))
+        return herr(launch_k1_fwd2p(a, f2 == 2 ? 1 : f2 == 3 ? 2 : 3, (hipStream_t)stream));
     if ((flags & PET_GATE) && !(a.dbg & 64))      // two-chain gate forward: one wave per chain (VLPET_DBG=64: single-wave form)
         return herr(launch_pet_gate_fwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));
     return herr(launch_pet_fwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));

@@ -56,6 +56,10 @@ struct PetFwdArgs {
 hipError_t launch_pet_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream);
 hipError_t launch_pet_gate_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream);   // PET_GATE only
 hipError_t launch_pet_lowrank_fwd(const PetFwdArgs& a, int io_fp32, hipStream_t stream);   // low-rank visual projector form (d_in != d)
+// gated K1 forward, training form, as two passes with the weights resident in registers (pet_fwd2p.hip; bf16, d = 768)
+bool k1_fwd2p_applies(const PetFwdArgs& a, int io_fp32);
+bool k1_fwd2p_preferred(const PetFwdArgs& a);      // by shape: where the two-pass form measured faster than the one-kernel forward
+hipError_t launch_k1_fwd2p(const PetFwdArgs& a, int passes, hipStream_t stream);     // passes: bit 0 = pass A (down), bit 1 = pass B (up)
 
 struct PetBwdArgs {
     const void* dy;     // [M,d]
