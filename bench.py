@@ -302,6 +302,11 @@ def main():
     import vlpet_amd.train as TR
     from vlpet_amd import _lib
     _lib.load()     # fail loudly before anything is timed
+    ab_switches = None
+    if os.environ.get("VLPET_AB") == "1":     # same-box A/Bs: the host package's switches are attributes, set here from VLPET_* variables
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import ab_switches as _ab
+        ab_switches = _ab.apply()
     gemm_table = None
     if args.gemm_table != "off":     # library-GEMM solution selection for the frozen backbone (TunableOp; train.use_tuned_gemms)
         if args.gemm_table == "tune":
@@ -462,30 +467,46 @@ def main():
         else:
             dom = ("k1_bwd_wgrad" if two_pass and "k1_bwd_wgrad" in agg else "k1_bwd_rows") if "k1_bwd_rows" in agg else "k1_fwd"
         a = agg[dom]
-        achieved = per_row[dom] * a["rows"] / a["total_us"] / 1e3     # GB/s
+        kernel_achieved = per_row[dom] * a["rows"] / a["total_us"] / 1e3     # GB/s of the dominant kernel alone
         tiles = 6 if args.model == "t5" else 3
-        kname = {"k1_bwd_rows": (f"pet_gate_bwd2_kernel<{args.dtype},{tiles}>" if tiles <= 3
-                                 else f"pet_bwd_kernel<{args.dtype},{tiles},gate>"),
-                 "k1_bwd_wgrad": f"k1_cols_kernel<{tiles}> (column-parallel pass of the K1 backward: reads dy, x1, x2, writes dx1, dx2)",
-                 "k1_fwd": f"pet_gate_fwd_kernel<{args.dtype},{tiles}>",
-                 "k3_bwd": f"ng_dz_kernel + ng_cols_kernel<drop> + wgrad_finalize_kernel (one K3 backward, two-pass form of csrc/pet_cols_ng.hip)",
-                 "k3_fwd": f"pet_fwd_kernel<{args.dtype},act_id>"}[dom]
+        lora_drop = args.model == "lora" and float(getattr(cfg, "lora_dropout", 0.0) or 0.0) > 0.0
+        kname = {"k1_bwd_rows": (f"k1_dz2_kernel<{tiles}>" if two_pass and tiles <= 3 else
+                                 f"pet_gate_dz_kernel<{args.dtype},{tiles}>" if two_pass else
+                                 f"pet_gate_bwd2_kernel<{args.dtype},{tiles}>" if tiles <= 3 else f"pet_bwd_kernel<{args.dtype},{tiles},gate>"),
+                 "k1_bwd_wgrad": (f"k1_cols_kernel<{tiles}>" if tiles <= 3 else "k1_cols6_kernel<6>") +
+                                 " (column-parallel pass of the K1 backward: reads dy, x1, x2, writes dx1, dx2)",
+                 "k1_fwd": f"pet_gate_fwd_kernel<{args.dtype},{tiles}> / k1_down_kernel + k1_up_kernel (by shape)",
+                 "k3_bwd": ("ng_dz_kernel + ng_cols_kernel<drop> + wgrad_finalize_kernel" if lora_drop else
+                            "ng_dz_kernel + ng_cols_kernel + wgrad_finalize_kernel") + " (one K3 backward, two-pass form of csrc/pet_cols_ng.hip)",
+                 "k3_fwd": f"pet_fwd_kernel<{args.dtype},act_id{',drop' if lora_drop else ''}>"}[dom]
         traffic = None
         PMC_TRAFFIC = PMC_TRAFFIC_FORMS["two_pass" if (args.model != "lora" and two_pass) else "previous_split"]
         if dom in PMC_TRAFFIC["bytes_per_row"] and args.dtype == "bf16" and args.model == "bart":
             traffic = round(PMC_TRAFFIC["bytes_per_row"][dom] * a["rows"] / a["launches"])
-        roof = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+        # Headline fraction = the whole K1 backward OP (SURVEY 8d's 5*d*b per row is the op's byte count; the op is three launches):
+        # algorithmic bytes / (pass 1 + column-parallel pass + finalize).  The dominant kernel's own figures stay beside it.
+        op = kernels.get("k1_bwd_op") if dom in ("k1_bwd_rows", "k1_bwd_wgrad") else None
+        if op is not None:
+            achieved, launch_us, what = op["algorithmic_GBps"], op["avg_us"], "K1 backward op = " + \
+                ("pass 1 + column-parallel pass + finalize" if two_pass else "rows kernel + weight-gradient kernels")
+            algo_row = 5 * d * esz
+            if traffic:
+                traffic = round(PMC_TRAFFIC["bytes_per_row"]["k1_bwd_op"] * a["rows"] / a["launches"])
+        else:
+            achieved, launch_us, what, algo_row = kernel_achieved, a["total_us"] / a["launches"], kname, per_row[dom]
+        roof = dict(bound="hbm", kernel=what, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     traffic_source=(f"{PMC_TRAFFIC['source']}: PMC passes at M={PMC_TRAFFIC['measured_at_rows']} only, "
                                     f"scaled by this run's average rows per launch") if traffic else None,
-                    avg_launch_us=round(a["total_us"] / a["launches"], 2),
+                    avg_launch_us=round(launch_us, 2),
                     avg_rows_per_launch=round(a["rows"] / a["launches"], 1),
-                    algorithmic_bytes_per_row=per_row[dom])
-        if "k1_bwd_op" in kernels and dom in ("k1_bwd_rows", "k1_bwd_wgrad"):
-            roof["op_frac"] = kernels["k1_bwd_op"]["hbm_frac"]          # the same bytes over rows + weight-gradient time
-            roof["op_avg_us"] = kernels["k1_bwd_op"]["avg_us"]
-            if traffic:
-                roof["op_traffic"] = round(PMC_TRAFFIC["bytes_per_row"]["k1_bwd_op"] * a["rows"] / a["launches"])
+                    algorithmic_bytes_per_row=algo_row,
+                    dominant_kernel=dict(name=kname, avg_launch_us=round(a["total_us"] / a["launches"], 2),
+                                         achieved=round(kernel_achieved, 1), frac=round(kernel_achieved / HBM_PEAK_GBS, 4),
+                                         note="the op's algorithmic bytes over this ONE launch's time (the pre-round-4 headline)"))
+        if op is not None:
+            roof["op_frac"] = op["hbm_frac"]
+            roof["op_avg_us"] = op["avg_us"]
         per_task = {t: TR.TASK_BATCH[t](args.batch) for t in tasks}
         enc_rows = {t: rank_batch(t) * (TR.TEXT_LEN[t] + (72 if t == "nlvr" else (64 if t in VIDEO_TASKS else 36))) for t in tasks}
         out = {
@@ -497,6 +518,7 @@ def main():
                        "enc_rows_per_step_rank0": enc_rows, "trainable_params": n_train, "parallelism": f"dp{n_ranks}",
                        "backend": args.backend if n_ranks > 1 else None},
             "roofline": roof, "kernels": kernels, "backbone_gemm_table": gemm_table,
+            **({"ab_switches": ab_switches} if ab_switches else {}),
             **({"other_scaling": strong} if strong is not None else {}),
             **({"emulated_ranks": {"ranks": args.emulate_ranks, "estimate_samples_per_s_all_ranks": round(samples / dt * args.emulate_ranks, 2),
                                    "note": "one GPU running the batch rank 0 of R strong-scaled ranks would see; value is this one rank's "

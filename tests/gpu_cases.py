@@ -27,6 +27,17 @@ def col_rel_err(a: torch.Tensor, ref: torch.Tensor) -> float:
     return float(((a - ref).abs() / ref.abs().clamp_min(floor)).max())
 
 
+def el_rel_err(a: torch.Tensor, ref: torch.Tensor, floor: float = 0.02) -> float:
+    """Element-wise |a - ref| / (|ref| + floor * max|ref|), worst element: every entry is held to its OWN magnitude, small ones
+    against a floor of 2 % of the tensor's maximum.  rel_err above is a global norm (max-abs over max-abs-ref) and cannot see an
+    entry that is wrong by its own size while small next to the largest one (VERDICT r03 weak #1)."""
+    a = a.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    if not torch.isfinite(a).all():
+        return float("inf")
+    return float(((a - ref).abs() / (ref.abs() + floor * ref.abs().max().clamp_min(1e-12))).max())
+
+
 def _rand(gen, *shape, scale=1.0):
     return torch.randn(*shape, generator=gen) * scale
 
@@ -43,7 +54,7 @@ def make_k1(seed, M, d, r, rg, nh, wscale=None):
 
 
 def run_k1(dtype, M=224, d=768, r=96, rg=96, nh=4, gate_mode=1, delta_scale=1.0, x2_scale=1.0, gate_scale=1.0,
-           seed=0, tensors=None, col_errs=None):
+           seed=0, tensors=None, col_errs=None, el_errs=None):
     """returns dict name -> relative error (max-abs / max-abs-ref) for y, dx1, dx2 and the 8 grads; ``col_errs`` (a dict)
     additionally receives the per-column relative errors of the four bias gradients"""
     import vlpet_amd.functional as F
@@ -80,6 +91,15 @@ def run_k1(dtype, M=224, d=768, r=96, rg=96, nh=4, gate_mode=1, delta_scale=1.0,
     if has_gate:
         for k in ("wgd", "bgd", "wgu", "bgu"):
             errs["d" + k] = rel_err(P[k].grad, g_ref[k])
+    if el_errs is not None:         # element-wise view of the input and weight gradients (el_rel_err)
+        el_errs["y"] = el_rel_err(y, y_ref)
+        el_errs["dx2"] = el_rel_err(x2.grad, g_ref["x2"])
+        el_errs["dwd"] = el_rel_err(torch.cat([w.grad for w in dws]), g_ref["wd"])
+        el_errs["dwu"] = el_rel_err(P["wu"].grad, g_ref["wu"])
+        if has_gate:
+            el_errs["dx1"] = el_rel_err(x1.grad, g_ref["x1"])
+            el_errs["dwgd"] = el_rel_err(P["wgd"].grad, g_ref["wgd"])
+            el_errs["dwgu"] = el_rel_err(P["wgu"].grad, g_ref["wgu"])
     if col_errs is not None:        # per-column view of the bias gradients (sums over all M rows)
         col_errs["dbd"] = col_rel_err(torch.cat([b.grad for b in dbs]), g_ref["bd"])
         col_errs["dbu"] = col_rel_err(P["bu"].grad, g_ref["bu"])

@@ -16,6 +16,11 @@ def _check(errs):
     assert not bad, errs
 
 
+# element-wise bound of the bf16 runs (|err| / (|ref| + 0.02 max|ref|)): a bf16-rounded output whose reference is ~0 next to a maximum
+# of ~4 sigma carries up to 2^-9 * (terms of the size of the maximum) / (0.02 max) ~ 0.2
+EL_TOL = 0.35
+
+
 def test_form_query():
     from vlpet_amd import _lib
     lib = _lib.load()
@@ -39,9 +44,14 @@ def test_form_query():
     dict(M=4321, r=160, rg=192, nh=4),
 ], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
 def test_k1_two_pass_bf16_vs_oracle(kw):
-    ce = {}
-    _check(C.run_k1(torch.bfloat16, col_errs=ce, **kw))
+    ce, ee = {}, {}
+    _check(C.run_k1(torch.bfloat16, col_errs=ce, el_errs=ee, **kw))
     assert max(ce.values()) <= 5e-2, ce          # bias gradients element by element (sums over all M rows of bf16-rounded terms)
+    # every element of y, dx1, dx2 and the four weight gradients against its OWN magnitude (floor: 2 % of the tensor's maximum;
+    # gpu_cases.el_rel_err) -- the per-tensor norm above cannot see a small entry that is wrong by its own size.  Measured on MI355X
+    # (bf16 IO: outputs rounded to 2^-9, operands of the contractions rounded to bf16): see EL_TOL
+    print("element-wise:", {k: f"{v:.3f}" for k, v in ee.items()})
+    assert max(ee.values()) <= EL_TOL, ee
 
 
 def _abi_case(M, dtype=torch.bfloat16, seed=11, gate_mode=1, r=96):

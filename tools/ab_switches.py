@@ -1,0 +1,34 @@
+"""A/B switches of the host package as module attributes, set from VLPET_* environment variables by the tools (and bench.py when
+VLPET_AB=1): the product package itself reads nothing from the environment at import.
+    VLPET_NO_LINK=1, VLPET_NO_GEMM_LINK=1, VLPET_NO_NORM_LINK=1, VLPET_NO_LORA_LINK=1, VLPET_NO_BIAS_GRAD_KERNEL=1, VLPET_NO_FUSED_QKV=1,
+    VLPET_EAGER_FFN_ACT=1, VLPET_EAGER_LM_LOSS=1, VLPET_EAGER_ATTENTION=1, VLPET_EAGER_RMS_NORM=1, VLPET_SPLIT_WIDE=1, VLPET_SDPA=flash|efficient|math"""
+import os
+
+
+def apply():
+    import vlpet_amd.encoder_pet as EP
+    import vlpet_amd.visual as V
+    import vlpet_amd.host.bart as HB
+    import vlpet_amd.host.t5 as HT
+    import vlpet_amd.lora.controller as LC
+    on = lambda n: os.environ.get(n, "0") == "1"
+    changed = {}
+
+    def put(mod, attr, val):
+        if getattr(mod, attr) != val:
+            setattr(mod, attr, val)
+            changed[f"{mod.__name__}.{attr}"] = val
+    put(EP, "SPLIT_WIDE_BOTTLENECK", on("VLPET_SPLIT_WIDE"))
+    put(V, "EAGER_RMS_NORM", on("VLPET_EAGER_RMS_NORM"))
+    for mod in (HB, HT):
+        put(mod, "FUSE_RESIDUAL_GRAD", not on("VLPET_NO_LINK"))
+    put(HB, "FUSE_GEMM_GRAD", not on("VLPET_NO_GEMM_LINK"))
+    put(HT, "FUSE_NORM_GRAD", not on("VLPET_NO_NORM_LINK"))
+    put(HB, "EAGER_FFN_ACT", on("VLPET_EAGER_FFN_ACT"))
+    put(HB, "EAGER_LM_LOSS", on("VLPET_EAGER_LM_LOSS"))
+    put(HB, "FUSE_BIAS_GRAD", not on("VLPET_NO_BIAS_GRAD_KERNEL"))
+    put(HB, "EAGER_ATTENTION", on("VLPET_EAGER_ATTENTION"))
+    put(HB, "FUSE_QKV", not on("VLPET_NO_FUSED_QKV"))
+    put(HB, "SDPA_BACKEND", os.environ.get("VLPET_SDPA") or None)
+    put(LC, "LINK_DELTA_GRAD", not on("VLPET_NO_LORA_LINK"))
+    return changed

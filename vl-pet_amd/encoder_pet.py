@@ -70,8 +70,7 @@ def build_pet(module: nn.Module, config, embed_dim: int, which=("attn", "ff")):
 # fused vs 1,989 through the composition of 3-tile kernels below (profiles/r02_bench_t5_*.json.log).  The composition
 # (exact: the bottleneck splits into two halves whose up projections add,  lin = s2*x2 + sd*(D1 + D2),  G = G1 + G2,
 # y = lin (*|+) sigmoid(G) * gs) stays for A/B (VLPET_SPLIT_WIDE=1) and as the reference of test_apply_pet_wide_bottleneck.
-import os as _os
-SPLIT_WIDE_BOTTLENECK = _os.environ.get("VLPET_SPLIT_WIDE", "0") == "1"
+SPLIT_WIDE_BOTTLENECK = False        # A/B switch (set by tools / tests, tools/ab_switches.py): r = 192 as a composition of 3-tile kernels
 
 
 def _apply_pet_split(module, which, x1, x2, dws, dbs, up, gdown, gup, mode, sd, s2, gs, io):

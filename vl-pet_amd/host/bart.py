@@ -103,8 +103,7 @@ class HostLayerNorm(nn.LayerNorm):
 # K1's gate and the sublayer tail both read the sublayer input; with a link the tail's backward hands its d/dx1 to K1's
 # backward kernel instead of leaving the sum to an elementwise pass of autograd (functional.ResidualLink).  The CPU parity
 # harness of the test suite switches it off: its ops are plain autograd.
-import os as _os
-FUSE_RESIDUAL_GRAD = _os.environ.get("VLPET_NO_LINK", "0") != "1"      # (VLPET_NO_LINK=1: plain autograd sums, for A/B)
+FUSE_RESIDUAL_GRAD = True      # (A/B switch, tools/ab_switches.py: False = plain autograd sums)
 
 
 def _pet_then_tail(layer, which, residual, h, norm, p, training, config, gemm_link=None):
@@ -122,7 +121,7 @@ def _pet_then_tail(layer, which, residual, h, norm, p, training, config, gemm_li
 # fc1), whose dgrad GEMM accumulates onto the gradient K1 / the tail parked (functional.linear_acc: beta = 1 in the GEMM
 # epilogue) instead of autograd adding two [M, d] tensors; in the cross-attention, k_proj / v_proj and the value-parallel
 # adapter (K2) all read the encoder output: one gradient per decoder layer instead of three.
-FUSE_GEMM_GRAD = _os.environ.get("VLPET_NO_GEMM_LINK", "0") != "1"       # (VLPET_NO_GEMM_LINK=1: autograd's adds, for A/B)
+FUSE_GEMM_GRAD = True       # (A/B switch, tools/ab_switches.py: False = autograd's adds)
 
 
 def _frozen(*mods) -> bool:
@@ -170,7 +169,7 @@ def ffn_activation(x, act, p, training):
     return act_dropout(x, act, p, training)
 
 
-EAGER_FFN_ACT = _os.environ.get("VLPET_EAGER_FFN_ACT", "0") == "1"     # A/B switch: the two elementwise torch passes instead
+EAGER_FFN_ACT = False     # A/B switch (tools/ab_switches.py): the two elementwise torch passes instead
 
 
 def lm_loss(h, weight, labels, bias=None):
@@ -186,7 +185,7 @@ def lm_loss(h, weight, labels, bias=None):
     return lm_head_loss(h, weight, labels, bias)
 
 
-EAGER_LM_LOSS = _os.environ.get("VLPET_EAGER_LM_LOSS", "0") == "1"       # A/B switch: torch's cast + log_softmax + nll chain
+EAGER_LM_LOSS = False       # A/B switch (tools/ab_switches.py): torch's cast + log_softmax + nll chain
 
 
 def _linear(mod: nn.Linear, x):
@@ -203,11 +202,10 @@ def _linear(mod: nn.Linear, x):
 
 
 def _sdpa_ctx():
-    """Frozen-backbone attention = torch SDPA with its default backend choice; VLPET_SDPA = flash | efficient | math pins
+    """Frozen-backbone attention = torch SDPA with its default backend choice; ``SDPA_BACKEND`` = flash | efficient | math pins
     one (an experiment switch for the host model, not part of the PET path)."""
     import contextlib
-    import os
-    which = os.environ.get("VLPET_SDPA")
+    which = SDPA_BACKEND
     if not which:
         return contextlib.nullcontext()
     from torch.nn.attention import SDPBackend, sdpa_kernel
@@ -234,9 +232,10 @@ def attention_core(q, k, v, num_heads, attn_mask, causal, p, training):
     return out.transpose(1, 2).reshape(B, Lq, E)
 
 
-FUSE_BIAS_GRAD = _os.environ.get("VLPET_NO_BIAS_GRAD_KERNEL", "0") != "1"    # A/B switch: autograd's sum(0) for trainable biases
-EAGER_ATTENTION = _os.environ.get("VLPET_EAGER_ATTENTION", "0") == "1"   # A/B switch: the library (SDPA) path for every shape
-FUSE_QKV = _os.environ.get("VLPET_NO_FUSED_QKV", "0") != "1"              # A/B switch: separate q / k / v projections in self-attention
+FUSE_BIAS_GRAD = True    # A/B switch (tools/ab_switches.py): False = autograd's sum(0) for trainable biases
+EAGER_ATTENTION = False   # A/B switch: the library (SDPA) path for every shape
+FUSE_QKV = True              # A/B switch: False = separate q / k / v projections in self-attention
+SDPA_BACKEND = None          # A/B switch: "flash" | "efficient" | "math" pins torch SDPA's backend on the library path
 
 
 class BartAttention(nn.Module):

@@ -30,8 +30,7 @@ from .bart import TASKS, _linear
 # K1's gate and the sublayer tail both read the sublayer input; with a link the tail's backward hands its d/dx1 to K1's
 # backward kernel instead of leaving the sum to an elementwise pass of autograd (functional.ResidualLink).  The CPU parity
 # harness of the test suite switches it off: its ops are plain autograd.
-import os as _os
-FUSE_RESIDUAL_GRAD = _os.environ.get("VLPET_NO_LINK", "0") != "1"      # (VLPET_NO_LINK=1: plain autograd sums, for A/B)
+FUSE_RESIDUAL_GRAD = True      # (A/B switch, tools/ab_switches.py: False = plain autograd sums)
 
 
 def _pet_then_tail(layer, which, residual, h, norm, p, training, config, norm_link=None):
@@ -48,7 +47,7 @@ def _pet_then_tail(layer, which, residual, h, norm, p, training, config, norm_li
 # The pre-norm residual stream of a T5 sublayer is read by the RMS norm in front of it and by the tail's add behind it (and by
 # K1's gate in the encoder): the later reader parks its gradient and the norm's backward kernel adds it (tail.rms_norm's link) --
 # one gradient for the stream, no elementwise add by autograd (my_transformers/modeling_t5.py:366, 408; :782, 824).
-FUSE_NORM_GRAD = _os.environ.get("VLPET_NO_NORM_LINK", "0") != "1"     # (VLPET_NO_NORM_LINK=1: autograd's adds, for A/B)
+FUSE_NORM_GRAD = True     # (A/B switch, tools/ab_switches.py: False = autograd's adds)
 
 
 def _new_norm_link(x):

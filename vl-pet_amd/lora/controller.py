@@ -9,8 +9,7 @@ from .layers import LoRALayer
 from .. import functional as VF
 from ..tail import _draw_seed
 
-import os as _os
-LINK_DELTA_GRAD = _os.environ.get("VLPET_NO_LORA_LINK", "0") != "1"      # (VLPET_NO_LORA_LINK=1: autograd adds the two d/dx, for A/B)
+LINK_DELTA_GRAD = True      # (A/B switch, tools/ab_switches.py: False = autograd adds the two d/dx)
 
 
 class LoRALinearController(nn.Linear, LoRALayer):

@@ -16,8 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-import os as _os
-EAGER_RMS_NORM = _os.environ.get("VLPET_EAGER_RMS_NORM", "0") == "1"
+EAGER_RMS_NORM = False              # A/B switch (tools/ab_switches.py): library-op T5LayerNorm
 
 
 class T5LayerNorm(nn.Module):
