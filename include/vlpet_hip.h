@@ -304,6 +304,12 @@ int vlpet_sublayer_tail_fwd(const void* y, const void* x1, const float* gamma, c
 int vlpet_sublayer_tail_bwd(const void* dout, const void* h_save, const float* mean, const float* rstd,
                             const float* gamma, void* dx1, void* dy, float* dgb_partials, int64_t M, int d,
                             float p, uint64_t seed, int norm_mode, int io_dtype, vlpet_stream_t stream);
+/* The same backward from the LayerNorm OUTPUT rows (out_save = the `out` of vlpet_sublayer_tail_fwd, which the next sublayer keeps
+ * anyway) instead of the pre-norm sum: xhat = (out - beta) / gamma (0 where gamma is 0).  The forward is then called with
+ * h_save = NULL and writes one row tensor instead of two (norm_mode 1 only; mean is not needed). */
+int vlpet_sublayer_tail_bwd_out(const void* dout, const void* out_save, const float* rstd, const float* gamma, const float* beta,
+                                void* dx1, void* dy, float* dgb_partials, int64_t M, int d,
+                                float p, uint64_t seed, int io_dtype, vlpet_stream_t stream);
 /* The LayerNorm parameter gradients of that backward (autograd of `self_attn_layer_norm` / `final_layer_norm`,
  * my_transformers/modeling_bart.py:1261, 1377): dgamma [d], dbeta [d] (fp32, OVERWRITTEN; either may be NULL) = the sum of
  * the n_partials = vlpet_sublayer_tail_partials(M) rows of dgb_partials.  One launch; the caller may point dgamma / dbeta

@@ -60,8 +60,11 @@ def test_k4_golden(name):
         assert rel_err(got, g[key]) <= 1e-3, key
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["gemm+norm", "fused-kernel"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 1e-2)])
-def test_k4_real_shape_vs_oracle(dtype, tol):
+def test_k4_real_shape_vs_oracle(dtype, tol, fused, monkeypatch):
+    import vlpet_amd.visproj as VP
+    monkeypatch.setattr(VP, "GEMM_THEN_NORM", not fused)      # (fp32 IO runs the fused kernel either way)
     torch.manual_seed(3)
     B, N, F, d = 9, 36, 2048, 768            # 324 rows: a partial last workgroup
     ve, table = build(d, F, False, vocab=300)
@@ -85,6 +88,34 @@ def test_k4_real_shape_vs_oracle(dtype, tol):
            ve.img_order_embedding.weight]
     for a, b in zip(got, ref[:9]):
         assert rel_err(a.grad, b.grad) <= tol
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["gemm+norm", "fused-kernel"])
+@pytest.mark.parametrize("B", [500, 833])
+def test_k4_forward_at_the_bench_rows_vs_oracle(B, fused, monkeypatch):
+    """The K4 forward at BASELINE configs[1]'s full size (vqa: 500 x 36 = 18,000 rows; gqa: 833 x 36 = 29,988 rows; feat_dim 2048 ->
+    768, bf16) against oracle.visual_embedding (src/modeling_bart.py:157, 162-190) -- the fixtures and the 324-row oracle case run
+    three workgroups, the bench 146+ (VERDICT r03 missing #5).  Both forms: the default library GEMM + LayerNorm pass, and the fused
+    kernel of csrc/visproj.hip."""
+    import vlpet_amd.visproj as VP
+    monkeypatch.setattr(VP, "GEMM_THEN_NORM", not fused)
+    torch.manual_seed(11)
+    N, F, d = 36, 2048, 768
+    ve, table = build(d, F, False, vocab=300)
+    with torch.no_grad():
+        for p in ve.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    feats = torch.randn(B, N, F).to(torch.bfloat16)
+    pos = torch.rand(B, N, 4)
+    fe, pe = ve.feat_embedding, ve.absolute_vis_pos_embedding
+    names = [fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias,
+             ve.img_order_embedding.weight, table.weight]
+    with torch.no_grad():
+        out_ref = O.visual_embedding(feats.float(), pos, *[t.detach() for t in names[:8]], names[8].detach(), names[9].detach())
+    ve = ve.cuda()
+    with torch.no_grad():
+        out = ve(feats.cuda(), pos.cuda())
+    assert out.shape == (B, N, d) and rel_err(out, out_ref) <= 1e-2
 
 
 @pytest.mark.parametrize("M,F,d", [(1, 256, 384), (31, 256, 384), (33, 512, 768), (4097, 2048, 768), (18700, 2048, 768)])

@@ -73,6 +73,41 @@ def test_tail_layernorm_dropout(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_tail_layernorm_with_saved_prenorm_rows(dtype, monkeypatch):
+    # default (round 4): the forward keeps only its output and the backward recovers xhat = (out - beta) / gamma
+    # (vlpet_sublayer_tail_bwd_out); this is the other form: the forward also writes the pre-norm sum (tail.SAVE_PRENORM)
+    import vlpet_amd.tail as T
+    monkeypatch.setattr(T, "SAVE_PRENORM", True)
+    _run(1000, 768, dtype, 0.0)
+    _run(2000, 768, dtype, 0.1)
+
+
+def test_tail_backward_from_output_with_zero_gamma_is_finite():
+    # xhat cannot be recovered where gamma == 0 (the column's output is beta whatever the input): the kernel takes xhat = 0 there,
+    # every gradient stays finite, and the columns with gamma != 0 match the oracle (a dead column's dxhat is dout * 0, so it
+    # contributes to neither row statistic; only its own dx lacks the -xhat * c2 * rstd term)
+    from vlpet_amd.tail import sublayer_tail
+    M, d = 300, 768
+    x1, y, gamma, beta, dout = _mk(M, d, torch.float32)
+    gamma[5] = 0.0; gamma[700] = 0.0
+    ln = torch.nn.LayerNorm(d).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(gamma); ln.bias.copy_(beta)
+    X1 = x1.cuda().requires_grad_(True); Y = y.cuda().requires_grad_(True)
+    out = sublayer_tail(X1, Y, ln, p=0.0, training=True)
+    out.backward(dout.cuda())
+    for t in (X1.grad, Y.grad, ln.weight.grad, ln.bias.grad):
+        assert bool(torch.isfinite(t).all())
+    x1r = x1.clone().requires_grad_(True); yr = y.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    O.bart_sublayer_tail(x1r, yr, gr, br, 1e-5).backward(dout)
+    live = torch.ones(d, dtype=torch.bool); live[5] = False; live[700] = False
+    assert _rel(X1.grad.cpu()[:, live], x1r.grad[:, live]) <= 2e-4
+    assert _rel(ln.weight.grad.cpu()[live], gr.grad[live]) <= 2e-4
+    assert _rel(ln.bias.grad, br.grad) <= 2e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_tail_t5_residual(dtype):
     _run(333, 768, dtype, 0.0, norm=False)
     mask = _run(333, 768, dtype, 0.25, norm=False)

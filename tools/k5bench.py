@@ -21,6 +21,8 @@ def main():
     x1 = torch.randn(M, d, device=dev).to(dt).requires_grad_(True)
     y = torch.randn(M, d, device=dev).to(dt).requires_grad_(True)
     norm = torch.nn.LayerNorm(d).to(dev)
+    T.SAVE_PRENORM = os.environ.get("K5BENCH_PRENORM", "0") == "1"       # A/B: the forward also writes the pre-norm sum (round-3 form)
+    print(f"SAVE_PRENORM = {T.SAVE_PRENORM}")
     for p in (0.0, 0.1):
         out = T.sublayer_tail(x1, y, norm, p, True, seed=1)
         g = torch.randn_like(out)

@@ -94,6 +94,7 @@ SIGNATURES = {
     "vlpet_sublayer_tail_partials": (c_int, [c_int64]),
     "vlpet_sublayer_tail_fwd": (c_int, [c_void_p] * 9 + [c_int64, c_int, c_float, c_float, c_uint64, c_int, c_int, c_void_p]),
     "vlpet_sublayer_tail_bwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_float, c_uint64, c_int, c_int, c_void_p]),
+    "vlpet_sublayer_tail_bwd_out": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_float, c_uint64, c_int, c_void_p]),
     "vlpet_sublayer_tail_reduce": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vlpet_layernorm_bwd_xhat": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_void_p]),
     "vlpet_colsum": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),

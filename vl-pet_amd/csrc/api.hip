@@ -7,7 +7,8 @@
 #include <stdio.h>
 #include <vector>
 
-#define VLPET_VERSION 300      // 300: column-parallel K1 backward pass (pet_cols.hip), phases bits 3 / 4, vlpet_adapter_gate_bwd_form;
+#define VLPET_VERSION 400      // 400: two-pass K1 forward (pet_fwd2p.hip), vlpet_sublayer_tail_bwd_out;
+#define VLPET_VERSION_R3 300      // 300: column-parallel K1 backward pass (pet_cols.hip), phases bits 3 / 4, vlpet_adapter_gate_bwd_form;
 #define VLPET_VERSION_R2 221      // 221: vlpet_sublayer_tail_reduce, vlpet_layernorm_bwd_xhat, vlpet_rmsnorm_{fwd,bwd}, vlpet_colsum;  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -959,6 +960,25 @@ extern "C" int vlpet_sublayer_tail_bwd(const void* dout, const void* h_save, con
     a.rstd = const_cast<float*>(rstd); a.gamma = gamma; a.beta = nullptr; a.x1 = dx1; a.y = dy; a.keep_out = nullptr;
     a.dgb = dgb_partials; a.M = M; a.d = d; a.eps = 0.f; a.thr = thr; a.keep_scale = 1.0f / (1.0f - p); a.seed = seed;
     a.norm = norm_mode;
+    return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
+}
+
+// The same backward from the LayerNorm OUTPUT rows (`out_save` = what vlpet_sublayer_tail_fwd wrote to `out`) instead of the pre-norm
+// sum: xhat = (out - beta) / gamma.  With it the forward is called with h_save = NULL and moves 3 row tensors instead of 4.
+extern "C" int vlpet_sublayer_tail_bwd_out(const void* dout, const void* out_save, const float* rstd, const float* gamma,
+                                           const float* beta, void* dx1, void* dy, float* dgb_partials, int64_t M, int d,
+                                           float p, uint64_t seed, int io_dtype, vlpet_stream_t stream) {
+    int rc = tail_common(M, d, p, io_dtype);
+    if (rc) return rc;
+    if (!dout || !dx1 || !out_save || !rstd || !gamma) return VLPET_E_NULL;
+    const uint32_t thr = tail_thr(p);
+    if (thr && !dy) return VLPET_E_NULL;
+    if (!aligned16(dout) || !aligned16(dx1) || (dy && !aligned16(dy)) || !aligned16(out_save)) return VLPET_E_ALIGN;
+    TailArgs a{};
+    a.out = const_cast<void*>(dout); a.h = const_cast<void*>(out_save); a.mean = nullptr;
+    a.rstd = const_cast<float*>(rstd); a.gamma = gamma; a.beta = beta; a.x1 = dx1; a.y = dy; a.keep_out = nullptr;
+    a.dgb = dgb_partials; a.M = M; a.d = d; a.eps = 0.f; a.thr = thr; a.keep_scale = 1.0f / (1.0f - p); a.seed = seed;
+    a.norm = 1; a.h_out = 1;
     return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
 }
 

@@ -218,6 +218,7 @@ struct TailArgs {
                             //    order-embedding term, src/modeling_bart.py:298-299, 324-325); forward only -- the backward of
                             //    that form is the plain one with h = y (dx1 := d/dy, the caller passes dout on as d/dx1)
     int h_xhat;             // bwd, norm = 1: `h` holds the normalised rows xhat (what K4's forward saves), `mean` is not read
+    int h_out;              // bwd, norm = 1: `h` holds the LayerNorm OUTPUT rows; xhat = (h - beta) / gamma (`beta` read, `mean` not)
     const void* dres;       // bwd, optional [M, d]: added to dx1 (the gradient another reader of the norm's input parked: the residual
                             //    stream of a pre-norm sublayer feeds the norm and the tail's add, my_transformers/modeling_t5.py:366, 408)
     int rms;                // norm = 1 as T5's RMS norm (my_transformers/modeling_t5.py:235-252): no mean subtraction, no beta; `mean`

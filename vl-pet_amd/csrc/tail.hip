@@ -149,8 +149,12 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
 
 // backward: dh = LN'(dout) (or dout when NORM == 0); dx1 = dh; dy = dh * keep / (1-p) (only written when
 // dropout is on -- with p = 0 the caller aliases dy to dx1); per-workgroup partial sums of dgamma / dbeta.
-template <typename IO, int NP, bool NORM>
+// HOUT (NORM only, round 4): `h` holds the LayerNorm OUTPUT rows (what the next sublayer keeps anyway) instead of the pre-norm sum,
+// and the normalised rows are recovered as xhat = (out - beta) / gamma (0 where gamma is 0): the forward then writes ONE row tensor
+// (out) instead of two (out and h) -- 3 units of traffic instead of 4.
+template <typename IO, int NP, bool NORM, bool HOUT = false>
 __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
+    static_assert(!HOUT || NORM, "recovering xhat from the output needs the norm");
     using P = Piece<IO>;
     constexpr int E = P::E;
     __shared__ float red[TAIL_WAVES][2];
@@ -159,6 +163,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
     const uint32_t thr = a.thr;
     const float scale = a.keep_scale;
     float gam[NORM ? NP : 1][E], dg[NORM ? NP : 1][E], db[NORM ? NP : 1][E];
+    float bet[HOUT ? NP : 1][E], ginv[HOUT ? NP : 1][E];
     if constexpr (NORM) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -167,6 +172,10 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
             for (int j = 0; j < E; ++j) {
                 gam[k][j] = p < pieces ? a.gamma[p * E + j] : 0.f;
                 dg[k][j] = 0.f; db[k][j] = 0.f;
+                if constexpr (HOUT) {
+                    bet[k][j] = (p < pieces && a.beta) ? a.beta[p * E + j] : 0.f;
+                    ginv[k][j] = gam[k][j] != 0.f ? 1.0f / gam[k][j] : 0.f;
+                }
             }
         }
     }
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
     auto load_row = [&](int64_t r, u32x4 (&rd)[NP], u32x4 (&rh)[NORM ? NP : 1], u32x4 (&rr)[NP], float& mu, float& rs) {
         if (r >= a.M) r = a.M - 1;                  // next row of this wave, requested one row ahead (see the forward)
         const int64_t o = r * d * (int64_t)sizeof(IO);
-        if constexpr (NORM) { mu = (a.h_xhat || a.rms) ? 0.f : a.mean[r]; rs = a.rstd[r]; }
+        if constexpr (NORM) { mu = (HOUT || a.h_xhat || a.rms) ? 0.f : a.mean[r]; rs = a.rstd[r]; }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = lane + 64 * k;
@@ -217,7 +226,8 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
                     P::from_raw(ch[k], vh);
 #pragma unroll
                     for (int j = 0; j < E; ++j) {
-                        xh[k][j] = (vh[j] - mean) * rin;
+                        if constexpr (HOUT) xh[k][j] = (vh[j] - bet[k][j]) * ginv[k][j];
+                        else xh[k][j] = (vh[j] - mean) * rin;
                         g[k][j] = vd[j] * gam[k][j];
                         s1 += g[k][j];
                         s2 += g[k][j] * xh[k][j];
@@ -425,7 +435,10 @@ int tail_blocks(int64_t M) {
 template <typename IO, int NP, bool NORM>
 static hipError_t launch_np(const TailArgs& a, bool bwd, hipStream_t stream) {
     const int blocks = tail_blocks(a.M);
-    if (bwd) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, NORM>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+    if (bwd && NORM && a.h_out) {
+        if constexpr (NORM) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, true, true>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+    }
+    else if (bwd) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, NORM>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
     else if (NORM && a.post) {
         if constexpr (NORM) hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, true, true>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
     }
@@ -447,6 +460,7 @@ static hipError_t launch_io(const TailArgs& a, bool bwd, hipStream_t stream) {
 
 hipError_t launch_tail(const TailArgs& a, int io_fp32, bool bwd, hipStream_t stream) {
     if (a.post && (!a.norm || bwd)) return hipErrorInvalidValue;      // forward-only form of the norm path
+    if (a.h_out && (!a.norm || !bwd || a.rms || a.h_xhat)) return hipErrorInvalidValue;
     if (a.norm) return io_fp32 ? launch_io<float, true>(a, bwd, stream) : launch_io<__bf16, true>(a, bwd, stream);
     return io_fp32 ? launch_io<float, false>(a, bwd, stream) : launch_io<__bf16, false>(a, bwd, stream);
 }

@@ -16,6 +16,14 @@ from . import _lib
 from .functional import _finish, _flat, _grad_dest, _grad_like, _io_dtype, _need_cuda, _ptr, _stream, _timed
 
 
+# K5 with a LayerNorm: the backward needs the normalised rows.  False (default since round 4): the forward saves nothing but its own
+# output (which the next sublayer reads anyway) + rstd, and the backward recovers xhat = (out - beta) / gamma -- 3 row tensors of
+# traffic instead of 4.  True: the forward also writes the pre-norm sum h for the backward (the round-1..3 form; exact where a
+# gamma is ~0, and what to use if a checkpoint's LayerNorm carries |beta / gamma| in the hundreds: the recovery loses
+# log2(|out| / |gamma xhat|) bits of the bf16 output).
+SAVE_PRENORM = False
+
+
 def _frozen_epoch():
     from . import functional as _VF
     return _VF.FROZEN_EPOCH
@@ -61,14 +69,15 @@ class _TailFn(torch.autograd.Function):
         if norm:
             g32, b32 = _f32_frozen(gamma), _f32_frozen(beta)
             mean, rstd = torch.empty(M, **f32), torch.empty(M, **f32)
-            h = torch.empty_like(yf) if need_bwd else None
+            h = torch.empty_like(yf) if (need_bwd and SAVE_PRENORM) else None
         mask = torch.empty(M, d, dtype=torch.uint8, device=y.device) if want_mask else None
         rc = _timed("k5_fwd", M, lambda: lib.vlpet_sublayer_tail_fwd(
             yf.data_ptr(), xf.data_ptr(), _ptr(g32), _ptr(b32), out.data_ptr(), _ptr(h), _ptr(mean), _ptr(rstd),
             _ptr(mask), M, d, float(eps), float(p), seed, int(norm), io, _stream()))
         _lib.check(rc, "vlpet_sublayer_tail_fwd")
-        ctx.save_for_backward(h, mean, rstd, g32, gamma, beta)
-        ctx.cfg = (float(p), seed, int(norm), y.shape, io)
+        from_out = bool(norm) and need_bwd and h is None
+        ctx.save_for_backward(out if from_out else h, mean, rstd, g32, gamma, beta, b32 if from_out else None)
+        ctx.cfg = (float(p), seed, int(norm), y.shape, io, from_out)
         ctx.link = link if (link is not None and link.armed) else None     # the op that armed it (K1, or a linear_acc GEMM) sums our dx1 into its own
         out = out.view(y.shape)
         if want_mask:
@@ -79,8 +88,8 @@ class _TailFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, *unused):
         lib = _lib.load()
-        h, mean, rstd, g32, gamma, beta = ctx.saved_tensors
-        p, seed, norm, shape, io = ctx.cfg
+        h, mean, rstd, g32, gamma, beta, b32 = ctx.saved_tensors
+        p, seed, norm, shape, io, from_out = ctx.cfg
         d = shape[-1]
         df = _flat(dout, d)
         M = df.shape[0]
@@ -91,9 +100,14 @@ class _TailFn(torch.autograd.Function):
         if train_ln:
             nb = lib.vlpet_sublayer_tail_partials(M)
             part = torch.empty(nb, 2, d, dtype=torch.float32, device=df.device)
-        rc = _timed("k5_bwd", M, lambda: lib.vlpet_sublayer_tail_bwd(
-            df.data_ptr(), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(g32), dx1.data_ptr(), _ptr(dy), _ptr(part), M, d,
-            p, seed, norm, io, _stream()))
+        if from_out:       # h holds the forward's OUTPUT rows: xhat = (out - beta) / gamma inside the kernel
+            rc = _timed("k5_bwd", M, lambda: lib.vlpet_sublayer_tail_bwd_out(
+                df.data_ptr(), h.data_ptr(), rstd.data_ptr(), g32.data_ptr(), _ptr(b32), dx1.data_ptr(), _ptr(dy), _ptr(part), M, d,
+                p, seed, io, _stream()))
+        else:
+            rc = _timed("k5_bwd", M, lambda: lib.vlpet_sublayer_tail_bwd(
+                df.data_ptr(), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(g32), dx1.data_ptr(), _ptr(dy), _ptr(part), M, d,
+                p, seed, norm, io, _stream()))
         _lib.check(rc, "vlpet_sublayer_tail_bwd")
         dgamma = dbeta = None
         if train_ln:

@@ -12,10 +12,27 @@ from . import _lib
 from .functional import _finish, _flat, _grad_dest, _grad_like, _io_dtype, _need_cuda, _param_dtype, _ptr, _stream, _timed
 
 
+# K4 forward, bf16 LayerNorm form: True (default since round 4) = library GEMM (hipBLASLt, a plain [M, F] x [F, d] product) followed by
+# ONE pass of the K5 kernel (LayerNorm + residual: vlpet_norm_residual_fwd) -- 48 + 12 us at 18,700 rows against 108 us for the
+# fused kernel of csrc/visproj.hip, whose 146 workgroups each stream the whole 3.1 MB weight through LDS (profiles/r03_k4bench.txt).
+# False = the fused kernel (what fp32 IO and T5's RMS norm always run).
+GEMM_THEN_NORM = True
+
+
 class VisProjPackCache:
     def __init__(self):
         self._key = None
         self._val = None
+        self._ckey = None
+        self._cval = None
+
+    def get_cast(self, w: torch.Tensor, b: torch.Tensor, dtype: torch.dtype):
+        """the weight and bias in the IO dtype for the library-GEMM form, refreshed when the parameters change"""
+        from . import functional as _VF
+        key = (dtype, _VF.WEIGHTS_EPOCH, w.data_ptr(), w._version, b.data_ptr(), b._version)
+        if key != self._ckey:
+            self._ckey, self._cval = key, (w.detach().to(dtype).contiguous(), b.detach().to(dtype).contiguous())
+        return self._cval
 
     def get(self, w: torch.Tensor, b: torch.Tensor, io_dtype: int) -> torch.Tensor:
         from . import functional as _VF
@@ -34,7 +51,7 @@ class VisProjPackCache:
 
 class _VisProjFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, R, w, b, gamma, beta, packed, eps, rms):
+    def forward(ctx, feats, R, w, b, gamma, beta, packed, eps, rms, cast=None):
         lib = _lib.load()
         _need_cuda(feats, w)
         F = feats.shape[-1]
@@ -46,6 +63,26 @@ class _VisProjFn(torch.autograd.Function):
         if R is not None:
             Rf = _flat(R.to(feats.dtype), d_out)
         out = torch.empty(M, d_out, dtype=feats.dtype, device=feats.device)
+        if cast is not None:            # library GEMM, then LayerNorm + residual in one pass of the K5 kernel
+            from .tail import _f32_frozen
+            wc, bc = cast
+            g32, b32 = _f32_frozen(gamma), _f32_frozen(beta)
+            mean = torch.empty(M, dtype=torch.float32, device=feats.device)
+            rstd = torch.empty(M, dtype=torch.float32, device=feats.device)
+            if Rf is None:
+                Rf = torch.zeros(M, d_out, dtype=feats.dtype, device=feats.device)
+            box = {}
+
+            def run():
+                box["pre"] = torch.addmm(bc, ff, wc.t())
+                return lib.vlpet_norm_residual_fwd(box["pre"].data_ptr(), Rf.data_ptr(), g32.data_ptr(), _ptr(b32), out.data_ptr(),
+                                                   mean.data_ptr(), rstd.data_ptr(), M, d_out, float(eps), io, _stream())
+            _lib.check(_timed("k4_fwd", M, run), "vlpet_norm_residual_fwd")
+            ctx.save_for_backward(ff, box["pre"], rstd, w, b, gamma, beta if beta is not None else gamma, mean)
+            ctx.cfg = (False, beta is not None, feats.shape[:-1], R is not None, R.dtype if R is not None else None)
+            ctx.composed = True
+            return out.view(*feats.shape[:-1], d_out)
+        ctx.composed = False
         xhat = torch.empty_like(out)
         rstd = torch.empty(M, dtype=torch.float32, device=feats.device)
         from .tail import _f32_frozen
@@ -54,14 +91,14 @@ class _VisProjFn(torch.autograd.Function):
             ff.data_ptr(), packed.data_ptr(), g32.data_ptr(), _ptr(b32), _ptr(Rf), out.data_ptr(), xhat.data_ptr(),
             rstd.data_ptr(), M, F, d_out, float(eps), int(bool(rms)), io, _stream()))
         _lib.check(rc, "vlpet_visproj_fwd")
-        ctx.save_for_backward(ff, xhat, rstd, w, b, gamma, beta if beta is not None else gamma)
+        ctx.save_for_backward(ff, xhat, rstd, w, b, gamma, beta if beta is not None else gamma, None)
         ctx.cfg = (bool(rms), beta is not None, feats.shape[:-1], R is not None, R.dtype if R is not None else None)
         return out.view(*feats.shape[:-1], d_out)
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        ff, xhat, rstd, w, b, gamma, beta = ctx.saved_tensors
+        ff, xhat, rstd, w, b, gamma, beta, mean = ctx.saved_tensors          # (composed form: `xhat` holds the pre-norm rows)
         rms, has_beta, lead, has_r, r_dtype = ctx.cfg
         M, F = ff.shape
         d_out = w.shape[0]
@@ -84,9 +121,14 @@ class _VisProjFn(torch.autograd.Function):
             dpre_io = torch.empty_like(xhat)
             train_ln = ctx.needs_input_grad[4] or (has_beta and ctx.needs_input_grad[5])
             part = torch.empty(lib.vlpet_sublayer_tail_partials(M), 2, d_out, dtype=torch.float32, device=ff.device) if train_ln else None
-            rc = _timed("k4_ln_bwd", M, lambda: lib.vlpet_layernorm_bwd_xhat(
-                dyc.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), _f32_frozen(gamma).data_ptr(), dpre_io.data_ptr(), _ptr(part),
-                M, d_out, io, _stream()))
+            if ctx.composed:
+                rc = _timed("k4_ln_bwd", M, lambda: lib.vlpet_sublayer_tail_bwd(
+                    dyc.data_ptr(), xhat.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _f32_frozen(gamma).data_ptr(), dpre_io.data_ptr(),
+                    None, _ptr(part), M, d_out, 0.0, 0, 1, io, _stream()))
+            else:
+                rc = _timed("k4_ln_bwd", M, lambda: lib.vlpet_layernorm_bwd_xhat(
+                    dyc.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), _f32_frozen(gamma).data_ptr(), dpre_io.data_ptr(), _ptr(part),
+                    M, d_out, io, _stream()))
             _lib.check(rc, "vlpet_layernorm_bwd_xhat")
             dgamma = dbeta = None
             if train_ln:
@@ -111,7 +153,7 @@ class _VisProjFn(torch.autograd.Function):
         else:
             gg = _finish([(dgamma, s_g, gamma)])[0]
             gbe = _finish([(dbeta, s_be, beta)])[0] if has_beta else None
-        return (dfeats, dR, gw, gb, gg, gbe, None, None, None)
+        return (dfeats, dR, gw, gb, gg, gbe, None, None, None, None)
 
 
 def visproj(feats, R, linear: torch.nn.Linear, norm: torch.nn.Module, cache: VisProjPackCache, rms: bool):
@@ -121,9 +163,12 @@ def visproj(feats, R, linear: torch.nn.Linear, norm: torch.nn.Module, cache: Vis
         base = feats.new_zeros(*feats.shape[:-1], linear.weight.shape[0]) if R is None else R.to(feats.dtype)
         return _empty_result(base, [linear.weight, linear.bias, norm.weight, getattr(norm, "bias", None)])
     io = _io_dtype(feats)
-    packed = cache.get(linear.weight, linear.bias, io)
     eps = getattr(norm, "eps", None)
     if eps is None:
         eps = norm.variance_epsilon
     beta = getattr(norm, "bias", None)
+    if GEMM_THEN_NORM and not rms and feats.dtype == torch.bfloat16:
+        cast = cache.get_cast(linear.weight, linear.bias, feats.dtype)
+        return _VisProjFn.apply(feats, R, linear.weight, linear.bias, norm.weight, beta, None, eps, rms, cast)
+    packed = cache.get(linear.weight, linear.bias, io)
     return _VisProjFn.apply(feats, R, linear.weight, linear.bias, norm.weight, beta, packed, eps, rms)
