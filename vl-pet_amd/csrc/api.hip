@@ -387,7 +387,9 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     if (phases & 1) {
         if (rows2) b.dxg_in = dx1_in;                   // the chain-split row kernel adds it in its epilogue
         const bool dz2 = two_pass && vlpet_tuning().dz2 != 0 && k1_dz2_applies(b, io_dtype == VLPET_F32);
+        const bool dz6 = two_pass && !dz2 && vlpet_tuning().dz6 != 0 && k1_dz6_applies(b, io_dtype == VLPET_F32);
         hipError_t e = dz2 ? launch_k1_dz2(b, (hipStream_t)stream)
+                     : dz6 ? launch_k1_dz6(b, (hipStream_t)stream)
                      : two_pass ? launch_pet_gate_dz(b, io_dtype == VLPET_F32, (hipStream_t)stream)
                      : rows2 ? launch_pet_gate_bwd2(b, io_dtype == VLPET_F32, (hipStream_t)stream)
                              : launch_pet_bwd(b, io_dtype == VLPET_F32, (hipStream_t)stream);

@@ -152,6 +152,9 @@ hipError_t launch_pet_gate_dz(const PetBwdArgs& a, int io_fp32, hipStream_t stre
 // the same pass with the stage's features split over the two waves of a row group (pet_dz2.hip; bf16, r <= 96)
 bool k1_dz2_applies(const PetBwdArgs& a, int io_fp32);
 hipError_t launch_k1_dz2(const PetBwdArgs& a, hipStream_t stream);
+// the same pass at six tiles (r = 192 / 128): four waves per workgroup, one per SIMD, each with the whole register file (pet_dz6.hip)
+bool k1_dz6_applies(const PetBwdArgs& a, int io_fp32);
+hipError_t launch_k1_dz6(const PetBwdArgs& a, hipStream_t stream);
 hipError_t launch_pet_gate_cols(const PetBwdArgs& a, const WgradArgs& g, int GS, int NG, int io_fp32, hipStream_t stream);
 
 // Column-parallel pass 2 of the gated K1 backward, round-3 form (pet_cols.hip): weights resident in registers, row tensors streamed
