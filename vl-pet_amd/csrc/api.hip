@@ -348,7 +348,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     }
     b.M = M; b.d = d; b.RT = tiles;
     b.s2 = s2; b.sd = sd; b.gs = gs; b.flags = flags;
-    b.gm = 1.f; b.go = 0.f;
+    b.gm = 1.f; b.go = 0.f; b.fsplit = 0; b.dz_part = nullptr;
     if (saved && !aligned16(saved)) return VLPET_E_ALIGN;
     b.saved = saved; b.saved_stride = (int64_t)saved_stride(M, tiles, io_dtype);
     if (saved) {        // z comes from the forward; the rows kernel does not write it
@@ -387,6 +387,14 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     if (phases & 1) {
         if (rows2) b.dxg_in = dx1_in;                   // the chain-split row kernel adds it in its epilogue
         const bool dz2 = two_pass && vlpet_tuning().dz2 != 0 && k1_dz2_applies(b, io_dtype == VLPET_F32);
+        if (dz2 && gate) {      // small M: feature blocks (their fp32 partial dz in the dh / dq area, which the two-pass form does not use)
+            const int nfb = k1_dz2_feature_blocks(M, d);
+            const size_t need = (size_t)nfb * (size_t)M * 2 * 32 * tiles * 4;
+            if (nfb > 1 && need <= 2 * align256((size_t)M * d * (io_dtype == VLPET_F32 ? 4 : 2))) {
+                b.fsplit = nfb;
+                b.dz_part = reinterpret_cast<float*>(ws + w.dh);
+            }
+        }
         const bool dz6 = two_pass && !dz2 && vlpet_tuning().dz6 != 0 && k1_dz6_applies(b, io_dtype == VLPET_F32);
         hipError_t e = dz2 ? launch_k1_dz2(b, (hipStream_t)stream)
                      : dz6 ? launch_k1_dz6(b, (hipStream_t)stream)
@@ -792,7 +800,7 @@ extern "C" int vlpet_lowrank_gate_bwd(const void* dfe, const void* feats, const 
     if (workspace_bytes < w.total) return VLPET_E_WORKSPACE;
     uint8_t* ws = reinterpret_cast<uint8_t*>(workspace);
     const uint8_t* sv = reinterpret_cast<const uint8_t*>(saved);
-    PetBwdArgs b;
+    PetBwdArgs b{};
     b.dy = dfe; b.xa = feats; b.res = nullptr; b.xg = feats;
     b.dxa = nullptr; b.dxg = nullptr; b.dxg_in = nullptr;
     b.saved = saved; b.saved_stride = (int64_t)saved_stride(M, tiles, io_dtype);

@@ -84,6 +84,8 @@ struct PetBwdArgs {
     float s2, sd, gs;
     int flags;
     float gm, go;           // low-rank visual projector: gate value = gm * sigmoid(.) + go (unused otherwise)
+    int fsplit;             // pass 1 of the two-pass form (pet_dz2.hip), small M: feature blocks (> 1: partial dz in dz_part, summed by a second launch)
+    float* dz_part;         //   [fsplit][M][2][32*RT] fp32
 };
 hipError_t launch_pet_bwd(const PetBwdArgs& a, int io_fp32, hipStream_t stream);
 // chain-split form of the same (pet_gate_bwd2.hip): gated K1 with saved activations
@@ -152,6 +154,7 @@ hipError_t launch_pet_gate_dz(const PetBwdArgs& a, int io_fp32, hipStream_t stre
 // the same pass with the stage's features split over the two waves of a row group (pet_dz2.hip; bf16, r <= 96)
 bool k1_dz2_applies(const PetBwdArgs& a, int io_fp32);
 hipError_t launch_k1_dz2(const PetBwdArgs& a, hipStream_t stream);
+int k1_dz2_feature_blocks(int64_t M, int d);
 // the same pass at six tiles (r = 192 / 128): four waves per workgroup, one per SIMD, each with the whole register file (pet_dz6.hip)
 bool k1_dz6_applies(const PetBwdArgs& a, int io_fp32);
 hipError_t launch_k1_dz6(const PetBwdArgs& a, hipStream_t stream);

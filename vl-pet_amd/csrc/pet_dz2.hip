@@ -52,7 +52,11 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = wave & 3, fh = wave >> 2;            // waves w and w + 4 share a SIMD: the two feature halves of a row group
     const int m = lane & 31, h = lane >> 5;
-    const int d = a.d, S = d >> 6;
+    const int d = a.d;
+    // feature split (small M: PetBwdArgs::fsplit > 1): workgroup (x, y) walks only the stages of feature block y and leaves fp32
+    // partial dz; k1_dz_reduce_kernel sums the blocks.  S0 .. S = this workgroup's stages.
+    const int NFB = a.fsplit > 1 ? a.fsplit : 1;
+    const int S0 = (int)blockIdx.y * ((d >> 6) / NFB), S = S0 + (d >> 6) / NFB;
     const int64_t ld2 = (int64_t)d * 2;
     const int64_t row0 = (int64_t)blockIdx.x * 128;
     const int64_t grow_raw = row0 + 32 * rg + m;
@@ -270,8 +274,8 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // z in registers, biases in LDS
 #pragma unroll
     for (int t = 0; t < (AW > AX ? AW : AX); ++t) {        // (same order as in the loop: W(t' + AW), X(t' + AX) for t' = t - max .. )
-        if (t < AW && t < S) issue_w(t);
-        if (t < AX && t < S) issue_x(t);
+        if (t < AW && S0 + t < S) issue_w(S0 + t);
+        if (t < AX && S0 + t < S) issue_x(S0 + t);
     }
     // The two waves of a SIMD (the feature halves of a row group) run the same three phases -- up projections (LDS + matrix
     // cores), elementwise (VALU, 1.1 k cycles), contraction (LDS + matrix cores) -- and in lockstep they would queue for the same
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
     // and vice versa.  The weight image of a stage therefore lives for two steps (three weight slots).
     if (fh == 0) {
 #pragma unroll 1
-        for (int s = 0; s < S; ++s) {
+        for (int s = S0; s < S; ++s) {
             step_top(s);
             uint32_t bh[8], bq[8];
             up_ew(s, bh, bq);
@@ -289,11 +293,11 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
         }
     } else {
         uint32_t bh[8], bq[8];
-        step_top(0);
-        up_ew(0, bh, bq);
+        step_top(S0);
+        up_ew(S0, bh, bq);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
-        for (int s = 1; s < S; ++s) {
+        for (int s = S0 + 1; s < S; ++s) {
             step_top(s);
             contract(s - 1, bh, bq);
             up_ew(s, bh, bq);
@@ -333,7 +337,20 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
             }
     }
     __syncthreads();
-    {
+    if (NFB > 1) {      // feature split: this block's fp32 sums of the chain this wave finishes -> dz_part[fb][row][chain][32 RT]
+        const float* got = reinterpret_cast<const float*>(smem) + (size_t)(4 * (1 - fh) + rg) * (RT * 16 * 64);
+        float* out = a.dz_part + (((int64_t)blockIdx.y * a.M + grow) * 2 + fh) * (32 * RT) + 4 * h;
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(got + (size_t)((ct * 4 + q) * 64 + lane) * 4);
+                f32x4 r4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r4[j] = (fh == 0 ? dzA[ct][4 * q + j] : dzG[ct][4 * q + j]) + o[j];
+                if (row_ok) *reinterpret_cast<f32x4*>(out + 32 * ct + 8 * q) = r4;
+            }
+    } else {
         const float* got = reinterpret_cast<const float*>(smem) + (size_t)(4 * (1 - fh) + rg) * (RT * 16 * 64);
         __bf16* out = reinterpret_cast<__bf16*>(fh == 0 ? a.dp_a : a.dp_g) + grow * (int64_t)(32 * RT) + 4 * h;
         const float sc = fh == 0 ? sd : 1.0f;           // dz_a = sd * Wu^T dh: the delta scale once, here
@@ -353,6 +370,33 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
     }
 }
 
+// sums the feature blocks of the split form: dpre[row][c] = (chain a: sd, chain g: 1) * act'(pre)[row][c] * sum_fb dz_part[fb][row][chain][c]
+__global__ __launch_bounds__(256) void k1_dz_reduce_kernel(PetBwdArgs a, int PR) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const int64_t n4 = a.M * 2 * (PR / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % (PR / 4)), chain = (int)((i / (PR / 4)) & 1);
+        const int64_t row = i / (2 * (PR / 4));
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int fb = 0; fb < a.fsplit; ++fb)
+            s += *reinterpret_cast<const f32x4*>(a.dz_part + (((int64_t)fb * a.M + row) * 2 + chain) * PR + 4 * c4);
+        const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved) + (chain == 0 ? 1 : 3) * a.saved_stride;
+        const bf16x4 gp = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(sv) + row * PR + 4 * c4);
+        const float sc = chain == 0 ? a.sd : 1.0f;
+        bf16x4 r4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r4[j] = (__bf16)(sc * s[j] * (float)gp[j]);
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(chain == 0 ? a.dp_a : a.dp_g) + row * PR + 4 * c4) = r4;
+    }
+}
+
+// feature blocks of pass 1 by shape: the kernel is a chain of d / 64 stages whatever its rows, and below 8,192 rows fewer than 64 of
+// the 256 CUs have a workgroup -- four feature blocks give each a quarter of the chain (profiles/r04_k1bench_small_m.txt)
+int k1_dz2_feature_blocks(int64_t M, int d) {
+    if (const int f = vlpet_tuning().dz2_fsplit; f >= 1) return ((d >> 6) % f == 0) ? f : 1;
+    return (M <= 8192 && (d >> 6) % 4 == 0) ? 4 : 1;
+}
+
 bool k1_dz2_applies(const PetBwdArgs& a, int io_fp32) {
     if (io_fp32 || !(a.flags & PET_GATE) || a.saved == nullptr || drop_active(a.drop) || a.d % 64 != 0 || a.d < 64) return false;
     // (the up-side biases of every feature sit in LDS next to the rings: very wide models go to pet_gate_dz_kernel)
@@ -370,8 +414,14 @@ static hipError_t launch_dz2_rt(const PetBwdArgs& a, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const unsigned blocks = (unsigned)((a.M + 127) / 128);
-    if (add) hipLaunchKernelGGL((k1_dz2_kernel<RT, true>), dim3(blocks), dim3(512), lds, stream, a);
-    else hipLaunchKernelGGL((k1_dz2_kernel<RT, false>), dim3(blocks), dim3(512), lds, stream, a);
+    const unsigned nfb = a.fsplit > 1 ? (unsigned)a.fsplit : 1u;
+    if (add) hipLaunchKernelGGL((k1_dz2_kernel<RT, true>), dim3(blocks, nfb), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL((k1_dz2_kernel<RT, false>), dim3(blocks, nfb), dim3(512), lds, stream, a);
+    if (nfb > 1) {
+        const int64_t n4 = a.M * 2 * (32 * RT / 4);
+        const unsigned rb = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(k1_dz_reduce_kernel, dim3(rb), dim3(256), 0, stream, a, 32 * RT);
+    }
     return hipGetLastError();
 }
 
