@@ -18,7 +18,8 @@ def _check(errs):
 
 @pytest.mark.parametrize("kw", [dict(M=1), dict(M=31), dict(M=33), dict(M=127), dict(M=129), dict(M=777, r=8), dict(M=1000, r=32),
                                 dict(M=640, d=256, r=16), dict(M=3000, d=1024), dict(M=5000, scale=0.25), dict(M=28000), dict(M=46648),
-                                dict(M=100, r=192), dict(M=2100, r=192), dict(M=16800, r=192), dict(M=1000, r=128)],   # six tiles
+                                dict(M=100, r=192), dict(M=2100, r=192), dict(M=16800, r=192), dict(M=1000, r=128),    # six tiles
+                                dict(M=3528), dict(M=15272), dict(M=17000), dict(M=33200), dict(M=41999, r=32)],       # round 4: two-pass forward sizes
                          ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
 def test_k2_two_pass_vs_oracle(kw):
     _check(C.run_k2(torch.bfloat16, **kw))

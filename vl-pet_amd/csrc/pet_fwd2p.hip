@@ -21,9 +21,23 @@
 //
 // Traffic: x1, x2 once in pass A, z / gelu' written (they are outputs of the training form), x2 again + z back in pass B, out
 // written: 4 row units + 2.5 bottleneck units instead of 3 + 1 -- but no per-workgroup weight stream (129 MB of L2->LDS traffic at
-// M = 28,000, 169 MB at r = 192 / 18,250 rows) and no 25-stage chain.  bf16, d = 768, gated forms; everything else stays on
-// pet_gate_fwd.hip.
+// M = 28,000, 169 MB at r = 192 / 18,250 rows) and no 25-stage chain.  bf16, d = 768; everything else stays on
+// pet_gate_fwd.hip / pet_fwd.hip.
+//
+// The forms without a gate take the same two passes (round 4, second session): K2 (adapters/adapter_modeling.py:55-61,
+// adapter_controller.py:149-162: out = y + s*up(gelu_new(down(x)))) and K3 (lora/controller.py:56-70: out = base +
+// (dropout(x) A^T B^T) * alpha / r).  Pass A runs ONE chain (grid = row blocks), with the identity instead of gelu_new for K3;
+// pass B has no gate projection and adds the residual input (y / base) instead of x2.  For them the cut costs almost nothing in
+// traffic -- x is not needed after pass A, so the op still moves 3 row units + z twice -- and it removes what made the
+// one-kernel forward slow outside one well-filled round: the 24-stage chain of a 128-row workgroup (decoder-side LoRA calls of
+// 2,500-10,000 rows: 18 of the 36 calls of a step) and the second round above 32,768 rows.
+// K3's dropout: the keep flags no longer come out of the Philox generator INSIDE the forward (13 us of a 42 us kernel at
+// M = 28,000: ~100 VALU instructions per 8 elements in the one wave that also runs the MFMAs).  drop_bits_kernel writes the
+// packed mask the backward wants anyway (rng.h drop_pos layout, 1 bit per element, M*d/8 bytes) as a plain elementwise launch
+// over the whole chip; pass A's loader brings each sub-step's mask words along with the rows (one 4-byte global_load_lds per
+// lane and stage) and the compute waves clear the dropped elements of their B fragments; 1/(1-p) goes onto the sums.
 #include "cols_common.h"
+#include "rng.h"
 
 namespace {
 
@@ -62,25 +76,28 @@ __host__ __device__ inline unsigned f2_grid(int U, int S, int ngroups) {
 // ------------------------------------------------------------------------------------------------ pass A
 // SSN = stages per sub-step (ring slot = 32 rows x 64 SSN features): 6 -> two sub-steps per row tile, 3 or 4 slots; 3 -> four sub-steps,
 // 6 slots (the same LDS, 5/6 of it in flight instead of 2/3)
-template <int RT, int SSN> struct DownGeo {
+template <int RT, int SSN, bool DROP = false> struct DownGeo {
     static constexpr int SUB_B = SSN * 4096;
     static constexpr int NPT = F2_NST / SSN;            // sub-steps per row tile
     static constexpr int NSLOT = SSN == 6 ? (RT == 6 ? 4 : 2) : (RT == 6 ? 6 : 5);
-    static constexpr int NI = 4 * SSN;                  // global_load_lds instructions per sub-step
+    static constexpr int NI = (4 + (DROP ? 1 : 0)) * SSN;   // global_load_lds instructions per sub-step (DROP: + the mask words of each stage)
     static constexpr int PB = 64 * RT;                  // bytes of a bottleneck row
     static constexpr int STG_OFF = NSLOT * SUB_B;       // staging of the z and gelu' tiles of a row tile: 2 x [32 rows x PB]
     static constexpr int BIAS_OFF = STG_OFF + 2 * 32 * PB;
-    static constexpr int LDS = BIAS_OFF + 32 * RT * 4;
+    static constexpr int BITS_OFF = BIAS_OFF + 32 * RT * 4;          // DROP: NSLOT x SSN x [32 rows x 8 mask bytes]
+    static constexpr int LDS = BITS_OFF + (DROP ? NSLOT * SSN * 256 : 0);
     static constexpr int THREADS = (RT + 1) * 64;
 };
 
-template <int RT, int SSN>
+// NCH = chains (2: the gated K1, block parity = chain; 1: K2 / K3); ACT_ID: identity instead of gelu_new (K3; z only is saved);
+// DROP: a.drop.bits = packed keep flags of the chain input (K3)
+template <int RT, int SSN, int NCH, bool ACT_ID, bool DROP>
 __global__ __launch_bounds__((RT + 1) * 64, 2) void k1_down_kernel(PetFwdArgs a, int rows_per_block, int write_grad) {
-    using GEO = DownGeo<RT, SSN>;
+    using GEO = DownGeo<RT, SSN, DROP>;
     constexpr int NSLOT = GEO::NSLOT, NPT = GEO::NPT, SUB_B = GEO::SUB_B, NI = GEO::NI, PB = GEO::PB;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int chain = blockIdx.x & 1, rb = blockIdx.x >> 1;
+    const int chain = NCH == 2 ? (int)(blockIdx.x & 1) : 0, rb = NCH == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
     const int64_t r_begin = (int64_t)rb * rows_per_block;
     int64_t r_end = r_begin + rows_per_block;
     if (r_end > a.M) r_end = a.M;
@@ -111,6 +128,17 @@ __global__ __launch_bounds__((RT + 1) * 64, 2) void k1_down_kernel(PetFwdArgs a,
                 const uint32_t o = roff[q] - (uint32_t)(row > last ? row - last : 0) * (uint32_t)(F2_D * 2);
 #pragma unroll
                 for (int st = 0; st < SSN; ++st) glds16_row(src + o + st * 128, dst + st * 4096 + q * 1024);
+            }
+            if constexpr (DROP) {
+                // mask words of the sub-step: lane L brings the dword of (row L / 2, half L % 2) of each stage -- the four bytes
+                // of the k-steps u = 0..3 of compute lane (m = row, h = half) in the packed layout (rng.h drop_pos)
+                int brow = lane >> 1;
+                if (brow > last) brow = last;
+                const uint8_t* bsrc = a.drop.bits + (row0 + brow) * (int64_t)(F2_D / 8) + (i % NPT) * (SSN * 8) + (lane & 1) * 4;
+                uint8_t* bdst = smem + GEO::BITS_OFF + (size_t)(i % NSLOT) * (SSN * 256);
+#pragma unroll
+                for (int st = 0; st < SSN; ++st)
+                    __builtin_amdgcn_global_load_lds((gmem_cv*)(bsrc + st * 8), (lmem_v*)(bdst + st * 256), 4, 0, 0);
             }
         };
 #pragma unroll
@@ -154,6 +182,8 @@ __global__ __launch_bounds__((RT + 1) * 64, 2) void k1_down_kernel(PetFwdArgs a,
 #pragma unroll
     for (int u = 0; u < 4; ++u) a_b[u] = lds0 + (uint32_t)(m * 128 + (((2 * u + h) ^ swz(m)) * 16));
     const uint32_t a_bias = lds0 + (uint32_t)(GEO::BIAS_OFF + (32 * ct + 8 * h) * 4);
+    const uint32_t a_kw = lds0 + (uint32_t)(GEO::BITS_OFF + (2 * m + h) * 4);      // (DROP) the lane's mask word of a stage
+    const float kscale = DROP ? a.drop.keep_scale : 1.0f;
     __bf16* sv_z = reinterpret_cast<__bf16*>(reinterpret_cast<uint8_t*>(a.save) + (size_t)(chain == 0 ? 0 : 2) * a.save_stride);
     __bf16* sv_g = reinterpret_cast<__bf16*>(reinterpret_cast<uint8_t*>(a.save) + (size_t)(chain == 0 ? 1 : 3) * a.save_stride);
 
@@ -207,11 +237,22 @@ __global__ __launch_bounds__((RT + 1) * 64, 2) void k1_down_kernel(PetFwdArgs a,
         sfor<SSN>([&](auto ST) {
             constexpr int st = ST.value;
             u32x4 bf[4];
+            uint32_t kw = 0;
+            if constexpr (DROP)
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(kw) : "v"(a_kw + (uint32_t)((i % NSLOT) * (SSN * 256))), "n"(st * 256) : "memory");
             sfor<4>([&](auto U) { lds_read16<st * 4096>(bf[U.value], a_b[U.value] + sb); });
             lgkm_fence(bf[0]);
+            if constexpr (DROP) asm volatile("" : "+v"(kw) :: "memory");
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (u) lgkm_tie(bf[u]);
+                if constexpr (DROP) {                         // clear the dropped elements: byte u of kw = the 8 features of k-step u
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int lo = ((int)(kw << (31 - 8 * u - 2 * q))) >> 31, hi = ((int)(kw << (30 - 8 * u - 2 * q))) >> 31;
+                        bf[u][q] &= __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x07060100u);
+                    }
+                }
                 acc = mfma32(wf[(hf * SSN + st) * 4 + u], as_bf(bf[u]), acc);
             }
         });
@@ -237,16 +278,19 @@ __global__ __launch_bounds__((RT + 1) * 64, 2) void k1_down_kernel(PetFwdArgs a,
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float bj = __uint_as_float(j < 4 ? b0[j] : b1[j - 4]);
-                const float xv = acc[8 * sh + j] + bj;
-                const float x2 = xv * xv;
-                const float u = VLPET_GELU_K * (xv + 0.044715f * xv * x2);
-                const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.0f * 1.4426950408889634f * u));
-                v[j] = xv * s;
-                const float du = VLPET_GELU_K * (1.0f + 3.0f * 0.044715f * x2);
-                gd[j] = s + xv * s * (1.0f - s) * 2.0f * du;
+                const float xv = (DROP ? acc[8 * sh + j] * kscale : acc[8 * sh + j]) + bj;
+                if constexpr (ACT_ID) { v[j] = xv; gd[j] = 1.0f; }
+                else {
+                    const float x2 = xv * xv;
+                    const float u = VLPET_GELU_K * (xv + 0.044715f * xv * x2);
+                    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.0f * 1.4426950408889634f * u));
+                    v[j] = xv * s;
+                    const float du = VLPET_GELU_K * (1.0f + 3.0f * 0.044715f * x2);
+                    gd[j] = s + xv * s * (1.0f - s) * 2.0f * du;
+                }
             }
-            if (sh == 0) { lds_write16<0>(a_stg, pack8(v)); lds_write16<32 * PB>(a_stg, pack8(gd)); }
-            else { lds_write16<32>(a_stg, pack8(v)); lds_write16<32 * PB + 32>(a_stg, pack8(gd)); }
+            if (sh == 0) { lds_write16<0>(a_stg, pack8(v)); if constexpr (!ACT_ID) lds_write16<32 * PB>(a_stg, pack8(gd)); }
+            else { lds_write16<32>(a_stg, pack8(v)); if constexpr (!ACT_ID) lds_write16<32 * PB + 32>(a_stg, pack8(gd)); }
         }
         acc = zero16();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the staged pieces are in LDS at the next barrier
@@ -274,12 +318,14 @@ template <int RT, int NX_> struct UpGeo {
     static constexpr int LDS = BIAS_OFF + 2 * NW * 32 * 4;
 };
 
-template <int RT, bool ADD, int WPE, int NXD>
+// GATE = false (K2 / K3): no gate projection; out = s2 * res + sd * (bu + Wu z), res = the residual input (y / base)
+template <int RT, bool ADD, int WPE, int NXD, bool GATE>
 __global__ __launch_bounds__(512, WPE) void k1_up_kernel(PetFwdArgs a, int row_chunks, int64_t rows_per_chunk) {
     using GEO = UpGeo<RT, NXD>;
     constexpr int NW = GEO::NW, NX = GEO::NX, NZ = GEO::NZ, KT = GEO::KT, PB = GEO::PB, PT_B = GEO::PT_B, X_B = GEO::X_B;
     constexpr int NCG = F2_D / (32 * NW);               // column groups
-    constexpr int NB = (4 * RT + NW - 1) / NW;          // bottleneck pieces per wave (some waves one fewer)
+    constexpr int NPZ = (GATE ? 4 : 2) * RT;            // 1 KiB pieces of the bottleneck tiles of a step
+    constexpr int NB = (NPZ + NW - 1) / NW;             // bottleneck pieces per wave (some waves one fewer)
     constexpr int GRP = WPE >= 4 ? (KT % 3 == 0 ? 3 : KT) : (KT > 6 ? 6 : KT);     // B fragments per LDS batch (what the register budget allows)
     static_assert(NZ == 2, "the counted waits below assume the z tiles travel one step ahead");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -303,11 +349,11 @@ __global__ __launch_bounds__(512, WPE) void k1_up_kernel(PetFwdArgs a, int row_c
     {
         float* sbias = reinterpret_cast<float*>(smem + GEO::BIAS_OFF);
         const uint8_t* pkb = tid < 32 * NW ? a.pk_a : a.pk_g;
-        sbias[tid] = reinterpret_cast<const float*>(pkb + pg.bias_off)[32 * RT + colg + (tid & (32 * NW - 1))];
+        if (GATE || tid < 32 * NW) sbias[tid] = reinterpret_cast<const float*>(pkb + pg.bias_off)[32 * RT + colg + (tid & (32 * NW - 1))];
     }
     // resident A fragments of the wave's 32 columns from the "up" packs, gathered so that a lane (m, h) ends with the 16 CONTIGUOUS
     // columns c0 + 16h .. + 15 of row m (the gather of pet_cols.hip: MFMA row i = column c0 + 16*((i>>2)&1) + 4*(i>>3) + (i&3))
-    bf16x8 wA[KT], wG[KT];
+    bf16x8 wA[KT], wG[GATE ? KT : 1];
     {
         const int cb = c0 >> 7, wc = (c0 >> 5) & 3, pp = wc >> 1, ntt = wc & 1;
         const int i = m, v = (i >> 2) & 1, ip = (i & 3) | (ntt << 2) | ((i >> 3) << 3);
@@ -315,7 +361,7 @@ __global__ __launch_bounds__(512, WPE) void k1_up_kernel(PetFwdArgs a, int row_c
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) {
             wA[ks] = *reinterpret_cast<const bf16x8*>(a.pk_a + off + ks * 1024);
-            wG[ks] = *reinterpret_cast<const bf16x8*>(a.pk_g + off + ks * 1024);
+            if constexpr (GATE) wG[ks] = *reinterpret_cast<const bf16x8*>(a.pk_g + off + ks * 1024);
         }
     }
     // ---- stage pieces of this wave (1 KiB each): x2 pieces q = wave, wave + NW (pair tile q / 4, rows 8 (q % 4) ..); bottleneck
@@ -359,7 +405,7 @@ __global__ __launch_bounds__(512, WPE) void k1_up_kernel(PetFwdArgs a, int row_c
         const int last = (int)(r_end - rb) - 1;
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-            if (wave + NW * j < 4 * RT)
+            if (wave + NW * j < NPZ)
                 glds16(sbase(zbase[pten[j] ? 1 : 0] + rb * PB) + poff[j] - (uint32_t)(prow[j] > last ? prow[j] - last : 0) * PB, st + pdst[j]);
     };
     // per-lane LDS addresses (relative to the slot bases)
@@ -429,7 +475,7 @@ __global__ __launch_bounds__(512, WPE) void k1_up_kernel(PetFwdArgs a, int row_c
         if (VLPET_F2_ABL & 1) { aA = zero16(); aG = zero16(); } else
 #endif
         {
-        project_up(std::integral_constant<int, 1>{}, std::integral_constant<int, 32 * NW * 4>{}, wG, aG);
+        if constexpr (GATE) project_up(std::integral_constant<int, 1>{}, std::integral_constant<int, 32 * NW * 4>{}, wG, aG);
         project_up(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, wA, aA);
         }
         u32x4 xv[2];
@@ -445,12 +491,14 @@ __global__ __launch_bounds__(512, WPE) void k1_up_kernel(PetFwdArgs a, int row_c
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int e = 8 * k + j;
-                const float gt = sigm(aG[e]);
                 const float lin = s2g * bf_at(xv[k], j) + sdg * aA[e];
-                o[j] = ADD ? lin + gs * gt : lin * gt;
+                if constexpr (GATE) {
+                    const float gt = sigm(aG[e]);
+                    o[j] = ADD ? lin + gs * gt : lin * gt;
 #ifdef VLPET_F2_ABL
-                if (VLPET_F2_ABL & 2) o[j] = aG[e] + aA[e];
+                    if (VLPET_F2_ABL & 2) o[j] = aG[e] + aA[e];
 #endif
+                } else o[j] = lin;
             }
             lds_write16<0>(sbx + a_xcl[k], pack8(o));
         }
@@ -473,29 +521,51 @@ __global__ __launch_bounds__(512, WPE) void k1_up_kernel(PetFwdArgs a, int row_c
     F2_STAMP_PRINT("up", "top(wait+barrier) %llu  issue+proj %llu  ew+store %llu")
 }
 
-template <int RT, int SSN>
+// ------------------------------------------------------------------------------------------------ K3's keep flags
+// One thread per mask dword (32 elements): byte j of dword w of a row holds group G = (p & ~7) + 2 (p & 3) + ((p >> 2) & 1),
+// p = 4 w + j (the inverse of rng.h drop_pos), flags from the generator of rng.h (a function of seed and element index only:
+// the same mask the in-kernel generator of pet_fwd.hip produces).  keep_out (optional): the 0/1 byte export for parity tests.
+__global__ __launch_bounds__(256) void drop_bits_kernel(uint8_t* bits, uint8_t* keep_out, int64_t M, int d, uint64_t seed, uint32_t thr) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int wpr = d >> 5;
+    if (t >= M * wpr) return;
+    const int64_t row = t / wpr;
+    const int w = (int)(t - row * wpr);
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = 4 * w + j, G = (p & ~7) + 2 * (p & 3) + ((p >> 2) & 1);
+        const int64_t grp = row * (int64_t)(d >> 3) + G;
+        const uint32_t kb = keep8(grp, seed, thr);
+        if (keep_out != nullptr) drop_export8(keep_out, grp * 8, kb);
+        out |= kb << (8 * j);
+    }
+    reinterpret_cast<uint32_t*>(bits)[t] = out;
+}
+
+template <int RT, int SSN, int NCH, bool ACT_ID, bool DROP>
 hipError_t launch_down(const PetFwdArgs& a, hipStream_t stream) {
-    using GEO = DownGeo<RT, SSN>;
-    auto kern = k1_down_kernel<RT, SSN>;
+    using GEO = DownGeo<RT, SSN, DROP>;
+    auto kern = k1_down_kernel<RT, SSN, NCH, ACT_ID, DROP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEO::LDS);
     if (e != hipSuccess) return e;
     // row blocks: one round of the chip (two workgroups per CU up to r = 96, one at r = 192), any multiple of 32 rows
-    const int slots_per_chain = RT == 6 ? 128 : 256;
+    const int slots_per_chain = (RT == 6 ? 256 : 512) / NCH;
     int64_t tiles = (a.M + 31) / 32;
     int64_t tpb = (tiles + slots_per_chain - 1) / slots_per_chain;
     if (tpb < 1) tpb = 1;
     const int rows_per_block = (int)(32 * tpb);
     const int nblocks = (int)((a.M + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL(kern, dim3(2 * nblocks), dim3(GEO::THREADS), GEO::LDS, stream, a, rows_per_block, 1);
+    hipLaunchKernelGGL(kern, dim3(NCH * nblocks), dim3(GEO::THREADS), GEO::LDS, stream, a, rows_per_block, ACT_ID ? 0 : 1);
     return hipGetLastError();
 }
 
-template <int RT, int WPE, int NXD>
+template <int RT, int WPE, int NXD, bool GATE>
 hipError_t launch_up(const PetFwdArgs& a, hipStream_t stream) {
     using GEO = UpGeo<RT, NXD>;
     constexpr int NCG = F2_D / (32 * GEO::NW);
-    const bool add = a.flags & PET_GATE_ADD;
-    auto kern = add ? k1_up_kernel<RT, true, WPE, NXD> : k1_up_kernel<RT, false, WPE, NXD>;
+    const bool add = GATE && (a.flags & PET_GATE_ADD);
+    auto kern = add ? k1_up_kernel<RT, GATE, WPE, NXD, GATE> : k1_up_kernel<RT, false, WPE, NXD, GATE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEO::LDS);
     if (e != hipSuccess) return e;
     constexpr int S = 16 * WPE;                           // workgroup slots per XCD: 32 CUs x (WPE / 2) 512-thread workgroups
@@ -510,37 +580,72 @@ hipError_t launch_up(const PetFwdArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// pass A of one shape family: the gated K1 (two chains), K2 (one chain, gelu_new), K3 (one chain, identity, with or without the mask)
+template <int RT>
+hipError_t launch_down_rt(const PetFwdArgs& a, hipStream_t stream) {
+    if (a.flags & PET_GATE) return launch_down<RT, 3, 2, false, false>(a, stream);
+    if (!(a.flags & PET_ACT_IDENTITY)) return launch_down<RT, 3, 1, false, false>(a, stream);
+    return a.drop.bits != nullptr ? launch_down<RT, 3, 1, true, true>(a, stream) : launch_down<RT, 3, 1, true, false>(a, stream);
+}
+template <int RT, int WPE, int NXD>
+hipError_t launch_up_rt(const PetFwdArgs& a, hipStream_t stream) {
+    return (a.flags & PET_GATE) ? launch_up<RT, WPE, NXD, true>(a, stream) : launch_up<RT, WPE, NXD, false>(a, stream);
+}
+
 }  // namespace
 
+// Shapes the two-pass forward takes: bf16, d = 768, training form (the z the cut goes through is an output there), square
+// (not the low-rank visual projector).  Dropout (K3): the library's generator or none -- an explicit byte mask stays on pet_fwd.hip.
 bool k1_fwd2p_applies(const PetFwdArgs& a, int io_fp32) {
-    return !io_fp32 && a.d == F2_D && (a.flags & PET_GATE) && a.save != nullptr && a.d_in == 0 && a.M >= 1 &&
-           !(a.flags & PET_ACT_IDENTITY) && a.drop.thr == 0 && a.drop.keep == nullptr;
+    if (io_fp32 || a.d != F2_D || a.save == nullptr || a.d_in != 0 || a.M < 1 || a.drop.keep != nullptr) return false;
+    if (a.flags & PET_GATE) return !(a.flags & PET_ACT_IDENTITY) && !drop_active(a.drop);
+    if (a.flags & PET_ACT_IDENTITY) return !drop_active(a.drop) || (a.drop.thr != 0 && a.drop.bits_out != nullptr);
+    return !drop_active(a.drop);
 }
 // Which form is faster (MI355X, bf16, profiles/r04_k1fwd_two_pass_ab.txt): at r = 192 the two-pass form at every size (51 vs 124 us at
 // 18,250 rows, 15 vs 62 us at 2,100); up to r = 96 everywhere except where the one-kernel forward runs ONE well-filled round of its
 // 128-row workgroups (17,000 < M <= 32,768: 45.7 vs 50.6 us at 28,000 rows) -- below that it is a latency chain of few workgroups
 // (32 vs 14 us at 3,500 rows), above it two rounds (81 vs 57 us at 33,200).
 bool k1_fwd2p_preferred(const PetFwdArgs& a) {
-    if (a.RT == 6) return true;
-    return !(a.M > 17000 && a.M <= 32768);
+    if (a.flags & PET_GATE) {
+        if (a.RT == 6) return true;
+        return !(a.M > 17000 && a.M <= 32768);
+    }
+    // K2 / K3 (profiles/r04_k2k3_fwd_two_pass_ab.txt): below one well-filled round of the one-kernel forward's 128-row workgroups the
+    // two passes win by 1.3-2.7x (K2 at 3,500 rows 26 -> 11 us, K3 r = 64 with dropout at 2,500 rows 36 -> 14 us); just above
+    // 32,768 rows (the one-kernel form's second round) by 15 %; at six tiles above 32,768 rows (66 -> 56 us).  With dropout at
+    // large M the one-kernel forward with its in-kernel generator stays ahead (42.7 vs 46.6 us at 28,000 rows, r = 64).
+    if (a.M <= 17000) return true;
+    if (a.RT == 6 && a.M > 32768) return true;
+    return !drop_active(a.drop) && a.M > 32768 && a.M <= 42000;
 }
 
-hipError_t launch_k1_fwd2p(const PetFwdArgs& a, int passes, hipStream_t stream) {
+hipError_t launch_k1_fwd2p(const PetFwdArgs& a0, int passes, hipStream_t stream) {
+    PetFwdArgs a = a0;
     hipError_t e = hipSuccess;
     if (passes & 1) {
+        if (!(a.flags & PET_GATE) && a.drop.thr != 0 && a.drop.bits == nullptr) {
+            // K3: the packed mask first (where the training form leaves it for the backward), then pass A reads it back
+            const int64_t words = a.M * (int64_t)(a.d >> 5);
+            hipLaunchKernelGGL(drop_bits_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream,
+                               a.drop.bits_out, a.drop.keep_out, a.M, a.d, a.drop.seed, a.drop.thr);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            a.drop.bits = a.drop.bits_out;
+        }
         switch (a.RT) {
-            case 1: e = launch_down<1, 3>(a, stream); break;
-            case 3: e = launch_down<3, 3>(a, stream); break;
-            case 6: e = launch_down<6, 3>(a, stream); break;
+            case 1: e = launch_down_rt<1>(a, stream); break;
+            case 3: e = launch_down_rt<3>(a, stream); break;
+            case 6: e = launch_down_rt<6>(a, stream); break;
             default: return hipErrorInvalidValue;
         }
         if (e != hipSuccess) return e;
     }
     if (passes & 2) {
         switch (a.RT) {
-            case 1: return launch_up<1, 4, 3>(a, stream);
-            case 3: return launch_up<3, 4, 3>(a, stream);
-            case 6: return launch_up<6, 2, 4>(a, stream);
+            case 1: return launch_up_rt<1, 4, 3>(a, stream);
+            case 3: return launch_up_rt<3, 4, 3>(a, stream);
+            case 6: return launch_up_rt<6, 2, 4>(a, stream);
             default: return hipErrorInvalidValue;
         }
     }

@@ -767,6 +767,17 @@ struct FinArgs {
     int RC, PR;
 };
 
+// the partials are read once, by one workgroup; non-temporal loads measured no faster here (K1 backward pass 2 + finalize 75.1 / 75.7 us
+// with them against 73.8 / 74.4 us without at M = 28,000, same box: profiles/r04_finalize_ab.txt), unlike for the row streams (pet16.h;
+// -DVLPET_FIN_NT=1 builds the non-temporal variant for A/B)
+#ifndef VLPET_FIN_NT
+#define VLPET_FIN_NT 0
+#endif
+#if VLPET_FIN_NT
+#define VLPET_FIN_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define VLPET_FIN_LOAD(p) (*(p))
+#endif
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(FinArgs a) {
     __shared__ float tile[16][65];
     const FinJob J = a.job[blockIdx.y];
@@ -782,25 +793,25 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(FinArgs a) {
         const float* p0 = part + (int64_t)(c0 + cc) * xc + n0 + nn;
         const int64_t cstride = (int64_t)PR * xc;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        int rc = 0;
-        for (; rc + 16 <= RC; rc += 16) {
-            f32x4 v[16];
+        // Round 4: every row-chunk load of the tile is requested before the first add (one trip of up to 48 loads, or 24 when
+        // there are at most 24 chunks, instead of trips of 16: with 40-42 chunks the kernel waited out three memory round trips,
+        // now one); chunk order kept, indices past the end re-read the last chunk and are not added.
+        auto batch = [&](auto NB, int rc0) {
+            constexpr int N = decltype(NB)::value;
+            f32x4 v[N];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = *reinterpret_cast<const f32x4*>(p0 + (rc + q) * cstride);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) s += v[q];             // chunk order kept
-        }
-        if (rc < RC) {
-            f32x4 v[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int r2 = rc + q < RC ? rc + q : RC - 1;
-                v[q] = *reinterpret_cast<const f32x4*>(p0 + r2 * cstride);
+            for (int q = 0; q < N; ++q) {
+                const int r2 = rc0 + q < RC ? rc0 + q : RC - 1;
+                v[q] = VLPET_FIN_LOAD(reinterpret_cast<const f32x4*>(p0 + r2 * cstride));
             }
+            __builtin_amdgcn_sched_barrier(0);                           // (every request before the first add)
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                if (rc + q < RC) s += v[q];
-        }
+            for (int q = 0; q < N; ++q) s += rc0 + q < RC ? v[q] : zero;
+        };
+        if (RC <= 24) batch(std::integral_constant<int, 24>{}, 0);
+        else
+            for (int rc = 0; rc < RC; rc += 48) batch(std::integral_constant<int, 48>{}, rc);
         s = s * J.scale;
         if (!J.transposed) {
             if (c0 + cc < R) {
