@@ -125,6 +125,16 @@ int vlpet_adapter_gate_bwd_phase(int phases, const void* dy, const void* x1, con
  * 0 = row kernel + weight-gradient kernels; < 0: bad arguments.  (What a bench labels its kernel brackets with.) */
 int vlpet_adapter_gate_bwd_form(int64_t M, int d, int tiles, int io_dtype);
 
+/* Dropout seeds under graph replay (train.Trainer(graph=True): forward + backward of a step captured once with hipGraph and replayed).
+ * A replayed launch repeats its kernel arguments, so the per-call `seed` values of the dropout-carrying entry points below
+ * (vlpet_lora_delta_*, vlpet_sublayer_tail_*, vlpet_act_dropout_*, vlpet_attn_*) would give every step the same masks.  With a
+ * counter registered here -- a 64-bit word in DEVICE memory that the caller increments once per step, outside the captured
+ * region or as its first node -- every such kernel uses seed + counter * 0x9E3779B97F4A7C15 instead (one scalar load in its
+ * prologue); forward and backward of a step read the same value, so regenerated masks still match.  NULL (the default) = seeds
+ * are used as passed.  Process-wide; the only state the library keeps between calls.  No reference counterpart: the reference
+ * draws from torch's global generator (my_transformers/modeling_bart.py:1259, lora/controller.py:66). */
+int vlpet_set_seed_counter(const uint64_t* device_counter);
+
 /* 1 for a diagnosis build (make DEBUG=1): the only builds whose kernels' experiment switches (csrc/tuning.h) can be set from
  * VLPET_* environment variables, read once at load time.  The product library (0) reads nothing from the environment. */
 int vlpet_debug_build(void);

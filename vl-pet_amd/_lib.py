@@ -43,6 +43,7 @@ SIGNATURES = {
     "vlpet_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
     "vlpet_adapter_gate_bwd_form": (c_int, [c_int64, c_int, c_int, c_int]),
     "vlpet_debug_build": (c_int, []),
+    "vlpet_set_seed_counter": (c_int, [c_void_p]),
     "vlpet_adapter_gate_bwd": (c_int, [c_void_p] * 7 + [c_void_p] * 8 + [c_int, c_int, c_void_p, c_size_t, c_int64,
                                                                          c_int, c_int, c_int, c_float, c_float,
                                                                          c_float, c_int, c_void_p]),

@@ -55,6 +55,7 @@ template <typename IO, int ACT, bool DROP, bool BWD>
 __global__ __launch_bounds__(256) void act_dropout_kernel(ActDropArgs a) {
     const int64_t groups = a.n >> 3;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint64_t seed = DROP ? vlpet_eff_seed(a.seed, a.seed_ctr) : 0;
     // two groups per thread and iteration, both loads (four in the backward) issued before the arithmetic of either
     for (int64_t g0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g0 < groups; g0 += 2 * stride) {
         const int64_t g1 = g0 + stride;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void act_dropout_kernel(ActDropArgs a) {
             const int64_t g = u == 0 ? g0 : g1;
             Vec8<IO> o;
             uint32_t bits = 0xffu;
-            if constexpr (DROP) bits = keep8(g, a.seed, a.thr);
+            if constexpr (DROP) bits = keep8(g, seed, a.thr);
             if constexpr (BWD) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {

@@ -1,4 +1,5 @@
 // C ABI of libvlpet_hip.so (declared in include/vlpet_hip.h): argument checking + launch plumbing.
+#include <atomic>
 #include "../../include/vlpet_hip.h"
 #include "common.h"
 #include "kernels.h"
@@ -120,7 +121,15 @@ extern "C" size_t vlpet_saved_bytes(int64_t M, int tiles, int io_dtype) {
     return 4 * saved_stride(M, tiles, io_dtype);
 }
 
-static const DropSpec NO_DROP = {nullptr, nullptr, nullptr, nullptr, 0, 0, 1.f};
+static const DropSpec NO_DROP = {nullptr, nullptr, nullptr, nullptr, 0, 0, 1.f, nullptr};
+
+// Device step counter mixed into every dropout seed (rng.h vlpet_eff_seed): process-wide, set by the trainer that replays captured
+// steps (train.Trainer(graph=True)); nullptr = seeds are used as passed.  The only state the library keeps between calls.
+static std::atomic<const uint64_t*> g_seed_ctr{nullptr};
+extern "C" int vlpet_set_seed_counter(const uint64_t* device_counter) {
+    g_seed_ctr.store(device_counter);
+    return 0;
+}
 
 // p in [0, 1): explicit mask (keep_mask != NULL) or the in-kernel generator keyed by `seed`; p == 0: no dropout
 static int make_drop(const uint8_t* keep_mask, float p, uint64_t seed, uint8_t* keep_out, DropSpec* ds) {
@@ -130,6 +139,7 @@ static int make_drop(const uint8_t* keep_mask, float p, uint64_t seed, uint8_t* 
     ds->keep = keep_mask;
     ds->keep_out = keep_out;
     ds->seed = seed;
+    ds->seed_ctr = g_seed_ctr.load();
     double t = (double)p * 65536.0 + 0.5;
     if (t > 65535.0) t = 65535.0;
     ds->thr = (uint32_t)t;
@@ -936,7 +946,7 @@ extern "C" int vlpet_sublayer_tail_fwd(const void* y, const void* x1, const floa
     TailArgs a{};
     a.y = y; a.x1 = x1; a.out = out; a.h = h_save; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd;
     a.keep_out = keep_out; a.dgb = nullptr; a.M = M; a.d = d; a.eps = eps; a.thr = tail_thr(p);
-    a.keep_scale = 1.0f / (1.0f - p); a.seed = seed; a.norm = norm_mode;
+    a.keep_scale = 1.0f / (1.0f - p); a.seed = seed; a.seed_ctr = g_seed_ctr.load(); a.norm = norm_mode;
     return herr(launch_tail(a, io_dtype == VLPET_F32, false, (hipStream_t)stream));
 }
 
@@ -949,7 +959,7 @@ extern "C" int vlpet_norm_residual_fwd(const void* y, const void* r, const float
     if (!aligned16(y) || !aligned16(r) || !aligned16(out)) return VLPET_E_ALIGN;
     TailArgs a{};
     a.y = y; a.x1 = r; a.out = out; a.h = nullptr; a.gamma = gamma; a.beta = beta; a.mean = mean; a.rstd = rstd;
-    a.keep_out = nullptr; a.dgb = nullptr; a.M = M; a.d = d; a.eps = eps; a.thr = 0; a.keep_scale = 1.f; a.seed = 0;
+    a.keep_out = nullptr; a.dgb = nullptr; a.M = M; a.d = d; a.eps = eps; a.thr = 0; a.keep_scale = 1.f; a.seed = 0; a.seed_ctr = nullptr;
     a.norm = 1; a.post = 1;
     return herr(launch_tail(a, io_dtype == VLPET_F32, false, (hipStream_t)stream));
 }
@@ -968,7 +978,7 @@ extern "C" int vlpet_sublayer_tail_bwd(const void* dout, const void* h_save, con
     TailArgs a{};
     a.out = const_cast<void*>(dout); a.h = const_cast<void*>(h_save); a.mean = const_cast<float*>(mean);
     a.rstd = const_cast<float*>(rstd); a.gamma = gamma; a.beta = nullptr; a.x1 = dx1; a.y = dy; a.keep_out = nullptr;
-    a.dgb = dgb_partials; a.M = M; a.d = d; a.eps = 0.f; a.thr = thr; a.keep_scale = 1.0f / (1.0f - p); a.seed = seed;
+    a.dgb = dgb_partials; a.M = M; a.d = d; a.eps = 0.f; a.thr = thr; a.keep_scale = 1.0f / (1.0f - p); a.seed = seed; a.seed_ctr = g_seed_ctr.load();
     a.norm = norm_mode;
     return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
 }
@@ -987,7 +997,7 @@ extern "C" int vlpet_sublayer_tail_bwd_out(const void* dout, const void* out_sav
     TailArgs a{};
     a.out = const_cast<void*>(dout); a.h = const_cast<void*>(out_save); a.mean = nullptr;
     a.rstd = const_cast<float*>(rstd); a.gamma = gamma; a.beta = beta; a.x1 = dx1; a.y = dy; a.keep_out = nullptr;
-    a.dgb = dgb_partials; a.M = M; a.d = d; a.eps = 0.f; a.thr = thr; a.keep_scale = 1.0f / (1.0f - p); a.seed = seed;
+    a.dgb = dgb_partials; a.M = M; a.d = d; a.eps = 0.f; a.thr = thr; a.keep_scale = 1.0f / (1.0f - p); a.seed = seed; a.seed_ctr = g_seed_ctr.load();
     a.norm = 1; a.h_out = 1;
     return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
 }
@@ -1020,7 +1030,7 @@ extern "C" int vlpet_attn_fwd_ld(const void* q, const void* k, const void* v, co
     a.ld_q = ld_q; a.ld_kv = ld_kv;
     a.q = (const __bf16*)q; a.k = (const __bf16*)k; a.v = (const __bf16*)v; a.o = (__bf16*)o; a.lse = lse;
     a.key_mask = key_mask; a.keep_out = keep_out; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.causal = causal ? 1 : 0;
-    a.scale = scale; a.thr = attn_thr(p); a.inv_keep = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
+    a.scale = scale; a.thr = attn_thr(p); a.inv_keep = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed; a.seed_ctr = g_seed_ctr.load();
     return herr(launch_attn(a, false, (hipStream_t)stream));
 }
 
@@ -1044,7 +1054,7 @@ extern "C" int vlpet_attn_bwd_ld(const void* q, const void* k, const void* v, co
     a.q = (const __bf16*)q; a.k = (const __bf16*)k; a.v = (const __bf16*)v; a.o = (__bf16*)const_cast<void*>(o);
     a.lse = const_cast<float*>(lse); a.dout = (const __bf16*)dout; a.dq = (__bf16*)dq; a.dk = (__bf16*)dk; a.dv = (__bf16*)dv;
     a.key_mask = key_mask; a.keep_out = nullptr; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.causal = causal ? 1 : 0;
-    a.scale = scale; a.thr = attn_thr(p); a.inv_keep = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
+    a.scale = scale; a.thr = attn_thr(p); a.inv_keep = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed; a.seed_ctr = g_seed_ctr.load();
     return herr(launch_attn(a, true, (hipStream_t)stream));
 }
 
@@ -1100,7 +1110,7 @@ extern "C" int vlpet_act_dropout_fwd(const void* x, void* out, uint8_t* keep_out
     if (!aligned16(x) || !aligned16(out)) return VLPET_E_ALIGN;
     ActDropArgs a{};
     a.x = x; a.dy = nullptr; a.out = out; a.keep_out = keep_out; a.n = n; a.act = act; a.thr = tail_thr(p);
-    a.keep_scale = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
+    a.keep_scale = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed; a.seed_ctr = g_seed_ctr.load();
     return herr(launch_act_dropout(a, false, io_dtype == VLPET_F32, (hipStream_t)stream));
 }
 
@@ -1112,7 +1122,7 @@ extern "C" int vlpet_act_dropout_bwd(const void* dy, const void* x, void* dx, in
     if (!aligned16(dy) || !aligned16(x) || !aligned16(dx)) return VLPET_E_ALIGN;
     ActDropArgs a{};
     a.x = x; a.dy = dy; a.out = dx; a.keep_out = nullptr; a.n = n; a.act = act; a.thr = tail_thr(p);
-    a.keep_scale = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed;
+    a.keep_scale = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed; a.seed_ctr = g_seed_ctr.load();
     return herr(launch_act_dropout(a, true, io_dtype == VLPET_F32, (hipStream_t)stream));
 }
 

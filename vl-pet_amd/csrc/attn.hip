@@ -157,6 +157,7 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.x * AT_FW + wave;
     if (bh >= a.B * a.H) return;
+    const uint64_t seed = a.thr ? vlpet_eff_seed(a.seed, a.seed_ctr) : 0;
     const int b = bh / a.H, h = bh % a.H;
     const int m = lane & 31, hh = lane >> 5;
     constexpr int Lkp = 32 * T;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
         const float inv = sum > 0.f ? 1.0f / sum : 0.f;
         if (hh == 0 && i < a.Lq) a.lse[((int64_t)b * a.H + h) * a.Lq + i] = sum > 0.f ? mx + log2f(sum) : INFINITY;
         // ---- dropout, probabilities -> B operands
-        const uint32_t rk = row_key(a.seed, ((int64_t)b * a.H + h) * a.Lq + iq);
+        const uint32_t rk = row_key(seed, ((int64_t)b * a.H + h) * a.Lq + iq);
         f32x16 ot0 = zero16(), ot1 = zero16();
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t seed = a.thr ? vlpet_eff_seed(a.seed, a.seed_ctr) : 0;
     const int m = lane & 31, hh = lane >> 5;
     const int Lkp = (a.Lk + 31) & ~31, T = Lkp >> 5;
     const int Lqp = (a.Lq + 31) & ~31, NQB = Lqp >> 5;
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
                 f32x4 rv;
                 rv[0] = live ? a.lse[((int64_t)b * a.H + h) * a.Lq + row] : INFINITY;
                 rv[1] = live ? acc : 0.f;
-                rv[2] = __uint_as_float(row_key(a.seed, ((int64_t)b * a.H + h) * a.Lq + (live ? row : a.Lq - 1)));
+                rv[2] = __uint_as_float(row_key(seed, ((int64_t)b * a.H + h) * a.Lq + (live ? row : a.Lq - 1)));
                 rv[3] = 0.f;
                 rowv[row] = rv;
             }

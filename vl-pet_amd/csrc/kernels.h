@@ -219,6 +219,7 @@ struct TailArgs {
     uint32_t thr;           // drop iff 16-bit uniform < thr;  0 = no dropout
     float keep_scale;       // 1 / (1 - p)
     uint64_t seed;
+    const uint64_t* seed_ctr;   // optional device step counter mixed into the seed (rng.h vlpet_eff_seed)
     int norm;
     int post;               // 1: out = LayerNorm(dropout(y)) + x1  (x1 is added AFTER the norm: the visual projectors' position /
                             //    order-embedding term, src/modeling_bart.py:298-299, 324-325); forward only -- the backward of
@@ -317,6 +318,7 @@ struct ActDropArgs {
     uint32_t thr;           // drop iff 16-bit uniform < thr (0: no dropout)
     float keep_scale;
     uint64_t seed;
+    const uint64_t* seed_ctr;   // optional device step counter mixed into the seed (rng.h vlpet_eff_seed)
 };
 hipError_t launch_act_dropout(const ActDropArgs& a, bool bwd, int io_fp32, hipStream_t stream);
 
@@ -349,6 +351,7 @@ struct AttnArgs {
     uint32_t thr;           // drop iff hash < thr (p * 2^32); 0 = no dropout
     float inv_keep;
     uint64_t seed;
+    const uint64_t* seed_ctr;   // optional device step counter mixed into the seed (rng.h vlpet_eff_seed)
 };
 size_t attn_lds_bytes(int Lq, int Lk, int bwd);
 hipError_t launch_attn(const AttnArgs& a, bool bwd, hipStream_t stream);

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
     const int total = P3 + S;
 
     const RowLanes rl = row_lanes<IO>(row0_wave, a.M, d, wave, lane);
+    const DropSpec drop_r = DROP ? drop_resolved(a.drop) : a.drop;      // (the step counter folded into the seed: rng.h)
     const int lane16 = lane * 16;
 
     // stage decoding: weight pack / pack stage, row tensors (t0, t1) and their stage offset
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
             }
             Frag<NS> bA = cur.bA;
             if constexpr (DROP) {
-                const uint32_t kb = drop_bits8(a.drop, grow, s * G::FE + 16 * u + 8 * h, d);
+                const uint32_t kb = drop_bits8(drop_r, grow, s * G::FE + 16 * u + 8 * h, d);
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_bwd_kernel(PetBwdArgs a) {
         uint32_t kp[4] = {0, 0, 0, 0};
         if constexpr (DROP) {
 #pragma unroll
-            for (int c = 0; c < G::LW / 8; ++c) kp[c] = drop_bits8(a.drop, grow, su * G::FE + G::LW * h + 8 * c, d);
+            for (int c = 0; c < G::LW / 8; ++c) kp[c] = drop_bits8(drop_r, grow, su * G::FE + G::LW * h + 8 * c, d);
         }
 #pragma unroll
         for (int e = 0; e < G::E4; ++e) {

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
     const int nb = 32 * RT + d;
 
     const RowLanes rl = row_lanes<IO>(row0_wave, a.M, d, wave, lane);
+    const DropSpec drop_r = DROP ? drop_resolved(a.drop) : a.drop;      // (the step counter folded into the seed: rng.h)
     const int lane16 = lane * 16;
 
     auto rows_count = [&](int s2) { return s2 < S ? 4 * NTEN : ((s2 < 2 * S && !KEEP) ? 4 : 0); };
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(WAVES * 64) void pet_fwd_kernel(PetFwdArgs a) {
 #pragma unroll
             for (int u = 0; u < G::KU; ++u) {
                 const int f0 = s * G::FE + 16 * u + 8 * h;
-                const uint32_t kb = drop_bits8(a.drop, grow, f0, d);
+                const uint32_t kb = drop_bits8(drop_r, grow, f0, d);
                 if (a.drop.keep_out != nullptr && live) drop_export8(a.drop.keep_out, grow * d + f0, kb);
                 w |= kb << (8 * u);
             }

@@ -525,7 +525,8 @@ __global__ __launch_bounds__(512, WPE) void k1_up_kernel(PetFwdArgs a, int row_c
 // One thread per mask dword (32 elements): byte j of dword w of a row holds group G = (p & ~7) + 2 (p & 3) + ((p >> 2) & 1),
 // p = 4 w + j (the inverse of rng.h drop_pos), flags from the generator of rng.h (a function of seed and element index only:
 // the same mask the in-kernel generator of pet_fwd.hip produces).  keep_out (optional): the 0/1 byte export for parity tests.
-__global__ __launch_bounds__(256) void drop_bits_kernel(uint8_t* bits, uint8_t* keep_out, int64_t M, int d, uint64_t seed, uint32_t thr) {
+__global__ __launch_bounds__(256) void drop_bits_kernel(uint8_t* bits, uint8_t* keep_out, int64_t M, int d, uint64_t seed0, const uint64_t* seed_ctr, uint32_t thr) {
+    const uint64_t seed = vlpet_eff_seed(seed0, seed_ctr);
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int wpr = d >> 5;
     if (t >= M * wpr) return;
@@ -628,7 +629,7 @@ hipError_t launch_k1_fwd2p(const PetFwdArgs& a0, int passes, hipStream_t stream)
             // K3: the packed mask first (where the training form leaves it for the backward), then pass A reads it back
             const int64_t words = a.M * (int64_t)(a.d >> 5);
             hipLaunchKernelGGL(drop_bits_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream,
-                               a.drop.bits_out, a.drop.keep_out, a.M, a.d, a.drop.seed, a.drop.thr);
+                               a.drop.bits_out, a.drop.keep_out, a.M, a.d, a.drop.seed, a.drop.seed_ctr, a.drop.thr);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             a.drop.bits = a.drop.bits_out;

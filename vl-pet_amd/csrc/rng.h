@@ -23,6 +23,14 @@ __device__ __forceinline__ void philox7(uint32_t c0, uint32_t c1, uint32_t k0, u
     }
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
+// Seeds under graph replay.  A captured train step replays its kernel arguments, so a per-call seed passed by value would give
+// every step the same masks.  vlpet_set_seed_counter (include/vlpet_hip.h) hands the library the address of a 64-bit device
+// counter the trainer bumps once per step; every dropout-carrying kernel reads it ONCE in its prologue (a scalar load) and
+// mixes it into its call's seed.  No counter (nullptr): the seed is used as passed.  Forward and backward of a step see the same
+// counter value, so regenerated masks still match.
+__device__ __forceinline__ uint64_t vlpet_eff_seed(uint64_t seed, const uint64_t* ctr) {
+    return ctr != nullptr ? seed + *ctr * 0x9E3779B97F4A7C15ull : seed;
+}
 // keep flags (bit j = element j of the 8-element group kept)
 __device__ __forceinline__ uint32_t keep8(int64_t group, uint64_t seed, uint32_t thr) {
     uint32_t o[4];
@@ -47,7 +55,15 @@ struct DropSpec {
     uint64_t seed;
     uint32_t thr;            // drop iff 16-bit uniform < thr
     float keep_scale;        // 1 / (1 - p)
+    const uint64_t* seed_ctr;   // optional device step counter mixed into `seed` (vlpet_eff_seed); kernels resolve it once: drop_resolved
 };
+// the spec with the step counter folded into the seed (one scalar load: call it in the kernel prologue, never inside a loop)
+__device__ __forceinline__ DropSpec drop_resolved(const DropSpec& s) {
+    DropSpec r = s;
+    if (s.thr != 0 && s.keep == nullptr && s.bits == nullptr) r.seed = vlpet_eff_seed(s.seed, s.seed_ctr);
+    r.seed_ctr = nullptr;
+    return r;
+}
 static inline bool drop_active(const DropSpec& s) { return s.keep != nullptr || s.bits != nullptr || s.thr != 0; }
 
 // Byte position, inside a row's d/8 mask bytes, of 8-element group G (elements 8G .. 8G+7).  Not the natural order: inside

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int d = a.d, pieces = d / E;
     const uint32_t thr = a.thr;
+    const uint64_t seed = thr ? vlpet_eff_seed(a.seed, a.seed_ctr) : 0;      // (one scalar load, before the row loop)
     const float scale = a.keep_scale;
     float gam[NORM ? NP : 1][E], bet[NORM ? NP : 1][E];
     if constexpr (NORM) {
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
                 uint32_t bits = 0xffu;
                 if (thr) {
                     const int64_t e0 = row * d + (int64_t)p * E;
-                    bits = keep8(e0 >> 3, a.seed, thr) >> (e0 & 7);       // fp32 piece = half a group
+                    bits = keep8(e0 >> 3, seed, thr) >> (e0 & 7);       // fp32 piece = half a group
                 }
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int d = a.d, pieces = d / E;
     const uint32_t thr = a.thr;
+    const uint64_t seed = thr ? vlpet_eff_seed(a.seed, a.seed_ctr) : 0;      // (one scalar load, before the row loop)
     const float scale = a.keep_scale;
     float gam[NORM ? NP : 1][E], dg[NORM ? NP : 1][E], db[NORM ? NP : 1][E];
     float bet[HOUT ? NP : 1][E], ginv[HOUT ? NP : 1][E];
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
                 P::store(dx1 + rb + p * 16, g[k]);
                 if (thr) {
                     const int64_t e0 = row * d + (int64_t)p * E;
-                    const uint32_t bits = keep8(e0 >> 3, a.seed, thr) >> (e0 & 7);
+                    const uint32_t bits = keep8(e0 >> 3, seed, thr) >> (e0 & 7);
                     float o[E];
 #pragma unroll
                     for (int j = 0; j < E; ++j) o[j] = ((bits >> j) & 1u) ? g[k][j] * scale : 0.f;

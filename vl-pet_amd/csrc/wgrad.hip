@@ -142,7 +142,7 @@ __global__ __launch_bounds__(VLPET_THREADS) void wgrad_kernel(WgradArgs a) {
     const IO* P = reinterpret_cast<const IO*>(a.job[jb].P);
     const IO* X = reinterpret_cast<const IO*>(a.job[jb].X);
     const bool has_drop = a.job[jb].has_drop != 0;
-    const DropSpec drop = a.job[jb].drop;
+    const DropSpec drop = drop_resolved(a.job[jb].drop);
     const int ldp = a.job[jb].ldp, ldx = a.job[jb].ldx, xc = a.job[jb].xcols;
     const int n0 = wg.slice * 64;
     if (n0 >= xc) return;

@@ -207,7 +207,7 @@ class PackCache:
         return self._val
 
 
-def repack_all() -> int:
+def repack_all(every_pair: bool = False) -> int:
     """Re-pack, in a few batched launches (vlpet_pack_pairs: 8 pairs each), every projection pair that was used since the
     previous call -- what a trainer does right after its optimizer step, instead of ~30 single 7.6-us pack launches spread over
     the next forward.  Pairs are re-packed INTO their existing buffers and their cache keys moved to the current weights
@@ -222,8 +222,8 @@ def repack_all() -> int:
         if src is None or val is None:
             continue
         down_w, down_b, up_w, up_b, io_dtype, tiles, used = src
-        if used < WEIGHTS_EPOCH - 1:                 # not used in the step that just ended: leave it to the lazy path
-            continue
+        if used < WEIGHTS_EPOCH - 1 and not every_pair:   # not used in the step that just ended: leave it to the lazy path
+            continue                                      # (every_pair: a trainer replaying captured steps runs no Python forward)
         ts = down_w + (down_b or []) + [up_w] + ([up_b] if up_b is not None else [])
         if not all(t.is_cuda and t.is_contiguous() for t in ts) or len({t.dtype for t in ts}) != 1:
             continue

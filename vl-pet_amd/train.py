@@ -242,6 +242,7 @@ class FlatGrads:
         self.dp = world_size > 1 or force_collectives      # force: run the bucket all-reduces on a 1-rank group (RCCL smoke test)
         self.group = process_group
         self.epoch = 0
+        self.defer = False          # True: gradients are exchanged by finish() only (no bucket launches from the backward: graph capture)
         self.sinks_enabled = bool(sinks)
         off = 0
         self.slices = []
@@ -319,7 +320,7 @@ class FlatGrads:
         if self._ready_epoch[i] == self.epoch:
             return
         self._ready_epoch[i] = self.epoch
-        if self.dp:
+        if self.dp and not self.defer:
             b = self.bucket_of[i]
             self._pending[b] += 1
             if self._pending[b] == self.bucket_count[b]:
@@ -431,6 +432,7 @@ class FusedAdamW:
             if not any(nd in name for nd in NO_DECAY):
                 mask[a:b] = 1
         self.decay = mask.to(dev)
+        self.repack_every_pair = False      # set by a trainer that replays captured steps (no Python forward marks the pairs as used)
         self.nb = self.lib.vlpet_optim_blocks(n)
         self.partials = torch.empty(self.nb, dtype=torch.float32, device=dev)
         self.norm = torch.zeros((), dtype=torch.float32, device=dev)
@@ -484,7 +486,7 @@ class FusedAdamW:
                 self.bc_dev.data_ptr(), self.variant, 1, self.norm.data_ptr(), st)
             _lib.check(rc, "vlpet_adamw_step_sliced")
             VF.bump_weights_epoch()
-            VF.repack_all()        # the adapters' fragment packs for the next step: a few batched launches
+            VF.repack_all(self.repack_every_pair)        # the adapters' fragment packs for the next step: a few batched launches
             return
         rc = self.lib.vlpet_adamw_step(f.flat_p.data_ptr(), f.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                        self.decay.data_ptr(), n, self.partials.data_ptr(), self.nb, float(self.max_norm),
@@ -492,7 +494,7 @@ class FusedAdamW:
                                        self.betas[1], self.eps, self.wd, self.t, self.variant, 1, self.norm.data_ptr(), st)
         _lib.check(rc, "vlpet_adamw_step")
         VF.bump_weights_epoch()
-        VF.repack_all()            # the adapters' fragment packs for the next step: a few batched launches
+        VF.repack_all(self.repack_every_pair)            # the adapters' fragment packs for the next step: a few batched launches
 
 
 # Set by the test / CPU-baseline harness: factory(flat: FlatGrads, lr, max_norm) -> object with .step(lr).
@@ -502,10 +504,25 @@ CPU_OPTIMIZER_FACTORY = None
 
 class Trainer:
     """One process per GPU.  ``step(batch)`` = forward, backward (with overlapped gradient exchange),
-    clip, AdamW, scheduler -- multitask.py:217-342."""
+    clip, AdamW, scheduler -- multitask.py:217-342.
+
+    ``graph=True`` (GPU only): forward + loss + backward of a step are captured ONCE per batch signature (task, shapes) with
+    hipGraph (``torch.cuda.graph``) and replayed from then on; gradient exchange, clip and AdamW stay eager (a handful of
+    launches).  What it buys: a step issues ~2,000 kernel launches from Python, about 16 ms of host time -- hidden behind 19 ms
+    of GPU work at the full single-GPU batch, but the whole story at the strong-scaled per-rank batch of an 8-GPU run
+    (1/8 of the rows: 6 ms of GPU work; profiles/r04_graph_probe.txt: 17.8 -> 6.4 ms per step).  What it needs, and how it is
+    met: (i) static input buffers (each batch is copied into the captured step's own tensors); (ii) dropout masks that change
+    from step to step although a replay repeats its kernel arguments -- a device step counter mixed into every seed
+    (``vlpet_set_seed_counter``; torch's own dropout kernels take their Philox offset from the graph-registered generator);
+    (iii) no collective inside the capture -- the gradient buckets are reduced by ``FlatGrads.finish`` after the replay
+    (``FlatGrads.defer``), at the price of the overlap with the backward (24 MB of fp32 gradients: ~0.2 ms on xGMI);
+    (iv) every weight-derived buffer refreshed without the Python forward: the PET fragment packs by ``repack_all(True)`` right
+    after the optimizer kernel (into their existing buffers), the epoch-keyed caches (K4 pack, IO-dtype copies of trainable
+    weights) by their own rebuild kernels, which are stale at capture time and therefore part of the graph.
+    Not captured: per-task adapters / LoRA (the active parameter set is host state) -- such trainers stay eager."""
 
     def __init__(self, model: nn.Module, config, lr=1e-3, clip=5.0, total_steps=1000, warmup_ratio=0.1,
-                 world_size=1, n_buckets=3, process_group=None, overlap_wgrad=False, force_collectives=False):
+                 world_size=1, n_buckets=3, process_group=None, overlap_wgrad=False, force_collectives=False, graph=False):
         self.model, self.config, self.clip, self.base_lr = model, config, clip, lr
         on_gpu = next(model.parameters()).is_cuda
         if on_gpu:
@@ -522,14 +539,125 @@ class Trainer:
         self.warmup, self.total = int(total_steps * warmup_ratio), total_steps
         self.step_idx = 0
         self.flat.begin_step(zero=True)
+        self.graph = False
+        self._graphs, self._graph_seen, self._graph_pool = {}, {}, None
+        self.seed_ctr = None
+        if graph:
+            self.enable_graph()
 
-    def step(self, batch) -> torch.Tensor:
+    # ---- captured steps
+    def enable_graph(self):
+        if not self.flat.flat.is_cuda:
+            raise RuntimeError("vl-pet_amd: Trainer(graph=True) needs the GPU product path")
+        if self.flat.per_task or overlap_stream_active():
+            return False                 # host-side state decides what a step does: stay eager
+        from . import _lib
+        if self.seed_ctr is None:
+            self.seed_ctr = torch.zeros(1, dtype=torch.int64, device=self.flat.flat.device)
+            _lib.check(_lib.load().vlpet_set_seed_counter(self.seed_ctr.data_ptr()), "vlpet_set_seed_counter")
+        self.optim.repack_every_pair = True
+        self.graph = True
+        return True
+
+    def disable_graph(self):
+        self.graph = False
+
+    @staticmethod
+    def _leaves(batch):
+        out = []
+        for k in sorted(batch):
+            v = batch[k]
+            if torch.is_tensor(v):
+                out.append((k, None, v))
+            elif isinstance(v, (tuple, list)):
+                out += [(k, i, t) for i, t in enumerate(v) if torch.is_tensor(t)]
+        return out
+
+    def _signature(self, batch):
+        return (batch["task"], bool(batch.get("no_padding", False)),
+                tuple((k, i, tuple(t.shape), t.dtype, tuple(t.stride())) for k, i, t in self._leaves(batch)))
+
+    def _fwd_bwd(self, batch) -> torch.Tensor:
         per_token, _ = self.model(batch["input_ids"], batch["vis_inputs"], batch["labels"], batch["task"],
                                   attention_mask=batch.get("attention_mask"), no_padding=bool(batch.get("no_padding", False)))
         loss = task_loss(per_token, batch["labels"], batch.get("scores"), batch["task"])
         loss.backward()
+        return loss
+
+    def _finish_step(self):
         self.flat.finish(average=False)
         self.optim.step(lr_at(self.step_idx, self.base_lr, self.warmup, self.total))   # clips, updates, zeroes the grads
         self.step_idx += 1
         self.flat.begin_step(zero=False)
+
+    def _capture(self, key, batch):
+        from . import functional as VF
+        static = {}
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                static[k] = v.clone()
+            elif isinstance(v, (tuple, list)):
+                static[k] = type(v)(t.clone() if torch.is_tensor(t) else t for t in v)
+            else:
+                static[k] = v
+        timer, VF.TIMER = VF.TIMER, None            # (event brackets are host-timed launches: not inside a capture)
+        self.flat.defer = True
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        try:
+            # thread_local: a collective library's watchdog thread may query events while this thread captures
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
+                loss = self._fwd_bwd(static)
+        except Exception as e:      # a model whose step cannot be captured (host sync, data-dependent shape): stay eager, loudly
+            import warnings
+            warnings.warn(f"vl-pet_amd: capturing the train step failed ({type(e).__name__}: {e}); this trainer continues with eager launches")
+            self.graph = False
+            self.optim.repack_every_pair = False
+            torch.cuda.synchronize()
+            self.flat.flat.zero_()
+            return None
+        finally:
+            self.flat.defer = False
+            VF.TIMER = timer
+            self.flat.begin_step(zero=False)        # (the capture ran the sinks' host-side bookkeeping, not their kernels)
+        self._graph_pool = g.pool()
+        ent = (g, static, loss)
+        self._graphs[key] = ent
+        return ent
+
+    def _graph_step(self, batch) -> torch.Tensor:
+        key = self._signature(batch)
+        ent = self._graphs.get(key)
+        self.seed_ctr += 1
+        if ent is None:
+            seen = self._graph_seen.get(key, 0)
+            self._graph_seen[key] = seen + 1
+            if seen < 1:       # the first step of a shape runs eagerly: lazy initialisation, GEMM solution lookups, the label check
+                loss = self._fwd_bwd(batch)
+                self._finish_step()
+                return loss.detach()
+            ent = self._capture(key, batch)
+            if ent is None:
+                loss = self._fwd_bwd(batch)
+                self._finish_step()
+                return loss.detach()
+        g, static, loss = ent
+        for (k, i, src), (_, _, dst) in zip(self._leaves(batch), self._leaves(static)):
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        g.replay()
+        self._finish_step()
+        return loss.detach().clone()
+
+    def step(self, batch) -> torch.Tensor:
+        if self.graph:
+            return self._graph_step(batch)
+        loss = self._fwd_bwd(batch)
+        self._finish_step()
         return loss.detach()
+
+
+def overlap_stream_active() -> bool:
+    """Weight gradients on a side stream (Trainer(overlap_wgrad=True)) are not captured."""
+    from . import functional as VF
+    return VF.WGRAD_STREAM is not None
