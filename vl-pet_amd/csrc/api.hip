@@ -8,7 +8,7 @@
 #include <stdio.h>
 #include <vector>
 
-#define VLPET_VERSION 400      // 400: two-pass K1 forward (pet_fwd2p.hip), vlpet_sublayer_tail_bwd_out;
+#define VLPET_VERSION 410      // 410: vlpet_set_seed_counter (dropout seeds under graph replay), two-pass K2 / K3 forward; 400: two-pass K1 forward (pet_fwd2p.hip), vlpet_sublayer_tail_bwd_out;
 #define VLPET_VERSION_R3 300      // 300: column-parallel K1 backward pass (pet_cols.hip), phases bits 3 / 4, vlpet_adapter_gate_bwd_form;
 #define VLPET_VERSION_R2 221      // 221: vlpet_sublayer_tail_reduce, vlpet_layernorm_bwd_xhat, vlpet_rmsnorm_{fwd,bwd}, vlpet_colsum;  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
 

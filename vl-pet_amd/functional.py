@@ -542,6 +542,10 @@ class _AdapterGateFn(torch.autograd.Function):
                 rc = _timed("k1_bwd_wgrad", M, lambda: phase(2 | 4, args))
         elif TIMER is None or not TIMER.wants("k1_bwd_rows"):
             rc = phase(3, args)
+        elif not gate:
+            # adapter-only K1 (small / middle gate scripts): its two-pass form is taken for the WHOLE op only (csrc/api.hip ng2), so the
+            # bracketed path issues it as one call too -- split phases would time the round-2 row kernel instead of what ships
+            rc = TIMER.bracket("k1_bwd_rows", M, lambda: phase(3, args))
         else:       # same work, its kernels bracketed separately
             rc = TIMER.bracket("k1_bwd_rows", M, lambda: phase(1, args))
             two_pass = act is not None and lib.vlpet_adapter_gate_bwd_form(M, d, pk_a.tiles, io) == 2

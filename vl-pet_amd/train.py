@@ -607,7 +607,8 @@ class Trainer:
         try:
             # thread_local: a collective library's watchdog thread may query events while this thread captures
             with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
-                loss = self._fwd_bwd(static)
+                loss = self._fwd_bwd(static).detach()     # (detached: keeping the graph's root would keep its AccumulateGrad nodes, and
+                                                          #  their capture stream, alive into later eager steps)
         except Exception as e:      # a model whose step cannot be captured (host sync, data-dependent shape): stay eager, loudly
             import warnings
             warnings.warn(f"vl-pet_amd: capturing the train step failed ({type(e).__name__}: {e}); this trainer continues with eager launches")
