@@ -37,8 +37,10 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # launch, so for the other task shapes they are an extrapolation (labelled as such in the line).
 # Two tables: the two-pass form (round 3: pass 1 + column-parallel pass + finalize) and the previous split (--k1-previous-split).
 PMC_TRAFFIC_FORMS = {
-    "two_pass": {"source": "profiles/r03_pmc_traffic_k1_bwd.md", "measured_at_rows": 28000,
-                 "bytes_per_row": {"k1_bwd_rows": 4217.0, "k1_bwd_wgrad": 10083.0, "k1_bwd_op": 16000.0}},
+    "two_pass": {"source": "profiles/r04_pmc_traffic.md", "measured_at_rows": 28000,       # (118.1 / 289.0 / 457.1 MB per launch)
+                 "bytes_per_row": {"k1_bwd_rows": 4218.0, "k1_bwd_wgrad": 10321.0, "k1_bwd_op": 16325.0}},
+    "two_pass_t5": {"source": "profiles/r04_pmc_traffic.md", "measured_at_rows": 18250,    # r = 192: 100.7 / 255.9 / 407.7 MB per launch
+                    "bytes_per_row": {"k1_bwd_rows": 5518.0, "k1_bwd_wgrad": 14022.0, "k1_bwd_op": 22340.0}},
     "previous_split": {"source": "profiles/r02_pmc_traffic_k1_bwd.md", "measured_at_rows": 28000,
                        "bytes_per_row": {"k1_bwd_rows": 11881.0, "k1_bwd_op": 20432.0}},
 }
@@ -501,8 +503,9 @@ def main():
                             "ng_dz_kernel + ng_cols_kernel + wgrad_finalize_kernel") + " (one K3 backward, two-pass form of csrc/pet_cols_ng.hip)",
                  "k3_fwd": f"pet_fwd_kernel<{args.dtype},act_id{',drop' if lora_drop else ''}>"}[dom]
         traffic = None
-        PMC_TRAFFIC = PMC_TRAFFIC_FORMS["two_pass" if (args.model != "lora" and two_pass) else "previous_split"]
-        if dom in PMC_TRAFFIC["bytes_per_row"] and args.dtype == "bf16" and args.model == "bart":
+        PMC_TRAFFIC = PMC_TRAFFIC_FORMS[("two_pass_t5" if args.model == "t5" else "two_pass") if (args.model != "lora" and two_pass)
+                                        else "previous_split"]
+        if dom in PMC_TRAFFIC["bytes_per_row"] and args.dtype == "bf16" and args.model in ("bart", "t5", "video"):
             traffic = round(PMC_TRAFFIC["bytes_per_row"][dom] * a["rows"] / a["launches"])
         # Headline fraction = the whole K1 backward OP (SURVEY 8d's 5*d*b per row is the op's byte count; the op is three launches):
         # algorithmic bytes / (pass 1 + column-parallel pass + finalize).  The dominant kernel's own figures stay beside it.
