@@ -398,6 +398,18 @@ int vlpet_attn_fwd_ld(const void* q, const void* k, const void* v, const uint8_t
 int vlpet_attn_bwd_ld(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                       const uint8_t* key_mask, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int ld_q, int ld_kv,
                       int causal, float scale, float p, uint64_t seed, vlpet_stream_t stream);
+/* The same with an additive score bias shared by the batch: softmax(scale * q k^T + bias[h] + mask) -- T5's relative position bias
+ * (my_transformers/modeling_t5.py:520-560 compute_bias, added at :640-660; T5 runs with scale = 1).  bias: [H, Lqp, Lkp] fp32,
+ * Lqp / Lkp = Lq / Lk rounded up to a multiple of 32, zero padded, 16-byte aligned; the backward also takes its transpose
+ * bias_t [H, Lkp, Lqp] (its key-major phase reads the bias along queries).  The bias gets no gradient (a frozen embedding in every
+ * script).  NULL bias = the plain entry points above. */
+int vlpet_attn_fwd_bias(const void* q, const void* k, const void* v, const uint8_t* key_mask, const float* bias, void* o,
+                        float* lse, uint8_t* keep_out, int B, int H, int Lq, int Lk, int ld_q, int ld_kv, int causal,
+                        float scale, float p, uint64_t seed, vlpet_stream_t stream);
+int vlpet_attn_bwd_bias(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                        const uint8_t* key_mask, const float* bias, const float* bias_t, void* dq, void* dk, void* dv,
+                        int B, int H, int Lq, int Lk, int ld_q, int ld_kv, int causal, float scale, float p, uint64_t seed,
+                        vlpet_stream_t stream);
 
 /* ---- Downsample (the step before K4) -------------------------------------------------------
  * AdaptiveMaxPool2d(s_in x s_in -> s_out x s_out) over the token grid of x [n_images, s_in*s_in, dim]

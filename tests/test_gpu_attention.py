@@ -1,6 +1,8 @@
 """Short-sequence attention (csrc/attn.hip, vlpet_amd.attention) against the eager chain of BartAttention.forward
 (my_transformers/modeling_bart.py:283-566: scores, mask, softmax, dropout, weighted sum) in fp32 on the same bf16 inputs,
 with the dropout mask the kernel applied exported so that forward and backward compare element for element."""
+import contextlib
+
 import pytest
 import torch
 
@@ -11,11 +13,13 @@ pytestmark = pytest.mark.gpu
 H = 12
 
 
-def _eager(q, k, v, key_mask, causal, keep, p):
+def _eager(q, k, v, key_mask, causal, keep, p, bias=None, scale=64 ** -0.5):
     B, Lq, _ = q.shape
     Lk = k.shape[1]
     sh = lambda t, L: t.view(B, L, H, 64).transpose(1, 2)
-    s = (sh(q, Lq) @ sh(k, Lk).transpose(-1, -2)) * 64 ** -0.5
+    s = (sh(q, Lq) @ sh(k, Lk).transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias[None]
     if key_mask is not None:
         s = s.masked_fill(~key_mask[:, None, None, :].bool(), float("-inf"))
     if causal:
@@ -74,6 +78,100 @@ def test_short_attention_matches_the_eager_chain(B, Lq, Lk, causal, masked, p):
     assert close(qg.grad, qr.grad)
     assert close(kg.grad, kr.grad)
     assert close(vg.grad, vr.grad)
+
+
+BIAS_CASES = [  # B, Lq, Lk, causal, masked, p      (T5: scale 1, a [H, Lq, Lk] bias shared by the batch -- my_transformers/modeling_t5.py:520-560, 640-660)
+    (3, 56, 56, False, True, 0.1),          # encoder self-attention of the image-text tasks (20 text + 36 visual tokens)
+    (2, 92, 92, False, True, 0.1),          # nlvr
+    (2, 76, 76, False, False, 0.0),
+    (4, 5, 5, True, False, 0.1),            # decoder self-attention: relative bias + causal
+    (3, 20, 20, True, False, 0.0),
+    (2, 33, 97, False, True, 0.1),          # ragged against the 32-wide padding of the bias
+    (2, 128, 128, False, False, 0.0),
+]
+
+
+@pytest.mark.parametrize("B,Lq,Lk,causal,masked,p", BIAS_CASES)
+def test_short_attention_with_a_shared_bias_matches_the_eager_chain(B, Lq, Lk, causal, masked, p):
+    from vlpet_amd.attention import AttnBias, short_attention
+    g = torch.Generator().manual_seed(Lq * 17 + Lk)
+    mk = lambda L: (torch.randn(B, L, H * 64, generator=g) * 0.35).bfloat16()      # scale 1: keep the scores of 64-wide heads in softmax range
+    q, k, v, do = mk(Lq), mk(Lk), mk(Lk), mk(Lq)
+    bias = torch.randn(H, Lq, Lk, generator=g) * 2.0
+    key_mask = None
+    if masked:
+        key_mask = torch.rand(B, Lk, generator=g) > 0.25
+        key_mask[:, -1] = True
+    qg, kg, vg = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out = short_attention(qg, kg, vg, H, None if key_mask is None else key_mask.cuda(), causal, p, True, scale=1.0, seed=7,
+                          return_mask=p > 0, bias=AttnBias(bias.cuda()[None]))
+    keep = None
+    if p > 0:
+        out, keep = out
+        keep = keep.cpu()
+    out.backward(do.cuda())
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref = _eager(qr, kr, vr, key_mask, causal, keep, p, bias=bias, scale=1.0)
+    ref.backward(do.float())
+    tol = 2e-2
+    def close(a, r):
+        return float((a.float().cpu() - r).abs().max()) <= tol * max(float(r.abs().max()), 1e-2)
+    assert rel_err(out, ref) <= tol
+    assert close(qg.grad, qr.grad) and close(kg.grad, kr.grad) and close(vg.grad, vr.grad)
+    # and the bias really took part: without it the output differs
+    out0 = short_attention(qg.detach(), kg.detach(), vg.detach(), H, None if key_mask is None else key_mask.cuda(), causal, 0.0, False, scale=1.0)
+    ref0 = _eager(q.float(), k.float(), v.float(), key_mask, causal, None, 0.0, bias=bias, scale=1.0)
+    assert rel_err(out0, ref0) > 5e-2
+
+
+def test_t5_host_attention_fast_path_equals_the_dense_sdpa_path():
+    """host/t5.py: a VLT5 with 64-wide heads in bf16 runs its three attentions (encoder self with the text-block relative bias +
+    padding, decoder self with relative bias + causal, cross with padding) on the on-chip kernels; EAGER_ATTENTION = True sends the
+    same model through torch's SDPA with the merged dense mask the reference builds.  Same loss, same gradients."""
+    import copy
+    import vlpet_amd.host.t5 as HT
+    import vlpet_amd.train as TR
+    cfg = HT.vlt5_config(d_model=128, d_kv=64, num_heads=2, d_ff=256, num_layers=2, num_decoder_layers=2, vocab_size=600,
+                         feat_dim=128, adapter_down_dim=8, adapter_gating_down_dim=16, encoder_adapter_multihead_num_head=4,
+                         decoder_enc_attn_value_parallel_adapter_down_dim=8, dropout_rate=0.0)
+    torch.manual_seed(3)
+    model = HT.VLT5(cfg)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(torch.randn_like(p) * 0.02)
+    TR.trainable_names(model, cfg)
+    model.cuda()
+    TR.cast_frozen(model, torch.bfloat16)
+    model.train()
+    gen = torch.Generator().manual_seed(4)
+    b = TR.synthetic_batch("vqa", 6, cfg, "cpu", gen)
+    ids = b["input_ids"].clone()
+    ids[2, 15:] = cfg.pad_token_id                    # padded rows: the key mask matters
+    ids[4, 9:] = cfg.pad_token_id
+    vis = tuple(t.cuda() for t in b["vis_inputs"])
+    res = {}
+    for mode in ("math", "sdpa", "fast"):       # torch's math SDPA (the yardstick), its default fused SDPA, the on-chip kernels
+        HT.EAGER_ATTENTION = mode != "fast"
+        try:
+            for p in model.parameters():
+                p.grad = None
+            ctx = torch.nn.attention.sdpa_kernel(torch.nn.attention.SDPBackend.MATH) if mode == "math" else contextlib.nullcontext()
+            with ctx:
+                per_token, _ = model(ids.cuda(), vis, b["labels"].cuda(), "vqa")
+                loss = TR.task_loss(per_token, b["labels"].cuda(), b["scores"].cuda(), "vqa")
+                loss.backward()
+            res[mode] = (float(loss.detach()), torch.cat([p.grad.detach().float().reshape(-1) for _, p in sorted(model.named_parameters())
+                                                          if p.grad is not None]))
+        finally:
+            HT.EAGER_ATTENTION = False
+    (lm, gm), (ls, gs), (lf, gf) = res["math"], res["sdpa"], res["fast"]
+    assert gm.numel() == gf.numel() > 1000
+    assert abs(lm - lf) <= 2e-3 * abs(lm), (lm, ls, lf)
+    # bf16 through a 2 + 2-layer stack: two library implementations already differ by a few percent on the (small) PET gradients; the
+    # on-chip kernels must sit as close to the math path as the library's fused kernels do
+    err = lambda a, r: float((a - r).norm() / r.norm())
+    e_fast, e_sdpa = err(gf, gm), err(gs, gm)
+    assert e_fast <= max(1.5 * e_sdpa, 2e-2), (e_fast, e_sdpa)
 
 
 def test_short_attention_mask_depends_on_seed_only_and_eval_has_no_dropout():

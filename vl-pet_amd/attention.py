@@ -5,7 +5,9 @@ workgroup per (batch, head).
 Reference op chain replaced: BartAttention.forward (my_transformers/modeling_bart.py:283-566): bmm, mask add, softmax,
 F.dropout(p=attention_dropout), bmm, head transposes.  Tensors stay in the ``[B, L, H * 64]`` layout the projections
 produce (no head transpose / re-pack in either direction).  ``supported`` tells the caller whether a call fits; anything
-else (fp32 parity runs, long video sequences, additive biases) stays on the library path.  No CPU fallback."""
+else (fp32 parity runs, long video sequences, per-sample additive biases) stays on the library path.  A bias shared by the
+batch -- T5's relative position bias (my_transformers/modeling_t5.py:520-560, 640-660) -- is taken as ``AttnBias`` (round 4).
+No CPU fallback."""
 from __future__ import annotations
 
 from typing import Optional
@@ -20,6 +22,25 @@ MAX_LEN = 128
 HEAD_DIM = 64
 
 
+class AttnBias:
+    """An additive score bias ``[1 or none, H, Lq, Lk]`` shared by every sample, in the layout the kernels read: fp32, both
+    sequence axes zero-padded to multiples of 32, plus its transpose for the key-major phase of the backward.  Built once per
+    forward (it is the same for every layer of a T5 stack) and passed to ``short_attention(..., bias=...)``.  No gradient."""
+
+    def __init__(self, bias: torch.Tensor):
+        b = bias.detach()
+        if b.dim() == 4:
+            if b.shape[0] != 1:
+                raise RuntimeError("vl-pet_amd: AttnBias is shared by the batch ([1, H, Lq, Lk] or [H, Lq, Lk])")
+            b = b[0]
+        H, Lq, Lk = b.shape
+        Lqp, Lkp = (Lq + 31) // 32 * 32, (Lk + 31) // 32 * 32
+        self.H, self.Lq, self.Lk = H, Lq, Lk
+        self.b = torch.zeros(H, Lqp, Lkp, dtype=torch.float32, device=b.device)
+        self.b[:, :Lq, :Lk] = b.float()
+        self.bt = self.b.transpose(1, 2).contiguous()
+
+
 def supported(q: torch.Tensor, k: torch.Tensor, num_heads: int) -> bool:
     return (q.is_cuda and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and q.shape[-1] == num_heads * HEAD_DIM
             and q.shape[1] <= MAX_LEN and k.shape[1] <= MAX_LEN)
@@ -27,21 +48,25 @@ def supported(q: torch.Tensor, k: torch.Tensor, num_heads: int) -> bool:
 
 class _AttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, key_mask, H, causal, scale, p, seed, want_mask):
+    def forward(ctx, q, k, v, key_mask, H, causal, scale, p, seed, want_mask, bias=None):
         lib = _lib.load()
         _need_cuda(q, k, v)
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         B, Lq, _ = q.shape
         Lk = k.shape[1]
+        if bias is not None and (bias.H, bias.Lq, bias.Lk) != (H, Lq, Lk):
+            raise RuntimeError(f"vl-pet_amd: attention bias [{bias.H}, {bias.Lq}, {bias.Lk}] does not match [{H}, {Lq}, {Lk}]")
         o = torch.empty_like(q)
         lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
         # (the kernel writes the mask only when it drops something: without dropout every element is kept)
         keep = torch.ones(B, H, Lq, Lk, dtype=torch.uint8, device=q.device) if want_mask else None
-        rc = _timed("attn_fwd", B * Lq, lambda: lib.vlpet_attn_fwd(
-            q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(key_mask), o.data_ptr(), lse.data_ptr(), _ptr(keep),
-            B, H, Lq, Lk, int(causal), float(scale), float(p), seed, _stream()))
+        rc = _timed("attn_fwd", B * Lq, lambda: lib.vlpet_attn_fwd_bias(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(key_mask), bias.b.data_ptr() if bias is not None else None,
+            o.data_ptr(), lse.data_ptr(), _ptr(keep), B, H, Lq, Lk, H * HEAD_DIM, H * HEAD_DIM, int(causal), float(scale), float(p), seed,
+            _stream()))
         _lib.check(rc, "vlpet_attn_fwd")
         ctx.save_for_backward(q, k, v, o, lse, key_mask)
+        ctx.bias = bias
         ctx.cfg = (H, int(causal), float(scale), float(p), seed)
         if want_mask:
             ctx.mark_non_differentiable(keep)
@@ -59,11 +84,14 @@ class _AttnFn(torch.autograd.Function):
         if do.dtype != q.dtype:
             do = do.to(q.dtype)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        rc = _timed("attn_bwd", B * Lq, lambda: lib.vlpet_attn_bwd(
+        bias = ctx.bias
+        rc = _timed("attn_bwd", B * Lq, lambda: lib.vlpet_attn_bwd_bias(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), _ptr(key_mask),
-            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Lq, Lk, causal, scale, p, seed, _stream()))
+            bias.b.data_ptr() if bias is not None else None, bias.bt.data_ptr() if bias is not None else None,
+            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Lq, Lk, H * HEAD_DIM, H * HEAD_DIM, causal, scale, p, seed, _stream()))
         _lib.check(rc, "vlpet_attn_bwd")
-        return dq, dk, dv, None, None, None, None, None, None, None
+        ctx.bias = None
+        return dq, dk, dv, None, None, None, None, None, None, None, None
 
 
 class _AttnQkvFn(torch.autograd.Function):
@@ -128,8 +156,9 @@ def short_self_attention(qkv: torch.Tensor, num_heads: int, key_mask: Optional[t
 
 def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, key_mask: Optional[torch.Tensor] = None,
                     causal: bool = False, p: float = 0.0, training: bool = False, scale: Optional[float] = None, seed=None,
-                    return_mask: bool = False):
-    """q [B, Lq, H*64], k / v [B, Lk, H*64] (bf16) -> [B, Lq, H*64].  key_mask: [B, Lk] bool / uint8, True = attend."""
+                    return_mask: bool = False, bias: Optional[AttnBias] = None):
+    """q [B, Lq, H*64], k / v [B, Lk, H*64] (bf16) -> [B, Lq, H*64].  key_mask: [B, Lk] bool / uint8, True = attend.
+    bias: an ``AttnBias`` ([H, Lq, Lk] added to the scaled scores of every sample; no gradient)."""
     if not supported(q, k, num_heads):
         raise RuntimeError("vl-pet_amd: short_attention needs bf16 CUDA tensors, head dim 64 and at most 128 keys / queries")
     if key_mask is not None:
@@ -138,4 +167,4 @@ def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads
     if seed is None:
         seed = _draw_seed() if pe > 0.0 else 0
     return _AttnFn.apply(q, k, v, key_mask, num_heads, bool(causal), HEAD_DIM ** -0.5 if scale is None else float(scale),
-                         pe, int(seed), bool(return_mask))
+                         pe, int(seed), bool(return_mask), bias)

@@ -151,7 +151,8 @@ __device__ __forceinline__ bool key_ok(const AttnArgs& a, const uint8_t* km, int
 // compute unit interleaves ~10 independent waves (the first version gave a pair to a 4-wave workgroup: half the waves had
 // no query block at S = 56, 354 registers kept it at one workgroup per CU, and every workgroup paid load -> barrier -> load
 // latencies in sequence: 208 us per call against 104 for the library kernel).
-template <int T>
+// BIAS: a.bias != nullptr -- scores = scale * q k^T + bias[h][i][j] (T5)
+template <int T, bool BIAS>
 __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,6 +199,15 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
+            if constexpr (BIAS) {      // the lane's 16 keys of the tile are four runs of four: 16-byte loads from the padded bias row of query i
+                const float* brow = a.bias + ((int64_t)h * (32 * NQB) + i) * Lkp + 32 * t + 4 * hh;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 8 * q4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) st[t][4 * q4 + e] += bv[e] * (1.0f / a.scale);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
 // S = 56 (two tiles, two blocks) each of the four waves has exactly one and nothing is computed twice.
 // NW = waves per workgroup: 4, or 6 for sequences of 65-96 tokens (three key tiles + three query blocks = six units: one round
 // instead of a full one and a half-empty one; two 6-wave workgroups per CU = three waves per SIMD, the OCC = 3 register budget)
-template <int OCC, int NW = AT_NW>
+template <int OCC, int NW = AT_NW, bool BIAS = false>
 __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
@@ -330,6 +340,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
                     s = mfma32(nat_frag(Qs, 32 * qb + m, ks, hh), nat_frag(Ks, keyr, ks, hh), s);        // D[query][key]
                     dp = mfma32(nat_frag(Ds, 32 * qb + m, ks, hh), nat_frag(Vs, keyr, ks, hh), dp);
                 }
+                if constexpr (BIAS) {      // bias[h][i][key] for the lane's key and its 16 queries: four runs of four along the transposed copy
+                    const float* brow = a.bias_t + ((int64_t)h * Lkp + key) * Lqp + 32 * qb + 4 * hh;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 8 * q4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[4 * q4 + e] += bv[e] * (1.0f / a.scale);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = 32 * qb + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -376,6 +395,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
                     s = mfma32(nat_frag(Ks, 32 * t + m, ks, hh), qf[ks], s);             // D[key][query]
                     dp = mfma32(nat_frag(Vs, 32 * t + m, ks, hh), df[ks], dp);
                 }
+                if constexpr (BIAS) {
+                    const float* brow = a.bias + ((int64_t)h * Lqp + i) * Lkp + 32 * t + 4 * hh;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 8 * q4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[4 * q4 + e] += bv[e] * (1.0f / a.scale);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -402,15 +430,20 @@ size_t attn_lds_bytes(int Lq, int Lk, int bwd) {
     return bwd ? AttnLds::bwd_bytes(Lqp, Lkp) : AttnLds::fwd_bytes(Lkp);
 }
 
-template <int T>
-static hipError_t launch_attn_fwd_t(const AttnArgs& a, hipStream_t stream) {
+template <int T, bool BIAS>
+static hipError_t launch_attn_fwd_tb(const AttnArgs& a, hipStream_t stream) {
     const size_t lds = AttnLds::fwd_bytes(32 * T);
-    auto kern = attn_fwd_kernel<T>;
+    auto kern = attn_fwd_kernel<T, BIAS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const unsigned pairs = (unsigned)(a.B * a.H);
     hipLaunchKernelGGL(kern, dim3((pairs + AT_FW - 1) / AT_FW), dim3(AT_FW * 64), lds, stream, a);
     return hipGetLastError();
+}
+
+template <int T>
+static hipError_t launch_attn_fwd_t(const AttnArgs& a, hipStream_t stream) {
+    return a.bias != nullptr ? launch_attn_fwd_tb<T, true>(a, stream) : launch_attn_fwd_tb<T, false>(a, stream);
 }
 
 hipError_t launch_attn(const AttnArgs& a, bool bwd, hipStream_t stream) {
@@ -440,6 +473,13 @@ hipError_t launch_attn(const AttnArgs& a, bool bwd, hipStream_t stream) {
         return hipGetLastError();
     }
     const size_t lds = attn_lds_bytes(a.Lq, a.Lk, 1);
+    if (a.bias != nullptr) {       // T5's biased scores: the two-waves-per-SIMD register budget (16 more live values per tile)
+        auto kb = attn_bwd_kernel<2, AT_NW, true>;
+        hipError_t eb = hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (eb != hipSuccess) return eb;
+        hipLaunchKernelGGL(kb, dim3((unsigned)(a.B * a.H)), dim3(AT_NW * 64), lds, stream, a);
+        return hipGetLastError();
+    }
     // Three waves per SIMD (168 registers, one spilled) whenever three workgroups fit the CU's LDS -- sequences of at most 64
     // tokens: the memory phase of a pair then overlaps the compute phase of two others (142 -> 114 us at B = 500, S = 56);
     // longer sequences (two workgroups per CU by LDS either way) keep the 171-register build.  VLPET_ATTN_OCC = 2 | 3 forces one.

@@ -343,6 +343,9 @@ struct AttnArgs {
     const __bf16* dout;     // backward
     __bf16* dq; __bf16* dk; __bf16* dv;
     const uint8_t* key_mask;   // [B, Lk] 1 = attend, or nullptr
+    const float* bias;      // optional additive score bias shared by the batch (T5's relative position bias, my_transformers/modeling_t5.py
+                            //   :520-560): [H, Lqp, Lkp] fp32, Lqp / Lkp = Lq / Lk rounded up to 32, zero padded; nullptr = none
+    const float* bias_t;    // the same bias transposed, [H, Lkp, Lqp] (the key-major phase of the backward reads it along queries)
     uint8_t* keep_out;      // forward only: optional [B, H, Lq, Lk] export of the dropout mask (tests)
     int B, H, Lq, Lk, causal;
     int ld_q, ld_kv;        // row stride (elements) of q / dq and of k, v / dk, dv: H*64 for separate projection outputs, 3*H*64

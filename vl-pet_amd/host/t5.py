@@ -142,6 +142,48 @@ def relative_position_bucket(relative_position, bidirectional, num_buckets=32, m
     return buckets + torch.where(small, relative_position, large)
 
 
+EAGER_ATTENTION = False   # A/B switch (tools/ab_switches.py): True = torch SDPA with a dense additive mask for every T5 attention
+
+
+class AttnSpec:
+    """What a T5 attention adds to its scores, kept in parts: the relative-position bias shared by the batch ``rel``
+    [1, H, Lq, Lk] (or None), the key padding ``keep`` [B, Lk] (1 = attend, or None) and causality.  ``dense()`` is the merged
+    additive mask the reference builds (my_transformers/modeling_t5.py:640-660; src/modeling_t5.py:311-327 for the joint
+    encoder) and torch's SDPA takes; ``fast()`` the form of vlpet_amd.attention's on-chip kernels -- an ``AttnBias`` built once per
+    forward for all layers + the boolean key mask + the causal flag -- which removes the [B, H, L, L] mask tensor and the library's
+    long-sequence flash kernels from the step (round 4: 220 -> ~70 us per encoder attention backward at B = 300, S = 56)."""
+
+    def __init__(self, rel, keep, causal, rel_trainable=False):
+        self.rel, self.keep, self.causal, self.rel_trainable = rel, keep, bool(causal), bool(rel_trainable)
+        self._dense, self._fast = {}, None
+
+    def dense(self, dtype):
+        if dtype not in self._dense:
+            m = None
+            if self.rel is not None:
+                m = self.rel
+            if self.causal:
+                L = self.rel.shape[-1]
+                tri = torch.tril(torch.ones(L, L, device=self.rel.device))
+                m = m + (1.0 - tri)[None, None] * -10000.0
+            if self.keep is not None:
+                pad = (1.0 - self.keep[:, None, None, :].to(torch.float32)) * (-10000.0 if self.rel is not None else -1e9)
+                m = pad if m is None else m + pad
+            self._dense[dtype] = None if m is None else m.to(dtype)
+        return self._dense[dtype]
+
+    def fast(self):
+        """(AttnBias or None, key_mask uint8 or None) for the short-sequence kernels, or None when they do not apply."""
+        if self.rel_trainable:
+            return None
+        if self._fast is None:
+            from .. import attention as A
+            bias = A.AttnBias(self.rel) if self.rel is not None else None
+            km = None if self.keep is None else (self.keep > 0.5).to(torch.uint8).contiguous()
+            self._fast = (bias, km)
+        return self._fast
+
+
 class T5Attention(nn.Module):
     """softmax(Q K^T + bias) V without the 1/sqrt(d) scale (folded into T5's initialisation); optional
     value-parallel adapter on the cross-attention value (``project_vpa``, :588-613)."""
@@ -203,7 +245,14 @@ class T5Attention(nn.Module):
             q, k, v = _linear(self.q, hidden), _linear(self.k, src), _linear(self.v, src)
             if kv is not None and self.attn_value_parallel_adapter is not None:
                 v = self.attn_value_parallel_adapter(src, task, y=v)                      # K2
-        mask = None if bias is None else bias.to(q.dtype)
+        from .. import attention as A
+        spec = bias if isinstance(bias, AttnSpec) else None
+        if spec is not None and not EAGER_ATTENTION and self.d_kv == A.HEAD_DIM and A.supported(q, k, self.n_heads):
+            fast = spec.fast()
+            if fast is not None:        # on-chip kernels: bias shared by the batch + boolean key mask + causal flag; T5 has no 1/sqrt(d)
+                out = A.short_attention(q, k, v, self.n_heads, fast[1], spec.causal, self.dropout, self.training, scale=1.0, bias=fast[0])
+                return _linear(self.o, out)
+        mask = spec.dense(q.dtype) if spec is not None else (None if bias is None else bias.to(q.dtype))
         out = F.scaled_dot_product_attention(self._shape(q, B), self._shape(k, B), self._shape(v, B), attn_mask=mask,
                                              dropout_p=self.dropout if self.training else 0.0, scale=1.0)
         return _linear(self.o, out.transpose(1, 2).reshape(B, Lq, self.inner))
@@ -323,10 +372,11 @@ class JointEncoder(nn.Module):
             attention_mask = input_ids.ne(self.config.pad_token_id)
         full = torch.cat([attention_mask.to(torch.float32), torch.ones(B, V, device=x.device)], dim=1)
         # relative position bias only between text positions (src/modeling_t5.py:311-327)
-        text_bias = self.block[0].layer[0].SelfAttention.compute_bias(L, L)
-        bias = text_bias.new_zeros(1, text_bias.shape[1], L + V, L + V)
-        bias[:, :, :L, :L] = text_bias
-        bias = bias + _pad_bias(full, bias.dtype)
+        sa0 = self.block[0].layer[0].SelfAttention
+        text_bias = sa0.compute_bias(L, L)
+        rel = text_bias.new_zeros(1, text_bias.shape[1], L + V, L + V)
+        rel[:, :, :L, :L] = text_bias
+        bias = AttnSpec(rel, full, causal=False, rel_trainable=sa0.relative_attention_bias.weight.requires_grad and torch.is_grad_enabled())
         x = F.dropout(x, p=self.p, training=self.training)
         for blk in self.block:
             x = blk(x, bias, task=task)
@@ -346,9 +396,10 @@ class T5Decoder(nn.Module):
     def forward(self, input_ids, enc, enc_keep, task=None):
         B, L = input_ids.shape
         x = F.dropout(self.embed_tokens(input_ids), p=self.p, training=self.training)
-        causal = torch.tril(torch.ones(L, L, device=x.device))
-        self_bias = self.block[0].layer[0].SelfAttention.compute_bias(L, L) + (1.0 - causal)[None, None] * -10000.0
-        cross_bias = (1.0 - enc_keep[:, None, None, :].to(torch.float32)) * -1e9      # invert_attention_mask (fp32 form)
+        sa0 = self.block[0].layer[0].SelfAttention
+        self_bias = AttnSpec(sa0.compute_bias(L, L), None, causal=True,
+                             rel_trainable=sa0.relative_attention_bias.weight.requires_grad and torch.is_grad_enabled())
+        cross_bias = AttnSpec(None, enc_keep, causal=False)      # (dense form: invert_attention_mask, (1 - keep) * -1e9 in fp32)
         for blk in self.block:
             x = blk(x, self_bias, enc, cross_bias, task)
         return F.dropout(self.final_layer_norm(x), p=self.p, training=self.training)
