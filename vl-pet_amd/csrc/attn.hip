@@ -126,6 +126,19 @@ __device__ __forceinline__ void store_rows_T(uint8_t* stg, const f32x16& t0, con
     }
 }
 
+// accumulator tile initialised with the lane's 16 bias values (four runs of four floats from a padded fp32 row) over the score scale:
+// the MFMAs then accumulate q k^T onto it and no extra registers live through the products
+__device__ __forceinline__ f32x16 bias_tile(const float* brow, float inv_scale) {
+    f32x16 t;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 8 * q4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[4 * q4 + e] = bv[e] * inv_scale;
+    }
+    return t;
+}
+
 #define AT_FW 2                        // forward: waves per workgroup (each wave owns whole (batch, head) pairs: no barrier)
 
 struct AttnLds {
@@ -191,7 +204,8 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
         f32x16 st[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            st[t] = zero16();
+            if constexpr (BIAS) st[t] = bias_tile(a.bias + ((int64_t)h * (32 * NQB) + i) * Lkp + 32 * t + 4 * hh, 1.0f / a.scale);
+            else st[t] = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) st[t] = mfma32(kf[t][ks], qf[ks], st[t]);
         }
@@ -199,15 +213,6 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            if constexpr (BIAS) {      // the lane's 16 keys of the tile are four runs of four: 16-byte loads from the padded bias row of query i
-                const float* brow = a.bias + ((int64_t)h * (32 * NQB) + i) * Lkp + 32 * t + 4 * hh;
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 8 * q4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) st[t][4 * q4 + e] += bv[e] * (1.0f / a.scale);
-                }
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -329,7 +334,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
             const int key = 32 * t + m;
             f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
             for (int qb = 0; qb < NQB; ++qb) {
-                f32x16 s = zero16(), dp = zero16();
+                f32x16 s, dp = zero16();
+                // bias[h][i][key] for the lane's key and its 16 queries: four runs of four along the transposed copy
+                if constexpr (BIAS) s = bias_tile(a.bias_t + ((int64_t)h * Lkp + key) * Lqp + 32 * qb + 4 * hh, 1.0f / a.scale);
+                else s = zero16();
                 // Register diet (three waves per SIMD without scratch): the key / value fragments are re-read from LDS per query
                 // block (the opaque copy of the row index keeps the compiler from hoisting them out of the loop), and P / dS
                 // overwrite S / dP in place.
@@ -339,15 +347,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
                 for (int ks = 0; ks < 4; ++ks) {
                     s = mfma32(nat_frag(Qs, 32 * qb + m, ks, hh), nat_frag(Ks, keyr, ks, hh), s);        // D[query][key]
                     dp = mfma32(nat_frag(Ds, 32 * qb + m, ks, hh), nat_frag(Vs, keyr, ks, hh), dp);
-                }
-                if constexpr (BIAS) {      // bias[h][i][key] for the lane's key and its 16 queries: four runs of four along the transposed copy
-                    const float* brow = a.bias_t + ((int64_t)h * Lkp + key) * Lqp + 32 * qb + 4 * hh;
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 8 * q4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) s[4 * q4 + e] += bv[e] * (1.0f / a.scale);
-                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -389,20 +388,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
             const uint32_t rk = __float_as_uint(rvq[2]);
             f32x16 dq0 = zero16(), dq1 = zero16();
             for (int t = 0; t < T; ++t) {
-                f32x16 s = zero16(), dp = zero16();
+                f32x16 s, dp = zero16();
+                if constexpr (BIAS) s = bias_tile(a.bias + ((int64_t)h * Lqp + i) * Lkp + 32 * t + 4 * hh, 1.0f / a.scale);
+                else s = zero16();
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     s = mfma32(nat_frag(Ks, 32 * t + m, ks, hh), qf[ks], s);             // D[key][query]
                     dp = mfma32(nat_frag(Vs, 32 * t + m, ks, hh), df[ks], dp);
-                }
-                if constexpr (BIAS) {
-                    const float* brow = a.bias + ((int64_t)h * Lqp + i) * Lkp + 32 * t + 4 * hh;
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 8 * q4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) s[4 * q4 + e] += bv[e] * (1.0f / a.scale);
-                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -473,11 +465,13 @@ hipError_t launch_attn(const AttnArgs& a, bool bwd, hipStream_t stream) {
         return hipGetLastError();
     }
     const size_t lds = attn_lds_bytes(a.Lq, a.Lk, 1);
-    if (a.bias != nullptr) {       // T5's biased scores: the two-waves-per-SIMD register budget (16 more live values per tile)
-        auto kb = attn_bwd_kernel<2, AT_NW, true>;
-        hipError_t eb = hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (a.bias != nullptr) {       // T5's biased scores: same occupancy rule as below (VLPET_ATTN_OCC forces one in a diagnosis build)
+        const bool o3 = occ_env == 3 || (occ_env != 2 && 3 * (lds + 512) <= (size_t)160 * 1024);
+        const void* kb = o3 ? reinterpret_cast<const void*>(attn_bwd_kernel<3, AT_NW, true>) : reinterpret_cast<const void*>(attn_bwd_kernel<2, AT_NW, true>);
+        hipError_t eb = hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (eb != hipSuccess) return eb;
-        hipLaunchKernelGGL(kb, dim3((unsigned)(a.B * a.H)), dim3(AT_NW * 64), lds, stream, a);
+        if (o3) hipLaunchKernelGGL((attn_bwd_kernel<3, AT_NW, true>), dim3((unsigned)(a.B * a.H)), dim3(AT_NW * 64), lds, stream, a);
+        else hipLaunchKernelGGL((attn_bwd_kernel<2, AT_NW, true>), dim3((unsigned)(a.B * a.H)), dim3(AT_NW * 64), lds, stream, a);
         return hipGetLastError();
     }
     // Three waves per SIMD (168 registers, one spilled) whenever three workgroups fit the CU's LDS -- sequences of at most 64
