@@ -326,6 +326,15 @@ int vlpet_sublayer_tail_bwd_out(const void* dout, const void* out_save, const fl
  * straight at the parameters' slots of its flat gradient buffer. */
 int vlpet_sublayer_tail_reduce(const float* dgb_partials, int n_partials, int d, float* dgamma, float* dbeta,
                                vlpet_stream_t stream);
+/* Deferred form of the two reductions above, for a trainer (nobody reads a parameter gradient before the optimizer step):
+ * vlpet_colsum_partial runs only the first pass of vlpet_colsum (workspace [vlpet_sublayer_tail_partials(M)][n]); vlpet_reduce_batch
+ * sums n_jobs partial blocks in ONE launch per 96 jobs: job j reduces partials[j] viewed as [n_partials[j]][2 d[j]] into out0[j] [d]
+ * and out1[j] [d] (OVERWRITTEN; either may be NULL) -- a LayerNorm's (dgamma, dbeta) with d = d_model, or a bias gradient of width
+ * n as (out, out + n / 2) with d = n / 2.  Host arrays; the reference's counterpart is autograd's per-parameter sum(0) + accumulate
+ * (trainer_base.py:339-344 unfreezes every bias in the LoRA runs). */
+int vlpet_colsum_partial(const void* x, int64_t M, int n, float* workspace, int io_dtype, vlpet_stream_t stream);
+int vlpet_reduce_batch(const float* const* partials, float* const* out0, float* const* out1, const int* n_partials,
+                       const int* d, int n_jobs, vlpet_stream_t stream);
 /* LayerNorm backward from the NORMALISED rows: xhat [M, d] (IO dtype) and rstd [M] as vlpet_visproj_fwd saves them
  * (autograd of `feat_embedding`'s LayerNorm, src/modeling_bart.py:157, 171).  dx [M, d] = gradient of the pre-norm rows,
  * dgb_partials as above (NULL when the LayerNorm is frozen); one pass over [M, d]. */

@@ -1,7 +1,7 @@
 """A/B switches of the host package as module attributes, set from VLPET_* environment variables by the tools (and bench.py when
 VLPET_AB=1): the product package itself reads nothing from the environment at import.
     VLPET_NO_LINK=1, VLPET_NO_GEMM_LINK=1, VLPET_NO_NORM_LINK=1, VLPET_NO_LORA_LINK=1, VLPET_NO_BIAS_GRAD_KERNEL=1, VLPET_NO_FUSED_QKV=1,
-    VLPET_EAGER_FFN_ACT=1, VLPET_EAGER_LM_LOSS=1, VLPET_EAGER_ATTENTION=1, VLPET_EAGER_RMS_NORM=1, VLPET_SPLIT_WIDE=1, VLPET_SDPA=flash|efficient|math"""
+    VLPET_EAGER_FFN_ACT=1, VLPET_EAGER_LM_LOSS=1, VLPET_EAGER_ATTENTION=1, VLPET_EAGER_RMS_NORM=1, VLPET_SPLIT_WIDE=1, VLPET_SDPA=flash|efficient|math, VLPET_NO_DEFER_REDUCES=1"""
 import os
 
 
@@ -32,4 +32,6 @@ def apply():
     put(HB, "FUSE_QKV", not on("VLPET_NO_FUSED_QKV"))
     put(HB, "SDPA_BACKEND", os.environ.get("VLPET_SDPA") or None)
     put(LC, "LINK_DELTA_GRAD", not on("VLPET_NO_LORA_LINK"))
+    import vlpet_amd.train as TR
+    put(TR, "DEFER_PARAM_REDUCES", not on("VLPET_NO_DEFER_REDUCES"))
     return changed

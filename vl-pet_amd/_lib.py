@@ -99,6 +99,8 @@ SIGNATURES = {
     "vlpet_sublayer_tail_reduce": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vlpet_layernorm_bwd_xhat": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_void_p]),
     "vlpet_colsum": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "vlpet_colsum_partial": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
+    "vlpet_reduce_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vlpet_rmsnorm_fwd": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_float, c_int, c_void_p]),
     "vlpet_rmsnorm_bwd": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p]),
     "vlpet_attn_fwd": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_float, c_float, c_uint64, c_void_p]),

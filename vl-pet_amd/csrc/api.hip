@@ -926,6 +926,35 @@ extern "C" int vlpet_colsum(const void* x, int64_t M, int n, float* workspace, f
     return herr(launch_colsum(x, M, n, workspace, out, io_dtype == VLPET_F32, (hipStream_t)stream));
 }
 
+extern "C" int vlpet_colsum_partial(const void* x, int64_t M, int n, float* workspace, int io_dtype, vlpet_stream_t stream) {
+    if (M <= 0 || n <= 0 || n % 16 != 0) return VLPET_E_SHAPE;
+    if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    if (n / (io_dtype == VLPET_F32 ? 4 : 8) > 8 * 64) return VLPET_E_SHAPE;
+    if (!x || !workspace) return VLPET_E_NULL;
+    if (!aligned16(x)) return VLPET_E_ALIGN;
+    return herr(launch_colsum_partial(x, M, n, workspace, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
+extern "C" int vlpet_reduce_batch(const float* const* partials, float* const* out0, float* const* out1, const int* n_partials,
+                                  const int* d, int n_jobs, vlpet_stream_t stream) {
+    if (n_jobs <= 0) return n_jobs == 0 ? 0 : VLPET_E_SHAPE;
+    if (!partials || !out0 || !out1 || !n_partials || !d) return VLPET_E_NULL;
+    for (int k0 = 0; k0 < n_jobs; k0 += VLPET_REDUCE_BATCH) {
+        ReduceBatch b{};
+        int max_d = 0;
+        b.n = n_jobs - k0 < VLPET_REDUCE_BATCH ? n_jobs - k0 : VLPET_REDUCE_BATCH;
+        for (int k = 0; k < b.n; ++k) {
+            const int j = k0 + k;
+            if (!partials[j] || (!out0[j] && !out1[j])) return VLPET_E_NULL;
+            if (n_partials[j] <= 0 || d[j] <= 0) return VLPET_E_SHAPE;
+            b.j[k] = ReduceJob{partials[j], out0[j], out1[j], n_partials[j], d[j]};
+            if (d[j] > max_d) max_d = d[j];
+        }
+        if (int rc = herr(launch_tail_reduce_batch(b, max_d, (hipStream_t)stream))) return rc;
+    }
+    return 0;
+}
+
 extern "C" int vlpet_sublayer_tail_reduce(const float* dgb_partials, int n_partials, int d, float* dgamma, float* dbeta,
                                           vlpet_stream_t stream) {
     if (n_partials <= 0 || d <= 0) return VLPET_E_SHAPE;

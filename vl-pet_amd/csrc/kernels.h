@@ -235,6 +235,12 @@ hipError_t launch_tail(const TailArgs& a, int io_fp32, bool bwd, hipStream_t str
 int tail_blocks(int64_t M);
 hipError_t launch_tail_reduce(const float* part, int nb, int d, float* dgamma, float* dbeta, hipStream_t stream);
 hipError_t launch_colsum(const void* x, int64_t M, int n, float* part, float* out, int io_fp32, hipStream_t stream);
+hipError_t launch_colsum_partial(const void* x, int64_t M, int n, float* part, int io_fp32, hipStream_t stream);
+// batched form of launch_tail_reduce: part [nb][2 d] -> out0 [d], out1 [d] (either may be null) per job, one launch
+struct ReduceJob { const float* part; float* out0; float* out1; int nb; int d; };
+#define VLPET_REDUCE_BATCH 96
+struct ReduceBatch { ReduceJob j[VLPET_REDUCE_BATCH]; int n; };
+hipError_t launch_tail_reduce_batch(const ReduceBatch& b, int max_d, hipStream_t stream);
 
 // Downsample (adaptive max pool over the token grid), downsample.hip
 struct PoolArgs {

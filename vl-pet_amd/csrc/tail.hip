@@ -423,6 +423,49 @@ hipError_t launch_colsum(const void* x, int64_t M, int n, float* part, float* ou
     return launch_tail_reduce(part, blocks, n / 2, out, out + n / 2, stream);
 }
 
+// Several such reductions in ONE launch (blockIdx.y = job): the LoRA runs train every bias, 96 column-sum reductions + 30 LayerNorm ones
+// per step, each a 5.6 us launch of a few dozen workgroups (0.7 ms of a 23 ms step).  A trainer queues them during the backward and
+// flushes once (functional.flush_reduces): nobody reads a parameter gradient before the optimizer.
+__global__ __launch_bounds__(1024) void tail_reduce_batch_kernel(ReduceBatch b) {
+    __shared__ float acc[16][64];
+    const ReduceJob J = b.j[blockIdx.y];
+    const int c = threadIdx.x & 63, s = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    const int w = 2 * J.d, nb = J.nb;
+    if ((int)blockIdx.x * 64 >= w) return;            // (jobs narrower than the widest one of the batch)
+    float v = 0.f;
+    if (col < w) {
+        const float* src = J.part + col;
+        int r = s;
+        for (; r + 48 < nb; r += 64) {
+            const float a0 = src[(size_t)r * w], a1 = src[(size_t)(r + 16) * w], a2 = src[(size_t)(r + 32) * w],
+                        a3 = src[(size_t)(r + 48) * w];
+            v += (a0 + a1) + (a2 + a3);
+        }
+        for (; r < nb; r += 16) v += src[(size_t)r * w];
+    }
+    acc[s][c] = v;
+    __syncthreads();
+    if (s == 0 && col < w) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += acc[k][c];
+        if (col < J.d) { if (J.out0) J.out0[col] = t; }
+        else if (J.out1) J.out1[col - J.d] = t;
+    }
+}
+
+hipError_t launch_tail_reduce_batch(const ReduceBatch& b, int max_d, hipStream_t stream) {
+    hipLaunchKernelGGL(tail_reduce_batch_kernel, dim3((2 * max_d + 63) / 64, b.n), dim3(1024), 0, stream, b);
+    return hipGetLastError();
+}
+
+// pass 1 of launch_colsum alone (the reduction is queued by the caller)
+hipError_t launch_colsum_partial(const void* x, int64_t M, int n, float* part, int io_fp32, hipStream_t stream) {
+    const int blocks = tail_blocks(M);
+    return io_fp32 ? launch_colsum_io<float>(x, M, n, part, blocks, stream) : launch_colsum_io<__bf16>(x, M, n, part, blocks, stream);
+}
+
 hipError_t launch_tail_reduce(const float* part, int nb, int d, float* dgamma, float* dbeta, hipStream_t stream) {
     hipLaunchKernelGGL(tail_reduce_kernel, dim3((2 * d + 63) / 64), dim3(1024), 0, stream, part, nb, d, dgamma, dbeta);
     return hipGetLastError();

@@ -57,6 +57,36 @@ TIMER: Optional[KernelTimer] = None
 WGRAD_STREAM: Optional["torch.cuda.Stream"] = None
 
 
+# Deferred reductions of parameter gradients (bias column sums, LayerNorm dgamma / dbeta): a trainer sets DEFER_REDUCES for its
+# backward and calls flush_reduces() once after it -- one batched launch (vlpet_reduce_batch) instead of one 5.6-us launch per
+# parameter (127 per step in the LoRA runs, which train every bias).  Only gradients written straight into the trainer's flat buffer
+# are deferred (train.GradSink: nobody reads them before the optimizer); with bucketed all-reduces running from inside the backward the
+# trainer leaves the switch off.
+DEFER_REDUCES = False
+_PENDING_REDUCES: list = []
+
+
+def reduce_partials(part: torch.Tensor, nb: int, d: int, out0: Optional[torch.Tensor], out1: Optional[torch.Tensor], deferrable: bool):
+    """``part`` viewed as [nb][2 d] -> out0 [d], out1 [d] (fp32, overwritten; either may be None): now, or at flush_reduces()."""
+    if DEFER_REDUCES and deferrable:
+        _PENDING_REDUCES.append((part, int(nb), int(d), out0, out1))
+        return
+    rc = _lib.load().vlpet_sublayer_tail_reduce(part.data_ptr(), int(nb), int(d), _ptr(out0), _ptr(out1), _stream())
+    _lib.check(rc, "vlpet_sublayer_tail_reduce")
+
+
+def flush_reduces():
+    if not _PENDING_REDUCES:
+        return 0
+    jobs, n = list(_PENDING_REDUCES), len(_PENDING_REDUCES)
+    _PENDING_REDUCES.clear()
+    vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+    rc = _lib.load().vlpet_reduce_batch(vp(*[j[0].data_ptr() for j in jobs]), vp(*[_ptr(j[3]) for j in jobs]), vp(*[_ptr(j[4]) for j in jobs]),
+                                        ip(*[j[1] for j in jobs]), ip(*[j[2] for j in jobs]), n, _stream())
+    _lib.check(rc, "vlpet_reduce_batch")
+    return n
+
+
 def _timed(name, rows, fn):
     if TIMER is None or not TIMER.wants(name):
         return fn()
@@ -404,9 +434,16 @@ class _LinearTrainBiasFn(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             M = dy2.shape[0]
             (t, sink) = _grad_dest(b, (n,))
-            ws = torch.empty(lib.vlpet_sublayer_tail_partials(M) * n, dtype=torch.float32, device=dy2.device)
-            rc = lib.vlpet_colsum(dy2.data_ptr(), M, n, ws.data_ptr(), t.data_ptr(), _io_dtype(dy2), _stream())
-            _lib.check(rc, "vlpet_colsum")
+            nb = lib.vlpet_sublayer_tail_partials(M)
+            ws = torch.empty(nb * n, dtype=torch.float32, device=dy2.device)
+            if DEFER_REDUCES and sink is not None:       # pass 1 now, the reduction with the step's other ones (flush_reduces)
+                rc = lib.vlpet_colsum_partial(dy2.data_ptr(), M, n, ws.data_ptr(), _io_dtype(dy2), _stream())
+                _lib.check(rc, "vlpet_colsum_partial")
+                tf = t.reshape(-1)
+                reduce_partials(ws, nb, n // 2, tf[:n // 2], tf[n // 2:], True)
+            else:
+                rc = lib.vlpet_colsum(dy2.data_ptr(), M, n, ws.data_ptr(), t.data_ptr(), _io_dtype(dy2), _stream())
+                _lib.check(rc, "vlpet_colsum")
             db = _finish([(t, sink, b)])[0]
         return dx, None, db, None
 

@@ -117,8 +117,8 @@ class _TailFn(torch.autograd.Function):
             want_b = beta is not None and bool(ctx.needs_input_grad[3])
             (tg, sg) = _grad_dest(gamma, (d,)) if want_g else (None, None)
             (tb, sb) = _grad_dest(beta, (d,)) if want_b else (None, None)
-            rc = lib.vlpet_sublayer_tail_reduce(part.data_ptr(), part.shape[0], d, _ptr(tg), _ptr(tb), _stream())
-            _lib.check(rc, "vlpet_sublayer_tail_reduce")
+            from .functional import reduce_partials
+            reduce_partials(part, part.shape[0], d, tg, tb, deferrable=(tg is None or sg is not None) and (tb is None or sb is not None))
             if want_g:
                 dgamma = _finish([(tg, sg, gamma)])[0]
             if want_b:

@@ -502,6 +502,9 @@ class FusedAdamW:
 CPU_OPTIMIZER_FACTORY = None
 
 
+DEFER_PARAM_REDUCES = True      # A/B switch (tools/ab_switches.py): False = one reduce launch per parameter gradient, as before round 4
+
+
 class Trainer:
     """One process per GPU.  ``step(batch)`` = forward, backward (with overlapped gradient exchange),
     clip, AdamW, scheduler -- multitask.py:217-342.
@@ -581,7 +584,19 @@ class Trainer:
         per_token, _ = self.model(batch["input_ids"], batch["vis_inputs"], batch["labels"], batch["task"],
                                   attention_mask=batch.get("attention_mask"), no_padding=bool(batch.get("no_padding", False)))
         loss = task_loss(per_token, batch["labels"], batch.get("scores"), batch["task"])
-        loss.backward()
+        if self.flat.flat.is_cuda:
+            from . import functional as VF
+            # parameter-gradient reductions of this backward (bias column sums, LayerNorm gradients) as one batched launch at its
+            # end -- unless bucket all-reduces start from inside the backward (they would read the buckets before the flush)
+            VF.DEFER_REDUCES = DEFER_PARAM_REDUCES and ((not self.flat.dp) or self.flat.defer)
+            try:
+                loss.backward()
+                VF.flush_reduces()
+            finally:
+                VF.DEFER_REDUCES = False
+                VF._PENDING_REDUCES.clear()
+        else:
+            loss.backward()
         return loss
 
     def _finish_step(self):
