@@ -23,6 +23,13 @@ def test_k1_t5_rank_192_full_size_bf16(M):
     _check(C.run_k1(torch.bfloat16, M=M, r=192, rg=192, nh=4, delta_scale=4.0, x2_scale=0.5, gate_scale=0.3), 1e-2)
 
 
+@pytest.mark.parametrize("M", [130, 2128, 3528, 8192, 8200])
+def test_k1_t5_rank_192_per_rank_sizes_bf16(M):
+    # the strong-scaled per-rank launches of configs[2] (2,128 = 38 x 56 rows, 3,528 = 63 x 56): up to 8,192 rows pass 1 of the backward
+    # is the six-tile kernel in four feature blocks + the reduce launch (round 4); 8,200: just past that dispatch boundary
+    _check(C.run_k1(torch.bfloat16, M=M, r=192, rg=192, nh=4, delta_scale=4.0, x2_scale=0.5, gate_scale=0.3), 1e-2)
+
+
 def test_k1_t5_rank_192_per_rank_size_fp32():
     # 16,800 rows over 8 ranks: the strong-scaled per-GPU launch
     _check(C.run_k1(torch.float32, M=2100, r=192, rg=192, nh=4, delta_scale=4.0, x2_scale=0.5, gate_scale=0.3), 1e-3)

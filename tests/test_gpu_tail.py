@@ -222,3 +222,39 @@ def test_linear_with_trainable_bias_matches_autograd(M, n, dtype):
     assert _rel(out, ref.detach()) <= tol
     assert _rel(X.grad, xr.grad) <= tol
     assert B.grad.dtype == torch.float32 and _rel(B.grad, br.grad) <= (1e-5 if dtype == torch.float32 else 2e-3)
+
+
+def test_deferred_reductions_in_one_batched_launch_equal_the_immediate_ones():
+    """vlpet_colsum_partial + vlpet_reduce_batch (round 4: a trainer queues the bias column sums and LayerNorm gradient reductions of
+    a backward and sums them in one launch) against vlpet_colsum / torch sums: several jobs of different widths and partial counts
+    in one call, more jobs than one launch takes (96), a job with only one of its two outputs."""
+    import ctypes
+    from vlpet_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(11)
+    jobs, refs = [], []
+    shapes = [(1000, 768), (37, 768), (5000, 3072), (300, 64), (28000, 768)] + [(200 + 7 * k, 768) for k in range(100)]
+    for M, n in shapes:
+        x = (torch.randn(M, n, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        nb = lib.vlpet_sublayer_tail_partials(M)
+        ws = torch.empty(nb * n, dtype=torch.float32, device="cuda")
+        assert lib.vlpet_colsum_partial(x.data_ptr(), M, n, ws.data_ptr(), 1, st) == 0
+        out = torch.full((n,), float("nan"), device="cuda")
+        jobs.append((ws, nb, n // 2, out))
+        refs.append(x.float().sum(0))
+    # one LayerNorm-style job with only its second output: partials [nb][2][d]
+    part = torch.randn(50, 2, 768, generator=g).cuda()
+    only_b = torch.full((768,), float("nan"), device="cuda")
+    n = len(jobs) + 1
+    vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+    rc = lib.vlpet_reduce_batch(vp(*([j[0].data_ptr() for j in jobs] + [part.data_ptr()])),
+                                vp(*([j[3].data_ptr() for j in jobs] + [None])),
+                                vp(*([j[3][j[2]:].data_ptr() for j in jobs] + [only_b.data_ptr()])),
+                                ip(*([j[1] for j in jobs] + [50])), ip(*([j[2] for j in jobs] + [768])), n, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    for (ws, nb, d, out), ref in zip(jobs, refs):
+        assert float((out - ref).abs().max()) <= 2e-3 * max(float(ref.abs().max()), 1.0)
+    assert float((only_b - part[:, 1].sum(0)).abs().max()) <= 1e-3
+    assert lib.vlpet_reduce_batch(None, None, None, None, None, 0, st) == 0          # nothing queued: no launch, no error

@@ -279,7 +279,13 @@ static BwdWs bwd_ws(int64_t M, int d, int tiles, bool gate, int io_dtype) {
     BwdWs w{};
     const size_t esz = io_dtype == VLPET_F32 ? 4 : 2;
     const size_t side = align256((size_t)M * 32 * tiles * esz);
-    const size_t wide = align256((size_t)M * d * esz);
+    size_t wide = align256((size_t)M * d * esz);
+    // the feature-split pass 1 parks its fp32 partial dz in the dh / dq area (unused by the two-pass form): four blocks at six tiles
+    // need twice the room of the two wide tensors
+    if (gate && tiles == 6 && io_dtype != VLPET_F32 && k1_dz6_feature_blocks(M, d) > 1) {
+        const size_t need = align256((size_t)k1_dz6_feature_blocks(M, d) * (size_t)M * 32 * tiles * 4);
+        if (need > wide) wide = need;
+    }
     size_t o = 0;
     w.z_a = o; o += side;
     w.dp_a = o; o += side;
@@ -406,6 +412,14 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
             }
         }
         const bool dz6 = two_pass && !dz2 && vlpet_tuning().dz6 != 0 && k1_dz6_applies(b, io_dtype == VLPET_F32);
+        if (dz6 && gate) {
+            const int nfb = k1_dz6_feature_blocks(M, d);
+            const size_t need = (size_t)nfb * (size_t)M * 2 * 32 * tiles * 4;
+            if (nfb > 1 && w.dq > w.dh && need <= 2 * (w.dq - w.dh)) {
+                b.fsplit = nfb;
+                b.dz_part = reinterpret_cast<float*>(ws + w.dh);
+            }
+        }
         hipError_t e = dz2 ? launch_k1_dz2(b, (hipStream_t)stream)
                      : dz6 ? launch_k1_dz6(b, (hipStream_t)stream)
                      : two_pass ? launch_pet_gate_dz(b, io_dtype == VLPET_F32, (hipStream_t)stream)

@@ -158,6 +158,8 @@ int k1_dz2_feature_blocks(int64_t M, int d);
 // the same pass at six tiles (r = 192 / 128): four waves per workgroup, one per SIMD, each with the whole register file (pet_dz6.hip)
 bool k1_dz6_applies(const PetBwdArgs& a, int io_fp32);
 hipError_t launch_k1_dz6(const PetBwdArgs& a, hipStream_t stream);
+int k1_dz6_feature_blocks(int64_t M, int d);
+hipError_t launch_k1_dz_reduce(const PetBwdArgs& a, int PR, hipStream_t stream);     // sums the feature blocks of either split form (pet_dz2.hip)
 hipError_t launch_pet_gate_cols(const PetBwdArgs& a, const WgradArgs& g, int GS, int NG, int io_fp32, hipStream_t stream);
 
 // Column-parallel pass 2 of the gated K1 backward, round-3 form (pet_cols.hip): weights resident in registers, row tensors streamed

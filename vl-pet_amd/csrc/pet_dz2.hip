@@ -390,6 +390,13 @@ __global__ __launch_bounds__(256) void k1_dz_reduce_kernel(PetBwdArgs a, int PR)
     }
 }
 
+hipError_t launch_k1_dz_reduce(const PetBwdArgs& a, int PR, hipStream_t stream) {
+    const int64_t n4 = a.M * 2 * (PR / 4);
+    const unsigned rb = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k1_dz_reduce_kernel, dim3(rb), dim3(256), 0, stream, a, PR);
+    return hipGetLastError();
+}
+
 // feature blocks of pass 1 by shape: the kernel is a chain of d / 64 stages whatever its rows, and below 8,192 rows fewer than 64 of
 // the 256 CUs have a workgroup -- four feature blocks give each a quarter of the chain (profiles/r04_k1bench_small_m.txt)
 int k1_dz2_feature_blocks(int64_t M, int d) {
@@ -417,11 +424,7 @@ static hipError_t launch_dz2_rt(const PetBwdArgs& a, hipStream_t stream) {
     const unsigned nfb = a.fsplit > 1 ? (unsigned)a.fsplit : 1u;
     if (add) hipLaunchKernelGGL((k1_dz2_kernel<RT, true>), dim3(blocks, nfb), dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((k1_dz2_kernel<RT, false>), dim3(blocks, nfb), dim3(512), lds, stream, a);
-    if (nfb > 1) {
-        const int64_t n4 = a.M * 2 * (32 * RT / 4);
-        const unsigned rb = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-        hipLaunchKernelGGL(k1_dz_reduce_kernel, dim3(rb), dim3(256), 0, stream, a, 32 * RT);
-    }
+    if (nfb > 1) return launch_k1_dz_reduce(a, 32 * RT, stream);
     return hipGetLastError();
 }
 

@@ -40,7 +40,11 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = wave;
     const int m = lane & 31, h = lane >> 5;
-    const int d = a.d, S = d >> 6;
+    const int d = a.d;
+    // feature split (small M, PetBwdArgs::fsplit > 1, as in pet_dz2.hip): workgroup (x, y) walks only the stages [S0, S) of feature block
+    // y and leaves fp32 partial sums in dz_part; k1_dz_reduce_kernel adds the blocks and applies act'(pre)
+    const int NFB = a.fsplit > 1 ? a.fsplit : 1;
+    const int S0 = (int)blockIdx.y * ((d >> 6) / NFB), S = S0 + (d >> 6) / NFB;
     const int64_t ld2 = (int64_t)d * 2;
     const int64_t row0 = (int64_t)blockIdx.x * 128;
     const int64_t grow_raw = row0 + 32 * rg + m;
@@ -182,12 +186,12 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
     };
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // z in registers, biases in LDS
-    issue_w(0);
-    issue_x(0);
+    issue_w(2 * S0);
+    issue_x(S0);
 
     // request order per step (what the counted waits rely on): half-stage (s, 0): W(2s + 1), X(s + 1); half-stage (s, 1): W(2s + 2)
 #pragma unroll 1
-    for (int ss = 0; ss < 2 * S; ++ss) {
+    for (int ss = 2 * S0; ss < 2 * S; ++ss) {
         const int s = ss >> 1, fh = ss & 1;
         // everything this wave requested for half-stage ss has landed: younger than W(ss) are only the row pieces of stage s + 1
         // (requested in half-stage (s, 0), after W(2s + 1))
@@ -239,6 +243,22 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (every LDS access of this step is complete at the next barrier)
     }
 
+    if (NFB > 1) {      // feature split: this block's fp32 sums of both chains -> dz_part[fb][row][chain][32 RT]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float* out = a.dz_part + (((int64_t)blockIdx.y * a.M + grow) * 2 + t) * (32 * RT) + 4 * h;
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 r4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r4[j] = t == 0 ? dzA[ct][4 * q + j] : dzG[ct][4 * q + j];
+                    if (row_ok) *reinterpret_cast<f32x4*>(out + 32 * ct + 8 * q) = r4;
+                }
+        }
+        return;
+    }
     // ---- dpre = dz * act'(pre) of both chains (dz_a carries the delta scale once, here)
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #pragma unroll
@@ -263,12 +283,20 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
     }
 }
 
+int k1_dz6_feature_blocks(int64_t M, int d) {
+    if (const int f = vlpet_tuning().dz2_fsplit; f >= 1) return ((d >> 6) % f == 0) ? f : 1;
+    return (M <= 8192 && (d >> 6) % 4 == 0) ? 4 : 1;
+}
+
 bool k1_dz6_applies(const PetBwdArgs& a, int io_fp32) {
     if (io_fp32 || !(a.flags & PET_GATE) || a.saved == nullptr || drop_active(a.drop) || a.d % 64 != 0 || a.d < 64) return false;
     // by shape (profiles/r04_k1bench_r192_dz6_ab.txt): the chain-split pet_gate_dz_kernel runs 64-row workgroups, ONE round of them up to
     // 16,384 rows in 42-44 us; above that it needs two rounds (87 us at 16,800 / 18,250 rows, 90 at 28,000) and this kernel -- a fixed chain
     // of 24 half-stages, 66-74 us whatever the rows up to 32,768 -- is the faster one (71 us at 18,250 rows, 74 at 28,000)
-    if (a.M <= 16384 && vlpet_tuning().dz6 != 2) return false;
+    // Second session: below 8,192 rows this kernel runs in four feature blocks (k1_dz6_feature_blocks; the per-rank shapes of the 8-GPU T5
+    // config): a quarter of the 24-half-stage chain per workgroup + the reduce launch, against the 42-us chain of pet_gate_dz_kernel.
+    if (a.M > 8192 && a.M <= 16384 && vlpet_tuning().dz6 != 2) return false;
+    if (a.M <= 8192 && vlpet_tuning().dz6 != 2 && k1_dz6_feature_blocks(a.M, a.d) <= 1) return false;
     return a.RT == 6 && Dz6Geo<6>::bytes(a.d) <= (size_t)160 * 1024;
 }
 
@@ -280,7 +308,9 @@ hipError_t launch_k1_dz6(const PetBwdArgs& a, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const unsigned blocks = (unsigned)((a.M + 127) / 128);
-    if (add) hipLaunchKernelGGL((k1_dz6_kernel<6, true>), dim3(blocks), dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((k1_dz6_kernel<6, false>), dim3(blocks), dim3(256), lds, stream, a);
+    const unsigned nfb = a.fsplit > 1 ? (unsigned)a.fsplit : 1u;
+    if (add) hipLaunchKernelGGL((k1_dz6_kernel<6, true>), dim3(blocks, nfb), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((k1_dz6_kernel<6, false>), dim3(blocks, nfb), dim3(256), lds, stream, a);
+    if (nfb > 1) return launch_k1_dz_reduce(a, 32 * 6, stream);
     return hipGetLastError();
 }
