@@ -200,8 +200,8 @@ class _RmsNormFn(torch.autograd.Function):
         dgamma = None
         if train:
             (tg, sg) = _grad_dest(weight, (d,))
-            rc = lib.vlpet_sublayer_tail_reduce(part.data_ptr(), part.shape[0], d, tg.data_ptr(), None, _stream())
-            _lib.check(rc, "vlpet_sublayer_tail_reduce")
+            from .functional import reduce_partials
+            reduce_partials(part, part.shape[0], d, tg, None, deferrable=sg is not None)      # (queued by a trainer: flush_reduces)
             dgamma = _finish([(tg, sg, weight)])[0]
         return dx.view(shape), dgamma, None, None
 

@@ -134,8 +134,8 @@ class _VisProjFn(torch.autograd.Function):
             if train_ln:
                 (dgamma, s_g) = _grad_dest(gamma, (d_out,))
                 (dbeta, s_be) = _grad_dest(beta, (d_out,)) if has_beta else (None, None)
-                rc = lib.vlpet_sublayer_tail_reduce(part.data_ptr(), part.shape[0], d_out, dgamma.data_ptr(), _ptr(dbeta), _stream())
-                _lib.check(rc, "vlpet_sublayer_tail_reduce")
+                from .functional import reduce_partials
+                reduce_partials(part, part.shape[0], d_out, dgamma, dbeta, deferrable=s_g is not None and (dbeta is None or s_be is not None))
         (dw, s_w), (db, s_b) = _grad_dest(w, (d_out, F)), _grad_dest(b, (d_out,))
         nws = lib.vlpet_visproj_wgrad_workspace_bytes(M, F, d_out)
         ws = torch.empty(nws, dtype=torch.uint8, device=ff.device)
