@@ -394,6 +394,17 @@ class _LinearAccFn(torch.autograd.Function):
         return (dx, None) + (None,) * (2 * len(ws))
 
 
+def io_view(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """``p`` in the activation dtype: the parameter's slice of its trainer's IO-dtype shadow buffer when that is current
+    (train.FlatGrads.refresh_io_shadow: one cast launch per optimizer step for all trainable parameters), else a cast."""
+    if p.dtype == dtype:
+        return p
+    sh = getattr(p, "_vlpet_io", None)
+    if sh is not None and sh[0].io_epoch == WEIGHTS_EPOCH and sh[1].dtype == dtype:
+        return sh[1]
+    return p.to(dtype)
+
+
 class _LinearTrainBiasFn(torch.autograd.Function):
     """``x W^T + b`` with a FROZEN weight and a TRAINABLE bias (the reference's LoRA runs unfreeze every bias next to the frozen
     projections): the bias gradient = column sums of dy through vlpet_colsum (two HIP launches, fp32, straight into the
@@ -407,7 +418,7 @@ class _LinearTrainBiasFn(torch.autograd.Function):
             link.armed = True           # K3's delta on this projection (same x, downstream of this output) parks its d/dx
             ctx.link = link
         ctx.save_for_backward(w, b)
-        return F.linear(x, w, b if b.dtype == x.dtype else b.to(x.dtype))
+        return F.linear(x, w, io_view(b, x.dtype))
 
     @staticmethod
     def backward(ctx, dy):

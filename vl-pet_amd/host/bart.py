@@ -142,6 +142,13 @@ def _first_linear(mod, x, link):
     if link is not None and _frozen(mod):
         from ..functional import linear_acc
         return linear_acc(x, link, mod)
+    if (link is not None and FUSE_BIAS_GRAD and isinstance(mod, nn.Linear) and not mod.weight.requires_grad and mod.bias is not None
+            and mod.bias.requires_grad):
+        # frozen weight, trainable bias (the LoRA runs): the same hand-over through the bias-gradient form of the projection
+        from ..functional import linear_train_bias, linear_train_bias_ok
+        w = mod.weight if mod.weight.dtype == x.dtype else mod.weight.to(x.dtype)
+        if linear_train_bias_ok(x, w, mod.bias):
+            return linear_train_bias(x, w, mod.bias, link)
     return _linear(mod, x)
 
 

@@ -252,6 +252,8 @@ class FlatGrads:
             self.slices.append((off, off + n))
             off += n
         self.flat_p = None
+        self.flat_p_io = None       # IO-dtype shadow of flat_p (refresh_io_shadow): the trainable biases' bf16 copies as views of ONE buffer
+        self.io_epoch = -1
         if flatten_params:
             self.flat_p = torch.zeros(total_pad, dtype=torch.float32, device=dev)
             for p, (a, b) in zip(self.params, self.slices):
@@ -363,6 +365,20 @@ class FlatGrads:
             if average:
                 self.flat.div_(self.world_size)
 
+    def refresh_io_shadow(self, dtype=torch.bfloat16):
+        """One cast launch over the flat parameter buffer after an optimizer step instead of one ``b.to(bf16)`` per trainable
+        bias and forward (96 per step in the LoRA runs, which train every bias next to frozen bf16 weights; under graph replay
+        they were 96 nodes).  ``functional.io_view(p, dtype)`` hands out the parameter's slice while the shadow is current."""
+        from . import functional as VF
+        if self.flat_p is None or not self.flat_p.is_cuda:
+            return
+        if self.flat_p_io is None or self.flat_p_io.dtype != dtype:
+            self.flat_p_io = torch.empty_like(self.flat_p, dtype=dtype)
+            for p, (a, b) in zip(self.params, self.slices):
+                p._vlpet_io = (self, self.flat_p_io[a:b].view_as(p))
+        self.flat_p_io.copy_(self.flat_p)
+        self.io_epoch = VF.WEIGHTS_EPOCH
+
     def begin_step(self, zero: bool = True):
         """New accumulation epoch: every sink accepts one direct write again."""
         self.epoch += 1
@@ -433,6 +449,11 @@ class FusedAdamW:
                 mask[a:b] = 1
         self.decay = mask.to(dev)
         self.repack_every_pair = False      # set by a trainer that replays captured steps (no Python forward marks the pairs as used)
+        # bf16 shadow of the trainable parameters, refreshed after every step: only where it is used (trainable biases of frozen
+        # bf16 projections = the LoRA runs; FlatGrads.refresh_io_shadow)
+        self.io_shadow = any(n.endswith(".bias") and p.dim() == 1 for n, p in zip(flat.names, flat.params)) and not flat.per_task
+        if self.io_shadow:
+            flat.refresh_io_shadow()
         self.nb = self.lib.vlpet_optim_blocks(n)
         self.partials = torch.empty(self.nb, dtype=torch.float32, device=dev)
         self.norm = torch.zeros((), dtype=torch.float32, device=dev)
@@ -487,6 +508,8 @@ class FusedAdamW:
             _lib.check(rc, "vlpet_adamw_step_sliced")
             VF.bump_weights_epoch()
             VF.repack_all(self.repack_every_pair)        # the adapters' fragment packs for the next step: a few batched launches
+            if self.io_shadow:
+                f.refresh_io_shadow()
             return
         rc = self.lib.vlpet_adamw_step(f.flat_p.data_ptr(), f.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                        self.decay.data_ptr(), n, self.partials.data_ptr(), self.nb, float(self.max_norm),
@@ -495,6 +518,8 @@ class FusedAdamW:
         _lib.check(rc, "vlpet_adamw_step")
         VF.bump_weights_epoch()
         VF.repack_all(self.repack_every_pair)            # the adapters' fragment packs for the next step: a few batched launches
+        if self.io_shadow:
+            f.refresh_io_shadow()
 
 
 # Set by the test / CPU-baseline harness: factory(flat: FlatGrads, lr, max_norm) -> object with .step(lr).
