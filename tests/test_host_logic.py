@@ -216,3 +216,37 @@ def test_linear_acc_without_a_park_and_without_grad():
     assert not link.armed                   # nothing to hand over when the input needs no gradient
     with pytest.raises(RuntimeError):
         VF.linear_acc(x, None, torch.nn.Linear(6, 4))      # trainable projections are refused
+
+
+def test_t5_attn_spec_dense_forms_are_the_reference_masks():
+    """host/t5.AttnSpec keeps T5's relative bias / key padding / causality apart for the on-chip attention kernels; its dense() is
+    what the reference adds to the scores (my_transformers/modeling_t5.py:640-660, src/modeling_t5.py:311-327): bias + (1 - mask) *
+    -10000 in the joint encoder, bias + causal * -10000 in the decoder, (1 - mask) * -1e9 for the cross attention."""
+    import vlpet_amd.host.t5 as HT
+    g = torch.Generator().manual_seed(0)
+    H, L = 3, 7
+    rel = torch.randn(1, H, L, L, generator=g)
+    keep = torch.tensor([[1, 1, 1, 1, 1, 0, 0], [1, 1, 1, 1, 1, 1, 1]], dtype=torch.float32)
+    enc = HT.AttnSpec(rel, keep, causal=False).dense(torch.float32)
+    assert torch.equal(enc, rel + (1.0 - keep[:, None, None, :]) * -10000.0)
+    dec = HT.AttnSpec(rel, None, causal=True).dense(torch.float32)
+    tri = torch.tril(torch.ones(L, L))
+    assert torch.equal(dec, rel + (1.0 - tri)[None, None] * -10000.0)
+    cross = HT.AttnSpec(None, keep, causal=False).dense(torch.float32)
+    assert torch.equal(cross, (1.0 - keep[:, None, None, :]) * -1e9)
+    assert HT.AttnSpec(None, None, causal=False).dense(torch.float32) is None
+    assert HT.AttnSpec(rel, keep, causal=False, rel_trainable=True).fast() is None      # a trainable bias needs its gradient: dense path
+
+
+def test_trainer_batch_signature_separates_tasks_and_shapes():
+    """train.Trainer captures one graph per batch signature: same task + same shapes -> same key, anything else a new one."""
+    import vlpet_amd.train as TR
+    b1 = dict(task="vqa", input_ids=torch.zeros(4, 20, dtype=torch.long), labels=torch.zeros(4, 5, dtype=torch.long),
+              vis_inputs=(torch.zeros(4, 49, 8), torch.zeros(4, 49, 4)), scores=torch.ones(4), no_padding=False)
+    b2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b1.items()}
+    b3 = dict(b1, task="gqa")
+    b4 = dict(b1, input_ids=torch.zeros(5, 20, dtype=torch.long))
+    b5 = dict(b1, no_padding=True)
+    sig = TR.Trainer._signature
+    assert sig(b1) == sig(b2)
+    assert len({sig(b) for b in (b1, b3, b4, b5)}) == 4

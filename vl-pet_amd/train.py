@@ -601,9 +601,10 @@ class Trainer:
                 out += [(k, i, t) for i, t in enumerate(v) if torch.is_tensor(t)]
         return out
 
-    def _signature(self, batch):
+    @staticmethod
+    def _signature(batch):
         return (batch["task"], bool(batch.get("no_padding", False)),
-                tuple((k, i, tuple(t.shape), t.dtype, tuple(t.stride())) for k, i, t in self._leaves(batch)))
+                tuple((k, i, tuple(t.shape), t.dtype, tuple(t.stride())) for k, i, t in Trainer._leaves(batch)))
 
     def _fwd_bwd(self, batch) -> torch.Tensor:
         per_token, _ = self.model(batch["input_ids"], batch["vis_inputs"], batch["labels"], batch["task"],
