@@ -100,20 +100,23 @@ class _AttnQkvFn(torch.autograd.Function):
     projection's dgrad GEMM consumes directly."""
 
     @staticmethod
-    def forward(ctx, qkv, key_mask, H, causal, scale, p, seed):
+    def forward(ctx, qkv, key_mask, H, causal, scale, p, seed, bias=None):
         lib = _lib.load()
         _need_cuda(qkv)
         qkv = qkv.contiguous()
         B, L, E3 = qkv.shape
         E = E3 // 3
+        if bias is not None and (bias.H, bias.Lq, bias.Lk) != (H, L, L):
+            raise RuntimeError(f"vl-pet_amd: attention bias [{bias.H}, {bias.Lq}, {bias.Lk}] does not match [{H}, {L}, {L}]")
         o = torch.empty(B, L, E, dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(B, H, L, dtype=torch.float32, device=qkv.device)
         base, esz = qkv.data_ptr(), qkv.element_size()
-        rc = _timed("attn_fwd", B * L, lambda: lib.vlpet_attn_fwd_ld(
-            base, base + E * esz, base + 2 * E * esz, _ptr(key_mask), o.data_ptr(), lse.data_ptr(), None,
-            B, H, L, L, E3, E3, int(causal), float(scale), float(p), seed, _stream()))
-        _lib.check(rc, "vlpet_attn_fwd_ld")
+        rc = _timed("attn_fwd", B * L, lambda: lib.vlpet_attn_fwd_bias(
+            base, base + E * esz, base + 2 * E * esz, _ptr(key_mask), bias.b.data_ptr() if bias is not None else None, o.data_ptr(),
+            lse.data_ptr(), None, B, H, L, L, E3, E3, int(causal), float(scale), float(p), seed, _stream()))
+        _lib.check(rc, "vlpet_attn_fwd_bias")
         ctx.save_for_backward(qkv, o, lse, key_mask)
+        ctx.bias = bias
         ctx.cfg = (H, int(causal), float(scale), float(p), seed)
         return o
 
@@ -129,11 +132,14 @@ class _AttnQkvFn(torch.autograd.Function):
             do = do.to(qkv.dtype)
         dqkv = torch.empty_like(qkv)
         base, dbase, esz = qkv.data_ptr(), dqkv.data_ptr(), qkv.element_size()
-        rc = _timed("attn_bwd", B * L, lambda: lib.vlpet_attn_bwd_ld(
+        bias = ctx.bias
+        rc = _timed("attn_bwd", B * L, lambda: lib.vlpet_attn_bwd_bias(
             base, base + E * esz, base + 2 * E * esz, o.data_ptr(), do.data_ptr(), lse.data_ptr(), _ptr(key_mask),
+            bias.b.data_ptr() if bias is not None else None, bias.bt.data_ptr() if bias is not None else None,
             dbase, dbase + E * esz, dbase + 2 * E * esz, B, H, L, L, E3, E3, causal, scale, p, seed, _stream()))
-        _lib.check(rc, "vlpet_attn_bwd_ld")
-        return dqkv, None, None, None, None, None, None
+        _lib.check(rc, "vlpet_attn_bwd_bias")
+        ctx.bias = None
+        return dqkv, None, None, None, None, None, None, None
 
 
 def supported_qkv(qkv: torch.Tensor, num_heads: int) -> bool:
@@ -142,8 +148,9 @@ def supported_qkv(qkv: torch.Tensor, num_heads: int) -> bool:
 
 
 def short_self_attention(qkv: torch.Tensor, num_heads: int, key_mask: Optional[torch.Tensor] = None, causal: bool = False,
-                         p: float = 0.0, training: bool = False, scale: Optional[float] = None, seed=None):
-    """qkv [B, L, 3*H*64] (bf16; the output of one fused q|k|v projection) -> [B, L, H*64]."""
+                         p: float = 0.0, training: bool = False, scale: Optional[float] = None, seed=None,
+                         bias: Optional[AttnBias] = None):
+    """qkv [B, L, 3*H*64] (bf16; the output of one fused q|k|v projection) -> [B, L, H*64].  bias: see short_attention."""
     if not supported_qkv(qkv, num_heads):
         raise RuntimeError("vl-pet_amd: short_self_attention needs a bf16 CUDA [B, L, 3*H*64] tensor with L <= 128")
     if key_mask is not None:
@@ -151,7 +158,7 @@ def short_self_attention(qkv: torch.Tensor, num_heads: int, key_mask: Optional[t
     pe = float(p) if training else 0.0
     if seed is None:
         seed = _draw_seed() if pe > 0.0 else 0
-    return _AttnQkvFn.apply(qkv, key_mask, num_heads, bool(causal), HEAD_DIM ** -0.5 if scale is None else float(scale), pe, int(seed))
+    return _AttnQkvFn.apply(qkv, key_mask, num_heads, bool(causal), HEAD_DIM ** -0.5 if scale is None else float(scale), pe, int(seed), bias)
 
 
 def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, key_mask: Optional[torch.Tensor] = None,

@@ -143,6 +143,7 @@ def relative_position_bucket(relative_position, bidirectional, num_buckets=32, m
 
 
 EAGER_ATTENTION = False   # A/B switch (tools/ab_switches.py): True = torch SDPA with a dense additive mask for every T5 attention
+FUSE_QKV = True           # A/B switch: False = separate q / k / v projections in self-attention
 
 
 class AttnSpec:
@@ -224,9 +225,39 @@ class T5Attention(nn.Module):
     def _shape(self, t, B):
         return t.view(B, -1, self.n_heads, self.d_kv).transpose(1, 2)
 
+    def _fused_qkv(self, dtype):
+        """The frozen q | k | v projections of a self-attention as one [3 inner, d] weight (as host/bart.py: a derived cache keyed on the
+        three modules' tensors, never a parameter -- the state dict keeps q / k / v)."""
+        mods = (self.q, self.k, self.v)
+        key = tuple((m.weight.data_ptr(), m.weight._version) for m in mods) + (dtype, VF.FROZEN_EPOCH)
+        c = getattr(self, "_qkv_cache", None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                w = torch.cat([m.weight.to(dtype) for m in mods], 0).contiguous()
+            c = (key, w)
+            self._qkv_cache = c
+        return c[1]
+
     def forward(self, hidden, bias, kv=None, task=None):
         B, Lq, _ = hidden.shape
         src = hidden if kv is None else kv
+        from .. import attention as A
+        spec = bias if isinstance(bias, AttnSpec) else None
+        if (kv is None and FUSE_QKV and spec is not None and not EAGER_ATTENTION and hidden.is_cuda and hidden.dtype == torch.bfloat16
+                and self.d_kv == A.HEAD_DIM and Lq <= A.MAX_LEN and not any(m.weight.requires_grad for m in (self.q, self.k, self.v))):
+            fast = spec.fast()
+            if fast is not None:
+                # self-attention with frozen projections: ONE [d -> 3 inner] GEMM each way (T5's projections carry no bias), the
+                # attention kernels read / write the q | k | v column blocks in place -- 2 library launches instead of 6 and one
+                # input gradient instead of three (at the per-rank batch of an 8-GPU run each of those GEMMs is a ~9 us launch)
+                w = self._fused_qkv(hidden.dtype)
+                if FUSE_RESIDUAL_GRAD and FUSE_NORM_GRAD and torch.is_grad_enabled() and hidden.requires_grad:
+                    from ..functional import linear_acc
+                    qkv = linear_acc(hidden, None, (w, None))
+                else:
+                    qkv = F.linear(hidden, w)
+                out = A.short_self_attention(qkv, self.n_heads, fast[1], spec.causal, self.dropout, self.training, scale=1.0, bias=fast[0])
+                return _linear(self.o, out)
         fused = (FUSE_RESIDUAL_GRAD and FUSE_NORM_GRAD and hidden.is_cuda and torch.is_grad_enabled() and src.requires_grad
                  and not any(m.weight.requires_grad for m in (self.q, self.k, self.v)))
         if fused:
@@ -245,8 +276,6 @@ class T5Attention(nn.Module):
             q, k, v = _linear(self.q, hidden), _linear(self.k, src), _linear(self.v, src)
             if kv is not None and self.attn_value_parallel_adapter is not None:
                 v = self.attn_value_parallel_adapter(src, task, y=v)                      # K2
-        from .. import attention as A
-        spec = bias if isinstance(bias, AttnSpec) else None
         if spec is not None and not EAGER_ATTENTION and self.d_kv == A.HEAD_DIM and A.supported(q, k, self.n_heads):
             fast = spec.fast()
             if fast is not None:        # on-chip kernels: bias shared by the batch + boolean key mask + causal flag; T5 has no 1/sqrt(d)
