@@ -527,6 +527,7 @@ class FusedAdamW:
 CPU_OPTIMIZER_FACTORY = None
 
 
+_REGISTERED_SEED_CTR = None     # address of the device step counter currently registered with the library (Trainer.enable_graph / close)
 DEFER_PARAM_REDUCES = True      # A/B switch (tools/ab_switches.py): False = one reduce launch per parameter gradient, as before round 4
 
 
@@ -583,12 +584,35 @@ class Trainer:
         if self.seed_ctr is None:
             self.seed_ctr = torch.zeros(1, dtype=torch.int64, device=self.flat.flat.device)
             _lib.check(_lib.load().vlpet_set_seed_counter(self.seed_ctr.data_ptr()), "vlpet_set_seed_counter")
+            global _REGISTERED_SEED_CTR
+            _REGISTERED_SEED_CTR = self.seed_ctr.data_ptr()
         self.optim.repack_every_pair = True
         self.graph = True
         return True
 
     def disable_graph(self):
         self.graph = False
+
+    def close(self):
+        """Unregister this trainer's device step counter from the library (the pointer is process-wide state: a trainer that goes
+        away while registered would leave the dropout kernels reading freed memory -- harmless numerically, wrong in principle)."""
+        global _REGISTERED_SEED_CTR
+        if self.seed_ctr is not None:
+            try:
+                if _REGISTERED_SEED_CTR == self.seed_ctr.data_ptr():      # (a later trainer may have registered its own)
+                    from . import _lib
+                    _lib.load().vlpet_set_seed_counter(None)
+                    _REGISTERED_SEED_CTR = None
+            except Exception:
+                pass
+            self.seed_ctr = None
+        self.graph = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @staticmethod
     def _leaves(batch):
