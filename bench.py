@@ -343,8 +343,9 @@ def main():
     want_graph = args.graph == "on" or (args.graph == "auto" and (args.emulate_ranks > 1 or (n_ranks > 1 and args.scaling == "strong")
                                                                   or args.model != "bart"))
     graph_on = bool(want_graph and tr.enable_graph())      # (False for per-task adapters / a side-stream trainer: those stay eager)
-    if graph_on and args.warmup < 2 * len(tasks):          # a shape runs once eagerly, is captured at its second step, replays from then on
-        args.warmup = 2 * len(tasks)
+    # a shape runs once eagerly, is captured at its second step and replays from then on: two untimed SETUP steps per task in front of
+    # the W warm-up steps (which then already replay), so that --warmup / --steps keep their meaning
+    setup_steps = 2 * len(tasks) if graph_on else 0
 
     def rank_batch(task):
         gb = TR.TASK_BATCH[task](args.batch)
@@ -356,9 +357,11 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     batches = {t: TR.synthetic_batch(t, rank_batch(t), cfg, dev, gen, no_padding=not args.pad_mask) for t in tasks}
     order = [tasks[i % len(tasks)] for i in range(args.warmup + args.steps)]
-    total_steps = max(args.steps + args.warmup, 10) + 8
+    total_steps = max(args.steps + args.warmup + setup_steps, 10) + 8
     tr.total, tr.warmup = total_steps, int(total_steps * 0.1)
 
+    for i in range(setup_steps):
+        tr.step(batches[tasks[i % len(tasks)]])
     for i in range(args.warmup):
         tr.step(batches[order[i]])
     torch.cuda.synchronize()
@@ -553,8 +556,9 @@ def main():
                                    "note": "one GPU running the batch rank 0 of R strong-scaled ranks would see; value is this one rank's "
                                            "throughput, the estimate = R x value ignores the gradient exchange (about 24 MB per step)"}}
                if args.emulate_ranks > 1 else {}),
-            "step_mode": ("hipGraph replay: forward + loss + backward captured once per task shape (train.Trainer(graph=True)), gradient "
-                          "exchange + clip + AdamW eager; roofline brackets from eager steps right after the timed region") if graph_on
+            "step_mode": (f"hipGraph replay: forward + loss + backward captured once per task shape (train.Trainer(graph=True); {setup_steps} "
+                          "untimed setup steps before the warm-up), gradient exchange + clip + AdamW eager; roofline brackets from eager "
+                          "steps right after the timed region") if graph_on
                          else "eager launches (roofline op bracketed inside the timed region)",
             "attention_mask": ("default input_ids.ne(pad) mask built and applied every step, as the reference does" if args.pad_mask
                                else "none built (--no-pad-mask: the synthetic rows carry no padding)"),
