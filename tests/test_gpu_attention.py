@@ -43,6 +43,15 @@ CASES = [  # B, Lq, Lk, causal, masked, p
     (3, 5, 56, False, True, 0.1),
     (2, 33, 97, False, False, 0.5),
     (2, 1, 1, True, False, 0.0),
+    # batches of several workgroup rounds (the small cases above are one partial round): four units, three (cross attention), two, six,
+    # five, eight
+    (90, 56, 56, False, True, 0.1),
+    (90, 20, 56, False, True, 0.1),
+    (96, 5, 5, True, False, 0.1),
+    (44, 92, 92, False, False, 0.1),
+    (44, 70, 40, False, True, 0.0),
+    (90, 33, 97, False, False, 0.5),
+    (44, 128, 128, False, True, 0.1),
 ]
 
 
@@ -88,6 +97,10 @@ BIAS_CASES = [  # B, Lq, Lk, causal, masked, p      (T5: scale 1, a [H, Lq, Lk] 
     (3, 20, 20, True, False, 0.0),
     (2, 33, 97, False, True, 0.1),          # ragged against the 32-wide padding of the bias
     (2, 128, 128, False, False, 0.0),
+    (90, 56, 56, False, True, 0.1),         # several workgroup rounds (see CASES)
+    (44, 92, 92, False, True, 0.1),
+    (90, 20, 20, True, False, 0.0),
+    (44, 33, 97, False, True, 0.1),
 ]
 
 

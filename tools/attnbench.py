@@ -17,13 +17,14 @@ def timeit(fn, iters=30, warm=5):
     return e0.elapsed_time(e1) / iters * 1e3
 
 H = 12
+P = float(os.environ.get("ATTNBENCH_P", "0.1"))
 for name, B, S in [("vqa", 500, 56), ("gqa", 833, 56), ("nlvr", 166, 92), ("caption", 416, 76), ("dec-self", 500, 5)]:
     q, k, v, do = (torch.randn(B, S, H * 64, device="cuda").bfloat16().requires_grad_(i < 3) for i in range(4))
-    o = short_attention(q, k, v, H, p=0.1, training=True, seed=1)
-    t_f = timeit(lambda: short_attention(q, k, v, H, p=0.1, training=True, seed=1))
-    t_fb = timeit(lambda: torch.autograd.grad(short_attention(q, k, v, H, p=0.1, training=True, seed=1), (q, k, v), do))
+    o = short_attention(q, k, v, H, p=P, training=True, seed=1)
+    t_f = timeit(lambda: short_attention(q, k, v, H, p=P, training=True, seed=1))
+    t_fb = timeit(lambda: torch.autograd.grad(short_attention(q, k, v, H, p=P, training=True, seed=1), (q, k, v), do))
     sh = lambda t: t.view(B, S, H, 64).transpose(1, 2)
-    sd = lambda: F.scaled_dot_product_attention(sh(q), sh(k), sh(v), dropout_p=0.1).transpose(1, 2).reshape(B, S, H * 64)
+    sd = lambda: F.scaled_dot_product_attention(sh(q), sh(k), sh(v), dropout_p=P).transpose(1, 2).reshape(B, S, H * 64)
     t_sf = timeit(sd)
     t_sfb = timeit(lambda: torch.autograd.grad(sd(), (q, k, v), do))
     unit = B * S * H * 64 * 2 / 1e6

@@ -363,6 +363,7 @@ struct AttnArgs {
     float inv_keep;
     uint64_t seed;
     const uint64_t* seed_ctr;   // optional device step counter mixed into the seed (rng.h vlpet_eff_seed)
+    int dbg;                // diagnosis build only (VLPET_DBG): backward ablations -- 1 no units, 4 no stores, 8 no compute (zeros stored)
 };
 size_t attn_lds_bytes(int Lq, int Lk, int bwd);
 hipError_t launch_attn(const AttnArgs& a, bool bwd, hipStream_t stream);
