@@ -471,9 +471,16 @@ hipError_t launch_tail_reduce(const float* part, int nb, int d, float* dgamma, f
     return hipGetLastError();
 }
 
+// Workgroups of the row kernels: a wave walks rows with the next one prefetched, and its prologue (gamma / beta, 2 us) and the
+// partial sums it leaves are per workgroup, so few rows per wave is NOT what makes a short launch short.  Sweep of the cap at
+// 1,240-28,000 rows (profiles/r04_k5_workgroup_cap.txt): one workgroup per CU up to ~3,000 rows (9.6 vs 14.0 us at 2,100 rows with
+// 525), two around 6,000, three from ~9,000 on (the round-3 value at full-batch sizes).
 int tail_blocks(int64_t M) {
     const int64_t need = (M + TAIL_WAVES - 1) / TAIL_WAVES;
-    const int64_t cap = 256 * 3;   // 3 workgroups of 4 waves per CU (with the row prefetch: best of 256 .. 2048; fewer partial sums)
+    int64_t cap = M / 12;
+    if (cap < 256) cap = 256;
+    if (cap > 768) cap = 768;
+    if (VLPET_IS_DEBUG_BUILD && vlpet_tuning().dbg >= 64) cap = vlpet_tuning().dbg;      // (diagnosis: VLPET_DBG = cap)
     return (int)(need < cap ? need : cap);
 }
 
