@@ -250,3 +250,24 @@ def test_trainer_batch_signature_separates_tasks_and_shapes():
     sig = TR.Trainer._signature
     assert sig(b1) == sig(b2)
     assert len({sig(b) for b in (b1, b3, b4, b5)}) == 4
+
+
+def test_key_mask_byte_conversion_is_cached_per_source_and_version():
+    """attention._key_mask_u8: every layer passes a fresh view of the same boolean mask; the byte form is converted once and
+    reconverted after an in-place write to the mask (the version counter is part of the key)."""
+    import vlpet_amd.attention as A
+    A._KM_CACHE.clear()
+    m = torch.rand(4, 1, 1, 7) > 0.3
+    a = A._key_mask_u8(m[:, 0, 0, :], 4, 7)
+    b = A._key_mask_u8(m[:, 0, 0, :], 4, 7)
+    assert a is b and a.dtype == torch.uint8 and a.shape == (4, 7) and a.is_contiguous()
+    assert bool((a == m[:, 0, 0, :].to(torch.uint8)).all())
+    m[0, 0, 0, 0] = ~m[0, 0, 0, 0]                                # in place: same storage, new version
+    c = A._key_mask_u8(m[:, 0, 0, :], 4, 7)
+    assert c is not a and bool((c == m[:, 0, 0, :].to(torch.uint8)).all())
+    other = torch.ones(4, 7, dtype=torch.bool)
+    d = A._key_mask_u8(other, 4, 7)
+    assert bool((d == 1).all()) and A._key_mask_u8(m[:, 0, 0, :], 4, 7) is c     # two sources are kept
+    u8 = torch.ones(4, 7, dtype=torch.uint8)
+    assert A._key_mask_u8(u8, 4, 7) is u8                         # already bytes: passed through
+    assert len(A._KM_CACHE) <= 2

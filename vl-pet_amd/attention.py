@@ -147,6 +147,25 @@ def supported_qkv(qkv: torch.Tensor, num_heads: int) -> bool:
             and qkv.shape[1] <= MAX_LEN)
 
 
+# The kernels take the key mask as [B, Lk] bytes; the models hand every layer the same boolean mask (a fresh view of it per layer), so
+# the conversion is kept for the last two sources: same storage, same version counter (an in-place write to the mask bumps it),
+# same geometry -> the same bytes.  The entry holds the source view, which keeps its storage from being recycled under the key.
+_KM_CACHE: list = []
+
+
+def _key_mask_u8(key_mask: torch.Tensor, B: int, L: int) -> torch.Tensor:
+    if key_mask.dtype == torch.uint8 and key_mask.shape == (B, L) and key_mask.is_contiguous():
+        return key_mask
+    for src, ver, out in _KM_CACHE:
+        if (src.data_ptr() == key_mask.data_ptr() and ver == key_mask._version and src.dtype == key_mask.dtype
+                and src.shape == key_mask.shape and src.stride() == key_mask.stride() and out.shape == (B, L)):
+            return out
+    out = key_mask.reshape(B, L).to(torch.uint8).contiguous()
+    _KM_CACHE.insert(0, (key_mask, key_mask._version, out))
+    del _KM_CACHE[2:]
+    return out
+
+
 def short_self_attention(qkv: torch.Tensor, num_heads: int, key_mask: Optional[torch.Tensor] = None, causal: bool = False,
                          p: float = 0.0, training: bool = False, scale: Optional[float] = None, seed=None,
                          bias: Optional[AttnBias] = None):
@@ -154,7 +173,7 @@ def short_self_attention(qkv: torch.Tensor, num_heads: int, key_mask: Optional[t
     if not supported_qkv(qkv, num_heads):
         raise RuntimeError("vl-pet_amd: short_self_attention needs a bf16 CUDA [B, L, 3*H*64] tensor with L <= 128")
     if key_mask is not None:
-        key_mask = key_mask.reshape(qkv.shape[0], qkv.shape[1]).to(torch.uint8).contiguous()
+        key_mask = _key_mask_u8(key_mask, qkv.shape[0], qkv.shape[1])
     pe = float(p) if training else 0.0
     if seed is None:
         seed = _draw_seed() if pe > 0.0 else 0
@@ -169,7 +188,7 @@ def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads
     if not supported(q, k, num_heads):
         raise RuntimeError("vl-pet_amd: short_attention needs bf16 CUDA tensors, head dim 64 and at most 128 keys / queries")
     if key_mask is not None:
-        key_mask = key_mask.reshape(k.shape[0], k.shape[1]).to(torch.uint8).contiguous()
+        key_mask = _key_mask_u8(key_mask, k.shape[0], k.shape[1])
     pe = float(p) if training else 0.0
     if seed is None:
         seed = _draw_seed() if pe > 0.0 else 0
