@@ -226,6 +226,15 @@ int vlpet_lora_delta_fwd_save(const void* x, const void* base, const void* packe
                               const uint8_t* keep_mask, float p, uint64_t seed, uint8_t* keep_out, void* out,
                               void* saved, int64_t M, int d, int tiles, float scaling,
                               int io_dtype, vlpet_stream_t stream);
+/* K3 at rank r <= 8 (bf16, d % 64 == 0, d <= 1024 -- vlpet_lora_r8_applies): the same delta as a streaming row kernel without the
+ * matrix cores (csrc/lora8.hip; eight multiply-adds per element are not a matrix product).  Same `packed` pair, same dropout
+ * generator and masks as the entry points above; `saved` NULL = inference form, else the saved block of
+ * vlpet_lora_saved_bytes(M, d, 1, io_dtype) as vlpet_lora_delta_fwd_save leaves it, so vlpet_lora_delta_bwd_saved takes it as is.
+ * Replaces lora/controller.py:56-70 at lora_dim <= 8.  VLPET_E_SHAPE when the form does not apply. */
+int vlpet_lora_r8_applies(int64_t M, int d, int r, int io_dtype);
+int vlpet_lora_delta_fwd_r8(const void* x, const void* base, const void* packed, const uint8_t* keep_mask, float p,
+                            uint64_t seed, uint8_t* keep_out, void* out, void* saved, int64_t M, int d, int r,
+                            float scaling, int io_dtype, vlpet_stream_t stream);
 int vlpet_lora_delta_bwd_saved(const void* dy, const void* x, const void* saved, const void* packed,
                                const uint8_t* keep_mask, float p, uint64_t seed, void* dx,
                                float* da, float* db, int r,

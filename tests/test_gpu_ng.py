@@ -36,3 +36,44 @@ def test_k1_adapter_only_two_pass_vs_oracle(kw):
 def test_k3_two_pass_vs_oracle(M, r, p):
     """p > 0: the training form with the forward's packed mask (the oracle gets the exported mask); r = 128: six tiles."""
     _check(C.run_k3(torch.bfloat16, M=M, r=r, p=p))
+
+
+@pytest.mark.parametrize("M,d,r,p,explicit", [(1, 768, 8, 0.0, False), (63, 768, 8, 0.1, False), (257, 768, 4, 0.1, False), (1000, 768, 1, 0.0, False),
+                                                (777, 512, 8, 0.1, False), (640, 1024, 6, 0.1, True), (3500, 768, 8, 0.1, True),
+                                                (5000, 256, 8, 0.5, False), (28000, 768, 8, 0.1, False)])
+def test_k3_rank8_streaming_form_vs_oracle(M, d, r, p, explicit):
+    """K3 at lora_dim <= 8 runs as a streaming row kernel (csrc/lora8.hip; lora/controller.py:56-70): forward (+ the saved block the
+    unchanged two-pass backward reads) against the oracle -- one row, ragged sizes, ranks below 8, one / two pieces per lane, both
+    mask sources."""
+    import vlpet_amd.functional as F
+    from vlpet_amd import _lib
+    assert F.LORA_R8_STREAMING and _lib.load().vlpet_lora_r8_applies(M, d, r, F._io_dtype(torch.empty(1, dtype=torch.bfloat16))) == 1
+    _check(C.run_k3(torch.bfloat16, M=M, d=d, r=r, p=p, explicit_mask=explicit))
+
+
+def test_k3_rank8_streaming_form_equals_the_mfma_form():
+    """Same pack, same generator: the two forward forms give the same mask bit for bit, the same saved block, and outputs / gradients
+    that differ by summation order only."""
+    import vlpet_amd.functional as F
+    g = torch.Generator().manual_seed(11)
+    M, d, r, p = 4100, 768, 8, 0.1
+    x = (torch.randn(M, d, generator=g)).cuda().bfloat16()
+    base = (torch.randn(M, d, generator=g)).cuda().bfloat16()
+    dy = (torch.randn(M, d, generator=g)).cuda().bfloat16()
+    A0, B0 = (torch.randn(r, d, generator=g) / d ** 0.5).cuda(), (torch.randn(d, r, generator=g) * 0.3).cuda()
+    res = []
+    try:
+        for streaming in (True, False):
+            F.LORA_R8_STREAMING = streaming
+            xg = x.clone().requires_grad_(True)
+            Ag, Bg = A0.clone().requires_grad_(True), B0.clone().requires_grad_(True)
+            pk = F.pack_pair([Ag], None, Bg, None, F._io_dtype(xg))
+            out, mask = F.lora_delta(xg, base, Ag, Bg, pk, 4.0, None, p, 1234, return_mask=True)
+            out.backward(dy)
+            res.append((out.detach().float(), mask.clone(), xg.grad.float(), Ag.grad.clone(), Bg.grad.clone()))
+    finally:
+        F.LORA_R8_STREAMING = True
+    (o1, m1, dx1, da1, db1), (o2, m2, dx2, da2, db2) = res
+    assert torch.equal(m1, m2)
+    for a, b in ((o1, o2), (dx1, dx2), (da1, da2), (db1, db2)):
+        assert float((a - b).abs().max()) <= 1e-2 * float(b.abs().max())

@@ -49,8 +49,17 @@ def main():
             def bwd_s():
                 rc = lib.vlpet_lora_delta_bwd_saved(dy.data_ptr(), x.data_ptr(), sv.data_ptr(), pk.buf.data_ptr(), kp, p, 1234, dx.data_ptr(),
                                                     da.data_ptr(), db.data_ptr(), r, ws.data_ptr(), nws, M, d, tiles, 0.5, io, st); assert rc == 0
+            def fwd_r8(save):   # rank <= 8: the streaming row kernel (csrc/lora8.hip), inference / training form
+                def f():
+                    rc = lib.vlpet_lora_delta_fwd_r8(x.data_ptr(), base.data_ptr(), pk.buf.data_ptr(), kp, p, 1234, None, out.data_ptr(),
+                                                     sv.data_ptr() if save else None, M, d, r, 0.5, io, st); assert rc == 0
+                return f
             tf, tb = timeit(fwd), timeit(bwd)
             tfs = timeit(fwd_s); tbs = timeit(bwd_s)
+            if lib.vlpet_lora_r8_applies(M, d, r, io):
+                t8, t8s = timeit(fwd_r8(False)), timeit(fwd_r8(True))
+                print(f"r={r:4d}         {label:18s}: streaming form (lora8): fwd {t8:7.1f} us (frac {by/t8/1e3/8000:.3f})   training form: fwd {t8s:7.1f} us "
+                      f"(frac {by/t8s/1e3/8000:.3f})")
             print(f"r={r:4d} tiles={tiles} {label:18s}: fwd {tf:7.1f} us ({by/tf/1e3:7.1f} GB/s, frac {by/tf/1e3/8000:.3f})   "
                   f"bwd rows+wgrad {tb:7.1f} us ({by/tb/1e3:7.1f} GB/s, frac {by/tb/1e3/8000:.3f})   | training form: fwd {tfs:7.1f} us "
                   f"(frac {by/tfs/1e3/8000:.3f}), bwd {tbs:7.1f} us (frac {by/tbs/1e3/8000:.3f})")

@@ -64,6 +64,9 @@ SIGNATURES = {
     "vlpet_lora_saved_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "vlpet_lora_delta_fwd_save": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_uint64, c_void_p, c_void_p,
                                           c_void_p, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
+    "vlpet_lora_r8_applies": (c_int, [c_int64, c_int, c_int, c_int]),
+    "vlpet_lora_delta_fwd_r8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_uint64, c_void_p, c_void_p,
+                                        c_void_p, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
     "vlpet_lora_delta_bwd_saved": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_uint64, c_void_p,
                                            c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int64, c_int, c_int, c_float,
                                            c_int, c_void_p]),

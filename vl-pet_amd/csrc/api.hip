@@ -8,7 +8,7 @@
 #include <stdio.h>
 #include <vector>
 
-#define VLPET_VERSION 410      // 410: vlpet_set_seed_counter (dropout seeds under graph replay), two-pass K2 / K3 forward; 400: two-pass K1 forward (pet_fwd2p.hip), vlpet_sublayer_tail_bwd_out;
+#define VLPET_VERSION 420      // 420: vlpet_lora_delta_fwd_r8 (K3 at rank <= 8 as a streaming kernel, lora8.hip); 410: vlpet_set_seed_counter (dropout seeds under graph replay), two-pass K2 / K3 forward; 400: two-pass K1 forward (pet_fwd2p.hip), vlpet_sublayer_tail_bwd_out;
 #define VLPET_VERSION_R3 300      // 300: column-parallel K1 backward pass (pet_cols.hip), phases bits 3 / 4, vlpet_adapter_gate_bwd_form;
 #define VLPET_VERSION_R2 221      // 221: vlpet_sublayer_tail_reduce, vlpet_layernorm_bwd_xhat, vlpet_rmsnorm_{fwd,bwd}, vlpet_colsum;  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
 
@@ -267,6 +267,29 @@ extern "C" int vlpet_lora_delta_fwd_save(const void* x, const void* base, const 
     if (int rc = make_drop(keep_mask, p, seed, keep_out, &ds)) return rc;
     return run_fwd(x, base, nullptr, packed, nullptr, ds, out, M, d, tiles, 1.f, scaling, 1.f,
                    PET_ACT_IDENTITY, io_dtype, stream, saved);
+}
+
+// K3 at rank <= 8: the streaming form (lora8.hip).  `saved` NULL = inference form; else the training form's saved block
+// (vlpet_lora_saved_bytes(M, d, 1, io): z, then the packed mask) exactly as vlpet_lora_delta_fwd_save leaves it.
+extern "C" int vlpet_lora_delta_fwd_r8(const void* x, const void* base, const void* packed, const uint8_t* keep_mask, float p,
+                                       uint64_t seed, uint8_t* keep_out, void* out, void* saved, int64_t M, int d, int r,
+                                       float scaling, int io_dtype, vlpet_stream_t stream) {
+    int rc = check_common(M, d, 1, io_dtype);
+    if (rc) return rc;
+    if (!x || !base || !packed || !out) return VLPET_E_NULL;
+    if (!lora8_applies(M, d, r, io_dtype == VLPET_F32)) return VLPET_E_SHAPE;
+    if (!aligned16(x) || !aligned16(base) || !aligned16(out) || !aligned16(packed) || (saved && !aligned16(saved)) ||
+        (keep_mask && !aligned16(keep_mask)) || (keep_out && !aligned16(keep_out)))
+        return VLPET_E_ALIGN;
+    Lora8Args a{};
+    if (int rd = make_drop(keep_mask, p, seed, keep_out, &a.drop)) return rd;
+    if (saved && drop_active(a.drop)) a.drop.bits_out = reinterpret_cast<uint8_t*>(saved) + saved_stride(M, 1, io_dtype);
+    a.x = x; a.base = base; a.out = out; a.pk = reinterpret_cast<const uint8_t*>(packed);
+    a.save = saved; a.M = M; a.d = d; a.scaling = scaling;
+    return herr(launch_lora8_fwd(a, (hipStream_t)stream));
+}
+extern "C" int vlpet_lora_r8_applies(int64_t M, int d, int r, int io_dtype) {
+    return lora8_applies(M, d, r, io_dtype == VLPET_F32) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------ backward workspace

@@ -235,6 +235,18 @@ struct TailArgs {
 };
 hipError_t launch_tail(const TailArgs& a, int io_fp32, bool bwd, hipStream_t stream);
 int tail_blocks(int64_t M);
+
+// K3 at rank <= 8 as a streaming row kernel (lora8.hip)
+struct Lora8Args {
+    const void* x; const void* base; void* out;     // [M, d] bf16
+    const uint8_t* pk;      // the pair's packs (bf16 plane, one tile): the kernel decodes A [r, d] and B [d, r] from the down / up packs
+    DropSpec drop;          // dropout of x (generator / explicit mask); bits_out = where the packed mask goes in the training form
+    void* save;             // training form: z [M, 32] bf16 (columns >= 8 zero), or nullptr
+    int64_t M; int d;
+    float scaling;
+};
+bool lora8_applies(int64_t M, int d, int r, int io_fp32);
+hipError_t launch_lora8_fwd(const Lora8Args& a, hipStream_t stream);
 hipError_t launch_tail_reduce(const float* part, int nb, int d, float* dgamma, float* dbeta, hipStream_t stream);
 hipError_t launch_colsum(const void* x, int64_t M, int n, float* part, float* out, int io_fp32, hipStream_t stream);
 hipError_t launch_colsum_partial(const void* x, int64_t M, int n, float* part, int io_fp32, hipStream_t stream);

@@ -719,6 +719,9 @@ def parallel_adapter(x, y, wd, bd, wu, bu, pk: PackedPair, scale: float = 1.0, l
     return _ParallelAdapterFn.apply(x, y, pk, scale, link, wd, bd, wu, bu)
 
 
+LORA_R8_STREAMING = True     # A/B switch (tools/): False = the MFMA kernels at every rank
+
+
 class _LoraDeltaFn(torch.autograd.Function):
     """K3: out = base + scaling * ((dropout(x) A^T) B^T); base comes from the library GEMM.
 
@@ -744,7 +747,15 @@ class _LoraDeltaFn(torch.autograd.Function):
                 kf = kf.to(torch.uint8)
         mask = torch.empty(M, d, dtype=torch.uint8, device=xf.device) if (want_mask and p > 0) else None
         act = None
-        if SAVE_ACTIVATIONS and any(ctx.needs_input_grad):      # training: z = dropout(x) A^T for the backward (see K1 / K2)
+        train_form = SAVE_ACTIVATIONS and any(ctx.needs_input_grad)
+        if LORA_R8_STREAMING and lib.vlpet_lora_r8_applies(M, d, pk.r, io):
+            # rank <= 8: the streaming row kernel (csrc/lora8.hip) -- same pack, same masks, same saved block as the MFMA form
+            if train_form:
+                act = torch.empty(lib.vlpet_lora_saved_bytes(M, d, pk.tiles, io), dtype=torch.uint8, device=xf.device)
+            rc = _timed("k3_fwd", M, lambda: lib.vlpet_lora_delta_fwd_r8(
+                xf.data_ptr(), bf.data_ptr(), pk.buf.data_ptr(), _ptr(kf), float(p), int(seed), _ptr(mask), out.data_ptr(),
+                _ptr(act), M, d, pk.r, float(scaling), io, _stream()))
+        elif train_form:      # training: z = dropout(x) A^T for the backward (see K1 / K2)
             act = torch.empty(lib.vlpet_lora_saved_bytes(M, d, pk.tiles, io), dtype=torch.uint8, device=xf.device)
             rc = _timed("k3_fwd", M, lambda: lib.vlpet_lora_delta_fwd_save(
                 xf.data_ptr(), bf.data_ptr(), pk.buf.data_ptr(), _ptr(kf), float(p), int(seed), _ptr(mask), out.data_ptr(),
