@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: validation of HEAD -- the whole GPU suite, smoke, the bench line of every config and the emulated per-rank lines
-mkdir -p gpurun_out/r4fin
-O=gpurun_out/r4fin
+mkdir -p gpurun_out/r4fin2
+O=gpurun_out/r4fin2
 timeout 3000 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 python bench.py > $O/bench_bart.json.log 2> $O/bench_bart.err
