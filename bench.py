@@ -344,8 +344,10 @@ def main():
                                                                   or args.model != "bart"))
     graph_on = bool(want_graph and tr.enable_graph())      # (False for per-task adapters / a side-stream trainer: those stay eager)
     # a shape runs once eagerly, is captured at its second step and replays from then on: two untimed SETUP steps per task in front of
-    # the W warm-up steps (which then already replay), so that --warmup / --steps keep their meaning
-    setup_steps = 2 * len(tasks) if graph_on else 0
+    # the W warm-up steps (which then already replay), so that --warmup / --steps keep their meaning.  Eager: one setup step per task
+    # (first-use costs of a fresh process -- code-object loads of the library GEMMs, the GEMM table, allocator growth: the first bench
+    # run on a fresh box measured 23.9 k samples/s against 26.7 k for the second with W = 4 alone)
+    setup_steps = 2 * len(tasks) if graph_on else len(tasks)
 
     def rank_batch(task):
         gb = TR.TASK_BATCH[task](args.batch)
@@ -559,7 +561,7 @@ def main():
             "step_mode": (f"hipGraph replay: forward + loss + backward captured once per task shape (train.Trainer(graph=True); {setup_steps} "
                           "untimed setup steps before the warm-up), gradient exchange + clip + AdamW eager; roofline brackets from eager "
                           "steps right after the timed region") if graph_on
-                         else "eager launches (roofline op bracketed inside the timed region)",
+                         else f"eager launches (roofline op bracketed inside the timed region; {setup_steps} untimed setup steps, one per task shape, before the warm-up)",
             "attention_mask": ("default input_ids.ne(pad) mask built and applied every step, as the reference does" if args.pad_mask
                                else "none built (--no-pad-mask: the synthetic rows carry no padding)"),
             "kernel_table": {"after": "roofline op bracketed inside the timed region; the other launch groups in one step per task after it",
