@@ -389,6 +389,11 @@ int vlpet_ce_loss_fwd(const void* logits, const int64_t* labels, float* loss, fl
                       int io_dtype, vlpet_stream_t stream);
 int vlpet_ce_loss_bwd(const void* logits, const int64_t* labels, const float* lse, const float* dloss, void* dlogits,
                       int64_t N, int V, int ld, int io_dtype, vlpet_stream_t stream);
+/* The forward with a tally of suspicious labels: a label outside [0, V) is treated like ignore_index (torch's loss raises a device
+ * assert for it); *bad_count (a 32-bit word in device memory, may be NULL) is incremented once per label outside [0, V) that is not
+ * -100, so that the caller can notice a tokenizer / vocabulary mismatch without synchronising every step. */
+int vlpet_ce_loss_fwd_checked(const void* logits, const int64_t* labels, float* loss, float* lse, unsigned int* bad_count,
+                              int64_t N, int V, int ld, int io_dtype, vlpet_stream_t stream);
 
 /* ---- Short-sequence attention of the frozen backbone (my_transformers/modeling_bart.py:283-566, BartAttention.forward) ----
  * o = dropout(softmax(scale * q k^T + mask), p) v per (batch, head), bf16, head dim 64, at most VLPET_ATTN_MAX_LEN keys and

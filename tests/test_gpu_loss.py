@@ -129,3 +129,25 @@ def test_out_of_range_label_raises_and_empty_batch_is_empty():
     e = L.cross_entropy_rows(lg[:0].requires_grad_(True), torch.zeros(0, dtype=torch.long, device="cuda"), V)
     assert e.shape == (0,) and e.dtype == torch.float32
     e.sum().backward()
+
+
+def test_later_batches_with_bad_labels_are_tallied_on_the_device():
+    """the host-side check looks at the first batch per vocabulary only.  Every batch is counted by the forward kernel
+    (vlpet_ce_loss_fwd_checked: labels outside [0, V) other than -100), without a synchronisation; lmloss.bad_label_count reads the
+    tally and train.Trainer.check_labels raises on it."""
+    import vlpet_amd.lmloss as L
+    V = 48
+    lg = torch.randn(8, V, device="cuda", dtype=torch.bfloat16)
+    old = L.CHECK_LABELS
+    L.CHECK_LABELS = "never"                                     # (as if this vocabulary's first batch had been clean)
+    try:
+        before = L.bad_label_count()
+        ok = L.cross_entropy_rows(lg, torch.tensor([1, 2, 3, -100, 0, 5, 6, 7], device="cuda"), V)
+        assert L.bad_label_count() == before and float(ok[3]) == 0.0
+        out = L.cross_entropy_rows(lg, torch.tensor([1, V, 3, -100, -5, 5, V + 9, 7], device="cuda"), V)
+        assert L.bad_label_count() == before + 3                 # V, -5, V + 9; -100 is the ignore index
+        assert float(out[1]) == 0.0 and float(out[4]) == 0.0 and float(out[6]) == 0.0 and float(out[0]) > 0.0
+    finally:
+        L.CHECK_LABELS = old
+        for t in L._BAD.values():                                # leave a clean tally for the trainers of later tests
+            t.zero_()

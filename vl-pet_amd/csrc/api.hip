@@ -1150,16 +1150,20 @@ static int ce_common(int64_t N, int V, int ld, int io_dtype) {
     return 0;
 }
 
-extern "C" int vlpet_ce_loss_fwd(const void* logits, const int64_t* labels, float* loss, float* lse, int64_t N, int V, int ld,
-                                 int io_dtype, vlpet_stream_t stream) {
+extern "C" int vlpet_ce_loss_fwd_checked(const void* logits, const int64_t* labels, float* loss, float* lse, unsigned int* bad_count,
+                                         int64_t N, int V, int ld, int io_dtype, vlpet_stream_t stream) {
     int rc = ce_common(N, V, ld, io_dtype);
     if (rc) return rc;
     if (!logits || !labels || !loss || !lse) return VLPET_E_NULL;
     if (!aligned16(logits)) return VLPET_E_ALIGN;
     CeArgs a{};
     a.logits = logits; a.labels = labels; a.loss = loss; a.lse = lse; a.dloss = nullptr; a.dlogits = nullptr;
-    a.N = N; a.V = V; a.ld = ld;
+    a.N = N; a.V = V; a.ld = ld; a.bad = bad_count;
     return herr(launch_ce(a, false, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+extern "C" int vlpet_ce_loss_fwd(const void* logits, const int64_t* labels, float* loss, float* lse, int64_t N, int V, int ld,
+                                 int io_dtype, vlpet_stream_t stream) {
+    return vlpet_ce_loss_fwd_checked(logits, labels, loss, lse, nullptr, N, V, ld, io_dtype, stream);
 }
 
 extern "C" int vlpet_ce_loss_bwd(const void* logits, const int64_t* labels, const float* lse, const float* dloss, void* dlogits,

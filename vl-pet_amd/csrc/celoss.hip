@@ -31,7 +31,10 @@ __global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(CeArgs a) {
     const int64_t n = blockIdx.x;
     const int64_t lab = a.labels[n];
     if (lab < 0 || lab >= a.V) {                     // ignored token (or an id outside the vocabulary: treated as ignored)
-        if (threadIdx.x == 0) { a.loss[n] = 0.f; a.lse[n] = 0.f; }
+        if (threadIdx.x == 0) {
+            a.loss[n] = 0.f; a.lse[n] = 0.f;
+            if (a.bad != nullptr && lab != -100) atomicAdd(a.bad, 1u);      // not ignore_index: a vocabulary / tokenizer mismatch
+        }
         return;
     }
     const IO* row = reinterpret_cast<const IO*>(a.logits) + n * (int64_t)a.ld;

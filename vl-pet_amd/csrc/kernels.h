@@ -352,6 +352,7 @@ struct CeArgs {
     void* dlogits;          // backward: [N, ld]
     int64_t N;
     int V, ld;
+    unsigned int* bad;      // forward, optional: += number of labels outside [0, V) other than ignore_index -100 (treated as ignored)
 };
 hipError_t launch_ce(const CeArgs& a, bool bwd, int io_fp32, hipStream_t stream);
 

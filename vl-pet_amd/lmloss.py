@@ -34,9 +34,10 @@ class _CeFn(torch.autograd.Function):
             lab = lab.long()
         loss = torch.empty(N, dtype=torch.float32, device=logits.device)
         lse = torch.empty(N, dtype=torch.float32, device=logits.device)
-        rc = _timed("ce_fwd", N, lambda: lib.vlpet_ce_loss_fwd(logits.data_ptr(), lab.data_ptr(), loss.data_ptr(), lse.data_ptr(),
-                                                               N, V, ld, io, _stream()))
-        _lib.check(rc, "vlpet_ce_loss_fwd")
+        bad = _bad_counter(logits.device)
+        rc = _timed("ce_fwd", N, lambda: lib.vlpet_ce_loss_fwd_checked(logits.data_ptr(), lab.data_ptr(), loss.data_ptr(), lse.data_ptr(),
+                                                                       bad.data_ptr(), N, V, ld, io, _stream()))
+        _lib.check(rc, "vlpet_ce_loss_fwd_checked")
         ctx.save_for_backward(logits, lab, lse)
         ctx.cfg = (V, io)
         return loss
@@ -74,6 +75,24 @@ def cross_entropy_rows(logits: torch.Tensor, labels: torch.Tensor, V: Optional[i
 # dtype) is validated on the host (one synchronisation per process and vocabulary); CHECK_LABELS = "always" checks every call.
 CHECK_LABELS = "once"
 _CHECKED = set()
+# ... and every later batch is tallied on the device: the forward kernel counts the labels outside [0, V) other than -100 into a
+# 32-bit word per device (vlpet_ce_loss_fwd_checked; no synchronisation, works inside a captured graph -- the word is allocated at
+# the first, eager, call).  bad_label_count() reads it (one 4-byte copy); train.Trainer checks it every LABEL_CHECK_EVERY steps.
+_BAD = {}
+
+
+def _bad_counter(device: torch.device) -> torch.Tensor:
+    key = (device.type, device.index)
+    t = _BAD.get(key)
+    if t is None:
+        t = _BAD[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def bad_label_count(device=None) -> int:
+    """Labels outside the vocabulary (and not ignore_index) seen by the loss so far on ``device`` (all devices if None)."""
+    ts = [t for k, t in _BAD.items() if device is None or k == (torch.device(device).type, torch.device(device).index)]
+    return int(sum(int(t.item()) for t in ts))
 
 
 def _check_labels_once(labels: torch.Tensor, V: int):

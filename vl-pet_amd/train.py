@@ -528,6 +528,7 @@ CPU_OPTIMIZER_FACTORY = None
 
 
 _REGISTERED_SEED_CTR = None     # address of the device step counter currently registered with the library (Trainer.enable_graph / close)
+LABEL_CHECK_EVERY = 100      # steps between reads of the device-side bad-label tally (0: never)
 DEFER_PARAM_REDUCES = True      # A/B switch (tools/ab_switches.py): False = one reduce launch per parameter gradient, as before round 4
 
 
@@ -654,6 +655,18 @@ class Trainer:
         self.optim.step(lr_at(self.step_idx, self.base_lr, self.warmup, self.total))   # clips, updates, zeroes the grads
         self.step_idx += 1
         self.flat.begin_step(zero=False)
+        if LABEL_CHECK_EVERY and self.step_idx % LABEL_CHECK_EVERY == 0:
+            self.check_labels()
+
+    def check_labels(self):
+        """Raise if the loss kernels have met labels outside the vocabulary (other than ignore_index -100) since the process started:
+        they are treated as ignored tokens, i.e. the run would silently train on fewer tokens (lmloss.bad_label_count; one 4-byte
+        device read, every LABEL_CHECK_EVERY steps and from close())."""
+        from . import lmloss
+        n = lmloss.bad_label_count()
+        if n:
+            raise IndexError(f"vl-pet_amd: {n} label(s) outside the LM-head vocabulary (and not ignore_index -100) reached the loss -- "
+                             "tokenizer / vocabulary mismatch")
 
     def _capture(self, key, batch):
         from . import functional as VF
