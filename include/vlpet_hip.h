@@ -259,6 +259,8 @@ int vlpet_visproj_fwd(const void* feats, const void* packed, const float* gamma,
 /* Weight gradient of the projection:  dw [d_out, F] = dpre^T @ feats,  db [d_out] = column sums of dpre
  * (dpre = gradient w.r.t. the pre-norm activations, [M, d_out], IO dtype).  fp32, overwritten. */
 size_t vlpet_visproj_wgrad_workspace_bytes(int64_t M, int feat_dim, int d_out);
+/* The same per IO dtype (the bf16 form keeps fp32 split-K partials: ~100 MB at feat_dim 2048 -> 768; the fp32 path needs a few MB). */
+size_t vlpet_visproj_wgrad_workspace_bytes_io(int64_t M, int feat_dim, int d_out, int io_dtype);
 int vlpet_visproj_wgrad(const void* dpre, const void* feats, float* dw, float* db,
                         void* workspace, size_t workspace_bytes,
                         int64_t M, int feat_dim, int d_out, int io_dtype, vlpet_stream_t stream);

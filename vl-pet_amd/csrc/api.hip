@@ -681,16 +681,21 @@ static void visproj_wgrad_plan(int64_t M, int feat_dim, int d_out, int* RT, int*
     wgrad_plan(M, 4, feat_dim, rc, rpc);
 }
 
-extern "C" size_t vlpet_visproj_wgrad_workspace_bytes(int64_t M, int feat_dim, int d_out) {
-    if (M <= 0 || feat_dim <= 0 || d_out <= 0) return 0;
+// The tiled split-K form (bf16, visproj_wgrad.hip) keeps one fp32 [d_out, feat_dim] partial per row chunk: 16 chunks x 6.3 MB = 100 MB at
+// feat_dim 2048 -> 768, written once and read once by the finalize launch (16.5 of the kernel's 87 us); the job-stream form of the
+// fp32 path needs a few MB.  The size is asked for per IO dtype; the dtype-less entry point returns the larger of the two.
+extern "C" size_t vlpet_visproj_wgrad_workspace_bytes_io(int64_t M, int feat_dim, int d_out, int io_dtype) {
+    if (M <= 0 || feat_dim <= 0 || d_out <= 0 || !dtype_ok(io_dtype)) return 0;
+    if (vlpet_tuning().k4_wgrad2 != 0 && k4_wgrad2_applies(M, feat_dim, d_out, io_dtype == VLPET_F32))
+        return align256(k4_wgrad2_workspace_bytes(M, feat_dim, d_out));
     int RT, pcols, rc; int64_t rpc;
     visproj_wgrad_plan(M, feat_dim, d_out, &RT, &pcols, &rc, &rpc);
-    size_t n = wgrad_workspace_bytes(4, RT, feat_dim, rc);
-    if (k4_wgrad2_applies(M, feat_dim, d_out, 0)) {                 // (dtype-independent size: the larger of the two forms)
-        const size_t n2 = k4_wgrad2_workspace_bytes(M, feat_dim, d_out);
-        if (n2 > n) n = n2;
-    }
-    return align256(n);
+    return align256(wgrad_workspace_bytes(4, RT, feat_dim, rc));
+}
+extern "C" size_t vlpet_visproj_wgrad_workspace_bytes(int64_t M, int feat_dim, int d_out) {
+    const size_t a = vlpet_visproj_wgrad_workspace_bytes_io(M, feat_dim, d_out, VLPET_BF16);
+    const size_t b = vlpet_visproj_wgrad_workspace_bytes_io(M, feat_dim, d_out, VLPET_F32);
+    return a > b ? a : b;
 }
 
 extern "C" int vlpet_visproj_wgrad(const void* dpre, const void* feats, float* dw, float* db, void* workspace,

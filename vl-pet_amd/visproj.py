@@ -137,7 +137,7 @@ class _VisProjFn(torch.autograd.Function):
                 from .functional import reduce_partials
                 reduce_partials(part, part.shape[0], d_out, dgamma, dbeta, deferrable=s_g is not None and (dbeta is None or s_be is not None))
         (dw, s_w), (db, s_b) = _grad_dest(w, (d_out, F)), _grad_dest(b, (d_out,))
-        nws = lib.vlpet_visproj_wgrad_workspace_bytes(M, F, d_out)
+        nws = lib.vlpet_visproj_wgrad_workspace_bytes_io(M, F, d_out, io)
         ws = torch.empty(nws, dtype=torch.uint8, device=ff.device)
         rc = _timed("k4_wgrad", M, lambda: lib.vlpet_visproj_wgrad(
             dpre_io.data_ptr(), ff.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, M, F, d_out, io,
