@@ -86,15 +86,17 @@ template <int RT, int SSN, bool DROP = false> struct DownGeo {
     static constexpr int BIAS_OFF = STG_OFF + 2 * 32 * PB;
     static constexpr int BITS_OFF = BIAS_OFF + 32 * RT * 4;          // DROP: NSLOT x SSN x [32 rows x 8 mask bytes]
     static constexpr int LDS = BITS_OFF + (DROP ? NSLOT * SSN * 256 : 0);
-    static constexpr int THREADS = (RT + 1) * 64;
+    static constexpr int NLD = RT == 6 ? 2 : 1;         // loader waves: at six tiles (one workgroup per CU, 13 of a wave's 41 k cycles spent at the
+                                                        // stage barrier behind ONE wave issuing 24 LDS-DMA instructions per sub-step) two share the rows
+    static constexpr int THREADS = (RT + NLD) * 64;
 };
 
 // NCH = chains (2: the gated K1, block parity = chain; 1: K2 / K3); ACT_ID: identity instead of gelu_new (K3; z only is saved);
 // DROP: a.drop.bits = packed keep flags of the chain input (K3)
 template <int RT, int SSN, int NCH, bool ACT_ID, bool DROP>
-__global__ __launch_bounds__((RT + 1) * 64, 2) void k1_down_kernel(PetFwdArgs a, int rows_per_block, int write_grad) {
+__global__ __launch_bounds__((RT + (RT == 6 ? 2 : 1)) * 64, 2) void k1_down_kernel(PetFwdArgs a, int rows_per_block, int write_grad) {
     using GEO = DownGeo<RT, SSN, DROP>;
-    constexpr int NSLOT = GEO::NSLOT, NPT = GEO::NPT, SUB_B = GEO::SUB_B, NI = GEO::NI, PB = GEO::PB;
+    constexpr int NSLOT = GEO::NSLOT, NPT = GEO::NPT, SUB_B = GEO::SUB_B, NI = GEO::NI, PB = GEO::PB, NLD = GEO::NLD, QN = 4 / NLD;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chain = NCH == 2 ? (int)(blockIdx.x & 1) : 0, rb = NCH == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
@@ -108,13 +110,15 @@ __global__ __launch_bounds__((RT + 1) * 64, 2) void k1_down_kernel(PetFwdArgs a,
     const PackGeom pg = pack_geom(RT, F2_D, 1);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
 
-    if (wave == RT) {
-        // ---------------------------------------------------------------- loader wave: every global_load_lds of the workgroup
+    if (wave >= RT) {
+        // ---------------------------------------------------------------- loader wave(s): every global_load_lds of the workgroup
+        // (NLD = 2: loader ld brings the row groups q = 2 ld, 2 ld + 1 of every stage; the mask words travel with loader 0)
+        const int ld = wave - RT;
         // sub-step i = (row tile i / NPT, feature part i % NPT): SSN stages x 4 instructions of 8 rows x 128 B; slot = piece ^ swz(row)
-        uint32_t roff[4];
+        uint32_t roff[QN];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 8 * i + (lane >> 3);
+        for (int i = 0; i < QN; ++i) {
+            const int row = 8 * (ld * QN + i) + (lane >> 3);
             roff[i] = (uint32_t)row * (uint32_t)(F2_D * 2) + (uint32_t)(((lane & 7) ^ swz(row)) * 16);
         }
         auto issue = [&](int i) {
@@ -123,13 +127,14 @@ __global__ __launch_bounds__((RT + 1) * 64, 2) void k1_down_kernel(PetFwdArgs a,
             const uint8_t* src = x + row0 * (F2_D * 2) + (i % NPT) * (SSN * 128);
             uint8_t* dst = smem + (size_t)(i % NSLOT) * SUB_B;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int qq = 0; qq < QN; ++qq) {
+                const int q = ld * QN + qq;
                 const int row = 8 * q + (lane >> 3);
-                const uint32_t o = roff[q] - (uint32_t)(row > last ? row - last : 0) * (uint32_t)(F2_D * 2);
+                const uint32_t o = roff[qq] - (uint32_t)(row > last ? row - last : 0) * (uint32_t)(F2_D * 2);
 #pragma unroll
                 for (int st = 0; st < SSN; ++st) glds16_row(src + o + st * 128, dst + st * 4096 + q * 1024);
             }
-            if constexpr (DROP) {
+            if (DROP && ld == 0) {
                 // mask words of the sub-step: lane L brings the dword of (row L / 2, half L % 2) of each stage -- the four bytes
                 // of the k-steps u = 0..3 of compute lane (m = row, h = half) in the packed layout (rng.h drop_pos)
                 int brow = lane >> 1;
@@ -148,7 +153,8 @@ __global__ __launch_bounds__((RT + 1) * 64, 2) void k1_down_kernel(PetFwdArgs a,
         for (int i = 0; i < nss; ++i) {
             int ahead = nss - 1 - i;                                      // sub-steps already requested beyond i
             if (ahead > NSLOT - 2) ahead = NSLOT - 2;
-            switch (ahead) {
+            if constexpr (NLD > 1) vm_wait(ahead * (QN * SSN + ((DROP && ld == 0) ? SSN : 0)));    // (this loader's instructions per sub-step)
+            else switch (ahead) {
                 case 0: vmw<0>(); break;
                 case 1: vmw<NI>(); break;
                 case 2: vmw<2 * NI>(); break;
