@@ -52,6 +52,8 @@ CASES = [  # B, Lq, Lk, causal, masked, p
     (44, 70, 40, False, True, 0.0),
     (90, 33, 97, False, False, 0.5),
     (44, 128, 128, False, True, 0.1),
+    (90, 20, 20, True, True, 0.1),          # decoder self-attention: causal + padding mask + dropout over several rounds
+    (90, 20, 56, False, False, 0.0),
 ]
 
 
