@@ -64,7 +64,10 @@ def test_short_attention_matches_the_eager_chain(B, Lq, Lk, causal, masked, p):
     mk = lambda L: (torch.randn(B, L, H * 64, generator=g) * 1.5).bfloat16()
     q, k, v, do = mk(Lq), mk(Lk), mk(Lk), mk(Lq)
     key_mask = None
-    if masked:
+    if masked and causal:                                       # decoder self-attention: padding is a suffix (key 0 is visible to every query)
+        lens = torch.randint(1, Lk + 1, (B,), generator=g)
+        key_mask = torch.arange(Lk)[None, :] < lens[:, None]
+    elif masked:
         key_mask = torch.rand(B, Lk, generator=g) > 0.25
         key_mask[:, -1] = True                                  # (at least one key per row)
     qg, kg, vg = (t.cuda().requires_grad_(True) for t in (q, k, v))
