@@ -52,7 +52,62 @@ __global__ __launch_bounds__(256) void downsample_kernel(PoolArgs a) {
     }
 }
 
+// The same through LDS: a workgroup owns (image, 256-channel slab), reads the slab of every input token ONCE (whole 1 KiB rows), and
+// forms the outputs from the LDS copy.  The gather kernel above asks the memory system for every window separately: at 7 -> 6 each
+// input token is requested by up to four windows (2.9x the bytes through L2 / TA: 98 us for 274 MB at B = 500).  fp32 in, bf16 / fp32 out.
+template <typename OUT>
+__global__ __launch_bounds__(256) void downsample_slab_kernel(PoolArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];          // [s_in * s_in][256]
+    const int slabs = a.dim / 256;
+    const int64_t img = blockIdx.x / slabs;
+    const int slab = (int)(blockIdx.x % slabs);
+    const int ntok = a.s_in * a.s_in, nout = a.s_out * a.s_out;
+    const int tid = threadIdx.x;
+    const float* src = reinterpret_cast<const float*>(a.x) + img * (int64_t)ntok * a.dim + slab * 256;
+    for (int i = tid; i < ntok * 64; i += 256) {                          // 64 float4 per token row
+        const int t = i >> 6, c4 = i & 63;
+        reinterpret_cast<f32x4*>(tile)[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)t * a.dim + 4 * c4);
+    }
+    __syncthreads();
+    const int cg = tid & 31;                                              // 8 channels
+    for (int o = tid >> 5; o < nout; o += 8) {
+        const int oi = o / a.s_out, oj = o % a.s_out;
+        const int h0 = (oi * a.s_in) / a.s_out, h1 = ((oi + 1) * a.s_in + a.s_out - 1) / a.s_out;
+        const int w0 = (oj * a.s_in) / a.s_out, w1 = ((oj + 1) * a.s_in + a.s_out - 1) / a.s_out;
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+        for (int hh = h0; hh < h1; ++hh)
+            for (int ww = w0; ww < w1; ++ww) {
+                const f32x4* p = reinterpret_cast<const f32x4*>(tile + (hh * a.s_in + ww) * 256 + cg * 8);
+                const f32x4 lo = p[0], hi = p[1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    m[j] = (lo[j] > m[j] || lo[j] != lo[j]) ? lo[j] : m[j];          // NaN propagates like torch
+                    m[4 + j] = (hi[j] > m[4 + j] || hi[j] != hi[j]) ? hi[j] : m[4 + j];
+                }
+            }
+        OUT* q = reinterpret_cast<OUT*>(a.out) + (img * nout + o) * (int64_t)a.dim + slab * 256 + cg * 8;
+        if constexpr (sizeof(OUT) == 4) {
+            const f32x4 lo = {m[0], m[1], m[2], m[3]}, hi = {m[4], m[5], m[6], m[7]};
+            *reinterpret_cast<f32x4*>(q) = lo; *reinterpret_cast<f32x4*>(q + 4) = hi;
+        } else {
+            bf16x8 t;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = (__bf16)m[j];
+            *reinterpret_cast<bf16x8*>(q) = t;
+        }
+    }
+}
+
 hipError_t launch_downsample(const PoolArgs& a, int in_fp32, int out_fp32, hipStream_t stream) {
+    const size_t slab_lds = (size_t)a.s_in * a.s_in * 256 * 4;
+    if (in_fp32 && a.dim % 256 == 0 && slab_lds <= 64 * 1024 && a.n_img * (a.dim / 256) <= 0x7fffffff) {
+        const dim3 g((unsigned)(a.n_img * (a.dim / 256))), b(256);
+        if (out_fp32) hipLaunchKernelGGL((downsample_slab_kernel<float>), g, b, slab_lds, stream, a);
+        else hipLaunchKernelGGL((downsample_slab_kernel<__bf16>), g, b, slab_lds, stream, a);
+        return hipGetLastError();
+    }
     const int64_t total = a.n_img * a.s_out * a.s_out * (a.dim / 8);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
