@@ -156,6 +156,8 @@ _KM_CACHE: list = []
 def _key_mask_u8(key_mask: torch.Tensor, B: int, L: int) -> torch.Tensor:
     if key_mask.dtype == torch.uint8 and key_mask.shape == (B, L) and key_mask.is_contiguous():
         return key_mask
+    if key_mask.is_inference():             # tensors made under torch.inference_mode() track no version: nothing to key the cache on
+        return key_mask.reshape(B, L).to(torch.uint8).contiguous()
     for src, ver, out in _KM_CACHE:
         if (src.data_ptr() == key_mask.data_ptr() and ver == key_mask._version and src.dtype == key_mask.dtype
                 and src.shape == key_mask.shape and src.stride() == key_mask.stride() and out.shape == (B, L)):

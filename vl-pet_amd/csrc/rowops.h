@@ -2,6 +2,9 @@
 // owns the 16-byte pieces lane, lane + 64, ... of the row (whole 128-byte lines per 8 lanes).
 #pragma once
 #include "common.h"
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -9,9 +12,23 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <typename IO> struct Piece {
-    static constexpr int E = 16 / (int)sizeof(IO);     // elements per 16-byte piece (8 bf16 / 4 fp32)
+// PB = bytes of a piece: 16 (8 bf16 / 4 fp32), or 8 for bf16 rows whose 16-byte pieces leave lanes idle (round 5: d = 768 is 96
+// 16-byte pieces -- lanes 32..63 own one piece, lanes 0..31 two, every per-lane array is sized for two -- but 192 8-byte pieces =
+// three per lane exactly: 12 elements per lane instead of 16 slots, a quarter fewer registers and no idle half wave).
+// two sums at once (the shuffles of the two chains interleave)
+__device__ __forceinline__ void wave_sum2(float a, float b, float& ra, float& rb) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    ra = a; rb = b;
+}
+
+template <typename IO, int PB = 16> struct Piece {
+    static constexpr int E = PB / (int)sizeof(IO);     // elements per piece
+    static constexpr int B = PB;
+    static_assert(PB == 16 || (PB == 8 && sizeof(IO) == 2), "8-byte pieces are the bf16 form");
+    using Raw = typename std::conditional<PB == 16, u32x4, u32x2>::type;
     static __device__ __forceinline__ void load(const void* p, float* v) {
+        static_assert(PB == 16, "");
         if constexpr (E == 8) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
@@ -23,11 +40,14 @@ template <typename IO> struct Piece {
         }
     }
     // the same piece kept raw (a prefetched row lives in registers unconverted)
-    static __device__ __forceinline__ u32x4 load_raw(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
-    static __device__ __forceinline__ void from_raw(const u32x4& r, float* v) {
-        if constexpr (E == 8) {
+    static __device__ __forceinline__ Raw load_raw(const void* p) { return *reinterpret_cast<const Raw*>(p); }
+    // the same load with the non-temporal policy: a row tensor one wave reads once (tools/bw_probe.hip: cold streams read at
+    // 4.5 TB/s with it against 2.4-2.6 TB/s with the default policy)
+    static __device__ __forceinline__ Raw load_raw_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const Raw*>(p)); }
+    static __device__ __forceinline__ void from_raw(const Raw& r, float* v) {
+        if constexpr (sizeof(IO) == 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < PB / 4; ++i) {
                 const unsigned int u = r[i];
                 v[2 * i] = __builtin_bit_cast(float, u << 16);
                 v[2 * i + 1] = __builtin_bit_cast(float, u & 0xffff0000u);
@@ -38,7 +58,11 @@ template <typename IO> struct Piece {
         }
     }
     static __device__ __forceinline__ void store(void* p, const float* v) {
-        if constexpr (E == 8) {
+        if constexpr (PB == 8) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+            const bf16x4_t a = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *reinterpret_cast<bf16x4_t*>(p) = a;
+        } else if constexpr (E == 8) {
             bf16x8 a;
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = (__bf16)v[j];

@@ -22,12 +22,43 @@
 
 constexpr int TAIL_WAVES = 4;
 
+// Keep flags of this lane's NP pieces (piece k = elements row_e0 + E (lane + 64 k) ..) of one row; bit j of kb[k] = element j kept.
+// E = 8: a piece is one generator group.  E = 4 (fp32 IO, or the 8-byte bf16 pieces): a piece is HALF a group and lanes 2j, 2j + 1
+// own the two halves of the same groups -- instead of one generator call per piece in both lanes (NP calls), the even lane draws
+// the groups of pieces k = 0, 2, .. and the odd lane those of k = 1, 3, .. (ceil(NP / 2) calls per lane) and each fetches the other's
+// word with a quad-permute.  The mask is the same function of (seed, element index) either way.
+template <int NP, int E>
+__device__ __forceinline__ void row_keep_bits(int64_t row_e0, int lane, int pieces, uint64_t seed, uint32_t thr, uint32_t (&kb)[NP]) {
+    if constexpr (E == 8) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = lane + 64 * k;
+            kb[k] = p < pieces ? keep8((row_e0 + (int64_t)p * 8) >> 3, seed, thr) : 0u;
+        }
+    } else {
+        static_assert(E == 4, "pieces of 4 or 8 elements");
+        const int par = lane & 1, half = 4 * par;
+#pragma unroll
+        for (int c = 0; c < (NP + 1) / 2; ++c) {
+            int k = 2 * c + par;
+            if (k >= NP) k = NP - 1;                               // (odd NP: the odd lane repeats the last even piece's group)
+            const int p = (lane & ~1) + 64 * k;                    // even piece of the pair = first element of the group
+            const uint32_t mine = keep8((row_e0 + (int64_t)p * 4) >> 3, seed, thr);
+            const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);     // lane ^ 1 (quad_perm [1,0,3,2])
+            // piece 2c belongs to the even lane's call, piece 2c + 1 to the odd lane's
+            kb[2 * c] = ((par == 0 ? mine : other) >> half) & 0xfu;
+            if (2 * c + 1 < NP) kb[2 * c + 1] = ((par == 1 ? mine : other) >> half) & 0xfu;
+        }
+    }
+}
+
 // POST (NORM only): out = LayerNorm(dropout(y)) + x1 -- the residual joins AFTER the norm (visual projectors:
 // src/modeling_bart.py:298-299 then :324-325); statistics and the saved pre-norm tensor are those of dropout(y) alone.
-template <typename IO, int NP, bool NORM, bool POST = false>
+template <typename IO, int NP, bool NORM, bool POST = false, int PB = 16>
 __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
     static_assert(!POST || NORM, "post-norm residual needs the norm");
-    using P = Piece<IO>;
+    using P = Piece<IO, PB>;
+    using Raw = typename P::Raw;
     constexpr int E = P::E;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int d = a.d, pieces = d / E;
@@ -54,14 +85,14 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
     // the next row of this wave is requested before the current one is reduced: a wave that loads, reduces, stores
     // and only then loads again has nothing in flight half of the time (2.8-3.3 TB/s before)
     const int64_t rstride = (int64_t)gridDim.x * TAIL_WAVES;
-    u32x4 cy[NP], cx[NP];
-    auto load_row = [&](int64_t r, u32x4 (&ry)[NP], u32x4 (&rx)[NP]) {
+    Raw cy[NP], cx[NP];
+    auto load_row = [&](int64_t r, Raw (&ry)[NP], Raw (&rx)[NP]) {
         if (r >= a.M) r = a.M - 1;                  // unconditional (clamped) loads keep the vmcnt waits counted
         const int64_t o = r * d * (int64_t)sizeof(IO);
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = lane + 64 * k;
-            if (p < pieces) { if (y) ry[k] = P::load_raw(y + o + p * 16); rx[k] = P::load_raw(x1 + o + p * 16); }
+            if (p < pieces) { if (y) ry[k] = P::load_raw_nt(y + o + p * PB); rx[k] = P::load_raw_nt(x1 + o + p * PB); }
         }
     };
     {
@@ -70,11 +101,13 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
     }
     for (int64_t row = (int64_t)blockIdx.x * TAIL_WAVES + wave; row < a.M; row += rstride) {
         const int64_t rb = row * d * (int64_t)sizeof(IO);
-        u32x4 ny[NP], nx[NP];
+        Raw ny[NP], nx[NP];
         load_row(row + rstride, ny, nx);
         float h[NP][E];
         float xpost[POST ? NP : 1][E];
         float s = 0.f;
+        uint32_t kb[NP];
+        if (thr) row_keep_bits<NP, E>(row * d, lane, pieces, seed, thr, kb);
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = lane + 64 * k;
@@ -90,11 +123,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
 #pragma unroll
                     for (int j = 0; j < E; ++j) { xpost[k][j] = vx[j]; vx[j] = 0.f; }
                 }
-                uint32_t bits = 0xffu;
-                if (thr) {
-                    const int64_t e0 = row * d + (int64_t)p * E;
-                    bits = keep8(e0 >> 3, seed, thr) >> (e0 & 7);       // fp32 piece = half a group
-                }
+                const uint32_t bits = thr ? kb[k] : 0xffu;
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
                     h[k][j] = vx[j] + (((bits >> j) & 1u) ? vy[j] * scale : 0.f);
@@ -125,7 +154,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
             for (int k = 0; k < NP; ++k) {
                 const int p = lane + 64 * k;
                 if (p < pieces) {
-                    if (hs) P::store(hs + rb + p * 16, h[k]);
+                    if (hs) P::store(hs + rb + p * PB, h[k]);
                     float o[E];
 #pragma unroll
                     for (int j = 0; j < E; ++j) o[j] = (h[k][j] - mean) * rstd * gam[k][j] + bet[k][j];
@@ -133,14 +162,14 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
 #pragma unroll
                         for (int j = 0; j < E; ++j) o[j] += xpost[k][j];
                     }
-                    P::store(out + rb + p * 16, o);
+                    P::store(out + rb + p * PB, o);
                 }
             }
         } else {
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int p = lane + 64 * k;
-                if (p < pieces) P::store(out + rb + p * 16, h[k]);
+                if (p < pieces) P::store(out + rb + p * PB, h[k]);
             }
         }
 #pragma unroll
@@ -153,34 +182,56 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
 // HOUT (NORM only, round 4): `h` holds the LayerNorm OUTPUT rows (what the next sublayer keeps anyway) instead of the pre-norm sum,
 // and the normalised rows are recovered as xhat = (out - beta) / gamma (0 where gamma is 0): the forward then writes ONE row tensor
 // (out) instead of two (out and h) -- 3 units of traffic instead of 4.
-template <typename IO, int NP, bool NORM, bool HOUT = false>
+// Round 5: the per-column constants (gamma; HOUT: 1 / gamma and beta / gamma too) live in LDS, one piece-sized vector per lane and
+// piece, and are fetched where a sweep uses them; what stays in registers for the whole launch are the dgamma / dbeta sums only.
+// With 8-byte pieces at d = 768 (three per lane, every lane busy) the HOUT form went from 196 registers / 2 waves per SIMD to <= 128 / 4.
+// The row is swept twice from its raw registers (sums first, then the gradient: g and xhat are recomputed per piece instead of being
+// held across the wave reduction -- 24 registers at d = 768), DRES (the parked gradient of T5's norm link) is a template flag.
+template <typename IO, int NP, bool NORM, bool HOUT = false, int PB = 16, bool DRES = false>
 __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
     static_assert(!HOUT || NORM, "recovering xhat from the output needs the norm");
-    using P = Piece<IO>;
+    using P = Piece<IO, PB>;
+    using Raw = typename P::Raw;
     constexpr int E = P::E;
-    __shared__ float red[TAIL_WAVES][2];
+    constexpr int NPRM = NORM ? (HOUT ? 3 : 1) : 0;                 // gamma [, 1 / gamma, beta / gamma]
+    constexpr int PRM_F = NPRM * NP * 64 * E, ACC_F = TAIL_WAVES * 2 * 64 * E;
+    __shared__ __attribute__((aligned(16))) float sm[(PRM_F > ACC_F ? PRM_F : ACC_F) > 0 ? (PRM_F > ACC_F ? PRM_F : ACC_F) : 4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int d = a.d, pieces = d / E;
     const uint32_t thr = a.thr;
     const uint64_t seed = thr ? vlpet_eff_seed(a.seed, a.seed_ctr) : 0;      // (one scalar load, before the row loop)
     const float scale = a.keep_scale;
-    float gam[NORM ? NP : 1][E], dg[NORM ? NP : 1][E], db[NORM ? NP : 1][E];
-    float bet[HOUT ? NP : 1][E], ginv[HOUT ? NP : 1][E];
+    float dg[NORM ? NP : 1][E], db[NORM ? NP : 1][E];
     if constexpr (NORM) {
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int p = lane + 64 * k;
+        // slot (arr, k, lane) of the parameter area holds the E values of piece lane + 64 k
+        for (int q = threadIdx.x; q < NP * 64; q += TAIL_WAVES * 64) {
+            const int p = q;                                        // piece index = lane' + 64 k'  (q = 64 k' + lane')
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                gam[k][j] = p < pieces ? a.gamma[p * E + j] : 0.f;
-                dg[k][j] = 0.f; db[k][j] = 0.f;
+                const float gm = p < pieces ? a.gamma[p * E + j] : 0.f;
+                sm[q * E + j] = gm;
                 if constexpr (HOUT) {
-                    bet[k][j] = (p < pieces && a.beta) ? a.beta[p * E + j] : 0.f;
-                    ginv[k][j] = gam[k][j] != 0.f ? 1.0f / gam[k][j] : 0.f;
+                    const float gi = gm != 0.f ? 1.0f / gm : 0.f;
+                    const float be = (p < pieces && a.beta) ? a.beta[p * E + j] : 0.f;
+                    sm[(NP * 64 + q) * E + j] = gi;
+                    sm[(2 * NP * 64 + q) * E + j] = be * gi;
                 }
             }
         }
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+#pragma unroll
+            for (int j = 0; j < E; ++j) { dg[k][j] = 0.f; db[k][j] = 0.f; }
+        __syncthreads();
     }
+    auto prm = [&](int arr, int k, float* v) {                      // this lane's piece k of parameter vector `arr`
+        const float* src = sm + ((arr * NP + k) * 64 + lane) * E;
+#pragma unroll
+        for (int j = 0; j < E; j += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(src + j);
+            v[j] = t[0]; v[j + 1] = t[1]; v[j + 2] = t[2]; v[j + 3] = t[3];
+        }
+    };
     const uint8_t* dout = reinterpret_cast<const uint8_t*>(a.out);     // `out` carries dout in the backward
     const uint8_t* hs = reinterpret_cast<const uint8_t*>(a.h);
     uint8_t* dx1 = reinterpret_cast<uint8_t*>(const_cast<void*>(a.x1));
@@ -188,9 +239,9 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
     const float inv_d = 1.0f / (float)d;
     const int64_t rstride = (int64_t)gridDim.x * TAIL_WAVES;
     const uint8_t* dres = reinterpret_cast<const uint8_t*>(a.dres);
-    u32x4 cd[NP], ch[NORM ? NP : 1], cr[NP];
+    Raw cd[NP], ch[NORM ? NP : 1], cr[DRES ? NP : 1];
     float cmean = 0.f, crstd = 1.f;
-    auto load_row = [&](int64_t r, u32x4 (&rd)[NP], u32x4 (&rh)[NORM ? NP : 1], u32x4 (&rr)[NP], float& mu, float& rs) {
+    auto load_row = [&](int64_t r, Raw (&rd)[NP], Raw (&rh)[NORM ? NP : 1], Raw (&rr)[DRES ? NP : 1], float& mu, float& rs) {
         if (r >= a.M) r = a.M - 1;                  // next row of this wave, requested one row ahead (see the forward)
         const int64_t o = r * d * (int64_t)sizeof(IO);
         if constexpr (NORM) { mu = (HOUT || a.h_xhat || a.rms) ? 0.f : a.mean[r]; rs = a.rstd[r]; }
@@ -198,9 +249,9 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
         for (int k = 0; k < NP; ++k) {
             const int p = lane + 64 * k;
             if (p < pieces) {
-                rd[k] = P::load_raw(dout + o + p * 16);
-                if constexpr (NORM) rh[k] = P::load_raw(hs + o + p * 16);
-                if (dres) rr[k] = P::load_raw(dres + o + p * 16);
+                rd[k] = P::load_raw_nt(dout + o + p * PB);
+                if constexpr (NORM) rh[k] = P::load_raw_nt(hs + o + p * PB);
+                if constexpr (DRES) rr[k] = P::load_raw_nt(dres + o + p * PB);
             }
         }
     };
@@ -210,96 +261,103 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
     }
     for (int64_t row = (int64_t)blockIdx.x * TAIL_WAVES + wave; row < a.M; row += rstride) {
         const int64_t rb = row * d * (int64_t)sizeof(IO);
-        u32x4 nd[NP], nh[NORM ? NP : 1], nr[NP];
+        Raw nd[NP], nh[NORM ? NP : 1], nr[DRES ? NP : 1];
         float nmean = 0.f, nrstd = 1.f;
         load_row(row + rstride, nd, nh, nr, nmean, nrstd);
-        float g[NP][E], xh[NORM ? NP : 1][E];
         float s1 = 0.f, s2 = 0.f;
         const float mean = cmean, rstd = crstd;
         const float rin = a.h_xhat ? 1.f : rstd;            // (rows already normalised: K4's saved xhat)
+        // g = dout * gamma and xhat of piece k, from the raw registers
+        auto piece_gx = [&](int k, float* gq, float* xq, float* vd) {
+            float vh[E], gm[E];
+            P::from_raw(cd[k], vd);
+            P::from_raw(ch[k], vh);
+            prm(0, k, gm);
+            if constexpr (HOUT) {
+                float gi[E], bg[E];
+                prm(1, k, gi); prm(2, k, bg);
+#pragma unroll
+                for (int j = 0; j < E; ++j) xq[j] = vh[j] * gi[j] - bg[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < E; ++j) xq[j] = (vh[j] - mean) * rin;
+            }
+#pragma unroll
+            for (int j = 0; j < E; ++j) gq[j] = vd[j] * gm[j];
+        };
+        float c1 = 0.f, c2 = 0.f;
+        if constexpr (NORM) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if (lane + 64 * k < pieces) {
+                    float gq[E], xq[E], vd[E];
+                    piece_gx(k, gq, xq, vd);
+#pragma unroll
+                    for (int j = 0; j < E; ++j) {
+                        s1 += gq[j];
+                        s2 += gq[j] * xq[j];
+                        dg[k][j] += vd[j] * xq[j];
+                        db[k][j] += vd[j];
+                    }
+                }
+            }
+            wave_sum2(s1, s2, c1, c2);
+            c1 = a.rms ? 0.f : c1 * inv_d; c2 *= inv_d;
+        }
+        uint32_t kb[NP];
+        if (thr) row_keep_bits<NP, E>(row * d, lane, pieces, seed, thr, kb);
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = lane + 64 * k;
             if (p < pieces) {
-                float vd[E];
-                P::from_raw(cd[k], vd);
+                float g[E];
                 if constexpr (NORM) {
-                    float vh[E];
-                    P::from_raw(ch[k], vh);
+                    float xq[E], vd[E];
+                    piece_gx(k, g, xq, vd);
 #pragma unroll
-                    for (int j = 0; j < E; ++j) {
-                        if constexpr (HOUT) xh[k][j] = (vh[j] - bet[k][j]) * ginv[k][j];
-                        else xh[k][j] = (vh[j] - mean) * rin;
-                        g[k][j] = vd[j] * gam[k][j];
-                        s1 += g[k][j];
-                        s2 += g[k][j] * xh[k][j];
-                        dg[k][j] += vd[j] * xh[k][j];
-                        db[k][j] += vd[j];
-                    }
+                    for (int j = 0; j < E; ++j) g[j] = (g[j] - c1 - xq[j] * c2) * rstd;
                 } else {
-#pragma unroll
-                    for (int j = 0; j < E; ++j) g[k][j] = vd[j];
+                    P::from_raw(cd[k], g);
                 }
-            }
-        }
-        if constexpr (NORM) {
-            const float c1 = a.rms ? 0.f : wave_sum(s1) * inv_d, c2 = wave_sum(s2) * inv_d;
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                if (lane + 64 * k < pieces) {
-#pragma unroll
-                    for (int j = 0; j < E; ++j) g[k][j] = (g[k][j] - c1 - xh[k][j] * c2) * rstd;
-                }
-            }
-        }
-        if (dres) {                                  // the parked gradient of the other reader of this input
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                if (lane + 64 * k < pieces) {
+                if constexpr (DRES) {                    // the parked gradient of the other reader of this input
                     float vr[E];
                     P::from_raw(cr[k], vr);
 #pragma unroll
-                    for (int j = 0; j < E; ++j) g[k][j] += vr[j];
+                    for (int j = 0; j < E; ++j) g[j] += vr[j];
                 }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int p = lane + 64 * k;
-            if (p < pieces) {
-                P::store(dx1 + rb + p * 16, g[k]);
+                P::store(dx1 + rb + p * PB, g);
                 if (thr) {
-                    const int64_t e0 = row * d + (int64_t)p * E;
-                    const uint32_t bits = keep8(e0 >> 3, seed, thr) >> (e0 & 7);
+                    const uint32_t bits = kb[k];
                     float o[E];
 #pragma unroll
-                    for (int j = 0; j < E; ++j) o[j] = ((bits >> j) & 1u) ? g[k][j] * scale : 0.f;
-                    P::store(dy + rb + p * 16, o);
+                    for (int j = 0; j < E; ++j) o[j] = ((bits >> j) & 1u) ? g[j] * scale : 0.f;
+                    P::store(dy + rb + p * PB, o);
                 }
             }
         }
 #pragma unroll
-        for (int k = 0; k < NP; ++k) { cd[k] = nd[k]; if constexpr (NORM) ch[k] = nh[k]; cr[k] = nr[k]; }
+        for (int k = 0; k < NP; ++k) { cd[k] = nd[k]; if constexpr (NORM) ch[k] = nh[k]; if constexpr (DRES) cr[k] = nr[k]; }
         cmean = nmean; crstd = nrstd;
     }
     if constexpr (NORM) {
         if (a.dgb) {
-            // partial sums of this workgroup: [blockIdx][2][d]; waves combined through LDS one piece at a time
-            __shared__ float acc[TAIL_WAVES][2][64 * 8];
-            (void)red;
+            // partial sums of this workgroup: [blockIdx][2][d]; waves combined through LDS one piece at a time (the parameter
+            // area is dead by now: every wave is past its last row)
+            __syncthreads();
+            float* acc = sm;                                        // [TAIL_WAVES][2][64 * E]
             float* dst = a.dgb + (size_t)blockIdx.x * 2 * d;
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int p = lane + 64 * k;
 #pragma unroll
-                for (int j = 0; j < E; ++j) { acc[wave][0][lane * 8 + j] = dg[k][j]; acc[wave][1][lane * 8 + j] = db[k][j]; }
+                for (int j = 0; j < E; ++j) { acc[(wave * 2 + 0) * 64 * E + lane * E + j] = dg[k][j]; acc[(wave * 2 + 1) * 64 * E + lane * E + j] = db[k][j]; }
                 __syncthreads();
                 if (wave == 0 && p < pieces) {
 #pragma unroll
                     for (int j = 0; j < E; ++j) {
                         float sg = 0.f, sb = 0.f;
 #pragma unroll
-                        for (int w = 0; w < TAIL_WAVES; ++w) { sg += acc[w][0][lane * 8 + j]; sb += acc[w][1][lane * 8 + j]; }
+                        for (int w = 0; w < TAIL_WAVES; ++w) { sg += acc[(w * 2 + 0) * 64 * E + lane * E + j]; sb += acc[(w * 2 + 1) * 64 * E + lane * E + j]; }
                         dst[p * E + j] = sg; dst[d + p * E + j] = sb;
                     }
                 }
@@ -479,40 +537,58 @@ int tail_blocks(int64_t M) {
     const int64_t need = (M + TAIL_WAVES - 1) / TAIL_WAVES;
     int64_t cap = M / 12;
     if (cap < 256) cap = 256;
-    if (cap > 768) cap = 768;
+    if (cap > 1024) cap = 1024;                 // (round 5: the row kernels fit four workgroups per CU; 768 -> 1024 is 2-4 % at 28,000+ rows, profiles/r05_k5abi_ab.txt)
     if (VLPET_IS_DEBUG_BUILD && vlpet_tuning().dbg >= 64) cap = vlpet_tuning().dbg;      // (diagnosis: VLPET_DBG = cap)
     return (int)(need < cap ? need : cap);
 }
 
-template <typename IO, int NP, bool NORM>
+template <typename IO, int NP, bool NORM, int PB>
 static hipError_t launch_np(const TailArgs& a, bool bwd, hipStream_t stream) {
     const int blocks = tail_blocks(a.M);
     if (bwd && NORM && a.h_out) {
-        if constexpr (NORM) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, true, true>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+        if constexpr (NORM) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, true, true, PB>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
     }
-    else if (bwd) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, NORM>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+    else if (bwd && a.dres) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, NORM, false, PB, true>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+    else if (bwd) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, NORM, false, PB>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
     else if (NORM && a.post) {
-        if constexpr (NORM) hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, true, true>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+        if constexpr (NORM) hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, true, true, PB>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
     }
-    else hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, NORM>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+    else hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, NORM, false, PB>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
     return hipGetLastError();
+}
+
+// Piece size of a bf16 row: 8-byte pieces when they leave fewer per-lane element slots than 16-byte ones (d = 768: 3 x 4 = 12
+// against 2 x 8 = 16 with half the wave idle on the second piece); ties go to the wider loads.
+static bool tail_pieces8(int d) {
+    if (d % 4 != 0) return false;
+    const int np16 = (d / 8 + 63) / 64, np8 = (d / 4 + 63) / 64;
+    return d % 8 == 0 && np8 <= 4 && np8 * 4 < np16 * 8;
 }
 
 template <typename IO, bool NORM>
 static hipError_t launch_io(const TailArgs& a, bool bwd, hipStream_t stream) {
+    if constexpr (sizeof(IO) == 2) {
+        if (tail_pieces8(a.d)) {
+            const int np = (a.d / 4 + 63) / 64;
+            if (np <= 1) return launch_np<IO, 1, NORM, 8>(a, bwd, stream);
+            if (np <= 2) return launch_np<IO, 2, NORM, 8>(a, bwd, stream);
+            if (np <= 3) return launch_np<IO, 3, NORM, 8>(a, bwd, stream);
+            return launch_np<IO, 4, NORM, 8>(a, bwd, stream);
+        }
+    }
     const int pieces = a.d / Piece<IO>::E;
     const int np = (pieces + 63) / 64;
-    if (np <= 1) return launch_np<IO, 1, NORM>(a, bwd, stream);
-    if (np <= 2) return launch_np<IO, 2, NORM>(a, bwd, stream);
-    if (np <= 3) return launch_np<IO, 3, NORM>(a, bwd, stream);
-    if (np <= 4) return launch_np<IO, 4, NORM>(a, bwd, stream);
-    if (np <= 8) return launch_np<IO, 8, NORM>(a, bwd, stream);
+    if (np <= 1) return launch_np<IO, 1, NORM, 16>(a, bwd, stream);
+    if (np <= 2) return launch_np<IO, 2, NORM, 16>(a, bwd, stream);
+    if (np <= 3) return launch_np<IO, 3, NORM, 16>(a, bwd, stream);
+    if (np <= 4) return launch_np<IO, 4, NORM, 16>(a, bwd, stream);
+    if (np <= 8) return launch_np<IO, 8, NORM, 16>(a, bwd, stream);
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_tail(const TailArgs& a, int io_fp32, bool bwd, hipStream_t stream) {
     if (a.post && (!a.norm || bwd)) return hipErrorInvalidValue;      // forward-only form of the norm path
-    if (a.h_out && (!a.norm || !bwd || a.rms || a.h_xhat)) return hipErrorInvalidValue;
+    if (a.h_out && (!a.norm || !bwd || a.rms || a.h_xhat || a.dres)) return hipErrorInvalidValue;
     if (a.norm) return io_fp32 ? launch_io<float, true>(a, bwd, stream) : launch_io<__bf16, true>(a, bwd, stream);
     return io_fp32 ? launch_io<float, false>(a, bwd, stream) : launch_io<__bf16, false>(a, bwd, stream);
 }

@@ -137,7 +137,9 @@ class PackedPair:
 
 def pack_pair(down_w: Sequence[torch.Tensor], down_b: Optional[Sequence[torch.Tensor]],
               up_w: torch.Tensor, up_b: Optional[torch.Tensor], io_dtype: int,
-              tiles: Optional[int] = None) -> PackedPair:
+              tiles: Optional[int] = None, out: Optional["PackedPair"] = None) -> PackedPair:
+    """``out``: an earlier pack of the same geometry to refresh IN PLACE (its buffer may be baked into a captured graph: a cache that
+    answered a miss with a new buffer would leave the graph reading the old one -- or freed memory)."""
     lib = _lib.load()
     _need_cuda(up_w, *down_w)
     n = len(down_w)
@@ -156,7 +158,11 @@ def pack_pair(down_w: Sequence[torch.Tensor], down_b: Optional[Sequence[torch.Te
         if _param_dtype(t) != pd:
             raise RuntimeError("vl-pet_amd: mixed parameter dtypes in one projection pair")
     nbytes = lib.vlpet_packed_bytes(tiles, d, io_dtype)
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=uw.device)
+    if (out is not None and out.buf.numel() == nbytes and out.buf.device == uw.device and out.tiles == tiles and out.r == r
+            and out.d == d and out.io_dtype == io_dtype):
+        buf = out.buf
+    else:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=uw.device)
     arr_w = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
     arr_b = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bs]) if bs is not None else None
     rc = lib.vlpet_pack_pair(arr_w, arr_b, n, uw.data_ptr(), _ptr(ub), r, d, tiles, pd, io_dtype,
@@ -215,7 +221,7 @@ class PackCache:
     def get(self, down_w, down_b, up_w, up_b, io_dtype, tiles=None) -> PackedPair:
         key = self._make_key(down_w, down_b, up_w, up_b, io_dtype, tiles)
         if key != self._key:
-            self._val = pack_pair(down_w, down_b, up_w, up_b, io_dtype, tiles)
+            self._val = pack_pair(down_w, down_b, up_w, up_b, io_dtype, tiles, out=self._val)
             self._key = key
         global _PACK_CACHES
         if _PACK_CACHES is None:
@@ -232,7 +238,7 @@ class PackCache:
         up_w, up_b) runs only on a miss."""
         key = (io_dtype, tiles, WEIGHTS_EPOCH, tag) + tuple((t.data_ptr(), t._version) for t in sources)
         if key != self._key:
-            self._val = pack_pair(*build(), io_dtype, tiles)
+            self._val = pack_pair(*build(), io_dtype, tiles, out=self._val)
             self._key = key
         return self._val
 

@@ -16,12 +16,19 @@ from . import _lib
 from .functional import _finish, _flat, _grad_dest, _grad_like, _io_dtype, _need_cuda, _ptr, _stream, _timed
 
 
-# K5 with a LayerNorm: the backward needs the normalised rows.  False (default since round 4): the forward saves nothing but its own
-# output (which the next sublayer reads anyway) + rstd, and the backward recovers xhat = (out - beta) / gamma -- 3 row tensors of
-# traffic instead of 4.  True: the forward also writes the pre-norm sum h for the backward (the round-1..3 form; exact where a
-# gamma is ~0, and what to use if a checkpoint's LayerNorm carries |beta / gamma| in the hundreds: the recovery loses
-# log2(|out| / |gamma xhat|) bits of the bf16 output).
-SAVE_PRENORM = False
+# K5 with a LayerNorm: the backward needs the normalised rows.  Two forms: (a) the forward saves nothing but its own output (which
+# the next sublayer reads anyway) + rstd, and the backward recovers xhat = (out - beta) / gamma -- 3 row tensors of traffic instead
+# of 4; (b) the forward also writes the pre-norm sum h for the backward (the round-1..3 form, exact).  (a) divides the rounding of the
+# IO-dtype output by gamma: the recovered xhat is off by about (|xhat| + |beta / gamma|) * 2^-9 in bf16, i.e. it loses
+# log2(1 + |beta / gamma|) bits -- invisible for gamma ~ 1, beta ~ 0.1 (random init), NOT for a checkpoint whose LayerNorm has outlier
+# channels (small gamma, large beta) or a trainable LayerNorm that drifts there.
+# SAVE_PRENORM = None (default, round 5): chosen per LayerNorm from max |beta / gamma| -- form (a) up to PRENORM_RATIO, (b) above it or
+# where a gamma is 0; frozen parameters are looked at once (keyed on storage + version), trainable ones every PRENORM_RECHECK
+# optimizer steps (one host read each time; never inside a graph capture, where the last decision -- or the exact form -- is used).
+# True / False force a form (tests, tools/k5bench.py).
+SAVE_PRENORM = None
+PRENORM_RATIO = 8.0          # measured (tests/test_gpu_tail.py::test_tail_backward_from_output_error_grows_with_beta_over_gamma, profiles/r05_k5abi_ab.txt): worst element of dgamma 0.019 / 0.027 / 0.075 / 0.27 of the 0.1 bound at max |beta / gamma| = 1 / 4 / 16 / 64
+PRENORM_RECHECK = 256
 
 
 def _frozen_epoch():
@@ -51,6 +58,27 @@ def _f32_frozen(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return c[1]
 
 
+def needs_prenorm(gamma: torch.Tensor, beta: Optional[torch.Tensor]) -> bool:
+    """True: this LayerNorm's K5 backward wants the saved pre-norm rows (form (b) above)."""
+    if SAVE_PRENORM is not None:
+        return bool(SAVE_PRENORM)
+    from . import functional as _VF
+    trainable = gamma.requires_grad or (beta is not None and beta.requires_grad)
+    bkey = (beta.data_ptr(), beta._version) if beta is not None else None
+    key = (gamma.data_ptr(), bkey is None) if trainable else (gamma.data_ptr(), gamma._version, bkey, _VF.FROZEN_EPOCH)
+    ent = getattr(gamma, "_vlpet_prenorm", None)
+    if ent is not None and ent[0] == key and (not trainable or _VF.WEIGHTS_EPOCH - ent[1] < PRENORM_RECHECK):
+        return ent[2]
+    if torch.cuda.is_current_stream_capturing():          # no host read inside a capture
+        return ent[2] if ent is not None else True
+    g = gamma.detach().float().abs()
+    b = beta.detach().float().abs() if beta is not None else torch.zeros_like(g)
+    ratio = float(torch.where(g > 0, b / g, torch.full_like(g, float("inf"))).max())
+    dec = not (ratio <= PRENORM_RATIO)
+    gamma._vlpet_prenorm = (key, _VF.WEIGHTS_EPOCH, dec)
+    return dec
+
+
 class _TailFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, x1, gamma, beta, eps, p, seed, norm, want_mask, link=None):
@@ -69,7 +97,7 @@ class _TailFn(torch.autograd.Function):
         if norm:
             g32, b32 = _f32_frozen(gamma), _f32_frozen(beta)
             mean, rstd = torch.empty(M, **f32), torch.empty(M, **f32)
-            h = torch.empty_like(yf) if (need_bwd and SAVE_PRENORM) else None
+            h = torch.empty_like(yf) if (need_bwd and needs_prenorm(gamma, beta)) else None
         mask = torch.empty(M, d, dtype=torch.uint8, device=y.device) if want_mask else None
         rc = _timed("k5_fwd", M, lambda: lib.vlpet_sublayer_tail_fwd(
             yf.data_ptr(), xf.data_ptr(), _ptr(g32), _ptr(b32), out.data_ptr(), _ptr(h), _ptr(mean), _ptr(rstd),

@@ -31,7 +31,13 @@ class VisProjPackCache:
         from . import functional as _VF
         key = (dtype, _VF.WEIGHTS_EPOCH, w.data_ptr(), w._version, b.data_ptr(), b._version)
         if key != self._ckey:
-            self._ckey, self._cval = key, (w.detach().to(dtype).contiguous(), b.detach().to(dtype).contiguous())
+            old = self._cval
+            if (old is not None and old[0].dtype == dtype and old[0].shape == w.shape and old[0].device == w.device
+                    and old[1].shape == b.shape):
+                old[0].copy_(w.detach()); old[1].copy_(b.detach())      # in place: a captured graph may hold these addresses
+            else:
+                self._cval = (w.detach().to(dtype).contiguous(), b.detach().to(dtype).contiguous())
+            self._ckey = key
         return self._cval
 
     def get(self, w: torch.Tensor, b: torch.Tensor, io_dtype: int) -> torch.Tensor:
@@ -40,7 +46,9 @@ class VisProjPackCache:
         if key != self._key:
             lib = _lib.load()
             d_out, F = w.shape
-            buf = torch.empty(lib.vlpet_visproj_packed_bytes(d_out, F, io_dtype), dtype=torch.uint8, device=w.device)
+            nb = lib.vlpet_visproj_packed_bytes(d_out, F, io_dtype)
+            buf = self._val if (self._val is not None and self._val.numel() == nb and self._val.device == w.device) \
+                else torch.empty(nb, dtype=torch.uint8, device=w.device)      # (refreshed in place, as get_cast)
             wc, bc = w.detach().contiguous(), b.detach().contiguous()
             rc = lib.vlpet_visproj_pack(wc.data_ptr(), bc.data_ptr(), d_out, F, _param_dtype(wc), io_dtype,
                                         buf.data_ptr(), _stream())
