@@ -73,6 +73,53 @@ def test_replayed_trainer_equals_eager_trainer(lora):
     assert worst <= 1e-5, worst
 
 
+def test_capture_after_an_eval_forward_still_refreshes_the_weight_caches():
+    """a forward between the last optimizer step and the capture (validation, a no_grad probe) leaves the
+    epoch-keyed caches (K4 weight copies / pack, IO-dtype shadows) CURRENT at capture time -- without the forced new epoch in
+    Trainer._capture their rebuild would not become a graph node and every replay would read weights frozen at the capture.
+    Replayed training with such forwards in between must land on the eager trainer's losses and parameters."""
+    import vlpet_amd.train as TR
+    model, cfg = _tiny(0.0)
+    m_eager, m_graph = copy.deepcopy(model).cuda(), copy.deepcopy(model).cuda()
+    gen = torch.Generator().manual_seed(11)
+    bs = [_cuda_batch(TR.synthetic_batch("vqa", 5, cfg, "cpu", gen)) for _ in range(6)]      # one shape: eager, capture, 4 replays
+    tre = TR.Trainer(m_eager, cfg, lr=1e-2, total_steps=20, warmup_ratio=0.1)
+    trg = TR.Trainer(m_graph, cfg, lr=1e-2, total_steps=20, warmup_ratio=0.1, graph=True)
+
+    def probe(m, b):
+        m.eval()
+        with torch.no_grad():
+            m(b["input_ids"], b["vis_inputs"], b["labels"], b["task"])
+        m.train()
+    le, lg = [], []
+    for i, b in enumerate(bs):
+        le.append(float(tre.step(b)))
+        lg.append(float(trg.step(b)))
+        probe(m_graph, b)                                     # between every pair of steps, incl. right before the capture step
+    assert len(trg._graphs) == 1
+    for a, b in zip(lg, le):
+        assert abs(a - b) <= 1e-5 * abs(b), (lg, le)
+    ref = dict(m_eager.named_parameters())
+    worst = max(float((p - ref[n]).abs().max() / (ref[n].abs().max() + 1e-12)) for n, p in m_graph.named_parameters() if p.requires_grad)
+    assert worst <= 1e-5, worst
+
+
+def test_graph_cache_is_bounded():
+    """one captured graph per batch signature, least recently replayed evicted beyond Trainer.max_graphs."""
+    import vlpet_amd.train as TR
+    model, cfg = _tiny(0.0)
+    m = copy.deepcopy(model).cuda()
+    tr = TR.Trainer(m, cfg, lr=1e-3, total_steps=100, warmup_ratio=0.1, graph=True)
+    tr.max_graphs = 2
+    gen = torch.Generator().manual_seed(3)
+    by_size = {n: _cuda_batch(TR.synthetic_batch("vqa", n, cfg, "cpu", gen)) for n in (3, 4, 5)}
+    for n in (3, 3, 4, 4, 5, 5, 3, 3, 3):                     # third shape evicts the first; the first comes back through eager + capture
+        loss = tr.step(by_size[n])
+        assert bool(torch.isfinite(loss))
+        assert len(tr._graphs) <= 2
+    assert len(tr._graphs) == 2
+
+
 def test_seed_counter_changes_the_masks_and_null_restores_them():
     """Kernel level: the K5 tail's exported mask with the same call seed at counter values 0 / 1 / 0 and without a counter."""
     from vlpet_amd import _lib

@@ -242,25 +242,31 @@ __global__ __launch_bounds__((RT + (RT == 6 ? 2 : 1)) * 64, 2) void k1_down_kern
 #endif
         sfor<SSN>([&](auto ST) {
             constexpr int st = ST.value;
-            u32x4 bf[4];
             uint32_t kw = 0;
             if constexpr (DROP)
                 asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(kw) : "v"(a_kw + (uint32_t)((i % NSLOT) * (SSN * 256))), "n"(st * 256) : "memory");
-            sfor<4>([&](auto U) { lds_read16<st * 4096>(bf[U.value], a_b[U.value] + sb); });
-            lgkm_fence(bf[0]);
-            if constexpr (DROP) asm volatile("" : "+v"(kw) :: "memory");
+            // B fragments in batches: all four of a stage at once, two at a time under DROP (the masking temporaries next to the 192
+            // resident weight registers spilled 8 registers into the loop with four in flight)
+            constexpr int GB = DROP ? 2 : 4;
+            sfor<4 / GB>([&](auto G) {
+                u32x4 bf[GB];
+                sfor<GB>([&](auto U) { lds_read16<st * 4096>(bf[U.value], a_b[G.value * GB + U.value] + sb); });
+                lgkm_fence(bf[0]);
+                if constexpr (DROP) asm volatile("" : "+v"(kw) :: "memory");
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (u) lgkm_tie(bf[u]);
-                if constexpr (DROP) {                         // clear the dropped elements: byte u of kw = the 8 features of k-step u
+                for (int uu = 0; uu < GB; ++uu) {
+                    const int u = G.value * GB + uu;
+                    if (uu) lgkm_tie(bf[uu]);
+                    if constexpr (DROP) {                     // clear the dropped elements: byte u of kw = the 8 features of k-step u
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int lo = ((int)(kw << (31 - 8 * u - 2 * q))) >> 31, hi = ((int)(kw << (30 - 8 * u - 2 * q))) >> 31;
-                        bf[u][q] &= __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x07060100u);
+                        for (int q = 0; q < 4; ++q) {
+                            const int lo = ((int)(kw << (31 - 8 * u - 2 * q))) >> 31, hi = ((int)(kw << (30 - 8 * u - 2 * q))) >> 31;
+                            bf[uu][q] &= __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x07060100u);
+                        }
                     }
+                    acc = mfma32(wf[(hf * SSN + st) * 4 + u], as_bf(bf[uu]), acc);
                 }
-                acc = mfma32(wf[(hf * SSN + st) * 4 + u], as_bf(bf[u]), acc);
-            }
+            });
         });
 #ifdef VLPET_F2_STAMPS
         asm volatile("s_nop 0" : "+v"(acc[15]));

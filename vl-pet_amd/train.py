@@ -21,6 +21,7 @@ No per-step barrier.
 """
 from __future__ import annotations
 
+import collections
 import math
 import os
 import random
@@ -528,6 +529,7 @@ CPU_OPTIMIZER_FACTORY = None
 
 
 _REGISTERED_SEED_CTR = None     # address of the device step counter currently registered with the library (Trainer.enable_graph / close)
+MAX_GRAPHS = 16              # captured step shapes a trainer keeps (least recently replayed evicted); ragged data beyond it runs eager + capture
 LABEL_CHECK_EVERY = 100      # steps between reads of the device-side bad-label tally (0: never)
 DEFER_PARAM_REDUCES = True      # A/B switch (tools/ab_switches.py): False = one reduce launch per parameter gradient, as before round 4
 
@@ -570,7 +572,8 @@ class Trainer:
         self.step_idx = 0
         self.flat.begin_step(zero=True)
         self.graph = False
-        self._graphs, self._graph_seen, self._graph_pool = {}, {}, None
+        self._graphs, self._graph_seen, self._graph_pool = collections.OrderedDict(), {}, None
+        self.max_graphs = MAX_GRAPHS
         self.seed_ctr = None
         if graph:
             self.enable_graph()
@@ -608,6 +611,7 @@ class Trainer:
                 pass
             self.seed_ctr = None
         self.graph = False
+        self._graphs.clear()
 
     def __del__(self):
         try:
@@ -661,7 +665,8 @@ class Trainer:
     def check_labels(self):
         """Raise if the loss kernels have met labels outside the vocabulary (other than ignore_index -100) since the process started:
         they are treated as ignored tokens, i.e. the run would silently train on fewer tokens (lmloss.bad_label_count; one 4-byte
-        device read, every LABEL_CHECK_EVERY steps and from close())."""
+        device read, every LABEL_CHECK_EVERY steps; the tally is process-wide, so close() does not raise on it -- call this at the end of
+        a run)."""
         from . import lmloss
         n = lmloss.bad_label_count()
         if n:
@@ -670,6 +675,16 @@ class Trainer:
 
     def _capture(self, key, batch):
         from . import functional as VF
+        # Every weight-derived cache must MISS inside the capture, so that its rebuild becomes a node of the graph (a replay runs no
+        # Python forward).  They are stale right after an optimizer step -- but not if any forward ran since (validation between two
+        # train steps, a no_grad probe): the graph would then bake in buffers nothing refreshes.  A new weights epoch makes them
+        # stale by construction; the packs and the IO-dtype shadow, which the optimizer step refreshes itself, are brought to it here.
+        VF.bump_weights_epoch()
+        VF.repack_all(True)
+        if self.flat.flat_p_io is not None:
+            self.flat.refresh_io_shadow(self.flat.flat_p_io.dtype)
+        while len(self._graphs) >= max(1, int(self.max_graphs)):       # least recently replayed shape goes (its pool blocks are reused)
+            self._graphs.popitem(last=False)
         static = {}
         for k, v in batch.items():
             if torch.is_tensor(v):
@@ -710,16 +725,16 @@ class Trainer:
         self.seed_ctr += 1
         if ent is None:
             seen = self._graph_seen.get(key, 0)
+            if len(self._graph_seen) > 64 * max(1, int(self.max_graphs)):      # (ragged data: do not remember every shape ever met)
+                self._graph_seen.clear()
             self._graph_seen[key] = seen + 1
             if seen < 1:       # the first step of a shape runs eagerly: lazy initialisation, GEMM solution lookups, the label check
-                loss = self._fwd_bwd(batch)
-                self._finish_step()
-                return loss.detach()
+                return self._eager_step_in_graph_mode(batch)
             ent = self._capture(key, batch)
             if ent is None:
-                loss = self._fwd_bwd(batch)
-                self._finish_step()
-                return loss.detach()
+                return self._eager_step_in_graph_mode(batch)
+        else:
+            self._graphs.move_to_end(key)
         g, static, loss = ent
         for (k, i, src), (_, _, dst) in zip(self._leaves(batch), self._leaves(static)):
             if src.data_ptr() != dst.data_ptr():
@@ -727,6 +742,19 @@ class Trainer:
         g.replay()
         self._finish_step()
         return loss.detach().clone()
+
+    def _eager_step_in_graph_mode(self, batch) -> torch.Tensor:
+        """An eager step of a trainer that otherwise replays graphs (first sight of a shape, a failed capture).  Under data
+        parallelism its gradient buckets are exchanged by finish() in index order, exactly as after a replay: ranks decide eager vs
+        replay from their OWN batch shapes, and a rank launching its buckets from inside the backward (readiness order, e.g. 1, 0, 2)
+        next to one replaying (0, 1, 2) would issue mismatched collectives."""
+        self.flat.defer = True
+        try:
+            loss = self._fwd_bwd(batch)
+        finally:
+            self.flat.defer = False
+        self._finish_step()
+        return loss.detach()
 
     def step(self, batch) -> torch.Tensor:
         if self.graph:
