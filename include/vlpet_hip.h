@@ -256,6 +256,24 @@ int vlpet_visproj_fwd(const void* feats, const void* packed, const float* gamma,
                       const void* r, void* out, void* xhat, float* rstd,
                       int64_t M, int feat_dim, int d_out, float eps, int rms,
                       int io_dtype, vlpet_stream_t stream);
+/* The same forward as a tiled GEMM whose column tiles exchange the LayerNorm statistics (round 5; csrc/visproj_gemm.hip): bf16 IO,
+ * d_out a multiple of 256 (<= 1024), feat_dim a multiple of 64.  w_io [d_out, feat_dim] = the weight in the IO dtype, row-major (no
+ * pack); bias [d_out] fp32 or NULL; mean [M] optional.  workspace: vlpet_visproj_gemm_workspace_bytes (0 = shape not supported by
+ * this form); the CALLER zeroes it once -- every launch leaves the exchange area (byte 256 on) zeroed, so it is reused across calls
+ * without a memset; launches sharing one workspace must be ordered (one stream).  Its first 32-bit word is a status the kernel only
+ * ever ORs into: nonzero = a statistics exchange between workgroups timed out (the GPU was not this kernel's alone for seconds), the
+ * rows are not normalised consistently and the area must be zeroed again; bytes 64..119: wall-clock stamps of workgroup 0.  replaces: src/modeling_bart.py:91-110,157 (T5: src/modeling_t5.py:56-66). */
+size_t vlpet_visproj_gemm_workspace_bytes(int64_t M, int feat_dim, int d_out);
+int vlpet_visproj_fwd_gemm(const void* feats, const void* w_io, const float* bias, const float* gamma, const float* beta,
+                           const void* r, void* out, void* xhat, float* rstd, float* mean, void* workspace,
+                           size_t workspace_bytes, int64_t M, int feat_dim, int d_out, float eps, int rms, int io_dtype,
+                           vlpet_stream_t stream);
+/* ... with the LDS ring form (1: 64 input features per stage / 2 slots, 2: 32 / 4, 3: 32 / 3; 0: default) and the rows per
+ * workgroup (128 / 256; 0: by shape) forced: measurement and parity of the non-default forms. */
+int vlpet_visproj_fwd_gemm_cfg(const void* feats, const void* w_io, const float* bias, const float* gamma, const float* beta,
+                               const void* r, void* out, void* xhat, float* rstd, float* mean, void* workspace,
+                               size_t workspace_bytes, int64_t M, int feat_dim, int d_out, float eps, int rms, int io_dtype,
+                               int form, int rows_per_workgroup, vlpet_stream_t stream);
 /* Weight gradient of the projection:  dw [d_out, F] = dpre^T @ feats,  db [d_out] = column sums of dpre
  * (dpre = gradient w.r.t. the pre-norm activations, [M, d_out], IO dtype).  fp32, overwritten. */
 size_t vlpet_visproj_wgrad_workspace_bytes(int64_t M, int feat_dim, int d_out);

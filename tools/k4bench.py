@@ -54,6 +54,26 @@ for M in Ms:
         pre = torch.addmm(bb, feats, wb.t())
         rc = lib.vlpet_norm_residual_fwd(pre.data_ptr(), R.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), mean.data_ptr(),
                                          rstd.data_ptr(), M, d, 1e-5, 1, st); assert rc == 0
+    nwg = lib.vlpet_visproj_gemm_workspace_bytes(M, Fd, d); wsg = torch.zeros(max(nwg, 256), dtype=torch.uint8, device=dev)
+    b32 = lin.bias.detach().float()
+
+    def fwd_gemm(form, bm):      # round 5: the hand-written tiled GEMM + statistics exchange (csrc/visproj_gemm.hip), R added like the composed form
+        def f():
+            rc = lib.vlpet_visproj_fwd_gemm_cfg(feats.data_ptr(), wb.data_ptr(), b32.data_ptr(), gamma.data_ptr(), beta.data_ptr(), R.data_ptr(),
+                                                out.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), None, wsg.data_ptr(), nwg, M, Fd, d, 1e-5, 0, 1,
+                                                form, bm, st); assert rc == 0, rc
+        return f
+    gemm_cols = []
+    for form, bm in ((0, 0),) + tuple((f, b) for b in (256, 128) for f in (1, 2, 3, 4, 5, 6)):
+        tg = timed(fwd_gemm(form, bm)); torch.cuda.synchronize()
+        refg = torch.nn.functional.layer_norm((feats.float() @ lin.weight.detach().float().t() + lin.bias.detach().float()), (d,), gamma, beta, 1e-5)
+        eg = float((out.float() - refg).abs().max() / refg.abs().max())
+        stat = int(wsg[:4].view(torch.int32)[0].item())
+        st7 = wsg[64:64 + 56].view(torch.int64).tolist()
+        if (form, bm) in ((0, 0), (4, 256), (5, 256), (4, 128)):      # workgroup 0's wall-clock stamps (10 ns units -> us)
+            d7 = [(st7[k + 1] - st7[k]) / 100.0 for k in range(6)]
+            print(f"   stamps form {form} bm {bm}: prologue {d7[0]:.1f}  K loop {d7[1]:.1f}  wave stats {d7[2]:.1f}  exchange {d7[3]:.1f}  norm + out {d7[4]:.1f}  xhat {d7[5]:.1f} us")
+        gemm_cols.append(f"form {form} bm {bm:3d}: {tg:6.1f} us ({fl_ / tg / 1e6 / 2500:.3f}, err {eg:.1e}, status {stat})" if False else (form, bm, tg, eg, stat))
     t_fc = timed(fwd_composed)
     t_f, t_w = timed(fwd), timed(wgrad)
     t_lf = timed(lambda: torch.nn.functional.linear(feats, wb))
@@ -65,6 +85,8 @@ for M in Ms:
     e_f = float((out.float() - ref).abs().max() / ref.abs().max())
     refw = dpre.float().t() @ feats.float()
     e_w = float((dw - refw).abs().max() / refw.abs().max())
+    print(f"k4bench {tag:8s} M={M:6d}: tiled GEMM + exchange (form, rows/WG: us, frac of 2.5 PF, err, status): "
+          + "  ".join(f"({fo},{bm}: {tg:.1f}, {fl / tg / 1e6 / 2500:.3f}, {eg:.0e}, {stt})" for fo, bm, tg, eg, stt in gemm_cols), flush=True)
     print(f"k4bench {tag:8s} M={M:6d}: fwd (library GEMM + norm pass) {t_fc:7.1f} us ({fl / t_fc / 1e6:6.0f} TFLOP/s, frac {fl / t_fc / 1e6 / 2500:.3f})  |  fused kernel: "
           f"fwd {t_f:7.1f} us ({fl / t_f / 1e6:6.0f} TFLOP/s, frac {fl / t_f / 1e6 / 2500:.3f}, err {e_f:.1e})   "
           f"wgrad {t_w:7.1f} us ({fl / t_w / 1e6:6.0f} TFLOP/s, frac {fl / t_w / 1e6 / 2500:.3f}, err {e_w:.1e})   | library GEMMs alone: "

@@ -73,6 +73,9 @@ SIGNATURES = {
     "vlpet_visproj_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vlpet_visproj_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vlpet_visproj_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "vlpet_visproj_gemm_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "vlpet_visproj_fwd_gemm": (c_int, [c_void_p] * 11 + [c_size_t, c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "vlpet_visproj_fwd_gemm_cfg": (c_int, [c_void_p] * 11 + [c_size_t, c_int64, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "vlpet_visproj_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "vlpet_visproj_wgrad_workspace_bytes_io": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "vlpet_visproj_wgrad": (c_int, [c_void_p] * 5 + [c_size_t, c_int64, c_int, c_int, c_int, c_void_p]),

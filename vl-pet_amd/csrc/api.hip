@@ -675,6 +675,42 @@ extern "C" int vlpet_visproj_fwd(const void* feats, const void* packed, const fl
     return herr(launch_visproj_fwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));
 }
 
+// K4 forward as a tiled GEMM (visproj_gemm.hip): bf16, d_out a multiple of 256 (<= 1024), feat_dim a multiple of 64.
+extern "C" size_t vlpet_visproj_gemm_workspace_bytes(int64_t M, int feat_dim, int d_out) {
+    return visproj_gemm_workspace_bytes(M, feat_dim, d_out);
+}
+static int visproj_gemm_call(const void* feats, const void* w_io, const float* bias, const float* gamma, const float* beta,
+                             const void* r, void* out, void* xhat, float* rstd, float* mean, void* workspace, size_t workspace_bytes,
+                             int64_t M, int feat_dim, int d_out, float eps, int rms, int io_dtype, int form, int bm, vlpet_stream_t stream) {
+    if (!feats || !w_io || !gamma || !out || !workspace) return VLPET_E_NULL;
+    if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    if (!visproj_gemm_applies(M, feat_dim, d_out, io_dtype == VLPET_F32)) return VLPET_E_SHAPE;
+    if (workspace_bytes < visproj_gemm_workspace_bytes(M, feat_dim, d_out)) return VLPET_E_WORKSPACE;
+    if (!aligned16(feats) || !aligned16(w_io) || !aligned16(out) || (r && !aligned16(r)) || (xhat && !aligned16(xhat)) || !aligned16(workspace))
+        return VLPET_E_ALIGN;
+    VisGemmArgs a{};
+    a.feats = feats; a.w = w_io; a.bias = bias; a.gamma = gamma; a.beta = beta; a.R = r; a.out = out; a.xhat = xhat; a.rstd = rstd;
+    a.mean = mean; a.M = M; a.F = feat_dim; a.d_out = d_out; a.eps = eps; a.rms = rms;
+    return herr(launch_visproj_gemm(a, workspace, form, bm, (hipStream_t)stream));
+}
+extern "C" int vlpet_visproj_fwd_gemm(const void* feats, const void* w_io, const float* bias, const float* gamma, const float* beta,
+                                      const void* r, void* out, void* xhat, float* rstd, float* mean, void* workspace,
+                                      size_t workspace_bytes, int64_t M, int feat_dim, int d_out, float eps, int rms, int io_dtype,
+                                      vlpet_stream_t stream) {
+    return visproj_gemm_call(feats, w_io, bias, gamma, beta, r, out, xhat, rstd, mean, workspace, workspace_bytes, M, feat_dim, d_out,
+                             eps, rms, io_dtype, 0, 0, stream);
+}
+// the same with the ring form (1: BK 64 / 2 slots, 2: BK 32 / 4 slots, 3: BK 32 / 3 slots; 0: default) and the rows per workgroup
+// (128 / 256; 0: by shape) forced -- tools/k4bench.py and the parity tests of the non-default forms
+extern "C" int vlpet_visproj_fwd_gemm_cfg(const void* feats, const void* w_io, const float* bias, const float* gamma, const float* beta,
+                                          const void* r, void* out, void* xhat, float* rstd, float* mean, void* workspace,
+                                          size_t workspace_bytes, int64_t M, int feat_dim, int d_out, float eps, int rms, int io_dtype,
+                                          int form, int rows_per_workgroup, vlpet_stream_t stream) {
+    if (form < 0 || form > 6 || (rows_per_workgroup != 0 && rows_per_workgroup != 128 && rows_per_workgroup != 256)) return VLPET_E_SHAPE;
+    return visproj_gemm_call(feats, w_io, bias, gamma, beta, r, out, xhat, rstd, mean, workspace, workspace_bytes, M, feat_dim, d_out,
+                             eps, rms, io_dtype, form, rows_per_workgroup, stream);
+}
+
 static void visproj_wgrad_plan(int64_t M, int feat_dim, int d_out, int* RT, int* pcols, int* rc, int64_t* rpc) {
     *RT = (d_out % 96 == 0) ? 3 : 1;
     *pcols = 32 * *RT;

@@ -203,6 +203,21 @@ struct VisprojArgs {
 };
 hipError_t launch_visproj_fwd(const VisprojArgs& a, int io_fp32, hipStream_t stream);
 
+// K4 forward as a tiled GEMM with the LayerNorm statistics exchanged between the column tiles (visproj_gemm.hip, round 5)
+struct VisGemmArgs {
+    const void* feats; const void* w;
+    const float* bias; const float* gamma; const float* beta;
+    const void* R; void* out; void* xhat; float* rstd; float* mean;
+    unsigned long long* xch;        // granules [2 parities][nteams][NT consumers][NT producers][BM * 2]: zero before the first launch, left zero
+    unsigned* status;               // != 0: a statistics exchange timed out
+    int64_t M; int F, d_out; float eps; int rms;
+    int nteams, row_blocks;
+};
+
+bool visproj_gemm_applies(int64_t M, int F, int d_out, int io_fp32);
+size_t visproj_gemm_workspace_bytes(int64_t M, int F, int d_out);
+hipError_t launch_visproj_gemm(VisGemmArgs& a, void* ws, int form, int bm, hipStream_t stream);
+
 // K5 sublayer tail: out = LayerNorm(x1 + dropout(y)) (norm = 1) or x1 + dropout(y) (norm = 0); tail.hip
 struct TailArgs {
     const void* y;          // fwd: sublayer output [M, d];          bwd: dy  (written when thr != 0)

@@ -667,7 +667,10 @@ class Trainer:
         they are treated as ignored tokens, i.e. the run would silently train on fewer tokens (lmloss.bad_label_count; one 4-byte
         device read, every LABEL_CHECK_EVERY steps; the tally is process-wide, so close() does not raise on it -- call this at the end of
         a run)."""
-        from . import lmloss
+        from . import lmloss, visproj
+        if visproj.gemm_exchange_status():
+            raise RuntimeError("vl-pet_amd: a visual-projection launch timed out waiting for a partner workgroup's LayerNorm statistics "
+                               "(csrc/visproj_gemm.hip: the GPU was shared with another long-running kernel); the affected step is invalid")
         n = lmloss.bad_label_count()
         if n:
             raise IndexError(f"vl-pet_amd: {n} label(s) outside the LM-head vocabulary (and not ignore_index -100) reached the loss -- "

@@ -12,11 +12,43 @@ from . import _lib
 from .functional import _finish, _flat, _grad_dest, _grad_like, _io_dtype, _need_cuda, _param_dtype, _ptr, _stream, _timed
 
 
-# K4 forward, bf16 LayerNorm form: True (default since round 4) = library GEMM (hipBLASLt, a plain [M, F] x [F, d] product) followed by
-# ONE pass of the K5 kernel (LayerNorm + residual: vlpet_norm_residual_fwd) -- 48 + 12 us at 18,700 rows against 108 us for the
-# fused kernel of csrc/visproj.hip, whose 146 workgroups each stream the whole 3.1 MB weight through LDS (profiles/r03_k4bench.txt).
-# False = the fused kernel (what fp32 IO and T5's RMS norm always run).
-GEMM_THEN_NORM = True
+# K4 forward, bf16:
+#   K4_FORM = "gemm" (default, round 5): the hand-written tiled GEMM of csrc/visproj_gemm.hip -- [rows x 256 features] tiles, the three
+#       column tiles of a row block exchange the LayerNorm / RMS statistics through L2 and finish the norm + residual add themselves
+#       (one launch, d_model a multiple of 256: both backbones' 768); saves xhat + rstd for the backward like the fused kernel.
+#   "library" (the round-4 default, kept for same-box A/Bs): hipBLASLt GEMM + ONE pass of the K5 kernel (vlpet_norm_residual_fwd);
+#       LayerNorm form only.
+#   "fused" (round 2): csrc/visproj.hip, a workgroup owns 128 rows x all features (what fp32 IO and other widths always run).
+K4_FORM = "gemm"
+GEMM_THEN_NORM = True          # (honoured when K4_FORM == "library")
+
+
+# Exchange area of the tiled-GEMM form: zeroed ONCE per device; every launch leaves it zeroed (each consumer clears the granules it has
+# read), so no memset runs between launches.  One area per device: K4 launches of one process are issued on one stream at a time.
+_GEMM_WS = {}
+
+
+def _gemm_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    key = (device.type, device.index)
+    ws = _GEMM_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _GEMM_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
+def gemm_exchange_status(device=None) -> int:
+    """Nonzero: a K4 launch on ``device`` (any, if None) gave up waiting for a partner workgroup's LayerNorm statistics (the GPU was not
+    this process's alone for seconds) -- its rows were normalised with incomplete statistics.  Clears the word and re-zeroes the area
+    (one 4-byte device read; train.Trainer.check_labels calls it every LABEL_CHECK_EVERY steps)."""
+    bad = 0
+    for key, ws in _GEMM_WS.items():
+        if device is not None and key != (torch.device(device).type, torch.device(device).index):
+            continue
+        st = int(ws[:4].view(torch.int32)[0].item())
+        if st:
+            bad |= st
+            ws.zero_()
+    return bad
 
 
 class VisProjPackCache:
@@ -58,8 +90,10 @@ class VisProjPackCache:
 
 
 class _VisProjFn(torch.autograd.Function):
+    last_status = None
+
     @staticmethod
-    def forward(ctx, feats, R, w, b, gamma, beta, packed, eps, rms, cast=None):
+    def forward(ctx, feats, R, w, b, gamma, beta, packed, eps, rms, cast=None, gemm=False):
         lib = _lib.load()
         _need_cuda(feats, w)
         F = feats.shape[-1]
@@ -71,6 +105,23 @@ class _VisProjFn(torch.autograd.Function):
         if R is not None:
             Rf = _flat(R.to(feats.dtype), d_out)
         out = torch.empty(M, d_out, dtype=feats.dtype, device=feats.device)
+        if gemm:                        # tiled GEMM + statistics exchange (csrc/visproj_gemm.hip)
+            from .tail import _f32_frozen
+            wc, _ = cast
+            g32, be32, b32 = _f32_frozen(gamma), _f32_frozen(beta), _f32_frozen(b)
+            xhat = torch.empty_like(out)
+            rstd = torch.empty(M, dtype=torch.float32, device=feats.device)
+            ws = _gemm_workspace(feats.device, lib.vlpet_visproj_gemm_workspace_bytes(M, F, d_out))
+            nws = ws.numel()
+            rc = _timed("k4_fwd", M, lambda: lib.vlpet_visproj_fwd_gemm(
+                ff.data_ptr(), wc.data_ptr(), _ptr(b32), g32.data_ptr(), _ptr(be32), _ptr(Rf), out.data_ptr(), xhat.data_ptr(),
+                rstd.data_ptr(), None, ws.data_ptr(), nws, M, F, d_out, float(eps), int(bool(rms)), io, _stream()))
+            _lib.check(rc, "vlpet_visproj_fwd_gemm")
+            _VisProjFn.last_status = ws[:4]         # (tests: view of the launch's status word)
+            ctx.composed = False
+            ctx.save_for_backward(ff, xhat, rstd, w, b, gamma, beta if beta is not None else gamma, None)
+            ctx.cfg = (bool(rms), beta is not None, feats.shape[:-1], R is not None, R.dtype if R is not None else None)
+            return out.view(*feats.shape[:-1], d_out)
         if cast is not None:            # library GEMM, then LayerNorm + residual in one pass of the K5 kernel
             from .tail import _f32_frozen
             wc, bc = cast
@@ -161,7 +212,7 @@ class _VisProjFn(torch.autograd.Function):
         else:
             gg = _finish([(dgamma, s_g, gamma)])[0]
             gbe = _finish([(dbeta, s_be, beta)])[0] if has_beta else None
-        return (dfeats, dR, gw, gb, gg, gbe, None, None, None, None)
+        return (dfeats, dR, gw, gb, gg, gbe, None, None, None, None, None)
 
 
 def visproj(feats, R, linear: torch.nn.Linear, norm: torch.nn.Module, cache: VisProjPackCache, rms: bool):
@@ -175,7 +226,13 @@ def visproj(feats, R, linear: torch.nn.Linear, norm: torch.nn.Module, cache: Vis
     if eps is None:
         eps = norm.variance_epsilon
     beta = getattr(norm, "bias", None)
-    if GEMM_THEN_NORM and not rms and feats.dtype == torch.bfloat16:
+    if K4_FORM == "gemm" and feats.dtype == torch.bfloat16 and feats.is_cuda:
+        lib = _lib.load()
+        M = feats.numel() // feats.shape[-1]
+        if lib.vlpet_visproj_gemm_workspace_bytes(M, feats.shape[-1], linear.weight.shape[0]) > 0:
+            cast = cache.get_cast(linear.weight, linear.bias, feats.dtype)
+            return _VisProjFn.apply(feats, R, linear.weight, linear.bias, norm.weight, beta, None, eps, rms, cast, True)
+    if K4_FORM != "fused" and GEMM_THEN_NORM and not rms and feats.dtype == torch.bfloat16:
         cast = cache.get_cast(linear.weight, linear.bias, feats.dtype)
         return _VisProjFn.apply(feats, R, linear.weight, linear.bias, norm.weight, beta, None, eps, rms, cast)
     packed = cache.get(linear.weight, linear.bias, io)
