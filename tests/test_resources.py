@@ -21,7 +21,7 @@ ALLOWED = [
     (r"^void pet_gate_cols2?_kernel<", "round-2 two-pass backward (ABI phases bit 2 / debug switches): the default is pet_dz2 / pet_dz6 + pet_cols / pet_cols6"),
     (r"^void visproj_fwd_kernel<", "4-wave K4 forward: VLPET_K4_WAVES4 of a debug build only"),
     (r"^void visproj_fwd2_kernel<float, ", "fp32 IO = parity mode"),
-    (r"^void visproj_fwd2_kernel<__bf16, 24>", "round-2 fused K4 forward: superseded by visproj_gemm_kernel (round 5); kept for A/B behind VLPET_K4_FUSED"),
+    (r"^void visproj_fwd2_kernel<__bf16, 24>", "round-2 fused K4 forward: superseded by visproj_gemm_kernel (round 5) wherever d_model is a multiple of 256 (both backbones); left for other widths and for visproj.K4_FORM = \"fused\" A/Bs"),
     (r"^void attn_bwd_kernel<3, 4, true>", "backbone pass (SURVEY 8d: ungraded): three waves per SIMD with 7 spilled registers measured faster than two without (DESIGN.md, round 2 fourth session)"),
 ]
 
