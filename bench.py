@@ -37,13 +37,34 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # launch, so for the other task shapes they are an extrapolation (labelled as such in the line).
 # Two tables: the two-pass form (round 3: pass 1 + column-parallel pass + finalize) and the previous split (--k1-previous-split).
 PMC_TRAFFIC_FORMS = {
-    "two_pass": {"source": "profiles/r04_pmc_traffic.md", "measured_at_rows": 28000,       # (118.1 / 289.0 / 457.1 MB per launch)
-                 "bytes_per_row": {"k1_bwd_rows": 4218.0, "k1_bwd_wgrad": 10321.0, "k1_bwd_op": 16325.0}},
-    "two_pass_t5": {"source": "profiles/r04_pmc_traffic.md", "measured_at_rows": 18250,    # r = 192: 100.7 / 255.9 / 407.7 MB per launch
-                    "bytes_per_row": {"k1_bwd_rows": 5518.0, "k1_bwd_wgrad": 14022.0, "k1_bwd_op": 22340.0}},
-    "previous_split": {"source": "profiles/r02_pmc_traffic_k1_bwd.md", "measured_at_rows": 28000,
-                       "bytes_per_row": {"k1_bwd_rows": 11881.0, "k1_bwd_op": 20432.0}},
+    # round 5: measured at all four task sizes of configs[1] (profiles/r05_pmc_traffic.md); bytes per LAUNCH by rows, interpolated per launch
+    "two_pass": {"source": "profiles/r05_pmc_traffic.md", "measured_at_rows": [15272, 28000, 31616, 46648],
+                 "bytes_by_rows": {"k1_bwd_rows": {15272: 65.5e6, 28000: 118.1e6, 31616: 133.0e6, 46648: 197.0e6},
+                                   "k1_bwd_wgrad": {15272: 177.5e6, 28000: 288.9e6, 31616: 318.0e6, 46648: 445.6e6},
+                                   "k1_bwd_op": {15272: 290.6e6, 28000: 457.1e6, 31616: 501.0e6, 46648: 692.5e6}}},
+    "two_pass_t5": {"source": "profiles/r05_pmc_traffic.md", "measured_at_rows": [18250, 28000],    # r = 192
+                    "bytes_by_rows": {"k1_bwd_rows": {18250: 100.8e6, 28000: 152.0e6}, "k1_bwd_wgrad": {18250: 256.5e6, 28000: 381.0e6},
+                                      "k1_bwd_op": {18250: 408.2e6, 28000: 583.9e6}}},
+    "previous_split": {"source": "profiles/r02_pmc_traffic_k1_bwd.md", "measured_at_rows": [28000],
+                       "bytes_by_rows": {"k1_bwd_rows": {28000: 11881.0 * 28000}, "k1_bwd_op": {28000: 20432.0 * 28000}}},
 }
+
+
+def pmc_bytes(table, rows):
+    """PMC-measured bytes of one launch at `rows`: linear interpolation between the measured sizes (the traffic is affine in the rows:
+    fixed partial sums + a per-row term), proportional scaling outside them / with a single point."""
+    pts = sorted(table.items())
+    if len(pts) == 1 or rows <= 0:
+        return pts[0][1] * rows / pts[0][0]
+    lo = max([p for p in pts if p[0] <= rows] or [pts[0]], key=lambda p: p[0])
+    hi = min([p for p in pts if p[0] >= rows] or [pts[-1]], key=lambda p: p[0])
+    if lo[0] == hi[0]:
+        if rows == lo[0]:
+            return lo[1]
+        lo, hi = (pts[0], pts[1]) if rows < pts[0][0] else (pts[-2], pts[-1])      # extrapolate along the nearest segment
+    return lo[1] + (hi[1] - lo[1]) * (rows - lo[0]) / (hi[0] - lo[0])
+
+
 IMAGE_TASKS = ["vqa", "gqa", "nlvr", "caption"]
 VIDEO_TASKS = ["tvqa", "how2qa", "tvc", "yc2c"]
 
@@ -442,6 +463,34 @@ def main():
                   ("per_gpu_task_batch" if other == "weak" else "global_task_batch"): {t: TR.TASK_BATCH[t](args.batch) for t in tasks},
                   "note": f"same ranks, {other} scaling (timed right after the main region)"}
 
+    exchange = None
+    if args.emulate_ranks > 1 and dev.type == "cuda":
+        own_group = not dist.is_initialized()
+        if own_group:           # (a one-rank RCCL group of this process: rendezvous on 127.0.0.1)
+            dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=dev)
+        # What the estimate R x value leaves out: the gradient exchange.  Measured here: the flat trainable-gradient buffer through the
+        # collective library on THIS process's (one-rank) group -- launch + kernel cost of the call the trainer makes after a replay --
+        # and, beside it, the bandwidth term of a ring all-reduce over R ranks on one xGMI link per hop (153 GB/s per direction,
+        # MI355X: 7 links per GPU; RCCL's multi-ring schedules can only be faster).  Under graph replay the exchange follows the
+        # replayed backward (train.FlatGrads.finish), i.e. it is fully exposed: both are ADDED to the emulated step.
+        buf = tr.flat.flat
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        e1.record(); torch.cuda.synchronize()
+        one_rank_us = e0.elapsed_time(e1) / 20 * 1e3
+        R, nbytes = args.emulate_ranks, buf.numel() * 4
+        ring_us = 2.0 * (R - 1) / R * nbytes / 153e9 * 1e6
+        exchange = {"bytes": nbytes, "one_rank_all_reduce_us": round(one_rank_us, 1), "ring_model_us": round(ring_us, 1),
+                    "ring_model": f"2 (R - 1) / R x {nbytes} B / 153 GB/s (one xGMI link per hop), R = {R}"}
+        tr.flat.flat.zero_()
+        if own_group:
+            dist.destroy_process_group()
+
     if rank == 0:
         esz = 2 if dtype == torch.bfloat16 else 4
         d = cfg.d_model
@@ -456,7 +505,11 @@ def main():
         # writes only the [M, r] dpre) + the column-parallel pass (k1_cols_kernel: reads dy, x1, x2, writes dx1, dx2 and the
         # weight-gradient partials) + the finalize launch; otherwise rows kernel + weight-gradient kernels as in round 2.
         k1_tiles = 6 if args.model == "t5" else 3
-        k1_form = VF._lib.load().vlpet_adapter_gate_bwd_form(28000, d, k1_tiles, 1 if dtype == torch.bfloat16 else 0)
+        # ... asked for THIS run's row counts (every K1 launch size the timers saw), not for a fixed size (ADVICE r03 / VERDICT r04 #11)
+        k1_rows = sorted(agg["k1_bwd_rows"]["by_rows"]) if "k1_bwd_rows" in agg else []
+        k1_forms = {int(m): int(VF._lib.load().vlpet_adapter_gate_bwd_form(int(m), d, k1_tiles, 1 if dtype == torch.bfloat16 else 0)) for m in k1_rows}
+        k1_form = max(set(k1_forms.values()), key=list(k1_forms.values()).count) if k1_forms else \
+            VF._lib.load().vlpet_adapter_gate_bwd_form(28000, d, k1_tiles, 1 if dtype == torch.bfloat16 else 0)
         two_pass = k1_form == 2 and not args.k1_previous_split
         per_row = {"k1_fwd": 3 * d * esz, "k1_bwd_rows": (2 if two_pass else 5) * d * esz, "k1_bwd_wgrad": (5 if two_pass else 0) * d * esz,
                    "k1_bwd_fin": 0, "k2_fwd": 3 * d * esz,
@@ -515,8 +568,12 @@ def main():
         traffic = None
         PMC_TRAFFIC = PMC_TRAFFIC_FORMS[("two_pass_t5" if args.model == "t5" else "two_pass") if (args.model != "lora" and two_pass)
                                         else "previous_split"]
-        if dom in PMC_TRAFFIC["bytes_per_row"] and args.dtype == "bf16" and args.model in ("bart", "t5", "video"):
-            traffic = round(PMC_TRAFFIC["bytes_per_row"][dom] * a["rows"] / a["launches"])
+        def pmc_avg(group):          # average PMC bytes per launch over THIS run's launch sizes
+            tab = PMC_TRAFFIC["bytes_by_rows"][group]
+            br = a["by_rows"]
+            return round(sum(pmc_bytes(tab, m) * c[0] for m, c in br.items()) / max(1, sum(c[0] for c in br.values())))
+        if dom in PMC_TRAFFIC["bytes_by_rows"] and args.dtype == "bf16" and args.model in ("bart", "t5", "video"):
+            traffic = pmc_avg(dom)
         # Headline fraction = the whole K1 backward OP (SURVEY 8d's 5*d*b per row is the op's byte count; the op is three launches):
         # algorithmic bytes / (pass 1 + column-parallel pass + finalize).  The dominant kernel's own figures stay beside it.
         op = kernels.get("k1_bwd_op") if dom in ("k1_bwd_rows", "k1_bwd_wgrad") else None
@@ -525,13 +582,13 @@ def main():
                 ("pass 1 + column-parallel pass + finalize" if two_pass else "rows kernel + weight-gradient kernels")
             algo_row = 5 * d * esz
             if traffic:
-                traffic = round(PMC_TRAFFIC["bytes_per_row"]["k1_bwd_op"] * a["rows"] / a["launches"])
+                traffic = pmc_avg("k1_bwd_op")
         else:
             achieved, launch_us, what, algo_row = kernel_achieved, a["total_us"] / a["launches"], kname, per_row[dom]
         roof = dict(bound="hbm", kernel=what, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    traffic_source=(f"{PMC_TRAFFIC['source']}: PMC passes at M={PMC_TRAFFIC['measured_at_rows']} only, "
-                                    f"scaled by this run's average rows per launch") if traffic else None,
+                    traffic_source=(f"{PMC_TRAFFIC['source']}: PMC passes at M = {PMC_TRAFFIC['measured_at_rows']}, interpolated per launch "
+                                    f"over this run's launch sizes") if traffic else None,
                     avg_launch_us=round(launch_us, 2),
                     avg_rows_per_launch=round(a["rows"] / a["launches"], 1),
                     algorithmic_bytes_per_row=algo_row,
@@ -555,8 +612,14 @@ def main():
             **({"ab_switches": ab_switches} if ab_switches else {}),
             **({"other_scaling": strong} if strong is not None else {}),
             **({"emulated_ranks": {"ranks": args.emulate_ranks, "estimate_samples_per_s_all_ranks": round(samples / dt * args.emulate_ranks, 2),
+                                   **({"gradient_exchange": exchange,
+                                       "estimate_with_exchange_samples_per_s_all_ranks": round(
+                                           samples * args.emulate_ranks / (dt + args.steps * 1e-6 * (exchange["one_rank_all_reduce_us"] + exchange["ring_model_us"])), 2)}
+                                      if exchange else {}),
                                    "note": "one GPU running the batch rank 0 of R strong-scaled ranks would see; value is this one rank's "
-                                           "throughput, the estimate = R x value ignores the gradient exchange (about 24 MB per step)"}}
+                                           "throughput; estimate = R x value ignores the gradient exchange, estimate_with_exchange adds the "
+                                           "measured one-rank collective call and the ring bandwidth term to every step (exposed: the "
+                                           "exchange follows the replayed backward)"}}
                if args.emulate_ranks > 1 else {}),
             "step_mode": (f"hipGraph replay: forward + loss + backward captured once per task shape (train.Trainer(graph=True); {setup_steps} "
                           "untimed setup steps before the warm-up), gradient exchange + clip + AdamW eager; roofline brackets from eager "

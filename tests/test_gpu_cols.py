@@ -16,9 +16,15 @@ def _check(errs):
     assert not bad, errs
 
 
-# element-wise bound of the bf16 runs (|err| / (|ref| + 0.02 max|ref|)): a bf16-rounded output whose reference is ~0 next to a maximum
-# of ~4 sigma carries up to 2^-9 * (terms of the size of the maximum) / (0.02 max) ~ 0.2
-EL_TOL = 0.35
+# Element-wise bound of the bf16 runs: |err| <= EL_TOL * (|ref| + EL_FLOOR * max|ref|), i.e. every element within 10 % of its own
+# magnitude once it is above 6 % of the tensor's maximum, and within 0.6 % of the maximum below that.  Why a floor at all, and why 6 %:
+# the operands of the backward's contractions (dh, dq, dpre, z tiles) are bf16, so an output element is a sum of terms each rounded
+# at 2^-9 of ITS size -- an element whose reference is ~0 next to a 4-sigma maximum still carries the rounding of a few maximum-sized
+# terms, measured 0.0044 max|ref| at worst over all shapes of this file (profiles/r05_pytest_gpu_s1.txt: 0.22 against the old 2 %
+# floor); 0.0044 / 0.06 = 0.073 leaves a quarter of the bound as margin.  (Round 4's bound was 0.35 on a 2 % floor: a 30 % error on any
+# element above 2 % of the maximum would have passed.)
+EL_TOL = 0.1
+EL_FLOOR = 0.06
 
 
 def test_form_query():

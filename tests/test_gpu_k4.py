@@ -159,8 +159,7 @@ def _gemm_abi(M, F, d, rms, form, bm, with_r=True, seed=0, mean_shift=0.0, ws_ke
     return (out, xhat, rstd, mean, status), (r_out, r_xhat, r_rstd, r_mean)
 
 
-@pytest.mark.parametrize("form", [1, 2, 3, 4, 5, 6])
-@pytest.mark.parametrize("bm", [128, 256])
+@pytest.mark.parametrize("form,bm", [(f, b) for f in (1, 2, 3, 4, 5, 6) for b in (128, 256)] + [(1, 192), (4, 192), (0, 0)])
 @pytest.mark.parametrize("M,F,d,rms", [(1, 64, 256, False), (300, 512, 768, False), (1000, 2048, 768, True), (12000, 512, 512, False),
                                        (18700, 2048, 768, False), (29988, 2048, 768, False), (23000, 512, 1024, True)])
 def test_k4_gemm_kernel_through_the_abi(M, F, d, rms, form, bm):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One op of the path launched a few times through the C ABI -- target of rocprofv3 --pmc / --kernel-trace passes (round 4).
-usage: pmc_target.py <op> [M] [r]      op: k1fwd (training form), k1bwd, k2fwd, k2bwd, k3fwd (p = 0.1), k3bwd, k5fwd, k5bwd (p = 0.1)"""
+usage: pmc_target.py <op> [M] [r]      op: k1fwd (training form), k1bwd, k2fwd, k2bwd, k3fwd (p = 0.1), k3bwd, k5fwd, k5bwd (p = 0.1), k4fwd (tiled GEMM form)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -52,6 +52,15 @@ elif op.startswith("k3"):
                                                 M, d, tiles, 0.5, io, st)
     bwd = lambda: lib.vlpet_lora_delta_bwd_saved(dy.data_ptr(), x1.data_ptr(), sv.data_ptr(), pk.buf.data_ptr(), None, 0.1, 1234, dx1.data_ptr(),
                                                  da.data_ptr(), db.data_ptr(), r, ws.data_ptr(), nws, M, d, tiles, 0.5, io, st)
+elif op.startswith("k4"):          # K4 forward, tiled-GEMM form (csrc/visproj_gemm.hip), 2048 -> 768
+    Fd = 2048
+    feats = rn(M, Fd).to(dt); wv = (rn(d, Fd) * 0.02).to(dt); bv = rn(d) * 0.1
+    gam, bet = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+    Rr = rn(M, d).to(dt); xh = torch.empty_like(out); rstd = torch.empty(M, device=dev)
+    nwsg = lib.vlpet_visproj_gemm_workspace_bytes(M, Fd, d); wsg = torch.zeros(nwsg, dtype=torch.uint8, device=dev)
+    fwd = lambda: lib.vlpet_visproj_fwd_gemm(feats.data_ptr(), wv.data_ptr(), bv.data_ptr(), gam.data_ptr(), bet.data_ptr(), Rr.data_ptr(), out.data_ptr(),
+                                             xh.data_ptr(), rstd.data_ptr(), None, wsg.data_ptr(), nwsg, M, Fd, d, 1e-5, 0, io, st)
+    bwd = fwd
 else:
     gam, bet = torch.ones(d, device=dev), torch.zeros(d, device=dev)
     mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)

@@ -37,9 +37,11 @@
 
 template <int N, int RTN>
 __device__ __forceinline__ void visg_frag_wait(u32x4 (&w)[2], u32x4 (&x)[RTN]) {
-    static_assert(RTN == 2 || RTN == 4, "");
+    static_assert(RTN >= 2 && RTN <= 4, "");
     if constexpr (RTN == 4)
         asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(w[0]), "+v"(w[1]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(N) : "memory");
+    else if constexpr (RTN == 3)
+        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(w[0]), "+v"(w[1]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]) : "n"(N) : "memory");
     else
         asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(x[0]), "+v"(x[1]) : "n"(N) : "memory");
 }
@@ -60,7 +62,7 @@ template <int BM, int BK, int NSLOT> struct VisGemmGeo {
     static constexpr int WST_OFF = PRM_OFF + 3 * 256 * 4;        // per-wave statistics [BM][4] x (mean, M2)
     static constexpr int RST_OFF = WST_OFF + BM * 32;            // row statistics [BM] x (mean, rstd)
     static constexpr int LDS_B = RST_OFF + BM * 8;
-    static_assert(PX >= 1 && PW >= 1 && LDS_B <= 160 * 1024, "");
+    static_assert(PX >= 1 && PW >= 1 && XT_B % 8192 == 0 && LDS_B <= 160 * 1024, "");
     static_assert(BK == 64 || BK == 32, "");
 };
 
@@ -439,12 +441,19 @@ bool visproj_gemm_applies(int64_t M, int F, int d_out, int io_fp32) {
     return M * wide * 2 < ((int64_t)1 << 32);           // (32-bit per-lane byte offsets)
 }
 static int visg_teams_max(int d_out) { return cols_groups_max(d_out / 256); }
-// rows per workgroup: 256, or 128 where that needs fewer (weighted) passes of the teams over the row blocks
+// rows per workgroup (128 / 192 / 256): the one that needs the least (weighted) passes of the teams over the row blocks -- a workgroup's
+// time is close to affine in its rows (profiles/r05_k4bench.txt: 18 us + 0.2 us per row), and a pass costs a whole workgroup time
+// whatever its fill.  Ties go to the larger tile (less L2 -> LDS traffic per flop).
 static int visg_pick_bm(int64_t M, int d_out, int forced) {
-    if (forced == 128 || forced == 256) return forced;
+    if (forced == 128 || forced == 192 || forced == 256) return forced;
     const int tmax = visg_teams_max(d_out);
-    const double c256 = (double)(((M + 255) / 256 + tmax - 1) / tmax), c128 = 0.56 * (double)(((M + 127) / 128 + tmax - 1) / tmax);
-    return c128 < c256 ? 128 : 256;
+    int best = 256; double bc = 1e30;
+    for (int bm : {256, 192, 128}) {
+        const double passes = (double)(((M + bm - 1) / bm + tmax - 1) / tmax);
+        const double c = passes * (18.0 + 0.2 * bm);
+        if (c < bc - 1e-9) { bc = c; best = bm; }
+    }
+    return best;
 }
 size_t visproj_gemm_workspace_bytes(int64_t M, int F, int d_out) {
     if (!visproj_gemm_applies(M, F, d_out, 0)) return 0;
@@ -472,17 +481,23 @@ static hipError_t launch_visg(VisGemmArgs& a, uint8_t* ws, hipStream_t stream) {
 // the stage ahead spread between the MFMA groups; bm: 0 = by shape
 hipError_t launch_visproj_gemm(VisGemmArgs& a, void* ws, int form, int bm, hipStream_t stream) {
     uint8_t* w8 = reinterpret_cast<uint8_t*>(ws);
-    const int BMv = visg_pick_bm(a.M, a.d_out, bm);
     if (form == 0) form = VISG_DEFAULT_FORM;
+    int BMv = visg_pick_bm(a.M, a.d_out, bm);
+    if (BMv == 192 && form != 1 && form != 4) {         // (192-row tiles exist for the 64-feature stages only)
+        if (bm == 192) return hipErrorInvalidValue;
+        BMv = visg_pick_bm(a.M, a.d_out, 0) == 192 ? 256 : BMv;
+    }
 #define VISG_GO(BK_, NS_, SP_) return BMv == 256 ? launch_visg<256, BK_, NS_, SP_>(a, w8, stream) : launch_visg<128, BK_, NS_, SP_>(a, w8, stream)
+#define VISG_GO3(NS_, SP_) return BMv == 256 ? launch_visg<256, 64, NS_, SP_>(a, w8, stream) : BMv == 192 ? launch_visg<192, 64, NS_, SP_>(a, w8, stream) : launch_visg<128, 64, NS_, SP_>(a, w8, stream)
     switch (form) {
-        case 1: VISG_GO(64, 2, false);
+        case 1: VISG_GO3(2, false);
         case 2: VISG_GO(32, 4, false);
         case 3: VISG_GO(32, 3, false);
-        case 4: VISG_GO(64, 2, true);
+        case 4: VISG_GO3(2, true);
         case 5: VISG_GO(32, 4, true);
         case 6: VISG_GO(32, 3, true);
         default: return hipErrorInvalidValue;
     }
 #undef VISG_GO
+#undef VISG_GO3
 }

@@ -36,13 +36,17 @@ class KernelTimer:
         return out
 
     def summary(self):
-        """name -> dict(launches, rows, total_us); call after torch.cuda.synchronize()."""
+        """name -> dict(launches, rows, total_us, by_rows = {rows of a launch: [launches, total_us]}); call after torch.cuda.synchronize()."""
         agg = {}
         for name, rows, e0, e1 in self.records:
-            a = agg.setdefault(name, dict(launches=0, rows=0, total_us=0.0))
+            a = agg.setdefault(name, dict(launches=0, rows=0, total_us=0.0, by_rows={}))
+            us = e0.elapsed_time(e1) * 1e3
             a["launches"] += 1
             a["rows"] += rows
-            a["total_us"] += e0.elapsed_time(e1) * 1e3
+            a["total_us"] += us
+            b = a["by_rows"].setdefault(int(rows), [0, 0.0])
+            b[0] += 1
+            b[1] += us
         return agg
 
 
