@@ -75,7 +75,7 @@ __device__ __forceinline__ void stage_image(uint8_t* img, const __bf16* src, int
     for (int idx = tid; idx < rows_pad * 8; idx += nthreads) {
         const int row = idx >> 3, pc = idx & 7;
         u32x4 v = z;
-        if (row < n_rows) v = *reinterpret_cast<const u32x4*>(src + (int64_t)row * rs + pc * 8);
+        if (row < n_rows) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + (int64_t)row * rs + pc * 8));      // (read once per launch: nt)
         *reinterpret_cast<u32x4*>(img + (size_t)row * AT_ROW + pc * 16) = v;
     }
 }
@@ -91,7 +91,7 @@ __device__ __forceinline__ void stage_images(uint8_t* const* img, const __bf16* 
         for (int c = 0; c < MAXP; ++c) {
             const int idx = tid + c * nthreads, row = idx >> 3, pc = idx & 7;
             const int rr = row < n_rows[g] ? row : n_rows[g] - 1;
-            v[g][c] = *reinterpret_cast<const u32x4*>(src[g] + (int64_t)rr * rs[g] + pc * 8);
+            v[g][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src[g] + (int64_t)rr * rs[g] + pc * 8));
         }
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -459,8 +459,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
             const int rr = row < a.Lq ? row : a.Lq - 1;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                xo[c][e] = *reinterpret_cast<const bf16x8*>(a.o + ooff + (int64_t)rr * rs + 16 * part + 8 * e);
-                xd[c][e] = *reinterpret_cast<const bf16x8*>(a.dout + ooff + (int64_t)rr * rs + 16 * part + 8 * e);
+                xo[c][e] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(a.o + ooff + (int64_t)rr * rs + 16 * part + 8 * e));
+                xd[c][e] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(a.dout + ooff + (int64_t)rr * rs + 16 * part + 8 * e));
             }
         }
         if (tid < Lkp) kval[tid] = key_bias(a, km, tid);

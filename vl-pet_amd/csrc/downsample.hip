@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void downsample_slab_kernel(PoolArgs a) {
     const float* src = reinterpret_cast<const float*>(a.x) + img * (int64_t)ntok * a.dim + slab * 256;
     for (int i = tid; i < ntok * 64; i += 256) {                          // 64 float4 per token row
         const int t = i >> 6, c4 = i & 63;
-        reinterpret_cast<f32x4*>(tile)[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)t * a.dim + 4 * c4);
+        reinterpret_cast<f32x4*>(tile)[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (int64_t)t * a.dim + 4 * c4));      // (every input token is read once)
     }
     __syncthreads();
     const int cg = tid & 31;                                              // 8 channels

@@ -29,12 +29,12 @@ template <typename IO, int PB = 16> struct Piece {
     using Raw = typename std::conditional<PB == 16, u32x4, u32x2>::type;
     static __device__ __forceinline__ void load(const void* p, float* v) {
         static_assert(PB == 16, "");
-        if constexpr (E == 8) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+        if constexpr (E == 8) {          // (non-temporal: the row kernels read every row tensor once per launch)
+            const bf16x8 a = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
         } else {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+            const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = a[j];
         }

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void colsum_partial_kernel(const v
         if (r >= M) r = M - 1;
         const int64_t o = r * n * (int64_t)sizeof(IO);
 #pragma unroll
-        for (int k = 0; k < NP; ++k) { const int p = lane + 64 * k; if (p < pieces) rd[k] = P::load_raw(x + o + p * 16); }
+        for (int k = 0; k < NP; ++k) { const int p = lane + 64 * k; if (p < pieces) rd[k] = P::load_raw_nt(x + o + p * 16); }
     };
     const int64_t r0 = (int64_t)blockIdx.x * TAIL_WAVES + wave;
     if (r0 < M) load_row(r0, cur);
