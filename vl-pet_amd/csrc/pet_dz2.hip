@@ -19,6 +19,15 @@
 // like pet_cols' bottleneck tiles) + the dy and x2 tiles [128 rows x 128 B] (pet16.h swz); three weight slots + two row slots + the biases = 142 KiB (see the loop for why three).
 #include "cols_common.h"
 
+// Cache policy of pass 1's row loads (dy, x2).  Pass 2 reads both tensors again right after this launch: with the non-temporal policy
+// of the other row streams (aux 2) pass 1 discourages exactly the lines pass 2 is about to ask for; -DVLPET_P1_AUX=0 = default policy.
+#ifndef VLPET_P1_AUX
+#define VLPET_P1_AUX 2
+#endif
+__device__ __forceinline__ void glds16_p1(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gmem_cv*)gsrc, (lmem_v*)lds_wave_base, 16, 0, VLPET_P1_AUX);
+}
+
 #ifndef VLPET_DZ2_AW1
 #define VLPET_DZ2_AW1 2     // stages the weight / row requests run ahead at RT = 1 (LDS allows it); RT = 3: 1 / 1
 #define VLPET_DZ2_AX1 2
@@ -120,8 +129,8 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
     };
     auto issue_x1 = [&](int s, int j) {
         uint8_t* st = smem + X_OFF + (size_t)(s % NXS) * XS_B;
-        glds16_row(sbase(dyp + s * 128) + xoff[j], st + xdst[j]);
-        glds16_row(sbase(x2p + s * 128) + xoff[j], st + XT_B + xdst[j]);
+        glds16_p1(sbase(dyp + s * 128) + xoff[j], st + xdst[j]);
+        glds16_p1(sbase(x2p + s * 128) + xoff[j], st + XT_B + xdst[j]);
     };
     auto issue_x = [&](int s) { issue_x1(s, 0); issue_x1(s, 1); };
 

@@ -16,6 +16,15 @@
 // refilled every second half-stage) + the up biases (6 KiB) = 118 KiB.
 #include "cols_common.h"
 
+// Cache policy of pass 1's row loads (dy, x2).  Pass 2 reads both tensors again right after this launch: with the non-temporal policy
+// of the other row streams (aux 2) pass 1 discourages exactly the lines pass 2 is about to ask for; -DVLPET_P1_AUX=0 = default policy.
+#ifndef VLPET_P1_AUX
+#define VLPET_P1_AUX 2
+#endif
+__device__ __forceinline__ void glds16_p1(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gmem_cv*)gsrc, (lmem_v*)lds_wave_base, 16, 0, VLPET_P1_AUX);
+}
+
 template <int RT> struct Dz6Geo {
     static constexpr int PB = 64 * RT;                 // bytes of a weight row (one feature, all bottleneck columns)
     static constexpr int NPS = PB / 16;
@@ -114,8 +123,8 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
         uint8_t* st = smem + X_OFF + (size_t)(s & 1) * XS_B;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            glds16_row(sbase(dyp + s * 128) + xoff[j], st + xdst[j]);
-            glds16_row(sbase(x2p + s * 128) + xoff[j], st + XT_B + xdst[j]);
+            glds16_p1(sbase(dyp + s * 128) + xoff[j], st + xdst[j]);
+            glds16_p1(sbase(x2p + s * 128) + xoff[j], st + XT_B + xdst[j]);
         }
     };
 
