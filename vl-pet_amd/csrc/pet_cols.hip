@@ -341,6 +341,10 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
                     });
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dyv[0]), "+v"(x2v[0]), "+v"(dyv[1]), "+v"(x2v[1]), "+v"(dyv[2]), "+v"(x2v[2]), "+v"(dyv[3]), "+v"(x2v[3]) :: "memory");
                 }
+#if defined(VLPET_COLS_ABL) && (VLPET_COLS_ABL & 4)
+                asm volatile("" :: "v"(aA[0]), "v"(aG[0]), "v"(dyv[0]), "v"(x2v[0]));
+                if (false)
+#endif
                 sfor<4>([&](auto C) {                                     // 4 columns at a time (a small live set): dy, x2 in, dh, dq out
                     constexpr int c = C.value;
                     if constexpr (!EW_AHEAD) {
@@ -376,8 +380,10 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
             // this wave's own columns of dh, dq: its writes above are ordered before these reads by the waits in between
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             COLS_STAMP(2)
+#if !(defined(VLPET_COLS_ABL) && (VLPET_COLS_ABL & 1))
             wg_products(sb, I0{}, I0{}, dh0 + a_xtr[0], dh0 + a_xtr[1], accA, 0);
             wg_products(sb, I1{}, I0{}, dq0 + a_xtr[0], dq0 + a_xtr[1], accG, 1);
+#endif
             if (want_csp) {                                               // its own block (inside the products it would make every accumulator a phi)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -471,7 +477,9 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
             COLS_STAMP(4)
             step_top(s, s >= 2 ? 4 : 0);
             COLS_STAMP(0)
+#if !(defined(VLPET_COLS_ABL) && (VLPET_COLS_ABL & 2))
             if (s > 0) finish(s - 1, dinA, dinB);
+#endif
             COLS_STAMP(1)
             if constexpr (HAS_IN) {
                 lds_read16<3 * 8192>(dinA, sb + a_xcl[0]); lds_read16<3 * 8192>(dinB, sb + a_xcl[1]);

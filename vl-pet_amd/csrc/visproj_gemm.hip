@@ -471,6 +471,16 @@ static hipError_t launch_visg(VisGemmArgs& a, uint8_t* ws, hipStream_t stream) {
     a.xch = reinterpret_cast<unsigned long long*>(ws + 256);
     (void)NT;
     auto kern = visproj_gemm_kernel<BM, BK, NSLOT, SPREAD>;
+    // residency: a team's members must run concurrently, which one workgroup per CU and a grid no larger than the device's CU count
+    // guarantee (a smaller device gets fewer teams and more passes, never a grid it cannot hold)
+    {
+        int dev = 0, cus = 0;
+        hipError_t eq = hipGetDevice(&dev);
+        if (eq == hipSuccess) eq = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (eq != hipSuccess) return eq;
+        while (a.nteams > 1 && (int)cols_grid(NT, a.nteams) > cus) --a.nteams;
+        if ((int)cols_grid(NT, a.nteams) > cus) return hipErrorInvalidConfiguration;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEO::LDS_B);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(cols_grid(NT, a.nteams)), dim3(512), GEO::LDS_B, stream, a);
