@@ -332,7 +332,8 @@ int vlpet_norm_residual_fwd(const void* y, const void* r, const float* gamma, co
  * backward regenerates it from the same seed -- nothing is stored.  p = 0 switches it off.
  *   h_save [M, d] (IO dtype), mean [M], rstd [M]: saved for the backward (norm_mode 1; h_save may
  *       be NULL for inference);  keep_out: optional [M, d] uint8 export of the mask (tests).
- * Backward: dx1 [M, d] always; dy [M, d] only when p > 0 (with p = 0, dy == dx1: pass NULL and
+ * Backward: dx1 [M, d] (may be NULL for norm_mode 0 with p > 0: there d/dx1 is dout itself and the
+ * caller hands dout on -- no copy); dy [M, d] only when p > 0 (with p = 0, dy == dx1: pass NULL and
  * alias); dgb_partials [vlpet_sublayer_tail_partials(M)][2][d] fp32 = per-workgroup partial
  * sums of (dgamma, dbeta), or NULL when the LayerNorm is frozen. */
 int vlpet_sublayer_tail_partials(int64_t M);
@@ -377,6 +378,16 @@ int vlpet_rmsnorm_fwd(const void* x, const float* gamma, void* out, float* rstd,
                       vlpet_stream_t stream);
 int vlpet_rmsnorm_bwd(const void* dout, const void* x, const float* rstd, const float* gamma, const void* dx_in, void* dx,
                       float* dgb_partials, int64_t M, int d, int io_dtype, vlpet_stream_t stream);
+/* T5's residual tail + the NEXT sublayer's T5LayerNorm in one pass (round 5): sum = x1 + dropout(y) (modeling_t5.py:408 / 824), normed =
+ * rmsnorm(sum) * gamma_next (:366 / 782 of the next sublayer; the statistic is taken on the sum rounded to the IO dtype, as a second
+ * launch would have read it); rstd [M] saved for the backward. */
+int vlpet_sublayer_tail_rms_fwd(const void* y, const void* x1, const float* gamma_next, void* sum, void* normed, float* rstd,
+                                int64_t M, int d, float eps, float p, uint64_t seed, int io_dtype, vlpet_stream_t stream);
+/* ... backward: d_sum = rmsnorm'(d_normed) + dsum_in (optional: what the sum's other readers parked); dx1 = d_sum; dy = d_sum * keep / (1 - p)
+ * (p > 0; else dy == dx1, pass NULL); dgb_partials as in vlpet_rmsnorm_bwd. */
+int vlpet_rmsnorm_tail_bwd(const void* d_normed, const void* sum, const float* rstd, const float* gamma_next, const void* dsum_in,
+                           void* dx1, void* dy, float* dgb_partials, int64_t M, int d, float p, uint64_t seed, int io_dtype,
+                           vlpet_stream_t stream);
 /* out [n] (fp32, OVERWRITTEN) = column sums of x [M, n] (IO dtype): the gradient of a trainable Linear bias -- the reference's LoRA
  * runs train every bias (src/trainer_base.py `unfreeze "bias"` rule; autograd's dy.sum(0) of my_transformers/modeling_bart.py:791-811).
  * workspace: vlpet_sublayer_tail_partials(M) * n floats.  n % 16 == 0, n <= 4096 (bf16) / 2048 (fp32).  Two launches. */

@@ -269,6 +269,42 @@ def test_rms_norm_matches_the_eager_t5_layer_norm(M, d, dtype):
     assert _rel(W.grad, wr.grad) <= tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("p", [0.0, 0.25])
+@pytest.mark.parametrize("M,d", [(1, 64), (333, 768), (3111, 768), (130, 1024)])
+def test_tail_fused_with_the_next_rms_norm_matches_the_oracle(M, d, p, dtype):
+    """vlpet_sublayer_tail_rms_fwd / vlpet_rmsnorm_tail_bwd behind tail.sublayer_tail_rms: sum = x1 + dropout(y) and the next T5LayerNorm of
+    the sum in one pass each way, against the oracle's tail followed by the eager fp32 norm -- both outputs, d/dx1, d/dy, d/dweight, with a
+    gradient arriving for the sum itself (another reader) next to the one for the normalised rows.  The mask is read back from the
+    plain tail run with the same seed (the generator is a function of (seed, element index) only)."""
+    from vlpet_amd.tail import sublayer_tail, sublayer_tail_rms
+    from vlpet_amd.visual import T5LayerNorm
+    g = torch.Generator().manual_seed(31)
+    q = lambda t: t.to(dtype).float()
+    x1, y = q(torch.randn(M, d, generator=g)), q(torch.randn(M, d, generator=g) * 0.7 + 0.1)
+    w = 1.0 + 0.2 * torch.randn(d, generator=g)
+    dn, ds = q(torch.randn(M, d, generator=g)), q(torch.randn(M, d, generator=g))
+    norm = T5LayerNorm(d, eps=1e-6).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(w)
+    X1 = x1.to("cuda", dtype).requires_grad_(True); Y = y.to("cuda", dtype).requires_grad_(True)
+    _, mask = sublayer_tail(x1.to("cuda", dtype), y.to("cuda", dtype), None, p=p, training=True, seed=77, return_mask=True)
+    mask = mask.float().cpu()
+    s = sublayer_tail_rms(X1, Y, norm, p=p, training=True, seed=77)
+    n = norm(s)
+    assert n is s._vlpet_norm.normed
+    (n.float() * dn.cuda() + s.float() * ds.cuda()).sum().backward()
+    x1r, yr, wr = x1.clone().requires_grad_(True), y.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    sr = O.t5_sublayer_tail(x1r, yr * mask / (1.0 - p))
+    srq = sr + (q(sr.detach()) - sr.detach())               # the norm reads the sum as stored (rounded to the IO dtype), straight-through
+    nr = wr * (srq * torch.rsqrt(srq.pow(2).mean(-1, keepdim=True) + 1e-6))
+    (nr * dn + sr * ds).sum().backward()
+    tol = TOL[dtype]
+    for name, a, b in (("sum", s, sr.detach()), ("normed", n, nr.detach()), ("dx1", X1.grad, x1r.grad), ("dy", Y.grad, yr.grad),
+                       ("dweight", norm.weight.grad, wr.grad)):
+        assert _rel(a, b) <= tol, (name, _rel(a, b))
+
+
 def test_t5_layer_norm_module_uses_the_hip_path_and_keeps_the_activation_dtype():
     from vlpet_amd.visual import T5LayerNorm
     ln = T5LayerNorm(256).cuda()                          # fp32 master weight next to bf16 activations

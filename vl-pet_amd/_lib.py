@@ -110,6 +110,8 @@ SIGNATURES = {
     "vlpet_reduce_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vlpet_rmsnorm_fwd": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_float, c_int, c_void_p]),
     "vlpet_rmsnorm_bwd": (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int, c_void_p]),
+    "vlpet_sublayer_tail_rms_fwd": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_float, c_float, c_uint64, c_int, c_void_p]),
+    "vlpet_rmsnorm_tail_bwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_float, c_uint64, c_int, c_void_p]),
     "vlpet_attn_fwd": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_float, c_float, c_uint64, c_void_p]),
     "vlpet_attn_bwd": (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_float, c_float, c_uint64, c_void_p]),
     "vlpet_attn_fwd_ld": (c_int, [c_void_p] * 7 + [c_int] * 7 + [c_float, c_float, c_uint64, c_void_p]),

@@ -993,6 +993,37 @@ extern "C" int vlpet_rmsnorm_bwd(const void* dout, const void* x, const float* r
     return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
 }
 
+// T5's residual tail and the NEXT sublayer's T5LayerNorm in one pass (round 5):  sum = x1 + dropout(y);  normed = rmsnorm(sum) * gamma_next.
+// Replaces my_transformers/modeling_t5.py:408 (824) followed by :366 (782) of the next sublayer.  Backward: vlpet_rmsnorm_tail_bwd.
+extern "C" int vlpet_sublayer_tail_rms_fwd(const void* y, const void* x1, const float* gamma_next, void* sum, void* normed, float* rstd,
+                                           int64_t M, int d, float eps, float p, uint64_t seed, int io_dtype, vlpet_stream_t stream) {
+    int rc = tail_common(M, d, p, io_dtype);
+    if (rc) return rc;
+    if (!y || !x1 || !gamma_next || !sum || !normed || !rstd) return VLPET_E_NULL;
+    if (!aligned16(y) || !aligned16(x1) || !aligned16(sum) || !aligned16(normed)) return VLPET_E_ALIGN;
+    TailArgs a{};
+    a.y = y; a.x1 = x1; a.out = sum; a.out2 = normed; a.gamma2 = gamma_next; a.rstd = rstd; a.M = M; a.d = d; a.eps = eps;
+    a.thr = tail_thr(p); a.keep_scale = 1.0f / (1.0f - p); a.seed = seed; a.seed_ctr = g_seed_ctr.load(); a.norm = 0;
+    return herr(launch_tail(a, io_dtype == VLPET_F32, false, (hipStream_t)stream));
+}
+// ... and its backward: d_sum = rmsnorm'(d_normed) (+ dsum_in, the gradient the sum's other readers parked);  dx1 = d_sum;
+// dy = d_sum * keep / (1 - p) (written when p > 0; with p = 0 dy == dx1).  One pass instead of the norm's backward + the tail's.
+extern "C" int vlpet_rmsnorm_tail_bwd(const void* d_normed, const void* sum, const float* rstd, const float* gamma_next, const void* dsum_in,
+                                      void* dx1, void* dy, float* dgb_partials, int64_t M, int d, float p, uint64_t seed, int io_dtype,
+                                      vlpet_stream_t stream) {
+    int rc = tail_common(M, d, p, io_dtype);
+    if (rc) return rc;
+    if (!d_normed || !sum || !rstd || !gamma_next || !dx1) return VLPET_E_NULL;
+    const uint32_t thr = tail_thr(p);
+    if (thr && !dy) return VLPET_E_NULL;
+    if (!aligned16(d_normed) || !aligned16(sum) || !aligned16(dx1) || (dy && !aligned16(dy)) || (dsum_in && !aligned16(dsum_in))) return VLPET_E_ALIGN;
+    TailArgs a{};
+    a.out = const_cast<void*>(d_normed); a.h = const_cast<void*>(sum); a.mean = nullptr; a.rstd = const_cast<float*>(rstd);
+    a.gamma = gamma_next; a.x1 = dx1; a.y = dy; a.dgb = dgb_partials; a.M = M; a.d = d; a.thr = thr; a.keep_scale = 1.0f / (1.0f - p);
+    a.seed = seed; a.seed_ctr = g_seed_ctr.load(); a.norm = 1; a.rms = 1; a.dres = dsum_in;
+    return herr(launch_tail(a, io_dtype == VLPET_F32, true, (hipStream_t)stream));
+}
+
 // Column sums of x [M, n] in fp32 (OVERWRITTEN): the gradient of a trainable bias (dy.sum(0)).  workspace: at least
 // vlpet_sublayer_tail_partials(M) * n floats.  n % 16 == 0.
 extern "C" int vlpet_colsum(const void* x, int64_t M, int n, float* workspace, float* out, int io_dtype, vlpet_stream_t stream) {
@@ -1076,12 +1107,14 @@ extern "C" int vlpet_sublayer_tail_bwd(const void* dout, const void* h_save, con
                                        float p, uint64_t seed, int norm_mode, int io_dtype, vlpet_stream_t stream) {
     int rc = tail_common(M, d, p, io_dtype);
     if (rc) return rc;
-    if (!dout || !dx1) return VLPET_E_NULL;
     if (norm_mode != 0 && norm_mode != 1) return VLPET_E_SHAPE;
-    if (norm_mode && (!h_save || !mean || !rstd || !gamma)) return VLPET_E_NULL;
     const uint32_t thr = tail_thr(p);
+    // dx1 may be NULL for the plain residual tail under dropout (norm_mode 0, p > 0): there d/dx1 IS dout, and a caller that hands dout on
+    // itself saves the copy (a third of the pass's traffic; T5 runs 60 such tails per step)
+    if (!dout || (!dx1 && (norm_mode != 0 || thr == 0))) return VLPET_E_NULL;
+    if (norm_mode && (!h_save || !mean || !rstd || !gamma)) return VLPET_E_NULL;
     if (thr && !dy) return VLPET_E_NULL;
-    if (!aligned16(dout) || !aligned16(dx1) || (dy && !aligned16(dy)) || (h_save && !aligned16(h_save))) return VLPET_E_ALIGN;
+    if (!aligned16(dout) || (dx1 && !aligned16(dx1)) || (dy && !aligned16(dy)) || (h_save && !aligned16(h_save))) return VLPET_E_ALIGN;
     TailArgs a{};
     a.out = const_cast<void*>(dout); a.h = const_cast<void*>(h_save); a.mean = const_cast<float*>(mean);
     a.rstd = const_cast<float*>(rstd); a.gamma = gamma; a.beta = nullptr; a.x1 = dx1; a.y = dy; a.keep_out = nullptr;

@@ -247,6 +247,8 @@ struct TailArgs {
                             //    stream of a pre-norm sublayer feeds the norm and the tail's add, my_transformers/modeling_t5.py:366, 408)
     int rms;                // norm = 1 as T5's RMS norm (my_transformers/modeling_t5.py:235-252): no mean subtraction, no beta; `mean`
                             //    is neither written nor read.  fwd: `y` may be null (out = rmsnorm(x1)); bwd: `h` = the norm's input rows
+    void* out2;             // fwd, norm = 0 only: second output = rmsnorm(out) * gamma2 (the NEXT sublayer's T5LayerNorm applied to the sum this
+    const float* gamma2;    //    tail produces: one pass instead of two, my_transformers/modeling_t5.py:408 + :366 of the next sublayer); rstd [M] written
 };
 hipError_t launch_tail(const TailArgs& a, int io_fp32, bool bwd, hipStream_t stream);
 int tail_blocks(int64_t M);

@@ -54,9 +54,12 @@ __device__ __forceinline__ void row_keep_bits(int64_t row_e0, int lane, int piec
 
 // POST (NORM only): out = LayerNorm(dropout(y)) + x1 -- the residual joins AFTER the norm (visual projectors:
 // src/modeling_bart.py:298-299 then :324-325); statistics and the saved pre-norm tensor are those of dropout(y) alone.
-template <typename IO, int NP, bool NORM, bool POST = false, int PB = 16>
+// RMS2 (plain residual tail only, round 5): the wave that has just formed the row x1 + dropout(y) also applies the NEXT sublayer's RMS norm
+// to it and writes both -- T5's pre-norm stream otherwise reads the sum back in a second launch (2 of that launch's 2 units + the launch).
+template <typename IO, int NP, bool NORM, bool POST = false, int PB = 16, bool RMS2 = false>
 __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
     static_assert(!POST || NORM, "post-norm residual needs the norm");
+    static_assert(!RMS2 || !NORM, "the second (normalised) output belongs to the plain residual tail");
     using P = Piece<IO, PB>;
     using Raw = typename P::Raw;
     constexpr int E = P::E;
@@ -77,9 +80,19 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
             }
         }
     }
+    float gam2[RMS2 ? NP : 1][E];
+    if constexpr (RMS2) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int p = lane + 64 * k;
+#pragma unroll
+            for (int j = 0; j < E; ++j) gam2[k][j] = p < pieces ? a.gamma2[p * E + j] : 0.f;
+        }
+    }
     const uint8_t* y = reinterpret_cast<const uint8_t*>(a.y);
     const uint8_t* x1 = reinterpret_cast<const uint8_t*>(a.x1);
     uint8_t* out = reinterpret_cast<uint8_t*>(a.out);
+    uint8_t* out2 = reinterpret_cast<uint8_t*>(a.out2);
     uint8_t* hs = reinterpret_cast<uint8_t*>(a.h);
     const float inv_d = 1.0f / (float)d;
     // the next row of this wave is requested before the current one is reduced: a wave that loads, reduces, stores
@@ -166,10 +179,38 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
                 }
             }
         } else {
+            float rstd2 = 0.f;
+            if constexpr (RMS2) {
+                float q = 0.f;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    if (lane + 64 * k < pieces) {
+#pragma unroll
+                        for (int j = 0; j < E; ++j) {
+                            // the norm sees the sum as the next launch would have read it: rounded to the IO dtype
+                            const float hr = sizeof(IO) == 2 ? (float)(__bf16)h[k][j] : h[k][j];
+                            q += hr * hr;
+                        }
+                    }
+                }
+                rstd2 = rsqrtf(wave_sum(q) * inv_d + a.eps);
+                if (lane == 0) a.rstd[row] = rstd2;
+            }
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int p = lane + 64 * k;
-                if (p < pieces) P::store(out + rb + p * PB, h[k]);
+                if (p < pieces) {
+                    P::store(out + rb + p * PB, h[k]);
+                    if constexpr (RMS2) {
+                        float o2[E];
+#pragma unroll
+                        for (int j = 0; j < E; ++j) {
+                            const float hr = sizeof(IO) == 2 ? (float)(__bf16)h[k][j] : h[k][j];
+                            o2[j] = hr * rstd2 * gam2[k][j];
+                        }
+                        P::store(out2 + rb + p * PB, o2);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -325,7 +366,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
 #pragma unroll
                     for (int j = 0; j < E; ++j) g[j] += vr[j];
                 }
-                P::store(dx1 + rb + p * PB, g);
+                if (NORM || DRES || dx1) P::store(dx1 + rb + p * PB, g);      // (plain residual tail: dx1 == dout, the caller may alias it and pass no dx1)
                 if (thr) {
                     const uint32_t bits = kb[k];
                     float o[E];
@@ -553,6 +594,9 @@ static hipError_t launch_np(const TailArgs& a, bool bwd, hipStream_t stream) {
     else if (NORM && a.post) {
         if constexpr (NORM) hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, true, true, PB>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
     }
+    else if (!NORM && a.out2) {
+        if constexpr (!NORM) hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, false, false, PB, true>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+    }
     else hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, NORM, false, PB>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
     return hipGetLastError();
 }
@@ -588,6 +632,7 @@ static hipError_t launch_io(const TailArgs& a, bool bwd, hipStream_t stream) {
 
 hipError_t launch_tail(const TailArgs& a, int io_fp32, bool bwd, hipStream_t stream) {
     if (a.post && (!a.norm || bwd)) return hipErrorInvalidValue;      // forward-only form of the norm path
+    if (a.out2 && (a.norm || bwd || !a.gamma2 || !a.rstd)) return hipErrorInvalidValue;
     if (a.h_out && (!a.norm || !bwd || a.rms || a.h_xhat || a.dres)) return hipErrorInvalidValue;
     if (a.norm) return io_fp32 ? launch_io<float, true>(a, bwd, stream) : launch_io<__bf16, true>(a, bwd, stream);
     return io_fp32 ? launch_io<float, false>(a, bwd, stream) : launch_io<__bf16, false>(a, bwd, stream);

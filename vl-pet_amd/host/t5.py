@@ -41,6 +41,10 @@ def _pet_then_tail(layer, which, residual, h, norm, p, training, config, norm_li
     from ..functional import ResidualLink
     link = ResidualLink()
     y = apply_pet(layer, which, residual, h, config, link=link, out_link=norm_link)
+    nxt = _fused_tail_ok(layer, y) if norm is None else None
+    if nxt is not None:
+        from ..tail import sublayer_tail_rms
+        return sublayer_tail_rms(residual, y, nxt, p, training, link=link)
     return sublayer_tail(residual, y, norm, p, training, link=link)
 
 
@@ -51,6 +55,9 @@ FUSE_NORM_GRAD = True     # (A/B switch, tools/ab_switches.py: False = autograd'
 
 
 def _new_norm_link(x):
+    fused = getattr(x, "_vlpet_norm", None)     # x came out of a fused tail + norm: its later readers park their gradients in THAT op's link
+    if fused is not None:
+        return fused.link
     if not (FUSE_RESIDUAL_GRAD and FUSE_NORM_GRAD) or not x.is_cuda or not x.requires_grad or not torch.is_grad_enabled():
         return None
     from ..functional import ResidualLink
@@ -61,7 +68,23 @@ def _normed(norm, hidden, link):
     return norm(hidden) if link is None else norm(hidden, link=link)
 
 
-def _tail_linked(hidden, y, p, training, link):
+# The sum a T5 tail produces is read next by the following sublayer's RMS norm: the tail kernel applies that norm to the row it has just
+# formed and writes both (tail.sublayer_tail_rms: one pass instead of two forward, one instead of two backward).  Each sublayer module
+# knows the norm that follows it (``_next_norm``, wired by ``_wire_next_norms`` when the stack is built; not a registered submodule).
+FUSE_TAIL_NORM = True     # (A/B switch: False = the tail and the next norm as two launches each way)
+
+
+def _fused_tail_ok(layer, y):
+    nn_ = getattr(layer, "_next_norm", None)
+    return (nn_[0] if (FUSE_TAIL_NORM and FUSE_RESIDUAL_GRAD and FUSE_NORM_GRAD and nn_ is not None and y.is_cuda
+                       and sublayer_tail is _HIP_SUBLAYER_TAIL and y.shape[-1] % 8 == 0) else None)
+
+
+def _tail_linked(hidden, y, p, training, link, layer=None):
+    nxt = _fused_tail_ok(layer, y) if layer is not None else None
+    if nxt is not None:
+        from ..tail import sublayer_tail_rms
+        return sublayer_tail_rms(hidden, y, nxt, p, training, link=link if (link is not None and link.armed) else None)
     if link is None or not link.armed:
         return sublayer_tail(hidden, y, None, p, training)
     return sublayer_tail(hidden, y, None, p, training, link=link)
@@ -85,6 +108,17 @@ def sublayer_tail(residual, h, norm, p, training, link=None):
     restatement, exactly as for host.bart."""
     from ..tail import sublayer_tail as _hip_tail
     return _hip_tail(residual, h, norm, p, training, link=link)
+
+
+_HIP_SUBLAYER_TAIL = sublayer_tail      # (a parity harness that swaps ``sublayer_tail`` for an eager restatement also switches the fusion off)
+
+
+def _wire_next_norms(blocks, final_norm):
+    """Every sublayer module of a stack learns which T5LayerNorm reads its output: the next sublayer's, the next block's first, or
+    the stack's final norm (a 1-tuple attribute, so that the norm is not registered a second time as a submodule)."""
+    subs = [m for b in blocks for m in b.layer]
+    for i, m in enumerate(subs):
+        object.__setattr__(m, "_next_norm", ((subs[i + 1].layer_norm if i + 1 < len(subs) else final_norm),))
 
 
 def vlt5_config(**over) -> SimpleNamespace:
@@ -313,7 +347,7 @@ class T5LayerSelfAttention(nn.Module):
         y = self.SelfAttention(_normed(self.layer_norm, hidden, nl), bias)
         if not self.is_decoder and has_pet(self, "attn"):                                 # K1 (x1 = un-normalised stream) + K5
             return _pet_then_tail(self, "attn", hidden, y, None, self.p, self.training, self.config, norm_link=nl)
-        return _tail_linked(hidden, y, self.p, self.training, nl)                         # K5
+        return _tail_linked(hidden, y, self.p, self.training, nl, layer=self)             # K5 (+ the next sublayer's norm)
 
 
 class T5LayerCrossAttention(nn.Module):
@@ -327,7 +361,7 @@ class T5LayerCrossAttention(nn.Module):
     def forward(self, hidden, enc, bias, task=None):
         nl = _new_norm_link(hidden)
         y = self.EncDecAttention(_normed(self.layer_norm, hidden, nl), bias, kv=enc, task=task)
-        return _tail_linked(hidden, y, self.p, self.training, nl)
+        return _tail_linked(hidden, y, self.p, self.training, nl, layer=self)
 
 
 class T5LayerFF(nn.Module):
@@ -344,7 +378,7 @@ class T5LayerFF(nn.Module):
         y = self.DenseReluDense(_normed(self.layer_norm, hidden, nl))
         if not self.is_decoder and has_pet(self, "ff"):
             return _pet_then_tail(self, "ff", hidden, y, None, self.p, self.training, self.config, norm_link=nl)      # K1 + K5
-        return _tail_linked(hidden, y, self.p, self.training, nl)
+        return _tail_linked(hidden, y, self.p, self.training, nl, layer=self)
 
 
 class T5Block(nn.Module):
@@ -376,6 +410,7 @@ class JointEncoder(nn.Module):
         self.embed_tokens = embed_tokens
         self.block = nn.ModuleList([T5Block(config, False, i == 0) for i in range(config.num_layers)])
         self.final_layer_norm = T5LayerNorm(config.d_model, eps=config.layer_norm_epsilon)
+        _wire_next_norms(self.block, self.final_layer_norm)
         self.p = config.dropout_rate
         vcfg = copy.copy(config)
         self.visual_embedding = VisualEmbedding(vcfg, embed_tokens, rms_norm=True)
@@ -420,6 +455,7 @@ class T5Decoder(nn.Module):
         self.embed_tokens = embed_tokens
         self.block = nn.ModuleList([T5Block(config, True, i == 0) for i in range(config.num_decoder_layers)])
         self.final_layer_norm = T5LayerNorm(config.d_model, eps=config.layer_norm_epsilon)
+        _wire_next_norms(self.block, self.final_layer_norm)
         self.p = config.dropout_rate
 
     def forward(self, input_ids, enc, enc_keep, task=None):

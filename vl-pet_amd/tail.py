@@ -29,6 +29,7 @@ from .functional import _finish, _flat, _grad_dest, _grad_like, _io_dtype, _need
 SAVE_PRENORM = None
 PRENORM_RATIO = 8.0          # measured (tests/test_gpu_tail.py::test_tail_backward_from_output_error_grows_with_beta_over_gamma, profiles/r05_k5abi_ab.txt): worst element of dgamma 0.019 / 0.027 / 0.075 / 0.27 of the 0.1 bound at max |beta / gamma| = 1 / 4 / 16 / 64
 PRENORM_RECHECK = 256
+ALIAS_RESIDUAL_GRAD = True   # the plain residual tail's d/dx1 = dout handed on without a copy (False: the kernel writes a copy, as before round 5)
 
 
 def _frozen_epoch():
@@ -121,7 +122,16 @@ class _TailFn(torch.autograd.Function):
         d = shape[-1]
         df = _flat(dout, d)
         M = df.shape[0]
-        dx1 = torch.empty_like(df)
+        # plain residual tail (T5): d/dx1 IS dout -- handed on as it is (no copy: a third of the pass's traffic), marked shared for a
+        # consumer that would accumulate in place; without dropout the whole backward is the identity
+        alias = (not norm) and ALIAS_RESIDUAL_GRAD
+        if alias and p == 0:
+            gx1 = df.view(shape)
+            if ctx.link is not None:
+                ctx.link.dx1, ctx.link.shared, gx1 = df.view(shape), True, None
+                ctx.link = None
+            return df.view(shape), gx1, None, None, None, None, None, None, None, None
+        dx1 = df if alias else torch.empty_like(df)
         dy = torch.empty_like(df) if p > 0 else None
         train_ln = norm and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
         part = None
@@ -134,7 +144,7 @@ class _TailFn(torch.autograd.Function):
                 p, seed, io, _stream()))
         else:
             rc = _timed("k5_bwd", M, lambda: lib.vlpet_sublayer_tail_bwd(
-                df.data_ptr(), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(g32), dx1.data_ptr(), _ptr(dy), _ptr(part), M, d,
+                df.data_ptr(), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(g32), None if alias else dx1.data_ptr(), _ptr(dy), _ptr(part), M, d,
                 p, seed, norm, io, _stream()))
         _lib.check(rc, "vlpet_sublayer_tail_bwd")
         dgamma = dbeta = None
@@ -156,7 +166,7 @@ class _TailFn(torch.autograd.Function):
         gx1 = dx1
         if ctx.link is not None:        # functional.ResidualLink: K1's backward / the sublayer's first dgrad GEMM returns the sum for x1
             ctx.link.dx1 = dx1
-            ctx.link.shared = dy is None        # without dropout dy IS dx1: a consumer must not accumulate into it in place
+            ctx.link.shared = dy is None or alias   # without dropout dy IS dx1 / the aliased dout is autograd's tensor: a consumer must not accumulate into it in place
             gx1 = None
             ctx.link = None
         return dyv, gx1, dgamma, dbeta, None, None, None, None, None, None
@@ -241,3 +251,108 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float, link=None) -> to
     if x.numel() == 0:
         return x * weight.to(x.dtype)
     return _RmsNormFn.apply(x, weight, eps, link)
+
+
+class FusedNorm:
+    """What a fused tail leaves on the sum it returns (``sum._vlpet_norm``): the sum already normalised by ONE T5LayerNorm (identified by
+    its weight tensor) and the link through which the sum's later readers hand their gradients to the fused backward."""
+    __slots__ = ("weight", "normed", "link")
+
+    def __init__(self, weight, normed, link):
+        self.weight, self.normed, self.link = weight, normed, link
+
+
+class _TailRmsFn(torch.autograd.Function):
+    """``sum = x1 + dropout(y)`` and ``normed = T5LayerNorm_next(sum)`` in one pass each way (vlpet_sublayer_tail_rms_fwd /
+    vlpet_rmsnorm_tail_bwd): the reference's modeling_t5.py:408 (824) followed by :366 (782) of the next sublayer."""
+
+    @staticmethod
+    def forward(ctx, y, x1, weight, eps, p, seed, link, norm_link):
+        lib = _lib.load()
+        _need_cuda(y, x1)
+        ctx.set_materialize_grads(False)
+        d = y.shape[-1]
+        io = _io_dtype(y)
+        if x1.dtype != y.dtype:
+            x1 = x1.to(y.dtype)
+        yf, xf = _flat(y, d), _flat(x1, d)
+        M = yf.shape[0]
+        out, normed = torch.empty_like(yf), torch.empty_like(yf)
+        rstd = torch.empty(M, dtype=torch.float32, device=y.device)
+        g32 = _f32_frozen(weight)
+        rc = _timed("k5_fwd", M, lambda: lib.vlpet_sublayer_tail_rms_fwd(
+            yf.data_ptr(), xf.data_ptr(), g32.data_ptr(), out.data_ptr(), normed.data_ptr(), rstd.data_ptr(), M, d, float(eps), float(p), seed,
+            io, _stream()))
+        _lib.check(rc, "vlpet_sublayer_tail_rms_fwd")
+        ctx.save_for_backward(out, rstd, g32, weight)
+        ctx.cfg = (float(p), seed, y.shape, io)
+        ctx.link = link if (link is not None and link.armed) else None       # K1 (or a linear_acc GEMM) takes our d/dx1
+        ctx.norm_link = norm_link                                            # the sum's later readers park their gradients here
+        if norm_link is not None:
+            norm_link.armed = True
+        return out.view(y.shape), normed.view(y.shape)
+
+    @staticmethod
+    def backward(ctx, d_sum, d_normed):
+        lib = _lib.load()
+        out, rstd, g32, weight = ctx.saved_tensors
+        p, seed, shape, io = ctx.cfg
+        M, d = out.shape
+        dx_in = None
+        if ctx.norm_link is not None:
+            dx_in, ctx.norm_link.dx1 = ctx.norm_link.dx1, None
+            ctx.norm_link.shared = False
+            ctx.norm_link = None
+        for extra in (d_sum,):              # a reader of the sum that did not use the link: autograd hands its gradient here
+            if extra is not None:
+                e = extra.reshape(out.shape)
+                dx_in = e if dx_in is None else dx_in.reshape(out.shape) + e
+        if dx_in is not None and (dx_in.dtype != out.dtype or dx_in.numel() != out.numel() or not dx_in.is_contiguous()):
+            dx_in = dx_in.reshape(out.shape).to(out.dtype).contiguous()
+        if d_normed is None:                # the normalised rows were never used: the plain tail's backward on d_sum
+            d_normed = torch.zeros_like(out)
+        df = _flat(d_normed, d)
+        if df.dtype != out.dtype:
+            df = df.to(out.dtype)
+        dx1 = torch.empty_like(out)
+        dy = torch.empty_like(out) if p > 0 else None
+        train = bool(ctx.needs_input_grad[2])
+        part = torch.empty(lib.vlpet_sublayer_tail_partials(M), 2, d, dtype=torch.float32, device=out.device) if train else None
+        rc = _timed("k5_bwd", M, lambda: lib.vlpet_rmsnorm_tail_bwd(
+            df.data_ptr(), out.data_ptr(), rstd.data_ptr(), g32.data_ptr(), _ptr(dx_in), dx1.data_ptr(), _ptr(dy), _ptr(part), M, d, p, seed,
+            io, _stream()))
+        _lib.check(rc, "vlpet_rmsnorm_tail_bwd")
+        dgamma = None
+        if train:
+            (tg, sg) = _grad_dest(weight, (d,))
+            from .functional import reduce_partials
+            reduce_partials(part, part.shape[0], d, tg, None, deferrable=sg is not None)
+            dgamma = _finish([(tg, sg, weight)])[0]
+        dx1 = dx1.view(shape)
+        dyv = dy.view(shape) if dy is not None else dx1
+        gx1 = dx1
+        if ctx.link is not None:
+            ctx.link.dx1 = dx1
+            ctx.link.shared = dy is None
+            gx1 = None
+            ctx.link = None
+        return dyv, gx1, dgamma, None, None, None, None, None
+
+
+def sublayer_tail_rms(x1: torch.Tensor, y: torch.Tensor, next_norm: torch.nn.Module, p: float = 0.0, training: bool = False,
+                      seed: Optional[int] = None, link=None):
+    """T5 form of K5 fused with the NEXT sublayer's RMS norm: returns ``sum = x1 + dropout(y, p)``, which carries the already normalised
+    rows for ``next_norm`` (``sum._vlpet_norm``: visual.T5LayerNorm.forward returns them instead of launching, host.t5._new_norm_link returns
+    the link through which the sum's later readers -- the next tail's add, K1's gate -- hand over their gradients)."""
+    from .functional import ResidualLink
+    p_eff = float(p) if training else 0.0
+    if seed is None:
+        seed = _draw_seed() if p_eff > 0 else 0
+    eps = getattr(next_norm, "variance_epsilon", None)
+    if eps is None:
+        eps = next_norm.eps
+    need_grad = torch.is_grad_enabled() and (x1.requires_grad or y.requires_grad or next_norm.weight.requires_grad)
+    norm_link = ResidualLink() if need_grad else None
+    out, normed = _TailRmsFn.apply(y, x1, next_norm.weight, eps, p_eff, seed, link, norm_link)
+    out._vlpet_norm = FusedNorm(next_norm.weight, normed, norm_link)
+    return out

@@ -29,6 +29,9 @@ class T5LayerNorm(nn.Module):
 
     def forward(self, x, link=None):
         """``link`` (not in the reference's signature): see vlpet_amd.tail.rms_norm; ignored on the eager path."""
+        fused = getattr(x, "_vlpet_norm", None)         # the tail that produced x already normalised it for this norm (tail.sublayer_tail_rms)
+        if fused is not None and fused.weight is self.weight:
+            return fused.normed
         if x.is_cuda and not EAGER_RMS_NORM and x.shape[-1] % 8 == 0 and x.dtype in (torch.bfloat16, torch.float32):
             from .tail import rms_norm
             return rms_norm(x, self.weight, self.variance_epsilon, link)  # one HIP pass each way (csrc/tail.hip, rms mode)
