@@ -173,6 +173,20 @@ int vlpet_adapter_gate_bwd_saved_acc(int phases, const void* dy, const void* x1,
                                      float delta_scale, float x2_scale, float gate_scale,
                                      int io_dtype, vlpet_stream_t stream);
 
+/* vlpet_adapter_gate_bwd_saved / _acc with the forward's OUTPUT y = gate_scale * h * g at hand (a training framework keeps it for
+ * free: it is the input of the sublayer tail).  With the multiplicative gate  dq = dh * h * (1 - g) = dy * y * (1 - g), so pass 1 of
+ * the two-pass forms recomputes the gate's up projection only -- the adapter chain's drops out, the row stream carries y instead of
+ * x2 (same bytes).  y: [M, d] IO dtype or NULL (then exactly the two functions above); dx1_in: optional.  The additive gate ignores
+ * y.  Autograd of my_transformers/modeling_bart.py:1147-1155, 1195-1209 (T5: modeling_t5.py:366-390, 782-806). */
+int vlpet_adapter_gate_bwd_saved_y(int phases, const void* dy, const void* x1, const void* x2, const void* y, const void* saved,
+                                   const void* packed_a, const void* packed_g, const void* dx1_in, void* dx1, void* dx2,
+                                   float* dwd, float* dbd, float* dwu, float* dbu,
+                                   float* dwgd, float* dbgd, float* dwgu, float* dbgu,
+                                   int r, int rg, void* workspace, size_t workspace_bytes,
+                                   int64_t M, int d, int tiles, int gate_mode,
+                                   float delta_scale, float x2_scale, float gate_scale,
+                                   int io_dtype, vlpet_stream_t stream);
+
 /* ---- K2: parallel adapter (decoder cross-attention value path) ----------------------------
  * out = y + scale * up(gelu_new(down(x)))
  * replaces adapters/adapter_modeling.py:55-61 + adapters/adapter_controller.py:149-162 as called at
@@ -356,6 +370,22 @@ int vlpet_sublayer_tail_bwd_out(const void* dout, const void* out_save, const fl
  * straight at the parameters' slots of its flat gradient buffer. */
 int vlpet_sublayer_tail_reduce(const float* dgb_partials, int n_partials, int d, float* dgamma, float* dbeta,
                                vlpet_stream_t stream);
+/* ---- deferred finalize of the weight gradients ------------------------------------------------
+ * Every backward entry point above that produces weight gradients ends with a "finalize" launch: the sum of its row-chunk partial
+ * blocks (in the call's workspace) into dW / db.  A training step holds one per adapter call and nobody reads a weight gradient
+ * before the optimizer, so a caller may collect them:
+ *   vlpet_finalize_defer(1)   from now on (this host thread) backward calls QUEUE that launch instead of issuing it; returns the
+ *                             previous setting.  The call's workspace and its gradient outputs must stay allocated -- and the
+ *                             outputs are incomplete -- until the flush.
+ *   vlpet_finalize_flush(s)   launches everything queued on stream s (which must be ordered after the queued calls' streams), up to
+ *                             16 calls per launch; same arithmetic and order of additions per call: bit-identical results.
+ *   vlpet_finalize_pending()  queue length;  vlpet_finalize_discard()  drops the queue (error paths).
+ * (The reference leaves this to autograd's per-parameter AccumulateGrad: src/trainer_base.py / multitask.py:682-695.) */
+int vlpet_finalize_defer(int on);
+int vlpet_finalize_pending(void);
+int vlpet_finalize_discard(void);
+int vlpet_finalize_flush(vlpet_stream_t stream);
+
 /* Deferred form of the two reductions above, for a trainer (nobody reads a parameter gradient before the optimizer step):
  * vlpet_colsum_partial runs only the first pass of vlpet_colsum (workspace [vlpet_sublayer_tail_partials(M)][n]); vlpet_reduce_batch
  * sums n_jobs partial blocks in ONE launch per 96 jobs: job j reduces partials[j] viewed as [n_partials[j]][2 d[j]] into out0[j] [d]

@@ -78,13 +78,17 @@ def _abi_case(M, dtype=torch.bfloat16, seed=11, gate_mode=1, r=96):
     assert lib.vlpet_adapter_gate_fwd_save(x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(), out.data_ptr(),
                                            sv.data_ptr(), M, d, tiles, gate_mode, 1.0, 1.0, 0.7, io, st) == 0
 
-    def run(phases_list, acc):
+    def run(phases_list, acc, from_y=None):        # from_y: None = the round-4 entry points, False / True = ..._bwd_saved_y without / with y
         dx1 = torch.zeros_like(x1); dx2 = torch.zeros_like(x2)
         ws = torch.empty(nws, dtype=torch.uint8, device=dev)
         G = [torch.zeros_like(w) for w in W]
         common = [t.data_ptr() for t in G] + [r, r, ws.data_ptr(), nws, M, d, tiles, gate_mode, 1.0, 1.0, 0.7, io, st]
         for ph in phases_list:
-            if acc:
+            if from_y is not None:
+                rc = lib.vlpet_adapter_gate_bwd_saved_y(ph, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), out.data_ptr() if from_y else None,
+                                                        sv.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(), dxin.data_ptr() if acc else None,
+                                                        dx1.data_ptr(), dx2.data_ptr(), *common)
+            elif acc:
                 rc = lib.vlpet_adapter_gate_bwd_saved_acc(ph, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(),
                                                           pg.buf.data_ptr(), dxin.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), *common)
             else:
@@ -106,6 +110,41 @@ def test_incoming_dx1_travels_with_the_stage(M, r):
     assert (acc[0] - ref).abs().max().item() <= TOL * ref.abs().max().item()
     for a, b in zip(plain[1:], acc[1:]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,r", [(1, 96), (129, 96), (3500, 96), (8232, 96), (28000, 96), (33200, 96), (1000, 192), (8232, 192), (12000, 192), (18250, 192)])
+def test_backward_from_the_forward_output(M, r):
+    """vlpet_adapter_gate_bwd_saved_y: without y it IS the round-4 call (bit-identical, with and without dx1_in); with y pass 1 forms
+    dq = dy * y * (1 - g) from the bf16-rounded forward output instead of recomputing h -- every output within the bf16 tolerance of
+    the x2 form (the oracle comparison of both forms: test_k1_two_pass_bf16_vs_oracle / test_k1_from_x2_vs_oracle).  Sizes: single row,
+    workgroup boundary, the feature-split form (M <= 8192), both passes' full-size forms, two rounds (33,200), r = 192 on pet_dz6 and --
+    between 8,192 and 16,384 rows -- on the chain-split kernel, which ignores y."""
+    run, dxin = _abi_case(M, r=r)
+    for acc in (False, True):
+        plain, noy, fromy = run([3], acc), run([3], acc, False), run([3], acc, True)
+        for a, b in zip(plain, noy):
+            assert torch.equal(a, b)
+        for k, (a, b) in enumerate(zip(plain, fromy)):
+            assert (a - b).abs().max().item() <= TOL * a.abs().max().item(), (k, acc)
+    # the additive gate ignores y
+    run2, _ = _abi_case(M, r=r, gate_mode=2)
+    for a, b in zip(run2([3], False), run2([3], False, True)):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kw", [dict(M=33), dict(M=3500), dict(M=2100, gate_scale=0.3, delta_scale=0.5, x2_scale=0.7), dict(M=28000),
+                                dict(M=1000, r=192, rg=192, nh=4, delta_scale=4.0, x2_scale=0.5, gate_scale=0.3), dict(M=18250, r=192, rg=192, nh=4)],
+                         ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_k1_from_x2_vs_oracle(kw):
+    """The rounds 2-4 form of the backward (h recomputed from x2; functional.K1_BWD_FROM_OUTPUT = False) stays covered."""
+    import vlpet_amd.functional as F
+    F.K1_BWD_FROM_OUTPUT = False
+    try:
+        ee = {}
+        _check(C.run_k1(torch.bfloat16, el_errs=ee, **kw))
+        assert max(ee.values()) <= EL_TOL, ee
+    finally:
+        F.K1_BWD_FROM_OUTPUT = True
 
 
 @pytest.mark.parametrize("gate_mode", [1, 2])

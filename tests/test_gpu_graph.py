@@ -104,6 +104,87 @@ def test_capture_after_an_eval_forward_still_refreshes_the_weight_caches():
     assert worst <= 1e-5, worst
 
 
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("lora", [False, True])
+def test_deferred_finalize_is_bit_identical(graph, lora):
+    """functional.DEFER_FINALIZE (round 5): the weight-gradient finalize launches of a backward queued in the library
+    (vlpet_finalize_defer) and issued together at its end (vlpet_finalize_flush, 16 calls per launch) -- same per-call arithmetic, so
+    losses and parameters equal the per-call launches BIT FOR BIT, eager and replayed; the queue is empty after every step."""
+    import vlpet_amd.functional as VF
+    import vlpet_amd.train as TR
+    from vlpet_amd import _lib
+    kw = dict(use_adapter=False, use_encoder_adapter_down_multihead=False, use_encoder_adapter_gating_large_x_lowrank=False,
+              use_decoder_enc_attn_value_parallel_adapter_down_dim=False, unfreeze_encoder_layer_norms=False,
+              use_lora=True, lora_dim=16, use_single_lora=True, lora_dropout=0.0) if lora else {}
+    model, cfg = _tiny(0.0, **kw)
+    gen = torch.Generator().manual_seed(9)
+    bs = [_cuda_batch(TR.synthetic_batch(t, 6, cfg, "cpu", gen)) for t in ("vqa", "caption")] * 3
+    lib = _lib.load()
+    res = {}
+    for defer in (False, True):
+        VF.DEFER_FINALIZE = defer
+        try:
+            m = copy.deepcopy(model).cuda()
+            tr = TR.Trainer(m, cfg, lr=1e-2, total_steps=20, warmup_ratio=0.1, graph=graph)
+            losses = []
+            for b in bs:
+                losses.append(float(tr.step(b)))
+                assert lib.vlpet_finalize_pending() == 0
+            res[defer] = (losses, {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad})
+        finally:
+            VF.DEFER_FINALIZE = True
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    for n, p in res[False][1].items():
+        assert torch.equal(p, res[True][1][n]), n
+
+
+def test_finalize_queue_abi():
+    """vlpet_finalize_defer / _pending / _flush / _discard around two K2 backward calls: nothing is written before the flush, the flush
+    (one batched launch) writes exactly what the undeferred calls write."""
+    import vlpet_amd.functional as F
+    from vlpet_amd import _lib
+    lib = _lib.load()
+    dev, dt, d, r = "cuda", torch.bfloat16, 768, 96
+    g = torch.Generator(device=dev).manual_seed(2)
+    st = torch.cuda.current_stream().cuda_stream
+    io, tiles = F._io_dtype(torch.empty(1, dtype=dt)), F.rank_tiles(r)
+
+    def case(M):
+        x, dy = (torch.randn(M, d, device=dev, generator=g).to(dt) for _ in range(2))
+        mk = lambda *s: torch.randn(*s, device=dev, generator=g) * 0.05
+        W = [mk(r, d), mk(r), mk(d, r), mk(d)]
+        pk = F.pack_pair([W[0]], [W[1]], W[2], W[3], io, tiles)
+        nws = lib.vlpet_bwd_workspace_bytes(M, d, tiles, 0, io)
+
+        def run():
+            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+            G = [torch.full_like(w, 7.0) for w in W]
+            dx = torch.empty_like(x)
+            rc = lib.vlpet_parallel_adapter_bwd(dy.data_ptr(), x.data_ptr(), pk.buf.data_ptr(), dx.data_ptr(), *[t.data_ptr() for t in G],
+                                                r, ws.data_ptr(), nws, M, d, tiles, 1.0, io, st)
+            assert rc == 0
+            return G, ws
+        return run
+    runs = [case(1000), case(5000)]
+    plain = [run()[0] for run in runs]
+    assert lib.vlpet_finalize_defer(1) == 0
+    try:
+        held = [run() for run in runs]
+        assert lib.vlpet_finalize_defer(0) == 1
+        torch.cuda.synchronize()
+        assert lib.vlpet_finalize_pending() == 2
+        assert all(bool((t == 7.0).all()) for G, _ in held for t in (G[0], G[2]))      # the weight gradients are still untouched
+        assert lib.vlpet_finalize_flush(st) == 0 and lib.vlpet_finalize_pending() == 0
+        torch.cuda.synchronize()
+        for P, (G, _) in zip(plain, held):
+            for a, b in zip(P, G):
+                assert torch.equal(a, b)
+        lib.vlpet_finalize_defer(1); runs[0](); lib.vlpet_finalize_defer(0)
+        assert lib.vlpet_finalize_pending() == 1 and lib.vlpet_finalize_discard() == 0 and lib.vlpet_finalize_pending() == 0
+    finally:
+        lib.vlpet_finalize_defer(0); lib.vlpet_finalize_discard()
+
+
 def test_graph_cache_is_bounded():
     """one captured graph per batch signature, least recently replayed evicted beyond Trainer.max_graphs."""
     import vlpet_amd.train as TR

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """K1 forward (training form) and backward rows kernel only, at the sizes given: a quick A/B target for alternative builds
-(VLPET_LIB=...).  usage: k1bench.py tag M [M ...]"""
+(VLPET_LIB=...).  usage: k1bench.py tag M [M ...]    K1BENCH_R=192: six tiles; K1BENCH_FROM_X2=1: the backward recomputes h from x2
+(rounds 2-4) instead of starting from the forward's output (vlpet_adapter_gate_bwd_saved_y, round 5)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -33,11 +34,12 @@ def run(M, tag):
     def fwd_save():
         rc = lib.vlpet_adapter_gate_fwd_save(x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(), out.data_ptr(),
                                              sv.data_ptr(), M, d, tiles, 1, 1.0, 1.0, 1.0, io, st); assert rc == 0
+    yp = None if os.environ.get("K1BENCH_FROM_X2") else out.data_ptr()
     def bwd_saved(ph):
         def f():
-            rc = lib.vlpet_adapter_gate_bwd_saved(ph, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(),
-                                                  dx1.data_ptr(), dx2.data_ptr(), *[t.data_ptr() for t in G], r, r, ws.data_ptr(), nws,
-                                                  M, d, tiles, 1, 1.0, 1.0, 1.0, io, st); assert rc == 0
+            rc = lib.vlpet_adapter_gate_bwd_saved_y(ph, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), yp, sv.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(),
+                                                    None, dx1.data_ptr(), dx2.data_ptr(), *[t.data_ptr() for t in G], r, r, ws.data_ptr(), nws,
+                                                    M, d, tiles, 1, 1.0, 1.0, 1.0, io, st); assert rc == 0
         return f
     fwd_save()
     if os.environ.get("K1BENCH_FWD_ONLY"):      # forward only (A/B of forward forms: VLPET_LIB=<debug build> VLPET_FWD2P=0|1|2|3)

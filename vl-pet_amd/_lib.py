@@ -40,6 +40,14 @@ SIGNATURES = {
                                                                                             c_int64, c_int, c_int, c_int,
                                                                                             c_float, c_float, c_float, c_int,
                                                                                             c_void_p]),
+    "vlpet_adapter_gate_bwd_saved_y": (c_int, [c_int] + [c_void_p] * 10 + [c_void_p] * 8 + [c_int, c_int, c_void_p, c_size_t,
+                                                                                           c_int64, c_int, c_int, c_int,
+                                                                                           c_float, c_float, c_float, c_int,
+                                                                                           c_void_p]),
+    "vlpet_finalize_defer": (c_int, [c_int]),
+    "vlpet_finalize_pending": (c_int, []),
+    "vlpet_finalize_discard": (c_int, []),
+    "vlpet_finalize_flush": (c_int, [c_void_p]),
     "vlpet_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
     "vlpet_adapter_gate_bwd_form": (c_int, [c_int64, c_int, c_int, c_int]),
     "vlpet_debug_build": (c_int, []),

@@ -356,7 +356,8 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
                    float s2, float sd, float gs, int flags, int io_dtype, vlpet_stream_t stream,
                    int phases = 3 /* bit0: row-parallel kernel, bit1: weight gradients; bit3: skip the finalize of bit1, bit4: finalize only */,
                    const void* saved = nullptr /* vlpet_adapter_gate_fwd_save's block */,
-                   const void* dx1_in = nullptr /* gated K1: added to dxg (must not alias it) */) {
+                   const void* dx1_in = nullptr /* gated K1: added to dxg (must not alias it) */,
+                   const void* yout = nullptr /* gated K1: the forward's output (PetBwdArgs::y) */) {
     int rc = check_common(M, d, tiles, io_dtype);
     if (rc) return rc;
     const bool gate = flags & PET_GATE;
@@ -388,6 +389,8 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     b.M = M; b.d = d; b.RT = tiles;
     b.s2 = s2; b.sd = sd; b.gs = gs; b.flags = flags;
     b.gm = 1.f; b.go = 0.f; b.fsplit = 0; b.dz_part = nullptr;
+    if (yout && (!gate || !saved || !aligned16(yout))) return VLPET_E_ALIGN;
+    b.y = (flags & PET_GATE_ADD) ? nullptr : yout;
     if (saved && !aligned16(saved)) return VLPET_E_ALIGN;
     b.saved = saved; b.saved_stride = (int64_t)saved_stride(M, tiles, io_dtype);
     if (saved) {        // z comes from the forward; the rows kernel does not write it
@@ -585,6 +588,23 @@ extern "C" int vlpet_adapter_gate_bwd_saved_acc(int phases, const void* dy, cons
     return run_bwd(dy, x2, x2, x1, packed_a, packed_g, NO_DROP, dx2, dx1, dwd, dbd, dwu, dbu,
                    dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
                    x2_scale, delta_scale, gate_scale, flags, io_dtype, stream, phases & 31, saved, dx1_in);
+}
+
+// The same with the forward's output y at hand (round 5): pass 1 of the two-pass forms then needs the gate chain's up projection
+// only (dq = dy * y * (1 - g)); dx1_in is optional here.  y == NULL: exactly vlpet_adapter_gate_bwd_saved / _acc.
+extern "C" int vlpet_adapter_gate_bwd_saved_y(int phases, const void* dy, const void* x1, const void* x2, const void* y, const void* saved,
+                                              const void* packed_a, const void* packed_g, const void* dx1_in, void* dx1, void* dx2,
+                                              float* dwd, float* dbd, float* dwu, float* dbu,
+                                              float* dwgd, float* dbgd, float* dwgu, float* dbgu, int r, int rg,
+                                              void* workspace, size_t workspace_bytes, int64_t M, int d, int tiles,
+                                              int gate_mode, float delta_scale, float x2_scale, float gate_scale,
+                                              int io_dtype, vlpet_stream_t stream) {
+    int flags;
+    if (gate_flags(gate_mode, &flags)) return VLPET_E_SHAPE;
+    if (!dbd || !dbu || !saved || !flags || (phases & 19) == 0) return VLPET_E_NULL;
+    return run_bwd(dy, x2, x2, x1, packed_a, packed_g, NO_DROP, dx2, dx1, dwd, dbd, dwu, dbu,
+                   dwgd, dbgd, dwgu, dbgu, r, rg, workspace, workspace_bytes, M, d, tiles,
+                   x2_scale, delta_scale, gate_scale, flags, io_dtype, stream, phases & 31, saved, dx1_in, y);
 }
 
 extern "C" int vlpet_parallel_adapter_bwd(const void* dy, const void* x, const void* packed, void* dx,
@@ -1043,6 +1063,12 @@ extern "C" int vlpet_colsum_partial(const void* x, int64_t M, int n, float* work
     if (!aligned16(x)) return VLPET_E_ALIGN;
     return herr(launch_colsum_partial(x, M, n, workspace, io_dtype == VLPET_F32, (hipStream_t)stream));
 }
+
+// Deferred weight-gradient finalize passes (csrc/wgrad.hip finalize_flush): see include/vlpet_hip.h
+extern "C" int vlpet_finalize_defer(int on) { return finalize_defer(on); }
+extern "C" int vlpet_finalize_pending(void) { return finalize_pending(); }
+extern "C" int vlpet_finalize_discard(void) { finalize_discard(); return 0; }
+extern "C" int vlpet_finalize_flush(vlpet_stream_t stream) { return herr(finalize_flush((hipStream_t)stream)); }
 
 extern "C" int vlpet_reduce_batch(const float* const* partials, float* const* out0, float* const* out1, const int* n_partials,
                                   const int* d, int n_jobs, vlpet_stream_t stream) {

@@ -86,6 +86,8 @@ struct PetBwdArgs {
     float gm, go;           // low-rank visual projector: gate value = gm * sigmoid(.) + go (unused otherwise)
     int fsplit;             // pass 1 of the two-pass form (pet_dz2.hip), small M: feature blocks (> 1: partial dz in dz_part, summed by a second launch)
     float* dz_part;         //   [fsplit][M][2][32*RT] fp32
+    const void* y;          // optional (gated K1, multiplicative gate, saved form): the forward's OUTPUT [M,d] -- pass 1 then forms
+                            //   dq = dy * y * (1 - g) and skips the adapter chain's up projection (pet_dz2.hip / pet_dz6.hip)
 };
 hipError_t launch_pet_bwd(const PetBwdArgs& a, int io_fp32, hipStream_t stream);
 // chain-split form of the same (pet_gate_bwd2.hip): gated K1 with saved activations
@@ -134,6 +136,11 @@ __host__ __device__ inline WgradLayout wgrad_layout(const WgradArgs& a) {
 }
 size_t wgrad_workspace_bytes(int njobs, int RT, int xcols_max, int row_chunks);
 hipError_t launch_wgrad_finalize(const WgradArgs& a, hipStream_t stream);      // sums the row-chunk partials into the outputs
+// ... or queues that pass (per host thread) while finalize_defer(1) is in force; finalize_flush launches the queue, up to 16 calls per launch
+int finalize_defer(int on);            // returns the previous setting
+int finalize_pending();
+void finalize_discard();
+hipError_t finalize_flush(hipStream_t stream);
 void wgrad_plan(int64_t M, int njobs, int xcols_max, int* row_chunks, int64_t* rows_per_chunk);
 hipError_t launch_wgrad(const WgradArgs& a, int io_fp32, hipStream_t stream);
 // Backward without a gate (K2, adapter-only K1, K3 without dropout) in two passes (pet_cols_ng.hip; bf16, r <= 96, saved activations)

@@ -49,8 +49,15 @@ template <int RT> struct Dz2Geo {
     static size_t bytes(int d) { return (size_t)BIAS_OFF + (size_t)2 * d * 4; }
 };
 
-template <int RT, bool ADD>
+// YF (round 5, "from the output"): the caller still has the forward's result y = gs * h * g (PetBwdArgs::y).  Then
+//     dq = dh * h * (1 - g) = gs * dy * g * h * (1 - g) = dy * y * (1 - g),       dh = gs * dy * g
+// need the gate's up projection only: the adapter chain's (half of this pass's projection MFMAs and weight-fragment reads, its z
+// fragments, its bias) drops out, and the row ring carries y in the place of x2 -- same traffic.  y is the forward's bf16 rounding of
+// gs * h * g: a 2^-9 relative change of dq before dq itself is rounded to bf16 for the matrix cores.
+template <int RT, bool ADD, bool YF>
 __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
+    static_assert(!(ADD && YF), "the additive gate's backward needs neither h nor y");
+    constexpr bool NEED_A = !ADD && !YF;               // the adapter chain's up projection feeds h only
     using GEO = Dz2Geo<RT>;
     constexpr int KT = 2 * RT;
     constexpr int PB = GEO::PB, NPS = GEO::NPS, WT_B = GEO::WT_B, XT_B = GEO::XT_B, WS_B = GEO::WS_B, XS_B = GEO::XS_B;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
         const __bf16* sg = reinterpret_cast<const __bf16*>(sv + 2 * a.saved_stride) + grow * (int64_t)(32 * RT) + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) {
-            zA[ks] = *reinterpret_cast<const bf16x8*>(sa + 16 * ks);
+            if constexpr (NEED_A) zA[ks] = *reinterpret_cast<const bf16x8*>(sa + 16 * ks);
             zG[ks] = *reinterpret_cast<const bf16x8*>(sg + 16 * ks);
         }
     }
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
         return reinterpret_cast<const uint8_t*>(((uint64_t)hi << 32) | lo);
     };
     const uint8_t* dyp = reinterpret_cast<const uint8_t*>(a.dy) + row0 * ld2;
-    const uint8_t* x2p = reinterpret_cast<const uint8_t*>(a.res) + row0 * ld2;
+    const uint8_t* x2p = reinterpret_cast<const uint8_t*>(YF ? a.y : a.res) + row0 * ld2;
     auto issue_w = [&](int s) {
         uint8_t* st = smem + (size_t)(s % NWS) * WS_B;
 #pragma unroll
@@ -190,12 +197,12 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
         const uint32_t sb = lds0 + (uint32_t)((s % NWS) * WS_B);
         const uint32_t xb = lds0 + (uint32_t)(X_OFF + (s % NXS) * XS_B);
         f32x16 aA, aG;
-        project_up(sb, std::integral_constant<int, 0>{}, zA, aA, (s * 64) * 4);
+        if constexpr (NEED_A) project_up(sb, std::integral_constant<int, 0>{}, zA, aA, (s * 64) * 4);
         if (SPREAD && s + AX < S) issue_x1(s + AX, 0);     // the row requests of the stage ahead are spread over the step: up front,
         project_up(sb, std::integral_constant<int, 1>{}, zG, aG, (d + s * 64) * 4);
         if (SPREAD && s + AX < S) issue_x1(s + AX, 1);     // all 56 pieces of a workgroup queue at the texture path at once (~1 k cycles of blocked issue)
 #ifdef VLPET_DZ2_STAMPS
-        asm volatile("s_nop 0" : "+v"(aG[15]), "+v"(aA[15]));
+        asm volatile("s_nop 0" : "+v"(aG[15]));
 #endif
         DZ2_STAMP(2)
         u32x2 dyv[4], x2v[4];
@@ -212,10 +219,15 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
             for (int j = 0; j < 4; ++j) {
                 const int e = 4 * q + j;
                 const float gt = sigm(aG[e]);
-                const float dy_ = gs * ((j & 1) ? bf_hi(dyv[q][j >> 1]) : bf_lo(dyv[q][j >> 1]));
+                const float dyr = (j & 1) ? bf_hi(dyv[q][j >> 1]) : bf_lo(dyv[q][j >> 1]);
+                const float dy_ = gs * dyr;
                 if constexpr (ADD) {
                     dh[j] = dy_;
                     dq[j] = dy_ * gt * (1.0f - gt);
+                } else if constexpr (YF) {      // (the row ring's second tile is y)
+                    const float yv = (j & 1) ? bf_hi(x2v[q][j >> 1]) : bf_lo(x2v[q][j >> 1]);
+                    dh[j] = dy_ * gt;
+                    dq[j] = dyr * yv * (1.0f - gt);
                 } else {
                     const float hv = s2 * ((j & 1) ? bf_hi(x2v[q][j >> 1]) : bf_lo(x2v[q][j >> 1])) + sd * aA[e];
                     dh[j] = dy_ * gt;
@@ -421,20 +433,24 @@ bool k1_dz2_applies(const PetBwdArgs& a, int io_fp32) {
     return false;
 }
 
-template <int RT>
-static hipError_t launch_dz2_rt(const PetBwdArgs& a, hipStream_t stream) {
+template <int RT, bool ADD, bool YF>
+static hipError_t launch_dz2_form(const PetBwdArgs& a, hipStream_t stream) {
     using GEO = Dz2Geo<RT>;
     const size_t lds = GEO::bytes(a.d);
-    const bool add = (a.flags & PET_GATE_ADD) != 0;
-    const void* kern = add ? reinterpret_cast<const void*>(k1_dz2_kernel<RT, true>) : reinterpret_cast<const void*>(k1_dz2_kernel<RT, false>);
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1_dz2_kernel<RT, ADD, YF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const unsigned blocks = (unsigned)((a.M + 127) / 128);
     const unsigned nfb = a.fsplit > 1 ? (unsigned)a.fsplit : 1u;
-    if (add) hipLaunchKernelGGL((k1_dz2_kernel<RT, true>), dim3(blocks, nfb), dim3(512), lds, stream, a);
-    else hipLaunchKernelGGL((k1_dz2_kernel<RT, false>), dim3(blocks, nfb), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((k1_dz2_kernel<RT, ADD, YF>), dim3(blocks, nfb), dim3(512), lds, stream, a);
     if (nfb > 1) return launch_k1_dz_reduce(a, 32 * RT, stream);
     return hipGetLastError();
+}
+
+template <int RT>
+static hipError_t launch_dz2_rt(const PetBwdArgs& a, hipStream_t stream) {
+    if (a.flags & PET_GATE_ADD) return launch_dz2_form<RT, true, false>(a, stream);
+    if (a.y != nullptr) return launch_dz2_form<RT, false, true>(a, stream);      // from the forward's output (see the kernel)
+    return launch_dz2_form<RT, false, false>(a, stream);
 }
 
 hipError_t launch_k1_dz2(const PetBwdArgs& a, hipStream_t stream) {

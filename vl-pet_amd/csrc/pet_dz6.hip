@@ -38,8 +38,12 @@ template <int RT> struct Dz6Geo {
     static size_t bytes(int d) { return (size_t)BIAS_OFF + (size_t)2 * d * 4; }
 };
 
-template <int RT, bool ADD>
+// YF: from the forward's output y instead of x2 (k1_dz2_kernel's note): dq = dy * y * (1 - g) -- no adapter-chain projection (12 of the
+// 48 MFMAs and a third of the LDS fragment reads of a half-stage), no z_a fragments (48 registers).
+template <int RT, bool ADD, bool YF>
 __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
+    static_assert(!(ADD && YF), "the additive gate's backward needs neither h nor y");
+    constexpr bool NEED_A = !ADD && !YF;
     using GEO = Dz6Geo<RT>;
     constexpr int KT = 2 * RT;
     constexpr int PB = GEO::PB, NPS = GEO::NPS, WT_B = GEO::WT_B, WS_B = GEO::WS_B, XT_B = GEO::XT_B, XS_B = GEO::XS_B;
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
         const __bf16* sg = reinterpret_cast<const __bf16*>(sv + 2 * a.saved_stride) + grow * (int64_t)(32 * RT) + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) {
-            zA[ks] = *reinterpret_cast<const bf16x8*>(sa + 16 * ks);
+            if constexpr (NEED_A) zA[ks] = *reinterpret_cast<const bf16x8*>(sa + 16 * ks);
             zG[ks] = *reinterpret_cast<const bf16x8*>(sg + 16 * ks);
         }
     }
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
         return reinterpret_cast<const uint8_t*>(((uint64_t)hi << 32) | lo);
     };
     const uint8_t* dyp = reinterpret_cast<const uint8_t*>(a.dy) + row0 * ld2;
-    const uint8_t* x2p = reinterpret_cast<const uint8_t*>(a.res) + row0 * ld2;
+    const uint8_t* x2p = reinterpret_cast<const uint8_t*>(YF ? a.y : a.res) + row0 * ld2;
     const uint8_t* wpa = a.pk_a + pg.pack_bytes;
     const uint8_t* wpg = a.pk_g + pg.pack_bytes;
     auto issue_w = [&](int ss) {            // half-stage ss = 2 s + fh
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
         const uint32_t sb = lds0 + (uint32_t)((ss & 1) * WS_B);
         const uint32_t xb = lds0 + (uint32_t)(X_OFF + (s & 1) * XS_B);
         f32x16 aA, aG;
-        project_up(sb, std::integral_constant<int, 0>{}, zA, aA, (s * 64 + 32 * fh) * 4);
+        if constexpr (NEED_A) project_up(sb, std::integral_constant<int, 0>{}, zA, aA, (s * 64 + 32 * fh) * 4);
         project_up(sb, std::integral_constant<int, 1>{}, zG, aG, (d + s * 64 + 32 * fh) * 4);
         uint32_t bh[8], bq[8];
         {
@@ -229,10 +233,15 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
                 for (int j = 0; j < 4; ++j) {
                     const int e = 4 * q + j;
                     const float gt = sigm(aG[e]);
-                    const float dy_ = gs * ((j & 1) ? bf_hi(dyv[q][j >> 1]) : bf_lo(dyv[q][j >> 1]));
+                    const float dyr = (j & 1) ? bf_hi(dyv[q][j >> 1]) : bf_lo(dyv[q][j >> 1]);
+                    const float dy_ = gs * dyr;
                     if constexpr (ADD) {
                         dh[j] = dy_;
                         dq[j] = dy_ * gt * (1.0f - gt);
+                    } else if constexpr (YF) {      // (the row ring's second tile is y)
+                        const float yv = (j & 1) ? bf_hi(x2v[q][j >> 1]) : bf_lo(x2v[q][j >> 1]);
+                        dh[j] = dy_ * gt;
+                        dq[j] = dyr * yv * (1.0f - gt);
                     } else {
                         const float hv = s2 * ((j & 1) ? bf_hi(x2v[q][j >> 1]) : bf_lo(x2v[q][j >> 1])) + sd * aA[e];
                         dh[j] = dy_ * gt;
@@ -309,17 +318,21 @@ bool k1_dz6_applies(const PetBwdArgs& a, int io_fp32) {
     return a.RT == 6 && Dz6Geo<6>::bytes(a.d) <= (size_t)160 * 1024;
 }
 
-hipError_t launch_k1_dz6(const PetBwdArgs& a, hipStream_t stream) {
+template <bool ADD, bool YF>
+static hipError_t launch_dz6_form(const PetBwdArgs& a, hipStream_t stream) {
     using GEO = Dz6Geo<6>;
     const size_t lds = GEO::bytes(a.d);
-    const bool add = (a.flags & PET_GATE_ADD) != 0;
-    const void* kern = add ? reinterpret_cast<const void*>(k1_dz6_kernel<6, true>) : reinterpret_cast<const void*>(k1_dz6_kernel<6, false>);
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1_dz6_kernel<6, ADD, YF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const unsigned blocks = (unsigned)((a.M + 127) / 128);
     const unsigned nfb = a.fsplit > 1 ? (unsigned)a.fsplit : 1u;
-    if (add) hipLaunchKernelGGL((k1_dz6_kernel<6, true>), dim3(blocks, nfb), dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((k1_dz6_kernel<6, false>), dim3(blocks, nfb), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((k1_dz6_kernel<6, ADD, YF>), dim3(blocks, nfb), dim3(256), lds, stream, a);
     if (nfb > 1) return launch_k1_dz_reduce(a, 32 * 6, stream);
     return hipGetLastError();
+}
+
+hipError_t launch_k1_dz6(const PetBwdArgs& a, hipStream_t stream) {
+    if (a.flags & PET_GATE_ADD) return launch_dz6_form<true, false>(a, stream);
+    if (a.y != nullptr) return launch_dz6_form<false, true>(a, stream);
+    return launch_dz6_form<false, false>(a, stream);
 }

@@ -571,14 +571,14 @@ hipError_t launch_tail_reduce(const float* part, int nb, int d, float* dgamma, f
 }
 
 // Workgroups of the row kernels: a wave walks rows with the next one prefetched, and its prologue (gamma / beta, 2 us) and the
-// partial sums it leaves are per workgroup, so few rows per wave is NOT what makes a short launch short.  Sweep of the cap at
-// 1,240-28,000 rows (profiles/r04_k5_workgroup_cap.txt): one workgroup per CU up to ~3,000 rows (9.6 vs 14.0 us at 2,100 rows with
-// 525), two around 6,000, three from ~9,000 on (the round-3 value at full-batch sizes).
+// partial sums it leaves are per workgroup, so few rows per wave is NOT what makes a short launch short.  Round-5 sweep of the cap with
+// the 118-register kernels (four workgroups per CU; profiles/r05_k5abi_small_m_cap.txt, debug build, VLPET_DBG = cap): a short launch is
+// a ~5 us floor plus ~1.3 us per 1,000 rows whatever the cap between 256 and 1,024; one workgroup per CU is best up to ~2,500 rows
+// (7.2 vs 7.8 us at 2,000), two from there to ~8,500 (9.9 vs 10.4 / 11.3 us at 3,500 rows with 256 / 875 workgroups; 10.8 vs 12.7 / 12.0
+// at 5,000), four above (profiles/r05_k5abi_ab.txt: 768 -> 1,024 is 2-4 % at 28,000+ rows).
 int tail_blocks(int64_t M) {
     const int64_t need = (M + TAIL_WAVES - 1) / TAIL_WAVES;
-    int64_t cap = M / 12;
-    if (cap < 256) cap = 256;
-    if (cap > 1024) cap = 1024;                 // (round 5: the row kernels fit four workgroups per CU; 768 -> 1024 is 2-4 % at 28,000+ rows, profiles/r05_k5abi_ab.txt)
+    int64_t cap = M <= 2500 ? 256 : M <= 8500 ? 512 : 1024;
     if (VLPET_IS_DEBUG_BUILD && vlpet_tuning().dbg >= 64) cap = vlpet_tuning().dbg;      // (diagnosis: VLPET_DBG = cap)
     return (int)(need < cap ? need : cap);
 }

@@ -13,6 +13,7 @@
 #include "pet16.h"      // common.h + glds16
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 #include "kernels.h"
 
 size_t wgrad_workspace_bytes(int njobs, int RT, int xcols_max, int row_chunks) {
@@ -765,6 +766,7 @@ struct FinJob {
 struct FinArgs {
     FinJob job[4];
     int RC, PR;
+    int njobs, blocks;      // (used by the batched launch: a call's own grid inside the batch's)
 };
 
 // the partials are read once, by one workgroup; non-temporal loads measured no faster here (K1 backward pass 2 + finalize 75.1 / 75.7 us
@@ -778,8 +780,7 @@ struct FinArgs {
 #else
 #define VLPET_FIN_LOAD(p) (*(p))
 #endif
-__global__ __launch_bounds__(256) void wgrad_finalize_kernel(FinArgs a) {
-    __shared__ float tile[16][65];
+__device__ __forceinline__ void finalize_body(const FinArgs& a, float (*tile)[65]) {
     const FinJob J = a.job[blockIdx.y];
     const int PR = a.PR, RC = a.RC;
     const float* part = J.part;
@@ -866,12 +867,60 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(FinArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(FinArgs a) {
+    __shared__ float tile[16][65];
+    finalize_body(a, tile);
+}
+
+// Several calls' finalize passes as ONE launch (round 5).  A training step runs one per adapter call (19 in a BART-base step, 37 in
+// T5-base), each a few dozen to a few hundred workgroups of pure latency; at the per-rank sizes of an 8-GPU run a launch boundary
+// (~5 us in a replayed graph, profiles/r05_rank1of8_timeline.md) is as long as the sum itself.  Nobody reads a weight gradient before
+// the optimizer, so a caller may queue them (vlpet_finalize_defer) and launch the queue once (vlpet_finalize_flush): blockIdx.z = the
+// call, (x, y) its own grid; same per-call arithmetic and order of additions, so the results are bit-identical.
+#define VLPET_FIN_BATCH 16
+struct FinBatch { FinArgs a[VLPET_FIN_BATCH]; };
+static_assert(sizeof(FinBatch) <= 4096, "kernel-argument segment");
+__global__ __launch_bounds__(256) void wgrad_finalize_batch_kernel(FinBatch b) {
+    __shared__ float tile[16][65];
+    const FinArgs& a = b.a[blockIdx.z];
+    if ((int)blockIdx.y >= a.njobs || (int)blockIdx.x >= a.blocks) return;
+    finalize_body(a, tile);
+}
+
+static thread_local bool g_fin_defer = false;
+static thread_local std::vector<FinArgs> g_fin_queue;
+
+int finalize_defer(int on) { const int was = g_fin_defer ? 1 : 0; g_fin_defer = on != 0; return was; }
+int finalize_pending() { return (int)g_fin_queue.size(); }
+void finalize_discard() { g_fin_queue.clear(); }
+hipError_t finalize_flush(hipStream_t stream) {
+    const size_t n = g_fin_queue.size();
+    for (size_t k0 = 0; k0 < n; k0 += VLPET_FIN_BATCH) {
+        const int nb = (int)(n - k0 < VLPET_FIN_BATCH ? n - k0 : VLPET_FIN_BATCH);
+        if (nb == 1) {
+            const FinArgs& f = g_fin_queue[k0];
+            hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)f.blocks, f.njobs), dim3(256), 0, stream, f);
+            continue;
+        }
+        FinBatch b{};
+        int bx = 0, by = 0;
+        for (int k = 0; k < nb; ++k) {
+            b.a[k] = g_fin_queue[k0 + k];
+            if (b.a[k].blocks > bx) bx = b.a[k].blocks;
+            if (b.a[k].njobs > by) by = b.a[k].njobs;
+        }
+        hipLaunchKernelGGL(wgrad_finalize_batch_kernel, dim3((unsigned)bx, (unsigned)by, (unsigned)nb), dim3(256), 0, stream, b);
+    }
+    g_fin_queue.clear();
+    return hipGetLastError();
+}
+
 static hipError_t launch_finalize(const WgradArgs& a, int RT, int xmax, int rmax, hipStream_t stream, bool mask_unscaled = false) {
     const int PR = 32 * RT;
     const int blocks = finalize_tiles(PR, xmax) + (xmax + rmax + 255) / 256;   // tiles of every job fit: xcols <= xmax
     const WgradLayout L = wgrad_layout(a);
     FinArgs f{};
-    f.RC = a.row_chunks; f.PR = PR;
+    f.RC = a.row_chunks; f.PR = PR; f.njobs = a.njobs; f.blocks = blocks;
     for (int j = 0; j < a.njobs; ++j) {
         const WgradJob& J = a.job[j];
         FinJob& F = f.job[j];
@@ -881,6 +930,7 @@ static hipError_t launch_finalize(const WgradArgs& a, int RT, int xmax, int rmax
         F.scale = J.scale; F.ntile = finalize_tiles(PR, J.xcols);
         if (mask_unscaled && J.has_drop) F.scale *= J.drop.keep_scale;      // the streaming kernel only clears the dropped elements
     }
+    if (g_fin_defer) { g_fin_queue.push_back(f); return hipSuccess; }      // (launched by finalize_flush)
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)blocks, a.njobs), dim3(256), 0, stream, f);
     return hipGetLastError();
 }

@@ -68,6 +68,43 @@ WGRAD_STREAM: Optional["torch.cuda.Stream"] = None
 # trainer leaves the switch off.
 DEFER_REDUCES = False
 _PENDING_REDUCES: list = []
+# ... and, round 5, the finalize launches of the weight-gradient kernels (the sum of a call's row-chunk partials into dW / db): with
+# the switch on, a backward op whose gradients all go to sinks queues that launch inside the library (vlpet_finalize_defer) and
+# flush_reduces() issues the queue, 16 calls per launch (19 launches -> 2 in a BART-base step, 37 -> 3 in T5-base).  The call's
+# workspace (the partial sums) is kept alive here until then.
+DEFER_FINALIZE = True
+_PENDING_FINALIZE_KEEP: list = []
+
+
+class _deferred_finalize:
+    """``with _deferred_finalize(all_sinks, ws, ...):`` around a backward call -- its finalize launch is queued when a trainer defers."""
+
+    __slots__ = ("on", "keep")
+
+    def __init__(self, all_sinks: bool, *keep):
+        self.on = bool(DEFER_REDUCES and DEFER_FINALIZE and all_sinks)
+        self.keep = keep
+
+    def __enter__(self):
+        if self.on:
+            _lib.load().vlpet_finalize_defer(1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _lib.load().vlpet_finalize_defer(0)
+            _PENDING_FINALIZE_KEEP.extend(self.keep)
+        return False
+
+
+def discard_pending():
+    """Error path of a trainer's backward: nothing queued survives the step."""
+    _PENDING_REDUCES.clear()
+    if _PENDING_FINALIZE_KEEP:
+        _PENDING_FINALIZE_KEEP.clear()
+    lib = _lib.load()
+    if lib.vlpet_finalize_pending():
+        lib.vlpet_finalize_discard()
 
 
 def reduce_partials(part: torch.Tensor, nb: int, d: int, out0: Optional[torch.Tensor], out1: Optional[torch.Tensor], deferrable: bool):
@@ -80,6 +117,11 @@ def reduce_partials(part: torch.Tensor, nb: int, d: int, out0: Optional[torch.Te
 
 
 def flush_reduces():
+    lib = _lib.load()
+    if lib.vlpet_finalize_pending():
+        rc = lib.vlpet_finalize_flush(_stream())
+        _PENDING_FINALIZE_KEEP.clear()
+        _lib.check(rc, "vlpet_finalize_flush")
     if not _PENDING_REDUCES:
         return 0
     jobs, n = list(_PENDING_REDUCES), len(_PENDING_REDUCES)
@@ -183,6 +225,10 @@ SAVE_ACTIVATIONS = True
 # A/B switch for benches and tests: True = the round-2 split of the gated K1 backward (row kernel that also writes dh / dq +
 # streaming weight-gradient kernel, ABI phases bit 2) instead of pass 1 + the column-parallel pass
 K1_BWD_PREVIOUS_SPLIT = False
+# round 5: the multiplicative gate's backward starts from the forward's OUTPUT y = gs * h * g when the forward saved its
+# activations: dq = dy * y * (1 - g), so pass 1 recomputes the gate's up projection only (vlpet_adapter_gate_bwd_saved_y).
+# False = from x2 (recompute h = s2 * x2 + sd * up_A(z_a)), the rounds 2-4 form.
+K1_BWD_FROM_OUTPUT = True
 
 WEIGHTS_EPOCH = 0
 # Part of the keys of the derived copies of FROZEN tensors (fused q|k|v weight, padded LM head, fp32 LayerNorm copies, the
@@ -529,7 +575,10 @@ class _AdapterGateFn(torch.autograd.Function):
             ctx.link = link
         # the other direction: the sublayer's first GEMM (upstream of x2) armed `out_link` -- this backward parks d/dx1 there
         ctx.out_link = out_link if (out_link is not None and out_link.armed and gate_mode != GATE_NONE) else None
-        ctx.save_for_backward(x1f if x1f is not None else x2f, x2f, *params)
+        # the multiplicative gate's backward can start from this output (dq = dy * y * (1 - g): csrc/pet_dz2.hip "YF"); keeping it
+        # costs nothing new -- the sublayer tail that consumes it is alive until its own backward anyway
+        ctx.has_y = bool(K1_BWD_FROM_OUTPUT and act is not None and gate_mode == GATE_MUL)
+        ctx.save_for_backward(x1f if x1f is not None else x2f, x2f, *params, *((out,) if ctx.has_y else ()))
         ctx.pk = (pk_a, pk_g)
         ctx.cfg = (n_heads, gate_mode, float(delta_scale), float(x2_scale), float(gate_scale), x2.shape,
                    x1.shape if x1 is not None else None)
@@ -539,6 +588,7 @@ class _AdapterGateFn(torch.autograd.Function):
     def backward(ctx, dy):
         lib = _lib.load()
         x1f, x2f, *params = ctx.saved_tensors
+        yf = params.pop() if ctx.has_y else None
         pk_a, pk_g = ctx.pk
         n_heads, gate_mode, sd, s2, gs, shp2, shp1 = ctx.cfg
         M, d = x2f.shape
@@ -577,6 +627,9 @@ class _AdapterGateFn(torch.autograd.Function):
         ctx.link = None
 
         def phase(ph, a):       # one or both halves of the backward, with or without the forward's saved activations
+            if act is not None and yf is not None:
+                return lib.vlpet_adapter_gate_bwd_saved_y(ph, a[0], a[1], a[2], yf.data_ptr(), act.data_ptr(), a[3], a[4], _ptr(dx1_in),
+                                                          *a[5:])
             if act is not None and dx1_in is not None:
                 return lib.vlpet_adapter_gate_bwd_saved_acc(ph, a[0], a[1], a[2], act.data_ptr(), a[3], a[4], dx1_in.data_ptr(),
                                                             *a[5:])
@@ -592,14 +645,16 @@ class _AdapterGateFn(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     sargs = args[:-1] + (_stream(),)
                     rc = _timed("k1_bwd_wgrad", M, lambda: phase(2 | 4, sargs))
-                for t in (x1f, x2f, dyf, ws, pk_a.buf) + ((pk_g.buf,) if gate else ()) + ((act,) if act is not None else ()):
+                for t in (x1f, x2f, dyf, ws, pk_a.buf) + ((pk_g.buf,) if gate else ()) + ((act,) if act is not None else ()) \
+                        + ((yf,) if yf is not None else ()):
                     t.record_stream(side)        # the caching allocator must not recycle them under the side stream
         elif K1_BWD_PREVIOUS_SPLIT:
             rc = _timed("k1_bwd_rows", M, lambda: phase(1 | 4, args))
             if rc == 0:
                 rc = _timed("k1_bwd_wgrad", M, lambda: phase(2 | 4, args))
         elif TIMER is None or not TIMER.wants("k1_bwd_rows"):
-            rc = phase(3, args)
+            with _deferred_finalize(all(s is not None for s in sinks), ws):
+                rc = phase(3, args)
         elif not gate:
             # adapter-only K1 (small / middle gate scripts): its two-pass form is taken for the WHOLE op only (csrc/api.hip ng2), so the
             # bracketed path issues it as one call too -- split phases would time the round-2 row kernel instead of what ships
@@ -702,14 +757,15 @@ class _ParallelAdapterFn(torch.autograd.Function):
         nws = lib.vlpet_bwd_workspace_bytes(M, d, pk.tiles, 0, io)
         ws = torch.empty(nws, dtype=torch.uint8, device=xf.device)
         act = ctx.act
-        if act is not None:
-            rc = _timed("k2_bwd", M, lambda: lib.vlpet_parallel_adapter_bwd_saved(
-                dyf.data_ptr(), xf.data_ptr(), act.data_ptr(), pk.buf.data_ptr(), dx.data_ptr(), dwd.data_ptr(), dbd.data_ptr(),
-                dwu.data_ptr(), dbu.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, ctx.scale, io, _stream()))
-        else:
-            rc = _timed("k2_bwd", M, lambda: lib.vlpet_parallel_adapter_bwd(
-                dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), dx.data_ptr(), dwd.data_ptr(), dbd.data_ptr(),
-                dwu.data_ptr(), dbu.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, ctx.scale, io, _stream()))
+        with _deferred_finalize(s0 is not None and s1 is not None and s2 is not None and (s3 is not None or bu is None), ws, dbu):
+            if act is not None:
+                rc = _timed("k2_bwd", M, lambda: lib.vlpet_parallel_adapter_bwd_saved(
+                    dyf.data_ptr(), xf.data_ptr(), act.data_ptr(), pk.buf.data_ptr(), dx.data_ptr(), dwd.data_ptr(), dbd.data_ptr(),
+                    dwu.data_ptr(), dbu.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, ctx.scale, io, _stream()))
+            else:
+                rc = _timed("k2_bwd", M, lambda: lib.vlpet_parallel_adapter_bwd(
+                    dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), dx.data_ptr(), dwd.data_ptr(), dbd.data_ptr(),
+                    dwu.data_ptr(), dbu.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, ctx.scale, io, _stream()))
         ctx.act = None
         _lib.check(rc, "vlpet_parallel_adapter_bwd")
         gw = _finish([(dwd, s0, wd), (dbd, s1, bd), (dwu, s2, wu)])
@@ -801,14 +857,15 @@ class _LoraDeltaFn(torch.autograd.Function):
         nws = lib.vlpet_bwd_workspace_bytes(M, d, pk.tiles, 0, io)
         ws = torch.empty(nws, dtype=torch.uint8, device=xf.device)
         act = ctx.act
-        if act is not None:
-            rc = _timed("k3_bwd", M, lambda: lib.vlpet_lora_delta_bwd_saved(
-                dyf.data_ptr(), xf.data_ptr(), act.data_ptr(), pk.buf.data_ptr(), _ptr(ctx.keep), p, seed, dx.data_ptr(),
-                da.data_ptr(), db.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, scaling, io, _stream()))
-        else:
-            rc = _timed("k3_bwd", M, lambda: lib.vlpet_lora_delta_bwd(
-                dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), _ptr(ctx.keep), p, seed, dx.data_ptr(), da.data_ptr(),
-                db.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, scaling, io, _stream()))
+        with _deferred_finalize(s0 is not None and s1 is not None, ws):
+            if act is not None:
+                rc = _timed("k3_bwd", M, lambda: lib.vlpet_lora_delta_bwd_saved(
+                    dyf.data_ptr(), xf.data_ptr(), act.data_ptr(), pk.buf.data_ptr(), _ptr(ctx.keep), p, seed, dx.data_ptr(),
+                    da.data_ptr(), db.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, scaling, io, _stream()))
+            else:
+                rc = _timed("k3_bwd", M, lambda: lib.vlpet_lora_delta_bwd(
+                    dyf.data_ptr(), xf.data_ptr(), pk.buf.data_ptr(), _ptr(ctx.keep), p, seed, dx.data_ptr(), da.data_ptr(),
+                    db.data_ptr(), r, ws.data_ptr(), nws, M, d, pk.tiles, scaling, io, _stream()))
         ctx.act = None
         _lib.check(rc, "vlpet_lora_delta_bwd")
         gx = dx.view(shape)

@@ -172,6 +172,8 @@ class GradSink:
         if not self.owner.sinks_enabled:
             return None
         if self.epoch == self.owner.epoch:
+            from . import functional as VF
+            VF.flush_reduces()          # a queued first write (deferred finalize / reduction) must land before autograd adds the second
             if self.owner.dp:
                 raise RuntimeError("vl-pet_amd: a parameter with a direct-write gradient slot was used twice in one "
                                    "backward under data parallelism; build FlatGrads(sinks=False) for such models")
@@ -649,7 +651,7 @@ class Trainer:
                 VF.flush_reduces()
             finally:
                 VF.DEFER_REDUCES = False
-                VF._PENDING_REDUCES.clear()
+                VF.discard_pending()              # (empty after a clean flush)
         else:
             loss.backward()
         return loss
