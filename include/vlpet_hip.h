@@ -374,8 +374,9 @@ int vlpet_sublayer_tail_reduce(const float* dgb_partials, int n_partials, int d,
  * Every backward entry point above that produces weight gradients ends with a "finalize" launch: the sum of its row-chunk partial
  * blocks (in the call's workspace) into dW / db.  A training step holds one per adapter call and nobody reads a weight gradient
  * before the optimizer, so a caller may collect them:
- *   vlpet_finalize_defer(1)   from now on (this host thread) backward calls QUEUE that launch instead of issuing it; returns the
- *                             previous setting.  The call's workspace and its gradient outputs must stay allocated -- and the
+ *   vlpet_finalize_defer(1)   from now on backward calls made by THIS host thread queue that launch instead of issuing it (returns
+ *                             the previous setting); the queue itself is per process -- a framework's autograd worker thread
+ *                             fills it, the thread that called backward() flushes it.  The call's workspace and its gradient outputs must stay allocated -- and the
  *                             outputs are incomplete -- until the flush.
  *   vlpet_finalize_flush(s)   launches everything queued on stream s (which must be ordered after the queued calls' streams), up to
  *                             16 calls per launch; same arithmetic and order of additions per call: bit-identical results.

@@ -82,29 +82,8 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
     if (r_end > a.M) r_end = a.M;
     const int nsteps = r_end > r_begin ? (int)((r_end - r_begin + 31) >> 5) : 0;
 
-    // up-side biases of the workgroup's 128 columns -> LDS (fp32)
     const PackGeom pg = pack_geom(RT, d, 1);
-    if (tid < 256) {
-        float* sbias = reinterpret_cast<float*>(smem + BIAS_OFF);
-        const uint8_t* pk = tid < 128 ? a.pk_a : a.pk_g;
-        sbias[tid] = reinterpret_cast<const float*>(pk + pg.bias_off)[PR + 128 * cb + (tid & 127)];
-    }
-    // resident weights: A fragments of this wave's 32 columns.  Role U: Wu / Wgu from the "up" packs (slot = W[f][16ks + 8hh + j]);
-    // role D: Wd / Wgd transposed from the "down_t" packs (slot = W[16ks + 8hh + j][f]).  MFMA row i stands for column c0 +
-    // 16*((i>>2)&1) + 4*(i>>3) + (i&3), so that a lane (m, h) ends with the 16 CONTIGUOUS columns c0 + 16h .. +15 of row m; in the
-    // packs' own numbering (tests/packing_spec.py f_of4) that row is lane (i&3) | (nt << 2) | (i>>3 << 3) of n-tile v = (i>>2)&1.
-    bf16x8 wA[KT], wG[KT];
-    {
-        const int i = m, v = (i >> 2) & 1, ip = (i & 3) | (nt << 2) | ((i >> 3) << 3);
-        const int64_t off = (int64_t)(role == 0 ? 1 : 3) * pg.pack_bytes + (int64_t)(2 * cb + pp) * (4 * RT * 1024)
-                          + (int64_t)(v * KT) * 1024 + (ip + 32 * h) * 16;
-#pragma unroll
-        for (int ks = 0; ks < KT; ++ks) {
-            wA[ks] = *reinterpret_cast<const bf16x8*>(a.pk_a + off + ks * 1024);
-            wG[ks] = *reinterpret_cast<const bf16x8*>(a.pk_g + off + ks * 1024);
-        }
-    }
-
+    bf16x8 wA[KT], wG[KT];                              // resident weights (loaded below, after the first stage requests)
     // ---- the stage pieces (1 KiB each) of this wave: pieces q = wave, wave + 8, wave + 16 are 8 rows of a pair tile of a row
     // tensor (tensor q / 8, pair (q / 4) % 2, rows 8 (q % 4) ..), pieces q' = wave + 8 j < 8 RT belong to the bottleneck tiles
     // (tensor q' / KT, piece q' % KT of the 32 contiguous rows)
@@ -261,10 +240,35 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
         }
     };
 
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // weights in registers, biases in LDS
+    // The first stages' requests go out BEFORE the wave fetches its resident weights and the biases (round 5; they used to follow them:
+    // two memory round trips in a row at the head of every launch).  One wait covers both.
 #pragma unroll
     for (int s0 = 0; s0 < NSTG - 1; ++s0)
         if (s0 < nsteps) issue(s0);
+    // up-side biases of the workgroup's 128 columns -> LDS (fp32)
+    if (tid < 256) {
+        float* sbias = reinterpret_cast<float*>(smem + BIAS_OFF);
+        const uint8_t* pk = tid < 128 ? a.pk_a : a.pk_g;
+        sbias[tid] = reinterpret_cast<const float*>(pk + pg.bias_off)[PR + 128 * cb + (tid & 127)];
+    }
+    // resident weights: A fragments of this wave's 32 columns.  Role U: Wu / Wgu from the "up" packs (slot = W[f][16ks + 8hh + j]);
+    // role D: Wd / Wgd transposed from the "down_t" packs (slot = W[16ks + 8hh + j][f]).  MFMA row i stands for column c0 +
+    // 16*((i>>2)&1) + 4*(i>>3) + (i&3), so that a lane (m, h) ends with the 16 CONTIGUOUS columns c0 + 16h .. +15 of row m; in the
+    // packs' own numbering (tests/packing_spec.py f_of4) that row is lane (i&3) | (nt << 2) | (i>>3 << 3) of n-tile v = (i>>2)&1.
+    {
+        const int i = m, v = (i >> 2) & 1, ip = (i & 3) | (nt << 2) | ((i >> 3) << 3);
+        const int64_t off = (int64_t)(role == 0 ? 1 : 3) * pg.pack_bytes + (int64_t)(2 * cb + pp) * (4 * RT * 1024)
+                          + (int64_t)(v * KT) * 1024 + (ip + 32 * h) * 16;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+            wA[ks] = *reinterpret_cast<const bf16x8*>(a.pk_a + off + ks * 1024);
+            wG[ks] = *reinterpret_cast<const bf16x8*>(a.pk_g + off + ks * 1024);
+        }
+    }
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // weights in registers, biases in LDS (and the first stages landed)
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) { asm volatile("" : "+v"(wA[ks])); asm volatile("" : "+v"(wG[ks])); }   // (hipcc's own guard of these loads lands here, not in the first step)
 #ifdef VLPET_COLS_STAMPS      // diagnosis build: wall-clock time per phase, summed over the steps, printed by one wave of each side
     uint64_t tacc[5] = {0, 0, 0, 0, 0}, tlast = wall_clock64();
 #define COLS_STAMP(k) { const uint64_t tn = wall_clock64(); tacc[k] += tn - tlast; tlast = tn; }

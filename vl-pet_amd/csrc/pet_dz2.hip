@@ -80,26 +80,7 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
     const int64_t grow = row_ok ? grow_raw : a.M - 1;
     const PackGeom pg = pack_geom(RT, d, 1);
 
-    // up-side biases -> LDS (fp32): [bu_a (d) | bu_g (d)]
-    {
-        float* sbias = reinterpret_cast<float*>(smem + GEO::BIAS_OFF);
-        const float* ba = reinterpret_cast<const float*>(a.pk_a + pg.bias_off) + 32 * RT;
-        const float* bg = reinterpret_cast<const float*>(a.pk_g + pg.bias_off) + 32 * RT;
-        for (int i = tid; i < d; i += 512) { sbias[i] = ba[i]; sbias[d + i] = bg[i]; }
-    }
-    // the saved bottleneck activations of this lane's row: B fragments of the up projections (k-slot (h, j) of k-step ks = c 16 ks + 8 h + j)
-    bf16x8 zA[KT], zG[KT];
-    {
-        const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved);
-        const __bf16* sa = reinterpret_cast<const __bf16*>(sv) + grow * (int64_t)(32 * RT) + 8 * h;
-        const __bf16* sg = reinterpret_cast<const __bf16*>(sv + 2 * a.saved_stride) + grow * (int64_t)(32 * RT) + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < KT; ++ks) {
-            if constexpr (NEED_A) zA[ks] = *reinterpret_cast<const bf16x8*>(sa + 16 * ks);
-            zG[ks] = *reinterpret_cast<const bf16x8*>(sg + 16 * ks);
-        }
-    }
-
+    bf16x8 zA[KT], zG[KT];                                              // (loaded below, after the first stage requests)
     // ---- the stage pieces (1 KiB each) of this wave: two pieces (8 rows each) of the dy tile and of the x2 tile, RT pieces of the
     // weight blocks.  The weight blocks are gathered from the "up" packs (fragments (stage, v, ks): slot (i, hh, j) =
     // W[f_of4(stage, v, i)][16 ks + 8 hh + j], tests/packing_spec.py) into natural row-major [f][c] order.
@@ -292,11 +273,40 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
         if (!SPREAD && s + AX < S) issue_x(s + AX);
     };
 
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // z in registers, biases in LDS
+    // The first stages' requests go out BEFORE this wave fetches its own z rows and the biases (round 5): the two used to be serial -- z and
+    // biases, wait, then the stage requests and their full memory latency again before the first MFMA (~1.5 us of a launch that is a
+    // 17-us chain at the per-rank sizes).  One wait covers both; the counted waits of the loop see nothing older than the stage requests.
 #pragma unroll
     for (int t = 0; t < (AW > AX ? AW : AX); ++t) {        // (same order as in the loop: W(t' + AW), X(t' + AX) for t' = t - max .. )
         if (t < AW && S0 + t < S) issue_w(S0 + t);
         if (t < AX && S0 + t < S) issue_x(S0 + t);
+    }
+    // up-side biases -> LDS (fp32): [bu_a (d) | bu_g (d)]
+    {
+        float* sbias = reinterpret_cast<float*>(smem + GEO::BIAS_OFF);
+        const float* ba = reinterpret_cast<const float*>(a.pk_a + pg.bias_off) + 32 * RT;
+        const float* bg = reinterpret_cast<const float*>(a.pk_g + pg.bias_off) + 32 * RT;
+        for (int i = tid; i < d; i += 512) { sbias[i] = ba[i]; sbias[d + i] = bg[i]; }
+    }
+    // the saved bottleneck activations of this lane's row: B fragments of the up projections (k-slot (h, j) of k-step ks = c 16 ks + 8 h + j)
+    {
+        const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved);
+        const __bf16* sa = reinterpret_cast<const __bf16*>(sv) + grow * (int64_t)(32 * RT) + 8 * h;
+        const __bf16* sg = reinterpret_cast<const __bf16*>(sv + 2 * a.saved_stride) + grow * (int64_t)(32 * RT) + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+            if constexpr (NEED_A) zA[ks] = *reinterpret_cast<const bf16x8*>(sa + 16 * ks);
+            zG[ks] = *reinterpret_cast<const bf16x8*>(sg + 16 * ks);
+        }
+    }
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // z in registers, biases in LDS (and the first stages landed)
+    // (hipcc does not read the wait above: without a use HERE it guards the first MFMA that touches z with its own vmcnt(0), after the
+    //  first step has requested the stage ahead -- one full memory latency in front of the first product of every launch)
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) {
+        if constexpr (NEED_A) asm volatile("" : "+v"(zA[ks]));
+        asm volatile("" : "+v"(zG[ks]));
     }
     // The two waves of a SIMD (the feature halves of a row group) run the same three phases -- up projections (LDS + matrix
     // cores), elementwise (VALU, 1.1 k cycles), contraction (LDS + matrix cores) -- and in lockstep they would queue for the same

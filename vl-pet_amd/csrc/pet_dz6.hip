@@ -25,6 +25,17 @@ __device__ __forceinline__ void glds16_p1(const void* gsrc, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds((gmem_cv*)gsrc, (lmem_v*)lds_wave_base, 16, 0, VLPET_P1_AUX);
 }
 
+// A/B switches of the round-5 changes (tools/gpu/r5_q.sh builds the variants): first requests after the z / bias wait (rounds 4 order),
+// no use of the z registers at the wait, the epilogue's act' loads one at a time
+#ifndef VLPET_DZ6_LATE_ISSUE
+#define VLPET_DZ6_LATE_ISSUE 0
+#endif
+#ifndef VLPET_DZ6_PIN_Z
+#define VLPET_DZ6_PIN_Z 1
+#endif
+#ifndef VLPET_DZ6_EPI_SERIAL
+#define VLPET_DZ6_EPI_SERIAL 0
+#endif
 template <int RT> struct Dz6Geo {
     static constexpr int PB = 64 * RT;                 // bytes of a weight row (one feature, all bottleneck columns)
     static constexpr int NPS = PB / 16;
@@ -65,26 +76,7 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
     const int64_t grow = row_ok ? grow_raw : a.M - 1;
     const PackGeom pg = pack_geom(RT, d, 1);
 
-    // up-side biases -> LDS (fp32): [bu_a (d) | bu_g (d)]
-    {
-        float* sbias = reinterpret_cast<float*>(smem + GEO::BIAS_OFF);
-        const float* ba = reinterpret_cast<const float*>(a.pk_a + pg.bias_off) + 32 * RT;
-        const float* bg = reinterpret_cast<const float*>(a.pk_g + pg.bias_off) + 32 * RT;
-        for (int i = tid; i < d; i += 256) { sbias[i] = ba[i]; sbias[d + i] = bg[i]; }
-    }
-    // the saved bottleneck activations of this lane's row: B fragments of the up projections (k-slot (h, j) of k-step ks = c 16 ks + 8 h + j)
-    bf16x8 zA[KT], zG[KT];
-    {
-        const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved);
-        const __bf16* sa = reinterpret_cast<const __bf16*>(sv) + grow * (int64_t)(32 * RT) + 8 * h;
-        const __bf16* sg = reinterpret_cast<const __bf16*>(sv + 2 * a.saved_stride) + grow * (int64_t)(32 * RT) + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < KT; ++ks) {
-            if constexpr (NEED_A) zA[ks] = *reinterpret_cast<const bf16x8*>(sa + 16 * ks);
-            zG[ks] = *reinterpret_cast<const bf16x8*>(sg + 16 * ks);
-        }
-    }
-
+    bf16x8 zA[KT], zG[KT];                                              // (loaded below, after the first stage requests)
     // ---- the pieces (1 KiB each) of this wave: four pieces (8 rows each) of the dy tile and of the x2 tile per STAGE, NWP pieces of
     // the weight blocks per HALF-stage.  The weight blocks are gathered from the "up" packs (fragments (stage, v, ks): slot (i, hh, j)
     // = W[f_of4(stage, v, i)][16 ks + 8 hh + j], tests/packing_spec.py) into natural row-major [f][c] order; feature f = 32 fh + fl of
@@ -198,9 +190,42 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
         });
     };
 
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // z in registers, biases in LDS
+    // the first half-stage's requests go out before this wave fetches its own z rows and the biases (see k1_dz2_kernel)
+#if !VLPET_DZ6_LATE_ISSUE
     issue_w(2 * S0);
     issue_x(S0);
+#endif
+    // up-side biases -> LDS (fp32): [bu_a (d) | bu_g (d)]
+    {
+        float* sbias = reinterpret_cast<float*>(smem + GEO::BIAS_OFF);
+        const float* ba = reinterpret_cast<const float*>(a.pk_a + pg.bias_off) + 32 * RT;
+        const float* bg = reinterpret_cast<const float*>(a.pk_g + pg.bias_off) + 32 * RT;
+        for (int i = tid; i < d; i += 256) { sbias[i] = ba[i]; sbias[d + i] = bg[i]; }
+    }
+    // the saved bottleneck activations of this lane's row: B fragments of the up projections (k-slot (h, j) of k-step ks = c 16 ks + 8 h + j)
+    {
+        const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved);
+        const __bf16* sa = reinterpret_cast<const __bf16*>(sv) + grow * (int64_t)(32 * RT) + 8 * h;
+        const __bf16* sg = reinterpret_cast<const __bf16*>(sv + 2 * a.saved_stride) + grow * (int64_t)(32 * RT) + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+            if constexpr (NEED_A) zA[ks] = *reinterpret_cast<const bf16x8*>(sa + 16 * ks);
+            zG[ks] = *reinterpret_cast<const bf16x8*>(sg + 16 * ks);
+        }
+    }
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // z in registers, biases in LDS (and the first half-stage landed)
+#if VLPET_DZ6_PIN_Z
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) {                  // (a use here: hipcc's own guard of the z loads lands on the wait above, see k1_dz2_kernel)
+        if constexpr (NEED_A) asm volatile("" : "+v"(zA[ks]));
+        asm volatile("" : "+v"(zG[ks]));
+    }
+#endif
+#if VLPET_DZ6_LATE_ISSUE
+    issue_w(2 * S0);
+    issue_x(S0);
+#endif
 
     // request order per step (what the counted waits rely on): half-stage (s, 0): W(2s + 1), X(s + 1); half-stage (s, 1): W(2s + 2)
 #pragma unroll 1
@@ -277,8 +302,12 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
         }
         return;
     }
-    // ---- dpre = dz * act'(pre) of both chains (dz_a carries the delta scale once, here)
+    // ---- dpre = dz * act'(pre) of both chains (dz_a carries the delta scale once, here).  All 48 act' pieces of the lane are requested
+    // before the first product (the z fragments are dead: 96 free registers): written as load / multiply / store per piece, hipcc kept
+    // every load behind the previous store (gp and out may alias for all it knows) -- 48 dependent memory round trips at the end of
+    // every workgroup (round 5: found in the ISA, 48 x "global_load_dwordx2; s_waitcnt vmcnt(0)").
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#if VLPET_DZ6_EPI_SERIAL
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved) + (t == 0 ? 1 : 3) * a.saved_stride;
@@ -288,17 +317,43 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
 #pragma unroll
         for (int ct = 0; ct < RT; ++ct)
 #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16x4 g1 = *reinterpret_cast<const bf16x4*>(gp + 32 * ct + 8 * q);
+                bf16x4 r4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r4[j] = (__bf16)(sc * (t == 0 ? dzA[ct][4 * q + j] : dzG[ct][4 * q + j]) * (float)g1[j]);
+                if (row_ok) *reinterpret_cast<bf16x4*>(out + 32 * ct + 8 * q) = r4;
+            }
+    }
+#else
+    bf16x4 gpv[2][RT][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved) + (t == 0 ? 1 : 3) * a.saved_stride;
+        const __bf16* gp = reinterpret_cast<const __bf16*>(sv) + grow * (int64_t)(32 * RT) + 4 * h;
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gpv[t][ct][q] = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(gp + 32 * ct + 8 * q));
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        __bf16* out = reinterpret_cast<__bf16*>(t == 0 ? a.dp_a : a.dp_g) + grow * (int64_t)(32 * RT) + 4 * h;
+        const float sc = t == 0 ? sd : 1.0f;
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
             for (int q = 0; q < 4; ++q) {               // columns 32 ct + 8 q + 4 h .. + 3
-                const bf16x4 gpv = *reinterpret_cast<const bf16x4*>(gp + 32 * ct + 8 * q);
                 bf16x4 r4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float mine = t == 0 ? dzA[ct][4 * q + j] : dzG[ct][4 * q + j];
-                    r4[j] = (__bf16)(sc * mine * (float)gpv[j]);
+                    r4[j] = (__bf16)(sc * mine * (float)gpv[t][ct][q][j]);
                 }
                 if (row_ok) *reinterpret_cast<bf16x4*>(out + 32 * ct + 8 * q) = r4;
             }
     }
+#endif
 }
 
 int k1_dz6_feature_blocks(int64_t M, int d) {

@@ -56,7 +56,19 @@ __device__ __forceinline__ void row_keep_bits(int64_t row_e0, int lane, int piec
 // src/modeling_bart.py:298-299 then :324-325); statistics and the saved pre-norm tensor are those of dropout(y) alone.
 // RMS2 (plain residual tail only, round 5): the wave that has just formed the row x1 + dropout(y) also applies the NEXT sublayer's RMS norm
 // to it and writes both -- T5's pre-norm stream otherwise reads the sum back in a second launch (2 of that launch's 2 units + the launch).
-template <typename IO, int NP, bool NORM, bool POST = false, int PB = 16, bool RMS2 = false>
+template <int E> __device__ __forceinline__ void load_f32_vec(const float* src, float* v) {      // src 16-byte aligned, E % 4 == 0
+#pragma unroll
+    for (int j = 0; j < E; j += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + j);
+        v[j] = t[0]; v[j + 1] = t[1]; v[j + 2] = t[2]; v[j + 3] = t[3];
+    }
+}
+
+// FULL (round 5): the row is exactly NP x 64 pieces (d = 768 with 8-byte pieces, 1024 with either): every "is this piece inside the row"
+// test folds away and -- what matters -- the row loads become UNCONDITIONAL.  With loads under a branch hipcc cannot count how many
+// requests are younger than the row it is about to use, so it guarded that use with s_waitcnt vmcnt(0): the row requested one ahead
+// was awaited before the current one was reduced, i.e. the prefetch hid nothing (found in the ISA, tools/isa_waits.py).
+template <typename IO, int NP, bool NORM, bool POST = false, int PB = 16, bool RMS2 = false, bool FULL = false>
 __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
     static_assert(!POST || NORM, "post-norm residual needs the norm");
     static_assert(!RMS2 || !NORM, "the second (normalised) output belongs to the plain residual tail");
@@ -64,7 +76,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
     using Raw = typename P::Raw;
     constexpr int E = P::E;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int d = a.d, pieces = d / E;
+    const int d = FULL ? NP * 64 * E : a.d, pieces = FULL ? NP * 64 : d / E;
     const uint32_t thr = a.thr;
     const uint64_t seed = thr ? vlpet_eff_seed(a.seed, a.seed_ctr) : 0;      // (one scalar load, before the row loop)
     const float scale = a.keep_scale;
@@ -73,10 +85,19 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = lane + 64 * k;
+            if constexpr (FULL) {       // 16-byte vectors, no branch (the launcher checked the alignment); element by element they were 24 dword loads
+                const float bm = a.beta ? 1.f : 0.f;
+                const float* bsrc = a.beta ? a.beta : a.gamma;
+                load_f32_vec<E>(a.gamma + p * E, gam[k]);
+                load_f32_vec<E>(bsrc + p * E, bet[k]);
 #pragma unroll
-            for (int j = 0; j < E; ++j) {
-                gam[k][j] = p < pieces ? a.gamma[p * E + j] : 0.f;
-                bet[k][j] = (p < pieces && a.beta) ? a.beta[p * E + j] : 0.f;
+                for (int j = 0; j < E; ++j) bet[k][j] *= bm;
+            } else {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    gam[k][j] = p < pieces ? a.gamma[p * E + j] : 0.f;
+                    bet[k][j] = (p < pieces && a.beta) ? a.beta[p * E + j] : 0.f;
+                }
             }
         }
     }
@@ -85,12 +106,16 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = lane + 64 * k;
+            if constexpr (FULL) load_f32_vec<E>(a.gamma2 + p * E, gam2[k]);
+            else {
 #pragma unroll
-            for (int j = 0; j < E; ++j) gam2[k][j] = p < pieces ? a.gamma2[p * E + j] : 0.f;
+                for (int j = 0; j < E; ++j) gam2[k][j] = p < pieces ? a.gamma2[p * E + j] : 0.f;
+            }
         }
     }
     const uint8_t* y = reinterpret_cast<const uint8_t*>(a.y);
     const uint8_t* x1 = reinterpret_cast<const uint8_t*>(a.x1);
+    const uint8_t* ysrc = y ? y : x1;               // (no y: the request still goes out -- to x1's lines -- and its value is not used)
     uint8_t* out = reinterpret_cast<uint8_t*>(a.out);
     uint8_t* out2 = reinterpret_cast<uint8_t*>(a.out2);
     uint8_t* hs = reinterpret_cast<uint8_t*>(a.h);
@@ -105,7 +130,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int p = lane + 64 * k;
-            if (p < pieces) { if (y) ry[k] = P::load_raw_nt(y + o + p * PB); rx[k] = P::load_raw_nt(x1 + o + p * PB); }
+            if (p < pieces) { ry[k] = P::load_raw_nt(ysrc + o + p * PB); rx[k] = P::load_raw_nt(x1 + o + p * PB); }
         }
     };
     {
@@ -228,7 +253,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_fwd_kernel(TailArgs a) {
 // With 8-byte pieces at d = 768 (three per lane, every lane busy) the HOUT form went from 196 registers / 2 waves per SIMD to <= 128 / 4.
 // The row is swept twice from its raw registers (sums first, then the gradient: g and xhat are recomputed per piece instead of being
 // held across the wave reduction -- 24 registers at d = 768), DRES (the parked gradient of T5's norm link) is a template flag.
-template <typename IO, int NP, bool NORM, bool HOUT = false, int PB = 16, bool DRES = false>
+template <typename IO, int NP, bool NORM, bool HOUT = false, int PB = 16, bool DRES = false, bool FULL = false>
 __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
     static_assert(!HOUT || NORM, "recovering xhat from the output needs the norm");
     using P = Piece<IO, PB>;
@@ -238,7 +263,7 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
     constexpr int PRM_F = NPRM * NP * 64 * E, ACC_F = TAIL_WAVES * 2 * 64 * E;
     __shared__ __attribute__((aligned(16))) float sm[(PRM_F > ACC_F ? PRM_F : ACC_F) > 0 ? (PRM_F > ACC_F ? PRM_F : ACC_F) : 4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int d = a.d, pieces = d / E;
+    const int d = FULL ? NP * 64 * E : a.d, pieces = FULL ? NP * 64 : d / E;      // (FULL: see the forward)
     const uint32_t thr = a.thr;
     const uint64_t seed = thr ? vlpet_eff_seed(a.seed, a.seed_ctr) : 0;      // (one scalar load, before the row loop)
     const float scale = a.keep_scale;
@@ -247,15 +272,31 @@ __global__ __launch_bounds__(TAIL_WAVES * 64) void tail_bwd_kernel(TailArgs a) {
         // slot (arr, k, lane) of the parameter area holds the E values of piece lane + 64 k
         for (int q = threadIdx.x; q < NP * 64; q += TAIL_WAVES * 64) {
             const int p = q;                                        // piece index = lane' + 64 k'  (q = 64 k' + lane')
+            float gv[E], bv[E];
+            if constexpr (FULL) {       // (vector loads, no branch: see the forward)
+                const float bm = a.beta ? 1.f : 0.f;
+                const float* bsrc = a.beta ? a.beta : a.gamma;
+                load_f32_vec<E>(a.gamma + p * E, gv);
+                if constexpr (HOUT) {
+                    load_f32_vec<E>(bsrc + p * E, bv);
+#pragma unroll
+                    for (int j = 0; j < E; ++j) bv[j] *= bm;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    gv[j] = p < pieces ? a.gamma[p * E + j] : 0.f;
+                    if constexpr (HOUT) bv[j] = (p < pieces && a.beta) ? a.beta[p * E + j] : 0.f;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                const float gm = p < pieces ? a.gamma[p * E + j] : 0.f;
+                const float gm = gv[j];
                 sm[q * E + j] = gm;
                 if constexpr (HOUT) {
                     const float gi = gm != 0.f ? 1.0f / gm : 0.f;
-                    const float be = (p < pieces && a.beta) ? a.beta[p * E + j] : 0.f;
                     sm[(NP * 64 + q) * E + j] = gi;
-                    sm[(2 * NP * 64 + q) * E + j] = be * gi;
+                    sm[(2 * NP * 64 + q) * E + j] = bv[j] * gi;
                 }
             }
         }
@@ -583,22 +624,35 @@ int tail_blocks(int64_t M) {
     return (int)(need < cap ? need : cap);
 }
 
-template <typename IO, int NP, bool NORM, int PB>
-static hipError_t launch_np(const TailArgs& a, bool bwd, hipStream_t stream) {
+template <typename IO, int NP, bool NORM, int PB, bool FULL>
+static hipError_t launch_np_full(const TailArgs& a, bool bwd, hipStream_t stream) {
     const int blocks = tail_blocks(a.M);
+    const dim3 g(blocks), t(TAIL_WAVES * 64);
     if (bwd && NORM && a.h_out) {
-        if constexpr (NORM) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, true, true, PB>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+        if constexpr (NORM) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, true, true, PB, false, FULL>), g, t, 0, stream, a);
     }
-    else if (bwd && a.dres) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, NORM, false, PB, true>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
-    else if (bwd) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, NORM, false, PB>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+    else if (bwd && a.dres) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, NORM, false, PB, true, FULL>), g, t, 0, stream, a);
+    else if (bwd) hipLaunchKernelGGL((tail_bwd_kernel<IO, NP, NORM, false, PB, false, FULL>), g, t, 0, stream, a);
     else if (NORM && a.post) {
-        if constexpr (NORM) hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, true, true, PB>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+        if constexpr (NORM) hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, true, true, PB, false, FULL>), g, t, 0, stream, a);
     }
     else if (!NORM && a.out2) {
-        if constexpr (!NORM) hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, false, false, PB, true>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+        if constexpr (!NORM) hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, false, false, PB, true, FULL>), g, t, 0, stream, a);
     }
-    else hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, NORM, false, PB>), dim3(blocks), dim3(TAIL_WAVES * 64), 0, stream, a);
+    else hipLaunchKernelGGL((tail_fwd_kernel<IO, NP, NORM, false, PB, false, FULL>), g, t, 0, stream, a);
     return hipGetLastError();
+}
+
+template <typename IO, int NP, bool NORM, int PB>
+static hipError_t launch_np(const TailArgs& a, bool bwd, hipStream_t stream) {
+    // rows of exactly NP x 64 pieces (768 / 8-byte pieces, 1024, 2048 ...): the branch-free instantiation (bf16 only: the fp32 rows of the
+    // tests are not worth a second copy of every kernel); the per-column vectors must be 16-byte aligned for its vector loads (a view
+    // into a flat parameter buffer may not be)
+    const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (sizeof(IO) == 2 && NP <= 4 && a.d == NP * 64 * (PB / (int)sizeof(IO)) && al16(a.gamma) && al16(a.beta) && al16(a.gamma2)) {
+        if constexpr (sizeof(IO) == 2 && NP <= 4) return launch_np_full<IO, NP, NORM, PB, true>(a, bwd, stream);      // (eight pieces per lane: two rows in flight do not fit the registers)
+    }
+    return launch_np_full<IO, NP, NORM, PB, false>(a, bwd, stream);
 }
 
 // Piece size of a bf16 row: 8-byte pieces when they leave fewer per-lane element slots than 16-byte ones (d = 768: 3 x 4 = 12

@@ -13,6 +13,7 @@
 #include "pet16.h"      // common.h + glds16
 #include <cstdlib>
 #include <type_traits>
+#include <mutex>
 #include <vector>
 #include "kernels.h"
 
@@ -887,31 +888,35 @@ __global__ __launch_bounds__(256) void wgrad_finalize_batch_kernel(FinBatch b) {
     finalize_body(a, tile);
 }
 
+// The switch is per host thread (a caller brackets single calls with it); the QUEUE is per process: a training framework runs its
+// backward calls on its autograd engine's worker thread and flushes from the thread that called backward().
 static thread_local bool g_fin_defer = false;
-static thread_local std::vector<FinArgs> g_fin_queue;
+static std::mutex g_fin_mutex;
+static std::vector<FinArgs> g_fin_queue;
 
 int finalize_defer(int on) { const int was = g_fin_defer ? 1 : 0; g_fin_defer = on != 0; return was; }
-int finalize_pending() { return (int)g_fin_queue.size(); }
-void finalize_discard() { g_fin_queue.clear(); }
+int finalize_pending() { std::lock_guard<std::mutex> lk(g_fin_mutex); return (int)g_fin_queue.size(); }
+void finalize_discard() { std::lock_guard<std::mutex> lk(g_fin_mutex); g_fin_queue.clear(); }
 hipError_t finalize_flush(hipStream_t stream) {
-    const size_t n = g_fin_queue.size();
+    std::vector<FinArgs> q;
+    { std::lock_guard<std::mutex> lk(g_fin_mutex); q.swap(g_fin_queue); }
+    const size_t n = q.size();
     for (size_t k0 = 0; k0 < n; k0 += VLPET_FIN_BATCH) {
         const int nb = (int)(n - k0 < VLPET_FIN_BATCH ? n - k0 : VLPET_FIN_BATCH);
         if (nb == 1) {
-            const FinArgs& f = g_fin_queue[k0];
+            const FinArgs& f = q[k0];
             hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)f.blocks, f.njobs), dim3(256), 0, stream, f);
             continue;
         }
         FinBatch b{};
         int bx = 0, by = 0;
         for (int k = 0; k < nb; ++k) {
-            b.a[k] = g_fin_queue[k0 + k];
+            b.a[k] = q[k0 + k];
             if (b.a[k].blocks > bx) bx = b.a[k].blocks;
             if (b.a[k].njobs > by) by = b.a[k].njobs;
         }
         hipLaunchKernelGGL(wgrad_finalize_batch_kernel, dim3((unsigned)bx, (unsigned)by, (unsigned)nb), dim3(256), 0, stream, b);
     }
-    g_fin_queue.clear();
     return hipGetLastError();
 }
 
@@ -930,7 +935,11 @@ static hipError_t launch_finalize(const WgradArgs& a, int RT, int xmax, int rmax
         F.scale = J.scale; F.ntile = finalize_tiles(PR, J.xcols);
         if (mask_unscaled && J.has_drop) F.scale *= J.drop.keep_scale;      // the streaming kernel only clears the dropped elements
     }
-    if (g_fin_defer) { g_fin_queue.push_back(f); return hipSuccess; }      // (launched by finalize_flush)
+    if (g_fin_defer) {      // (launched by finalize_flush)
+        std::lock_guard<std::mutex> lk(g_fin_mutex);
+        g_fin_queue.push_back(f);
+        return hipSuccess;
+    }
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)blocks, a.njobs), dim3(256), 0, stream, f);
     return hipGetLastError();
 }
