@@ -132,7 +132,7 @@ def test_deferred_finalize_is_bit_identical(graph, lora):
                 assert lib.vlpet_finalize_pending() == 0
             res[defer] = (losses, {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad})
         finally:
-            VF.DEFER_FINALIZE = True
+            VF.DEFER_FINALIZE = False         # (the default: profiles/r05_deferred_finalize_ab.txt)
     assert res[False][0] == res[True][0], (res[False][0], res[True][0])
     for n, p in res[False][1].items():
         assert torch.equal(p, res[True][1][n]), n

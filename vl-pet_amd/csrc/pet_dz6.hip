@@ -34,8 +34,8 @@ __device__ __forceinline__ void glds16_p1(const void* gsrc, void* lds_wave_base)
 #define VLPET_DZ6_PIN_Z 1
 #endif
 #ifndef VLPET_DZ6_EPI_SERIAL
-#define VLPET_DZ6_EPI_SERIAL 0
-#endif
+#define VLPET_DZ6_EPI_SERIAL 1      // 0 = all 48 act' loads first (measured SLOWER: 69.9 vs 62.1 us at 18,250 rows -- 96 more live registers cost the loop more
+#endif                              //     than the batched loads save; profiles/r05_k1bench_dz6_variants.txt); 2 = no act' loads at all (diagnosis: a lower bound)
 template <int RT> struct Dz6Geo {
     static constexpr int PB = 64 * RT;                 // bytes of a weight row (one feature, all bottleneck columns)
     static constexpr int NPS = PB / 16;
@@ -318,7 +318,11 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
         for (int ct = 0; ct < RT; ++ct)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+#if VLPET_DZ6_EPI_SERIAL == 2
+                const bf16x4 g1 = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
+#else
                 const bf16x4 g1 = *reinterpret_cast<const bf16x4*>(gp + 32 * ct + 8 * q);
+#endif
                 bf16x4 r4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) r4[j] = (__bf16)(sc * (t == 0 ? dzA[ct][4 * q + j] : dzG[ct][4 * q + j]) * (float)g1[j]);

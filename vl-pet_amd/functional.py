@@ -71,8 +71,10 @@ _PENDING_REDUCES: list = []
 # ... and, round 5, the finalize launches of the weight-gradient kernels (the sum of a call's row-chunk partials into dW / db): with
 # the switch on, a backward op whose gradients all go to sinks queues that launch inside the library (vlpet_finalize_defer) and
 # flush_reduces() issues the queue, 16 calls per launch (19 launches -> 2 in a BART-base step, 37 -> 3 in T5-base).  The call's
-# workspace (the partial sums) is kept alive here until then.
-DEFER_FINALIZE = True
+# workspace (the partial sums) is kept alive here until then.  Bit-identical (tests/test_gpu_graph.py) -- and measured worth NOTHING:
+# BART-base 17.07 / 17.65 vs 17.19 / 16.96 ms per step, emulated rank 1 of 8 5.34 vs 5.35 ms, T5-base 24.2 vs 24.2, 9.30 vs 9.27
+# (profiles/r05_deferred_finalize_ab.txt): the batched launch reads the same partial sums, by then out of the caches.  Off by default.
+DEFER_FINALIZE = False
 _PENDING_FINALIZE_KEEP: list = []
 
 
