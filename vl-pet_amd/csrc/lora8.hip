@@ -59,7 +59,8 @@ __device__ __forceinline__ void wave_sum8(float (&z)[8], int lane) {
 }
 
 // NCH = chunks (4 features, 8 bytes) per lane: d = 256 * NCH
-template <int NCH, bool DROP>
+template <int NCH, int DROP>      // DROP: 0 no dropout, 1 the generator's mask (no mask LOADS in the row loop: hipcc keeps counted waits and the
+                                  // prefetched row overlaps -- tail.hip's FULL note), 2 any source (explicit / packed mask)
 __global__ __launch_bounds__(L8_WAVES * 64) void lora8_fwd_kernel(Lora8Args a) {
     constexpr int D = 256 * NCH, NG = D / 8, NR = (NG + 63) / 64;      // 8-feature groups of a row, generator rounds
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(L8_WAVES * 64) void lora8_fwd_kernel(Lora8Args a) {
             for (int rho = 0; rho < NR; ++rho) {
                 const int g = 64 * rho + lane;
                 const bool live = NG % 64 == 0 || g < NG;
-                gbits[rho] = drop_bits8(drop, row, 8 * (live ? g : 0), D);
+                gbits[rho] = DROP == 1 ? keep8((row * D + 8 * (live ? g : 0)) >> 3, drop.seed, drop.thr) : drop_bits8(drop, row, 8 * (live ? g : 0), D);
                 // (byte stores: gathering the four groups of a dword from their lanes first was measured and is no faster)
                 if (live && drop.bits_out != nullptr) drop.bits_out[row * (int64_t)(D >> 3) + drop_pos(g)] = (uint8_t)gbits[rho];
                 if (live && drop.keep_out != nullptr) drop_export8(drop.keep_out, row * D + 8 * g, gbits[rho]);
@@ -192,8 +193,13 @@ bool lora8_applies(int64_t M, int d, int r, int io_fp32) {
 template <int NCH>
 static hipError_t launch_lora8_n(const Lora8Args& a, hipStream_t stream) {
     const int blocks = tail_blocks(a.M);
-    if (drop_active(a.drop)) hipLaunchKernelGGL((lora8_fwd_kernel<NCH, true>), dim3(blocks), dim3(L8_WAVES * 64), 0, stream, a);
-    else hipLaunchKernelGGL((lora8_fwd_kernel<NCH, false>), dim3(blocks), dim3(L8_WAVES * 64), 0, stream, a);
+#ifndef VLPET_LORA8_GENERAL      // (-DVLPET_LORA8_GENERAL=1: every dropout launch on the any-source form, the round-4 behaviour, for A/B)
+#define VLPET_LORA8_GENERAL 0
+#endif
+    if (!VLPET_LORA8_GENERAL && drop_active(a.drop) && a.drop.keep == nullptr && a.drop.bits == nullptr)
+        hipLaunchKernelGGL((lora8_fwd_kernel<NCH, 1>), dim3(blocks), dim3(L8_WAVES * 64), 0, stream, a);
+    else if (drop_active(a.drop)) hipLaunchKernelGGL((lora8_fwd_kernel<NCH, 2>), dim3(blocks), dim3(L8_WAVES * 64), 0, stream, a);
+    else hipLaunchKernelGGL((lora8_fwd_kernel<NCH, 0>), dim3(blocks), dim3(L8_WAVES * 64), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t launch_lora8_fwd(const Lora8Args& a, hipStream_t stream) {

@@ -34,7 +34,7 @@ __device__ __forceinline__ void glds16_p1(const void* gsrc, void* lds_wave_base)
 #define VLPET_DZ6_PIN_Z 1
 #endif
 #ifndef VLPET_DZ6_EPI_SERIAL
-#define VLPET_DZ6_EPI_SERIAL 1      // 0 = all 48 act' loads first (measured SLOWER: 69.9 vs 62.1 us at 18,250 rows -- 96 more live registers cost the loop more
+#define VLPET_DZ6_EPI_SERIAL 3      // 3 = act' rows through LDS (below); 1 = the rounds 4 form, one load at a time; 0 = all 48 act' loads first (measured SLOWER: 69.9 vs 62.1 us at 18,250 rows -- 96 more live registers cost the loop more
 #endif                              //     than the batched loads save; profiles/r05_k1bench_dz6_variants.txt); 2 = no act' loads at all (diagnosis: a lower bound)
 template <int RT> struct Dz6Geo {
     static constexpr int PB = 64 * RT;                 // bytes of a weight row (one feature, all bottleneck columns)
@@ -307,7 +307,61 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
     // every load behind the previous store (gp and out may alias for all it knows) -- 48 dependent memory round trips at the end of
     // every workgroup (round 5: found in the ISA, 48 x "global_load_dwordx2; s_waitcnt vmcnt(0)").
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-#if VLPET_DZ6_EPI_SERIAL
+#if VLPET_DZ6_EPI_SERIAL == 3
+    // The act' rows of a wave's 32 rows are 2 x 12 KiB of CONTIGUOUS memory ([M, 192] bf16): they come in by LDS-DMA -- no registers, one
+    // memory latency for all of them -- into the (now free) stage rings, 24 KiB per wave, and are read back per piece.  16-byte chunk c of
+    // row r sits at slot (c + r) mod 24 of the row (the DMA's LDS side is fixed per lane, so the rotation is applied to the SOURCE address):
+    // rows are 96 dwords apart, unrotated every second lane of a read would hit the same banks.  The serial form costs 6 us of a 62 us
+    // launch (profiles/r05_k1bench_dz6_variants.txt: 62.3 vs 56.0 us without the loads).
+    {
+        __builtin_amdgcn_s_barrier();                                     // every wave is done with the rings
+        int lane_e = lane;                                                // (an opaque copy: the address arithmetic below must not be hoisted above the
+        asm volatile("" : "+v"(lane_e));                                  //  24-half-stage loop, where every register counts)
+        const int m_e = lane_e & 31, h_e = lane_e >> 5;
+        uint8_t* area = smem + (size_t)rg * (2 * 32 * PB);
+        const int64_t rb = row0 + 32 * rg;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved) + (t == 0 ? 1 : 3) * a.saved_stride;
+#pragma unroll
+            for (int pc = 0; pc < 32 * PB / 1024; ++pc) {
+                const int slot = pc * 64 + lane_e, r = slot / (PB / 16), cs = slot % (PB / 16);
+                int c = cs - (r % (PB / 16));
+                if (c < 0) c += PB / 16;
+                int64_t gr = rb + r;
+                if (gr >= a.M) gr = a.M - 1;
+                glds16(sv + gr * PB + c * 16, area + (size_t)t * (32 * PB) + (size_t)pc * 1024);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (a wave reads back only what it requested itself)
+        const uint32_t abase = lds0 + (uint32_t)(rg * (2 * 32 * PB)) + (uint32_t)(m_e * PB) + 8 * h_e;
+        const int mrot = m_e % (PB / 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            __bf16* out = reinterpret_cast<__bf16*>(t == 0 ? a.dp_a : a.dp_g) + grow * (int64_t)(32 * RT) + 4 * h;
+            const float sc = t == 0 ? sd : 1.0f;
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct) {
+                u32x2 gv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int cs = 4 * ct + q + mrot;
+                    if (cs >= PB / 16) cs -= PB / 16;
+                    lds_read8<0>(gv[q], abase + (uint32_t)(t * 32 * PB) + (uint32_t)(cs * 16));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]) :: "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {           // columns 32 ct + 8 q + 4 h .. + 3
+                    const bf16x4 g1 = __builtin_bit_cast(bf16x4, gv[q]);
+                    bf16x4 r4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r4[j] = (__bf16)(sc * (t == 0 ? dzA[ct][4 * q + j] : dzG[ct][4 * q + j]) * (float)g1[j]);
+                    if (row_ok) *reinterpret_cast<bf16x4*>(out + 32 * ct + 8 * q) = r4;
+                }
+            }
+        }
+    }
+#elif VLPET_DZ6_EPI_SERIAL
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved) + (t == 0 ? 1 : 3) * a.saved_stride;
