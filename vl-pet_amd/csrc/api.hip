@@ -487,7 +487,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     }
     if (cols4) {
         ColzArgs c{};
-        c.dy = dy; c.x1 = xg; c.x2 = res; c.dxin = dx1_in;
+        c.dy = dy; c.x1 = xg; c.x2 = res; c.dxin = dx1_in; c.y = b.y;
         c.z_a = b.z_a; c.z_g = b.z_g; c.dp_a = b.dp_a; c.dp_g = b.dp_g;
         c.dx1 = dxg; c.dx2 = dxa;
         c.pk_a = b.pk_a; c.pk_g = b.pk_g;
@@ -496,7 +496,8 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
         const WgradLayout L = wgrad_layout(g);
         for (int j = 0; j < 4; ++j) c.part[j] = g.partial + L.off[j];
         if (phases & 2) {
-            hipError_t e = cols6 ? launch_k1_cols6(c, (hipStream_t)stream) : launch_k1_cols(c, tiles, (hipStream_t)stream);
+            hipError_t e = cols6 ? (k1_cols6y_applies(c) ? launch_k1_cols6y(c, (hipStream_t)stream) : launch_k1_cols6(c, (hipStream_t)stream))
+                                 : launch_k1_cols(c, tiles, (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
         }
         if ((phases & 8) && !(phases & 16)) return 0;       // (the partial sums stay in the workspace)

@@ -174,6 +174,7 @@ hipError_t launch_pet_gate_cols(const PetBwdArgs& a, const WgradArgs& g, int GS,
 struct ColzArgs {
     const void* dy; const void* x1; const void* x2;      // [M, d] bf16
     const void* dxin;                                    // optional [M, d]: added to dx1
+    const void* y;                                       // optional [M, d]: the forward's output (pet_cols6y.hip: dq = dy * y * (1 - g))
     const void* z_a; const void* z_g;                    // the forward's saved z          [M, 32*RT]
     const void* dp_a; const void* dp_g;                  // pass 1's dpre                  [M, 32*RT]
     void* dx1; void* dx2;
@@ -192,6 +193,9 @@ hipError_t launch_k1_cols(const ColzArgs& c, int RT, hipStream_t stream);
 void k1_cols6_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk);
 bool k1_cols6_applies(const PetBwdArgs& a, int io_fp32);
 hipError_t launch_k1_cols6(const ColzArgs& c, hipStream_t stream);
+// ... with the up-side weight gradients one step late and the elementwise block from the forward's output (pet_cols6y.hip)
+bool k1_cols6y_applies(const ColzArgs& c);
+hipError_t launch_k1_cols6y(const ColzArgs& c, hipStream_t stream);
 
 // K4: out = LN(feats . W^T + b) * gamma + beta (+ R); optionally stores xhat and rstd for the backward
 struct VisprojArgs {
