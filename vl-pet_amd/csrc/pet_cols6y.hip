@@ -18,6 +18,11 @@
 // Applies when the caller passes y (vlpet_adapter_gate_bwd_saved_y) or the gate is additive (dq = gs * dy * g (1 - g): neither h nor y).
 #include "cols_common.h"
 
+// timing ablations (results wrong on purpose; tools/gpu/r5_u.sh): 1 = no wait for the stage pieces, 2 = no role work between the barriers,
+// 4 = no dx1 / dx2 stores
+#ifndef VLPET_C6Y_ABL
+#define VLPET_C6Y_ABL 0
+#endif
 template <int RT> struct Colz6yGeo {
     static constexpr int KT = 2 * RT;
     static constexpr int PB = 64 * RT, NPR = PB / 16;   // bytes / 16-byte slots of a bottleneck row
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void k1_cols6y_kernel(ColzArgs a) {
     // done), request stage s + 1.  Ring reuse: z slot (s + 1) % 3 was last read by UW in step s - 1, the dpre / row slots (s + 1) % 2 by
     // DE / DW in step s - 1, dh / dq slot s & 1 (written by UE in step s) by DE / UW in step s - 1.
     auto step_top = [&](int s, int extra) {
-        vm_wait(extra);
+        if (!(VLPET_C6Y_ABL & 1)) vm_wait(extra);
         __builtin_amdgcn_s_barrier();
         if (s + 1 < nsteps) issue(s + 1);
         const int valid = (int)(r_end - (r_begin + 32 * (int64_t)s));
@@ -239,6 +244,7 @@ __global__ __launch_bounds__(512, 2) void k1_cols6y_kernel(ColzArgs a) {
                     lane_row(a.dy, s + 1, ndy[0], ndy[1]);
                     if constexpr (!ADD) lane_row(a.y, s + 1, ny[0], ny[1]);
                 }
+                if (VLPET_C6Y_ABL & 2) continue;
                 f32x16 aG;
                 project(zslot(s), I1{}, std::integral_constant<int, 256>{}, wG, aG);
                 const float live = m < valid ? 1.f : 0.f, gsr = live * a.gs;
@@ -304,7 +310,8 @@ __global__ __launch_bounds__(512, 2) void k1_cols6y_kernel(ColzArgs a) {
 #pragma unroll 1
             for (int s = 0; s < nsteps; ++s) {
                 step_top(s, (s >= 2 ? 4 : 0) + (HAS_IN && s >= 1 ? 2 : 0));  // (younger than stage s: the four output stores of step s - 2, the two dx1_in loads of step s - 1)
-                if (s > 0) finish(s - 1);                                 // (uses p2 / p1 / din of step s - 1)
+                if (VLPET_C6Y_ABL & 2) continue;
+                if (s > 0 && !(VLPET_C6Y_ABL & 4)) finish(s - 1);         // (uses p2 / p1 / din of step s - 1)
                 if constexpr (HAS_IN) lane_row(a.dxin, s, dinA, dinB);  // this step's incoming rows: used by finish(s) in step s + 1 (one buffer: finish(s - 1) is done)
                 p2 = zero16(); p1 = zero16();
                 project(dslot(s), I0{}, std::integral_constant<int, -1>{}, wA, p2);
@@ -360,6 +367,7 @@ __global__ __launch_bounds__(512, 2) void k1_cols6y_kernel(ColzArgs a) {
 #pragma unroll 1
             for (int s = 0; s < nsteps; ++s) {
                 step_top(s, 0);
+                if (VLPET_C6Y_ABL & 2) continue;
                 if (s > 0) late(s - 1);
                 if (want_csp) {                                           // column sums of dpre_a, dpre_g of THIS stage: one wave per row chunk
                     const uint32_t sb = dslot(s);
@@ -404,6 +412,7 @@ __global__ __launch_bounds__(512, 2) void k1_cols6y_kernel(ColzArgs a) {
             for (int s = 0; s < nsteps; ++s) {
                 const uint32_t xs = xslot(s);
                 step_top(s, 0);
+                if (VLPET_C6Y_ABL & 2) continue;
                 wg_products(dslot(s), I0{}, NOSLOT{}, xs + a_xtr[0], xs + a_xtr[1], accA, accA[0]);
                 wg_products(dslot(s), I1{}, NOSLOT{}, xs + 4096 + a_xtr[0], xs + 4096 + a_xtr[1], accG, accG[0]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -421,11 +430,11 @@ bool k1_cols6y_applies(const ColzArgs& c) {
 template <bool ADD, bool HAS_IN>
 static hipError_t launch_cols6y_cfg(const ColzArgs& c, hipStream_t stream) {
     const size_t lds = Colz6yGeo<6>::lds();
+    const int cbh = c.d / 128;
+    const unsigned grid = cols_grid(cbh, 2 * c.row_chunks);
     auto kern = k1_cols6y_kernel<6, ADD, HAS_IN>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const int cbh = c.d / 128;
-    const unsigned grid = cols_grid(cbh, 2 * c.row_chunks);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, c);
     return hipGetLastError();
 }
