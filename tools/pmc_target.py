@@ -29,9 +29,11 @@ if op.startswith("k1"):
     G = [t.clone() for t in G]
     fwd = lambda: lib.vlpet_adapter_gate_fwd_save(x1.data_ptr(), x2.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(), out.data_ptr(), sv.data_ptr(),
                                                   M, d, tiles, 1, 1.0, 1.0, 1.0, io, st)
-    bwd = lambda: lib.vlpet_adapter_gate_bwd_saved(3, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), sv.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(),
-                                                   dx1.data_ptr(), dx2.data_ptr(), *[t.data_ptr() for t in G], r, r, ws.data_ptr(), nws, M, d, tiles, 1,
-                                                   1.0, 1.0, 1.0, io, st)
+    # (from the forward's output y: the form the package runs since round 5; PMC_FROM_X2=1: the rounds 2-4 call)
+    yp = None if os.environ.get("PMC_FROM_X2") else out.data_ptr()
+    bwd = lambda: lib.vlpet_adapter_gate_bwd_saved_y(3, dy.data_ptr(), x1.data_ptr(), x2.data_ptr(), yp, sv.data_ptr(), pa.buf.data_ptr(), pg.buf.data_ptr(),
+                                                     None, dx1.data_ptr(), dx2.data_ptr(), *[t.data_ptr() for t in G], r, r, ws.data_ptr(), nws, M, d, tiles, 1,
+                                                     1.0, 1.0, 1.0, io, st)
 elif op.startswith("k2"):
     wd, bd, wu, bu = mk(r, d), mk(r), mk(d, r), mk(d)
     pk = F.pack_pair([wd], [bd], wu, bu, io, tiles)

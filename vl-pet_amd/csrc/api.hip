@@ -338,6 +338,9 @@ static BwdWs bwd_ws(int64_t M, int d, int tiles, bool gate, int io_dtype) {
     }
     w.partial = o;
     o += align256(wgrad_workspace_bytes(njobs, tiles, d, chunks));
+    // the streaming K3 backward at r <= 8 (lora8.hip) keeps one [dA | dB] partial per workgroup at the start of the workspace instead
+    if (!gate && tiles == 1 && io_dtype != VLPET_F32 && d % 256 == 0 && d <= 768 && o < align256(lora8_bwd_part_bytes(M, d, 8)))
+        o = align256(lora8_bwd_part_bytes(M, d, 8));
     w.total = o;
     return w;
 }
@@ -649,6 +652,20 @@ extern "C" int vlpet_lora_delta_bwd_saved(const void* dy, const void* x, const v
     if (!saved) return VLPET_E_NULL;
     DropSpec ds;
     if (int rc = make_drop(keep_mask, p, seed, nullptr, &ds)) return rc;
+    // r <= 8: the streaming row kernel (lora8.hip, round 5) -- no matrix cores; mask = the packed one the forward left behind z
+    if (tiles == 1 && vlpet_tuning().lora8_bwd != 0 && lora8_bwd_applies(M, d, r, io_dtype == VLPET_F32, ds)) {
+        if (int rc = check_common(M, d, tiles, io_dtype)) return rc;
+        if (!dy || !x || !packed || !dx || !da || !db || !workspace) return VLPET_E_NULL;
+        if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(saved) || !aligned16(packed) || !aligned16(workspace)) return VLPET_E_ALIGN;
+        if (r <= 0) return VLPET_E_RANK;
+        if (workspace_bytes < lora8_bwd_part_bytes(M, d, r)) return VLPET_E_WORKSPACE;
+        if (drop_active(ds)) {
+            ds.bits = reinterpret_cast<const uint8_t*>(saved) + saved_stride(M, tiles, io_dtype);
+            ds.keep = nullptr;
+        }
+        return herr(launch_lora8_bwd(dy, x, saved, reinterpret_cast<const uint8_t*>(packed), ds, dx, da, db, reinterpret_cast<float*>(workspace),
+                                     M, d, r, scaling, (hipStream_t)stream));
+    }
     return run_bwd(dy, x, nullptr, nullptr, packed, nullptr, ds, dx, nullptr,
                    da, nullptr, db, nullptr, nullptr, nullptr, nullptr, nullptr, r, 0,
                    workspace, workspace_bytes, M, d, tiles, 1.f, scaling, 1.f, PET_ACT_IDENTITY,

@@ -22,6 +22,7 @@ struct VlpetTuning {
     int dz2 = 1;            // VLPET_DZ2=0: chain-split pass 1 of the K1 backward (pet_gate_dz_kernel) instead of the feature-split one
     int dz2_fsplit = 0;     // VLPET_DZ2_FSPLIT=1|2|4: feature blocks of pass 1 (0: by shape)
     int dz6 = 1;            // VLPET_DZ6=0: pet_gate_dz_kernel instead of the four-wave feature-split pass 1 at six tiles; 2: that pass at every size
+    int lora8_bwd = 1;      // VLPET_LORA8_BWD=0: K3 backward at r <= 8 on the two-pass MFMA form instead of the streaming row kernel (lora8.hip)
     int dz6c = 0;           // VLPET_DZ6C=1: pass 1 at six tiles from y / additive gate on the chain-split eight-wave kernel (two waves per SIMD; measured
                             //   SLOWER than the four-wave one: 65 vs 58 us at 18,250 rows, profiles/r05_k1bench_dz6c_ab.txt)
     int cols6y = 1;         // VLPET_COLS6Y=0: pass 2 at six tiles on pet_cols6.hip even when the forward's output is at hand (pet_cols6y.hip otherwise)
@@ -40,7 +41,7 @@ inline const VlpetTuning& vlpet_tuning() {
         rd("VLPET_RG", v.rg); rd("VLPET_BWD2", v.bwd2); rd("VLPET_BWD3", v.bwd3); rd("VLPET_BWD3_UNITS", v.bwd3_units);
         rd("VLPET_BWD3_FORM", v.bwd3_form); rd("VLPET_K4_WAVES4", v.k4_waves4); rd("VLPET_WGRAD_WGS", v.wgrad_wgs);
         rd("VLPET_WGRAD_TR", v.wgrad_tr); rd("VLPET_WGRAD_STREAM", v.wgrad_stream); rd("VLPET_WGRAD_NSTG", v.wgrad_nstg);
-        rd("VLPET_WGS_MODE", v.wgs_mode); rd("VLPET_ATTN_OCC", v.attn_occ); rd("VLPET_ATTN_NW", v.attn_nw); rd("VLPET_DBG", v.dbg); rd("VLPET_DZ2", v.dz2); rd("VLPET_DZ6", v.dz6); rd("VLPET_COLS6Y", v.cols6y); rd("VLPET_DZ6C", v.dz6c); rd("VLPET_DZ2_FSPLIT", v.dz2_fsplit); rd("VLPET_K4_WGRAD2", v.k4_wgrad2); rd("VLPET_NG2", v.ng2); rd("VLPET_FWD2P", v.fwd2p);
+        rd("VLPET_WGS_MODE", v.wgs_mode); rd("VLPET_ATTN_OCC", v.attn_occ); rd("VLPET_ATTN_NW", v.attn_nw); rd("VLPET_DBG", v.dbg); rd("VLPET_DZ2", v.dz2); rd("VLPET_DZ6", v.dz6); rd("VLPET_COLS6Y", v.cols6y); rd("VLPET_DZ6C", v.dz6c); rd("VLPET_LORA8_BWD", v.lora8_bwd); rd("VLPET_DZ2_FSPLIT", v.dz2_fsplit); rd("VLPET_K4_WGRAD2", v.k4_wgrad2); rd("VLPET_NG2", v.ng2); rd("VLPET_FWD2P", v.fwd2p);
         return v;
     }();
     return t;
