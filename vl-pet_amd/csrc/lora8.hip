@@ -198,6 +198,13 @@ __global__ __launch_bounds__(L8_WAVES * 64) void lora8_fwd_kernel(Lora8Args a) {
 // At the end the four waves of a role add their slices through LDS and the workgroup writes ONE partial [dA | dB] in the final layouts;
 // launch_tail_reduce sums the workgroups' partials (deterministic).  Grid = one workgroup per CU (fewer for short inputs): 256 x 48 KiB
 // of partials at r = 8, whatever the rows.  d <= 768 (at d = 1024 role RB needs 64 + 64 + 128 registers: the MFMA path keeps it).
+// MEASURED (profiles/r05_k3_streaming_bwd_ab.txt): parity-green and slower than the two-pass MFMA form it was meant to replace -- 54.3 vs 47.8 us
+// at 28,000 rows, 26.5 vs 19.3 at 2,500, the LoRA r = 8 step 19.14 vs 18.89 ms.  ~20 us do not depend on the rows (decoding the weight slices
+// from the packs, the LDS sums, 12.6 MB of partials through a reduce launch), and the row loop itself -- ~300 VALU instructions per row in
+// role RB, a third of them the 96 accumulator FMAs -- streams at 3.3 TB/s, no better than pass 1 + pass 2 of the matrix-core form, whose
+// padded 32-wide tile costs MFMA cycles that were idle anyway.  Unlike the forward, the backward is not a contraction of eight per
+// element: its weight gradients are two rank-8 OUTER products per row, and outer products are what the matrix cores are for.  Off by
+// default (csrc/tuning.h lora8_bwd); kept with its test for the measurement.
 struct Lora8BwdArgs {
     const void* dy; const void* x; const void* z;   // [M, d] bf16, [M, d] bf16, [M, 32] bf16 (the forward's saved sums)
     const uint8_t* pk;

@@ -22,7 +22,8 @@ struct VlpetTuning {
     int dz2 = 1;            // VLPET_DZ2=0: chain-split pass 1 of the K1 backward (pet_gate_dz_kernel) instead of the feature-split one
     int dz2_fsplit = 0;     // VLPET_DZ2_FSPLIT=1|2|4: feature blocks of pass 1 (0: by shape)
     int dz6 = 1;            // VLPET_DZ6=0: pet_gate_dz_kernel instead of the four-wave feature-split pass 1 at six tiles; 2: that pass at every size
-    int lora8_bwd = 1;      // VLPET_LORA8_BWD=0: K3 backward at r <= 8 on the two-pass MFMA form instead of the streaming row kernel (lora8.hip)
+    int lora8_bwd = 0;      // VLPET_LORA8_BWD=1: K3 backward at r <= 8 on the streaming row kernel (lora8.hip) instead of the two-pass MFMA form -- built in
+                            //   round 5, parity-green, and SLOWER (54 vs 48 us at 28,000 rows, 26 vs 19 at 2,500; profiles/r05_k3_streaming_bwd_ab.txt)
     int dz6c = 0;           // VLPET_DZ6C=1: pass 1 at six tiles from y / additive gate on the chain-split eight-wave kernel (two waves per SIMD; measured
                             //   SLOWER than the four-wave one: 65 vs 58 us at 18,250 rows, profiles/r05_k1bench_dz6c_ab.txt)
     int cols6y = 1;         // VLPET_COLS6Y=0: pass 2 at six tiles on pet_cols6.hip even when the forward's output is at hand (pet_cols6y.hip otherwise)
