@@ -289,6 +289,9 @@ def main():
                          "strong scaling, --emulate-ranks > 1) and for --model t5 / lora / video, where the eager step is bound by its "
                          "host-side launches; off for the headline workload (configs[1] at the full single-GPU batch: GPU-bound "
                          "either way, 19.24 vs 19.21 ms) so that its roofline op stays bracketed inside the timed region")
+    ap.add_argument("--capture-collectives", action="store_true",
+                    help="graph mode, --gpus > 1: launch the bucket all-reduces from inside the captured backward (RCCL collectives as graph nodes: "
+                         "overlap kept under replay) instead of after the replay.  Tested with a one-rank RCCL communicator only.")
     ap.add_argument("--model", default="bart", choices=["bart", "t5", "lora", "video"])
     ap.add_argument("--lora-r", type=int, default=64, help="LoRA rank for --model lora (BASELINE configs[3]: 8 / 64; script: 128)")
     args = ap.parse_args()
@@ -357,7 +360,7 @@ def main():
         args.batch = {"bart": 500, "lora": 500, "t5": 300, "video": 50}[args.model]
     total_steps = max(args.steps + args.warmup, 10) + 8
     tr = TR.Trainer(model, cfg, lr=1e-3, clip=5.0, total_steps=total_steps, world_size=n_ranks, n_buckets=args.buckets,
-                    overlap_wgrad=args.overlap_wgrad)
+                    overlap_wgrad=args.overlap_wgrad, capture_collectives=args.capture_collectives)
     # auto: replayed graphs wherever the eager step is bound by its host-side launches -- the strong-scaled per-rank batches, and the
     # T5 / LoRA / video configs even at the full batch (T5: 29.3 ms of kernels in a 37.4 ms eager step; LoRA: 21.5 in 27.1); the
     # headline workload (configs[1] at one GPU, GPU-bound: 18.85 vs 19.1 ms) stays eager so that its roofline op is bracketed inside

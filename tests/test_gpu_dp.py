@@ -94,7 +94,7 @@ def test_two_gpu_ranks_equal_one_rank(tmp_path, graph):
     assert worst <= 2e-2, worst        # same bound as the GPU-vs-CPU trainer test (Adam amplifies rounding in the first steps)
 
 
-def _rccl_worker(rank, world, port, out, graph=False):
+def _rccl_worker(rank, world, port, out, graph=False, captured=False):
     import vlpet_amd.train as TR
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
@@ -102,23 +102,28 @@ def _rccl_worker(rank, world, port, out, graph=False):
     cfg, model = _cfg_model()
     model.cuda()
     tr = TR.Trainer(model, cfg, lr=1e-2, total_steps=10, warmup_ratio=0.1, world_size=1, n_buckets=3, force_collectives=True,
-                    graph=graph)
+                    graph=graph, capture_collectives=captured)
+    assert tr.capture_collectives == captured
     for b in _batches(cfg, 8, GRAPH_ORDER if graph else ("nlvr", "caption", "nlvr")):
         tr.step(_shard(b, 0, 1))
     torch.cuda.synchronize()
+    if captured:        # the bucket all-reduces were launched from inside the captured backward and the captures succeeded (no eager fall-back)
+        assert tr.graph and len(tr._graphs) == 2, (tr.graph, len(tr._graphs))
     torch.save({n: p.detach().cpu() for n, p in model.named_parameters() if p.requires_grad}, out)
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
-def test_rccl_collectives_on_one_rank(tmp_path, graph):
+@pytest.mark.parametrize("graph,captured", [(False, False), (True, False), (True, True)], ids=["eager", "graph", "graph-captured-collectives"])
+def test_rccl_collectives_on_one_rank(tmp_path, graph, captured):
     """backend "nccl" (= RCCL): the bucketed asynchronous all-reduces, the side-stream join and the fused optimizer on
-    the real collective library, with a 1-rank communicator (the test box has one GPU).  Result == the plain run."""
+    the real collective library, with a 1-rank communicator (the test box has one GPU).  Result == the plain run.
+    graph-captured-collectives: Trainer(capture_collectives=True) -- the all-reduces leave from inside the captured backward and are
+    replayed as graph nodes on the library's stream (the overlap of the eager path, kept under replay)."""
     import vlpet_amd.train as TR
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "rccl.pt")
-    mp.spawn(_rccl_worker, args=(1, port, out, graph), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(1, port, out, graph, captured), nprocs=1, join=True)
     got = torch.load(out)
     cfg, model = _cfg_model()
     model.cuda()

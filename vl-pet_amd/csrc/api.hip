@@ -8,7 +8,7 @@
 #include <stdio.h>
 #include <vector>
 
-#define VLPET_VERSION 420      // 420: vlpet_lora_delta_fwd_r8 (K3 at rank <= 8 as a streaming kernel, lora8.hip); 410: vlpet_set_seed_counter (dropout seeds under graph replay), two-pass K2 / K3 forward; 400: two-pass K1 forward (pet_fwd2p.hip), vlpet_sublayer_tail_bwd_out;
+#define VLPET_VERSION 500      // 500 (round 5): vlpet_visproj_fwd_gemm (K4 as a tiled GEMM + exchanged statistics), vlpet_sublayer_tail_rms_fwd / vlpet_rmsnorm_tail_bwd, vlpet_adapter_gate_bwd_saved_y (backward from the forward's output), vlpet_finalize_defer / _flush; 420: vlpet_lora_delta_fwd_r8 (K3 at rank <= 8 as a streaming kernel, lora8.hip); 410: vlpet_set_seed_counter (dropout seeds under graph replay), two-pass K2 / K3 forward; 400: two-pass K1 forward (pet_fwd2p.hip), vlpet_sublayer_tail_bwd_out;
 #define VLPET_VERSION_R3 300      // 300: column-parallel K1 backward pass (pet_cols.hip), phases bits 3 / 4, vlpet_adapter_gate_bwd_form;
 #define VLPET_VERSION_R2 221      // 221: vlpet_sublayer_tail_reduce, vlpet_layernorm_bwd_xhat, vlpet_rmsnorm_{fwd,bwd}, vlpet_colsum;  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
 
@@ -181,9 +181,9 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
         static unsigned long long* dev = nullptr;
         static int nblk = 0;
         if (dev) {
-            hipDeviceSynchronize();
+            (void)hipDeviceSynchronize();
             std::vector<unsigned long long> h((size_t)nblk * 8);
-            hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost);
             double acc[8] = {0}; int n = 0;
             for (int b = 0; b < nblk; b += 7) {
                 const unsigned long long* t = &h[(size_t)b * 8];
@@ -194,7 +194,7 @@ static int run_fwd(const void* xa, const void* res, const void* xg, const void* 
             fprintf(stderr, "[vlpet ts] cycles: prologue=%.0f down=%.0f act=%.0f up=%.0f | down-stage 5: issue+reads+mfma=%.0f wait+barrier=%.0f (n=%d)\n",
                     acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, n);
         } else {
-            hipMalloc(&dev, 4096 * 8 * 8);
+            (void)hipMalloc(&dev, 4096 * 8 * 8);
         }
         nblk = (int)((M + 127) / 128); if (nblk > 4096) nblk = 4096;
         a.dbg_ts = dev;

@@ -556,7 +556,8 @@ class Trainer:
     Not captured: per-task adapters / LoRA (the active parameter set is host state) -- such trainers stay eager."""
 
     def __init__(self, model: nn.Module, config, lr=1e-3, clip=5.0, total_steps=1000, warmup_ratio=0.1,
-                 world_size=1, n_buckets=3, process_group=None, overlap_wgrad=False, force_collectives=False, graph=False):
+                 world_size=1, n_buckets=3, process_group=None, overlap_wgrad=False, force_collectives=False, graph=False,
+                 capture_collectives=False):
         self.model, self.config, self.clip, self.base_lr = model, config, clip, lr
         on_gpu = next(model.parameters()).is_cuda
         if on_gpu:
@@ -577,6 +578,18 @@ class Trainer:
         self._graphs, self._graph_seen, self._graph_pool = collections.OrderedDict(), {}, None
         self.max_graphs = MAX_GRAPHS
         self.seed_ctr = None
+        # graph mode under data parallelism: False = the three buckets are exchanged by finish() after the replay (serial: ~5 % of a 5.6 ms
+        # per-rank step); True = the bucket all-reduces are launched from INSIDE the captured backward, in readiness order, and become
+        # nodes of the graph on the collective library's stream (fork at the bucket's last gradient, join before the optimizer) -- the
+        # overlap north_star asks for, kept under replay.  Needs a backend whose collectives can be stream-captured (RCCL / "nccl").
+        # Tested with a ONE-rank RCCL communicator (tests/test_gpu_dp.py); no multi-GPU box was available to this build, so it is opt-in.
+        self.capture_collectives = False
+        if capture_collectives and self.flat.dp:
+            try:
+                self.capture_collectives = dist.get_backend(self.flat.group) == "nccl"
+            except Exception:
+                self.capture_collectives = False
+        self._exchange_in_graph = False
         if graph:
             self.enable_graph()
 
@@ -656,8 +669,9 @@ class Trainer:
             loss.backward()
         return loss
 
-    def _finish_step(self):
-        self.flat.finish(average=False)
+    def _finish_step(self, exchanged: bool = False):
+        if not exchanged:                                 # (exchanged: the replayed graph contained the bucket all-reduces and their joins)
+            self.flat.finish(average=False)
         self.optim.step(lr_at(self.step_idx, self.base_lr, self.warmup, self.total))   # clips, updates, zeroes the grads
         self.step_idx += 1
         self.flat.begin_step(zero=False)
@@ -699,7 +713,7 @@ class Trainer:
             else:
                 static[k] = v
         timer, VF.TIMER = VF.TIMER, None            # (event brackets are host-timed launches: not inside a capture)
-        self.flat.defer = True
+        self.flat.defer = not self.capture_collectives
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         try:
@@ -707,6 +721,8 @@ class Trainer:
             with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
                 loss = self._fwd_bwd(static).detach()     # (detached: keeping the graph's root would keep its AccumulateGrad nodes, and
                                                           #  their capture stream, alive into later eager steps)
+                if self.capture_collectives:              # the buckets left from inside the backward; their joins belong to the graph too
+                    self.flat.finish(average=False)
         except Exception as e:      # a model whose step cannot be captured (host sync, data-dependent shape): stay eager, loudly
             import warnings
             warnings.warn(f"vl-pet_amd: capturing the train step failed ({type(e).__name__}: {e}); this trainer continues with eager launches")
@@ -745,7 +761,7 @@ class Trainer:
             if src.data_ptr() != dst.data_ptr():
                 dst.copy_(src, non_blocking=True)
         g.replay()
-        self._finish_step()
+        self._finish_step(exchanged=self.capture_collectives)
         return loss.detach().clone()
 
     def _eager_step_in_graph_mode(self, batch) -> torch.Tensor:
@@ -753,7 +769,7 @@ class Trainer:
         parallelism its gradient buckets are exchanged by finish() in index order, exactly as after a replay: ranks decide eager vs
         replay from their OWN batch shapes, and a rank launching its buckets from inside the backward (readiness order, e.g. 1, 0, 2)
         next to one replaying (0, 1, 2) would issue mismatched collectives."""
-        self.flat.defer = True
+        self.flat.defer = not self.capture_collectives      # (captured collectives run in readiness order: so does this step)
         try:
             loss = self._fwd_bwd(batch)
         finally:
