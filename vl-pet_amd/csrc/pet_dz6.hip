@@ -675,6 +675,9 @@ __global__ __launch_bounds__(512, 2) void k1_dz6c_kernel(PetBwdArgs a) {
 
 int k1_dz6_feature_blocks(int64_t M, int d) {
     if (const int f = vlpet_tuning().dz2_fsplit; f >= 1) return ((d >> 6) % f == 0) ? f : 1;
+    // six blocks while the grid still fits one round of the chip (26.1 / 29.1 / 31.1 us at 1,100 / 2,128 / 3,500 rows against 27.5 / 30.8 / 32.9 with
+    // four; 47 row blocks x 6 at 6,000 rows is two rounds: 52 us -- profiles/r05_k1bench_fsplit_small_m.txt), four up to 8,192 rows
+    if (M <= 8192 && (d >> 6) % 6 == 0 && ((M + 127) / 128) * 6 <= 256) return 6;
     return (M <= 8192 && (d >> 6) % 4 == 0) ? 4 : 1;
 }
 
