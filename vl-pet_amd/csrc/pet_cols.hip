@@ -302,6 +302,9 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
             COLS_STAMP(4)
             step_top(s, 0);
             COLS_STAMP(0)
+#if defined(VLPET_COLS_ABL) && (VLPET_COLS_ABL & 8)
+            continue;                                                     // (timing ablation: the LDS-DMA stream + barriers alone)
+#endif
             // up projection of one chain, starting at its bias: the bias values and the first batch of B fragments are one LDS batch
             auto project_up = [&](auto TC, auto OC, const bf16x8* w, f32x16& acc) {
                 constexpr int T = decltype(TC)::value;
@@ -481,6 +484,9 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
             COLS_STAMP(4)
             step_top(s, s >= 2 ? 4 : 0);
             COLS_STAMP(0)
+#if defined(VLPET_COLS_ABL) && (VLPET_COLS_ABL & 8)
+            continue;
+#endif
 #if !(defined(VLPET_COLS_ABL) && (VLPET_COLS_ABL & 2))
             if (s > 0) finish(s - 1, dinA, dinB);
 #endif
