@@ -500,7 +500,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
         for (int j = 0; j < 4; ++j) c.part[j] = g.partial + L.off[j];
         if (phases & 2) {
             hipError_t e = cols6 ? (k1_cols6y_applies(c) ? launch_k1_cols6y(c, (hipStream_t)stream) : launch_k1_cols6(c, (hipStream_t)stream))
-                                 : launch_k1_cols(c, tiles, (hipStream_t)stream);
+                                 : (k1_colsy_applies(c, tiles) ? launch_k1_colsy(c, tiles, (hipStream_t)stream) : launch_k1_cols(c, tiles, (hipStream_t)stream));
             if (e != hipSuccess) return (int)e;
         }
         if ((phases & 8) && !(phases & 16)) return 0;       // (the partial sums stay in the workspace)

@@ -194,6 +194,8 @@ void k1_cols6_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk);
 bool k1_cols6_applies(const PetBwdArgs& a, int io_fp32);
 hipError_t launch_k1_cols6(const ColzArgs& c, hipStream_t stream);
 // ... with the up-side weight gradients one step late and the elementwise block from the forward's output (pet_cols6y.hip)
+bool k1_colsy_applies(const ColzArgs& c, int RT);                        // ... the same for r <= 96 (pet_colsy.hip)
+hipError_t launch_k1_colsy(const ColzArgs& c, int RT, hipStream_t stream);
 bool k1_cols6y_applies(const ColzArgs& c);
 hipError_t launch_k1_cols6y(const ColzArgs& c, hipStream_t stream);
 
