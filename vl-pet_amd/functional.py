@@ -99,6 +99,41 @@ class _deferred_finalize:
         return False
 
 
+# Under graph capture the finalize launch of a gated K1 backward (12 / 24 per step; ~10 us of a few dozen workgroups each) is issued on a
+# side stream: a parallel branch of the captured graph, joined by flush_reduces() at the end of the backward.  Nobody reads a weight
+# gradient before that, and the partial sums it reads are still warm (unlike the deferred + batched form above, which read them cold).
+# Eager steps keep it in line: two stream switches per op cost the host more than the launch hides.
+# MEASURED (profiles/r05_finalize_side_stream_ab.txt): the replayed step gets SLOWER -- 6.02 vs 5.37 ms (BART, emulated rank 1 of 8), 10.45 vs 9.17 ms
+# (T5), 24.9 vs 24.0 ms at T5's full batch: a fork + join inside a hipGraph costs ~50 us here (12 / 24 of them per step), five times the
+# launch it hides.  Off.
+FINALIZE_SIDE_STREAM = False
+_FIN_STREAM = None
+_FIN_PENDING = False
+_FIN_KEEP: list = []
+
+
+def _finalize_on_side(fn, *keep):
+    """``fn(stream_handle)`` = the finalize-only call of a backward op, issued on the side stream after everything queued on the current one."""
+    global _FIN_STREAM, _FIN_PENDING
+    cur = torch.cuda.current_stream()
+    if _FIN_STREAM is None:
+        _FIN_STREAM = torch.cuda.Stream()
+    _FIN_STREAM.wait_stream(cur)
+    with torch.cuda.stream(_FIN_STREAM):
+        rc = fn(_FIN_STREAM.cuda_stream)
+    _FIN_PENDING = True
+    _FIN_KEEP.extend(keep)            # (the partial sums live in the op's workspace: not to be recycled before the join)
+    return rc
+
+
+def join_finalize_stream():
+    global _FIN_PENDING
+    if _FIN_PENDING:
+        torch.cuda.current_stream().wait_stream(_FIN_STREAM)
+        _FIN_PENDING = False
+    _FIN_KEEP.clear()
+
+
 def discard_pending():
     """Error path of a trainer's backward: nothing queued survives the step."""
     _PENDING_REDUCES.clear()
@@ -120,6 +155,7 @@ def reduce_partials(part: torch.Tensor, nb: int, d: int, out0: Optional[torch.Te
 
 def flush_reduces():
     lib = _lib.load()
+    join_finalize_stream()
     if lib.vlpet_finalize_pending():
         rc = lib.vlpet_finalize_flush(_stream())
         _PENDING_FINALIZE_KEEP.clear()
@@ -654,6 +690,11 @@ class _AdapterGateFn(torch.autograd.Function):
             rc = _timed("k1_bwd_rows", M, lambda: phase(1 | 4, args))
             if rc == 0:
                 rc = _timed("k1_bwd_wgrad", M, lambda: phase(2 | 4, args))
+        elif (FINALIZE_SIDE_STREAM and gate and act is not None and TIMER is None and all(s is not None for s in sinks)
+              and torch.cuda.is_current_stream_capturing() and lib.vlpet_adapter_gate_bwd_form(M, d, pk_a.tiles, io) == 2):
+            rc = phase(3 | 8, args)                    # pass 1 + pass 2; the finalize launch as a parallel branch of the captured graph
+            if rc == 0:
+                rc = _finalize_on_side(lambda st: phase(16, args[:-1] + (st,)), ws)
         elif TIMER is None or not TIMER.wants("k1_bwd_rows"):
             with _deferred_finalize(all(s is not None for s in sinks), ws):
                 rc = phase(3, args)

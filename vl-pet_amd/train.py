@@ -665,6 +665,7 @@ class Trainer:
             finally:
                 VF.DEFER_REDUCES = False
                 VF.discard_pending()              # (empty after a clean flush)
+                VF._FIN_KEEP.clear()
         else:
             loss.backward()
         return loss
