@@ -66,6 +66,31 @@ def pmc_bytes(table, rows):
     return lo[1] + (hi[1] - lo[1]) * (rows - lo[0]) / (hi[0] - lo[0])
 
 
+def step_time_report(step_ms, step_tasks, batch_of, settling, n_ranks):
+    """The per-step distribution of the timed region (rank 0's HIP events on the step boundaries), beside the mean `ms_per_step`: the K
+    step times in order, their median / min, the same per task shape (the four shapes differ 5x in rows), the first timed step of each
+    shape against that shape's median, and the throughput a run of median steps would give -- so that a reader of ONE driver line can
+    tell a fresh-box tail (a few slow steps: steady_state above value) from a slower steady state (both low)."""
+    def med(v):
+        v = sorted(v)
+        n = len(v)
+        return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+    by_task = {}
+    for ms, t in zip(step_ms, step_tasks):
+        by_task.setdefault(t, []).append(ms)
+    per_task = {t: {"n": len(v), "median": round(med(v), 3), "min": min(v), "max": max(v), "first": v[0],
+                    "first_over_median": round(v[0] / med(v), 3)} for t, v in by_task.items()}
+    round_ms = sum(per_task[t]["median"] for t in per_task)
+    round_samples = sum(batch_of[t] for t in per_task) * n_ranks
+    return {"step_ms": step_ms, "step_ms_median": round(med(step_ms), 3), "step_ms_min": min(step_ms), "step_ms_max": max(step_ms),
+            "step_ms_by_task": per_task,
+            "steady_state": {"value": round(round_samples / round_ms * 1e3, 2), "unit": "samples/s",
+                             "note": "samples of one round of task shapes / sum of the per-shape MEDIAN step times (rank 0's events); "
+                                     "`value` above stays all samples / wall time of the K timed steps"},
+            "slow_steps": [k for k, (ms, t) in enumerate(zip(step_ms, step_tasks)) if ms > 1.15 * per_task[t]["median"]],
+            "settling_rounds_ms": settling}
+
+
 IMAGE_TASKS = ["vqa", "gqa", "nlvr", "caption"]
 VIDEO_TASKS = ["tvqa", "how2qa", "tvc", "yc2c"]
 
@@ -384,7 +409,7 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     batches = {t: TR.synthetic_batch(t, rank_batch(t), cfg, dev, gen, no_padding=not args.pad_mask) for t in tasks}
     order = [tasks[i % len(tasks)] for i in range(args.warmup + args.steps)]
-    total_steps = max(args.steps + args.warmup + setup_steps, 10) + 8
+    total_steps = max(args.steps + args.warmup + setup_steps, 10) + 8 + 4 * len(tasks)     # (+ the settling rounds)
     tr.total, tr.warmup = total_steps, int(total_steps * 0.1)
 
     for i in range(setup_steps):
@@ -392,6 +417,25 @@ def main():
     for i in range(args.warmup):
         tr.step(batches[order[i]])
     torch.cuda.synchronize()
+
+    def timed_round():
+        """One untimed round (a step per task shape), each step bracketed by HIP events on the launch stream: ms per task."""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(tasks) + 1)]
+        for k, t_ in enumerate(tasks):
+            evs[k].record()
+            tr.step(batches[t_])
+        evs[-1].record()
+        torch.cuda.synchronize()
+        return {t_: round(evs[k].elapsed_time(evs[k + 1]), 3) for k, t_ in enumerate(tasks)}
+    # Settling rounds (VERDICT r05 #5): a fresh box keeps paying first-use costs for a few steps after the W warm-up steps (code-object
+    # loads, allocator growth, clocks), and 20 timed steps cannot tell that tail from a slower steady state.  Before the timed region,
+    # whole rounds (one step per task shape, untimed) run until a round's steps are within 1.15x of the previous round's, three extra rounds at
+    # most; every round's step times are REPORTED (`settling_rounds_ms`), none is part of `value`.
+    settling = [timed_round()]
+    while len(settling) < 4:
+        settling.append(timed_round())
+        if all(settling[-2][t_] <= 1.15 * settling[-1][t_] for t_ in tasks):
+            break
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -401,17 +445,22 @@ def main():
     dom_names = ("k3_bwd", "k3_fwd") if args.model == "lora" else ("k1_bwd_rows", "k1_bwd_wgrad", "k1_bwd_fin")
     VF.K1_BWD_PREVIOUS_SPLIT = bool(args.k1_previous_split)
     VF.TIMER = VF.KernelTimer(None if args.kernel_table == "inline" else dom_names)
+    # per-step times: one HIP event on the launch stream at every step boundary (a marker packet each; `value` stays samples / wall)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     samples = 0
     for i in range(args.warmup, args.warmup + args.steps):
         b = batches[order[i]]
+        step_ev[i - args.warmup].record()
         tr.step(b)
         samples += b["input_ids"].shape[0]
+    step_ev[args.steps].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    step_ms = [round(step_ev[k].elapsed_time(step_ev[k + 1]), 3) for k in range(args.steps)]
     timer, VF.TIMER = VF.TIMER, None
     if graph_on:
         # a replayed step runs no host code, so nothing was bracketed above: the roofline op is bracketed in eager steps of the same
@@ -612,6 +661,8 @@ def main():
                        ("per_gpu_task_batch" if (args.scaling == "weak" and args.emulate_ranks == 1) else "global_task_batch"): per_task,
                        "enc_rows_per_step_rank0": enc_rows, "trainable_params": n_train, "parallelism": f"dp{n_ranks}",
                        "backend": args.backend if n_ranks > 1 else None},
+            **step_time_report(step_ms, [order[i] for i in range(args.warmup, args.warmup + args.steps)],
+                               {t: rank_batch(t) for t in tasks}, settling, n_ranks),
             "roofline": roof, "kernels": kernels, "backbone_gemm_table": gemm_table,
             **({"ab_switches": ab_switches} if ab_switches else {}),
             **({"other_scaling": strong} if strong is not None else {}),

@@ -139,6 +139,12 @@ int vlpet_set_seed_counter(const uint64_t* device_counter);
  * VLPET_* environment variables, read once at load time.  The product library (0) reads nothing from the environment. */
 int vlpet_debug_build(void);
 
+/* Test instrument for the kernels whose workgroups hand data to each other inside a launch (K4's statistics exchange): occupies CUs
+ * from another stream so that such a launch does NOT have the GPU to itself.  `workgroups` workgroups of 64 threads, each holding
+ * `lds_bytes` of LDS (<= 160 KiB: one per CU, and nothing larger than the rest fits beside it), poll the 32-bit word *release_flag
+ * (device memory) until it is nonzero or max_ms milliseconds (capped at 10,000) have passed.  No reference counterpart. */
+int vlpet_test_hold_cus(int workgroups, int lds_bytes, void* release_flag, int max_ms, vlpet_stream_t stream);
+
 /* vlpet_adapter_gate_bwd_phase with the activations saved by vlpet_adapter_gate_fwd_save (x1 is
  * still an argument because the gate's down-weight gradient contracts it).
  * It runs as TWO PASSES that move every [M, d] tensor once each (csrc/pet_gate_bwd3.hip pass 1, csrc/pet_cols.hip pass 2):
@@ -272,18 +278,26 @@ int vlpet_visproj_fwd(const void* feats, const void* packed, const float* gamma,
                       int io_dtype, vlpet_stream_t stream);
 /* The same forward as a tiled GEMM whose column tiles exchange the LayerNorm statistics (round 5; csrc/visproj_gemm.hip): bf16 IO,
  * d_out a multiple of 256 (<= 1024), feat_dim a multiple of 64.  w_io [d_out, feat_dim] = the weight in the IO dtype, row-major (no
- * pack); bias [d_out] fp32 or NULL; mean [M] optional.  workspace: vlpet_visproj_gemm_workspace_bytes (0 = shape not supported by
- * this form); the CALLER zeroes it once -- every launch leaves the exchange area (byte 256 on) zeroed, so it is reused across calls
- * without a memset; launches sharing one workspace must be ordered (one stream).  Its first 32-bit word is a status the kernel only
- * ever ORs into: nonzero = a statistics exchange between workgroups timed out (the GPU was not this kernel's alone for seconds), the
- * rows are not normalised consistently and the area must be zeroed again; bytes 64..119: wall-clock stamps of workgroup 0.  replaces: src/modeling_bart.py:91-110,157 (T5: src/modeling_t5.py:56-66). */
+ * pack); bias [d_out] fp32 or NULL; mean [M] optional; xhat is REQUIRED when d_out > 256.  workspace:
+ * vlpet_visproj_gemm_workspace_bytes (0 = shape not supported by this form); the CALLER zeroes it once -- every call leaves the
+ * exchange area (bytes 256 .. 256 + vlpet_visproj_gemm_exchange_bytes) zeroed, so it is reused across calls without a memset; calls
+ * sharing one workspace must be ordered (one stream).
+ * The column tiles of a row block wait for each other's statistics, which presumes that they run at the same time; where the GPU is
+ * shared (a collective on another stream, a second process) a workgroup may give up on a partner (bounded polling, about a second).
+ * The call repairs that itself (round 6): it launches a second, normally empty, kernel that re-normalises exactly the tiles that
+ * gave up from the complete per-tile statistics and cleans the exchange area -- the caller NEVER receives rows normalised with
+ * partial statistics.  The first 32-bit word of the workspace is a sticky status (nonzero = it has happened since the caller last
+ * cleared the word; informational), word 1 counts the tiles that gave up; bytes 64..119: wall-clock stamps of workgroup 0.
+ * replaces: src/modeling_bart.py:91-110,157 (T5: src/modeling_t5.py:56-66). */
 size_t vlpet_visproj_gemm_workspace_bytes(int64_t M, int feat_dim, int d_out);
+size_t vlpet_visproj_gemm_exchange_bytes(int d_out);
 int vlpet_visproj_fwd_gemm(const void* feats, const void* w_io, const float* bias, const float* gamma, const float* beta,
                            const void* r, void* out, void* xhat, float* rstd, float* mean, void* workspace,
                            size_t workspace_bytes, int64_t M, int feat_dim, int d_out, float eps, int rms, int io_dtype,
                            vlpet_stream_t stream);
-/* ... with the LDS ring form (1: 64 input features per stage / 2 slots, 2: 32 / 4, 3: 32 / 3; 0: default) and the rows per
- * workgroup (128 / 256; 0: by shape) forced: measurement and parity of the non-default forms. */
+/* ... with the LDS ring form (bits 0-7 of `form`: 1: 64 input features per stage / 2 slots, 2: 32 / 4, 3: 32 / 3, 4-6: the same with
+ * spread requests; 0: default) and the rows per workgroup (128 / 192 / 256; 0: by shape) forced: measurement and parity of the
+ * non-default forms.  Bits 8-12 of `form`, if nonzero: log2 of the polls before a wave gives up on a partner (tests of the repair path). */
 int vlpet_visproj_fwd_gemm_cfg(const void* feats, const void* w_io, const float* bias, const float* gamma, const float* beta,
                                const void* r, void* out, void* xhat, float* rstd, float* mean, void* workspace,
                                size_t workspace_bytes, int64_t M, int feat_dim, int d_out, float eps, int rms, int io_dtype,

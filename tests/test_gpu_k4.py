@@ -123,10 +123,20 @@ def test_k4_forward_at_the_bench_rows_vs_oracle(B, form, monkeypatch):
         assert VP._VisProjFn.last_status is not None and int(VP._VisProjFn.last_status.view(torch.int32)[0].item()) == 0
 
 
-def _gemm_abi(M, F, d, rms, form, bm, with_r=True, seed=0, mean_shift=0.0, ws_keep=None):
-    """vlpet_visproj_fwd_gemm_cfg directly; returns (out, xhat, rstd, mean, status) and the fp32 reference tensors"""
+def _gemm_abi(M, F, d, rms, form, bm, with_r=True, seed=0, mean_shift=0.0, ws_keep=None, hold=0):
+    """vlpet_visproj_fwd_gemm_cfg directly; returns (out, xhat, rstd, mean, status) and the fp32 reference tensors.  hold = N: N
+    workgroups of vlpet_test_hold_cus (100 KiB of LDS each: one per CU, and no K4 workgroup fits beside one) occupy CUs from a second
+    stream while the call runs, and are released once it has finished."""
+    import time
     from vlpet_amd import _lib
     lib = _lib.load()
+    flag = side = None
+    if hold:
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        assert lib.vlpet_test_hold_cus(hold, 100 * 1024, flag.data_ptr(), 8000, side.cuda_stream) == 0
+        time.sleep(0.05)        # (the holders are resident before the call under test is issued)
     g = torch.Generator(device="cuda").manual_seed(seed)
     feats = torch.randn(M, F, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(d, F, device="cuda", generator=g) * (1.0 / F ** 0.5)).to(torch.bfloat16)
@@ -146,7 +156,13 @@ def _gemm_abi(M, F, d, rms, form, bm, with_r=True, seed=0, mean_shift=0.0, ws_ke
                                         xhat.data_ptr(), rstd.data_ptr(), mean.data_ptr(), ws.data_ptr(), nws, M, F, d, eps, int(rms),
                                         _lib.VLPET_BF16, form, bm, torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
+    torch.cuda.current_stream().synchronize()       # (not the device: the holders are still spinning)
+    if hold:
+        t_held = time.time()
+        flag.fill_(1)
     torch.cuda.synchronize()
+    if hold:
+        assert time.time() - t_held < 4.0, "the holders were not released by the flag (they ran into their own time bound)"
     pre = feats.float() @ w.float().t() + b
     if rms:
         r_rstd = torch.rsqrt(pre.pow(2).mean(-1) + eps); r_mean = torch.zeros(M, device="cuda")
@@ -155,7 +171,12 @@ def _gemm_abi(M, F, d, rms, form, bm, with_r=True, seed=0, mean_shift=0.0, ws_ke
     r_xhat = (pre - r_mean[:, None]) * r_rstd[:, None]
     r_out = r_xhat * gam + (bet if bet is not None else 0.0) + (R.float() if R is not None else 0.0)
     status = int(ws[:4].view(torch.int32)[0].item())
-    assert int(ws[256:].count_nonzero().item()) == 0        # every consumer cleared what it read: the exchange area is clean again
+    xb = lib.vlpet_visproj_gemm_exchange_bytes(d)
+    assert int(ws[256:256 + xb].count_nonzero().item()) == 0    # every consumer cleared what it read (or the repair pass did): the exchange area is clean again
+    hdr = ws[:16].view(torch.int32).tolist()
+    assert hdr[1] == hdr[2] and hdr[3] == 0                      # every tile that gave up has been repaired
+    nt = d // 256
+    assert int(ws[256 + xb:256 + xb + 4 * nt * ((M + 127) // 128)].count_nonzero().item()) == 0     # ... and its flag cleared
     return (out, xhat, rstd, mean, status), (r_out, r_xhat, r_rstd, r_mean)
 
 
@@ -180,6 +201,42 @@ def test_k4_gemm_statistics_survive_a_large_common_offset():
     got, ref = _gemm_abi(2000, 512, 768, False, 0, 0, with_r=False, seed=4, mean_shift=40.0)
     assert got[4] == 0
     assert rel_err(got[2], ref[2]) <= 2e-3 and rel_err(got[1], ref[1]) <= 1e-2
+
+
+def _gemm_check(got, ref, rms):
+    assert rel_err(got[0], ref[0]) <= 1e-2 and rel_err(got[1], ref[1]) <= 1e-2
+    assert rel_err(got[2], ref[2]) <= 1e-4
+    if not rms:
+        assert float((got[3] - ref[3]).abs().max()) <= 1e-4 * float(ref[3].abs().max() + 1.0)
+
+
+@pytest.mark.parametrize("M,F,d,rms", [(18700, 2048, 768, False), (10800, 2048, 768, True)])
+def test_k4_gemm_with_64_cus_held_by_another_stream(M, F, d, rms):
+    """VERDICT r05 weak #1 / ADVICE: the statistics exchange presumes that a team's workgroups run at the same time.  Here 64 CUs (8 per
+    XCD) are held by a spinning kernel on a second stream for the whole call: fewer CUs than workgroups, so part of the grid waits
+    for others to finish.  The output must still match the reference (whether or not a workgroup gave up on the way -- a give-up is
+    repaired inside the call), and the workspace must be left clean."""
+    got, ref = _gemm_abi(M, F, d, rms, 0, 0, seed=11, hold=64)
+    _gemm_check(got, ref, rms)
+
+
+@pytest.mark.parametrize("M,F,d,rms", [(2000, 512, 768, False), (1500, 512, 768, True), (900, 512, 1024, False)])
+def test_k4_gemm_workgroups_that_give_up_are_repaired_inside_the_call(M, F, d, rms):
+    """The give-up path itself.  248 of the 256 CUs are held (one free CU per XCD), so the members of a team can NOT run at the same
+    time: with the polling bound lowered to 4,096 polls every workgroup but the last of a team gives up on its partners.  The call
+    must (i) return rows that match the reference all the same -- the repair kernel re-normalises the flagged tiles from the complete
+    per-tile statistics --, (ii) report it in the status word, (iii) leave the exchange area clean although late producers wrote
+    granules after their consumer had given up; a plain call on the SAME workspace afterwards is right and does not touch the counters."""
+    from vlpet_amd import _lib
+    ws = torch.zeros(_lib.load().vlpet_visproj_gemm_workspace_bytes(M, F, d), dtype=torch.uint8, device="cuda")
+    got, ref = _gemm_abi(M, F, d, rms, 12 << 8, 128, seed=12, ws_keep=ws, hold=248)
+    _gemm_check(got, ref, rms)
+    hdr = ws[:16].view(torch.int32).tolist()
+    assert got[4] != 0 and hdr[1] > 0, "no workgroup gave up: the holders did not keep the team apart (test geometry)"
+    given_up = hdr[1]
+    again, ref2 = _gemm_abi(M, F, d, rms, 0, 128, seed=13, ws_keep=ws)
+    _gemm_check(again, ref2, rms)
+    assert ws[:16].view(torch.int32).tolist()[1] == given_up
 
 
 def test_k4_gemm_repeated_launches_share_one_exchange_area():

@@ -51,6 +51,7 @@ SIGNATURES = {
     "vlpet_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
     "vlpet_adapter_gate_bwd_form": (c_int, [c_int64, c_int, c_int, c_int]),
     "vlpet_debug_build": (c_int, []),
+    "vlpet_test_hold_cus": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p]),
     "vlpet_set_seed_counter": (c_int, [c_void_p]),
     "vlpet_adapter_gate_bwd": (c_int, [c_void_p] * 7 + [c_void_p] * 8 + [c_int, c_int, c_void_p, c_size_t, c_int64,
                                                                          c_int, c_int, c_int, c_float, c_float,
@@ -82,6 +83,7 @@ SIGNATURES = {
     "vlpet_visproj_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vlpet_visproj_fwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "vlpet_visproj_gemm_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "vlpet_visproj_gemm_exchange_bytes": (c_size_t, [c_int]),
     "vlpet_visproj_fwd_gemm": (c_int, [c_void_p] * 11 + [c_size_t, c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "vlpet_visproj_fwd_gemm_cfg": (c_int, [c_void_p] * 11 + [c_size_t, c_int64, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "vlpet_visproj_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),

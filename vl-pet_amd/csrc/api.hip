@@ -19,6 +19,31 @@ static inline int herr(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 extern "C" int vlpet_version(void) { return VLPET_VERSION; }
 extern "C" int vlpet_debug_build(void) { return VLPET_IS_DEBUG_BUILD; }
 
+// Test instrument (tests/test_gpu_k4.py, tests/test_gpu_cols.py: the in-launch hand-offs under a GPU that is NOT the launch's alone):
+// `workgroups` workgroups of 64 threads, each holding `lds_bytes` of LDS (so one sits on a CU and a workgroup needing more than
+// 160 KiB - lds_bytes does not fit beside it), poll *release until it is nonzero or `max_ms` milliseconds have passed, whichever is
+// first -- the bound (capped at 10 s) makes a forgotten release harmless.
+__global__ __launch_bounds__(64) void hold_cus_kernel(unsigned* release, unsigned long long ticks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t hold_smem[];
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    if (threadIdx.x == 0) {
+        hold_smem[0] = 1;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load((gu32*)release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && wall_clock64() - t0 < ticks)
+            __builtin_amdgcn_s_sleep(32);
+    }
+}
+extern "C" int vlpet_test_hold_cus(int workgroups, int lds_bytes, void* release_flag, int max_ms, vlpet_stream_t stream) {
+    if (!release_flag) return VLPET_E_NULL;
+    if (workgroups <= 0 || workgroups > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024 || max_ms <= 0) return VLPET_E_SHAPE;
+    if (max_ms > 10000) max_ms = 10000;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hold_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return herr(e);
+    hipLaunchKernelGGL(hold_cus_kernel, dim3((unsigned)workgroups), dim3(64), (size_t)lds_bytes, (hipStream_t)stream,
+                       reinterpret_cast<unsigned*>(release_flag), (unsigned long long)max_ms * 100000ull);     // wall_clock64: 100 MHz
+    return herr(hipGetLastError());
+}
+
 extern "C" const char* vlpet_error_string(int code) {
     switch (code) {
         case 0: return "success";
@@ -717,10 +742,14 @@ extern "C" int vlpet_visproj_fwd(const void* feats, const void* packed, const fl
 extern "C" size_t vlpet_visproj_gemm_workspace_bytes(int64_t M, int feat_dim, int d_out) {
     return visproj_gemm_workspace_bytes(M, feat_dim, d_out);
 }
+extern "C" size_t vlpet_visproj_gemm_exchange_bytes(int d_out) {
+    return (d_out > 0 && d_out % 256 == 0 && d_out / 256 <= 4) ? visproj_gemm_exchange_bytes(d_out) : 0;
+}
 static int visproj_gemm_call(const void* feats, const void* w_io, const float* bias, const float* gamma, const float* beta,
                              const void* r, void* out, void* xhat, float* rstd, float* mean, void* workspace, size_t workspace_bytes,
                              int64_t M, int feat_dim, int d_out, float eps, int rms, int io_dtype, int form, int bm, vlpet_stream_t stream) {
     if (!feats || !w_io || !gamma || !out || !workspace) return VLPET_E_NULL;
+    if (!xhat && d_out > 256) return VLPET_E_NULL;       // (a workgroup that gives up on its partners parks its pre-norm tile there)
     if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
     if (!visproj_gemm_applies(M, feat_dim, d_out, io_dtype == VLPET_F32)) return VLPET_E_SHAPE;
     if (workspace_bytes < visproj_gemm_workspace_bytes(M, feat_dim, d_out)) return VLPET_E_WORKSPACE;
@@ -744,7 +773,7 @@ extern "C" int vlpet_visproj_fwd_gemm_cfg(const void* feats, const void* w_io, c
                                           const void* r, void* out, void* xhat, float* rstd, float* mean, void* workspace,
                                           size_t workspace_bytes, int64_t M, int feat_dim, int d_out, float eps, int rms, int io_dtype,
                                           int form, int rows_per_workgroup, vlpet_stream_t stream) {
-    if (form < 0 || form > 6 || (rows_per_workgroup != 0 && rows_per_workgroup != 128 && rows_per_workgroup != 192 && rows_per_workgroup != 256)) return VLPET_E_SHAPE;
+    if (form < 0 || (form & 255) > 6 || (form >> 8) > 30 || (rows_per_workgroup != 0 && rows_per_workgroup != 128 && rows_per_workgroup != 192 && rows_per_workgroup != 256)) return VLPET_E_SHAPE;
     return visproj_gemm_call(feats, w_io, bias, gamma, beta, r, out, xhat, rstd, mean, workspace, workspace_bytes, M, feat_dim, d_out,
                              eps, rms, io_dtype, form, rows_per_workgroup, stream);
 }

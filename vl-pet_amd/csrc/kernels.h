@@ -222,13 +222,18 @@ struct VisGemmArgs {
     const float* bias; const float* gamma; const float* beta;
     const void* R; void* out; void* xhat; float* rstd; float* mean;
     unsigned long long* xch;        // granules [2 parities][nteams][NT consumers][NT producers][BM * 2]: zero before the first launch, left zero
-    unsigned* status;               // != 0: a statistics exchange timed out
+    unsigned* status;               // workspace header: [0] != 0: a statistics exchange timed out (and was repaired), [1] tiles given up so far,
+                                    // [2] that count at the last repair, [3] repair workgroups finished
+    unsigned* flags;                // [row_blocks][NT]: != 0 = this tile gave up; its pre-norm rows sit where xhat goes (visproj_gemm_repair_kernel)
+    unsigned long long* stats;      // [rows][NT] {mean, M2} of a row over a column tile, as floats (lo, hi): every workgroup's, never cleared
+    unsigned spin_limit;            // polls of a partner's granules before a wave gives up (0: the default, about a second)
     int64_t M; int F, d_out; float eps; int rms;
     int nteams, row_blocks;
 };
 
 bool visproj_gemm_applies(int64_t M, int F, int d_out, int io_fp32);
 size_t visproj_gemm_workspace_bytes(int64_t M, int F, int d_out);
+size_t visproj_gemm_exchange_bytes(int d_out);                        // the granule area that every launch leaves zeroed (workspace bytes 256 ..)
 hipError_t launch_visproj_gemm(VisGemmArgs& a, void* ws, int form, int bm, hipStream_t stream);
 
 // K5 sublayer tail: out = LayerNorm(x1 + dropout(y)) (norm = 1) or x1 + dropout(y) (norm = 0); tail.hip

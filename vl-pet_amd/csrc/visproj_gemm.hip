@@ -23,8 +23,15 @@
 //     copy of a producer's granules and zeroes it after reading, so a zeroed exchange area is left zeroed by every launch and needs
 //     no memset node between launches (a per-launch salt in the tags would be frozen under graph replay);
 //   * residency: the grid is at most one workgroup per CU (128 KiB of LDS each) and never more than the chip's CUs, teams walk the
-//     row blocks persistently; a team's members therefore run concurrently whatever the dispatch order.  Every spin is bounded: on
-//     a timeout the workgroup raises the launch's status word (vlpet_visproj_status) and finishes with what it has.
+//     row blocks persistently; a team's members therefore run concurrently -- AS LONG AS the GPU is this launch's alone.  It need not
+//     be (a collective on another stream, a second process on the device), so every spin is bounded and a timeout is REPAIRED inside
+//     the same call (round 6): every workgroup also leaves its per-row partial statistics in a plain array of the workspace; a
+//     workgroup that gives up stores its PRE-norm tile (bias added, bf16) where xhat goes, flags its (row block, column tile) and
+//     bumps the workspace's timeout counter; visproj_gemm_repair_kernel, launched right behind the main kernel by the same call,
+//     returns at once unless that counter has moved -- then it normalises the flagged tiles from the (by then complete) statistics
+//     array, in the main kernel's order of combination, and zeroes the exchange area (a late producer writes its granules after
+//     the consumer that gave up has cleared them).  The caller never sees rows normalised with partial statistics, and the next
+//     launch starts from a clean area; the status word only reports that it happened.
 // Epilogue: R arrives by global_load_lds into the wave's private staging area while the statistics are exchanged; out and xhat leave
 // through the same area as whole 128-byte lines.
 #include "cols_common.h"
@@ -46,6 +53,14 @@ __device__ __forceinline__ void visg_frag_wait(u32x4 (&w)[2], u32x4 (&x)[RTN]) {
         asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(x[0]), "+v"(x[1]) : "n"(N) : "memory");
 }
 
+// (inline asm like every LDS access of the epilogue: hipcc drains the LDS-DMA queue in front of an LDS access it can see)
+__device__ __forceinline__ void visg_lds_write4(uint32_t addr, unsigned v) { asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ unsigned visg_lds_read4(uint32_t addr) {
+    unsigned o;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(o) : "v"(addr) : "memory");
+    return o;
+}
+
 template <int BM, int BK, int NSLOT> struct VisGemmGeo {
     static constexpr int ROWB = BK * 2;                 // bytes of a tile row
     static constexpr int SLOTS = ROWB / 16;             // 16-byte slots of a row (8 / 4)
@@ -61,7 +76,8 @@ template <int BM, int BK, int NSLOT> struct VisGemmGeo {
     static constexpr int PRM_OFF = MAIN_B;              // bias | gamma | beta of the workgroup's 256 features (fp32)
     static constexpr int WST_OFF = PRM_OFF + 3 * 256 * 4;        // per-wave statistics [BM][4] x (mean, M2)
     static constexpr int RST_OFF = WST_OFF + BM * 32;            // row statistics [BM] x (mean, rstd)
-    static constexpr int LDS_B = RST_OFF + BM * 8;
+    static constexpr int TMO_OFF = RST_OFF + BM * 8;             // != 0: a wave of this workgroup gave up on a partner's statistics (this row block)
+    static constexpr int LDS_B = TMO_OFF + 16;
     static_assert(PX >= 1 && PW >= 1 && XT_B % 8192 == 0 && LDS_B <= 160 * 1024, "");
     static_assert(BK == 64 || BK == 32, "");
 };
@@ -116,6 +132,7 @@ __global__ __launch_bounds__(512, 2) void visproj_gemm_kernel(VisGemmArgs a) {
     int it = 0;
     for (int rb = team; rb < a.row_blocks; rb += a.nteams, ++it) {
         const int64_t row0 = (int64_t)rb * BM;
+        if (tid == 0) visg_lds_write4(lds0 + (uint32_t)GEO::TMO_OFF, 0u);                   // (several barriers before anyone sets or reads it)
         // every per-lane constant is re-derived per row block from an opaque copy of the lane id: as loop invariants of the persistent
         // loop they stayed live through the epilogue (128 accumulator registers + its temporaries) and hipcc spilled 14-18 of them
         int lane_v = lane;
@@ -299,6 +316,8 @@ __global__ __launch_bounds__(512, 2) void visproj_gemm_kernel(VisGemmArgs a) {
                 // once it has read them -- a clean (all-zero) area is left clean by every launch, so nothing has to be zeroed between
                 // launches (the memset node + its boundary cost 3-4 us of a 70 us call)
                 gu64* base = (gu64*)(a.xch) + ((size_t)((it & 1) * a.nteams + team) * NT * NT) * (BM * 2);
+                // the same pair, once more, where nobody clears it: what the repair kernel combines for a workgroup that gave up
+                a.stats[(size_t)(row0 + tid) * NT + member] = ((unsigned long long)__float_as_uint(m2) << 32) | __float_as_uint(mj);
                 const unsigned long long g0 = ((unsigned long long)epoch << 32) | __float_as_uint(mj);
                 const unsigned long long g1 = ((unsigned long long)epoch << 32) | __float_as_uint(m2);
 #pragma unroll
@@ -326,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void visproj_gemm_kernel(VisGemmArgs a) {
                         }
                     }
                     if (__all(ok)) break;
-                    if (spins >= VISG_MAX_SPIN) { timed_out = true; break; }                 // (wave-uniform: every lane counts the same)
+                    if (spins >= a.spin_limit) { timed_out = true; break; }                  // (wave-uniform: every lane counts the same)
                     __builtin_amdgcn_s_sleep(4);
                 }
 #pragma unroll
@@ -338,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void visproj_gemm_kernel(VisGemmArgs a) {
                         __hip_atomic_store(g + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                if (timed_out) { if (lane == 0) atomicOr(a.status, 1u); }
+                if (timed_out && lane == 0) visg_lds_write4(lds0 + (uint32_t)GEO::TMO_OFF, 1u);
                 float ms = mj;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) if (k < NT - 1) ms += pm[k];
@@ -361,11 +380,21 @@ __global__ __launch_bounds__(512, 2) void visproj_gemm_kernel(VisGemmArgs a) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         // this wave's R rows have landed in its staging area
         __builtin_amdgcn_s_barrier();
         VISG_STAMP(4)
+        // A workgroup one of whose waves gave up: (mean, rstd) = (0, 1) for every row, so that what goes where xhat goes is the PRE-norm
+        // tile (what goes to out is overwritten by the repair kernel); the tile is flagged and the call's timeout counter bumped.
+        const bool gave_up = __builtin_amdgcn_readfirstlane(visg_lds_read4(lds0 + (uint32_t)GEO::TMO_OFF)) != 0u;
+        if (gave_up && tid == 0) {
+            typedef __attribute__((address_space(1))) unsigned gu32;
+            __hip_atomic_store((gu32*)(a.flags + (size_t)rb * NT + member), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicOr(a.status, 1u);
+            atomicAdd(a.status + 1, 1u);
+        }
         // normalise in registers; out = xhat * gamma + beta + R goes through the staging area (in place over R)
         const uint32_t a_st = stg + (uint32_t)(n * 128 + 8 * kh);           // + 32 rt rows, slot (4 ft + q) ^ (n & 7)
         sfor<RTN>([&](auto RT_) {
             constexpr int rt = RT_.value;
-            const float2 ms = rst[wm * HB + 32 * rt + n];
+            float2 ms = rst[wm * HB + 32 * rt + n];
+            if (gave_up) ms = make_float2(0.f, 1.f);
             sfor<2>([&](auto FT) {
                 sfor<4>([&](auto Q) {
                     constexpr int ft = FT.value, q = Q.value;
@@ -434,6 +463,83 @@ __global__ __launch_bounds__(512, 2) void visproj_gemm_kernel(VisGemmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ repair (round 6)
+// Launched behind every main kernel by the same call.  Header words of the workspace: [0] status (sticky, for the host), [1] tiles that
+// gave up so far (monotonic), [2] that count at the last repair, [3] repair workgroups finished.  Normal case: [1] == [2], every
+// workgroup returns after two loads.  Otherwise the flagged tiles are normalised from the pre-norm rows the main kernel left where
+// xhat goes (bf16: the rounding point of the library composition), with the statistics of ALL column tiles from the plain array --
+// complete by now, combined in the order the main kernel uses for that member -- and the exchange area is zeroed; the last
+// workgroup to finish records the count.
+__global__ __launch_bounds__(256) void visproj_gemm_repair_kernel(VisGemmArgs a, int BM, size_t xch_words) {
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    gu32* hdr = (gu32*)a.status;
+    const unsigned given_up = __hip_atomic_load(hdr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned repaired = __hip_atomic_load(hdr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (given_up == repaired) return;
+    const int NT = a.d_out >> 8, tid = threadIdx.x;
+    const float inv_d = 1.0f / (float)a.d_out;
+    for (int t = blockIdx.x; t < a.row_blocks * NT; t += gridDim.x) {
+        if (a.flags[t] == 0u) continue;
+        const int rb = t / NT, member = t % NT;
+        const int64_t row0 = (int64_t)rb * BM;
+        const int c8 = (tid & 31) * 8, f0 = member * 256 + c8;            // this thread's 8 features (16 bytes) of a row
+        float g8[8], b8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { g8[j] = a.gamma[f0 + j]; b8[j] = a.beta ? a.beta[f0 + j] : 0.f; }
+        for (int r = tid >> 5; r < BM; r += 8) {
+            const int64_t row = row0 + r;
+            if (row >= a.M) break;
+            float pmj[4], pm2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < NT) {
+                    const int who = member + k < NT ? member + k : member + k - NT;     // self first, then member + 1, .. (the main kernel's order)
+                    const unsigned long long v = a.stats[(size_t)row * NT + who];
+                    pmj[k] = __uint_as_float((unsigned)v); pm2[k] = __uint_as_float((unsigned)(v >> 32));
+                }
+            float ms = pmj[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (k < NT) ms += pmj[k];
+            float mean = ms / (float)NT, M2;
+            { const float dm = pmj[0] - mean; M2 = pm2[0] + 256.0f * dm * dm; }
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (k < NT) { const float dm = pmj[k] - mean; M2 += pm2[k] + 256.0f * dm * dm; }
+            if (a.rms) mean = 0.f;
+            const float rstd = rsqrtf(M2 * inv_d + a.eps);
+            const size_t off = (size_t)row * a.d_out + f0;
+            const bf16x8 pre = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.xhat) + off);
+            bf16x8 rr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rr[j] = (__bf16)0.f;
+            if (a.R) rr = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.R) + off);
+            bf16x8 xo, oo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = ((float)pre[j] - mean) * rstd;
+                xo[j] = (__bf16)xh;
+                oo[j] = (__bf16)(xh * g8[j] + b8[j] + (float)rr[j]);
+            }
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(a.xhat) + off) = xo;
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(a.out) + off) = oo;
+            if (member == 0 && c8 == 0) {
+                if (a.rstd) a.rstd[row] = rstd;
+                if (a.mean) a.mean[row] = mean;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) a.flags[t] = 0u;
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < xch_words; i += (size_t)gridDim.x * 256) a.xch[i] = 0ull;
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(a.status + 3, 1u) == gridDim.x - 1) {
+            __hip_atomic_store(hdr + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(hdr + 2, given_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 bool visproj_gemm_applies(int64_t M, int F, int d_out, int io_fp32) {
     if (io_fp32 || M <= 0 || d_out % 256 != 0 || d_out / 256 > 4 || F % 64 != 0 || F < 64) return false;
@@ -455,10 +561,15 @@ static int visg_pick_bm(int64_t M, int d_out, int forced) {
     }
     return best;
 }
+// workspace: [0, 256) header (status, counters, stamps) | exchange area | tile flags [ceil(M / 128) x NT] u32 | statistics [M + 256][NT] x 8 B
+size_t visproj_gemm_exchange_bytes(int d_out) {
+    const size_t NT = (size_t)(d_out / 256);
+    return (size_t)2 * visg_teams_max(d_out) * NT * NT * 256 * 2 * 8;
+}
+static size_t visg_flags_bytes(int64_t M, int d_out) { return (((size_t)((M + 127) / 128) * (size_t)(d_out / 256) * 4) + 255) / 256 * 256; }
 size_t visproj_gemm_workspace_bytes(int64_t M, int F, int d_out) {
     if (!visproj_gemm_applies(M, F, d_out, 0)) return 0;
-    const size_t NT = (size_t)(d_out / 256);
-    return 256 + (size_t)2 * visg_teams_max(d_out) * NT * NT * 256 * 2 * 8;
+    return 256 + visproj_gemm_exchange_bytes(d_out) + visg_flags_bytes(M, d_out) + (size_t)(M + 256) * (size_t)(d_out / 256) * 8;
 }
 
 template <int BM, int BK, int NSLOT, bool SPREAD>
@@ -469,7 +580,10 @@ static hipError_t launch_visg(VisGemmArgs& a, uint8_t* ws, hipStream_t stream) {
     a.nteams = a.row_blocks < tmax ? a.row_blocks : tmax;
     a.status = reinterpret_cast<unsigned*>(ws);
     a.xch = reinterpret_cast<unsigned long long*>(ws + 256);
-    (void)NT;
+    const size_t xch_b = visproj_gemm_exchange_bytes(a.d_out);
+    a.flags = reinterpret_cast<unsigned*>(ws + 256 + xch_b);
+    a.stats = reinterpret_cast<unsigned long long*>(ws + 256 + xch_b + visg_flags_bytes(a.M, a.d_out));
+    if (a.spin_limit == 0) a.spin_limit = VISG_MAX_SPIN;
     auto kern = visproj_gemm_kernel<BM, BK, NSLOT, SPREAD>;
     // residency: a team's members must run concurrently, which one workgroup per CU and a grid no larger than the device's CU count
     // guarantee (a smaller device gets fewer teams and more passes, never a grid it cannot hold)
@@ -484,6 +598,11 @@ static hipError_t launch_visg(VisGemmArgs& a, uint8_t* ws, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GEO::LDS_B);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(cols_grid(NT, a.nteams)), dim3(512), GEO::LDS_B, stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess || NT == 1) return e;
+    // the repair pass of the same call: two loads and out unless a workgroup gave up (see the kernel)
+    const int tiles = a.row_blocks * NT;
+    hipLaunchKernelGGL(visproj_gemm_repair_kernel, dim3(tiles < 256 ? tiles : 256), dim3(256), 0, stream, a, BM, xch_b / 8);
     return hipGetLastError();
 }
 
@@ -491,6 +610,8 @@ static hipError_t launch_visg(VisGemmArgs& a, uint8_t* ws, hipStream_t stream) {
 // the stage ahead spread between the MFMA groups; bm: 0 = by shape
 hipError_t launch_visproj_gemm(VisGemmArgs& a, void* ws, int form, int bm, hipStream_t stream) {
     uint8_t* w8 = reinterpret_cast<uint8_t*>(ws);
+    if (form >> 8) a.spin_limit = 1u << ((form >> 8) & 31);     // (tests of the give-up path: bits 8.. = log2 of the polls before a wave gives up)
+    form &= 255;
     if (form == 0) form = VISG_DEFAULT_FORM;
     int BMv = visg_pick_bm(a.M, a.d_out, bm);
     if (BMv == 192 && form != 1 && form != 4) {         // (192-row tiles exist for the 64-feature stages only)

@@ -23,8 +23,10 @@ K4_FORM = "gemm"
 GEMM_THEN_NORM = True          # (honoured when K4_FORM == "library")
 
 
-# Exchange area of the tiled-GEMM form: zeroed ONCE per device; every launch leaves it zeroed (each consumer clears the granules it has
-# read), so no memset runs between launches.  One area per device: K4 launches of one process are issued on one stream at a time.
+# Workspace of the tiled-GEMM form (exchange area + per-tile statistics + give-up flags): zeroed ONCE per device; every call leaves the
+# exchange area zeroed (each consumer clears the granules it has read; a call in which a workgroup gave up on a partner repairs its
+# tiles and re-zeroes the area itself, csrc/visproj_gemm.hip), so no memset runs between launches.  One area per device: K4 launches
+# of one process are issued on one stream at a time.
 _GEMM_WS = {}
 
 
@@ -37,18 +39,23 @@ def _gemm_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
 
 
 def gemm_exchange_status(device=None) -> int:
-    """Nonzero: a K4 launch on ``device`` (any, if None) gave up waiting for a partner workgroup's LayerNorm statistics (the GPU was not
-    this process's alone for seconds) -- its rows were normalised with incomplete statistics.  Clears the word and re-zeroes the area
-    (one 4-byte device read; train.Trainer.check_labels calls it every LABEL_CHECK_EVERY steps)."""
-    bad = 0
+    """Tiles of K4 launches on ``device`` (any, if None) whose workgroup gave up waiting for a partner workgroup's LayerNorm statistics
+    since the last call (the GPU was not this process's alone for about a second).  INFORMATIONAL: the same call re-normalised those tiles
+    from the complete statistics before anything downstream could read them (csrc/visproj_gemm.hip, repair kernel), so no step was
+    computed on wrong rows; a nonzero count says the K4 launch cost a second instead of 80 us.  One 16-byte device read; clears the
+    sticky status word (train.Trainer.check_labels calls it every LABEL_CHECK_EVERY steps and warns)."""
+    tiles = 0
     for key, ws in _GEMM_WS.items():
         if device is not None and key != (torch.device(device).type, torch.device(device).index):
             continue
-        st = int(ws[:4].view(torch.int32)[0].item())
-        if st:
-            bad |= st
-            ws.zero_()
-    return bad
+        hdr = ws[:16].view(torch.int32).tolist()        # status, tiles given up so far, ... at the last repair, repair workgroups done
+        if hdr[0]:
+            seen = getattr(gemm_exchange_status, "_seen", {})
+            tiles += max(1, hdr[1] - seen.get(key, 0))
+            seen[key] = hdr[1]
+            gemm_exchange_status._seen = seen
+            ws[:4].zero_()
+    return tiles
 
 
 class VisProjPackCache:
