@@ -124,6 +124,13 @@ int vlpet_adapter_gate_bwd_phase(int phases, const void* dy, const void* x1, con
  * (bf16, r, r_g <= 96, d % 128 == 0), 1 = pass 1 + the older column-parallel pass (csrc/pet_gate_bwd3.hip: r = 192, fp32 small M),
  * 0 = row kernel + weight-gradient kernels; < 0: bad arguments.  (What a bench labels its kernel brackets with.) */
 int vlpet_adapter_gate_bwd_form(int64_t M, int d, int tiles, int io_dtype);
+/* 1: that form ends in a separate finalize launch at this shape (`phases` bit 4 runs it alone); 0: it does not -- since round 6 the
+ * column-parallel pass at r, r_g <= 96 sums its row-chunk partials INSIDE the launch (csrc/cols_reduce.h: the workgroups of a column
+ * block each take a slice once all of them have published; bounded waits, the last arriver finishes what an owner gave up, results
+ * bit-identical to the two-launch form).  `phases` bit 5 (32) of the *_bwd_saved* entry points keeps the round-3 two-launch form for
+ * same-box A/Bs.  The reduce-scatter's control words are zeroed by pass 1, so `phases` = 2 alone presumes that pass 1 of the same
+ * backward ran on the same workspace before (as the bench's per-kernel brackets do). */
+int vlpet_adapter_gate_bwd_finalize_launch(int64_t M, int d, int tiles, int io_dtype);
 
 /* Dropout seeds under graph replay (train.Trainer(graph=True): forward + backward of a step captured once with hipGraph and replayed).
  * A replayed launch repeats its kernel arguments, so the per-call `seed` values of the dropout-carrying entry points below

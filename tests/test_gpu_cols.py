@@ -147,6 +147,57 @@ def test_k1_from_x2_vs_oracle(kw):
         F.K1_BWD_FROM_OUTPUT = True
 
 
+@pytest.mark.parametrize("M,r", [(1, 96), (33, 96), (1000, 96), (3500, 96), (15272, 96), (28000, 96), (46648, 96), (777, 8), (5000, 32)])
+@pytest.mark.parametrize("gate_mode", [1, 2])
+def test_in_launch_reduce_scatter_equals_the_finalize_launch(M, r, gate_mode):
+    """Round 6 (csrc/cols_reduce.h): pass 2 sums its row-chunk partials inside the launch -- slices of a column block's slab, one per
+    workgroup, in the finalize kernel's order of additions.  Every output must be BIT-identical to the round-3 form (ABI phases bit 5:
+    partial slabs + wgrad_finalize_kernel), with and without the incoming dx1, from one row to the largest launch of the bench, at
+    one and three bottleneck tiles; repeated calls on one workspace (the control words are re-zeroed by every pass 1)."""
+    run, _ = _abi_case(M, gate_mode=gate_mode, r=r)
+    for acc in (False, True):
+        new, old = run([3], acc, True), run([3 | 32], acc, True)
+        for k, (a, b) in enumerate(zip(new, old)):
+            assert torch.equal(a, b), (k, acc, (a - b).abs().max().item())
+    again = run([3], True, True)
+    for a, b in zip(new, again):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("held", [128, 248])
+def test_in_launch_reduce_scatter_with_cus_held_by_another_stream(held):
+    """The reduce-scatter must not presume that the workgroups of a column block run at the same time.  Here 128 / 248 of the 256 CUs are
+    held by a spinning kernel on a second stream (100 KiB of LDS each: no pass-2 workgroup fits beside one), so the 240 workgroups of
+    pass 2 run in several rounds: early ones wait for partners that cannot start, give up, and the LAST arriver of each column block
+    sums their slices.  Outputs bit-identical to the undisturbed run."""
+    import time
+    from vlpet_amd import _lib
+    lib = _lib.load()
+    run, _ = _abi_case(9000)
+    ref = run([3], True, True)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    assert lib.vlpet_test_hold_cus(held, 100 * 1024, flag.data_ptr(), 9000, side.cuda_stream) == 0
+    time.sleep(0.05)
+    import vlpet_amd.functional as F     # (run() ends in a device-wide synchronize: release the holders from a timer thread instead)
+    import threading
+    rel = torch.cuda.Stream()
+
+    def release():
+        with torch.cuda.stream(rel):
+            flag.fill_(1)
+    th = threading.Timer(3.0, release)
+    th.start()
+    t0 = time.time()
+    got = run([3], True, True)
+    th.join()
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 8.5, "the holders ran into their own time bound"
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert torch.equal(a, b), k
+
+
 @pytest.mark.parametrize("gate_mode", [1, 2])
 def test_kernel_brackets_and_previous_split_agree(gate_mode):
     """phases 1, 2|8, 16 (pass 1, pass 2 without finalize, finalize: what the bench brackets) == phases 3; and the previous

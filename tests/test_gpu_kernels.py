@@ -93,7 +93,7 @@ _SIX_TILE_CASES = [dict(M=1000, r=192, rg=192, nh=4, delta_scale=4.0, x2_scale=0
 _THREE_TILE_CASES = [dict(M=1000), dict(M=999, gate_mode=2, gate_scale=0.3), dict(M=777, r=8, rg=8, nh=4), dict(M=28000)]
 
 
-@pytest.mark.parametrize("switch", ["VLPET_DZ6C=1", "VLPET_COLS6Y=0", "VLPET_DZ6=2", "VLPET_COLSY=1"])
+@pytest.mark.parametrize("switch", ["VLPET_DZ6C=1", "VLPET_COLS6Y=0", "VLPET_DZ6=2"])
 def test_k1_six_tile_alternative_forms(switch):
     """The forms of the K1 backward that are NOT the default, through the diagnosis build in a child process (see above): at r = 192 pass 1
     as the chain-split eight-wave kernel (k1_dz6c_kernel: measured slower, kept), pass 2 on pet_cols6.hip although y is at hand, pass 1

@@ -319,7 +319,7 @@ extern "C" int vlpet_lora_r8_applies(int64_t M, int d, int r, int io_dtype) {
 
 // ------------------------------------------------------------------ backward workspace
 struct BwdWs {
-    size_t z_a, dp_a, z_g, dp_g, dh, dq, partial, total;
+    size_t z_a, dp_a, z_g, dp_g, dh, dq, partial, red_ctrl, total;     // red_ctrl: control words of the in-launch reduce-scatter (cols_reduce.h)
     int row_chunks;
     int64_t rows_per_chunk;
 };
@@ -363,6 +363,8 @@ static BwdWs bwd_ws(int64_t M, int d, int tiles, bool gate, int io_dtype) {
     }
     w.partial = o;
     o += align256(wgrad_workspace_bytes(njobs, tiles, d, chunks));
+    w.red_ctrl = o;
+    o += align256((size_t)(d >= 128 ? d / 128 : 1) * COLS_RED_STRIDE * 4);
     // the streaming K3 backward at r <= 8 (lora8.hip) keeps one [dA | dB] partial per workgroup at the start of the workspace instead
     if (!gate && tiles == 1 && io_dtype != VLPET_F32 && d % 256 == 0 && d <= 768 && o < align256(lora8_bwd_part_bytes(M, d, 8)))
         o = align256(lora8_bwd_part_bytes(M, d, 8));
@@ -419,6 +421,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     b.gm = 1.f; b.go = 0.f; b.fsplit = 0; b.dz_part = nullptr;
     if (yout && (!gate || !saved || !aligned16(yout))) return VLPET_E_ALIGN;
     b.y = (flags & PET_GATE_ADD) ? nullptr : yout;
+    b.red_ctrl = nullptr; b.red_words = 0;
     if (saved && !aligned16(saved)) return VLPET_E_ALIGN;
     b.saved = saved; b.saved_stride = (int64_t)saved_stride(M, tiles, io_dtype);
     if (saved) {        // z comes from the forward; the rows kernel does not write it
@@ -436,6 +439,10 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     // without a gate (K2, adapter-only K1, K3 without dropout), bf16, saved activations, whole call: pass 1 (dpre) + the
     // column-parallel pass of pet_cols_ng.hip (dx and both weight gradients from one read of dy and x)
     const bool ng2 = !gate && phases == 3 && vlpet_tuning().ng2 != 0 && ng_two_pass_applies(b, io_dtype == VLPET_F32);
+    // round 6: pass 2 sums its row-chunk partials inside the launch (cols_reduce.h) -- no finalize launch; `phases` bit 5 keeps the
+    // round-3 two-launch form (same-box A/Bs; the results are bit-identical)
+    const bool red4 = cols4 && !cols6 && !(phases & 32);
+    if (red4) { b.red_ctrl = reinterpret_cast<unsigned*>(ws + w.red_ctrl); b.red_words = (d / 128) * COLS_RED_STRIDE; }
     int gs3 = 0, ng3 = 0;
     if (ng2) {
         WgradArgs g{};
@@ -473,6 +480,10 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
                 b.fsplit = nfb;
                 b.dz_part = reinterpret_cast<float*>(ws + w.dh);
             }
+        }
+        if (b.red_ctrl && !dz2) {       // a pass 1 that does not zero the reduce-scatter state itself (non-default forms): a memset node
+            hipError_t em = hipMemsetAsync(b.red_ctrl, 0, (size_t)b.red_words * 4, (hipStream_t)stream);
+            if (em != hipSuccess) return (int)em;
         }
         hipError_t e = dz2 ? launch_k1_dz2(b, (hipStream_t)stream)
                      : dz6 ? launch_k1_dz6(b, (hipStream_t)stream)
@@ -523,9 +534,24 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
         c.row_chunks = g.row_chunks; c.rows_per_chunk = g.rows_per_chunk;
         const WgradLayout L = wgrad_layout(g);
         for (int j = 0; j < 4; ++j) c.part[j] = g.partial + L.off[j];
+        if (red4) {
+            // the same workspace bytes, cut differently: [RC][NCB] slabs (= the four [RC][PR][d] blocks), then the column-sum partials
+            const int64_t PRl = 32 * tiles;
+            c.red.slab = g.partial;
+            c.red.bias_x = g.partial + (int64_t)4 * g.row_chunks * PRl * d;
+            c.red.bias_p = c.red.bias_x + (int64_t)2 * g.row_chunks * d;
+            c.red.ctrl = reinterpret_cast<unsigned*>(ws + w.red_ctrl);
+            c.red.spin_limit = COLS_RED_SPIN_DEFAULT;
+            for (int j = 0; j < 4; ++j) {
+                const WgradJob& J = g.job[j];
+                c.red.job[j] = ColsRedJob{J.out, J.ldo, J.transposed, J.out_rows, J.scale, J.colsum_x, J.colsum_p};
+            }
+            if (!(phases & 2)) return 0;                    // ("finalize only": there is none)
+            return herr(launch_k1_cols(c, tiles, (hipStream_t)stream));
+        }
         if (phases & 2) {
             hipError_t e = cols6 ? (k1_cols6y_applies(c) ? launch_k1_cols6y(c, (hipStream_t)stream) : launch_k1_cols6(c, (hipStream_t)stream))
-                                 : (k1_colsy_applies(c, tiles) ? launch_k1_colsy(c, tiles, (hipStream_t)stream) : launch_k1_cols(c, tiles, (hipStream_t)stream));
+                                 : launch_k1_cols(c, tiles, (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
         }
         if ((phases & 8) && !(phases & 16)) return 0;       // (the partial sums stay in the workspace)
@@ -546,6 +572,16 @@ extern "C" int vlpet_adapter_gate_bwd_form(int64_t M, int d, int tiles, int io_d
     b.M = M; b.d = d; b.RT = tiles; b.flags = PET_GATE; b.saved = &b; b.drop = NO_DROP;
     if (k1_cols_applies(b, io_dtype == VLPET_F32) || k1_cols6_applies(b, io_dtype == VLPET_F32)) return 2;
     if (pet_gate_bwd3_applies(b)) return 1;
+    return 0;
+}
+
+// 1: the two-pass form at this shape ends in a separate finalize launch (`phases` bit 4 runs it); 0: pass 2 sums its row chunks itself
+// (round 6, cols_reduce.h) or the form is not the two-pass one
+extern "C" int vlpet_adapter_gate_bwd_finalize_launch(int64_t M, int d, int tiles, int io_dtype) {
+    if (check_common(M, d, tiles, io_dtype)) return -1;
+    PetBwdArgs b{};
+    b.M = M; b.d = d; b.RT = tiles; b.flags = PET_GATE; b.saved = &b; b.drop = NO_DROP;
+    if (k1_cols6_applies(b, io_dtype == VLPET_F32)) return 1;
     return 0;
 }
 

@@ -88,6 +88,8 @@ struct PetBwdArgs {
     float* dz_part;         //   [fsplit][M][2][32*RT] fp32
     const void* y;          // optional (gated K1, multiplicative gate, saved form): the forward's OUTPUT [M,d] -- pass 1 then forms
                             //   dq = dy * y * (1 - g) and skips the adapter chain's up projection (pet_dz2.hip / pet_dz6.hip)
+    unsigned* red_ctrl;     // optional: the control words of pass 2's in-launch reduce-scatter (cols_reduce.h) -- pass 1's first
+    int red_words;          //   workgroup zeroes them, so no memset node sits between the passes
 };
 hipError_t launch_pet_bwd(const PetBwdArgs& a, int io_fp32, hipStream_t stream);
 // chain-split form of the same (pet_gate_bwd2.hip): gated K1 with saved activations
@@ -171,6 +173,22 @@ hipError_t launch_pet_gate_cols(const PetBwdArgs& a, const WgradArgs& g, int GS,
 
 // Column-parallel pass 2 of the gated K1 backward, round-3 form (pet_cols.hip): weights resident in registers, row tensors streamed
 // once; bf16, saved activations, r <= 96.  Partials in the workspace layout of the weight-gradient kernels (wgrad_layout).
+// in-launch reduce-scatter of the row-chunk partials (cols_reduce.h has the device side and the protocol)
+struct ColsRedJob {                          // one weight gradient (the fields of a finalize job, wgrad.hip)
+    float* out; int ldo, transposed, out_rows; float scale;
+    float* colsum_x;                         // [d]: bias gradient = column sums of the job's X operand (scaled), or nullptr
+    float* colsum_p;                         // [out_rows]: column sums of the job's P operand (unscaled), or nullptr
+};
+struct ColsRedArgs {
+    float* slab;                             // [RC][NCB] slabs, each 8 waves x NJB x RT x 4 x 64 units of 16 bytes
+    float* bias_x;                           // [NXS][RC][d] column-sum partials over the columns
+    float* bias_p;                           // [RC][NPT * 32] column-sum partials of the bottleneck tiles
+    unsigned* ctrl;                          // [NCB][COLS_RED_STRIDE], zeroed by pass 1
+    ColsRedJob job[4];
+    unsigned spin_limit;
+};
+#define COLS_RED_STRIDE 320                  // words per column block: 2 + up to 256 row chunks (cols_groups_max(1)), padded
+#define COLS_RED_SPIN_DEFAULT (1u << 13)     // polls (~0.3-1 us each) before a workgroup gives up on the rest of its column block
 struct ColzArgs {
     const void* dy; const void* x1; const void* x2;      // [M, d] bf16
     const void* dxin;                                    // optional [M, d]: added to dx1
@@ -185,6 +203,7 @@ struct ColzArgs {
     int flags;
     int row_chunks; int64_t rows_per_chunk;              // rows_per_chunk % 32 == 0
     float* part[4];                                      // per job (0 dWd, 1 dWu, 2 dWgd, 3 dWgu): [RC][32RT][d] tiles, [RC][d] column sums of X, [RC][32RT] of P
+    ColsRedArgs red;                                     // red.slab != nullptr: the row chunks are summed inside the launch (cols_reduce.h), no finalize pass
 };
 void k1_cols_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk);
 bool k1_cols_applies(const PetBwdArgs& a, int io_fp32);
@@ -194,8 +213,6 @@ void k1_cols6_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk);
 bool k1_cols6_applies(const PetBwdArgs& a, int io_fp32);
 hipError_t launch_k1_cols6(const ColzArgs& c, hipStream_t stream);
 // ... with the up-side weight gradients one step late and the elementwise block from the forward's output (pet_cols6y.hip)
-bool k1_colsy_applies(const ColzArgs& c, int RT);                        // ... the same for r <= 96 (pet_colsy.hip)
-hipError_t launch_k1_colsy(const ColzArgs& c, int RT, hipStream_t stream);
 bool k1_cols6y_applies(const ColzArgs& c);
 hipError_t launch_k1_cols6y(const ColzArgs& c, hipStream_t stream);
 

@@ -29,6 +29,7 @@
 // fragments (lane = row) with ds_read_b128.  All LDS accesses of the loop are inline asm (see trread.h for why).
 // Partials go to the workspace in wgrad.hip's layout; wgrad_finalize_kernel sums the row chunks (deterministic).
 #include "cols_common.h"
+#include "cols_reduce.h"
 
 template <int RT, bool HAS_IN = false> struct ColzGeo {
     static constexpr int KT = 2 * RT;
@@ -418,6 +419,20 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
                    (unsigned long long)tacc[0], (unsigned long long)tacc[1], (unsigned long long)tacc[2], (unsigned long long)tacc[3], (unsigned long long)tacc[4]);
 #endif
         __builtin_amdgcn_s_barrier();                                     // the last dh tile is visible to role D
+        if (a.red.slab != nullptr) {                                      // (in-launch reduce: write-through partials, cols_reduce.h)
+            if (h == 0) {
+                cols_red_store_f32(a.red.bias_x + (int64_t)rc * d + col, sx[0]);
+                cols_red_store_f32(a.red.bias_x + ((int64_t)RC + rc) * d + col, sx[1]);
+                if (want_csp) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int k = csp_tile[j];
+                        if (k < 0) break;
+                        cols_red_store_f32(a.red.bias_p + (int64_t)rc * (2 * PR) + 32 * k + m, sx[2 + j]);
+                    }
+                }
+            }
+        } else
         if (h == 0) {
             a.part[1][(int64_t)RC * PR * d + (int64_t)rc * d + col] = sx[0];
             a.part[3][(int64_t)RC * PR * d + (int64_t)rc * d + col] = sx[1];
@@ -518,7 +533,25 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
         __builtin_amdgcn_s_barrier();                                     // role U has written the last dh tile
         if (nsteps > 0) finish(nsteps - 1, dinA, dinB);
     }
-    // ---- this row chunk's partial sums, in wgrad.hip's workspace layout (wgrad_finalize_kernel sums the chunks)
+    // ---- this row chunk's partial sums: summed over the row chunks INSIDE this launch by the workgroups of the column block (round 6,
+    // cols_reduce.h) ...
+    if (a.red.slab != nullptr) {
+        using RG = ColsRedGeo<RT, 2>;
+        const __amdgpu_buffer_rsrc_t mine = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(sbase(reinterpret_cast<const uint8_t*>(a.red.slab) + ((int64_t)rc * NCB + cb) * RG::SLAB_B)), 0, RG::SLAB_B, 0x00020000);
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct) {
+            cols_red_put<RT, 2>(mine, wave, lane, 0, ct, accA[ct]);
+            cols_red_put<RT, 2>(mine, wave, lane, 1, ct, accG[ct]);
+        }
+        cols_red_finish<RT, 2, 2, 2 * RT>(a.red, NCB, RC, cb, rc, d, reinterpret_cast<volatile unsigned*>(smem),
+            [](int rl, int jb) { return rl == 0 ? (jb == 0 ? 1 : 3) : (jb == 0 ? 0 : 2); },         // U: dWu, dWgu;  D: dWd, dWgd
+            [](int x) { return x == 0 ? 1 : 3; },                                                    // column sums of dh -> dbu, of dq -> dbgu
+            [](int k, int& job, int& first) { job = k / RT == 0 ? 0 : 2; first = 32 * (k % RT); });  // dpre_a tiles -> dbd, dpre_g tiles -> dbgd
+        return;
+    }
+    // ... or, without the reduce-scatter arguments, in wgrad.hip's workspace layout for wgrad_finalize_kernel (the round-3 form, kept
+    // for same-box A/Bs: api.hip run_bwd, `phases` bit 5)
     {
         float* tA = a.part[role == 0 ? 1 : 0] + (int64_t)rc * PR * d;
         float* tG = a.part[role == 0 ? 3 : 2] + (int64_t)rc * PR * d;

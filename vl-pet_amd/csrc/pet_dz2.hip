@@ -66,6 +66,8 @@ __global__ __launch_bounds__(512, 2) void k1_dz2_kernel(PetBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.red_ctrl != nullptr && blockIdx.x == 0 && blockIdx.y == 0)        // pass 2's reduce-scatter state (cols_reduce.h): zeroed HERE, so
+        for (int i = tid; i < a.red_words; i += 512) a.red_ctrl[i] = 0u;     // that no memset node sits between the passes
     const int rg = wave & 3, fh = wave >> 2;            // waves w and w + 4 share a SIMD: the two feature halves of a row group
     const int m = lane & 31, h = lane >> 5;
     const int d = a.d;

@@ -26,8 +26,6 @@ struct VlpetTuning {
                             //   round 5, parity-green, and SLOWER (54 vs 48 us at 28,000 rows, 26 vs 19 at 2,500; profiles/r05_k3_streaming_bwd_ab.txt)
     int dz6c = 0;           // VLPET_DZ6C=1: pass 1 at six tiles from y / additive gate on the chain-split eight-wave kernel (two waves per SIMD; measured
                             //   SLOWER than the four-wave one: 65 vs 58 us at 18,250 rows, profiles/r05_k1bench_dz6c_ab.txt)
-    int colsy = 0;          // VLPET_COLSY=1: pass 2 at r <= 96 on pet_colsy.hip (from the forward's output, late up-side products) -- built in round 5,
-                            //   parity-green, SLOWER than pet_cols.hip (79 vs 76 us warm, 93 vs 78 us in the step: y is a fourth row stream; profiles/r05_k1_colsy_ab.txt)
     int cols6y = 1;         // VLPET_COLS6Y=0: pass 2 at six tiles on pet_cols6.hip even when the forward's output is at hand (pet_cols6y.hip otherwise)
     int k4_wgrad2 = 1;      // VLPET_K4_WGRAD2=0: K4 weight gradient as jobs of the generic stream instead of the tiled split-K GEMM
     int ng2 = 1;            // VLPET_NG2=0: row kernel + streaming weight gradients for the backward without a gate instead of the two-pass form
@@ -44,7 +42,7 @@ inline const VlpetTuning& vlpet_tuning() {
         rd("VLPET_RG", v.rg); rd("VLPET_BWD2", v.bwd2); rd("VLPET_BWD3", v.bwd3); rd("VLPET_BWD3_UNITS", v.bwd3_units);
         rd("VLPET_BWD3_FORM", v.bwd3_form); rd("VLPET_K4_WAVES4", v.k4_waves4); rd("VLPET_WGRAD_WGS", v.wgrad_wgs);
         rd("VLPET_WGRAD_TR", v.wgrad_tr); rd("VLPET_WGRAD_STREAM", v.wgrad_stream); rd("VLPET_WGRAD_NSTG", v.wgrad_nstg);
-        rd("VLPET_WGS_MODE", v.wgs_mode); rd("VLPET_ATTN_OCC", v.attn_occ); rd("VLPET_ATTN_NW", v.attn_nw); rd("VLPET_DBG", v.dbg); rd("VLPET_DZ2", v.dz2); rd("VLPET_DZ6", v.dz6); rd("VLPET_COLS6Y", v.cols6y); rd("VLPET_COLSY", v.colsy); rd("VLPET_DZ6C", v.dz6c); rd("VLPET_LORA8_BWD", v.lora8_bwd); rd("VLPET_DZ2_FSPLIT", v.dz2_fsplit); rd("VLPET_K4_WGRAD2", v.k4_wgrad2); rd("VLPET_NG2", v.ng2); rd("VLPET_FWD2P", v.fwd2p);
+        rd("VLPET_WGS_MODE", v.wgs_mode); rd("VLPET_ATTN_OCC", v.attn_occ); rd("VLPET_ATTN_NW", v.attn_nw); rd("VLPET_DBG", v.dbg); rd("VLPET_DZ2", v.dz2); rd("VLPET_DZ6", v.dz6); rd("VLPET_COLS6Y", v.cols6y); rd("VLPET_DZ6C", v.dz6c); rd("VLPET_LORA8_BWD", v.lora8_bwd); rd("VLPET_DZ2_FSPLIT", v.dz2_fsplit); rd("VLPET_K4_WGRAD2", v.k4_wgrad2); rd("VLPET_NG2", v.ng2); rd("VLPET_FWD2P", v.fwd2p);
         return v;
     }();
     return t;

@@ -38,6 +38,7 @@
 #include "kernels.h"
 
 #define VISG_MAX_SPIN (1u << 20)
+#define VISG_FLAGS_B 65536       // give-up flags of the tiles: one fixed-size area (see visproj_gemm_workspace_bytes)
 #ifndef VISG_DEFAULT_FORM
 #define VISG_DEFAULT_FORM 4      // BK 64, two slots, spread requests: profiles/r05_k4bench.txt
 #endif
@@ -544,6 +545,7 @@ __global__ __launch_bounds__(256) void visproj_gemm_repair_kernel(VisGemmArgs a,
 bool visproj_gemm_applies(int64_t M, int F, int d_out, int io_fp32) {
     if (io_fp32 || M <= 0 || d_out % 256 != 0 || d_out / 256 > 4 || F % 64 != 0 || F < 64) return false;
     const int64_t wide = F > d_out ? F : d_out;
+    if ((M + 127) / 128 * (d_out / 256) > 65536 / 4) return false;      // (one give-up flag per 128-row tile: VISG_FLAGS_B)
     return M * wide * 2 < ((int64_t)1 << 32);           // (32-bit per-lane byte offsets)
 }
 static int visg_teams_max(int d_out) { return cols_groups_max(d_out / 256); }
@@ -561,15 +563,16 @@ static int visg_pick_bm(int64_t M, int d_out, int forced) {
     }
     return best;
 }
-// workspace: [0, 256) header (status, counters, stamps) | exchange area | tile flags [ceil(M / 128) x NT] u32 | statistics [M + 256][NT] x 8 B
+// workspace: [0, 256) header (status, counters, stamps) | exchange area | tile flags [<= 16,384] u32 (64 KiB) | statistics [M + 256][NT] x 8 B
 size_t visproj_gemm_exchange_bytes(int d_out) {
     const size_t NT = (size_t)(d_out / 256);
     return (size_t)2 * visg_teams_max(d_out) * NT * NT * 256 * 2 * 8;
 }
-static size_t visg_flags_bytes(int64_t M, int d_out) { return (((size_t)((M + 127) / 128) * (size_t)(d_out / 256) * 4) + 255) / 256 * 256; }
+// (the flag area has ONE size whatever M: callers share a workspace between launches of different sizes, and a smaller launch's
+//  statistics must never land where a larger launch looks for its flags)
 size_t visproj_gemm_workspace_bytes(int64_t M, int F, int d_out) {
     if (!visproj_gemm_applies(M, F, d_out, 0)) return 0;
-    return 256 + visproj_gemm_exchange_bytes(d_out) + visg_flags_bytes(M, d_out) + (size_t)(M + 256) * (size_t)(d_out / 256) * 8;
+    return 256 + visproj_gemm_exchange_bytes(d_out) + VISG_FLAGS_B + (size_t)(M + 256) * (size_t)(d_out / 256) * 8;
 }
 
 template <int BM, int BK, int NSLOT, bool SPREAD>
@@ -582,7 +585,7 @@ static hipError_t launch_visg(VisGemmArgs& a, uint8_t* ws, hipStream_t stream) {
     a.xch = reinterpret_cast<unsigned long long*>(ws + 256);
     const size_t xch_b = visproj_gemm_exchange_bytes(a.d_out);
     a.flags = reinterpret_cast<unsigned*>(ws + 256 + xch_b);
-    a.stats = reinterpret_cast<unsigned long long*>(ws + 256 + xch_b + visg_flags_bytes(a.M, a.d_out));
+    a.stats = reinterpret_cast<unsigned long long*>(ws + 256 + xch_b + VISG_FLAGS_B);
     if (a.spin_limit == 0) a.spin_limit = VISG_MAX_SPIN;
     auto kern = visproj_gemm_kernel<BM, BK, NSLOT, SPREAD>;
     // residency: a team's members must run concurrently, which one workgroup per CU and a grid no larger than the device's CU count

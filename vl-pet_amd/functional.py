@@ -267,6 +267,9 @@ K1_BWD_PREVIOUS_SPLIT = False
 # activations: dq = dy * y * (1 - g), so pass 1 recomputes the gate's up projection only (vlpet_adapter_gate_bwd_saved_y).
 # False = from x2 (recompute h = s2 * x2 + sd * up_A(z_a)), the rounds 2-4 form.
 K1_BWD_FROM_OUTPUT = True
+# round 6: pass 2 of the gated backward (r <= 96) sums its row-chunk partials inside the launch (csrc/cols_reduce.h).  True = the
+# round-3 form (partial slabs + a finalize launch, ABI phases bit 5) for same-box A/Bs; the results are bit-identical.
+K1_BWD_FINALIZE_LAUNCH = False
 
 WEIGHTS_EPOCH = 0
 # Part of the keys of the derived copies of FROZEN tensors (fused q|k|v weight, padded LM head, fp32 LayerNorm copies, the
@@ -665,6 +668,8 @@ class _AdapterGateFn(torch.autograd.Function):
         ctx.link = None
 
         def phase(ph, a):       # one or both halves of the backward, with or without the forward's saved activations
+            if K1_BWD_FINALIZE_LAUNCH:
+                ph |= 32            # (A/B: the round-3 form -- partial slabs + a finalize launch -- instead of the in-launch reduce-scatter)
             if act is not None and yf is not None:
                 return lib.vlpet_adapter_gate_bwd_saved_y(ph, a[0], a[1], a[2], yf.data_ptr(), act.data_ptr(), a[3], a[4], _ptr(dx1_in),
                                                           *a[5:])
@@ -705,9 +710,9 @@ class _AdapterGateFn(torch.autograd.Function):
         else:       # same work, its kernels bracketed separately
             rc = TIMER.bracket("k1_bwd_rows", M, lambda: phase(1, args))
             two_pass = act is not None and lib.vlpet_adapter_gate_bwd_form(M, d, pk_a.tiles, io) == 2
-            if rc == 0 and two_pass:        # (pass 2 and the finalize launch of the column-parallel form)
+            if rc == 0 and two_pass:        # (pass 2 and -- where the form has one -- the finalize launch of the column-parallel form)
                 rc = TIMER.bracket("k1_bwd_wgrad", M, lambda: phase(2 | 8, args))
-                if rc == 0:
+                if rc == 0 and (K1_BWD_FINALIZE_LAUNCH or lib.vlpet_adapter_gate_bwd_finalize_launch(M, d, pk_a.tiles, io) == 1):
                     rc = TIMER.bracket("k1_bwd_fin", M, lambda: phase(16, args))
             elif rc == 0:
                 rc = TIMER.bracket("k1_bwd_wgrad", M, lambda: phase(2, args))
