@@ -131,6 +131,12 @@ int vlpet_adapter_gate_bwd_form(int64_t M, int d, int tiles, int io_dtype);
  * same-box A/Bs.  The reduce-scatter's control words are zeroed by pass 1, so `phases` = 2 alone presumes that pass 1 of the same
  * backward ran on the same workspace before (as the bench's per-kernel brackets do). */
 int vlpet_adapter_gate_bwd_finalize_launch(int64_t M, int d, int tiles, int io_dtype);
+/* Process-wide: 0 = the column-parallel backward passes (gated K1 at r <= 96, K2, K3) always leave their partial slabs to a finalize
+ * launch; 1 (default) = they sum them inside the launch.  Turn it off where other kernels run BESIDE the backward (gradient
+ * collectives on their own stream overlapping it, a second process on the device): a workgroup waiting for partners that cannot
+ * start keeps its CU for as long as the foreign kernel lasts (bounded: ~3 ms, then it gives up and the last arriver sums its slice --
+ * results unchanged, time lost), where the two-launch form runs in two rounds.  Returns the previous setting. */
+int vlpet_set_in_launch_reduce(int on);
 
 /* Dropout seeds under graph replay (train.Trainer(graph=True): forward + backward of a step captured once with hipGraph and replayed).
  * A replayed launch repeats its kernel arguments, so the per-call `seed` values of the dropout-carrying entry points below

@@ -48,5 +48,5 @@ def apply():
     put(VF, "DEFER_FINALIZE", on("VLPET_DEFER_FINALIZE"))                       # weight-gradient finalize launches queued and issued 16 per launch at the end of the backward (default off: no gain)
     put(VF, "FINALIZE_SIDE_STREAM", on("VLPET_FINALIZE_SIDE_STREAM"))          # captured steps: K1's finalize launch as a parallel branch of the graph (default off: slower)
     put(VF, "K1_BWD_FROM_OUTPUT", not on("VLPET_K1_BWD_FROM_X2"))               # gated K1 backward from the forward's output y (default) | from x2
-    put(VF, "K1_BWD_FINALIZE_LAUNCH", on("VLPET_FINALIZE_LAUNCH"))             # round-3 form of the K1 / K2 / K3 backward: partial slabs + a finalize launch (default: in-launch reduce-scatter)
+    put(TR, "IN_LAUNCH_REDUCE", not on("VLPET_FINALIZE_LAUNCH"))               # VLPET_FINALIZE_LAUNCH=1: the K1 / K2 / K3 backward passes end in a finalize launch (round 3) instead of the in-launch reduce-scatter
     return changed

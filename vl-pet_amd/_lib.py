@@ -51,6 +51,7 @@ SIGNATURES = {
     "vlpet_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
     "vlpet_adapter_gate_bwd_form": (c_int, [c_int64, c_int, c_int, c_int]),
     "vlpet_adapter_gate_bwd_finalize_launch": (c_int, [c_int64, c_int, c_int, c_int]),
+    "vlpet_set_in_launch_reduce": (c_int, [c_int]),
     "vlpet_debug_build": (c_int, []),
     "vlpet_test_hold_cus": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p]),
     "vlpet_set_seed_counter": (c_int, [c_void_p]),

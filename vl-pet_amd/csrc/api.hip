@@ -156,6 +156,13 @@ extern "C" int vlpet_set_seed_counter(const uint64_t* device_counter) {
     return 0;
 }
 
+// Round 6: the column-parallel backward passes (gated K1 at r <= 96, K2 / K3) sum their row-chunk partials inside the launch
+// (cols_reduce.h) -- unless the caller has said that OTHER kernels may run beside the backward (gradient collectives on their own
+// stream, a second process on the device): a workgroup that waits for partners which cannot start holds its CU for as long as the
+// foreign kernel lasts, where the two-launch form simply runs in two rounds.  Process-wide, like the seed counter; default on.
+static std::atomic<int> g_in_launch_reduce{1};
+extern "C" int vlpet_set_in_launch_reduce(int on) { return g_in_launch_reduce.exchange(on != 0 ? 1 : 0); }
+
 // p in [0, 1): explicit mask (keep_mask != NULL) or the in-kernel generator keyed by `seed`; p == 0: no dropout
 static int make_drop(const uint8_t* keep_mask, float p, uint64_t seed, uint8_t* keep_out, DropSpec* ds) {
     if (!(p >= 0.f && p < 1.f)) return VLPET_E_SHAPE;
@@ -438,10 +445,10 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     const bool rows2 = !two_pass && pet_gate_bwd2_applies(b);
     // without a gate (K2, adapter-only K1, K3 without dropout), bf16, saved activations, whole call: pass 1 (dpre) + the
     // column-parallel pass of pet_cols_ng.hip (dx and both weight gradients from one read of dy and x)
-    const bool ng2 = !gate && phases == 3 && vlpet_tuning().ng2 != 0 && ng_two_pass_applies(b, io_dtype == VLPET_F32);
+    const bool ng2 = !gate && (phases & ~32) == 3 && vlpet_tuning().ng2 != 0 && ng_two_pass_applies(b, io_dtype == VLPET_F32);
     // round 6: pass 2 sums its row-chunk partials inside the launch (cols_reduce.h) -- no finalize launch; `phases` bit 5 keeps the
     // round-3 two-launch form (same-box A/Bs; the results are bit-identical)
-    const bool red4 = cols4 && !cols6 && !(phases & 32);
+    const bool red4 = cols4 && !cols6 && !(phases & 32) && g_in_launch_reduce.load() != 0 && vlpet_tuning().cols_red != 0;
     if (red4) { b.red_ctrl = reinterpret_cast<unsigned*>(ws + w.red_ctrl); b.red_words = (d / 128) * COLS_RED_STRIDE; }
     int gs3 = 0, ng3 = 0;
     if (ng2) {
@@ -457,8 +464,10 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
         WgradJob& J1 = g.job[1];                        // dWu[f,c] = sd * sum_m dy[m,f] z[m,c];  dbu = sd * column sums of dy
         J1.P = b.z_a; J1.ldp = ldp; J1.pcols = ldp; J1.X = dy; J1.ldx = d; J1.xcols = d; J1.drop = NO_DROP; J1.has_drop = 0;
         J1.scale = sd; J1.out = dwu; J1.ldo = r; J1.transposed = 1; J1.out_rows = r; J1.colsum_x = dbu; J1.colsum_p = nullptr;
+        const bool red2 = !(phases & 32) && g_in_launch_reduce.load() != 0 && vlpet_tuning().cols_red != 0;            // round 6: pass 2 sums its row chunks itself (cols_reduce.h); bit 5: the finalize launch
+        if (red2) { b.red_ctrl = reinterpret_cast<unsigned*>(ws + w.red_ctrl); b.red_words = (d / 128) * COLS_RED_STRIDE; }
         hipError_t e = launch_ng_two_pass(b, g, 3, (hipStream_t)stream);
-        if (e != hipSuccess) return (int)e;
+        if (e != hipSuccess || red2) return herr(e);
         return herr(launch_wgrad_finalize(g, (hipStream_t)stream));
     }
     if (phases & 1) {
@@ -582,6 +591,7 @@ extern "C" int vlpet_adapter_gate_bwd_finalize_launch(int64_t M, int d, int tile
     PetBwdArgs b{};
     b.M = M; b.d = d; b.RT = tiles; b.flags = PET_GATE; b.saved = &b; b.drop = NO_DROP;
     if (k1_cols6_applies(b, io_dtype == VLPET_F32)) return 1;
+    if (k1_cols_applies(b, io_dtype == VLPET_F32)) return (g_in_launch_reduce.load() != 0 && vlpet_tuning().cols_red != 0) ? 0 : 1;
     return 0;
 }
 

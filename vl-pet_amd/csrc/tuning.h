@@ -31,6 +31,8 @@ struct VlpetTuning {
     int ng2 = 1;            // VLPET_NG2=0: row kernel + streaming weight gradients for the backward without a gate instead of the two-pass form
     int fwd2p = -1;         // VLPET_FWD2P: gated forward of the training form: -1 by shape (k1_fwd2p_preferred), 0 one-kernel (pet_gate_fwd.hip), 1 two-pass
                             //   (pet_fwd2p.hip), 2 = pass A only, 3 = pass B only (timing)
+    int cols_red = 1;       // VLPET_COLS_RED=0: the column-parallel backward passes leave partial slabs for a finalize launch (round 3) instead of
+                            //   summing their row chunks inside the launch (round 6, cols_reduce.h)
     int dbg = 0;            // VLPET_DBG: ablation / stamp bits
 };
 
@@ -42,7 +44,7 @@ inline const VlpetTuning& vlpet_tuning() {
         rd("VLPET_RG", v.rg); rd("VLPET_BWD2", v.bwd2); rd("VLPET_BWD3", v.bwd3); rd("VLPET_BWD3_UNITS", v.bwd3_units);
         rd("VLPET_BWD3_FORM", v.bwd3_form); rd("VLPET_K4_WAVES4", v.k4_waves4); rd("VLPET_WGRAD_WGS", v.wgrad_wgs);
         rd("VLPET_WGRAD_TR", v.wgrad_tr); rd("VLPET_WGRAD_STREAM", v.wgrad_stream); rd("VLPET_WGRAD_NSTG", v.wgrad_nstg);
-        rd("VLPET_WGS_MODE", v.wgs_mode); rd("VLPET_ATTN_OCC", v.attn_occ); rd("VLPET_ATTN_NW", v.attn_nw); rd("VLPET_DBG", v.dbg); rd("VLPET_DZ2", v.dz2); rd("VLPET_DZ6", v.dz6); rd("VLPET_COLS6Y", v.cols6y); rd("VLPET_DZ6C", v.dz6c); rd("VLPET_LORA8_BWD", v.lora8_bwd); rd("VLPET_DZ2_FSPLIT", v.dz2_fsplit); rd("VLPET_K4_WGRAD2", v.k4_wgrad2); rd("VLPET_NG2", v.ng2); rd("VLPET_FWD2P", v.fwd2p);
+        rd("VLPET_WGS_MODE", v.wgs_mode); rd("VLPET_ATTN_OCC", v.attn_occ); rd("VLPET_ATTN_NW", v.attn_nw); rd("VLPET_DBG", v.dbg); rd("VLPET_DZ2", v.dz2); rd("VLPET_DZ6", v.dz6); rd("VLPET_COLS6Y", v.cols6y); rd("VLPET_DZ6C", v.dz6c); rd("VLPET_LORA8_BWD", v.lora8_bwd); rd("VLPET_DZ2_FSPLIT", v.dz2_fsplit); rd("VLPET_K4_WGRAD2", v.k4_wgrad2); rd("VLPET_NG2", v.ng2); rd("VLPET_FWD2P", v.fwd2p); rd("VLPET_COLS_RED", v.cols_red);
         return v;
     }();
     return t;

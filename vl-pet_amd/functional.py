@@ -268,7 +268,9 @@ K1_BWD_PREVIOUS_SPLIT = False
 # False = from x2 (recompute h = s2 * x2 + sd * up_A(z_a)), the rounds 2-4 form.
 K1_BWD_FROM_OUTPUT = True
 # round 6: pass 2 of the gated backward (r <= 96) sums its row-chunk partials inside the launch (csrc/cols_reduce.h).  True = the
-# round-3 form (partial slabs + a finalize launch, ABI phases bit 5) for same-box A/Bs; the results are bit-identical.
+# round-3 form (partial slabs + a finalize launch, ABI phases bit 5) for same-box A/Bs; the results are bit-identical.  (The
+# library-wide switch vlpet_set_in_launch_reduce -- train.Trainer turns it off where gradient collectives overlap the backward --
+# covers K2 / K3 as well.)
 K1_BWD_FINALIZE_LAUNCH = False
 
 WEIGHTS_EPOCH = 0

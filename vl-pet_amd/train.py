@@ -533,6 +533,7 @@ CPU_OPTIMIZER_FACTORY = None
 _REGISTERED_SEED_CTR = None     # address of the device step counter currently registered with the library (Trainer.enable_graph / close)
 MAX_GRAPHS = 16              # captured step shapes a trainer keeps (least recently replayed evicted); ragged data beyond it runs eager + capture
 LABEL_CHECK_EVERY = 100      # steps between reads of the device-side bad-label tally (0: never)
+IN_LAUNCH_REDUCE = True         # A/B switch (tools/ab_switches.py): False = the K1 / K2 / K3 backward passes always end in a finalize launch (round 3)
 DEFER_PARAM_REDUCES = True      # A/B switch (tools/ab_switches.py): False = one reduce launch per parameter gradient, as before round 4
 
 
@@ -659,10 +660,17 @@ class Trainer:
             # parameter-gradient reductions of this backward (bias column sums, LayerNorm gradients) as one batched launch at its
             # end -- unless bucket all-reduces start from inside the backward (they would read the buckets before the flush)
             VF.DEFER_REDUCES = DEFER_PARAM_REDUCES and ((not self.flat.dp) or self.flat.defer)
+            # ... and the column-parallel backward passes sum their row-chunk partials inside the launch (csrc/cols_reduce.h) only while
+            # nothing else runs beside the backward: with bucket all-reduces overlapping it (or the weight gradients on a side stream) a
+            # workgroup waiting for partners that cannot start would hold its CU for the collective's duration -- the two-launch form then
+            from . import _lib
+            was = _lib.load().vlpet_set_in_launch_reduce(
+                1 if IN_LAUNCH_REDUCE and VF.WGRAD_STREAM is None and ((not self.flat.dp) or self.flat.defer) else 0)
             try:
                 loss.backward()
                 VF.flush_reduces()
             finally:
+                _lib.load().vlpet_set_in_launch_reduce(was)
                 VF.DEFER_REDUCES = False
                 VF.discard_pending()              # (empty after a clean flush)
                 VF._FIN_KEEP.clear()
