@@ -125,14 +125,14 @@ int vlpet_adapter_gate_bwd_phase(int phases, const void* dy, const void* x1, con
  * 0 = row kernel + weight-gradient kernels; < 0: bad arguments.  (What a bench labels its kernel brackets with.) */
 int vlpet_adapter_gate_bwd_form(int64_t M, int d, int tiles, int io_dtype);
 /* 1: that form ends in a separate finalize launch at this shape (`phases` bit 4 runs it alone); 0: it does not -- since round 6 the
- * column-parallel pass at r, r_g <= 96 sums its row-chunk partials INSIDE the launch (csrc/cols_reduce.h: the workgroups of a column
+ * column-parallel pass at r, r_g <= 96 and M >= 8,192 rows sums its row-chunk partials INSIDE the launch (csrc/cols_reduce.h: the workgroups of a column
  * block each take a slice once all of them have published; bounded waits, the last arriver finishes what an owner gave up, results
  * bit-identical to the two-launch form).  `phases` bit 5 (32) of the *_bwd_saved* entry points keeps the round-3 two-launch form for
  * same-box A/Bs.  The reduce-scatter's control words are zeroed by pass 1, so `phases` = 2 alone presumes that pass 1 of the same
  * backward ran on the same workspace before (as the bench's per-kernel brackets do). */
 int vlpet_adapter_gate_bwd_finalize_launch(int64_t M, int d, int tiles, int io_dtype);
-/* Process-wide: 0 = the column-parallel backward passes (gated K1 at r <= 96, K2, K3) always leave their partial slabs to a finalize
- * launch; 1 (default) = they sum them inside the launch.  Turn it off where other kernels run BESIDE the backward (gradient
+/* Process-wide: 0 = pass 2 of the gated K1 backward always leaves its partial slabs to a finalize launch; 1 (default) = at r <= 96 and
+ * from 8,192 rows it sums them inside the launch (below that the finalize launch measured ahead).  Turn it off where other kernels run BESIDE the backward (gradient
  * collectives on their own stream overlapping it, a second process on the device): a workgroup waiting for partners that cannot
  * start keeps its CU for as long as the foreign kernel lasts (bounded: ~3 ms, then it gives up and the last arriver sums its slice --
  * results unchanged, time lost), where the two-launch form runs in two rounds.  Returns the previous setting. */

@@ -665,6 +665,76 @@ def golden_lowrank_vis(tag, gated, d=64, feat_dim=128, r=16, nh=4, rg=8, B=2, N=
 
 
 # -------------------------------------------------------- trainable-name lists
+# ------------------------------------------------------------------------- eager fallbacks ("else eager fallback")
+def golden_fallbacks():
+    """Reference outputs for the configurations the fused kernels do not cover and vl-pet_amd/eager.py runs as plain torch ops:
+    an Adapter with another non-linearity + track_z, the low-rank adapter, a rectangular and a fan_in_fan_out LoRA layer, the
+    VisualEmbedding with ONE LayerNorm over the sum."""
+    import torch.nn as nn
+    from adapters import AdapterController, AdapterConfig
+    from lora import LoRALinearController, LoraConfig
+    d, r, B, S = 64, 8, 2, 5
+    for tag, low_rank in (("fb_adapter_relu_trackz_d64_r8", False), ("fb_lowrank_adapter_d64", True)):
+        ac = AdapterConfig()
+        ac.tasks = ["vqa", "gqa"]; ac.input_dim = d; ac.d_model = d
+        ac.use_single_adapter = True; ac.share_down_sampler = False; ac.share_up_sampler = False
+        ac.shared_phm_rule_over_tasks = False
+        ac.track_z = True
+        ac.non_linearity = "relu"
+        ac.use_adapter_down_dim = True; ac.adapter_down_dim = r; ac.reduction_factor = 8
+        ac.use_parallel_adapter = True; ac.use_scaling_factor = True; ac.scaling_factor = 2.0
+        ac.low_rank_adapters = low_rank; ac.low_rank_rank = 2; ac.low_rank_w_init = "glorot-uniform"
+        gen = torch.Generator().manual_seed(20 + int(low_rank))
+        ctl = AdapterController(ac)
+        randomize(ctl, gen, std=0.2)
+        x = torch.randn(B, S, d, generator=gen).requires_grad_(True)
+        y = torch.randn(B, S, d, generator=gen).requires_grad_(True)
+        out = ctl(x, "gqa", y=y)
+        dy = torch.randn(out.shape, generator=gen)
+        out.backward(dy)
+        ad = ctl.adapters["gqa"]
+        params = {k.replace(".", "__"): T(v) for k, v in ad.state_dict().items()}
+        grads = {"g__" + k.replace(".", "__"): T(v.grad) for k, v in ad.named_parameters()}
+        save(tag, meta=np.array([d, r, B, S]), x=T(x), y=T(y), out=T(out), dy=T(dy), dx=T(x.grad), dyin=T(y.grad), z=T(ad.z),
+             state_keys=np.array(sorted(ctl.state_dict().keys())), **params, **grads)
+    for tag, din, dout, fifo in (("fb_lora_rect_64x48_r4", 64, 48, False), ("fb_lora_fanin_64_r4", 64, 64, True)):
+        lc = LoraConfig()
+        lc.lora_dim = 4; lc.lora_alpha = 32; lc.tasks = ["vqa", "nlvr"]; lc.use_single_lora = True
+        gen = torch.Generator().manual_seed(22 + int(fifo))
+        lin = LoRALinearController(din, dout, fan_in_fan_out=fifo, config=lc, bias=True)
+        randomize(lin, gen)
+        lin.eval()
+        x = torch.randn(7, din, generator=gen).requires_grad_(True)
+        out = lin(x, "nlvr")
+        dy = torch.randn(out.shape, generator=gen)
+        out.backward(dy)
+        save(tag, meta=np.array([din, dout, 4, 32, int(fifo)]), x=T(x), out=T(out), dy=T(dy), dx=T(x.grad), w=T(lin.weight), b=T(lin.bias),
+             a=T(lin.lora_As["nlvr"]), bb=T(lin.lora_Bs["nlvr"]), da=T(lin.lora_As["nlvr"].grad), dbb=T(lin.lora_Bs["nlvr"].grad),
+             dbias=T(lin.bias.grad))
+    # VisualEmbedding, one LayerNorm over the sum (use_vis_layer_norm, not individual_vis_layer_norm)
+    feat_dim, N = 128, 6
+    flags = list(VLPET_LARGE_FLAGS) + ["--feat_dim", str(feat_dim)]
+    config, args = make_config("bart", flags, d_model=d, heads=4, ffn=4 * d)
+    config.feat_dim = feat_dim; config.pos_dim = 4; config.vis_use_transformer = False
+    config.use_vis_order_embedding = True; config.use_vis_layer_norm = True; config.individual_vis_layer_norm = False
+    config.default_obj_order_ids = None; config.additional_visual_embedding_layers = 0
+    mod = load_vl_module("bart")
+    gen = torch.Generator().manual_seed(24)
+    table = nn.Embedding(200, d)
+    ve = mod.VisualEmbedding(config, table)
+    randomize(ve, gen, std=0.05)
+    with torch.no_grad():
+        ve.layer_norm.weight.add_(1.0)
+    feats = torch.randn(B, N, feat_dim, generator=gen); pos = torch.rand(B, N, 4, generator=gen)
+    out = ve(feats, pos)
+    dy = torch.randn(out.shape, generator=gen)
+    out.backward(dy)
+    params = {k.replace(".", "__"): T(v) for k, v in ve.state_dict().items()}
+    grads = {"g__" + k.replace(".", "__"): T(v.grad) for k, v in ve.named_parameters() if v.grad is not None}
+    save("fb_visemb_sharedln_d64_f128", meta=np.array([d, feat_dim, B, N]), feats=T(feats), pos=T(pos), out=T(out), dy=T(dy),
+         obj_table=T(table.weight), **params, **grads)
+
+
 def golden_trainable_names():
     """Parameter-name lists + trainable flags for the VL-PET-large BART encoder/decoder layer
     under TrainerBase.unfreeze_parameters' substring rules (trainer_base.py:308-542).  The rule
@@ -694,6 +764,9 @@ def main():
         golden_lowrank_vis("lowrank_vis_gated_d64", gated=True)
         # the fe + fe * gate form; a second bottleneck geometry (r = 24 over 3 heads, r_g = 32, 3 x 11 rows)
         golden_lowrank_vis("lowrank_vis_gated_res_d64", gated=True, residual=True, r=24, nh=3, rg=32, B=3, N=11, seed=12)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "fallbacks":
+        golden_fallbacks()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "video":
         golden_vlbart_tiny("vlbart_tiny_video_d64", seed=11, video=True)

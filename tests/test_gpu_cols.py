@@ -150,7 +150,7 @@ def test_k1_from_x2_vs_oracle(kw):
         F.K1_BWD_FROM_OUTPUT = True
 
 
-@pytest.mark.parametrize("M,r", [(1, 96), (33, 96), (1000, 96), (3500, 96), (15272, 96), (28000, 96), (46648, 96), (777, 8), (5000, 32)])
+@pytest.mark.parametrize("M,r", [(8192, 96), (8193, 96), (9000, 8), (12000, 32), (15272, 96), (28000, 96), (46648, 96), (3500, 96)])
 @pytest.mark.parametrize("gate_mode", [1, 2])
 def test_in_launch_reduce_scatter_equals_the_finalize_launch(M, r, gate_mode):
     """Round 6 (csrc/cols_reduce.h): pass 2 sums its row-chunk partials inside the launch -- slices of a column block's slab, one per
@@ -167,9 +167,9 @@ def test_in_launch_reduce_scatter_equals_the_finalize_launch(M, r, gate_mode):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("held", [128, 248])
+@pytest.mark.parametrize("held", [64, 200])
 def test_in_launch_reduce_scatter_with_cus_held_by_another_stream(held):
-    """The reduce-scatter must not presume that the workgroups of a column block run at the same time.  Here 128 / 248 of the 256 CUs are
+    """The reduce-scatter must not presume that the workgroups of a column block run at the same time.  Here 64 / 200 of the 256 CUs are
     held by a spinning kernel on a second stream (100 KiB of LDS each: no pass-2 workgroup fits beside one), so the 240 workgroups of
     pass 2 run in several rounds: early ones wait for partners that cannot start, give up, and the LAST arriver of each column block
     sums their slices.  Outputs bit-identical to the undisturbed run."""

@@ -93,12 +93,11 @@ _SIX_TILE_CASES = [dict(M=1000, r=192, rg=192, nh=4, delta_scale=4.0, x2_scale=0
 _THREE_TILE_CASES = [dict(M=1000), dict(M=999, gate_mode=2, gate_scale=0.3), dict(M=777, r=8, rg=8, nh=4), dict(M=28000)]
 
 
-@pytest.mark.parametrize("switch", ["VLPET_DZ6C=1", "VLPET_COLS6Y=0", "VLPET_DZ6=2"])
+@pytest.mark.parametrize("switch", ["VLPET_DZ6=2"])
 def test_k1_six_tile_alternative_forms(switch):
-    """The forms of the K1 backward that are NOT the default, through the diagnosis build in a child process (see above): at r = 192 pass 1
-    as the chain-split eight-wave kernel (k1_dz6c_kernel: measured slower, kept), pass 2 on pet_cols6.hip although y is at hand, pass 1
-    on the four-wave kernel at every size; at r <= 96 pass 2 on pet_colsy.hip (from the forward's output, late products: measured slower, kept) -- against the oracle, incl. the additive
-    gate, the feature-split sizes and a full-size call."""
+    """The forms of the K1 backward at r = 192 that are NOT the default, through the diagnosis build in a child process (see above): pass 1 on
+    the four-wave kernel at every size -- against the oracle, incl. the additive gate, the
+    feature-split sizes and a full-size call."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dbg = os.path.join(root, "vl-pet_amd", "lib", "libvlpet_hip_dbg.so")
@@ -107,7 +106,7 @@ def test_k1_six_tile_alternative_forms(switch):
     k, v = switch.split("=")
     env = dict(os.environ, VLPET_LIB=dbg, **{k: v})
     code = _SIX_TILE_CHILD.format(tests=os.path.dirname(os.path.abspath(__file__)), root=root,
-                                  cases=repr(_THREE_TILE_CASES if k == "VLPET_COLSY" else _SIX_TILE_CASES))
+                                  cases=repr(_SIX_TILE_CASES))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 

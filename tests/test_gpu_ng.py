@@ -51,36 +51,6 @@ def test_k3_rank8_streaming_form_vs_oracle(M, d, r, p, explicit):
     _check(C.run_k3(torch.bfloat16, M=M, d=d, r=r, p=p, explicit_mask=explicit))
 
 
-_K3_STREAM_BWD_CHILD = """
-import sys, torch
-sys.path.insert(0, {tests!r}); sys.path.insert(0, {root!r})
-import gpu_cases as C
-from vlpet_amd import _lib
-assert _lib.load().vlpet_debug_build() == 1
-for kw in (dict(M=1, r=8), dict(M=130, r=8, p=0.1), dict(M=2500, r=8, p=0.1), dict(M=5000, r=4, p=0.0), dict(M=1000, d=256, r=8, p=0.1),
-           dict(M=777, d=512, r=3, p=0.1, explicit_mask=True), dict(M=28000, r=8, p=0.1)):
-    errs = C.run_k3(torch.bfloat16, **kw)
-    errs.pop("keep_frac", None)
-    assert max(errs.values()) <= 1e-2, (kw, errs)
-print("ok")
-"""
-
-
-def test_k3_rank8_streaming_backward_vs_oracle():
-    """The streaming row kernel for the K3 BACKWARD at lora_dim <= 8 (csrc/lora8.hip lora8_bwd_kernel; lora/controller.py:56-70) is not the
-    default (measured slower than the two-pass MFMA form: profiles/r05_k3_streaming_bwd_ab.txt); the diagnosis build runs it with
-    VLPET_LORA8_BWD=1 -- in a child process, against the oracle: one row, ragged sizes, ranks below 8, d = 256 / 512 / 768, the generator's
-    and an explicit mask (the backward reads the packed mask the forward saved either way), a full-size call."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    dbg = os.path.join(root, "vl-pet_amd", "lib", "libvlpet_hip_dbg.so")
-    if not os.path.exists(dbg):
-        pytest.skip("no diagnosis build vl-pet_amd/lib/libvlpet_hip_dbg.so")
-    env = dict(os.environ, VLPET_LIB=dbg, VLPET_LORA8_BWD="1")
-    code = _K3_STREAM_BWD_CHILD.format(tests=os.path.dirname(os.path.abspath(__file__)), root=root)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
 
 def test_k3_rank8_streaming_form_equals_the_mfma_form():
     """Same pack, same generator: the two forward forms give the same mask bit for bit, the same saved block, and outputs / gradients

@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from .adapter_modeling import Adapter
+from .adapter_modeling import Adapter, LowRankAdapter
 
 
 class AdapterController(nn.Module):
@@ -12,10 +12,11 @@ class AdapterController(nn.Module):
 
     def __init__(self, config):
         super().__init__()
-        if getattr(config, "low_rank_adapters", False) or getattr(config, "hypercomplex_adapters", False):
-            raise NotImplementedError("low-rank / hypercomplex adapters are outside the VL-PET hot path")
+        if getattr(config, "hypercomplex_adapters", False):
+            # Compacter's PHM layers (adapters/hypercomplex/): a baseline of the reference, out of scope per SURVEY.md sections 1 / 2
+            raise NotImplementedError("hypercomplex (PHM / Compacter) adapters are a baseline outside the VL-PET hot path (SURVEY.md section 2)")
         self.config = config
-        self.low_rank_adapters = False
+        self.low_rank_adapters = bool(getattr(config, "low_rank_adapters", False))     # eager fallback: adapter_modeling.LowRankAdapter
         self.hypercomplex_adapters = False
         self.tasks = config.tasks
         self.use_single_adapter = config.use_single_adapter
@@ -34,13 +35,14 @@ class AdapterController(nn.Module):
 
     def construct_adapters(self, tasks):
         adapters = nn.ModuleDict()
+        Adapter_ = LowRankAdapter if self.low_rank_adapters else Adapter
         if self.use_single_adapter:
-            shared = Adapter(self.config)
+            shared = Adapter_(self.config)
             for task in tasks:
                 adapters[task] = shared
         else:
             for task in tasks:
-                adapters[task] = Adapter(self.config)
+                adapters[task] = Adapter_(self.config)
             if self.share_up_sampler:
                 for task in tasks:
                     adapters[task].up_sampler = adapters[tasks[0]].up_sampler

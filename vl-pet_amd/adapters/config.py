@@ -24,8 +24,10 @@ class AdapterConfig:
     use_scaling_factor: bool = False
     scaling_factor: float = 1.0
     track_z: bool = False
-    # variants that are outside the hot path; must stay False
+    # variants outside the hot path: low-rank adapters run as plain torch ops (eager fallback), hypercomplex (PHM) ones are refused
     low_rank_adapters: bool = False
+    low_rank_w_init: str = "glorot-uniform"
+    low_rank_rank: int = 1
     hypercomplex_adapters: bool = False
     shared_phm_rule: bool = False
     shared_phm_rule_over_tasks: bool = False

@@ -162,6 +162,13 @@ extern "C" int vlpet_set_seed_counter(const uint64_t* device_counter) {
 // foreign kernel lasts, where the two-launch form simply runs in two rounds.  Process-wide, like the seed counter; default on.
 static std::atomic<int> g_in_launch_reduce{1};
 extern "C" int vlpet_set_in_launch_reduce(int on) { return g_in_launch_reduce.exchange(on != 0 ? 1 : 0); }
+// ... and only where it was measured ahead (profiles/r06_in_launch_reduce_ab.txt, ABBA on one box): the configs[1] step at the full
+// batch (15,272-46,648 rows per call) 27.92 / 27.94 k samples/s with it against 27.73 / 27.45 k with the finalize launch, the K1
+// backward op 137.5 vs 138.9 us; at the per-rank sizes of an 8-GPU run (1,900-5,800 rows, replayed graph) 5.45 / 5.47 ms per step with it
+// against 5.43 / 5.43 without -- so small launches keep the finalize launch
+static bool k1_in_launch_reduce(int64_t M) {
+    return g_in_launch_reduce.load() != 0 && vlpet_tuning().cols_red != 0 && (vlpet_tuning().cols_red == 2 || M >= 8192);
+}
 
 // p in [0, 1): explicit mask (keep_mask != NULL) or the in-kernel generator keyed by `seed`; p == 0: no dropout
 static int make_drop(const uint8_t* keep_mask, float p, uint64_t seed, uint8_t* keep_out, DropSpec* ds) {
@@ -372,9 +379,6 @@ static BwdWs bwd_ws(int64_t M, int d, int tiles, bool gate, int io_dtype) {
     o += align256(wgrad_workspace_bytes(njobs, tiles, d, chunks));
     w.red_ctrl = o;
     o += align256((size_t)(d >= 128 ? d / 128 : 1) * COLS_RED_STRIDE * 4);
-    // the streaming K3 backward at r <= 8 (lora8.hip) keeps one [dA | dB] partial per workgroup at the start of the workspace instead
-    if (!gate && tiles == 1 && io_dtype != VLPET_F32 && d % 256 == 0 && d <= 768 && o < align256(lora8_bwd_part_bytes(M, d, 8)))
-        o = align256(lora8_bwd_part_bytes(M, d, 8));
     w.total = o;
     return w;
 }
@@ -445,10 +449,10 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
     const bool rows2 = !two_pass && pet_gate_bwd2_applies(b);
     // without a gate (K2, adapter-only K1, K3 without dropout), bf16, saved activations, whole call: pass 1 (dpre) + the
     // column-parallel pass of pet_cols_ng.hip (dx and both weight gradients from one read of dy and x)
-    const bool ng2 = !gate && (phases & ~32) == 3 && vlpet_tuning().ng2 != 0 && ng_two_pass_applies(b, io_dtype == VLPET_F32);
+    const bool ng2 = !gate && phases == 3 && vlpet_tuning().ng2 != 0 && ng_two_pass_applies(b, io_dtype == VLPET_F32);
     // round 6: pass 2 sums its row-chunk partials inside the launch (cols_reduce.h) -- no finalize launch; `phases` bit 5 keeps the
     // round-3 two-launch form (same-box A/Bs; the results are bit-identical)
-    const bool red4 = cols4 && !cols6 && !(phases & 32) && g_in_launch_reduce.load() != 0 && vlpet_tuning().cols_red != 0;
+    const bool red4 = cols4 && !cols6 && !(phases & 32) && k1_in_launch_reduce(M);
     if (red4) { b.red_ctrl = reinterpret_cast<unsigned*>(ws + w.red_ctrl); b.red_words = (d / 128) * COLS_RED_STRIDE; }
     int gs3 = 0, ng3 = 0;
     if (ng2) {
@@ -464,10 +468,10 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
         WgradJob& J1 = g.job[1];                        // dWu[f,c] = sd * sum_m dy[m,f] z[m,c];  dbu = sd * column sums of dy
         J1.P = b.z_a; J1.ldp = ldp; J1.pcols = ldp; J1.X = dy; J1.ldx = d; J1.xcols = d; J1.drop = NO_DROP; J1.has_drop = 0;
         J1.scale = sd; J1.out = dwu; J1.ldo = r; J1.transposed = 1; J1.out_rows = r; J1.colsum_x = dbu; J1.colsum_p = nullptr;
-        const bool red2 = !(phases & 32) && g_in_launch_reduce.load() != 0 && vlpet_tuning().cols_red != 0;            // round 6: pass 2 sums its row chunks itself (cols_reduce.h); bit 5: the finalize launch
-        if (red2) { b.red_ctrl = reinterpret_cast<unsigned*>(ws + w.red_ctrl); b.red_words = (d / 128) * COLS_RED_STRIDE; }
+        // (the in-launch reduce-scatter of cols_reduce.h was built for this pass 2 as well and measured no gain: K2 backward 67.9 / 66.7 us
+        //  with it against 66.4 / 67.1 us with the finalize launch in the configs[1] step, profiles/r06_in_launch_reduce_ab.txt -- not kept)
         hipError_t e = launch_ng_two_pass(b, g, 3, (hipStream_t)stream);
-        if (e != hipSuccess || red2) return herr(e);
+        if (e != hipSuccess) return (int)e;
         return herr(launch_wgrad_finalize(g, (hipStream_t)stream));
     }
     if (phases & 1) {
@@ -559,7 +563,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
             return herr(launch_k1_cols(c, tiles, (hipStream_t)stream));
         }
         if (phases & 2) {
-            hipError_t e = cols6 ? (k1_cols6y_applies(c) ? launch_k1_cols6y(c, (hipStream_t)stream) : launch_k1_cols6(c, (hipStream_t)stream))
+            hipError_t e = cols6 ? launch_k1_cols6y(c, (hipStream_t)stream)
                                  : launch_k1_cols(c, tiles, (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
         }
@@ -578,7 +582,7 @@ static int run_bwd(const void* dy, const void* xa, const void* res, const void* 
 extern "C" int vlpet_adapter_gate_bwd_form(int64_t M, int d, int tiles, int io_dtype) {
     if (check_common(M, d, tiles, io_dtype)) return -1;
     PetBwdArgs b{};
-    b.M = M; b.d = d; b.RT = tiles; b.flags = PET_GATE; b.saved = &b; b.drop = NO_DROP;
+    b.M = M; b.d = d; b.RT = tiles; b.flags = PET_GATE; b.saved = &b; b.drop = NO_DROP; b.y = &b;      // (the default path hands the forward's output over)
     if (k1_cols_applies(b, io_dtype == VLPET_F32) || k1_cols6_applies(b, io_dtype == VLPET_F32)) return 2;
     if (pet_gate_bwd3_applies(b)) return 1;
     return 0;
@@ -589,9 +593,9 @@ extern "C" int vlpet_adapter_gate_bwd_form(int64_t M, int d, int tiles, int io_d
 extern "C" int vlpet_adapter_gate_bwd_finalize_launch(int64_t M, int d, int tiles, int io_dtype) {
     if (check_common(M, d, tiles, io_dtype)) return -1;
     PetBwdArgs b{};
-    b.M = M; b.d = d; b.RT = tiles; b.flags = PET_GATE; b.saved = &b; b.drop = NO_DROP;
+    b.M = M; b.d = d; b.RT = tiles; b.flags = PET_GATE; b.saved = &b; b.drop = NO_DROP; b.y = &b;
     if (k1_cols6_applies(b, io_dtype == VLPET_F32)) return 1;
-    if (k1_cols_applies(b, io_dtype == VLPET_F32)) return (g_in_launch_reduce.load() != 0 && vlpet_tuning().cols_red != 0) ? 0 : 1;
+    if (k1_cols_applies(b, io_dtype == VLPET_F32)) return k1_in_launch_reduce(M) ? 0 : 1;
     return 0;
 }
 
@@ -723,20 +727,6 @@ extern "C" int vlpet_lora_delta_bwd_saved(const void* dy, const void* x, const v
     if (!saved) return VLPET_E_NULL;
     DropSpec ds;
     if (int rc = make_drop(keep_mask, p, seed, nullptr, &ds)) return rc;
-    // r <= 8: the streaming row kernel (lora8.hip, round 5) -- no matrix cores; mask = the packed one the forward left behind z
-    if (tiles == 1 && vlpet_tuning().lora8_bwd != 0 && lora8_bwd_applies(M, d, r, io_dtype == VLPET_F32, ds)) {
-        if (int rc = check_common(M, d, tiles, io_dtype)) return rc;
-        if (!dy || !x || !packed || !dx || !da || !db || !workspace) return VLPET_E_NULL;
-        if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(saved) || !aligned16(packed) || !aligned16(workspace)) return VLPET_E_ALIGN;
-        if (r <= 0) return VLPET_E_RANK;
-        if (workspace_bytes < lora8_bwd_part_bytes(M, d, r)) return VLPET_E_WORKSPACE;
-        if (drop_active(ds)) {
-            ds.bits = reinterpret_cast<const uint8_t*>(saved) + saved_stride(M, tiles, io_dtype);
-            ds.keep = nullptr;
-        }
-        return herr(launch_lora8_bwd(dy, x, saved, reinterpret_cast<const uint8_t*>(packed), ds, dx, da, db, reinterpret_cast<float*>(workspace),
-                                     M, d, r, scaling, (hipStream_t)stream));
-    }
     return run_bwd(dy, x, nullptr, nullptr, packed, nullptr, ds, dx, nullptr,
                    da, nullptr, db, nullptr, nullptr, nullptr, nullptr, nullptr, r, 0,
                    workspace, workspace_bytes, M, d, tiles, 1.f, scaling, 1.f, PET_ACT_IDENTITY,

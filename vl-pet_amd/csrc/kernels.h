@@ -211,9 +211,7 @@ hipError_t launch_k1_cols(const ColzArgs& c, int RT, hipStream_t stream);
 // the same pass for six tiles (r = 192; pet_cols6.hip: four roles per column quarter, 64-column workgroups)
 void k1_cols6_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk);
 bool k1_cols6_applies(const PetBwdArgs& a, int io_fp32);
-hipError_t launch_k1_cols6(const ColzArgs& c, hipStream_t stream);
 // ... with the up-side weight gradients one step late and the elementwise block from the forward's output (pet_cols6y.hip)
-bool k1_cols6y_applies(const ColzArgs& c);
 hipError_t launch_k1_cols6y(const ColzArgs& c, hipStream_t stream);
 
 // K4: out = LN(feats . W^T + b) * gamma + beta (+ R); optionally stores xhat and rstd for the backward
@@ -299,11 +297,6 @@ struct Lora8Args {
 };
 bool lora8_applies(int64_t M, int d, int r, int io_fp32);
 hipError_t launch_lora8_fwd(const Lora8Args& a, hipStream_t stream);
-// ... and its backward (round 5): dx, dA [r, d], dB [d, r] from dy, x, the forward's saved z and the same mask; part: lora8_bwd_part_bytes of workspace
-size_t lora8_bwd_part_bytes(int64_t M, int d, int r);
-bool lora8_bwd_applies(int64_t M, int d, int r, int io_fp32, const DropSpec& drop);
-hipError_t launch_lora8_bwd(const void* dy, const void* x, const void* z, const uint8_t* pk, const DropSpec& drop, void* dx, float* da, float* db,
-                            float* part, int64_t M, int d, int r, float scaling, hipStream_t stream);
 hipError_t launch_tail_reduce(const float* part, int nb, int d, float* dgamma, float* dbeta, hipStream_t stream);
 hipError_t launch_colsum(const void* x, int64_t M, int n, float* part, float* out, int io_fp32, hipStream_t stream);
 hipError_t launch_colsum_partial(const void* x, int64_t M, int n, float* part, int io_fp32, hipStream_t stream);

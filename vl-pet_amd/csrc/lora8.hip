@@ -186,318 +186,9 @@ __global__ __launch_bounds__(L8_WAVES * 64) void lora8_fwd_kernel(Lora8Args a) {
     }
 }
 
-// ---- the backward of the same op as a streaming row kernel (round 5; VERDICT r04 "missing" #5: it ran on the 32-wide MFMA tile).
-//     dz_c = scaling * sum_f dy_f B[f][c]          dx_f = keep_f / (1 - p) * sum_c dz_c A[c][f]
-//     dA[c][f] = sum_m dz_c (keep_f / (1 - p) x_f)  dB[f][c] = scaling * sum_m dy_f z_c            (z = the forward's saved, bf16-rounded sums)
-// Eight contractions of eight per element again -- but the weight gradients are 2 x 96 fp32 accumulators per lane (a lane owns 12 features
-// at d = 768), the two weight slices 2 x 48 registers, and VALU instructions cannot accumulate into the AGPR half of the file: no wave
-// can hold all of it.  So a workgroup is EIGHT waves in two roles, two waves per SIMD (<= 256 registers):
-//   RB (waves 0-3): dz (48 dot2 + the reduce-scatter of the forward), dx (48 dot2 on c-pairs) -> the dx row; dB += (scaling dy) (x) z
-//   WA (waves 4-7): dz again (its own copy: no hand-over between waves, no barrier per row), dA += dz (x) dropout(x)
-// Wave w of each role walks the same rows (blockIdx * 4 + w, stride 4 * grid), so dy is fetched from HBM once and once more from L2.
-// At the end the four waves of a role add their slices through LDS and the workgroup writes ONE partial [dA | dB] in the final layouts;
-// launch_tail_reduce sums the workgroups' partials (deterministic).  Grid = one workgroup per CU (fewer for short inputs): 256 x 48 KiB
-// of partials at r = 8, whatever the rows.  d <= 768 (at d = 1024 role RB needs 64 + 64 + 128 registers: the MFMA path keeps it).
-// MEASURED (profiles/r05_k3_streaming_bwd_ab.txt): parity-green and slower than the two-pass MFMA form it was meant to replace -- 54.3 vs 47.8 us
-// at 28,000 rows, 26.5 vs 19.3 at 2,500, the LoRA r = 8 step 19.14 vs 18.89 ms.  ~20 us do not depend on the rows (decoding the weight slices
-// from the packs, the LDS sums, 12.6 MB of partials through a reduce launch), and the row loop itself -- ~300 VALU instructions per row in
-// role RB, a third of them the 96 accumulator FMAs -- streams at 3.3 TB/s, no better than pass 1 + pass 2 of the matrix-core form, whose
-// padded 32-wide tile costs MFMA cycles that were idle anyway.  Unlike the forward, the backward is not a contraction of eight per
-// element: its weight gradients are two rank-8 OUTER products per row, and outer products are what the matrix cores are for.  Off by
-// default (csrc/tuning.h lora8_bwd); kept with its test for the measurement.
-struct Lora8BwdArgs {
-    const void* dy; const void* x; const void* z;   // [M, d] bf16, [M, d] bf16, [M, 32] bf16 (the forward's saved sums)
-    const uint8_t* pk;
-    DropSpec drop;          // generator (seed) or the forward's packed mask (bits); an explicit byte mask goes to the MFMA path
-    void* dx;
-    float* part;            // [gridDim.x][2][r * d]
-    int64_t M; int d; int r;
-    float scaling;
-};
-
-template <int NCH, int DROP>      // DROP: 0 none, 1 generator, 2 packed bits
-__global__ __launch_bounds__(512, 2) void lora8_bwd_kernel(Lora8BwdArgs a) {
-    constexpr int D = 256 * NCH, NG = D / 8, NR = (NG + 63) / 64;
-    constexpr int NV = NCH * 32;                        // accumulators per lane and role
-    extern __shared__ __attribute__((aligned(16))) float l8sm[];         // [4 waves][NV][64 lanes] for the final sums
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int role = wave >> 2, wr = wave & 3;          // 0 RB, 1 WA
-    const DropSpec drop = DROP ? drop_resolved(a.drop) : a.drop;
-    const float kscale = DROP ? drop.keep_scale : 1.0f, scaling = a.scaling;
-    const int r = a.r;
-    const PackGeom pg = pack_geom(1, D, 1);
-    const uint8_t* down = a.pk;
-    const uint8_t* up = a.pk + pg.pack_bytes;
-
-    // ---- resident weight slices of this lane's chunks, re-paired for the backward's contractions (decoding: see lora8_fwd_kernel):
-    //   bt[m][c][j] = (B[fc + 2j][c], B[fc + 2j + 1][c])   pairs over FEATURES: dz_c += <(dy_f, dy_f+1), bt>        (both roles)
-    //   ac[m][e][q] = (A[2q][fc + e], A[2q + 1][fc + e])   pairs over C:        dx_f  = sum_q <(dz_2q, dz_2q+1), ac>   (role RB)
-    uint32_t bt[NCH][8][2];
-#pragma unroll
-    for (int m = 0; m < NCH; ++m) {
-        const int fc = 256 * m + 4 * lane;
-        u32x4 wb[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int f = fc + e, T = f >> 6, rem = f & 63;
-            const int hp = (rem >> 5) & 1, v2 = (rem >> 4) & 1, q = rem & 15, i = 8 * (q >> 2) + 4 * hp + (q & 3);
-            wb[e] = *reinterpret_cast<const u32x4*>(up + (size_t)((2 * T + v2) * 2) * 1024 + (size_t)i * 16);
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t lo = wb[2 * j][c >> 1], hi = wb[2 * j + 1][c >> 1];
-                bt[m][c][j] = (c & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
-            }
-    }
-
-    const uint8_t* dy = reinterpret_cast<const uint8_t*>(a.dy);
-    const uint8_t* x = reinterpret_cast<const uint8_t*>(a.x);
-    const uint8_t* zs = reinterpret_cast<const uint8_t*>(a.z);
-    uint8_t* dx = reinterpret_cast<uint8_t*>(a.dx);
-    const int64_t rstride = (int64_t)gridDim.x * 4;
-    const int64_t row_first = (int64_t)blockIdx.x * 4 + wr;
-    auto clampr = [&](int64_t rr) { return rr < a.M ? rr : a.M - 1; };
-    auto keep_flags = [&](const uint32_t (&gb)[NR], uint32_t (&kb)[NCH]) {   // this lane's chunks' flags from the groups the lanes hold
-#pragma unroll
-        for (int m = 0; m < NCH; ++m) {
-            const int g = 32 * m + (lane >> 1);
-            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((g & 63) << 2, (int)gb[(32 * m) >> 6 < NR ? (32 * m) >> 6 : 0]);
-            kb[m] = (v >> ((lane & 1) * 4)) & 0xfu;
-        }
-    };
-    auto group_bits = [&](int64_t row, uint32_t (&gb)[NR]) {            // group 64 rho + lane (DROP == 2: unconditional byte loads; 1: the generator)
-#pragma unroll
-        for (int rho = 0; rho < NR; ++rho) {
-            const int g = 64 * rho + lane;
-            const int gl = (NG % 64 == 0 || g < NG) ? g : 0;
-            if constexpr (DROP == 1) gb[rho] = keep8((row * D + 8 * gl) >> 3, drop.seed, drop.thr);
-            else if constexpr (DROP == 2) gb[rho] = drop.bits[row * (int64_t)(D >> 3) + drop_pos(gl)];
-            else gb[rho] = 0xffu;
-        }
-    };
-    auto mask_pairs = [&](u32x2& v, uint32_t kbm) {                      // clears the dropped halves of two packed pairs
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int lo = ((int)(kbm << (31 - 2 * q))) >> 31, hi = ((int)(kbm << (30 - 2 * q))) >> 31;
-            v[q] &= __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x07060100u);
-        }
-    };
-    auto dz_of = [&](const u32x2 (&dyr)[NCH], float (&dz)[8]) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) dz[c] = 0.f;
-#pragma unroll
-        for (int m = 0; m < NCH; ++m)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                dz[c] = dot2_bf16(dyr[m][0], bt[m][c][0], dz[c]);
-                dz[c] = dot2_bf16(dyr[m][1], bt[m][c][1], dz[c]);
-            }
-        wave_sum8(dz, lane);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) dz[c] *= scaling;
-    };
-    float* part = a.part + (size_t)blockIdx.x * 2 * (size_t)r * D;
-    auto stash = [&](const float (&acc)[NCH][4][8]) {
-#pragma unroll
-        for (int m = 0; m < NCH; ++m)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) l8sm[((size_t)wr * NV + (m * 32 + e * 8 + c)) * 64 + lane] = acc[m][e][c];
-    };
-    auto sum_phase = [&](int ph) {                                        // ph 0: dA [r, D]; ph 1: dB [D, r]
-        for (int i = threadIdx.x; i < NV * 64; i += 512) {
-            const int k = i >> 6, ln = i & 63;
-            const float sv = (l8sm[(size_t)k * 64 + ln] + l8sm[((size_t)NV + k) * 64 + ln]) + (l8sm[((size_t)2 * NV + k) * 64 + ln] + l8sm[((size_t)3 * NV + k) * 64 + ln]);
-            const int m = k >> 5, e = (k >> 3) & 3, c = k & 7, f = 256 * m + 4 * ln + e;
-            if (c < r) part[ph == 0 ? (size_t)c * D + f : (size_t)r * D + (size_t)f * r + c] = sv;
-        }
-    };
-
-    if (role == 0) {
-        // ---------------------------------------------------------------- RB: dz, dx, dB[f][c] += scaling dy_f z_c
-        uint32_t ac[NCH][4][4];
-#pragma unroll
-        for (int m = 0; m < NCH; ++m) {
-            const int fc = 256 * m + 4 * lane, G = fc >> 3;
-            const int t = G >> 3, u = (G >> 1) & 3, hh = G & 1;
-            uint32_t wa[8][2];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int i = c < 4 ? c : 8 + (c - 4);
-                const u32x2 v = *reinterpret_cast<const u32x2*>(down + (size_t)(t * 4 + u) * 1024 + (size_t)(i + 32 * hh) * 16 + (fc & 4) * 2);
-                wa[c][0] = v[0]; wa[c][1] = v[1];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t lo = wa[2 * q][e >> 1], hi = wa[2 * q + 1][e >> 1];
-                    ac[m][e][q] = (e & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
-                }
-        }
-        float acc[NCH][4][8];
-#pragma unroll
-        for (int m = 0; m < NCH; ++m)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc[m][e][c] = 0.f;
-        u32x2 cd[NCH], nd[NCH];
-        u32x4 cz, nz;
-        uint32_t cg[NR], ng[NR];
-        auto load_row = [&](int64_t rr, u32x2 (&rd)[NCH], u32x4& rz, uint32_t (&gb)[NR]) {
-            rr = clampr(rr);
-            const int64_t o = rr * (D * 2) + lane * 8;
-#pragma unroll
-            for (int m = 0; m < NCH; ++m) rd[m] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(dy + o + m * 512));
-            rz = *reinterpret_cast<const u32x4*>(zs + rr * 64);           // (the same 16 bytes for every lane: one request)
-            group_bits(rr, gb);
-        };
-        load_row(row_first, cd, cz, cg);
-        for (int64_t row = row_first; row < a.M; row += rstride) {
-            load_row(row + rstride, nd, nz, ng);
-            float dz[8];
-            dz_of(cd, dz);
-            uint32_t zp[4], kb[NCH];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) zp[q] = pack_bf16x2(dz[2 * q], dz[2 * q + 1]);
-            if constexpr (DROP != 0) keep_flags(cg, kb);
-            const int64_t ro = row * (D * 2) + lane * 8;
-#pragma unroll
-            for (int m = 0; m < NCH; ++m) {
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float sv = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) sv = dot2_bf16(zp[q], ac[m][e][q], sv);
-                    o[e] = sv * kscale;
-                }
-                u32x2 ov = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                if constexpr (DROP != 0) mask_pairs(ov, kb[m]);
-                *reinterpret_cast<u32x2*>(dx + ro + m * 512) = ov;
-            }
-            float zc[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) zc[c] = (c & 1) ? __uint_as_float(cz[c >> 1] & 0xffff0000u) : __uint_as_float(cz[c >> 1] << 16);
-#pragma unroll
-            for (int m = 0; m < NCH; ++m)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t w = cd[m][e >> 1];
-                    const float dv = scaling * ((e & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16));
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[m][e][c] = __builtin_fmaf(dv, zc[c], acc[m][e][c]);
-                }
-#pragma unroll
-            for (int m = 0; m < NCH; ++m) cd[m] = nd[m];
-            cz = nz;
-#pragma unroll
-            for (int q = 0; q < NR; ++q) cg[q] = ng[q];
-        }
-        // (the four waves of WA, then those of RB, add their slices through LDS; every wave passes the same three barriers)
-        __syncthreads();                                                  // S1: WA has stashed dA
-        sum_phase(0);
-        __syncthreads();                                                  // S2: the dA sums are read
-        stash(acc);
-        __syncthreads();                                                  // S3
-        sum_phase(1);
-    } else {
-        // ---------------------------------------------------------------- WA: dz (own copy), dA[c][f] += dz_c (keep_f / (1 - p) x_f)
-        float acc[NCH][4][8];
-#pragma unroll
-        for (int m = 0; m < NCH; ++m)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc[m][e][c] = 0.f;
-        u32x2 cd[NCH], nd[NCH], cx[NCH], nx[NCH];
-        uint32_t cg[NR], ng[NR];
-        auto load_row = [&](int64_t rr, u32x2 (&rd)[NCH], u32x2 (&rx)[NCH], uint32_t (&gb)[NR]) {
-            rr = clampr(rr);
-            const int64_t o = rr * (D * 2) + lane * 8;
-#pragma unroll
-            for (int m = 0; m < NCH; ++m) {
-                rd[m] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(dy + o + m * 512));
-                rx[m] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(x + o + m * 512));
-            }
-            group_bits(rr, gb);
-        };
-        load_row(row_first, cd, cx, cg);
-        for (int64_t row = row_first; row < a.M; row += rstride) {
-            load_row(row + rstride, nd, nx, ng);
-            float dz[8];
-            dz_of(cd, dz);
-            uint32_t kb[NCH];
-            if constexpr (DROP != 0) keep_flags(cg, kb);
-#pragma unroll
-            for (int m = 0; m < NCH; ++m) {
-                u32x2 xm = cx[m];
-                if constexpr (DROP != 0) mask_pairs(xm, kb[m]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t w = xm[e >> 1];
-                    const float xv = kscale * ((e & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16));
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[m][e][c] = __builtin_fmaf(dz[c], xv, acc[m][e][c]);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < NCH; ++m) { cd[m] = nd[m]; cx[m] = nx[m]; }
-#pragma unroll
-            for (int q = 0; q < NR; ++q) cg[q] = ng[q];
-        }
-        stash(acc);
-        __syncthreads();                                                  // S1
-        sum_phase(0);
-        __syncthreads();                                                  // S2
-        __syncthreads();                                                  // S3: RB has stashed dB
-        sum_phase(1);
-    }
-}
-
-// workgroups of the streaming backward: one per CU, fewer when that would leave a wave without a row
-int lora8_bwd_blocks(int64_t M) { const int64_t b = (M + 3) / 4; return (int)(b < 256 ? b : 256); }
-size_t lora8_bwd_part_bytes(int64_t M, int d, int r) { return (size_t)lora8_bwd_blocks(M) * 2 * (size_t)r * d * sizeof(float); }
-bool lora8_bwd_applies(int64_t M, int d, int r, int io_fp32, const DropSpec& drop) {
-    (void)drop;                                         // (any mask source: the backward reads the packed mask the forward saved)
-    return !io_fp32 && M > 0 && r >= 1 && r <= 8 && d % 256 == 0 && d <= 768;
-}
-
-template <int NCH>
-static hipError_t launch_lora8_bwd_n(const Lora8BwdArgs& a, hipStream_t stream) {
-    const int blocks = lora8_bwd_blocks(a.M);
-    const size_t lds = (size_t)4 * NCH * 32 * 64 * sizeof(float);
-    const int mode = !drop_active(a.drop) ? 0 : (a.drop.bits != nullptr ? 2 : 1);
-    const void* kern = mode == 0 ? reinterpret_cast<const void*>(lora8_bwd_kernel<NCH, 0>)
-                     : mode == 1 ? reinterpret_cast<const void*>(lora8_bwd_kernel<NCH, 1>) : reinterpret_cast<const void*>(lora8_bwd_kernel<NCH, 2>);
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    if (mode == 0) hipLaunchKernelGGL((lora8_bwd_kernel<NCH, 0>), dim3(blocks), dim3(512), lds, stream, a);
-    else if (mode == 1) hipLaunchKernelGGL((lora8_bwd_kernel<NCH, 1>), dim3(blocks), dim3(512), lds, stream, a);
-    else hipLaunchKernelGGL((lora8_bwd_kernel<NCH, 2>), dim3(blocks), dim3(512), lds, stream, a);
-    return hipGetLastError();
-}
-
-// dx, dA [r, d], dB [d, r] (fp32, overwritten) of the K3 backward at r <= 8; part = lora8_bwd_part_bytes(M, d, r) of workspace
-hipError_t launch_lora8_bwd(const void* dy, const void* x, const void* z, const uint8_t* pk, const DropSpec& drop, void* dx, float* da, float* db,
-                            float* part, int64_t M, int d, int r, float scaling, hipStream_t stream) {
-    Lora8BwdArgs a{};
-    a.dy = dy; a.x = x; a.z = z; a.pk = pk; a.drop = drop; a.drop.keep_out = nullptr; a.drop.bits_out = nullptr;
-    a.dx = dx; a.part = part; a.M = M; a.d = d; a.r = r; a.scaling = scaling;
-    hipError_t e;
-    switch (d / 256) {
-        case 1: e = launch_lora8_bwd_n<1>(a, stream); break;
-        case 2: e = launch_lora8_bwd_n<2>(a, stream); break;
-        case 3: e = launch_lora8_bwd_n<3>(a, stream); break;
-        default: return hipErrorInvalidValue;
-    }
-    if (e != hipSuccess) return e;
-    return launch_tail_reduce(part, lora8_bwd_blocks(M), r * d, da, db, stream);
-}
+// (Round 5 also built the BACKWARD at r <= 8 as a streaming row kernel: parity-green and slower than the two-pass MFMA form -- 54.3 vs 47.8 us at
+//  28,000 rows, 26.5 vs 19.3 at 2,500, profiles/r05_k3_streaming_bwd_ab.txt: its weight gradients are rank-8 OUTER products per row, which is what
+//  the matrix cores are for.  Removed in round 6.)
 
 bool lora8_applies(int64_t M, int d, int r, int io_fp32) {
     return !io_fp32 && M > 0 && r >= 1 && r <= 8 && d % 256 == 0 && d <= 1024;

@@ -423,8 +423,26 @@ __global__ __launch_bounds__(512, 2) void k1_cols6y_kernel(ColzArgs a) {
     }
 }
 
-bool k1_cols6y_applies(const ColzArgs& c) {
-    return vlpet_tuning().cols6y != 0 && ((c.flags & PET_GATE_ADD) != 0 || c.y != nullptr) && Colz6yGeo<6>::lds() <= (size_t)160 * 1024;
+// Row chunks: (d / 64) column blocks in two halves; a group = (row chunk, half) keeps its d / 128 workgroups on one XCD, at
+// most 32 workgroups (one per CU) there: 8 * floor(32 / (d / 128)) groups = half as many row chunks.
+void k1_cols6_plan(int64_t M, int d, int* row_chunks, int64_t* rows_per_chunk) {
+    const int cbh = d >= 128 ? d / 128 : 1;
+    int64_t rc = cols_groups_max(cbh < 32 ? cbh : 32) / 2;
+    const int64_t blocks32 = (M + 31) / 32;
+    if (rc > blocks32) rc = blocks32;
+    if (rc < 1) rc = 1;
+    const int64_t per = (blocks32 + rc - 1) / rc;
+    rc = (blocks32 + per - 1) / per;
+    *row_chunks = (int)rc;
+    *rows_per_chunk = per * 32;
+}
+
+// six tiles, bf16, saved activations -- and what the elementwise block of this kernel starts from: the forward's output y, or the additive
+// gate (which needs neither h nor y).  (pet_cols6.hip, the round-3 form that recomputed h from x2, was removed in round 6: without y the
+// six-tile backward takes the older two-pass form of pet_gate_bwd3.hip.)
+bool k1_cols6_applies(const PetBwdArgs& a, int io_fp32) {
+    return !io_fp32 && (a.flags & PET_GATE) && a.saved != nullptr && !drop_active(a.drop) && a.RT == 6 &&
+           a.d % 128 == 0 && a.d / 128 <= 32 && ((a.flags & PET_GATE_ADD) != 0 || a.y != nullptr) && Colz6yGeo<6>::lds() <= (size_t)160 * 1024;
 }
 
 template <bool ADD, bool HAS_IN>

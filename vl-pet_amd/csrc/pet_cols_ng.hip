@@ -14,7 +14,6 @@
 //   pass 2: 8 waves = 4 column quarters x {up side: dWu + column sums of dy; down side: dWd, dx}; stage = dy and x as two
 //           128-byte pair tiles each + the z and dpre tiles, three stages, one barrier per step.
 #include "cols_common.h"
-#include "cols_reduce.h"
 
 struct NgArgs {
     const void* dy; const void* x; const void* z; const void* gp;     // gp = act'(pre) [M, 32*RT] or nullptr (identity activation)
@@ -27,8 +26,6 @@ struct NgArgs {
     const uint8_t* bits; float ks;                                      // K3 dropout on x: the forward's packed mask [M, d/8] (rng.h drop_pos) and 1 / (1 - p)
     int row_chunks; int64_t rows_per_chunk;
     float* part[2];                                                     // job 0: dWd (+ column sums of dpre), job 1: dWu (+ column sums of dy)
-    ColsRedArgs red;                                                    // red.slab != nullptr: pass 2 sums its row chunks inside the launch (cols_reduce.h)
-    unsigned* red_ctrl; int red_words;                                  // ... whose control words pass 1 zeroes
 };
 
 // ================================================================================================== pass 1
@@ -48,8 +45,6 @@ __global__ __launch_bounds__(512, 2) void ng_dz_kernel(NgArgs a) {
     constexpr int PB = GEO::PB, NPS = GEO::NPS, WT_B = GEO::WT_B, STG_B = GEO::STG_B, NWW = GEO::NWW;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (a.red_ctrl != nullptr && blockIdx.x == 0)                       // pass 2's reduce-scatter state (cols_reduce.h)
-        for (int i = tid; i < a.red_words; i += 512) a.red_ctrl[i] = 0u;
     const int rg = wave & 3, fh = wave >> 2;
     const int m = lane & 31, h = lane >> 5;
     const int d = a.d, S = d >> 6;
@@ -378,17 +373,6 @@ __global__ __launch_bounds__(512, 2) void ng_cols_kernel(NgArgs a) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        if (a.red.slab != nullptr) {
-            if (h == 0) {
-                cols_red_store_f32(a.red.bias_x + (int64_t)rc * d + col, sx[0]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int k = csp_tile[j];
-                    if (k < 0) break;
-                    cols_red_store_f32(a.red.bias_p + (int64_t)rc * PR + 32 * k + m, sx[2 + j]);
-                }
-            }
-        } else
         if (h == 0) {
             a.part[1][(int64_t)RC * PR * d + (int64_t)rc * d + col] = sx[0];
 #pragma unroll
@@ -458,20 +442,7 @@ __global__ __launch_bounds__(512, 2) void ng_cols_kernel(NgArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
-    // ---- this row chunk's partial sums: summed over the row chunks inside this launch (round 6, cols_reduce.h) ...
-    if (a.red.slab != nullptr) {
-        using RG = ColsRedGeo<RT, 1>;
-        const __amdgpu_buffer_rsrc_t mine = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint8_t*>(sbase(reinterpret_cast<const uint8_t*>(a.red.slab) + ((int64_t)rc * NCB + cb) * RG::SLAB_B)), 0, RG::SLAB_B, 0x00020000);
-#pragma unroll
-        for (int ct = 0; ct < RT; ++ct) cols_red_put<RT, 1>(mine, wave, lane, 0, ct, acc[ct]);
-        cols_red_finish<RT, 1, 1, RT>(a.red, NCB, RC, cb, rc, d, reinterpret_cast<volatile unsigned*>(smem),
-            [](int rl, int) { return rl == 0 ? 1 : 0; },                                 // up side: dWu;  down side: dWd
-            [](int) { return 1; },                                                       // column sums of dy -> dbu
-            [](int k, int& job, int& first) { job = 0; first = 32 * k; });              // dpre tiles -> dbd
-        return;
-    }
-    // ... or in wgrad.hip's workspace layout for wgrad_finalize_kernel (the round-3 form, kept for same-box A/Bs)
+    // ---- this row chunk's partial sums (wgrad.hip's workspace layout)
     {
         float* t = a.part[role == 0 ? 1 : 0] + (int64_t)rc * PR * d;
 #pragma unroll
@@ -544,18 +515,5 @@ hipError_t launch_ng_two_pass(const PetBwdArgs& b, const WgradArgs& g, int passe
     a.row_chunks = g.row_chunks; a.rows_per_chunk = g.rows_per_chunk;
     const WgradLayout L = wgrad_layout(g);
     a.part[0] = g.partial + L.off[0]; a.part[1] = g.partial + L.off[1];
-    a.red_ctrl = b.red_ctrl; a.red_words = b.red_words;
-    if (b.red_ctrl != nullptr) {        // in-launch reduce-scatter: the same workspace bytes as [RC][NCB] slabs + the column-sum partials
-        const int64_t PRl = 32 * b.RT;
-        a.red.slab = g.partial;
-        a.red.bias_x = g.partial + (int64_t)2 * g.row_chunks * PRl * b.d;
-        a.red.bias_p = a.red.bias_x + (int64_t)g.row_chunks * b.d;
-        a.red.ctrl = b.red_ctrl;
-        a.red.spin_limit = COLS_RED_SPIN_DEFAULT;
-        for (int j = 0; j < 2; ++j) {
-            const WgradJob& J = g.job[j];
-            a.red.job[j] = ColsRedJob{J.out, J.ldo, J.transposed, J.out_rows, J.scale, J.colsum_x, J.colsum_p};
-        }
-    }
     return b.RT == 1 ? launch_ng_rt<1>(a, passes, stream) : b.RT == 3 ? launch_ng_rt<3>(a, passes, stream) : launch_ng_rt<6>(a, passes, stream);
 }

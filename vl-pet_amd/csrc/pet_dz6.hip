@@ -415,263 +415,8 @@ __global__ __launch_bounds__(256) void k1_dz6_kernel(PetBwdArgs a) {
 }
 
 // ---- chain-split form (round 5, second session): two waves per SIMD.
-// The four-wave kernel above is one wave per SIMD walking a chain of LDS round trips, MFMAs and VALU work with nothing to hide any of it
-// behind (ISA: 36 MFMAs = 1.15 k cycles, ~1 k cycles of elementwise work and 3.6 k cycles of waiting per 5.8 k-cycle half-stage).  Once the
-// backward starts from the forward's output (or the gate is additive) no adapter-chain projection is left, and what a wave must hold for
-// ONE chain's contraction is z_g (48 registers: the gate projection, which BOTH chains' elementwise blocks need and both waves
-// therefore compute -- 12 MFMAs of redundancy) + that chain's dz (96): under 256.  So a 32-row group gets two waves, w (adapter chain:
-// dh = gs dy g, dz_a) and w + 4 (gate chain: dq = dy y (1 - g), dz_g), eight waves per workgroup, same LDS image and rings.
-// MEASURED: parity-green and 11 % SLOWER (65.2 vs 58.3 us at 18,250 rows, 68.4 vs 62.0 at 28,000; profiles/r05_k1bench_dz6c_ab.txt): the second
-// copy of the gate projection's fragment reads and of the sigmoid costs more LDS / VALU issue than the second wave hides.  The "waiting" of
-// the four-wave kernel is not idle latency a second wave could fill; kept behind VLPET_DZ6C (csrc/tuning.h, off) with its test.
-template <int RT, bool ADD>
-__global__ __launch_bounds__(512, 2) void k1_dz6c_kernel(PetBwdArgs a) {
-    using GEO = Dz6Geo<RT>;
-    constexpr int KT = 2 * RT;
-    constexpr int PB = GEO::PB, NPS = GEO::NPS, WT_B = GEO::WT_B, WS_B = GEO::WS_B, XT_B = GEO::XT_B, XS_B = GEO::XS_B;
-    constexpr int X_OFF = GEO::X_OFF;
-    constexpr int NWP = 2 * WT_B / 1024 / 8;           // weight pieces (1 KiB) per wave and half-stage
-    constexpr int NXP = 2;                             // pieces (8 rows) per wave, row tensor and stage
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = wave & 3, chain = wave >> 2;
-    const int m = lane & 31, h = lane >> 5;
-    const int d = a.d;
-    const int NFB = a.fsplit > 1 ? a.fsplit : 1;
-    const int S0 = (int)blockIdx.y * ((d >> 6) / NFB), S = S0 + (d >> 6) / NFB;
-    const int64_t ld2 = (int64_t)d * 2;
-    const int64_t row0 = (int64_t)blockIdx.x * 128;
-    const int64_t grow_raw = row0 + 32 * rg + m;
-    const bool row_ok = grow_raw < a.M;
-    const int64_t grow = row_ok ? grow_raw : a.M - 1;
-    const PackGeom pg = pack_geom(RT, d, 1);
-    bf16x8 zG[KT];
-
-    uint32_t xoff[NXP], xdst[NXP];
-#pragma unroll
-    for (int j = 0; j < NXP; ++j) {
-        const int p = wave + 8 * j, row = 8 * p + (lane >> 3);
-        int64_t gr = row0 + row;
-        if (gr >= a.M) gr = a.M - 1;
-        xoff[j] = (uint32_t)((gr - row0) * ld2) + (uint32_t)(((lane & 7) ^ swz(row)) * 16);
-        xdst[j] = (uint32_t)(p * 1024);
-    }
-    uint32_t woff[NWP], wdst[NWP]; int wten[NWP];
-#pragma unroll
-    for (int j = 0; j < NWP; ++j) {
-        const int q = wave + 8 * j, t = q / (2 * RT), piece = q % (2 * RT);
-        const int sig = piece * 64 + lane, fl = sig / NPS, sl = (sig % NPS) ^ gsw(fl);
-        const int i = 8 * ((fl >> 2) & 3) + (fl & 3), v = (fl >> 4) & 1;
-        wten[j] = t;
-        woff[j] = (uint32_t)((v * KT + (sl >> 1)) * 1024 + ((sl & 1) * 32 + i) * 16);       // (+ 64 fh: the pack lane's 4 fh term)
-        wdst[j] = (uint32_t)(t * WT_B + piece * 1024);
-    }
-    auto sbase = [](const uint8_t* p) {
-        const uint64_t u = reinterpret_cast<uint64_t>(p);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-        return reinterpret_cast<const uint8_t*>(((uint64_t)hi << 32) | lo);
-    };
-    const uint8_t* dyp = reinterpret_cast<const uint8_t*>(a.dy) + row0 * ld2;
-    const uint8_t* yp = reinterpret_cast<const uint8_t*>(ADD ? a.dy : a.y) + row0 * ld2;      // (additive gate: the second tile is not used)
-    const uint8_t* wpa = a.pk_a + pg.pack_bytes;
-    const uint8_t* wpg = a.pk_g + pg.pack_bytes;
-    auto issue_w = [&](int ss) {            // half-stage ss = 2 s + fh
-        uint8_t* st = smem + (size_t)(ss & 1) * WS_B;
-        const int64_t so = (int64_t)(ss >> 1) * (4 * RT * 1024) + (ss & 1) * 64;
-#pragma unroll
-        for (int j = 0; j < NWP; ++j) glds16(sbase((wten[j] ? wpg : wpa) + so) + woff[j], st + wdst[j]);
-    };
-    auto issue_x = [&](int s) {
-        uint8_t* st = smem + X_OFF + (size_t)(s & 1) * XS_B;
-#pragma unroll
-        for (int j = 0; j < NXP; ++j) {
-            glds16_p1(sbase(dyp + s * 128) + xoff[j], st + xdst[j]);
-            glds16_p1(sbase(yp + s * 128) + xoff[j], st + XT_B + xdst[j]);
-        }
-    };
-
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
-    uint32_t a_wup[2], a_wtr[2], a_row[4];
-    {
-        const int g = gsw(m);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) a_wup[k] = (uint32_t)(m * PB + (((2 * k + h) ^ g) * 16));
-        const int g4 = lane >> 4, sl = lane & 15, hp = g4 >> 1;
-        const int tslot = 2 * (g4 & 1) + ((sl & 3) >> 1), thalf = 8 * (sl & 1);
-#pragma unroll
-        for (int hi = 0; hi < 2; ++hi) {
-            const int r = 4 * hp + 8 * hi + (sl >> 2);
-            a_wtr[hi] = (uint32_t)(r * PB + ((tslot ^ gsw(r)) * 16) + thalf) + (uint32_t)(chain * WT_B);   // (this chain's block of the slot)
-        }
-        const int row = 32 * rg + m;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a_row[q] = (uint32_t)(row * 128 + ((q ^ swz(row)) * 16) + 8 * h);
-    }
-    const uint32_t a_bias = lds0 + (uint32_t)(GEO::BIAS_OFF + (4 * h) * 4);
-
-    f32x16 dz[RT];
-#pragma unroll
-    for (int ct = 0; ct < RT; ++ct) dz[ct] = zero16();
-    const float gs = a.gs;
-
-    // the gate's up projection over the 32 features of the half-stage, starting at its bias
-    auto project_gate = [&](uint32_t sb, f32x16& acc, int bias_off) {
-        constexpr int GRP = KT / 2;
-        u32x4 bb[4], wf[GRP];
-        sfor<4>([&](auto Q) { lds_read16<32 * Q.value>(bb[Q.value], a_bias + (uint32_t)bias_off); });
-        sfor<GRP>([&](auto K) { lds_read16<WT_B + 64 * (K.value >> 1)>(wf[K.value], sb + a_wup[K.value & 1]); });
-        lgkm_fence(bb[0]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q) lgkm_tie(bb[q]);
-#pragma unroll
-            for (int w2 = 0; w2 < 4; ++w2) acc[4 * q + w2] = __uint_as_float(bb[q][w2]);
-        }
-#pragma unroll
-        for (int k = 0; k < GRP; ++k) { lgkm_tie(wf[k]); acc = mfma32(as_bf(wf[k]), zG[k], acc); }
-        u32x4 wf2[GRP];
-        sfor<GRP>([&](auto K) { constexpr int ks = GRP + K.value; lds_read16<WT_B + 64 * (ks >> 1)>(wf2[K.value], sb + a_wup[ks & 1]); });
-        lgkm_fence(wf2[0]);
-#pragma unroll
-        for (int k = 0; k < GRP; ++k) { if (k) lgkm_tie(wf2[k]); acc = mfma32(as_bf(wf2[k]), zG[GRP + k], acc); }
-    };
-    // contraction over the 32 features of the half-stage: dz[ct] += W^T (transpose reads of this chain's image) . dh or dq
-    auto contract1 = [&](uint32_t sb, const uint32_t* bw) {
-        sfor<2>([&](auto KP) {
-            constexpr int kp = KP.value;
-            TrOp ap[RT];
-            sfor<RT>([&](auto CT) { tr_read2<kp * 16 * PB + 64 * CT.value>(ap[CT.value], sb + a_wtr[0], sb + a_wtr[1]); });
-            tr_fence(ap[0]);
-            const u32x4 bv = {bw[4 * kp], bw[4 * kp + 1], bw[4 * kp + 2], bw[4 * kp + 3]};
-#pragma unroll
-            for (int ct = 0; ct < RT; ++ct) {
-                if (ct) tr_tie(ap[ct]);
-                dz[ct] = mfma32(tr_val(ap[ct]), as_bf(bv), dz[ct]);
-            }
-        });
-    };
-
-    issue_w(2 * S0);
-    issue_x(S0);
-    {   // up-side bias of the gate -> LDS (fp32) at [d, 2 d) of the bias area (same place as in the four-wave kernel)
-        float* sbias = reinterpret_cast<float*>(smem + GEO::BIAS_OFF);
-        const float* bg = reinterpret_cast<const float*>(a.pk_g + pg.bias_off) + 32 * RT;
-        for (int i = tid; i < d; i += 512) sbias[d + i] = bg[i];
-    }
-    {
-        const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved);
-        const __bf16* sg = reinterpret_cast<const __bf16*>(sv + 2 * a.saved_stride) + grow * (int64_t)(32 * RT) + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < KT; ++ks) zG[ks] = *reinterpret_cast<const bf16x8*>(sg + 16 * ks);
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int ks = 0; ks < KT; ++ks) asm volatile("" : "+v"(zG[ks]));
-
-    // request order per step: half-stage (s, 0): W(2s + 1), X(s + 1); half-stage (s, 1): W(2s + 2)
-#pragma unroll 1
-    for (int ss = 2 * S0; ss < 2 * S; ++ss) {
-        const int s = ss >> 1, fh = ss & 1;
-        vm_wait(fh == 1 && s + 1 < S ? 2 * NXP : 0);                     // (younger than W(ss): only the row pieces of stage s + 1)
-        __builtin_amdgcn_s_barrier();
-        if (ss + 1 < 2 * S) issue_w(ss + 1);
-        if (fh == 0 && s + 1 < S) issue_x(s + 1);
-        const uint32_t sb = lds0 + (uint32_t)((ss & 1) * WS_B);
-        const uint32_t xb = lds0 + (uint32_t)(X_OFF + (s & 1) * XS_B);
-        f32x16 aG;
-        project_gate(sb, aG, (d + s * 64 + 32 * fh) * 4);
-        uint32_t bw[8];
-        {
-            u32x2 dyv[4], yv[4];
-            const uint32_t fbit = (uint32_t)fh << 6;
-            sfor<4>([&](auto Q) {
-                lds_read8<0>(dyv[Q.value], xb + (a_row[Q.value] ^ fbit));
-                lds_read8<XT_B>(yv[Q.value], xb + (a_row[Q.value] ^ fbit));
-            });
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dyv[0]), "+v"(yv[0]), "+v"(dyv[1]), "+v"(yv[1]), "+v"(dyv[2]), "+v"(yv[2]), "+v"(dyv[3]), "+v"(yv[3]) :: "memory");
-            sfor<4>([&](auto Q) {
-                constexpr int q = Q.value;
-                float v4[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int e = 4 * q + j;
-                    const float gt = sigm(aG[e]);
-                    const float dyr = (j & 1) ? bf_hi(dyv[q][j >> 1]) : bf_lo(dyv[q][j >> 1]);
-                    if constexpr (ADD) v4[j] = chain == 0 ? gs * dyr : gs * dyr * gt * (1.0f - gt);
-                    else {
-                        const float yy = (j & 1) ? bf_hi(yv[q][j >> 1]) : bf_lo(yv[q][j >> 1]);
-                        v4[j] = chain == 0 ? gs * dyr * gt : dyr * yy * (1.0f - gt);
-                    }
-                }
-                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-                const bf16x4 t4 = {(__bf16)v4[0], (__bf16)v4[1], (__bf16)v4[2], (__bf16)v4[3]};
-                const u32x2 u = __builtin_bit_cast(u32x2, t4);
-                bw[2 * q] = u[0]; bw[2 * q + 1] = u[1];
-            });
-        }
-        contract1(sb, bw);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-
-    if (NFB > 1) {      // feature split: this block's fp32 sums of this wave's chain -> dz_part[fb][row][chain][32 RT]
-        float* out = a.dz_part + (((int64_t)blockIdx.y * a.M + grow) * 2 + chain) * (32 * RT) + 4 * h;
-#pragma unroll
-        for (int ct = 0; ct < RT; ++ct)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 r4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) r4[j] = dz[ct][4 * q + j];
-                if (row_ok) *reinterpret_cast<f32x4*>(out + 32 * ct + 8 * q) = r4;
-            }
-        return;
-    }
-    // ---- dpre = dz * act'(pre) of this wave's chain; its act' rows (12 KiB, contiguous) through LDS as in the four-wave kernel
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-    {
-        __builtin_amdgcn_s_barrier();                                     // every wave is done with the rings
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
-        const int m_e = lane_e & 31, h_e = lane_e >> 5;
-        uint8_t* area = smem + (size_t)wave * (32 * PB);
-        const int64_t rb = row0 + 32 * rg;
-        const uint8_t* sv = reinterpret_cast<const uint8_t*>(a.saved) + (chain == 0 ? 1 : 3) * a.saved_stride;
-#pragma unroll
-        for (int pc = 0; pc < 32 * PB / 1024; ++pc) {
-            const int slot = pc * 64 + lane_e, r = slot / (PB / 16), cs = slot % (PB / 16);
-            int c = cs - (r % (PB / 16));
-            if (c < 0) c += PB / 16;
-            int64_t gr = rb + r;
-            if (gr >= a.M) gr = a.M - 1;
-            glds16(sv + gr * PB + c * 16, area + (size_t)pc * 1024);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t abase = lds0 + (uint32_t)(wave * (32 * PB)) + (uint32_t)(m_e * PB) + 8 * h_e;
-        const int mrot = m_e % (PB / 16);
-        __bf16* out = reinterpret_cast<__bf16*>(chain == 0 ? a.dp_a : a.dp_g) + grow * (int64_t)(32 * RT) + 4 * h;
-        const float sc = chain == 0 ? a.sd : 1.0f;
-#pragma unroll
-        for (int ct = 0; ct < RT; ++ct) {
-            u32x2 gv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int cs = 4 * ct + q + mrot;
-                if (cs >= PB / 16) cs -= PB / 16;
-                lds_read8<0>(gv[q], abase + (uint32_t)(cs * 16));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]) :: "memory");
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bf16x4 g1 = __builtin_bit_cast(bf16x4, gv[q]);
-                bf16x4 r4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) r4[j] = (__bf16)(sc * dz[ct][4 * q + j] * (float)g1[j]);
-                if (row_ok) *reinterpret_cast<bf16x4*>(out + 32 * ct + 8 * q) = r4;
-            }
-        }
-    }
-}
+// (A chain-split eight-wave form of this pass -- two waves per SIMD, one per chain -- was built in round 5, parity-green and 11 % slower:
+//  65.2 vs 58.3 us at 18,250 rows, profiles/r05_k1bench_dz6c_ab.txt; removed in round 6.)
 
 int k1_dz6_feature_blocks(int64_t M, int d) {
     if (const int f = vlpet_tuning().dz2_fsplit; f >= 1) return ((d >> 6) % f == 0) ? f : 1;
@@ -706,22 +451,8 @@ static hipError_t launch_dz6_form(const PetBwdArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <bool ADD>
-static hipError_t launch_dz6c_form(const PetBwdArgs& a, hipStream_t stream) {
-    using GEO = Dz6Geo<6>;
-    const size_t lds = GEO::bytes(a.d);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1_dz6c_kernel<6, ADD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    const unsigned blocks = (unsigned)((a.M + 127) / 128);
-    const unsigned nfb = a.fsplit > 1 ? (unsigned)a.fsplit : 1u;
-    hipLaunchKernelGGL((k1_dz6c_kernel<6, ADD>), dim3(blocks, nfb), dim3(512), lds, stream, a);
-    if (nfb > 1) return launch_k1_dz_reduce(a, 32 * 6, stream);
-    return hipGetLastError();
-}
-
 hipError_t launch_k1_dz6(const PetBwdArgs& a, hipStream_t stream) {
-    const bool split = vlpet_tuning().dz6c != 0;        // two waves per SIMD, one per chain (needs no adapter-chain projection: y or the additive gate)
-    if (a.flags & PET_GATE_ADD) return split ? launch_dz6c_form<true>(a, stream) : launch_dz6_form<true, false>(a, stream);
-    if (a.y != nullptr) return split ? launch_dz6c_form<false>(a, stream) : launch_dz6_form<false, true>(a, stream);
+    if (a.flags & PET_GATE_ADD) return launch_dz6_form<true, false>(a, stream);
+    if (a.y != nullptr) return launch_dz6_form<false, true>(a, stream);
     return launch_dz6_form<false, false>(a, stream);
 }

@@ -22,17 +22,12 @@ struct VlpetTuning {
     int dz2 = 1;            // VLPET_DZ2=0: chain-split pass 1 of the K1 backward (pet_gate_dz_kernel) instead of the feature-split one
     int dz2_fsplit = 0;     // VLPET_DZ2_FSPLIT=1|2|4: feature blocks of pass 1 (0: by shape)
     int dz6 = 1;            // VLPET_DZ6=0: pet_gate_dz_kernel instead of the four-wave feature-split pass 1 at six tiles; 2: that pass at every size
-    int lora8_bwd = 0;      // VLPET_LORA8_BWD=1: K3 backward at r <= 8 on the streaming row kernel (lora8.hip) instead of the two-pass MFMA form -- built in
-                            //   round 5, parity-green, and SLOWER (54 vs 48 us at 28,000 rows, 26 vs 19 at 2,500; profiles/r05_k3_streaming_bwd_ab.txt)
-    int dz6c = 0;           // VLPET_DZ6C=1: pass 1 at six tiles from y / additive gate on the chain-split eight-wave kernel (two waves per SIMD; measured
-                            //   SLOWER than the four-wave one: 65 vs 58 us at 18,250 rows, profiles/r05_k1bench_dz6c_ab.txt)
-    int cols6y = 1;         // VLPET_COLS6Y=0: pass 2 at six tiles on pet_cols6.hip even when the forward's output is at hand (pet_cols6y.hip otherwise)
     int k4_wgrad2 = 1;      // VLPET_K4_WGRAD2=0: K4 weight gradient as jobs of the generic stream instead of the tiled split-K GEMM
     int ng2 = 1;            // VLPET_NG2=0: row kernel + streaming weight gradients for the backward without a gate instead of the two-pass form
     int fwd2p = -1;         // VLPET_FWD2P: gated forward of the training form: -1 by shape (k1_fwd2p_preferred), 0 one-kernel (pet_gate_fwd.hip), 1 two-pass
                             //   (pet_fwd2p.hip), 2 = pass A only, 3 = pass B only (timing)
-    int cols_red = 1;       // VLPET_COLS_RED=0: the column-parallel backward passes leave partial slabs for a finalize launch (round 3) instead of
-                            //   summing their row chunks inside the launch (round 6, cols_reduce.h)
+    int cols_red = 1;       // VLPET_COLS_RED=0: pass 2 of the gated K1 backward always leaves partial slabs for a finalize launch (round 3) instead of
+                            //   summing its row chunks inside the launch (round 6, cols_reduce.h: from 8,192 rows); 2: inside the launch at every size
     int dbg = 0;            // VLPET_DBG: ablation / stamp bits
 };
 
@@ -44,7 +39,7 @@ inline const VlpetTuning& vlpet_tuning() {
         rd("VLPET_RG", v.rg); rd("VLPET_BWD2", v.bwd2); rd("VLPET_BWD3", v.bwd3); rd("VLPET_BWD3_UNITS", v.bwd3_units);
         rd("VLPET_BWD3_FORM", v.bwd3_form); rd("VLPET_K4_WAVES4", v.k4_waves4); rd("VLPET_WGRAD_WGS", v.wgrad_wgs);
         rd("VLPET_WGRAD_TR", v.wgrad_tr); rd("VLPET_WGRAD_STREAM", v.wgrad_stream); rd("VLPET_WGRAD_NSTG", v.wgrad_nstg);
-        rd("VLPET_WGS_MODE", v.wgs_mode); rd("VLPET_ATTN_OCC", v.attn_occ); rd("VLPET_ATTN_NW", v.attn_nw); rd("VLPET_DBG", v.dbg); rd("VLPET_DZ2", v.dz2); rd("VLPET_DZ6", v.dz6); rd("VLPET_COLS6Y", v.cols6y); rd("VLPET_DZ6C", v.dz6c); rd("VLPET_LORA8_BWD", v.lora8_bwd); rd("VLPET_DZ2_FSPLIT", v.dz2_fsplit); rd("VLPET_K4_WGRAD2", v.k4_wgrad2); rd("VLPET_NG2", v.ng2); rd("VLPET_FWD2P", v.fwd2p); rd("VLPET_COLS_RED", v.cols_red);
+        rd("VLPET_WGS_MODE", v.wgs_mode); rd("VLPET_ATTN_OCC", v.attn_occ); rd("VLPET_ATTN_NW", v.attn_nw); rd("VLPET_DBG", v.dbg); rd("VLPET_DZ2", v.dz2); rd("VLPET_DZ6", v.dz6); rd("VLPET_DZ2_FSPLIT", v.dz2_fsplit); rd("VLPET_K4_WGRAD2", v.k4_wgrad2); rd("VLPET_NG2", v.ng2); rd("VLPET_FWD2P", v.fwd2p); rd("VLPET_COLS_RED", v.cols_red);
         return v;
     }();
     return t;

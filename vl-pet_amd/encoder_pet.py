@@ -83,8 +83,13 @@ def _apply_pet_split(module, which, x1, x2, dws, dbs, up, gdown, gup, mode, sd, 
     elif nh == 1:                           # a single down projection: split its rows
         ra = r // 2
         wa, ba, wb, bb = [dws[0][:ra]], [dbs[0][:ra]], [dws[0][ra:]], [dbs[0][ra:]]
-    else:
-        raise NotImplementedError(f"vl-pet_amd: r > 96 with an odd number of down-projection heads ({nh}) is not supported")
+    else:       # an odd number (> 1) of heads does not split into two 3-tile halves: plain torch ops (vl-pet_amd/eager.py)
+        from . import eager
+        from .activations import get_activation
+        act = get_activation("gelu_new")
+        gp = None if mode == VF.GATE_NONE else (gdown.weight, gdown.bias, gup.weight, gup.bias)
+        return eager.adapter_gate(x1, x2, list(dws), list(dbs), up.weight, up.bias, gp, act, act,
+                                  {VF.GATE_MUL: "mul", VF.GATE_ADD: "add", VF.GATE_NONE: "none"}[mode], sd, s2, gs)
     cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(list(ts), 0)
     # Every pack below is keyed on the SOURCE parameters (PackCache.get_derived): the slices / concatenations / contiguous
     # copies are temporaries, rebuilt only when a source changed.

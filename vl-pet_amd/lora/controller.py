@@ -21,8 +21,6 @@ class LoRALinearController(nn.Linear, LoRALayer):
 
     def __init__(self, in_features: int, out_features: int, fan_in_fan_out: bool = False, config=None, **kwargs):
         nn.Linear.__init__(self, in_features, out_features, **kwargs)
-        if fan_in_fan_out:
-            raise NotImplementedError("fan_in_fan_out layers do not occur on the BART q_proj/v_proj path")
         self.tasks = config.tasks
         self.use_single_lora = config.use_single_lora
         LoRALayer.__init__(self, r=config.lora_dim, lora_alpha=config.lora_alpha,
@@ -35,6 +33,8 @@ class LoRALinearController(nn.Linear, LoRALayer):
             self.scaling = self.lora_alpha / self.r
             self.weight.requires_grad = False
         self.reset_parameters()
+        if fan_in_fan_out:          # (lora/controller.py:46-47: the weight is stored transposed; such layers take the eager path below)
+            self.weight.data = self.weight.data.T
         self._packs = {}
 
     def reset_parameters(self):
@@ -61,8 +61,14 @@ class LoRALinearController(nn.Linear, LoRALayer):
         return self.lora_As, self.lora_Bs
 
     def forward(self, x, task):
-        if self.in_features != self.out_features:
-            raise NotImplementedError("fused LoRA delta supports square projections (q_proj / v_proj) only")
+        if self.in_features != self.out_features or self.fan_in_fan_out:
+            # the fused delta kernel covers what the reference wraps (the square q_proj / v_proj of BART, my_transformers/
+            # modeling_bart.py:767-768); any other layer shape takes the plain-torch composition ("else eager fallback")
+            from .. import eager
+            if self.r <= 0:
+                return F.linear(x, (self.weight.t() if self.fan_in_fan_out else self.weight).to(x.dtype), None if self.bias is None else self.bias.to(x.dtype))
+            return eager.lora_linear(x, self.weight, self.bias, self.lora_As[task], self.lora_Bs[task], self.scaling,
+                                     float(self.lora_dropout_p), self.training, self.fan_in_fan_out)
         w, b = self.weight, self.bias
         if w.dtype != x.dtype:
             w = w.to(x.dtype)

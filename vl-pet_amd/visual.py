@@ -119,13 +119,13 @@ class VisualEmbedding(nn.Module):
         a 5-wide linear + norm + two gathers (host ops)."""
         B, N, _ = feats.shape
         assert pos.shape == (B, N, 4)
-        if not (self.config.use_vis_layer_norm and self.config.individual_vis_layer_norm):
-            raise NotImplementedError("fused visual projection needs the per-branch LayerNorm configuration "
-                                      "(use_vis_layer_norm and individual_vis_layer_norm, the reference default)")
+        per_branch = bool(self.config.use_vis_layer_norm and self.config.individual_vis_layer_norm)
         pos = pos.float()
         pos5 = torch.cat([pos, self.get_area(pos).unsqueeze(2)], dim=2)
-        pl, pn = self.absolute_vis_pos_embedding[0], self.absolute_vis_pos_embedding[1]
-        R = pn(F.linear(pos5, pl.weight.float(), pl.bias.float())).float()
+        pl = self.absolute_vis_pos_embedding[0]
+        R = F.linear(pos5, pl.weight.float(), pl.bias.float())
+        if per_branch:
+            R = self.absolute_vis_pos_embedding[1](R).float()
         if self.config.use_vis_order_embedding:
             dev = feats.device
             if img_order_ids is None:
@@ -134,10 +134,15 @@ class VisualEmbedding(nn.Module):
                 obj_order_ids = torch.arange(N, dtype=torch.long, device=dev).unsqueeze(0)
             obj_order_ids = self.obj_order_embedding.num_embeddings - obj_order_ids - 1
             R = R + self.img_order_embedding(img_order_ids).float() + self.obj_order_embedding(obj_order_ids).float()
+        R = R.expand(B, N, R.shape[-1])
+        if not per_branch:
+            # no LayerNorm behind the feature projection (use_vis_layer_norm off, or ONE norm over the sum: src/modeling_bart.py:186-188):
+            # not the fused kernel's shape -- plain torch ops ("else eager fallback"); no launch script sets these flags
+            from . import eager
+            return eager.visual_embedding(feats, R, self.feat_embedding, getattr(self, "layer_norm", None)).to(feats.dtype)
         from .visproj import VisProjPackCache, visproj
         if not hasattr(self, "_vis_cache"):
             self._vis_cache = VisProjPackCache()
-        R = R.expand(B, N, R.shape[-1])
         return visproj(feats, R, self.feat_embedding[0], self.feat_embedding[1], self._vis_cache, self.rms_norm)
 
 
@@ -168,10 +173,14 @@ class LowRankVisualEmbedding(nn.Module):
             self.visual_projector_gating_large_x_down = nn.Linear(feat_dim, rg)
             self.visual_projector_gating_large_x_up = nn.Linear(rg, d)
             self.gating_non_linear = get_activation("gelu_new")
-        if not (config.use_vis_layer_norm and config.individual_vis_layer_norm):
-            raise NotImplementedError("LowRankVisualEmbedding: the per-branch LayerNorm configuration is the supported one")
-        self.visual_projector_layer_norm = nn.LayerNorm(d)
-        self.absolute_vis_pos_embedding = nn.Sequential(nn.Linear(pos_dim + 1, d), nn.LayerNorm(d))
+        self._per_branch = bool(config.use_vis_layer_norm and config.individual_vis_layer_norm)
+        if self._per_branch:
+            self.visual_projector_layer_norm = nn.LayerNorm(d)
+            self.absolute_vis_pos_embedding = nn.Sequential(nn.Linear(pos_dim + 1, d), nn.LayerNorm(d))
+        else:       # (src/modeling_bart.py:231-252: bare projections, one LayerNorm over the sum if use_vis_layer_norm)
+            self.absolute_vis_pos_embedding = nn.Sequential(nn.Linear(pos_dim + 1, d))
+            if config.use_vis_layer_norm:
+                self.layer_norm = nn.LayerNorm(d)
         if config.use_vis_order_embedding:
             self.obj_order_embedding = obj_order_embedding
             self.img_order_embedding = nn.Embedding(config.n_images, d)
@@ -183,8 +192,10 @@ class LowRankVisualEmbedding(nn.Module):
         assert pos.shape == (B, N, 4)
         pos = pos.float()
         pos5 = torch.cat([pos, self.get_area(pos).unsqueeze(2)], dim=2)
-        pl, pn = self.absolute_vis_pos_embedding[0], self.absolute_vis_pos_embedding[1]
-        R = pn(F.linear(pos5, pl.weight.float(), pl.bias.float())).float()
+        pl = self.absolute_vis_pos_embedding[0]
+        R = F.linear(pos5, pl.weight.float(), pl.bias.float())
+        if self._per_branch:
+            R = self.absolute_vis_pos_embedding[1](R).float()
         if self.config.use_vis_order_embedding:
             dev = feats.device
             if img_order_ids is None:
@@ -194,10 +205,24 @@ class LowRankVisualEmbedding(nn.Module):
             obj_order_ids = self.obj_order_embedding.num_embeddings - obj_order_ids - 1
             R = R + self.img_order_embedding(img_order_ids).float() + self.obj_order_embedding(obj_order_ids).float()
         R = R.expand(B, N, R.shape[-1])
+        gated = hasattr(self, "visual_projector_gating_large_x_down")
+        r_max = max(self.visual_projector_multihead_up.weight.shape[1],
+                    self.visual_projector_gating_large_x_down.weight.shape[0] if gated else 0)
+        if not self._per_branch or r_max > 96:
+            # bottlenecks above 96 or no per-branch LayerNorm: outside the rectangular kernels -- plain torch ops
+            from . import eager
+            fe = eager.lowrank_visual_features(
+                feats, list(self.visual_projector_multihead_down), self.visual_projector_multihead_up, self.visual_projector_non_linear,
+                self.visual_projector_gating_large_x_down if gated else None, self.visual_projector_gating_large_x_up if gated else None,
+                getattr(self, "gating_non_linear", None), bool(getattr(self.config, "use_visual_projector_residual_connection", False)),
+                self.visual_projector_layer_norm if self._per_branch else None)
+            v = fe.to(R.dtype) + R
+            if not self._per_branch and hasattr(self, "layer_norm"):
+                v = self.layer_norm(v)
+            return v.to(feats.dtype)
         from .lowrank import LowRankPackCache, lowrank_project
         if not hasattr(self, "_lr_caches"):
             self._lr_caches = (LowRankPackCache(), LowRankPackCache())
-        gated = hasattr(self, "visual_projector_gating_large_x_down")
         return lowrank_project(
             feats, R, list(self.visual_projector_multihead_down), self.visual_projector_multihead_up,
             self.visual_projector_layer_norm,
