@@ -461,6 +461,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     step_ms = [round(step_ev[k].elapsed_time(step_ev[k + 1]), 3) for k in range(args.steps)]
+    peak_gb = round(torch.cuda.max_memory_allocated(dev) / 1e9, 3)     # peak of torch's allocator up to the end of the timed region (all task shapes seen)
     timer, VF.TIMER = VF.TIMER, None
     if graph_on:
         # a replayed step runs no host code, so nothing was bracketed above: the roofline op is bracketed in eager steps of the same
@@ -663,6 +664,7 @@ def main():
                        "backend": args.backend if n_ranks > 1 else None},
             **step_time_report(step_ms, [order[i] for i in range(args.warmup, args.warmup + args.steps)],
                                {t: rank_batch(t) for t in tasks}, settling, n_ranks),
+            "peak_memory_GB": peak_gb,
             "roofline": roof, "kernels": kernels, "backbone_gemm_table": gemm_table,
             **({"ab_switches": ab_switches} if ab_switches else {}),
             **({"other_scaling": strong} if strong is not None else {}),

@@ -27,13 +27,14 @@ def col_rel_err(a: torch.Tensor, ref: torch.Tensor) -> float:
     return float(((a - ref).abs() / ref.abs().clamp_min(floor)).max())
 
 
-EL_FLOOR = 0.06      # floor of the element-wise metric as a fraction of max|ref| (argued in tests/test_gpu_cols.py)
+EL_FLOOR = 0.02         # default floor of the element-wise metric as a fraction of max|ref|
+K1_EL_FLOOR = 0.06      # ... for the outputs and gradients of the K1 op (run_k1): argued in tests/test_gpu_cols.py, with its 0.1 bound
 
 
 def el_rel_err(a: torch.Tensor, ref: torch.Tensor, floor: float = EL_FLOOR) -> float:
     """Element-wise |a - ref| / (|ref| + floor * max|ref|), worst element: every entry is held to its OWN magnitude, small ones
-    against a floor of 6 % of the tensor's maximum (2 % until round 4).  rel_err above is a global norm (max-abs over max-abs-ref) and cannot see an
-    entry that is wrong by its own size while small next to the largest one (VERDICT r03 weak #1)."""
+    against a floor of `floor` of the tensor's maximum (2 % unless a caller argues another: ADVICE r05).  rel_err above is a global norm
+    (max-abs over max-abs-ref) and cannot see an entry that is wrong by its own size while small next to the largest one (VERDICT r03 weak #1)."""
     a = a.detach().float().cpu()
     ref = ref.detach().float().cpu()
     if not torch.isfinite(a).all():
@@ -95,14 +96,14 @@ def run_k1(dtype, M=224, d=768, r=96, rg=96, nh=4, gate_mode=1, delta_scale=1.0,
         for k in ("wgd", "bgd", "wgu", "bgu"):
             errs["d" + k] = rel_err(P[k].grad, g_ref[k])
     if el_errs is not None:         # element-wise view of the input and weight gradients (el_rel_err)
-        el_errs["y"] = el_rel_err(y, y_ref)
-        el_errs["dx2"] = el_rel_err(x2.grad, g_ref["x2"])
-        el_errs["dwd"] = el_rel_err(torch.cat([w.grad for w in dws]), g_ref["wd"])
-        el_errs["dwu"] = el_rel_err(P["wu"].grad, g_ref["wu"])
+        el_errs["y"] = el_rel_err(y, y_ref, K1_EL_FLOOR)
+        el_errs["dx2"] = el_rel_err(x2.grad, g_ref["x2"], K1_EL_FLOOR)
+        el_errs["dwd"] = el_rel_err(torch.cat([w.grad for w in dws]), g_ref["wd"], K1_EL_FLOOR)
+        el_errs["dwu"] = el_rel_err(P["wu"].grad, g_ref["wu"], K1_EL_FLOOR)
         if has_gate:
-            el_errs["dx1"] = el_rel_err(x1.grad, g_ref["x1"])
-            el_errs["dwgd"] = el_rel_err(P["wgd"].grad, g_ref["wgd"])
-            el_errs["dwgu"] = el_rel_err(P["wgu"].grad, g_ref["wgu"])
+            el_errs["dx1"] = el_rel_err(x1.grad, g_ref["x1"], K1_EL_FLOOR)
+            el_errs["dwgd"] = el_rel_err(P["wgd"].grad, g_ref["wgd"], K1_EL_FLOOR)
+            el_errs["dwgu"] = el_rel_err(P["wgu"].grad, g_ref["wgu"], K1_EL_FLOOR)
     if col_errs is not None:        # per-column view of the bias gradients (sums over all M rows)
         col_errs["dbd"] = col_rel_err(torch.cat([b.grad for b in dbs]), g_ref["bd"])
         col_errs["dbu"] = col_rel_err(P["bu"].grad, g_ref["bu"])

@@ -271,3 +271,22 @@ def test_key_mask_byte_conversion_is_cached_per_source_and_version():
     u8 = torch.ones(4, 7, dtype=torch.uint8)
     assert A._key_mask_u8(u8, 4, 7) is u8                         # already bytes: passed through
     assert len(A._KM_CACHE) <= 2
+
+
+def test_trainable_layernorm_form_recheck_is_one_batched_read_and_reports_flips():
+    """tail.recheck_trainable_norms: the K5 backward form of every trainable LayerNorm with a cached decision is re-derived in
+    one pass; a decision that flips is reported (a graph-replaying trainer drops its captures), frozen ones and untouched ones are left."""
+    import torch.nn as nn
+    from vlpet_amd import tail
+    import vlpet_amd.functional as VF
+    m = nn.Sequential(nn.LayerNorm(16), nn.LayerNorm(16), nn.LayerNorm(16))
+    m[2].weight.requires_grad_(False); m[2].bias.requires_grad_(False)
+    for ln in m:
+        ln.weight._vlpet_prenorm = (("k",), VF.WEIGHTS_EPOCH, False)
+    assert tail.recheck_trainable_norms(m) is False                      # gamma = 1, beta = 0: ratio 0 everywhere
+    with torch.no_grad():
+        m[1].bias.fill_(3.0); m[1].weight.fill_(0.1)                     # ratio 30 > PRENORM_RATIO: the exact form
+        m[2].bias.fill_(100.0)                                           # frozen: not looked at here
+    assert tail.recheck_trainable_norms(m) is True
+    assert m[0].weight._vlpet_prenorm[2] is False and m[1].weight._vlpet_prenorm[2] is True and m[2].weight._vlpet_prenorm[2] is False
+    assert tail.recheck_trainable_norms(m) is False                      # nothing flips the second time

@@ -809,7 +809,7 @@ extern "C" int vlpet_visproj_fwd_gemm_cfg(const void* feats, const void* w_io, c
                                           const void* r, void* out, void* xhat, float* rstd, float* mean, void* workspace,
                                           size_t workspace_bytes, int64_t M, int feat_dim, int d_out, float eps, int rms, int io_dtype,
                                           int form, int rows_per_workgroup, vlpet_stream_t stream) {
-    if (form < 0 || (form & 255) > 6 || (form >> 8) > 30 || (rows_per_workgroup != 0 && rows_per_workgroup != 128 && rows_per_workgroup != 192 && rows_per_workgroup != 256)) return VLPET_E_SHAPE;
+    if (form < 0 || (form & 255) > 6 || (form >> 8) > 31 || (rows_per_workgroup != 0 && rows_per_workgroup != 128 && rows_per_workgroup != 192 && rows_per_workgroup != 256)) return VLPET_E_SHAPE;
     return visproj_gemm_call(feats, w_io, bias, gamma, beta, r, out, xhat, rstd, mean, workspace, workspace_bytes, M, feat_dim, d_out,
                              eps, rms, io_dtype, form, rows_per_workgroup, stream);
 }

@@ -613,7 +613,7 @@ static hipError_t launch_visg(VisGemmArgs& a, uint8_t* ws, hipStream_t stream) {
 // the stage ahead spread between the MFMA groups; bm: 0 = by shape
 hipError_t launch_visproj_gemm(VisGemmArgs& a, void* ws, int form, int bm, hipStream_t stream) {
     uint8_t* w8 = reinterpret_cast<uint8_t*>(ws);
-    if (form >> 8) a.spin_limit = 1u << ((form >> 8) & 31);     // (tests of the give-up path: bits 8.. = log2 of the polls before a wave gives up)
+    if (form >> 8) a.spin_limit = ((form >> 8) & 31) == 31 ? 1u : 1u << ((form >> 8) & 31);     // (tests of the give-up path: bits 8.. = log2 of the polls before a wave gives up; 31: one poll)
     form &= 255;
     if (form == 0) form = VISG_DEFAULT_FORM;
     int BMv = visg_pick_bm(a.M, a.d_out, bm);

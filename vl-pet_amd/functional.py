@@ -618,8 +618,12 @@ class _AdapterGateFn(torch.autograd.Function):
             ctx.link = link
         # the other direction: the sublayer's first GEMM (upstream of x2) armed `out_link` -- this backward parks d/dx1 there
         ctx.out_link = out_link if (out_link is not None and out_link.armed and gate_mode != GATE_NONE) else None
-        # the multiplicative gate's backward can start from this output (dq = dy * y * (1 - g): csrc/pet_dz2.hip "YF"); keeping it
-        # costs nothing new -- the sublayer tail that consumes it is alive until its own backward anyway
+        # the multiplicative gate's backward can start from this output (dq = dy * y * (1 - g): csrc/pet_dz2.hip "YF").  Keeping it is
+        # NOT free: the sublayer tail that consumes it saves its own output / pre-norm sum, not y, so one more [M, d] tensor of
+        # the IO dtype lives from this forward to its backward -- 12 of them in a BART-base encoder, 24 in T5-base (43 MB each at 28,000
+        # rows: +0.5 GB of peak activation memory at the configs[1] batch, measured by bench.py's peak_memory_GB with
+        # VLPET_K1_BWD_FROM_X2=1 beside the default; profiles/r06_peak_memory_from_output_ab.txt).  On a 288 GB device the 3 % faster pass 1
+        # is the better trade; memory-constrained runs set K1_BWD_FROM_OUTPUT = False.
         ctx.has_y = bool(K1_BWD_FROM_OUTPUT and act is not None and gate_mode == GATE_MUL)
         ctx.save_for_backward(x1f if x1f is not None else x2f, x2f, *params, *((out,) if ctx.has_y else ()))
         ctx.pk = (pk_a, pk_g)

@@ -24,7 +24,10 @@ from .functional import _finish, _flat, _grad_dest, _grad_like, _io_dtype, _need
 # channels (small gamma, large beta) or a trainable LayerNorm that drifts there.
 # SAVE_PRENORM = None (default, round 5): chosen per LayerNorm from max |beta / gamma| -- form (a) up to PRENORM_RATIO, (b) above it or
 # where a gamma is 0; frozen parameters are looked at once (keyed on storage + version), trainable ones every PRENORM_RECHECK
-# optimizer steps (one host read each time; never inside a graph capture, where the last decision -- or the exact form -- is used).
+# optimizer steps: a trainer does that for ALL of them in one device reduction + one host read (recheck_trainable_norms; round 6) and,
+# when it replays captured steps, drops its graphs if a decision flipped -- a replay runs no Python forward, so the form baked into a
+# graph would otherwise never be revisited; without a trainer each LayerNorm re-reads its own ratio when its stamp is that old (never
+# inside a capture, where the last decision -- or the exact form -- is used).
 # True / False force a form (tests, tools/k5bench.py).
 SAVE_PRENORM = None
 PRENORM_RATIO = 8.0          # measured (tests/test_gpu_tail.py::test_tail_backward_from_output_error_grows_with_beta_over_gamma, profiles/r05_k5abi_ab.txt): worst element of dgamma 0.019 / 0.027 / 0.075 / 0.27 of the 0.1 bound at max |beta / gamma| = 1 / 4 / 16 / 64
@@ -78,6 +81,40 @@ def needs_prenorm(gamma: torch.Tensor, beta: Optional[torch.Tensor]) -> bool:
     dec = not (ratio <= PRENORM_RATIO)
     gamma._vlpet_prenorm = (key, _VF.WEIGHTS_EPOCH, dec)
     return dec
+
+
+def recheck_trainable_norms(model: torch.nn.Module) -> bool:
+    """All trainable LayerNorms of ``model`` that have a cached form decision, re-examined in ONE device reduction and ONE host read
+    (needs_prenorm did a blocking read per LayerNorm, ~40 per recheck, and under graph replay never ran at all -- a replay
+    runs no Python forward, so the form baked into a captured graph was never revisited).  Refreshes every cache entry's stamp; returns
+    True if a decision FLIPPED (a trainer that replays captured steps must then drop its graphs: train.Trainer._finish_step)."""
+    if SAVE_PRENORM is not None:
+        return False
+    from . import functional as _VF
+    ents = []
+    for m in model.modules():
+        g = getattr(m, "weight", None)
+        if not isinstance(g, torch.Tensor) or getattr(g, "_vlpet_prenorm", None) is None or g.dim() != 1:
+            continue
+        b = getattr(m, "bias", None)
+        if not (g.requires_grad or (isinstance(b, torch.Tensor) and b.requires_grad)):
+            continue
+        ents.append((g, b if isinstance(b, torch.Tensor) else None))
+    if not ents:
+        return False
+    ratios = []
+    for g, b in ents:
+        ga = g.detach().float().abs()
+        ba = b.detach().float().abs() if b is not None else torch.zeros_like(ga)
+        ratios.append(torch.where(ga > 0, ba / ga, torch.full_like(ga, float("inf"))).max())
+    vals = torch.stack(ratios).tolist()             # the one host read
+    flipped = False
+    for (g, b), ratio in zip(ents, vals):
+        key, _, old = g._vlpet_prenorm
+        dec = not (ratio <= PRENORM_RATIO)
+        flipped |= dec != old
+        g._vlpet_prenorm = (key, _VF.WEIGHTS_EPOCH, dec)
+    return flipped
 
 
 class _TailFn(torch.autograd.Function):

@@ -423,6 +423,11 @@ def use_tuned_gemms(path: Optional[str] = None, tune: bool = False) -> bool:
     return True
 
 
+def tail_recheck_every() -> int:
+    from . import tail as _tail
+    return max(1, int(_tail.PRENORM_RECHECK) - 1)       # (one step ahead of the per-LayerNorm expiry, so that one never triggers under a trainer)
+
+
 def lr_at(step: int, base_lr: float, warmup_steps: int, total_steps: int) -> float:
     """get_linear_schedule_with_warmup (trainer_base.py:633-720): factor for the update with 0-based index ``step``."""
     if step < warmup_steps:
@@ -686,6 +691,12 @@ class Trainer:
         self.flat.begin_step(zero=False)
         if LABEL_CHECK_EVERY and self.step_idx % LABEL_CHECK_EVERY == 0:
             self.check_labels()
+        if self.flat.flat.is_cuda and self.step_idx % tail_recheck_every() == 0:
+            # K5's backward form per trainable LayerNorm (tail.needs_prenorm), all of them in one reduction + one host read; a captured
+            # step has that form baked in, so a flipped decision drops the graphs (the next step of each shape re-captures)
+            from . import tail as _tail
+            if _tail.recheck_trainable_norms(self.model) and getattr(self, "_graphs", None):
+                self._graphs.clear()
 
     def check_labels(self):
         """Raise if the loss kernels have met labels outside the vocabulary (other than ignore_index -100) since the process started:
