@@ -31,9 +31,6 @@
 #include "cols_common.h"
 #include "cols_reduce.h"
 
-#ifndef VLPET_COLS_STAGED
-#define VLPET_COLS_STAGED 1
-#endif
 template <int RT, bool HAS_IN = false> struct ColzGeo {
     static constexpr int KT = 2 * RT;
     static constexpr int PB = 64 * RT;                  // bytes of a bottleneck row
@@ -43,12 +40,7 @@ template <int RT, bool HAS_IN = false> struct ColzGeo {
     static constexpr int STG_B = X_B + 4 * PT_B;        // + z_a, z_g, dpre_a, dpre_g
     static constexpr int DQ_B = 2 * 4096;
     static constexpr int BIAS_B = 2 * 128 * 4;
-    // round 6: the down side's dx1 / dx2 rows leave through a wave-private staging tile ([2 tensors][32 rows][64 B] per column quarter) so
-    // that a store instruction writes 16 rows x 64 contiguous bytes instead of 64 lanes x 16 bytes in 32 rows (the forward's pass B does
-    // the same, pet_fwd2p.hip); three tiles only: at one tile the three-slot ring leaves no room
-    static constexpr bool STAGED = VLPET_COLS_STAGED != 0 && RT == 3;
-    static constexpr int OST_B = STAGED ? 4 * 4096 : 0;
-    static constexpr size_t lds(int nstg) { return (size_t)nstg * STG_B + 2 * 8192 + DQ_B + BIAS_B + OST_B; }    // ring, dh (x2), dq, biases, output staging
+    static constexpr size_t lds(int nstg) { return (size_t)nstg * STG_B + 2 * 8192 + DQ_B + BIAS_B; }    // ring, dh (x2), dq, biases
 };
 
 #ifndef VLPET_COLS_GRP
@@ -65,8 +57,7 @@ template <int RT, int NSTG, bool ADD, bool HAS_IN>
 __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
     using GEO = ColzGeo<RT, HAS_IN>;
     constexpr int KT = GEO::KT, PB = GEO::PB, PT_B = GEO::PT_B, X_B = GEO::X_B, STG_B = GEO::STG_B, NX = GEO::NX;
-    constexpr int DH_OFF = NSTG * STG_B, DQ_OFF = DH_OFF + 2 * 8192, BIAS_OFF = DQ_OFF + GEO::DQ_B, OST_OFF = BIAS_OFF + GEO::BIAS_B;
-    constexpr bool STAGED = GEO::STAGED;
+    constexpr int DH_OFF = NSTG * STG_B, DQ_OFF = DH_OFF + 2 * 8192, BIAS_OFF = DQ_OFF + GEO::DQ_B;
     constexpr int PR = 32 * RT;
     constexpr int NW = NX + RT;                         // global_load_lds instructions per wave and stage
     // LDS round trips are what a step's instruction stream waits for (a wave alone covers none of them), so operands are
@@ -474,51 +465,8 @@ __global__ __launch_bounds__(512, 2) void k1_cols_kernel(ColzArgs a) {
             u32x4 dhv0, dhv1;
             lds_read16<0>(dhv0, dh0 + a_xcl[0]); lds_read16<0>(dhv1, dh0 + a_xcl[1]);
             lgkm_fence(dhv0); lgkm_tie(dhv1);
-            if constexpr (STAGED) {
-                // both tensors through this wave's staging tile: lane (m, h) writes slots 2h, 2h + 1 of row m (slot ^= (row >> 2) & 3: the eight
-                // lanes of a write group hit eight different 16-byte bank windows), reads back as 4 lanes per row and stores 16 rows x 64 B
-                const uint32_t stg = lds0 + (uint32_t)(OST_OFF + wc * 4096);
-                const int sw = (m >> 2) & 3;
-                const uint32_t aw0 = stg + (uint32_t)(m * 64 + (((2 * h) ^ sw) * 16)), aw1 = stg + (uint32_t)(m * 64 + (((2 * h + 1) ^ sw) * 16));
-                {
-                    float o[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[e] = s2 * bf_at(e < 8 ? dhv0 : dhv1, e & 7) + p2[e];
-                    lds_write16<0>(aw0, pack8(o)); lds_write16<0>(aw1, pack8(o + 8));
-                }
-                {
-                    float o[16];
-                    if constexpr (HAS_IN) {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) o[e] = p1[e] + bf_at(e < 8 ? din0 : din1, e & 7);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) o[e] = p1[e];
-                    }
-                    lds_write16<2048>(aw0, pack8(o)); lds_write16<2048>(aw1, pack8(o + 8));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (the wave's own writes, read back by the same wave: no barrier)
-                u32x4 o2[2], o1[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int rr = (lane >> 2) + 16 * j;
-                    const uint32_t ar = stg + (uint32_t)(rr * 64 + (((lane & 3) ^ ((rr >> 2) & 3)) * 16));
-                    lds_read16<0>(o2[j], ar); lds_read16<2048>(o1[j], ar);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o2[0]), "+v"(o2[1]), "+v"(o1[0]), "+v"(o1[1]) :: "memory");
-                uint8_t* q2 = const_cast<uint8_t*>(sbase(reinterpret_cast<const uint8_t*>(a.dx2) + rb * ld2));
-                uint8_t* q1 = const_cast<uint8_t*>(sbase(reinterpret_cast<const uint8_t*>(a.dx1) + rb * ld2));
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int rr = (lane >> 2) + 16 * j;
-                    const uint32_t off = (uint32_t)rr * (uint32_t)ld2 + (uint32_t)(c0 * 2 + (lane & 3) * 16);
-                    if (rr < valid) {
-                        *reinterpret_cast<u32x4*>(q2 + off) = o2[j];
-                        *reinterpret_cast<u32x4*>(q1 + off) = o1[j];
-                    }
-                }
-                return;
-            }
+            // (round 6: both tensors through a wave-private LDS tile, stored as 64-byte runs of 16 rows per instruction like the forward's pass B --
+            //  built, bit-identical, no gain alone and ~2 us per launch slower in the step: profiles/r06_k1_cols_staged_stores_ab.txt; removed)
             {
                 float o[16];
 #pragma unroll
