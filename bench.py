@@ -434,7 +434,12 @@ def main():
     settling = [timed_round()]
     while len(settling) < 4:
         settling.append(timed_round())
-        if all(settling[-2][t_] <= 1.15 * settling[-1][t_] for t_ in tasks):
+        settled = all(settling[-2][t_] <= 1.15 * settling[-1][t_] for t_ in tasks)
+        if world > 1:       # every rank must run the same number of rounds (each step is a collective): one more unless ALL have settled
+            flag = torch.tensor([0.0 if settled else 1.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            settled = float(flag.item()) == 0.0
+        if settled:
             break
     if world > 1:
         dist.barrier()

@@ -255,9 +255,20 @@ def test_lowrank_repack_after_weight_change_and_inference_form():
     assert float(ve.visual_projector_multihead_up.weight.grad.abs().max()) == 0.0
 
 
-def test_lowrank_rejects_wide_bottleneck():
-    """r > 96 has no rectangular rows kernel: an explicit refusal, not a fallback."""
+def test_lowrank_wide_bottleneck_falls_back_to_plain_torch():
+    """r > 96 has no rectangular rows kernel: since round 6 the module runs that case as plain torch ops (vl-pet_amd/eager.py, SURVEY 8b's
+    "else eager fallback") -- forward and every gradient against the oracle, fp32."""
     from vlpet_amd.visual import LowRankVisualEmbedding
-    ve = LowRankVisualEmbedding(make_cfg(128, 256, 128, 4, 16, True, False), nn.Embedding(50, 128)).cuda()
-    with pytest.raises(NotImplementedError):
-        ve(torch.randn(2, 5, 256).cuda(), torch.rand(2, 5, 4).cuda())
+    torch.manual_seed(3)
+    d, F_, r, nh, rg = 128, 256, 128, 4, 16
+    table = nn.Embedding(50, d)
+    ve = LowRankVisualEmbedding(make_cfg(d, F_, r, nh, rg, True, False), table).cuda()
+    feats, pos = torch.randn(2, 5, F_).cuda(), torch.rand(2, 5, 4).cuda()
+    dy = torch.randn(2, 5, d).cuda()
+    out = ve(feats, pos)
+    out.backward(dy)
+    ref, gref = oracle_run(ve, table, nh, True, False, feats, pos, dy)
+    assert float((out.float().cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    for n, p in ve.named_parameters():
+        if n in gref and gref[n] is not None and p.grad is not None:
+            assert float((p.grad.float().cpu() - gref[n]).abs().max()) <= 1e-3 * float(gref[n].abs().max() + 1e-6), n

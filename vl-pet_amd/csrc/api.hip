@@ -8,7 +8,7 @@
 #include <stdio.h>
 #include <vector>
 
-#define VLPET_VERSION 500      // 500 (round 5): vlpet_visproj_fwd_gemm (K4 as a tiled GEMM + exchanged statistics), vlpet_sublayer_tail_rms_fwd / vlpet_rmsnorm_tail_bwd, vlpet_adapter_gate_bwd_saved_y (backward from the forward's output), vlpet_finalize_defer / _flush; 420: vlpet_lora_delta_fwd_r8 (K3 at rank <= 8 as a streaming kernel, lora8.hip); 410: vlpet_set_seed_counter (dropout seeds under graph replay), two-pass K2 / K3 forward; 400: two-pass K1 forward (pet_fwd2p.hip), vlpet_sublayer_tail_bwd_out;
+#define VLPET_VERSION 600      // 600 (round 6): in-launch reduce-scatter of the K1 backward (cols_reduce.h; vlpet_set_in_launch_reduce, vlpet_adapter_gate_bwd_finalize_launch, phases bit 5), K4 give-up repair inside the call (vlpet_visproj_gemm_exchange_bytes; larger workspace), vlpet_test_hold_cus; 500 (round 5): vlpet_visproj_fwd_gemm (K4 as a tiled GEMM + exchanged statistics), vlpet_sublayer_tail_rms_fwd / vlpet_rmsnorm_tail_bwd, vlpet_adapter_gate_bwd_saved_y (backward from the forward's output), vlpet_finalize_defer / _flush; 420: vlpet_lora_delta_fwd_r8 (K3 at rank <= 8 as a streaming kernel, lora8.hip); 410: vlpet_set_seed_counter (dropout seeds under graph replay), two-pass K2 / K3 forward; 400: two-pass K1 forward (pet_fwd2p.hip), vlpet_sublayer_tail_bwd_out;
 #define VLPET_VERSION_R3 300      // 300: column-parallel K1 backward pass (pet_cols.hip), phases bits 3 / 4, vlpet_adapter_gate_bwd_form;
 #define VLPET_VERSION_R2 221      // 221: vlpet_sublayer_tail_reduce, vlpet_layernorm_bwd_xhat, vlpet_rmsnorm_{fwd,bwd}, vlpet_colsum;  round 2: LoRA dropout generator ABI, sliced AdamW, K3 training form; 210: strided attention entry points, streaming weight gradients; 220: low-rank visual projector
 

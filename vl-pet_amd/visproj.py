@@ -28,13 +28,21 @@ GEMM_THEN_NORM = True          # (honoured when K4_FORM == "library")
 # tiles and re-zeroes the area itself, csrc/visproj_gemm.hip), so no memset runs between launches.  One area per device: K4 launches
 # of one process are issued on one stream at a time.
 _GEMM_WS = {}
+# The area is sized ONCE, for GEMM_WS_ROWS rows, and never reallocated: a captured train step bakes its address into the graph, and since
+# round 6 the size depends on the row count (the per-tile statistics) -- an area that grew with the second task shape would leave the first
+# shape's graph writing into freed memory (found as a memory fault of the replayed LoRA bench).  More rows than that take the library form.
+GEMM_WS_ROWS = 1 << 19
 
 
-def _gemm_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    key = (device.type, device.index)
+def _gemm_workspace(device: torch.device, feat_dim: int, d_out: int) -> torch.Tensor:
+    key = (device.type, device.index, int(d_out))
     ws = _GEMM_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = _GEMM_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    if ws is None:
+        nbytes = _lib.load().vlpet_visproj_gemm_workspace_bytes(GEMM_WS_ROWS, 64, int(d_out))      # (the size does not depend on feat_dim)
+        with torch.cuda.device(device):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("vl-pet_amd: the K4 exchange area must exist before a step is captured (run one eager step first)")
+            ws = _GEMM_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
     return ws
 
 
@@ -46,7 +54,7 @@ def gemm_exchange_status(device=None) -> int:
     sticky status word (train.Trainer.check_labels calls it every LABEL_CHECK_EVERY steps and warns)."""
     tiles = 0
     for key, ws in _GEMM_WS.items():
-        if device is not None and key != (torch.device(device).type, torch.device(device).index):
+        if device is not None and key[:2] != (torch.device(device).type, torch.device(device).index):
             continue
         hdr = ws[:16].view(torch.int32).tolist()        # status, tiles given up so far, ... at the last repair, repair workgroups done
         if hdr[0]:
@@ -118,7 +126,7 @@ class _VisProjFn(torch.autograd.Function):
             g32, be32, b32 = _f32_frozen(gamma), _f32_frozen(beta), _f32_frozen(b)
             xhat = torch.empty_like(out)
             rstd = torch.empty(M, dtype=torch.float32, device=feats.device)
-            ws = _gemm_workspace(feats.device, lib.vlpet_visproj_gemm_workspace_bytes(M, F, d_out))
+            ws = _gemm_workspace(feats.device, F, d_out)
             nws = ws.numel()
             rc = _timed("k4_fwd", M, lambda: lib.vlpet_visproj_fwd_gemm(
                 ff.data_ptr(), wc.data_ptr(), _ptr(b32), g32.data_ptr(), _ptr(be32), _ptr(Rf), out.data_ptr(), xhat.data_ptr(),
@@ -236,7 +244,7 @@ def visproj(feats, R, linear: torch.nn.Linear, norm: torch.nn.Module, cache: Vis
     if K4_FORM == "gemm" and feats.dtype == torch.bfloat16 and feats.is_cuda:
         lib = _lib.load()
         M = feats.numel() // feats.shape[-1]
-        if lib.vlpet_visproj_gemm_workspace_bytes(M, feats.shape[-1], linear.weight.shape[0]) > 0:
+        if M <= GEMM_WS_ROWS and lib.vlpet_visproj_gemm_workspace_bytes(M, feats.shape[-1], linear.weight.shape[0]) > 0:
             cast = cache.get_cast(linear.weight, linear.bias, feats.dtype)
             return _VisProjFn.apply(feats, R, linear.weight, linear.bias, norm.weight, beta, None, eps, rms, cast, True)
     if K4_FORM != "fused" and GEMM_THEN_NORM and not rms and feats.dtype == torch.bfloat16:
