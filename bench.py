@@ -37,15 +37,15 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # launch, so for the other task shapes they are an extrapolation (labelled as such in the line).
 # Two tables: the two-pass form (round 3: pass 1 + column-parallel pass + finalize) and the previous split (--k1-previous-split).
 PMC_TRAFFIC_FORMS = {
-    # round 5: measured at all four task sizes of configs[1] (profiles/r05_pmc_traffic.md); bytes per LAUNCH by rows, interpolated per launch
-    # (second session: re-measured with the backward from the forward's output and, at r = 192, pet_cols6y.hip -- tools/gpu/r5_w.sh)
-    "two_pass": {"source": "profiles/r05_pmc_traffic.md", "measured_at_rows": [15272, 28000, 31616, 46648],
-                 "bytes_by_rows": {"k1_bwd_rows": {15272: 62.7e6, 28000: 112.8e6, 31616: 127.1e6, 46648: 187.8e6},
-                                   "k1_bwd_wgrad": {15272: 177.4e6, 28000: 289.0e6, 31616: 318.0e6, 46648: 445.6e6},
-                                   "k1_bwd_op": {15272: 287.8e6, 28000: 451.8e6, 31616: 495.1e6, 46648: 683.4e6}}},
-    "two_pass_t5": {"source": "profiles/r05_pmc_traffic.md", "measured_at_rows": [18250, 28000],    # r = 192
-                    "bytes_by_rows": {"k1_bwd_rows": {18250: 93.9e6, 28000: 141.5e6}, "k1_bwd_wgrad": {18250: 280.8e6, 28000: 408.4e6},
-                                      "k1_bwd_op": {18250: 425.6e6, 28000: 600.8e6}}},
+    # round 6: measured at all four task sizes of configs[1] (profiles/r06_pmc_traffic.md; tools/gpu/r6_g.sh); bytes per LAUNCH by rows, interpolated
+    # per launch.  r <= 96: pass 2 sums the row-chunk partials itself (no finalize launch), so its figure includes that read.
+    "two_pass": {"source": "profiles/r06_pmc_traffic.md", "measured_at_rows": [15272, 28000, 31616, 46648],
+                 "bytes_by_rows": {"k1_bwd_rows": {15272: 62.7e6, 28000: 112.8e6, 31616: 127.1e6, 46648: 187.6e6},
+                                   "k1_bwd_wgrad": {15272: 226.2e6, 28000: 340.3e6, 31616: 369.4e6, 46648: 496.9e6},
+                                   "k1_bwd_op": {15272: 288.9e6, 28000: 453.1e6, 31616: 496.5e6, 46648: 684.5e6}}},
+    "two_pass_t5": {"source": "profiles/r06_pmc_traffic.md", "measured_at_rows": [18250, 28000],    # r = 192
+                    "bytes_by_rows": {"k1_bwd_rows": {18250: 93.9e6, 28000: 141.5e6}, "k1_bwd_wgrad": {18250: 280.4e6, 28000: 409.2e6},
+                                      "k1_bwd_op": {18250: 425.2e6, 28000: 601.6e6}}},
     "previous_split": {"source": "profiles/r02_pmc_traffic_k1_bwd.md", "measured_at_rows": [28000],
                        "bytes_by_rows": {"k1_bwd_rows": {28000: 11881.0 * 28000}, "k1_bwd_op": {28000: 20432.0 * 28000}}},
 }

@@ -310,7 +310,7 @@ int vlpet_visproj_fwd_gemm(const void* feats, const void* w_io, const float* bia
                            vlpet_stream_t stream);
 /* ... with the LDS ring form (bits 0-7 of `form`: 1: 64 input features per stage / 2 slots, 2: 32 / 4, 3: 32 / 3, 4-6: the same with
  * spread requests; 0: default) and the rows per workgroup (128 / 192 / 256; 0: by shape) forced: measurement and parity of the
- * non-default forms.  Bits 8-12 of `form`, if nonzero: log2 of the polls before a wave gives up on a partner, 31 = a single poll (tests of the repair path). */
+ * non-default forms.  Bits 8-12 of `form`, if nonzero: log2 of the polls before a wave gives up on a partner, 31 = a single poll, 30 = every workgroup gives up without polling (tests of the repair path). */
 int vlpet_visproj_fwd_gemm_cfg(const void* feats, const void* w_io, const float* bias, const float* gamma, const float* beta,
                                const void* r, void* out, void* xhat, float* rstd, float* mean, void* workspace,
                                size_t workspace_bytes, int64_t M, int feat_dim, int d_out, float eps, int rms, int io_dtype,

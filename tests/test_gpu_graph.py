@@ -252,3 +252,41 @@ def test_replayed_training_with_dropout_reduces_the_loss():
     # step size, with fresh masks it jitters
     d = [losses[i + 1] - losses[i] for i in range(10, 39)]
     assert any(x > 0 for x in d)
+
+
+_NLVR_REPLAY_CHILD = r"""
+import copy, sys, torch
+sys.path.insert(0, {tests!r}); sys.path.insert(0, {root!r})
+import test_gpu_graph as T
+import vlpet_amd.train as TR
+model, cfg = T._tiny(0.0)
+m_eager, m_graph = copy.deepcopy(model).cuda(), copy.deepcopy(model).cuda()
+gen = torch.Generator().manual_seed(7)
+tasks = ("gqa", "nlvr", "caption")          # NLVR captured AFTER one shape and BEFORE another: the order that showed the fault
+batches = {{t: T._cuda_batch(TR.synthetic_batch(t, 48, cfg, "cpu", gen)) for t in tasks}}     # 48 x 72 image-order ids > 3,072: torch's sort-based embedding backward
+order = tasks * 5
+tre = TR.Trainer(m_eager, cfg, lr=1e-3, total_steps=40, warmup_ratio=0.1)
+le = [float(tre.step(batches[t])) for t in order]
+trg = TR.Trainer(m_graph, cfg, lr=1e-3, total_steps=40, warmup_ratio=0.1, graph=True)
+lg = []
+for t in order:
+    lg.append(float(trg.step(batches[t])))
+    torch.cuda.synchronize()
+assert len(trg._graphs) == 3
+for a, b in zip(lg, le):
+    assert abs(a - b) <= 1e-4 * abs(b), (lg, le)
+print("ok")
+"""
+
+
+def test_replayed_nlvr_step_survives_later_captures():
+    """Round 6: the replayed full-batch BART / LoRA bench died with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in the SECOND replay of the NLVR
+    step whenever another shape had been captured before AND after it.  Cause: NLVR hands the visual embedding one image-order id per
+    visual token (B x 72 > 3,072 indices), torch's embedding backward then takes its sort-based path, and that kernel sequence does not
+    survive hipGraph replay on this stack; visual._order_lookup runs the few-row table as a one-hot GEMM instead.  Child process (a memory
+    fault aborts the interpreter): three shapes with NLVR in the middle, five rounds, replayed losses equal the eager trainer's."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _NLVR_REPLAY_CHILD.format(tests=os.path.dirname(os.path.abspath(__file__)), root=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -203,6 +203,7 @@ def test_k4_gemm_statistics_survive_a_large_common_offset():
 
 
 _ONE_POLL = 31 << 8          # form bits 8-12 = 31: "log2 of the bound" 31 is read as the special value ONE poll (csrc/visproj_gemm.hip)
+_GIVE_UP = 30 << 8           # ... 30: every workgroup takes the give-up path without polling
 
 
 def _gemm_check(got, ref, rms):
@@ -222,21 +223,25 @@ def test_k4_gemm_with_64_cus_held_by_another_stream(M, F, d, rms):
     _gemm_check(got, ref, rms)
 
 
+@pytest.mark.parametrize("mode", ["all", "one_poll"])
 @pytest.mark.parametrize("M,F,d,rms", [(2000, 512, 768, False), (1500, 512, 768, True), (900, 512, 1024, False), (18700, 2048, 768, False)])
-def test_k4_gemm_workgroups_that_give_up_are_repaired_inside_the_call(M, F, d, rms):
-    """The give-up path itself, made certain: with the polling bound lowered to ONE poll (form bits 8..: log2 of the bound) a workgroup
-    gives up on every partner that has not published by the time it has -- i.e. all but the last publisher of every team, on an idle GPU.
-    The call must (i) return rows that match the reference all the same -- the repair kernel re-normalises the flagged tiles from the
-    complete per-tile statistics --, (ii) report it in the status word, (iii) leave the exchange area clean although late producers wrote
-    granules after their consumer had given up (checked inside _gemm_abi); a plain call on the SAME workspace afterwards is right and does
-    not touch the counters.  (Holding all but a few CUs from a second stream does not work as a trigger: while a high-priority kernel
-    still has workgroups to place, no other kernel is dispatched at all -- profiles/r06_in_launch_reduce_ab.txt (4).)"""
+def test_k4_gemm_workgroups_that_give_up_are_repaired_inside_the_call(M, F, d, rms, mode):
+    """The give-up path itself.  "all": every workgroup gives up on its partners without polling, so EVERY tile leaves its pre-norm rows
+    and is normalised by the repair kernel; "one_poll": the polling bound is one poll, so a workgroup gives up exactly when a partner has
+    not published by then (most of them at the large size, possibly none at the small ones -- whatever the timing gives).  The call must
+    (i) return rows that match the reference all the same -- the repair kernel re-normalises the flagged tiles from the complete
+    per-tile statistics --, (ii) report it in the status word, (iii) leave the exchange area clean although late producers wrote granules
+    after their consumer had given up (checked inside _gemm_abi); a plain call on the SAME workspace afterwards is right and does not
+    touch the counters.  (Holding all but a few CUs from a second stream does not work as a trigger: while a high-priority kernel still
+    has workgroups to place, no other kernel is dispatched at all -- profiles/r06_in_launch_reduce_ab.txt (4).)"""
     from vlpet_amd import _lib
     ws = torch.zeros(_lib.load().vlpet_visproj_gemm_workspace_bytes(M, F, d), dtype=torch.uint8, device="cuda")
-    got, ref = _gemm_abi(M, F, d, rms, _ONE_POLL, 128, seed=12, ws_keep=ws)
+    got, ref = _gemm_abi(M, F, d, rms, _GIVE_UP if mode == "all" else _ONE_POLL, 128, seed=12, ws_keep=ws)
     _gemm_check(got, ref, rms)
     hdr = ws[:16].view(torch.int32).tolist()
-    assert got[4] != 0 and hdr[1] > 0, "no workgroup gave up although the polling bound was one poll"
+    if mode == "all":
+        tiles = ((M + 127) // 128) * (d // 256)
+        assert got[4] != 0 and hdr[1] == tiles, (hdr, tiles)
     given_up = hdr[1]
     again, ref2 = _gemm_abi(M, F, d, rms, 0, 128, seed=13, ws_keep=ws)
     _gemm_check(again, ref2, rms)

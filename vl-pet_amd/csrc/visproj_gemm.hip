@@ -330,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void visproj_gemm_kernel(VisGemmArgs a) {
                         __hip_atomic_store(dst + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                float pm[3], pq[3];
+                float pm[3] = {0.f, 0.f, 0.f}, pq[3] = {0.f, 0.f, 0.f};
                 bool timed_out = false;
                 for (unsigned spins = 0;; ++spins) {
                     bool ok = true;
@@ -345,6 +345,7 @@ __global__ __launch_bounds__(512, 2) void visproj_gemm_kernel(VisGemmArgs a) {
                             pm[k] = __uint_as_float((unsigned)x0); pq[k] = __uint_as_float((unsigned)x1);
                         }
                     }
+                    if (a.spin_limit == 0xffffffffu) { timed_out = true; break; }            // (tests: every workgroup takes the give-up path)
                     if (__all(ok)) break;
                     if (spins >= a.spin_limit) { timed_out = true; break; }                  // (wave-uniform: every lane counts the same)
                     __builtin_amdgcn_s_sleep(4);
@@ -605,7 +606,8 @@ static hipError_t launch_visg(VisGemmArgs& a, uint8_t* ws, hipStream_t stream) {
     if (e != hipSuccess || NT == 1) return e;
     // the repair pass of the same call: two loads and out unless a workgroup gave up (see the kernel)
     const int tiles = a.row_blocks * NT;
-    hipLaunchKernelGGL(visproj_gemm_repair_kernel, dim3(tiles < 256 ? tiles : 256), dim3(256), 0, stream, a, BM, xch_b / 8);
+    // (16 workgroups: the normal case is "two loads and out", and a 213-workgroup launch of that took 4.8 us -- profiles/r06_pmc_traffic.md)
+    hipLaunchKernelGGL(visproj_gemm_repair_kernel, dim3(tiles < 16 ? tiles : 16), dim3(256), 0, stream, a, BM, xch_b / 8);
     return hipGetLastError();
 }
 
@@ -613,7 +615,8 @@ static hipError_t launch_visg(VisGemmArgs& a, uint8_t* ws, hipStream_t stream) {
 // the stage ahead spread between the MFMA groups; bm: 0 = by shape
 hipError_t launch_visproj_gemm(VisGemmArgs& a, void* ws, int form, int bm, hipStream_t stream) {
     uint8_t* w8 = reinterpret_cast<uint8_t*>(ws);
-    if (form >> 8) a.spin_limit = ((form >> 8) & 31) == 31 ? 1u : 1u << ((form >> 8) & 31);     // (tests of the give-up path: bits 8.. = log2 of the polls before a wave gives up; 31: one poll)
+    // (tests of the give-up path: bits 8.. = log2 of the polls before a wave gives up; 31: one poll; 30: every workgroup gives up at once)
+    if (form >> 8) a.spin_limit = ((form >> 8) & 31) == 31 ? 1u : ((form >> 8) & 31) == 30 ? 0xffffffffu : 1u << ((form >> 8) & 31);
     form &= 255;
     if (form == 0) form = VISG_DEFAULT_FORM;
     int BMv = visg_pick_bm(a.M, a.d_out, bm);

@@ -85,6 +85,19 @@ class Downsample(nn.Module):
         return x, boxes[:, :x.shape[1]]
 
 
+def _order_lookup(table: nn.Embedding, ids: torch.Tensor) -> torch.Tensor:
+    """``table(ids)`` for the image-order embedding (src/modeling_bart.py:170-171: ``n_images`` rows, trainable).  NLVR hands over one id
+    per visual token of every sample ([B, 72] = 11,952 indices of 2 distinct values); torch's embedding backward then takes its sort-based
+    path (radix sort + unique-by-key + segmented sums, ~15 launches), and THAT sequence does not survive hipGraph replay on this stack:
+    the second replay of a captured NLVR step, once another shape had been captured after it, died with
+    HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION (found in round 6 with tools/lora_graph_probe.py: full-batch BART and LoRA alike, gone with
+    this form).  A table of a few rows is a [n_ids, n_rows] one-hot GEMM both ways instead -- two small library GEMMs, no sort."""
+    if table.num_embeddings <= 8 and ids.numel() > 3072 and table.weight.requires_grad:
+        onehot = F.one_hot(ids.reshape(-1), table.num_embeddings).to(table.weight.dtype)
+        return (onehot @ table.weight).view(*ids.shape, table.embedding_dim)
+    return table(ids)
+
+
 class VisualEmbedding(nn.Module):
     def __init__(self, config, obj_order_embedding: nn.Embedding, rms_norm: bool = False):
         super().__init__()
@@ -133,7 +146,7 @@ class VisualEmbedding(nn.Module):
             if obj_order_ids is None:
                 obj_order_ids = torch.arange(N, dtype=torch.long, device=dev).unsqueeze(0)
             obj_order_ids = self.obj_order_embedding.num_embeddings - obj_order_ids - 1
-            R = R + self.img_order_embedding(img_order_ids).float() + self.obj_order_embedding(obj_order_ids).float()
+            R = R + _order_lookup(self.img_order_embedding, img_order_ids).float() + self.obj_order_embedding(obj_order_ids).float()
         R = R.expand(B, N, R.shape[-1])
         if not per_branch:
             # no LayerNorm behind the feature projection (use_vis_layer_norm off, or ONE norm over the sum: src/modeling_bart.py:186-188):
@@ -203,7 +216,7 @@ class LowRankVisualEmbedding(nn.Module):
             if obj_order_ids is None:
                 obj_order_ids = torch.arange(N, dtype=torch.long, device=dev).unsqueeze(0)
             obj_order_ids = self.obj_order_embedding.num_embeddings - obj_order_ids - 1
-            R = R + self.img_order_embedding(img_order_ids).float() + self.obj_order_embedding(obj_order_ids).float()
+            R = R + _order_lookup(self.img_order_embedding, img_order_ids).float() + self.obj_order_embedding(obj_order_ids).float()
         R = R.expand(B, N, R.shape[-1])
         gated = hasattr(self, "visual_projector_gating_large_x_down")
         r_max = max(self.visual_projector_multihead_up.weight.shape[1],
