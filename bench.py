@@ -310,10 +310,11 @@ def main():
                          "region brackets only the roofline's op), inline (every launch bracketed inside the timed region), off")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="train.Trainer(graph=True): forward + backward of a step captured per task shape with hipGraph and replayed "
-                         "(optimizer and gradient exchange eager).  auto = on for the strong-scaled per-rank batches (--gpus > 1 with "
-                         "strong scaling, --emulate-ranks > 1) and for --model t5 / lora / video, where the eager step is bound by its "
-                         "host-side launches; off for the headline workload (configs[1] at the full single-GPU batch: GPU-bound "
-                         "either way, 19.24 vs 19.21 ms) so that its roofline op stays bracketed inside the timed region")
+                         "(optimizer and gradient exchange eager).  auto = on wherever the trainer can replay (same box, round 6: the "
+                         "headline workload 16.99 ms replayed vs 17.93 ms eager -- the eager step's ~150 host launches are no longer hidden "
+                         "behind the kernels).  A replayed step runs no host code, and events recorded inside a captured graph cannot be "
+                         "read on this stack (tools/graph_event_probe.py), so the same K-step schedule runs once more eagerly right after "
+                         "the timed region with the roofline op bracketed (`eager_region`).  off = the eager step timed, brackets inside it")
     ap.add_argument("--capture-collectives", action="store_true",
                     help="graph mode, --gpus > 1: launch the bucket all-reduces from inside the captured backward (RCCL collectives as graph nodes: "
                          "overlap kept under replay) instead of after the replay.  Tested with a one-rank RCCL communicator only.")
@@ -386,12 +387,11 @@ def main():
     total_steps = max(args.steps + args.warmup, 10) + 8
     tr = TR.Trainer(model, cfg, lr=1e-3, clip=5.0, total_steps=total_steps, world_size=n_ranks, n_buckets=args.buckets,
                     overlap_wgrad=args.overlap_wgrad, capture_collectives=args.capture_collectives)
-    # auto: replayed graphs wherever the eager step is bound by its host-side launches -- the strong-scaled per-rank batches, and the
-    # T5 / LoRA / video configs even at the full batch (T5: 29.3 ms of kernels in a 37.4 ms eager step; LoRA: 21.5 in 27.1); the
-    # headline workload (configs[1] at one GPU, GPU-bound: 18.85 vs 19.1 ms) stays eager so that its roofline op is bracketed inside
-    # the timed region
-    want_graph = args.graph == "on" or (args.graph == "auto" and (args.emulate_ranks > 1 or (n_ranks > 1 and args.scaling == "strong")
-                                                                  or args.model != "bart"))
+    # auto: replayed graphs wherever the trainer can replay.  Rounds 3-5 kept the headline workload (configs[1], full one-GPU batch)
+    # eager: its NLVR shape faulted at the second replay (torch's sort-based embedding backward for the 36,000 image-order ids; fixed in
+    # round 6, visual._order_lookup) and the eager step was GPU-bound anyway.  With the round-6 kernels it no longer is: 16.99 ms
+    # replayed vs 17.93 ms eager on one box (profiles/r06_bench_bart_graph_s2.json.log, r06_bench_bart_s2.json.log)
+    want_graph = args.graph in ("on", "auto")
     graph_on = bool(want_graph and tr.enable_graph())      # (False for per-task adapters / a side-stream trainer: those stay eager)
     # a shape runs once eagerly, is captured at its second step and replays from then on: two untimed SETUP steps per task in front of
     # the W warm-up steps (which then already replay), so that --warmup / --steps keep their meaning.  Eager: one setup step per task
@@ -409,7 +409,7 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     batches = {t: TR.synthetic_batch(t, rank_batch(t), cfg, dev, gen, no_padding=not args.pad_mask) for t in tasks}
     order = [tasks[i % len(tasks)] for i in range(args.warmup + args.steps)]
-    total_steps = max(args.steps + args.warmup + setup_steps, 10) + 8 + 4 * len(tasks)     # (+ the settling rounds)
+    total_steps = max(args.steps + args.warmup + setup_steps, 10) + 8 + 5 * len(tasks) + args.steps     # (+ the settling rounds, + the eager region after a replayed one)
     tr.total, tr.warmup = total_steps, int(total_steps * 0.1)
 
     for i in range(setup_steps):
@@ -468,15 +468,30 @@ def main():
     step_ms = [round(step_ev[k].elapsed_time(step_ev[k + 1]), 3) for k in range(args.steps)]
     peak_gb = round(torch.cuda.max_memory_allocated(dev) / 1e9, 3)     # peak of torch's allocator up to the end of the timed region (all task shapes seen)
     timer, VF.TIMER = VF.TIMER, None
+    eager_region = None
     if graph_on:
-        # a replayed step runs no host code, so nothing was bracketed above: the roofline op is bracketed in eager steps of the same
-        # process right after the timed region (two per task), like the rest of the kernel table
+        # a replayed step runs no host code, so nothing was bracketed above (and an event recorded inside a captured graph cannot be
+        # read back: tools/graph_event_probe.py, "invalid resource handle").  The SAME K-step schedule runs once more, eagerly, in this
+        # process right after the timed region, with the roofline op bracketed on the launch stream exactly as --graph off brackets
+        # it: `roofline` comes from these K steps, and their wall time is reported beside `value` as `eager_region`.
         tr.disable_graph()
-        timer = VF.TIMER = VF.KernelTimer(None if args.kernel_table == "inline" else dom_names)
-        for i in range(2 * len(tasks)):
-            tr.step(batches[tasks[i % len(tasks)]])
+        for t_ in tasks:        # (one untimed eager step per task: the allocator's eager blocks)
+            tr.step(batches[t_])
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        timer = VF.TIMER = VF.KernelTimer(None if args.kernel_table == "inline" else dom_names)
+        e0 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + args.steps):
+            tr.step(batches[order[i]])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        e_dt = time.perf_counter() - e0
         VF.TIMER = None
+        eager_region = {"ms_per_step": round(e_dt / args.steps * 1e3, 3), "steps": args.steps,
+                        "samples_per_s_this_rank": round(samples / e_dt, 2),
+                        "note": "the same K steps, eager launches, right after the timed region; the roofline op's HIP-event brackets are from these steps"}
     table_timer = None
     if args.kernel_table == "after" and rank == 0:
         table_timer = VF.TIMER = VF.KernelTimer()
@@ -670,6 +685,7 @@ def main():
             **step_time_report(step_ms, [order[i] for i in range(args.warmup, args.warmup + args.steps)],
                                {t: rank_batch(t) for t in tasks}, settling, n_ranks),
             "peak_memory_GB": peak_gb,
+            **({"eager_region": eager_region} if eager_region else {}),
             "roofline": roof, "kernels": kernels, "backbone_gemm_table": gemm_table,
             **({"ab_switches": ab_switches} if ab_switches else {}),
             **({"other_scaling": strong} if strong is not None else {}),
@@ -684,13 +700,15 @@ def main():
                                            "exchange follows the replayed backward)"}}
                if args.emulate_ranks > 1 else {}),
             "step_mode": (f"hipGraph replay: forward + loss + backward captured once per task shape (train.Trainer(graph=True); {setup_steps} "
-                          "untimed setup steps before the warm-up), gradient exchange + clip + AdamW eager; roofline brackets from eager "
-                          "steps right after the timed region") if graph_on
+                          "untimed setup steps before the warm-up), gradient exchange + clip + AdamW eager; roofline brackets from the "
+                          "same K steps run eagerly right after the timed region (eager_region)") if graph_on
                          else f"eager launches (roofline op bracketed inside the timed region; {setup_steps} untimed setup steps, one per task shape, before the warm-up)",
             "attention_mask": ("default input_ids.ne(pad) mask built and applied every step, as the reference does" if args.pad_mask
                                else "none built (--no-pad-mask: the synthetic rows carry no padding)"),
-            "kernel_table": {"after": "roofline op bracketed inside the timed region; the other launch groups in one step per task after it",
-                             "inline": "every launch group bracketed inside the timed region", "off": "roofline op only"}[args.kernel_table],
+            "kernel_table": {"after": ("roofline op bracketed in the eager region (the timed region's K steps again, eager); " if graph_on
+                                       else "roofline op bracketed inside the timed region; ") + "the other launch groups in one step per task after it",
+                             "inline": "every launch group bracketed inside the " + ("eager region" if graph_on else "timed region"),
+                             "off": "roofline op only"}[args.kernel_table],
         }
         if n_ranks == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
