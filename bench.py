@@ -619,7 +619,8 @@ def main():
             kernels["k1_bwd_op"] = dict(launches=a["launches"], avg_us=round(op_us / a["launches"], 2),
                                         total_ms=round(op_us / 1e3, 3), algorithmic_GBps=round(gbps, 1),
                                         hbm_frac=round(gbps / HBM_PEAK_GBS, 4),
-                                        note=("pass 1 + column-parallel pass + finalize of one K1 backward, 5*d*b per row" if two_pass
+                                        note=(("pass 1 + column-parallel pass + finalize launch" if "k1_bwd_fin" in agg else
+                                               "pass 1 + column-parallel pass (weight gradients reduced in-launch)") + " of one K1 backward, 5*d*b per row" if two_pass
                                               else "rows kernel + weight-gradient kernels of one K1 backward, 5*d*b per row"))
         # dominant HIP kernel of the hot path by time
         if args.model == "lora":
@@ -653,7 +654,9 @@ def main():
         op = kernels.get("k1_bwd_op") if dom in ("k1_bwd_rows", "k1_bwd_wgrad") else None
         if op is not None:
             achieved, launch_us, what = op["algorithmic_GBps"], op["avg_us"], "K1 backward op = " + \
-                ("pass 1 + column-parallel pass + finalize" if two_pass else "rows kernel + weight-gradient kernels")
+                (("pass 1 + column-parallel pass + finalize launch" if "k1_bwd_fin" in agg else
+                  "pass 1 + column-parallel pass (in-launch reduce-scatter where M >= 8192, finalize launch below)") if two_pass
+                 else "rows kernel + weight-gradient kernels")
             algo_row = 5 * d * esz
             if traffic:
                 traffic = pmc_avg("k1_bwd_op")
