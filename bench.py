@@ -588,7 +588,7 @@ def main():
         per_row = {"k1_fwd": 3 * d * esz, "k1_bwd_rows": (2 if two_pass else 5) * d * esz, "k1_bwd_wgrad": (5 if two_pass else 0) * d * esz,
                    "k1_bwd_fin": 0, "k2_fwd": 3 * d * esz,
                    "k2_bwd": 3 * d * esz, "k3_fwd": 3 * d * esz, "k3_bwd": 3 * d * esz, "k5_fwd": 3 * d * esz,
-                   "k5_bwd": 3 * d * esz, "k4_ln_bwd": 3 * d * esz,
+                   "k5_bwd": 3 * d * esz, "k4_ln_bwd": 3 * d * esz, "k4_pos_fwd": d * esz, "k4_pos_bwd": d * esz,     # (R written / dout read)
                    "rms_fwd": 2 * d * esz, "rms_bwd": 3 * d * esz}      # (K4's LayerNorm backward: dout, xhat read, dpre written)
         d_ff = int(getattr(cfg, "encoder_ffn_dim", 0) or getattr(cfg, "d_ff", 0))
         per_row.update({"ffn_act_fwd": 2 * d_ff * esz, "ffn_act_bwd": 3 * d_ff * esz})   # backbone FFN activation + dropout pass

@@ -315,6 +315,30 @@ int vlpet_visproj_fwd_gemm_cfg(const void* feats, const void* w_io, const float*
                                const void* r, void* out, void* xhat, float* rstd, float* mean, void* workspace,
                                size_t workspace_bytes, int64_t M, int feat_dim, int d_out, float eps, int rms, int io_dtype,
                                int form, int rows_per_workgroup, vlpet_stream_t stream);
+/* K4's position / order branch, the R the feature projection adds behind its norm:
+ *     R[b, n, :] = norm_p( W_p [x1, x2, y1, y2, area] + b_p ) + img_order_embedding[img_id[b, n]] + obj_order_embedding[V - 1 - obj_id[b, n]]
+ * with area = (y2 - y1) (x2 - x1); norm_p = LayerNorm (BART) or T5LayerNorm (rms = 1: no mean, beta ignored).  One launch; rows are
+ * (b, n) pairs, M = B N.  pos [M, 4] fp32; w [d, 5], b, gamma, beta [d] fp32; tables [n_img, d] / [obj_rows, d] in fp32 or bf16
+ * (both NULL: no order embeddings -- config.use_vis_order_embedding off); ids int64 [B, N] (batch stride N) or [1, N] (stride 0), NULL =
+ * the reference's defaults (image 0, object n); ids outside their table are clamped.  out [M, d] in the IO dtype (the fp32 value
+ * rounded once).  d a multiple of 256 (<= 1024), n_img <= 4: vlpet_vispos_applies.
+ * replaces: src/modeling_bart.py:129-141,162-183 (T5: src/modeling_t5.py:109-122,143-165). */
+int vlpet_vispos_applies(int d, int n_img);
+int vlpet_vispos_fwd(const float* pos, const float* w, const float* b, const float* gamma, const float* beta,
+                     const void* img_table, int img_table_dtype, int n_img, const int64_t* img_ids, int64_t img_ids_bstride,
+                     const void* obj_table, int obj_table_dtype, int64_t obj_rows, const int64_t* obj_ids, int64_t obj_ids_bstride,
+                     void* out, int64_t M, int N, int d, float eps, int rms, int io_dtype, vlpet_stream_t stream);
+/* ... and its backward from dout = the gradient of the visual embedding's output (= dR), [M, d] IO dtype.  WRITES dw [d, 5], db, dgamma,
+ * dbeta [d] (dbeta NULL with rms), dimg [n_img, d] (NULL: no image-order table); two launches (per-workgroup column partials, then
+ * their sum in a fixed order: deterministic).  No gradient for the object-order table (the shared token table, frozen in every launch
+ * script).  workspace: vlpet_vispos_bwd_workspace_bytes.
+ * replaces: autograd of the lines above. */
+size_t vlpet_vispos_bwd_workspace_bytes(int64_t M, int d, int n_img);
+int vlpet_vispos_bwd(const void* dout, const float* pos, const float* w, const float* b, const float* gamma,
+                     int n_img, const int64_t* img_ids, int64_t img_ids_bstride,
+                     float* dw, float* db, float* dgamma, float* dbeta, float* dimg,
+                     void* workspace, size_t workspace_bytes, int64_t M, int N, int d, float eps, int rms, int io_dtype,
+                     vlpet_stream_t stream);
 /* Weight gradient of the projection:  dw [d_out, F] = dpre^T @ feats,  db [d_out] = column sums of dpre
  * (dpre = gradient w.r.t. the pre-norm activations, [M, d_out], IO dtype).  fp32, overwritten. */
 size_t vlpet_visproj_wgrad_workspace_bytes(int64_t M, int feat_dim, int d_out);

@@ -281,3 +281,140 @@ def test_k4_weight_gradient_tiled_gemm(M, F, d):
     ref_w = dpre.float().t() @ feats.float()
     ref_b = dpre.float().sum(0)
     assert rel_err(dw, ref_w) <= 1e-4 and rel_err(db, ref_b) <= 1e-4      # exact products of bf16 inputs, fp32 sums
+
+
+# ------------------------------------------------------------------------------------------------ position / order branch (csrc/vispos.hip)
+def _pos_oracle(pos, w, b, g, be, img_t, obj_t, img_ids, obj_ids, rms, eps):
+    """oracle.visual_embedding with a zero feature branch = the position branch + the order embeddings alone (src/modeling_bart.py:162-183)"""
+    B, N, _ = pos.shape
+    d = w.shape[0]
+    feats = torch.zeros(B, N, 8)
+    return O.visual_embedding(feats, pos, torch.zeros(d, 8), torch.zeros(d), None, None, w, b, g, be, img_t, obj_t,
+                              img_order_ids=img_ids, obj_order_ids=obj_ids, eps=eps, rms=rms)
+
+
+@pytest.mark.parametrize("d,B,N,ids,tab_dt,rms,io", [
+    (768, 9, 36, "default", "f32", False, "bf16"),
+    (768, 9, 36, "default", "f32", False, "f32"),
+    (768, 7, 72, "per_sample", "f32", False, "bf16"),          # NLVR: explicit image ids per sample, two images
+    (768, 5, 36, "broadcast", "bf16", False, "bf16"),          # a frozen bf16 token table, [1, N] ids
+    (768, 6, 36, "default", "f32", True, "bf16"),              # T5LayerNorm
+    (256, 3, 10, "per_sample", "f32", False, "f32"),
+    (1024, 4, 36, "per_sample", "bf16", True, "bf16"),
+    (768, 500, 36, "default", "f32", False, "bf16"),           # configs[1] vqa rows (18,000): every workgroup several rows per wave
+    (768, 4, 36, "none", "f32", False, "bf16"),                # use_vis_order_embedding off
+])
+def test_position_branch_kernel_through_the_abi_vs_oracle(d, B, N, ids, tab_dt, rms, io):
+    from vlpet_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(5)
+    M, n_img, V = B * N, (4 if d == 1024 else 2), 97
+    eps = 1e-6 if rms else 1e-5
+    pos = torch.rand(B, N, 4)
+    pos[..., 1] += pos[..., 0]; pos[..., 3] += pos[..., 2]
+    w, b = torch.randn(d, 5) * 0.3, torch.randn(d) * 0.1
+    g, be = 1 + 0.1 * torch.randn(d), (None if rms else 0.1 * torch.randn(d))
+    tdt = torch.bfloat16 if tab_dt == "bf16" else torch.float32
+    img_t, obj_t = (torch.randn(n_img, d) * 0.5).to(tdt), (torch.randn(V, d) * 0.5).to(tdt)
+    img_ids = obj_ids = None
+    if ids == "per_sample":
+        img_ids, obj_ids = torch.randint(0, n_img, (B, N)), torch.randint(0, V, (B, N))
+    elif ids == "broadcast":
+        img_ids, obj_ids = torch.randint(0, n_img, (1, N)), torch.randint(0, N, (1, N))
+    tabs = ids != "none"
+    leaves = [t.clone().requires_grad_(True) for t in (w, b, g)] + ([be.clone().requires_grad_(True)] if be is not None else [None])
+    img_leaf = img_t.float().clone().requires_grad_(True) if tabs else None
+    ref = _pos_oracle(pos, leaves[0], leaves[1], leaves[2], leaves[3], img_leaf, obj_t.float() if tabs else None, img_ids, obj_ids, rms, eps)
+    iot = torch.float32 if io == "f32" else torch.bfloat16
+    dout = torch.randn(B, N, d).to(iot)
+    ref.backward(dout.float())
+    dev = "cuda"
+    c = lambda t: None if t is None else t.to(dev).contiguous()
+    pos_c, w_c, b_c, g_c, be_c, img_c, obj_c = c(pos), c(w), c(b), c(g), c(be), c(img_t) if tabs else None, c(obj_t) if tabs else None
+    ii, oi = c(img_ids), c(obj_ids)
+    out = torch.empty(B, N, d, dtype=iot, device=dev)
+    iod = _lib.VLPET_F32 if io == "f32" else _lib.VLPET_BF16
+    tdd = _lib.VLPET_BF16 if tab_dt == "bf16" else _lib.VLPET_F32
+    P = lambda t: None if t is None else t.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    bstride = lambda t: 0 if (t is None or t.shape[0] == 1) else N
+    assert lib.vlpet_vispos_applies(d, n_img if tabs else 0) == 1
+    rc = lib.vlpet_vispos_fwd(P(pos_c), P(w_c), P(b_c), P(g_c), P(be_c), P(img_c), tdd, n_img if tabs else 0, P(ii), bstride(ii),
+                              P(obj_c), tdd, V if tabs else 0, P(oi), bstride(oi), P(out), M, N, d, eps, int(rms), iod, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    # the kernel rounds the fp32 value once to the IO dtype: one bf16 ulp of the largest entries
+    tol_el = 2e-5 if io == "f32" else 2.0 ** -8
+    err = (out.float().cpu() - ref.detach()).abs().max().item()
+    assert err <= tol_el * max(1.0, ref.detach().abs().max().item()), err
+    dw, db, dg = torch.full((d, 5), 7.0, device=dev), torch.full((d,), 7.0, device=dev), torch.full((d,), 7.0, device=dev)
+    dbe = None if rms else torch.full((d,), 7.0, device=dev)
+    dimg = torch.full((n_img, d), 7.0, device=dev) if tabs else None
+    nws = lib.vlpet_vispos_bwd_workspace_bytes(M, d, n_img if tabs else 0)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    dout_c = c(dout)
+    rc = lib.vlpet_vispos_bwd(P(dout_c), P(pos_c), P(w_c), P(b_c), P(g_c), n_img if tabs else 0, P(ii), bstride(ii),
+                              P(dw), P(db), P(dg), P(dbe), P(dimg), P(ws), nws, M, N, d, eps, int(rms), iod, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    pairs = [(dw, leaves[0].grad, "dw"), (db, leaves[1].grad, "db"), (dg, leaves[2].grad, "dgamma")]
+    if not rms:
+        pairs.append((dbe, leaves[3].grad, "dbeta"))
+    if tabs:
+        pairs.append((dimg, img_leaf.grad, "dimg"))
+    for got, want, name in pairs:
+        assert rel_err(got, want) <= 2e-4, (name, rel_err(got, want))
+    # deterministic: a second call writes the same bits
+    dw2 = torch.empty_like(dw)
+    rc = lib.vlpet_vispos_bwd(P(dout_c), P(pos_c), P(w_c), P(b_c), P(g_c), n_img if tabs else 0, P(ii), bstride(ii),
+                              P(dw2), P(db), P(dg), P(dbe), P(dimg), P(ws), nws, M, N, d, eps, int(rms), iod, st)
+    assert rc == 0 and torch.equal(dw, dw2)
+
+
+def test_position_branch_abi_rejects_what_it_does_not_cover():
+    from vlpet_amd import _lib
+    lib = _lib.load()
+    assert lib.vlpet_vispos_applies(64, 2) == 0 and lib.vlpet_vispos_applies(768, 5) == 0 and lib.vlpet_vispos_applies(1280, 2) == 0
+    t = torch.zeros(768 * 5, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.vlpet_vispos_fwd(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, 0, None, 0, None, 0, 0, None, 0,
+                                t.data_ptr(), 10, 3, 768, 1e-5, 0, _lib.VLPET_BF16, st) == -1      # VLPET_E_SHAPE: M not a multiple of N
+    assert lib.vlpet_vispos_fwd(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), None, None, 0, 0, None, 0, None, 0, 0, None, 0,
+                                t.data_ptr(), 9, 3, 768, 1e-5, 0, _lib.VLPET_BF16, st) == -5       # VLPET_E_NULL: LayerNorm without beta
+
+
+@pytest.mark.parametrize("nlvr", [False, True])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 1e-2)])
+def test_k4_module_with_a_frozen_token_table_takes_the_position_kernel(dtype, tol, nlvr, monkeypatch):
+    """The launch scripts' case: the shared token table (= obj_order_embedding) frozen, everything else of the visual embedding trainable
+    (trainer_base.py:308-542).  Output and every gradient against the oracle, and the position branch must have run as the HIP kernel."""
+    import vlpet_amd.visproj as VP
+    calls = []
+    orig = VP._VisPosFn.apply
+    monkeypatch.setattr(VP._VisPosFn, "apply", lambda *a: (calls.append(1), orig(*a))[1])
+    torch.manual_seed(4)
+    B, N, F, d = 6, (72 if nlvr else 36), 2048, 768
+    ve, table = build(d, F, False, vocab=300)
+    with torch.no_grad():
+        for p in ve.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    table.weight.requires_grad_(False)
+    feats = torch.randn(B, N, F).to(dtype)
+    pos = torch.rand(B, N, 4)
+    dy = torch.randn(B, N, d).to(dtype)
+    img_ids = obj_ids = None
+    if nlvr:        # src/nlvr_model.py:162-170: two images, 36 objects each
+        img_ids = torch.cat([torch.zeros(B, 36, dtype=torch.long), torch.ones(B, 36, dtype=torch.long)], 1)
+        obj_ids = torch.arange(36).repeat(2).unsqueeze(0).expand(B, -1).contiguous()
+    fe, pe = ve.feat_embedding, ve.absolute_vis_pos_embedding
+    names = [fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias, ve.img_order_embedding.weight]
+    ref = [t.detach().clone().requires_grad_(True) for t in names]
+    out_ref = O.visual_embedding(feats.float(), pos, *ref[:8], ref[8], table.weight.detach(), img_order_ids=img_ids, obj_order_ids=obj_ids)
+    out_ref.backward(dy.float())
+    ve = ve.cuda()
+    out = ve(feats.cuda(), pos.cuda(), None if img_ids is None else img_ids.cuda(), None if obj_ids is None else obj_ids.cuda())
+    assert calls, "the position branch did not take csrc/vispos.hip"
+    assert rel_err(out, out_ref) <= tol
+    out.backward(dy.cuda())
+    for a, b in zip(names, ref):
+        assert rel_err(a.grad, b.grad) <= tol

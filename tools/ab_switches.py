@@ -3,7 +3,7 @@ VLPET_AB=1): the product package itself reads nothing from the environment at im
     VLPET_NO_LINK=1, VLPET_NO_GEMM_LINK=1, VLPET_NO_NORM_LINK=1, VLPET_NO_LORA_LINK=1, VLPET_NO_BIAS_GRAD_KERNEL=1, VLPET_NO_FUSED_QKV=1,
     VLPET_EAGER_FFN_ACT=1, VLPET_EAGER_LM_LOSS=1, VLPET_EAGER_ATTENTION=1, VLPET_EAGER_RMS_NORM=1, VLPET_SPLIT_WIDE=1, VLPET_SDPA=flash|efficient|math, VLPET_NO_DEFER_REDUCES=1,
     VLPET_K4_FORM=gemm|library|fused, VLPET_SAVE_PRENORM=auto|0|1, VLPET_NO_TAIL_NORM_FUSION=1, VLPET_NO_ALIAS_RESIDUAL_GRAD=1,
-    VLPET_K1_BWD_FROM_X2=1, VLPET_DEFER_FINALIZE=1, VLPET_FINALIZE_SIDE_STREAM=1, VLPET_FINALIZE_LAUNCH=1"""
+    VLPET_K1_BWD_FROM_X2=1, VLPET_DEFER_FINALIZE=1, VLPET_FINALIZE_SIDE_STREAM=1, VLPET_FINALIZE_LAUNCH=1, VLPET_NO_POS_KERNEL=1"""
 import os
 
 
@@ -41,6 +41,7 @@ def apply():
     import vlpet_amd.visproj as VP
     import vlpet_amd.tail as TL
     put(VP, "K4_FORM", os.environ.get("VLPET_K4_FORM") or "gemm")           # gemm (default) | library | fused
+    put(VP, "FUSE_POS_BRANCH", not on("VLPET_NO_POS_KERNEL"))                # K4's position / order branch: csrc/vispos.hip (default) | library ops
     pn = os.environ.get("VLPET_SAVE_PRENORM")
     put(TL, "ALIAS_RESIDUAL_GRAD", not on("VLPET_NO_ALIAS_RESIDUAL_GRAD"))        # plain residual tail: d/dx1 = dout handed on without a copy
     put(TL, "SAVE_PRENORM", None if pn in (None, "", "auto") else pn == "1")  # K5: auto (default) | 1 = exact form | 0 = from the output

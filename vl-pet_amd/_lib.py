@@ -88,6 +88,12 @@ SIGNATURES = {
     "vlpet_visproj_gemm_exchange_bytes": (c_size_t, [c_int]),
     "vlpet_visproj_fwd_gemm": (c_int, [c_void_p] * 11 + [c_size_t, c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "vlpet_visproj_fwd_gemm_cfg": (c_int, [c_void_p] * 11 + [c_size_t, c_int64, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p]),
+    "vlpet_vispos_applies": (c_int, [c_int, c_int]),
+    "vlpet_vispos_fwd": (c_int, [c_void_p] * 5 + [c_void_p, c_int, c_int, c_void_p, c_int64] + [c_void_p, c_int, c_int64, c_void_p, c_int64]
+                         + [c_void_p, c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "vlpet_vispos_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "vlpet_vispos_bwd": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_int64] + [c_void_p] * 5
+                         + [c_void_p, c_size_t, c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "vlpet_visproj_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "vlpet_visproj_wgrad_workspace_bytes_io": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "vlpet_visproj_wgrad": (c_int, [c_void_p] * 5 + [c_size_t, c_int64, c_int, c_int, c_int, c_void_p]),

@@ -778,6 +778,61 @@ extern "C" int vlpet_visproj_fwd(const void* feats, const void* packed, const fl
 extern "C" size_t vlpet_visproj_gemm_workspace_bytes(int64_t M, int feat_dim, int d_out) {
     return visproj_gemm_workspace_bytes(M, feat_dim, d_out);
 }
+// K4's position / order branch (vispos.hip).  table dtypes: VLPET_F32 / VLPET_BF16 each; ids int64 [B or 1, N] with a batch stride of N or 0
+// (nullptr: image 0 / object n, the reference's defaults, src/modeling_bart.py:169-177)
+extern "C" int vlpet_vispos_applies(int d, int n_img) { return vispos_applies(d, n_img) ? 1 : 0; }
+extern "C" size_t vlpet_vispos_bwd_workspace_bytes(int64_t M, int d, int n_img) {
+    return (M > 0 && vispos_applies(d, n_img)) ? vispos_bwd_workspace_bytes(M, d, n_img) : 0;
+}
+static int vispos_common(const float* pos, const float* w, const float* b, const float* gamma, int64_t M, int N, int d, int n_img, int io_dtype) {
+    if (!pos || !w || !b || !gamma) return VLPET_E_NULL;
+    if (M <= 0 || M >= ((int64_t)1 << 31) || N <= 0 || M % N != 0 || !vispos_applies(d, n_img)) return VLPET_E_SHAPE;
+    if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    if (!aligned16(pos) || !aligned16(w) || !aligned16(b) || !aligned16(gamma)) return VLPET_E_ALIGN;
+    return 0;
+}
+extern "C" int vlpet_vispos_fwd(const float* pos, const float* w, const float* b, const float* gamma, const float* beta,
+                                const void* img_table, int img_table_dtype, int n_img, const int64_t* img_ids, int64_t img_ids_bstride,
+                                const void* obj_table, int obj_table_dtype, int64_t obj_rows, const int64_t* obj_ids, int64_t obj_ids_bstride,
+                                void* out, int64_t M, int N, int d, float eps, int rms, int io_dtype, vlpet_stream_t stream) {
+    const bool tabs = img_table != nullptr || obj_table != nullptr;
+    if (int rc = vispos_common(pos, w, b, gamma, M, N, d, tabs ? n_img : 0, io_dtype)) return rc;
+    if (!out || (!rms && !beta)) return VLPET_E_NULL;
+    if (tabs) {
+        if (!img_table || !obj_table) return VLPET_E_NULL;              // the reference adds both or neither (use_vis_order_embedding)
+        if (n_img < 1 || obj_rows < 1) return VLPET_E_SHAPE;
+        if (!dtype_ok(img_table_dtype) || !dtype_ok(obj_table_dtype)) return VLPET_E_DTYPE;
+        if (!aligned16(img_table) || !aligned16(obj_table)) return VLPET_E_ALIGN;
+    }
+    if (!aligned16(out) || (beta && !aligned16(beta))) return VLPET_E_ALIGN;
+    VisPosArgs a{};
+    a.pos = pos; a.w = w; a.b = b; a.gamma = gamma; a.beta = rms ? nullptr : beta;
+    a.img_tab = img_table; a.obj_tab = obj_table; a.img_tab_bf16 = img_table_dtype == VLPET_BF16; a.obj_tab_bf16 = obj_table_dtype == VLPET_BF16;
+    a.img_ids = img_ids; a.obj_ids = obj_ids; a.img_bstride = img_ids_bstride; a.obj_bstride = obj_ids_bstride;
+    a.n_img = n_img; a.obj_rows = obj_rows; a.out = out; a.M = M; a.N = N; a.d = d; a.eps = eps; a.rms = rms;
+    return herr(launch_vispos_fwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+// dout = the gradient of the visual embedding's output (= dR); results are WRITTEN: dw [d, 5], db [d], dgamma [d], dbeta [d] (nullptr with
+// rms), dimg [n_img, d] (nullptr / n_img = 0: no image-order table)
+extern "C" int vlpet_vispos_bwd(const void* dout, const float* pos, const float* w, const float* b, const float* gamma,
+                                int n_img, const int64_t* img_ids, int64_t img_ids_bstride,
+                                float* dw, float* db, float* dgamma, float* dbeta, float* dimg,
+                                void* workspace, size_t workspace_bytes, int64_t M, int N, int d, float eps, int rms, int io_dtype,
+                                vlpet_stream_t stream) {
+    if (!dimg) n_img = 0;
+    if (int rc = vispos_common(pos, w, b, gamma, M, N, d, n_img, io_dtype)) return rc;
+    if (!dout || !dw || !db || !dgamma || !workspace || (!rms && !dbeta)) return VLPET_E_NULL;
+    if (!aligned16(dout) || !aligned16(workspace)) return VLPET_E_ALIGN;
+    if (workspace_bytes < vispos_bwd_workspace_bytes(M, d, n_img)) return VLPET_E_WORKSPACE;
+    VisPosArgs a{};
+    a.pos = pos; a.w = w; a.b = b; a.gamma = gamma;
+    a.img_ids = img_ids; a.img_bstride = img_ids_bstride; a.n_img = n_img;
+    a.dout = dout; a.partial = reinterpret_cast<float*>(workspace);
+    a.dw = dw; a.db = db; a.dgamma = dgamma; a.dbeta = rms ? nullptr : dbeta; a.dimg = dimg;
+    a.M = M; a.N = N; a.d = d; a.eps = eps; a.rms = rms;
+    return herr(launch_vispos_bwd(a, io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
 extern "C" size_t vlpet_visproj_gemm_exchange_bytes(int d_out) {
     return (d_out > 0 && d_out % 256 == 0 && d_out / 256 <= 4) ? visproj_gemm_exchange_bytes(d_out) : 0;
 }

@@ -251,6 +251,27 @@ size_t visproj_gemm_workspace_bytes(int64_t M, int F, int d_out);
 size_t visproj_gemm_exchange_bytes(int d_out);                        // the granule area that every launch leaves zeroed (workspace bytes 256 ..)
 hipError_t launch_visproj_gemm(VisGemmArgs& a, void* ws, int form, int bm, hipStream_t stream);
 
+// K4's position / order branch R = LN_p(W_p [box, area] + b_p) + img_order_embedding[.] + obj_order_embedding[V - 1 - .] (vispos.hip, round 6)
+struct VisPosArgs {
+    const float* pos;               // [M, 4] fp32 (x1, x2, y1, y2); M = B N rows, row r = (b, n) = (r / N, r % N)
+    const float* w; const float* b; // Linear(5 -> d): [d, 5], [d]
+    const float* gamma; const float* beta;      // the branch's norm ([d]; beta nullptr with rms)
+    const void* img_tab; const void* obj_tab;   // [n_img, d], [obj_rows, d] (nullptr both: no order embeddings); fp32 or bf16 each
+    int img_tab_bf16, obj_tab_bf16;
+    const int64_t* img_ids; const int64_t* obj_ids;     // [B or 1, N] (nullptr: image 0 / object n); batch stride 0 broadcasts
+    int64_t img_bstride, obj_bstride;
+    int n_img; int64_t obj_rows;
+    void* out;                      // fwd: R [M, d] IO dtype
+    const void* dout;               // bwd: dR [M, d] IO dtype
+    float* partial;                 // bwd workspace: [workgroups][8 + image slots][d]
+    float* dw; float* db; float* dgamma; float* dbeta; float* dimg;     // bwd results (written, not accumulated); dbeta nullptr with rms, dimg [n_img, d] or nullptr
+    int64_t M; int N, d; float eps; int rms;
+};
+bool vispos_applies(int d, int n_img);
+size_t vispos_bwd_workspace_bytes(int64_t M, int d, int n_img);
+hipError_t launch_vispos_fwd(const VisPosArgs& a, int io_fp32, hipStream_t stream);
+hipError_t launch_vispos_bwd(const VisPosArgs& a, int io_fp32, hipStream_t stream);
+
 // K5 sublayer tail: out = LayerNorm(x1 + dropout(y)) (norm = 1) or x1 + dropout(y) (norm = 0); tail.hip
 struct TailArgs {
     const void* y;          // fwd: sublayer output [M, d];          bwd: dy  (written when thr != 0)

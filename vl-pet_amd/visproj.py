@@ -252,3 +252,116 @@ def visproj(feats, R, linear: torch.nn.Linear, norm: torch.nn.Module, cache: Vis
         return _VisProjFn.apply(feats, R, linear.weight, linear.bias, norm.weight, beta, None, eps, rms, cast)
     packed = cache.get(linear.weight, linear.bias, io)
     return _VisProjFn.apply(feats, R, linear.weight, linear.bias, norm.weight, beta, packed, eps, rms)
+
+
+# ------------------------------------------------------------------------------------------------ position / order branch
+# R = norm_p(Linear(5 -> d)([box, area])) + img_order_embedding[.] + obj_order_embedding[V - 1 - .] as ONE launch each way
+# (csrc/vispos.hip, round 6; src/modeling_bart.py:129-141,162-183).  A/B switch (tools/ab_switches.py: VLPET_NO_POS_KERNEL=1).
+FUSE_POS_BRANCH = True
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    return (t if t.dtype == torch.float32 else t.float()).contiguous()
+
+
+def _ids_arg(ids, B: int, N: int):
+    """(tensor kept alive, pointer, batch stride) of an id tensor shaped [N], [1, N] or [B, N]; None = the reference's default ids"""
+    if ids is None:
+        return None, None, 0
+    t = ids.detach()
+    if t.dim() == 1:
+        t = t.unsqueeze(0)
+    if t.dtype != torch.long:
+        t = t.long()
+    t = t.contiguous()
+    return t, t.data_ptr(), (0 if t.shape[0] == 1 else N)
+
+
+class _VisPosFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, w, b, gamma, beta, img_table, obj_table, img_ids, obj_ids, eps, rms, out_dtype):
+        lib = _lib.load()
+        B, N, _ = pos.shape
+        d = w.shape[0]
+        M = B * N
+        pf = _f32c(pos).view(M, 4)
+        wf, bf, gf = _f32c(w), _f32c(b), _f32c(gamma)
+        bef = _f32c(beta) if beta is not None else None
+        io = _lib.VLPET_F32 if out_dtype == torch.float32 else _lib.VLPET_BF16
+        out = torch.empty(B, N, d, dtype=out_dtype, device=pos.device)
+        it = ot = None
+        n_img = obj_rows = 0
+        if img_table is not None:
+            it, ot = img_table.detach().contiguous(), obj_table.detach().contiguous()
+            n_img, obj_rows = it.shape[0], ot.shape[0]
+        ik, ip, ibs = _ids_arg(img_ids, B, N)
+        ok, op, obs = _ids_arg(obj_ids, B, N)
+        rc = _timed("k4_pos_fwd", M, lambda: lib.vlpet_vispos_fwd(
+            pf.data_ptr(), wf.data_ptr(), bf.data_ptr(), gf.data_ptr(), _ptr(bef),
+            _ptr(it), _param_dtype(it) if it is not None else 0, n_img, ip, ibs,
+            _ptr(ot), _param_dtype(ot) if ot is not None else 0, obj_rows, op, obs,
+            out.data_ptr(), M, N, d, float(eps), int(bool(rms)), io, _stream()))
+        _lib.check(rc, "vlpet_vispos_fwd")
+        ctx.save_for_backward(pf, w, b, gamma, beta if beta is not None else gamma, img_table if img_table is not None else gamma, ik if ik is not None else gamma)
+        ctx.cfg = (B, N, d, float(eps), bool(rms), beta is not None, img_table is not None, ik is not None, ibs, io)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        pf, w, b, gamma, beta, img_table, ik = ctx.saved_tensors
+        B, N, d, eps, rms, has_beta, has_img, has_ids, ibs, io = ctx.cfg
+        M = B * N
+        dy = dout.contiguous()
+        want = torch.float32 if io == _lib.VLPET_F32 else torch.bfloat16
+        if dy.dtype != want:
+            dy = dy.to(want)
+        n_img = img_table.shape[0] if (has_img and ctx.needs_input_grad[5]) else 0
+        (dw, s_w), (db, s_b), (dg, s_g) = _grad_dest(w, (d, 5)), _grad_dest(b, (d,)), _grad_dest(gamma, (d,))
+        (dbe, s_be) = _grad_dest(beta, (d,)) if has_beta else (None, None)
+        (di, s_i) = _grad_dest(img_table, (n_img, d)) if n_img else (None, None)
+        nws = lib.vlpet_vispos_bwd_workspace_bytes(M, d, n_img)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dy.device)
+        wf, bf, gf = _f32c(w), _f32c(b), _f32c(gamma)
+        rc = _timed("k4_pos_bwd", M, lambda: lib.vlpet_vispos_bwd(
+            dy.data_ptr(), pf.data_ptr(), wf.data_ptr(), bf.data_ptr(), gf.data_ptr(),
+            n_img, ik.data_ptr() if has_ids else None, ibs,
+            dw.data_ptr(), db.data_ptr(), dg.data_ptr(), _ptr(dbe), _ptr(di),
+            ws.data_ptr(), nws, M, N, d, eps, int(rms), io, _stream()))
+        _lib.check(rc, "vlpet_vispos_bwd")
+        gw, gb, gg = _finish([(dw, s_w, w), (db, s_b, b), (dg, s_g, gamma)])
+        gbe = _finish([(dbe, s_be, beta)])[0] if has_beta else None
+        gi = _finish([(di, s_i, img_table)])[0] if n_img else None
+        return (None, gw, gb, gg, gbe, gi, None, None, None, None, None, None)
+
+
+def position_terms(pos, linear: torch.nn.Linear, norm: torch.nn.Module, img_embedding, obj_embedding, img_ids, obj_ids,
+                   rms: bool, out_dtype: torch.dtype):
+    """R [B, N, d] in ``out_dtype`` through csrc/vispos.hip, or None where the kernel does not apply (the caller keeps its torch ops):
+    d not a multiple of 256 / above 1024, more than 4 image-order rows, a trainable object-order table, id tensors of another shape."""
+    if not FUSE_POS_BRANCH or not pos.is_cuda or out_dtype not in (torch.float32, torch.bfloat16):
+        return None
+    B, N, _ = pos.shape
+    d = linear.weight.shape[0]
+    if B * N == 0 or linear.weight.shape[1] != 5 or linear.bias is None:
+        return None
+    n_img = img_embedding.num_embeddings if img_embedding is not None else 0
+    if not _lib.load().vlpet_vispos_applies(d, n_img):
+        return None
+    tabs = (None, None)
+    if img_embedding is not None:
+        if obj_embedding is None or (obj_embedding.weight.requires_grad and torch.is_grad_enabled()):
+            return None
+        for t in (img_embedding.weight, obj_embedding.weight):
+            if t.dtype not in (torch.float32, torch.bfloat16) or t.shape[1] != d:
+                return None
+        for ids in (img_ids, obj_ids):
+            if ids is not None and not (ids.dim() in (1, 2) and ids.shape[-1] == N and (ids.dim() == 1 or ids.shape[0] in (1, B))):
+                return None
+        tabs = (img_embedding.weight, obj_embedding.weight)
+    beta = None if rms else getattr(norm, "bias", None)
+    if not rms and beta is None:
+        return None
+    eps = norm.variance_epsilon if rms else norm.eps
+    return _VisPosFn.apply(pos, linear.weight, linear.bias, norm.weight, beta, tabs[0], tabs[1], img_ids, obj_ids, eps, rms, out_dtype)

@@ -98,6 +98,37 @@ def _order_lookup(table: nn.Embedding, ids: torch.Tensor) -> torch.Tensor:
     return table(ids)
 
 
+def _position_terms(mod, pos, img_order_ids, obj_order_ids, per_branch: bool, B: int, N: int):
+    """R = [LN](Linear(5 -> d)([box, area])) + the two order embeddings, fp32, with library ops (src/modeling_bart.py:129-141,162-183):
+    the form for CPU tensors and for whatever csrc/vispos.hip does not cover."""
+    pos = pos.float()
+    pos5 = torch.cat([pos, mod.get_area(pos).unsqueeze(2)], dim=2)
+    pl = mod.absolute_vis_pos_embedding[0]
+    R = F.linear(pos5, pl.weight.float(), pl.bias.float())
+    if per_branch:
+        R = mod.absolute_vis_pos_embedding[1](R).float()
+    if mod.config.use_vis_order_embedding:
+        dev = pos.device
+        if img_order_ids is None:
+            img_order_ids = torch.zeros(N, dtype=torch.long, device=dev).unsqueeze(0)
+        if obj_order_ids is None:
+            obj_order_ids = torch.arange(N, dtype=torch.long, device=dev).unsqueeze(0)
+        obj_order_ids = mod.obj_order_embedding.num_embeddings - obj_order_ids - 1
+        R = R + _order_lookup(mod.img_order_embedding, img_order_ids).float() + mod.obj_order_embedding(obj_order_ids).float()
+    return R.expand(B, N, R.shape[-1])
+
+
+def _position_terms_fused(mod, pos, img_order_ids, obj_order_ids, per_branch: bool, out_dtype):
+    """The same R in ``out_dtype`` through the HIP kernel, or None (visproj.position_terms says where it applies)."""
+    if not per_branch or not pos.is_cuda:
+        return None
+    from .visproj import position_terms
+    order = bool(mod.config.use_vis_order_embedding)
+    return position_terms(pos, mod.absolute_vis_pos_embedding[0], mod.absolute_vis_pos_embedding[1],
+                          mod.img_order_embedding if order else None, mod.obj_order_embedding if order else None,
+                          img_order_ids, obj_order_ids, isinstance(mod.absolute_vis_pos_embedding[1], T5LayerNorm), out_dtype)
+
+
 class VisualEmbedding(nn.Module):
     def __init__(self, config, obj_order_embedding: nn.Embedding, rms_norm: bool = False):
         super().__init__()
@@ -133,21 +164,9 @@ class VisualEmbedding(nn.Module):
         B, N, _ = feats.shape
         assert pos.shape == (B, N, 4)
         per_branch = bool(self.config.use_vis_layer_norm and self.config.individual_vis_layer_norm)
-        pos = pos.float()
-        pos5 = torch.cat([pos, self.get_area(pos).unsqueeze(2)], dim=2)
-        pl = self.absolute_vis_pos_embedding[0]
-        R = F.linear(pos5, pl.weight.float(), pl.bias.float())
-        if per_branch:
-            R = self.absolute_vis_pos_embedding[1](R).float()
-        if self.config.use_vis_order_embedding:
-            dev = feats.device
-            if img_order_ids is None:
-                img_order_ids = torch.zeros(N, dtype=torch.long, device=dev).unsqueeze(0)
-            if obj_order_ids is None:
-                obj_order_ids = torch.arange(N, dtype=torch.long, device=dev).unsqueeze(0)
-            obj_order_ids = self.obj_order_embedding.num_embeddings - obj_order_ids - 1
-            R = R + _order_lookup(self.img_order_embedding, img_order_ids).float() + self.obj_order_embedding(obj_order_ids).float()
-        R = R.expand(B, N, R.shape[-1])
+        R = _position_terms_fused(self, pos, img_order_ids, obj_order_ids, per_branch, feats.dtype)    # one launch each way (csrc/vispos.hip)
+        if R is None:
+            R = _position_terms(self, pos, img_order_ids, obj_order_ids, per_branch, B, N)
         if not per_branch:
             # no LayerNorm behind the feature projection (use_vis_layer_norm off, or ONE norm over the sum: src/modeling_bart.py:186-188):
             # not the fused kernel's shape -- plain torch ops ("else eager fallback"); no launch script sets these flags
@@ -203,25 +222,14 @@ class LowRankVisualEmbedding(nn.Module):
     def forward(self, feats, pos, img_order_ids=None, obj_order_ids=None):
         B, N, _ = feats.shape
         assert pos.shape == (B, N, 4)
-        pos = pos.float()
-        pos5 = torch.cat([pos, self.get_area(pos).unsqueeze(2)], dim=2)
-        pl = self.absolute_vis_pos_embedding[0]
-        R = F.linear(pos5, pl.weight.float(), pl.bias.float())
-        if self._per_branch:
-            R = self.absolute_vis_pos_embedding[1](R).float()
-        if self.config.use_vis_order_embedding:
-            dev = feats.device
-            if img_order_ids is None:
-                img_order_ids = torch.zeros(N, dtype=torch.long, device=dev).unsqueeze(0)
-            if obj_order_ids is None:
-                obj_order_ids = torch.arange(N, dtype=torch.long, device=dev).unsqueeze(0)
-            obj_order_ids = self.obj_order_embedding.num_embeddings - obj_order_ids - 1
-            R = R + _order_lookup(self.img_order_embedding, img_order_ids).float() + self.obj_order_embedding(obj_order_ids).float()
-        R = R.expand(B, N, R.shape[-1])
         gated = hasattr(self, "visual_projector_gating_large_x_down")
         r_max = max(self.visual_projector_multihead_up.weight.shape[1],
                     self.visual_projector_gating_large_x_down.weight.shape[0] if gated else 0)
-        if not self._per_branch or r_max > 96:
+        plain = not self._per_branch or r_max > 96
+        R = None if plain else _position_terms_fused(self, pos, img_order_ids, obj_order_ids, True, feats.dtype)
+        if R is None:
+            R = _position_terms(self, pos, img_order_ids, obj_order_ids, self._per_branch, B, N)
+        if plain:
             # bottlenecks above 96 or no per-branch LayerNorm: outside the rectangular kernels -- plain torch ops
             from . import eager
             fe = eager.lowrank_visual_features(
