@@ -290,3 +290,28 @@ def test_replayed_nlvr_step_survives_later_captures():
     code = _NLVR_REPLAY_CHILD.format(tests=os.path.dirname(os.path.abspath(__file__)), root=root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_batches_written_into_the_captured_input_buffers_replay_without_a_copy():
+    """Trainer.input_buffers: a loader may write each new batch INTO the captured step's input tensors and pass those to step(); the
+    losses equal the eager trainer's on the same data, and step() leaves the buffers' addresses alone (nothing is copied)."""
+    import vlpet_amd.train as TR
+    model, cfg = _tiny(0.0)
+    m_eager, m_graph = copy.deepcopy(model).cuda(), copy.deepcopy(model).cuda()
+    gen = torch.Generator().manual_seed(9)
+    data = [_cuda_batch(TR.synthetic_batch("vqa", 5, cfg, "cpu", gen)) for _ in range(5)]
+    tre = TR.Trainer(m_eager, cfg, lr=1e-2, total_steps=20, warmup_ratio=0.1)
+    le = [float(tre.step(b)) for b in data]
+    trg = TR.Trainer(m_graph, cfg, lr=1e-2, total_steps=20, warmup_ratio=0.1, graph=True)
+    assert trg.input_buffers(data[0]) is None                     # nothing captured yet
+    lg = [float(trg.step(data[0])), float(trg.step(data[1]))]     # eager, then capture + replay
+    buf = trg.input_buffers(data[2])
+    assert buf is not None and buf["task"] == "vqa"
+    ptrs = [t.data_ptr() for _, _, t in TR.Trainer._leaves(buf)]
+    for b in data[2:]:
+        for (_, _, src), (_, _, dst) in zip(TR.Trainer._leaves(b), TR.Trainer._leaves(buf)):
+            dst.copy_(src)                                        # the "loader" writes in place
+        lg.append(float(trg.step(buf)))
+    assert [t.data_ptr() for _, _, t in TR.Trainer._leaves(trg.input_buffers(buf))] == ptrs
+    for a, b in zip(lg, le):
+        assert abs(a - b) <= 1e-5 * abs(b), (lg, le)
