@@ -25,6 +25,18 @@ def test_exports_every_declared_symbol():
     assert set(syms) == set(_lib.SIGNATURES), "ctypes table and header disagree"
 
 
+def test_diagnosis_build_is_not_stale():
+    """The experiment-switch tests load vl-pet_amd/lib/libvlpet_hip_dbg.so (a DEBUG=1 build of the same sources) in child processes: if it
+    exists it must export what the header declares -- a product rebuild that added an entry point without rebuilding it (__graft_entry__.build()
+    does both) made those tests fail at load time on the GPU box, where nothing can be rebuilt."""
+    dbg = os.path.join(ROOT, "vl-pet_amd", "lib", "libvlpet_hip_dbg.so")
+    if not os.path.exists(dbg):
+        pytest.skip("no diagnosis build")
+    lib = ctypes.CDLL(dbg)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f"stale diagnosis build (run __graft_entry__.build()): {missing}"
+
+
 def test_error_codes_without_gpu():
     from vlpet_amd import _lib
     lib = _lib.load()

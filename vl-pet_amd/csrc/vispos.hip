@@ -24,8 +24,8 @@ namespace {
 
 constexpr int VP_WAVES = 4;
 
-template <bool BF> __device__ __forceinline__ void vp_tab4(const void* tab, int64_t row, int d, int c, float* v) {
-    if constexpr (BF) {
+__device__ __forceinline__ void vp_tab4(bool bf, const void* tab, int64_t row, int d, int c, float* v) {
+    if (bf) {                   // (wave-uniform)
         const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const __bf16*>(tab) + row * d + c);
         v[0] = __builtin_bit_cast(float, r[0] << 16); v[1] = __builtin_bit_cast(float, r[0] & 0xffff0000u);
         v[2] = __builtin_bit_cast(float, r[1] << 16); v[3] = __builtin_bit_cast(float, r[1] & 0xffff0000u);
@@ -92,7 +92,7 @@ __device__ __forceinline__ void vp_stats(const VpRow (&x)[RB], const float (&W)[
     }
 }
 
-template <int NG, typename IO, bool IMG_BF, bool OBJ_BF>
+template <int NG, typename IO>
 __global__ __launch_bounds__(VP_WAVES * 64) void vispos_fwd_kernel(VisPosArgs a) {
     constexpr int E = 4 * NG;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(VP_WAVES * 64) void vispos_fwd_kernel(VisPosArgs a)
 #pragma unroll
                 for (int j = 0; j < NG; ++j) {
                     float t0[4], t1[4];
-                    vp_tab4<IMG_BF>(a.img_tab, ii[i], d, 256 * j + 4 * lane, t0);
-                    vp_tab4<OBJ_BF>(a.obj_tab, oi[i], d, 256 * j + 4 * lane, t1);
+                    vp_tab4(a.img_tab_bf16 != 0, a.img_tab, ii[i], d, 256 * j + 4 * lane, t0);
+                    vp_tab4(a.obj_tab_bf16 != 0, a.obj_tab, oi[i], d, 256 * j + 4 * lane, t1);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[i][4 * j + e] = (v[i][4 * j + e] + t0[e]) + t1[e];      // (pos + img) + obj: the reference's order of the adds
                 }
@@ -295,11 +295,7 @@ __global__ __launch_bounds__(256) void vispos_finalize_kernel(VisPosArgs a, int 
 
 template <int NG, typename IO>
 hipError_t fwd_t(const VisPosArgs& a, unsigned grid, hipStream_t s) {
-    const bool ib = a.img_tab_bf16 != 0, ob = a.obj_tab_bf16 != 0;
-    if (ib && ob) hipLaunchKernelGGL((vispos_fwd_kernel<NG, IO, true, true>), dim3(grid), dim3(VP_WAVES * 64), 0, s, a);
-    else if (ib) hipLaunchKernelGGL((vispos_fwd_kernel<NG, IO, true, false>), dim3(grid), dim3(VP_WAVES * 64), 0, s, a);
-    else if (ob) hipLaunchKernelGGL((vispos_fwd_kernel<NG, IO, false, true>), dim3(grid), dim3(VP_WAVES * 64), 0, s, a);
-    else hipLaunchKernelGGL((vispos_fwd_kernel<NG, IO, false, false>), dim3(grid), dim3(VP_WAVES * 64), 0, s, a);
+    hipLaunchKernelGGL((vispos_fwd_kernel<NG, IO>), dim3(grid), dim3(VP_WAVES * 64), 0, s, a);
     return hipGetLastError();
 }
 template <int NG, typename IO>
