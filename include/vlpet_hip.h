@@ -315,6 +315,11 @@ int vlpet_visproj_fwd_gemm_cfg(const void* feats, const void* w_io, const float*
                                const void* r, void* out, void* xhat, float* rstd, float* mean, void* workspace,
                                size_t workspace_bytes, int64_t M, int feat_dim, int d_out, float eps, int rms, int io_dtype,
                                int form, int rows_per_workgroup, vlpet_stream_t stream);
+/* out = srcs[0] + ... + srcs[n - 1] over len elements of the IO dtype (len % 8 == 0; srcs = HOST array of n device pointers; out may be
+ * srcs[0]): fp32 accumulation, one rounding per launch of up to eight sources.  The gradient of a tensor several consumers read -- the
+ * encoder output under every decoder layer's cross-attention -- which autograd would sum pairwise (n - 1 passes of three row units).
+ * replaces: autograd's accumulation for my_transformers/modeling_bart.py:2300-2330 (every decoder layer takes encoder_hidden_states). */
+int vlpet_sum_n(const void* const* srcs, int n, void* out, int64_t len, int io_dtype, vlpet_stream_t stream);
 /* K4's position / order branch, the R the feature projection adds behind its norm:
  *     R[b, n, :] = norm_p( W_p [x1, x2, y1, y2, area] + b_p ) + img_order_embedding[img_id[b, n]] + obj_order_embedding[V - 1 - obj_id[b, n]]
  * with area = (y2 - y1) (x2 - x1); norm_p = LayerNorm (BART) or T5LayerNorm (rms = 1: no mean, beta ignored).  One launch; rows are

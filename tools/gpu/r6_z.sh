@@ -1,0 +1,26 @@
+#!/bin/bash
+# round 6, GPU pass z: fanout / vlpet_sum_n: tests, the model-level suites that run through the decoders, ABBA in the step
+O=gpurun_out/r6z; mkdir -p $O
+export HIP_FORCE_DEV_KERNARG=1
+timeout 1500 python -m pytest tests/test_gpu_fanout.py tests/test_host_golden.py tests/test_gpu_graph.py tests/test_gpu_modules.py tests/test_gpu_video.py tests/test_gpu_dp.py tests/test_host_caches.py -q -x 2>&1 | grep -v amdgpu.ids | tail -6 | tee $O/pytest.txt
+for tag in fan_a nofan_a nofan_b fan_b; do
+  case $tag in nofan*) export VLPET_NO_FANOUT_SUM=1;; *) unset VLPET_NO_FANOUT_SUM;; esac
+  VLPET_AB=1 timeout 600 python bench.py --steps 40 --warmup 4 --no-cpu-baseline > $O/bench_$tag.json.log 2>&1
+done
+unset VLPET_NO_FANOUT_SUM
+for tag in fan_a nofan_a nofan_b fan_b; do
+  case $tag in nofan*) export VLPET_NO_FANOUT_SUM=1;; *) unset VLPET_NO_FANOUT_SUM;; esac
+  VLPET_AB=1 timeout 600 python bench.py --model t5 --steps 24 --warmup 4 --no-cpu-baseline > $O/bench_t5_$tag.json.log 2>&1
+  VLPET_AB=1 timeout 600 python bench.py --emulate-ranks 8 --steps 40 --warmup 6 --no-cpu-baseline > $O/bench_r8_$tag.json.log 2>&1
+done
+python - <<'P' | tee $O/summary.txt
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r6z/bench_*.log")):
+    ok = False
+    for l in open(f):
+        if l.startswith("{"):
+            ok = True
+            j = json.loads(l); k = j["kernels"]
+            print(f.split("/")[-1], j["value"], j["ms_per_step"], "median", j["step_ms_median"], "steady", j["steady_state"]["value"], {n: k[n]["avg_us"] for n in ("fanout_sum",) if n in k}, j.get("ab_switches"))
+    if not ok: print(f, "NO JSON"); print(open(f).read()[-1500:])
+P

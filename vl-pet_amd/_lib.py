@@ -88,6 +88,7 @@ SIGNATURES = {
     "vlpet_visproj_gemm_exchange_bytes": (c_size_t, [c_int]),
     "vlpet_visproj_fwd_gemm": (c_int, [c_void_p] * 11 + [c_size_t, c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "vlpet_visproj_fwd_gemm_cfg": (c_int, [c_void_p] * 11 + [c_size_t, c_int64, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p]),
+    "vlpet_sum_n": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "vlpet_vispos_applies": (c_int, [c_int, c_int]),
     "vlpet_vispos_fwd": (c_int, [c_void_p] * 5 + [c_void_p, c_int, c_int, c_void_p, c_int64] + [c_void_p, c_int, c_int64, c_void_p, c_int64]
                          + [c_void_p, c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),

@@ -778,6 +778,36 @@ extern "C" int vlpet_visproj_fwd(const void* feats, const void* packed, const fl
 extern "C" size_t vlpet_visproj_gemm_workspace_bytes(int64_t M, int feat_dim, int d_out) {
     return visproj_gemm_workspace_bytes(M, feat_dim, d_out);
 }
+// out = the sum of n tensors of `len` IO-dtype elements (n >= 1 sources as an array of device pointers on the HOST; out may be srcs[0]):
+// fp32 accumulation, one rounding per launch of up to eight sources
+extern "C" int vlpet_sum_n(const void* const* srcs, int n, void* out, int64_t len, int io_dtype, vlpet_stream_t stream) {
+    if (!srcs || !out) return VLPET_E_NULL;
+    if (n < 1 || len <= 0 || len % 8 != 0) return VLPET_E_SHAPE;
+    if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    if (!aligned16(out)) return VLPET_E_ALIGN;
+    for (int i = 0; i < n; ++i) {
+        if (!srcs[i]) return VLPET_E_NULL;
+        if (!aligned16(srcs[i])) return VLPET_E_ALIGN;
+    }
+    const size_t esz = io_dtype == VLPET_F32 ? 4 : 2;
+    if (n == 1) {
+        if (srcs[0] == out) return 0;
+        return herr(hipMemcpyAsync(out, srcs[0], (size_t)len * esz, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    int done = 0;
+    while (done < n) {                      // eight sources per launch; later launches start from the running sum
+        SumNArgs a{};
+        int k = 0;
+        if (done > 0) a.src[k++] = out;
+        while (k < 8 && done < n) a.src[k++] = srcs[done++];
+        a.out = out;
+        if (k == 1) break;
+        hipError_t e = launch_sum_n(a, k, len, io_dtype == VLPET_F32, (hipStream_t)stream);
+        if (e != hipSuccess) return herr(e);
+    }
+    return 0;
+}
+
 // K4's position / order branch (vispos.hip).  table dtypes: VLPET_F32 / VLPET_BF16 each; ids int64 [B or 1, N] with a batch stride of N or 0
 // (nullptr: image 0 / object n, the reference's defaults, src/modeling_bart.py:169-177)
 extern "C" int vlpet_vispos_applies(int d, int n_img) { return vispos_applies(d, n_img) ? 1 : 0; }

@@ -374,6 +374,8 @@ struct AdamwArgs {
     const float* slice_bc;                         //   [n_slices][2]: 1 - b1^t, sqrt(1 - b2^t) per parameter; <= 0 = no grad this step
 };
 hipError_t launch_add_inplace(void* dst, const void* src, int64_t n, int io_fp32, hipStream_t stream);   // dst += src (IO dtype)
+struct SumNArgs { const void* src[8]; void* out; };
+hipError_t launch_sum_n(const SumNArgs& a, int n, int64_t len, int io_fp32, hipStream_t stream);      // out = src[0] + ... + src[n - 1], n in 2 .. 8 (optim.hip)
 hipError_t launch_sumsq(const float* g, int64_t n, float* partials, hipStream_t stream);
 hipError_t launch_adamw(const AdamwArgs& a, hipStream_t stream);
 int optim_blocks(int64_t n);

@@ -142,3 +142,43 @@ hipError_t launch_add_inplace(void* dst, const void* src, int64_t n, int io_fp32
                             reinterpret_cast<__bf16*>(dst), reinterpret_cast<const __bf16*>(src), n8);
     return hipGetLastError();
 }
+
+// out = src[0] + ... + src[n - 1] over `len` IO-dtype elements (len % 8 == 0, 16-byte aligned), fp32 accumulation, one rounding: the
+// gradient of a tensor that n consumers read (the encoder output feeding every decoder layer's cross-attention,
+// my_transformers/modeling_bart.py:2300-2330) -- autograd sums such gradients pairwise, n - 1 passes of
+// three row units each; this is one pass of n + 1 units.  Every source's piece is in flight before the first add.
+template <typename IO, int N>
+__global__ __launch_bounds__(OPT_THREADS) void sum_n_kernel(SumNArgs a, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n8; i += (int64_t)gridDim.x * OPT_THREADS) {
+        float v[N][8];
+#pragma unroll
+        for (int k = 0; k < N; ++k) load8_f32(reinterpret_cast<const IO*>(a.src[k]) + 8 * i, v[k]);
+#pragma unroll
+        for (int k = 1; k < N; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[0][j] += v[k][j];
+        store8_f32(reinterpret_cast<IO*>(a.out) + 8 * i, v[0]);
+    }
+}
+template <typename IO>
+static void sum_n_launch(const SumNArgs& a, int n, int64_t n8, unsigned blocks, hipStream_t s) {
+    switch (n) {
+        case 2: hipLaunchKernelGGL((sum_n_kernel<IO, 2>), dim3(blocks), dim3(OPT_THREADS), 0, s, a, n8); break;
+        case 3: hipLaunchKernelGGL((sum_n_kernel<IO, 3>), dim3(blocks), dim3(OPT_THREADS), 0, s, a, n8); break;
+        case 4: hipLaunchKernelGGL((sum_n_kernel<IO, 4>), dim3(blocks), dim3(OPT_THREADS), 0, s, a, n8); break;
+        case 5: hipLaunchKernelGGL((sum_n_kernel<IO, 5>), dim3(blocks), dim3(OPT_THREADS), 0, s, a, n8); break;
+        case 6: hipLaunchKernelGGL((sum_n_kernel<IO, 6>), dim3(blocks), dim3(OPT_THREADS), 0, s, a, n8); break;
+        case 7: hipLaunchKernelGGL((sum_n_kernel<IO, 7>), dim3(blocks), dim3(OPT_THREADS), 0, s, a, n8); break;
+        default: hipLaunchKernelGGL((sum_n_kernel<IO, 8>), dim3(blocks), dim3(OPT_THREADS), 0, s, a, n8); break;
+    }
+}
+// n in 2 .. 8 per launch; the caller chains launches for more sources (out may be src[0])
+hipError_t launch_sum_n(const SumNArgs& a, int n, int64_t len, int io_fp32, hipStream_t stream) {
+    const int64_t n8 = len / 8;
+    int64_t blocks = (n8 + OPT_THREADS - 1) / OPT_THREADS;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    if (io_fp32) sum_n_launch<float>(a, n, n8, (unsigned)blocks, stream);
+    else sum_n_launch<__bf16>(a, n, n8, (unsigned)blocks, stream);
+    return hipGetLastError();
+}

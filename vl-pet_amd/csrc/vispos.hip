@@ -184,7 +184,7 @@ __global__ __launch_bounds__(VP_WAVES * 64) void vispos_bwd_kernel(VisPosArgs a)
     using P = Piece<IO, sizeof(IO) == 2 ? 8 : 16>;
     // RB rows per trip (independent loads and reduction chains, as in the forward); a row past the end is a copy of the last row with a
     // zero gradient (it adds nothing).  The next trip's gradient rows are in flight while this trip is worked on.
-    constexpr int RB = 2;
+    constexpr int RB = NG == 4 ? 1 : 2;          // (d = 1024: sixteen columns per lane -- 12 accumulator kinds of them leave room for one row at a time)
     const int64_t stride = (int64_t)gridDim.x * VP_WAVES;
     const int64_t first = (int64_t)blockIdx.x * VP_WAVES + wave;
     typename P::Raw nxt[RB][NG];

@@ -422,6 +422,50 @@ def _finish(dests):
     return out
 
 
+FANOUT_SUM = True          # A/B switch (tools/ab_switches.py: VLPET_NO_FANOUT_SUM=1): fanout() below
+
+
+class _FanoutFn(torch.autograd.Function):
+    """``n`` aliases of one tensor for ``n`` consumers, so that their gradients arrive TOGETHER and are summed in one launch
+    (vlpet_sum_n: n + 1 row units, fp32 accumulation, one rounding) instead of autograd's pairwise accumulation (n - 1 passes of three
+    units, a bf16 rounding each).  The encoder output under the decoder layers' cross-attention is the case
+    (my_transformers/modeling_bart.py:2300-2330: every layer takes encoder_hidden_states)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        g0 = live[0]
+        same = all(g.dtype == g0.dtype and g.shape == g0.shape and g.is_contiguous() for g in live)
+        if not (same and g0.is_cuda and g0.dtype in (torch.bfloat16, torch.float32) and g0.numel() % 8 == 0 and g0.numel() > 0):
+            total = live[0]
+            for g in live[1:]:
+                total = total + g
+            return total, None
+        import ctypes
+        lib = _lib.load()
+        out = torch.empty_like(g0)
+        arr = (ctypes.c_void_p * len(live))(*[g.data_ptr() for g in live])
+        rc = _timed("fanout_sum", g0.numel() // g0.shape[-1], lambda: lib.vlpet_sum_n(arr, len(live), out.data_ptr(), g0.numel(), _io_dtype(g0), _stream()))
+        _lib.check(rc, "vlpet_sum_n")
+        return out, None
+
+
+def fanout(x: torch.Tensor, n: int):
+    """``n`` references to ``x`` for ``n`` consumers; on the GPU with gradients on, aliases whose gradients are summed in one launch."""
+    if n <= 1 or not FANOUT_SUM or not x.is_cuda or not (x.requires_grad and torch.is_grad_enabled()):
+        return (x,) * max(1, n)
+    return _FanoutFn.apply(x, n)
+
+
 class ResidualLink:
     """Hand-over of the residual-stream gradient between the two ops that read the sublayer input x1: the gate of K1 and
     the sublayer tail LayerNorm(x1 + dropout(y)) (my_transformers/modeling_bart.py:1196, 1259-1261).  Autograd would sum

@@ -482,8 +482,10 @@ class BartDecoder(nn.Module):
         B, L = input_ids.shape
         x = self.embed_tokens(input_ids) * self.embed_scale + self.embed_positions(L, input_ids.device)
         x = F.dropout(self.layernorm_embedding(x), p=self.dropout, training=self.training)
-        for layer in self.layers:
-            x = layer(x, enc, enc_mask, task)
+        from ..functional import fanout
+        encs = fanout(enc, len(self.layers))        # one gradient sum for the encoder output instead of autograd's pairwise adds
+        for layer, e in zip(self.layers, encs):
+            x = layer(x, e, enc_mask, task)
         return x
 
 

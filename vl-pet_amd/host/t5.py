@@ -465,8 +465,10 @@ class T5Decoder(nn.Module):
         self_bias = AttnSpec(sa0.compute_bias(L, L), None, causal=True,
                              rel_trainable=sa0.relative_attention_bias.weight.requires_grad and torch.is_grad_enabled())
         cross_bias = AttnSpec(None, enc_keep, causal=False)      # (dense form: invert_attention_mask, (1 - keep) * -1e9 in fp32)
-        for blk in self.block:
-            x = blk(x, self_bias, enc, cross_bias, task)
+        from ..functional import fanout
+        encs = fanout(enc, len(self.block))         # one gradient sum for the encoder output instead of autograd's pairwise adds
+        for blk, e in zip(self.block, encs):
+            x = blk(x, self_bias, e, cross_bias, task)
         return F.dropout(self.final_layer_norm(x), p=self.p, training=self.training)
 
 
