@@ -383,9 +383,10 @@ def test_position_branch_abi_rejects_what_it_does_not_cover():
                                 t.data_ptr(), 9, 3, 768, 1e-5, 0, _lib.VLPET_BF16, st) == -5       # VLPET_E_NULL: LayerNorm without beta
 
 
+@pytest.mark.parametrize("rms", [False, True])
 @pytest.mark.parametrize("nlvr", [False, True])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 1e-2)])
-def test_k4_module_with_a_frozen_token_table_takes_the_position_kernel(dtype, tol, nlvr, monkeypatch):
+def test_k4_module_with_a_frozen_token_table_takes_the_position_kernel(dtype, tol, nlvr, rms, monkeypatch):
     """The launch scripts' case: the shared token table (= obj_order_embedding) frozen, everything else of the visual embedding trainable
     (trainer_base.py:308-542).  Output and every gradient against the oracle, and the position branch must have run as the HIP kernel."""
     import vlpet_amd.visproj as VP
@@ -394,7 +395,7 @@ def test_k4_module_with_a_frozen_token_table_takes_the_position_kernel(dtype, to
     monkeypatch.setattr(VP._VisPosFn, "apply", lambda *a: (calls.append(1), orig(*a))[1])
     torch.manual_seed(4)
     B, N, F, d = 6, (72 if nlvr else 36), 2048, 768
-    ve, table = build(d, F, False, vocab=300)
+    ve, table = build(d, F, rms, vocab=300)          # rms: the T5 variant (T5LayerNorm on both branches, src/modeling_t5.py:56-73)
     with torch.no_grad():
         for p in ve.parameters():
             p.add_(torch.randn_like(p) * 0.05)
@@ -407,9 +408,15 @@ def test_k4_module_with_a_frozen_token_table_takes_the_position_kernel(dtype, to
         img_ids = torch.cat([torch.zeros(B, 36, dtype=torch.long), torch.ones(B, 36, dtype=torch.long)], 1)
         obj_ids = torch.arange(36).repeat(2).unsqueeze(0).expand(B, -1).contiguous()
     fe, pe = ve.feat_embedding, ve.absolute_vis_pos_embedding
-    names = [fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias, ve.img_order_embedding.weight]
-    ref = [t.detach().clone().requires_grad_(True) for t in names]
-    out_ref = O.visual_embedding(feats.float(), pos, *ref[:8], ref[8], table.weight.detach(), img_order_ids=img_ids, obj_order_ids=obj_ids)
+    if rms:
+        names = [fe[0].weight, fe[0].bias, fe[1].weight, pe[0].weight, pe[0].bias, pe[1].weight, ve.img_order_embedding.weight]
+        ref = [t.detach().clone().requires_grad_(True) for t in names]
+        out_ref = O.visual_embedding(feats.float(), pos, ref[0], ref[1], ref[2], None, ref[3], ref[4], ref[5], None, ref[6], table.weight.detach(),
+                                     img_order_ids=img_ids, obj_order_ids=obj_ids, eps=fe[1].variance_epsilon, rms=True)
+    else:
+        names = [fe[0].weight, fe[0].bias, fe[1].weight, fe[1].bias, pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias, ve.img_order_embedding.weight]
+        ref = [t.detach().clone().requires_grad_(True) for t in names]
+        out_ref = O.visual_embedding(feats.float(), pos, *ref[:8], ref[8], table.weight.detach(), img_order_ids=img_ids, obj_order_ids=obj_ids)
     out_ref.backward(dy.float())
     ve = ve.cuda()
     out = ve(feats.cuda(), pos.cuda(), None if img_ids is None else img_ids.cuda(), None if obj_ids is None else obj_ids.cuda())

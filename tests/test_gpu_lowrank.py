@@ -272,3 +272,33 @@ def test_lowrank_wide_bottleneck_falls_back_to_plain_torch():
     for n, p in ve.named_parameters():
         if n in gref and gref[n] is not None and p.grad is not None:
             assert float((p.grad.float().cpu() - gref[n]).abs().max()) <= 1e-3 * float(gref[n].abs().max() + 1e-6), n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lowrank_module_with_a_frozen_token_table_takes_the_position_kernel(dtype, monkeypatch):
+    """The launch scripts' case (shared token table frozen): the position / order branch of the low-rank visual embedding runs as
+    csrc/vispos.hip too; output and every trainable gradient against the oracle."""
+    import vlpet_amd.visproj as VP
+    from vlpet_amd.visual import LowRankVisualEmbedding
+    calls = []
+    orig = VP._VisPosFn.apply
+    monkeypatch.setattr(VP._VisPosFn, "apply", lambda *a: (calls.append(1), orig(*a))[1])
+    torch.manual_seed(12)
+    B, N, d, F_, r, nh, rg = 9, 36, 768, 2048, 96, 4, 96
+    table = nn.Embedding(300, d)
+    ve = LowRankVisualEmbedding(make_cfg(d, F_, r, nh, rg, True, False), table)
+    with torch.no_grad():
+        for p in ve.parameters():
+            p.add_(torch.randn_like(p) * 0.03)
+    feats, pos, dy = torch.randn(B, N, F_).to(dtype), torch.rand(B, N, 4), torch.randn(B, N, d).to(dtype)
+    ref_out, ref_g = oracle_run(ve, table, nh, True, False, feats, pos, dy)
+    table.weight.requires_grad_(False)
+    ve.cuda()
+    out = ve(feats.cuda(), pos.cuda())
+    assert calls, "the position branch did not take csrc/vispos.hip"
+    t_out, t_g = TOL[dtype]
+    assert rel_err(out, ref_out) <= t_out
+    out.backward(dy.cuda())
+    for n, p in ve.named_parameters():
+        if "obj_order" not in n:
+            assert rel_err(p.grad, ref_g[n]) <= t_g, n
