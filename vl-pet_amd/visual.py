@@ -100,7 +100,7 @@ def _order_lookup(table: nn.Embedding, ids: torch.Tensor) -> torch.Tensor:
 
 def _position_terms(mod, pos, img_order_ids, obj_order_ids, per_branch: bool, B: int, N: int):
     """R = [LN](Linear(5 -> d)([box, area])) + the two order embeddings, fp32, with library ops (src/modeling_bart.py:129-141,162-183):
-    the form for CPU tensors and for whatever csrc/vispos.hip does not cover."""
+    the form for whatever csrc/vispos.hip does not cover (other widths, a trainable object-order table, more than four image-order rows)."""
     pos = pos.float()
     pos5 = torch.cat([pos, mod.get_area(pos).unsqueeze(2)], dim=2)
     pl = mod.absolute_vis_pos_embedding[0]
