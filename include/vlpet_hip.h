@@ -551,6 +551,17 @@ int vlpet_attn_bwd_bias(const void* q, const void* k, const void* v, const void*
                         const uint8_t* key_mask, const float* bias, const float* bias_t, void* dq, void* dk, void* dv,
                         int B, int H, int Lq, int Lk, int ld_q, int ld_kv, int causal, float scale, float p, uint64_t seed,
                         vlpet_stream_t stream);
+/* ... and with separate row strides for k / dk (ld_k) and v / dv (ld_v) (round 6): the decoder layers' key projections of the encoder
+ * output run as ONE GEMM [M, d] -> [M, n_layers * d] (my_transformers/modeling_bart.py:2300-2330: every layer's encoder_attn projects the
+ * same encoder_hidden_states); a layer's attention reads its column block in place (ld_k = n_layers * d) and writes dk into the same block
+ * of one gradient buffer, which a single dgrad GEMM with K = n_layers * d consumes; v -- behind the value-parallel adapter -- keeps ld_v = d. */
+int vlpet_attn_fwd_kv(const void* q, const void* k, const void* v, const uint8_t* key_mask, const float* bias, void* o,
+                      float* lse, uint8_t* keep_out, int B, int H, int Lq, int Lk, int ld_q, int ld_k, int ld_v, int causal,
+                      float scale, float p, uint64_t seed, vlpet_stream_t stream);
+int vlpet_attn_bwd_kv(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                      const uint8_t* key_mask, const float* bias, const float* bias_t, void* dq, void* dk, void* dv,
+                      int B, int H, int Lq, int Lk, int ld_q, int ld_k, int ld_v, int causal, float scale, float p, uint64_t seed,
+                      vlpet_stream_t stream);
 
 /* ---- Downsample (the step before K4) -------------------------------------------------------
  * AdaptiveMaxPool2d(s_in x s_in -> s_out x s_out) over the token grid of x [n_images, s_in*s_in, dim]

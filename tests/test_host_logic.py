@@ -290,3 +290,27 @@ def test_trainable_layernorm_form_recheck_is_one_batched_read_and_reports_flips(
     assert tail.recheck_trainable_norms(m) is True
     assert m[0].weight._vlpet_prenorm[2] is False and m[1].weight._vlpet_prenorm[2] is True and m[2].weight._vlpet_prenorm[2] is False
     assert tail.recheck_trainable_norms(m) is False                      # nothing flips the second time
+
+
+def test_fused_key_projection_blocks_equal_separate_projections():
+    """functional.cross_key_blocks on CPU tensors (no attention kernel, so no shared gradient buffer: the per-block fallback of its backward):
+    n projections of one input as one GEMM whose column blocks are handed out == n separate nn.Linear calls, forward and d/dx."""
+    import torch
+    import vlpet_amd.functional as VF
+    torch.manual_seed(0)
+    n, E = 3, 16
+    x = torch.randn(2, 5, E, requires_grad=True)
+    lins = [torch.nn.Linear(E, E) for _ in range(n)]
+    w = torch.cat([l.weight for l in lins], 0).detach()
+    b = torch.cat([l.bias for l in lins], 0).detach()
+    ks, slot = VF.cross_key_blocks(x, w, b, n)
+    assert slot is not None and len(ks) == n and all(k.shape == (2, 5, E) for k in ks)
+    cs = [torch.randn(2, 5, E) for _ in range(n)]
+    sum((k * c).sum() for k, c in zip(ks, cs)).backward()
+    g, x.grad = x.grad, None
+    sum((l(x) * c).sum() for l, c in zip(lins, cs)).backward()
+    for k, l in zip(ks, lins):
+        assert torch.allclose(k, l(x), atol=1e-6)
+    assert torch.allclose(g, x.grad, atol=1e-5)
+    with torch.no_grad():
+        assert VF.cross_key_blocks(x, w, b, n)[1] is None

@@ -3,7 +3,7 @@ VLPET_AB=1): the product package itself reads nothing from the environment at im
     VLPET_NO_LINK=1, VLPET_NO_GEMM_LINK=1, VLPET_NO_NORM_LINK=1, VLPET_NO_LORA_LINK=1, VLPET_NO_BIAS_GRAD_KERNEL=1, VLPET_NO_FUSED_QKV=1,
     VLPET_EAGER_FFN_ACT=1, VLPET_EAGER_LM_LOSS=1, VLPET_EAGER_ATTENTION=1, VLPET_EAGER_RMS_NORM=1, VLPET_SPLIT_WIDE=1, VLPET_SDPA=flash|efficient|math, VLPET_NO_DEFER_REDUCES=1,
     VLPET_K4_FORM=gemm|library|fused, VLPET_SAVE_PRENORM=auto|0|1, VLPET_NO_TAIL_NORM_FUSION=1, VLPET_NO_ALIAS_RESIDUAL_GRAD=1,
-    VLPET_K1_BWD_FROM_X2=1, VLPET_DEFER_FINALIZE=1, VLPET_FINALIZE_SIDE_STREAM=1, VLPET_FINALIZE_LAUNCH=1, VLPET_NO_POS_KERNEL=1, VLPET_NO_FANOUT_SUM=1"""
+    VLPET_K1_BWD_FROM_X2=1, VLPET_DEFER_FINALIZE=1, VLPET_FINALIZE_SIDE_STREAM=1, VLPET_FINALIZE_LAUNCH=1, VLPET_NO_POS_KERNEL=1, VLPET_NO_FANOUT_SUM=1, VLPET_NO_FUSED_CROSS_KEYS=1"""
 import os
 
 
@@ -32,6 +32,7 @@ def apply():
     put(HB, "EAGER_ATTENTION", on("VLPET_EAGER_ATTENTION"))
     put(HT, "EAGER_ATTENTION", on("VLPET_EAGER_ATTENTION"))
     put(HB, "FUSE_QKV", not on("VLPET_NO_FUSED_QKV"))
+    put(HB, "FUSE_CROSS_KEYS", not on("VLPET_NO_FUSED_CROSS_KEYS"))        # the decoder layers' cross-attention key projections as one GEMM each way
     put(HT, "FUSE_QKV", not on("VLPET_NO_FUSED_QKV"))
     put(HB, "SDPA_BACKEND", os.environ.get("VLPET_SDPA") or None)
     put(LC, "LINK_DELTA_GRAD", not on("VLPET_NO_LORA_LINK"))

@@ -46,12 +46,39 @@ def supported(q: torch.Tensor, k: torch.Tensor, num_heads: int) -> bool:
             and q.shape[1] <= MAX_LEN and k.shape[1] <= MAX_LEN)
 
 
+class KeyGradSlot:
+    """Where the key gradients of n attention calls go when their keys are the column blocks of ONE ``[B, Lk, n * E]`` buffer (the
+    decoder layers' fused key projection of the encoder output, functional.cross_key_blocks): every call's backward writes its dk into
+    block ``index`` of one gradient buffer of the same geometry, allocated by the first call that gets there, and the projection's
+    backward consumes the whole buffer with a single GEMM."""
+
+    def __init__(self, n: int, E: int):
+        self.n, self.E, self.buf = n, E, None
+
+    def block(self, k: torch.Tensor, index: int) -> torch.Tensor:
+        if self.buf is None:
+            self.buf = torch.empty(k.shape[0], k.shape[1], self.n * self.E, dtype=k.dtype, device=k.device)
+        return self.buf[..., index * self.E:(index + 1) * self.E]
+
+
+def _is_row_block(t: torch.Tensor) -> bool:
+    """a [B, L, E] column block of a wider contiguous [B, L, ld] buffer that the kernels can read in place"""
+    return (t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1) and t.stride(1) % 8 == 0
+            and t.data_ptr() % 16 == 0)
+
+
 class _AttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, key_mask, H, causal, scale, p, seed, want_mask, bias=None):
+    def forward(ctx, q, k, v, key_mask, H, causal, scale, p, seed, want_mask, bias=None, k_slot=None):
         lib = _lib.load()
         _need_cuda(q, k, v)
-        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        # (k_slot = (KeyGradSlot, index): k is a column block of the fused key projection's output and is read in place, row stride n * E)
+        if k_slot is not None and not _is_row_block(k):
+            k_slot = None
+        q, v = q.contiguous(), v.contiguous()
+        if k_slot is None:
+            k = k.contiguous()
+        ld_k = k.stride(1)
         B, Lq, _ = q.shape
         Lk = k.shape[1]
         if bias is not None and (bias.H, bias.Lq, bias.Lk) != (H, Lq, Lk):
@@ -60,13 +87,14 @@ class _AttnFn(torch.autograd.Function):
         lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
         # (the kernel writes the mask only when it drops something: without dropout every element is kept)
         keep = torch.ones(B, H, Lq, Lk, dtype=torch.uint8, device=q.device) if want_mask else None
-        rc = _timed("attn_fwd", B * Lq, lambda: lib.vlpet_attn_fwd_bias(
+        rc = _timed("attn_fwd", B * Lq, lambda: lib.vlpet_attn_fwd_kv(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(key_mask), bias.b.data_ptr() if bias is not None else None,
-            o.data_ptr(), lse.data_ptr(), _ptr(keep), B, H, Lq, Lk, H * HEAD_DIM, H * HEAD_DIM, int(causal), float(scale), float(p), seed,
+            o.data_ptr(), lse.data_ptr(), _ptr(keep), B, H, Lq, Lk, H * HEAD_DIM, ld_k, H * HEAD_DIM, int(causal), float(scale), float(p), seed,
             _stream()))
         _lib.check(rc, "vlpet_attn_fwd")
         ctx.save_for_backward(q, k, v, o, lse, key_mask)
         ctx.bias = bias
+        ctx.k_slot = k_slot
         ctx.cfg = (H, int(causal), float(scale), float(p), seed)
         if want_mask:
             ctx.mark_non_differentiable(keep)
@@ -83,15 +111,18 @@ class _AttnFn(torch.autograd.Function):
         do = dout.contiguous()
         if do.dtype != q.dtype:
             do = do.to(q.dtype)
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dq, dv = torch.empty_like(q), torch.empty_like(v)
+        k_slot, ctx.k_slot = ctx.k_slot, None
+        dk = torch.empty_like(k) if k_slot is None else k_slot[0].block(k, k_slot[1])      # (the slot's block has k's strides)
+        assert dk.stride() == k.stride()
         bias = ctx.bias
-        rc = _timed("attn_bwd", B * Lq, lambda: lib.vlpet_attn_bwd_bias(
+        rc = _timed("attn_bwd", B * Lq, lambda: lib.vlpet_attn_bwd_kv(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), _ptr(key_mask),
             bias.b.data_ptr() if bias is not None else None, bias.bt.data_ptr() if bias is not None else None,
-            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Lq, Lk, H * HEAD_DIM, H * HEAD_DIM, causal, scale, p, seed, _stream()))
+            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Lq, Lk, H * HEAD_DIM, k.stride(1), H * HEAD_DIM, causal, scale, p, seed, _stream()))
         _lib.check(rc, "vlpet_attn_bwd")
         ctx.bias = None
-        return dq, dk, dv, None, None, None, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None
 
 
 class _AttnQkvFn(torch.autograd.Function):
@@ -184,9 +215,10 @@ def short_self_attention(qkv: torch.Tensor, num_heads: int, key_mask: Optional[t
 
 def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads: int, key_mask: Optional[torch.Tensor] = None,
                     causal: bool = False, p: float = 0.0, training: bool = False, scale: Optional[float] = None, seed=None,
-                    return_mask: bool = False, bias: Optional[AttnBias] = None):
+                    return_mask: bool = False, bias: Optional[AttnBias] = None, k_slot=None):
     """q [B, Lq, H*64], k / v [B, Lk, H*64] (bf16) -> [B, Lq, H*64].  key_mask: [B, Lk] bool / uint8, True = attend.
-    bias: an ``AttnBias`` ([H, Lq, Lk] added to the scaled scores of every sample; no gradient)."""
+    bias: an ``AttnBias`` ([H, Lq, Lk] added to the scaled scores of every sample; no gradient).  k_slot: (KeyGradSlot, index) when
+    ``k`` is a column block of a fused key projection (read in place; its gradient goes into the slot's shared buffer)."""
     if not supported(q, k, num_heads):
         raise RuntimeError("vl-pet_amd: short_attention needs bf16 CUDA tensors, head dim 64 and at most 128 keys / queries")
     if key_mask is not None:
@@ -195,4 +227,4 @@ def short_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, num_heads
     if seed is None:
         seed = _draw_seed() if pe > 0.0 else 0
     return _AttnFn.apply(q, k, v, key_mask, num_heads, bool(causal), HEAD_DIM ** -0.5 if scale is None else float(scale),
-                         pe, int(seed), bool(return_mask), bias)
+                         pe, int(seed), bool(return_mask), bias, k_slot)

@@ -1352,20 +1352,28 @@ static int attn_ld_ok(int H, int ld_q, int ld_kv) {
     return ld_q >= H * 64 && ld_kv >= H * 64 && ld_q % 8 == 0 && ld_kv % 8 == 0;
 }
 
-extern "C" int vlpet_attn_fwd_bias(const void* q, const void* k, const void* v, const uint8_t* key_mask, const float* bias, void* o,
-                                   float* lse, uint8_t* keep_out, int B, int H, int Lq, int Lk, int ld_q, int ld_kv, int causal,
-                                   float scale, float p, uint64_t seed, vlpet_stream_t stream) {
+// ... with separate row strides for k / dk (ld_k) and v / dv (ld_v): k may be a column block of a wider buffer (the decoder layers' fused
+// key projection of the encoder output) while v keeps its own width
+extern "C" int vlpet_attn_fwd_kv(const void* q, const void* k, const void* v, const uint8_t* key_mask, const float* bias, void* o,
+                                 float* lse, uint8_t* keep_out, int B, int H, int Lq, int Lk, int ld_q, int ld_k, int ld_v, int causal,
+                                 float scale, float p, uint64_t seed, vlpet_stream_t stream) {
+    const int ld_kv = ld_k;
     int rc = attn_common(B, H, Lq, Lk, p);
     if (rc) return rc;
-    if (!attn_ld_ok(H, ld_q, ld_kv) || !(scale != 0.f)) return VLPET_E_SHAPE;
+    if (!attn_ld_ok(H, ld_q, ld_kv) || !attn_ld_ok(H, ld_q, ld_v) || !(scale != 0.f)) return VLPET_E_SHAPE;
     if (!q || !k || !v || !o || !lse) return VLPET_E_NULL;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o) || (bias && !aligned16(bias))) return VLPET_E_ALIGN;
     AttnArgs a{};
-    a.ld_q = ld_q; a.ld_kv = ld_kv; a.bias = bias; a.bias_t = nullptr;
+    a.ld_q = ld_q; a.ld_kv = ld_kv; a.ld_v = ld_v; a.bias = bias; a.bias_t = nullptr;
     a.q = (const __bf16*)q; a.k = (const __bf16*)k; a.v = (const __bf16*)v; a.o = (__bf16*)o; a.lse = lse;
     a.key_mask = key_mask; a.keep_out = keep_out; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.causal = causal ? 1 : 0;
     a.scale = scale; a.thr = attn_thr(p); a.inv_keep = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed; a.seed_ctr = g_seed_ctr.load();
     return herr(launch_attn(a, false, (hipStream_t)stream));
+}
+extern "C" int vlpet_attn_fwd_bias(const void* q, const void* k, const void* v, const uint8_t* key_mask, const float* bias, void* o,
+                                   float* lse, uint8_t* keep_out, int B, int H, int Lq, int Lk, int ld_q, int ld_kv, int causal,
+                                   float scale, float p, uint64_t seed, vlpet_stream_t stream) {
+    return vlpet_attn_fwd_kv(q, k, v, key_mask, bias, o, lse, keep_out, B, H, Lq, Lk, ld_q, ld_kv, ld_kv, causal, scale, p, seed, stream);
 }
 
 extern "C" int vlpet_attn_fwd_ld(const void* q, const void* k, const void* v, const uint8_t* key_mask, void* o, float* lse,
@@ -1380,23 +1388,31 @@ extern "C" int vlpet_attn_fwd(const void* q, const void* k, const void* v, const
     return vlpet_attn_fwd_ld(q, k, v, key_mask, o, lse, keep_out, B, H, Lq, Lk, H * 64, H * 64, causal, scale, p, seed, stream);
 }
 
-extern "C" int vlpet_attn_bwd_bias(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                                   const uint8_t* key_mask, const float* bias, const float* bias_t, void* dq, void* dk, void* dv,
-                                   int B, int H, int Lq, int Lk, int ld_q, int ld_kv, int causal, float scale, float p, uint64_t seed,
-                                   vlpet_stream_t stream) {
+extern "C" int vlpet_attn_bwd_kv(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                                 const uint8_t* key_mask, const float* bias, const float* bias_t, void* dq, void* dk, void* dv,
+                                 int B, int H, int Lq, int Lk, int ld_q, int ld_k, int ld_v, int causal, float scale, float p, uint64_t seed,
+                                 vlpet_stream_t stream) {
+    const int ld_kv = ld_k;
     int rc = attn_common(B, H, Lq, Lk, p);
     if (rc) return rc;
-    if (!attn_ld_ok(H, ld_q, ld_kv) || !(scale != 0.f)) return VLPET_E_SHAPE;
+    if (!attn_ld_ok(H, ld_q, ld_kv) || !attn_ld_ok(H, ld_q, ld_v) || !(scale != 0.f)) return VLPET_E_SHAPE;
     if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || ((bias != nullptr) != (bias_t != nullptr))) return VLPET_E_NULL;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o) || !aligned16(dout) || !aligned16(dq) ||
         !aligned16(dk) || !aligned16(dv) || (bias && (!aligned16(bias) || !aligned16(bias_t)))) return VLPET_E_ALIGN;
     AttnArgs a{};
-    a.ld_q = ld_q; a.ld_kv = ld_kv; a.bias = bias; a.bias_t = bias_t;
+    a.ld_q = ld_q; a.ld_kv = ld_kv; a.ld_v = ld_v; a.bias = bias; a.bias_t = bias_t;
     a.q = (const __bf16*)q; a.k = (const __bf16*)k; a.v = (const __bf16*)v; a.o = (__bf16*)const_cast<void*>(o);
     a.lse = const_cast<float*>(lse); a.dout = (const __bf16*)dout; a.dq = (__bf16*)dq; a.dk = (__bf16*)dk; a.dv = (__bf16*)dv;
     a.key_mask = key_mask; a.keep_out = nullptr; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.causal = causal ? 1 : 0;
     a.scale = scale; a.thr = attn_thr(p); a.inv_keep = a.thr ? 1.0f / (1.0f - p) : 1.0f; a.seed = seed; a.seed_ctr = g_seed_ctr.load();
     return herr(launch_attn(a, true, (hipStream_t)stream));
+}
+extern "C" int vlpet_attn_bwd_bias(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                                   const uint8_t* key_mask, const float* bias, const float* bias_t, void* dq, void* dk, void* dv,
+                                   int B, int H, int Lq, int Lk, int ld_q, int ld_kv, int causal, float scale, float p, uint64_t seed,
+                                   vlpet_stream_t stream) {
+    return vlpet_attn_bwd_kv(q, k, v, o, dout, lse, key_mask, bias, bias_t, dq, dk, dv, B, H, Lq, Lk, ld_q, ld_kv, ld_kv, causal, scale, p, seed,
+                             stream);
 }
 
 extern "C" int vlpet_attn_bwd_ld(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,

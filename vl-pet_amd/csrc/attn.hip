@@ -194,10 +194,10 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
     const int b = bh / a.H, h = bh % a.H;
     const int m = lane & 31, hh = lane >> 5;
     constexpr int Lkp = 32 * T;
-    const int64_t rs = (int64_t)a.H * 64, rq = a.ld_q, rk = a.ld_kv;
+    const int64_t rs = (int64_t)a.H * 64, rq = a.ld_q, rk = a.ld_kv, rv = a.ld_v;
     const __bf16* qb_ = a.q + (int64_t)b * a.Lq * rq + h * 64;
     const __bf16* kb_ = a.k + (int64_t)b * a.Lk * rk + h * 64;
-    const __bf16* vb_ = a.v + (int64_t)b * a.Lk * rk + h * 64;
+    const __bf16* vb_ = a.v + (int64_t)b * a.Lk * rv + h * 64;
     __bf16* ob_ = a.o + (int64_t)b * a.Lq * rs + h * 64;
     const uint8_t* km = a.key_mask ? a.key_mask + (int64_t)b * a.Lk : nullptr;
     uint8_t* Vs = smem + (size_t)wave * AttnLds::fwd_wave_bytes(Lkp);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(AT_FW * 64, (T <= 2 ? 3 : 2)) void attn_fwd_kernel(
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) kf[t][ks] = *reinterpret_cast<const bf16x8*>(kb_ + (int64_t)jk * rk + 16 * ks + 8 * hh);
     }
-    stage_image(Vs, vb_, rk, a.Lk, Lkp, lane, 64);
+    stage_image(Vs, vb_, rv, a.Lk, Lkp, lane, 64);
 
     const float sc2 = a.scale * LOG2E;
     const int NQB = (a.Lq + 31) >> 5;
@@ -438,9 +438,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
     const int m = lane & 31, hh = lane >> 5;
     const int Lkp = (a.Lk + 31) & ~31, T = Lkp >> 5;
     const int Lqp = (a.Lq + 31) & ~31, NQB = Lqp >> 5;
-    const int64_t rs = (int64_t)a.H * 64, rq = a.ld_q, rk = a.ld_kv;
+    const int64_t rs = (int64_t)a.H * 64, rq = a.ld_q, rk = a.ld_kv, rv = a.ld_v;
     const int64_t ooff = (int64_t)b * a.Lq * rs + h * 64;                                            // o, dout
-    const int64_t qoff = (int64_t)b * a.Lq * rq + h * 64, koff = (int64_t)b * a.Lk * rk + h * 64;    // q / dq, k v / dk dv
+    const int64_t qoff = (int64_t)b * a.Lq * rq + h * 64, koff = (int64_t)b * a.Lk * rk + h * 64;    // q / dq, k / dk
+    const int64_t voff = (int64_t)b * a.Lk * rv + h * 64;                                            // v / dv
     const uint8_t* km = a.key_mask ? a.key_mask + (int64_t)b * a.Lk : nullptr;
     uint8_t* Qs = smem;
     uint8_t* Ds = Qs + (size_t)Lqp * AT_ROW;                     // dO
@@ -465,9 +466,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
         }
         if (tid < Lkp) kval[tid] = key_bias(a, km, tid);
         uint8_t* const imgs[4] = {Qs, Ds, Ks, Vs};
-        const __bf16* const srcs[4] = {a.q + qoff, a.dout + ooff, a.k + koff, a.v + koff};
+        const __bf16* const srcs[4] = {a.q + qoff, a.dout + ooff, a.k + koff, a.v + voff};
         const int nr[4] = {a.Lq, a.Lq, a.Lk, a.Lk}, rp[4] = {Lqp, Lqp, Lkp, Lkp};
-        const int64_t rss[4] = {rq, rs, rk, rk};
+        const int64_t rss[4] = {rq, rs, rk, rv};
         stage_images<4, (NW == 6 ? 3 : 4)>(imgs, srcs, nr, rp, rss, tid, NW * 64);          // 128 rows x 8 pieces / 256 threads = 4 per image
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_bwd_kernel(AttnArgs a) {
             f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
             if (!(a.dbg & 8)) bwd_k_unit<PadRd, BIAS>(a, c, rd, un, NQB, Lqp, Lkp, h, lane, dv0, dv1, dk0, dk1);
             if (a.dbg & 4) { if (dv0[0] + dv1[1] + dk0[2] + dk1[3] == 1.2345f) a.dv[0] = (__bf16)1.f; continue; }
-            store_rows_T(stg, dv0, dv1, a.dv + koff, rk, 32 * un, a.Lk, lane);
+            store_rows_T(stg, dv0, dv1, a.dv + voff, rv, 32 * un, a.Lk, lane);
             store_rows_T(stg, dk0, dk1, a.dk + koff, rk, 32 * un, a.Lk, lane);
         } else {
             f32x16 dq0 = zero16(), dq1 = zero16();

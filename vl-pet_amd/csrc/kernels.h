@@ -442,8 +442,10 @@ struct AttnArgs {
     const float* bias_t;    // the same bias transposed, [H, Lkp, Lqp] (the key-major phase of the backward reads it along queries)
     uint8_t* keep_out;      // forward only: optional [B, H, Lq, Lk] export of the dropout mask (tests)
     int B, H, Lq, Lk, causal;
-    int ld_q, ld_kv;        // row stride (elements) of q / dq and of k, v / dk, dv: H*64 for separate projection outputs, 3*H*64
+    int ld_q, ld_kv;        // row stride (elements) of q / dq and of k / dk: H*64 for separate projection outputs, 3*H*64
                             // for the columns of a fused [B, L, 3*H*64] q|k|v buffer (o and dout are always H*64 wide)
+    int ld_v;               // row stride of v / dv (round 6: k may be a column block of the decoder layers' fused key projection,
+                            // [B, Lk, n_layers*H*64], while v -- behind the value-parallel adapter -- stays H*64 wide)
     float scale;
     uint32_t thr;           // drop iff hash < thr (p * 2^32); 0 = no dropout
     float inv_keep;

@@ -466,6 +466,53 @@ def fanout(x: torch.Tensor, n: int):
     return _FanoutFn.apply(x, n)
 
 
+class _CrossKeyProjFn(torch.autograd.Function):
+    """``n`` frozen projections of ONE input as ONE GEMM: ``x [.., E] -> [.., n * E]``, handed out as its n column blocks (views).  The
+    decoder layers' cross-attention key projections of the encoder output (my_transformers/modeling_bart.py:2300-2330 hands every layer
+    the same encoder_hidden_states; each layer's ``encoder_attn.k_proj`` projects it, :425) -- n small GEMMs that all read x, and in
+    the backward n dgrad GEMMs that all accumulate into d/dx.  Here: one GEMM forward; backward, the attention calls write their dk
+    into the blocks of one gradient buffer (attention.KeyGradSlot) and ONE GEMM with K = n * E produces d/dx."""
+
+    @staticmethod
+    def forward(ctx, x, w_all, b_all, n, slot):
+        y = F.linear(x, w_all, b_all)
+        E = w_all.shape[0] // n
+        ctx.save_for_backward(w_all)
+        ctx.slot, ctx.n, ctx.xshape = slot, n, x.shape
+        return tuple(y[..., i * E:(i + 1) * E] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *dks):
+        (w_all,) = ctx.saved_tensors
+        n, slot = ctx.n, ctx.slot
+        ctx.slot = None
+        E = w_all.shape[0] // n
+        buf = slot.buf if slot is not None else None
+        if slot is not None:
+            slot.buf = None
+        whole = buf is not None and all(
+            dk is not None and dk.data_ptr() == buf.data_ptr() + i * E * buf.element_size() and dk.shape[:-1] == buf.shape[:-1]
+            and dk.stride() == buf.stride() for i, dk in enumerate(dks))
+        if whole:
+            dx = buf.view(-1, n * E) @ w_all
+        else:                       # (a consumer that went another way: per-block products)
+            dx = None
+            for i, dk in enumerate(dks):
+                if dk is None:
+                    continue
+                t = dk.reshape(-1, E).to(w_all.dtype) @ w_all[i * E:(i + 1) * E]
+                dx = t if dx is None else dx.add_(t)
+        return (None if dx is None else dx.view(ctx.xshape)), None, None, None, None
+
+
+def cross_key_blocks(x: torch.Tensor, w_all: torch.Tensor, b_all: torch.Tensor, n: int):
+    """(k_0 .. k_{n-1}, slot): the n key projections of ``x`` as column blocks of one GEMM's output and the KeyGradSlot their attention
+    calls pass on (``short_attention(..., k_slot=(slot, i))``)."""
+    from .attention import KeyGradSlot
+    slot = KeyGradSlot(n, w_all.shape[0] // n) if (x.requires_grad and torch.is_grad_enabled()) else None
+    return _CrossKeyProjFn.apply(x, w_all, b_all, n, slot), slot
+
+
 class ResidualLink:
     """Hand-over of the residual-stream gradient between the two ops that read the sublayer input x1: the gate of K1 and
     the sublayer tail LayerNorm(x1 + dropout(y)) (my_transformers/modeling_bart.py:1196, 1259-1261).  Autograd would sum

@@ -220,7 +220,7 @@ def _sdpa_ctx():
                         "math": SDPBackend.MATH}[which])
 
 
-def attention_core(q, k, v, num_heads, attn_mask, causal, p, training):
+def attention_core(q, k, v, num_heads, attn_mask, causal, p, training, k_slot=None):
     """``dropout(softmax(q k^T / sqrt(d) + mask), p) v`` on the projection outputs ``[B, L, H * d]``.  Sequences of at most
     128 tokens in bf16 with head dim 64 (every image-text shape) run on vlpet_amd.attention's on-chip kernels; anything
     else (fp32 parity runs, the 664-token video encoder, non-boolean masks) on torch's SDPA.  The parity / CPU-baseline
@@ -231,8 +231,8 @@ def attention_core(q, k, v, num_heads, attn_mask, causal, p, training):
                                              and attn_mask.shape[1] == 1 and attn_mask.shape[2] == 1)
     if not EAGER_ATTENTION and boolean_key_mask and A.supported(q, k, num_heads):
         km = None if attn_mask is None else attn_mask[:, 0, 0, :]
-        return A.short_attention(q, k, v, num_heads, km, causal and attn_mask is None, p, training)
-    sh = lambda t: t.view(B, -1, num_heads, E // num_heads).transpose(1, 2)
+        return A.short_attention(q, k, v, num_heads, km, causal and attn_mask is None, p, training, k_slot=k_slot)
+    sh = lambda t: t.reshape(B, -1, num_heads, E // num_heads).transpose(1, 2)
     with _sdpa_ctx():
         out = F.scaled_dot_product_attention(sh(q), sh(k), sh(v), attn_mask=attn_mask, is_causal=causal and attn_mask is None,
                                              dropout_p=p if training else 0.0)
@@ -242,6 +242,7 @@ def attention_core(q, k, v, num_heads, attn_mask, causal, p, training):
 FUSE_BIAS_GRAD = True    # A/B switch (tools/ab_switches.py): False = autograd's sum(0) for trainable biases
 EAGER_ATTENTION = False   # A/B switch: the library (SDPA) path for every shape
 FUSE_QKV = True              # A/B switch: False = separate q / k / v projections in self-attention
+FUSE_CROSS_KEYS = True       # A/B switch: False = every decoder layer projects its own cross-attention keys (round 5)
 SDPA_BACKEND = None          # A/B switch: "flash" | "efficient" | "math" pins torch SDPA's backend on the library path
 
 
@@ -290,8 +291,10 @@ class BartAttention(nn.Module):
             self._qkv_cache = c
         return c[1], c[2]
 
-    def forward(self, hidden, kv=None, attn_mask=None, causal=False, task=None, in_link=None):
-        """``in_link``: see _first_linear -- armed by the projection of ``hidden`` (q|k|v or q_proj) when that is frozen."""
+    def forward(self, hidden, kv=None, attn_mask=None, causal=False, task=None, in_link=None, k_pre=None):
+        """``in_link``: see _first_linear -- armed by the projection of ``hidden`` (q|k|v or q_proj) when that is frozen.
+        ``k_pre`` = (k, k_slot): this layer's keys already projected (cross-attention: a column block of the decoder's fused key
+        projection of the encoder output, BartDecoder._cross_keys)."""
         B, L, _ = hidden.shape
         src = hidden if kv is None else kv
         if kv is None and FUSE_QKV and not self.use_lora and not EAGER_ATTENTION:
@@ -322,10 +325,14 @@ class BartAttention(nn.Module):
             kv_link = _new_gemm_link(src) if (kv is not None and _frozen(self.k_proj, self.v_proj)) else None
             if kv_link is not None:
                 from ..functional import linear_acc
-                k, v = linear_acc(src, kv_link, self.k_proj, self.v_proj)      # one gradient for the encoder output, K2's included
+                k_slot = None
+                if k_pre is not None:
+                    (k, k_slot), v = k_pre, linear_acc(src, kv_link, self.v_proj)
+                else:
+                    k, v = linear_acc(src, kv_link, self.k_proj, self.v_proj)      # one gradient for the encoder output, K2's included
                 if self.attn_value_parallel_adapter is not None:
                     v = self.attn_value_parallel_adapter(src, task, y=v, link=kv_link)
-                out = attention_core(q, k, v, self.num_heads, attn_mask, causal, self.dropout, self.training)
+                out = attention_core(q, k, v, self.num_heads, attn_mask, causal, self.dropout, self.training, k_slot=k_slot)
                 return _linear(self.out_proj, out)
             v = _linear(self.v_proj, src)
             k = _linear(self.k_proj, src)
@@ -389,14 +396,14 @@ class BartDecoderLayer(nn.Module):
         self.fc2 = nn.Linear(config.decoder_ffn_dim, d)
         self.final_layer_norm = HostLayerNorm(d)
 
-    def forward(self, hidden, enc, enc_mask=None, task=None):
+    def forward(self, hidden, enc, enc_mask=None, task=None, k_pre=None):
         residual = hidden
         gl = _new_gemm_link(hidden)
         h = self.self_attn(hidden, causal=True, task=task, in_link=gl)
         hidden = _tail_linked(residual, h, self.self_attn_layer_norm, self.dropout, self.training, gl)   # K5
         residual = hidden
         gl = _new_gemm_link(hidden)
-        h = self.encoder_attn(hidden, kv=enc, attn_mask=enc_mask, task=task, in_link=gl)      # K2 inside
+        h = self.encoder_attn(hidden, kv=enc, attn_mask=enc_mask, task=task, in_link=gl, k_pre=k_pre)      # K2 inside
         hidden = _tail_linked(residual, h, self.encoder_attn_layer_norm, self.dropout, self.training, gl)  # K5
         residual = hidden
         gl = _new_gemm_link(hidden)
@@ -483,10 +490,38 @@ class BartDecoder(nn.Module):
         x = self.embed_tokens(input_ids) * self.embed_scale + self.embed_positions(L, input_ids.device)
         x = F.dropout(self.layernorm_embedding(x), p=self.dropout, training=self.training)
         from ..functional import fanout
-        encs = fanout(enc, len(self.layers))        # one gradient sum for the encoder output instead of autograd's pairwise adds
-        for layer, e in zip(self.layers, encs):
-            x = layer(x, e, enc_mask, task)
+        n = len(self.layers)
+        fused_keys = self._cross_keys_ok(enc, enc_mask)
+        encs = fanout(enc, n + (1 if fused_keys else 0))        # one gradient sum for the encoder output instead of autograd's pairwise adds
+        ks = self._cross_keys(encs[n]) if fused_keys else None
+        for i, (layer, e) in enumerate(zip(self.layers, encs)):
+            x = layer(x, e, enc_mask, task, k_pre=None if ks is None else (ks[0][i], None if ks[1] is None else (ks[1], i)))
         return x
+
+    def _cross_keys_ok(self, enc, enc_mask) -> bool:
+        """The layers' cross-attention key projections as ONE GEMM (functional.cross_key_blocks): frozen plain projections, bf16 on the
+        GPU, a shape the short-sequence attention kernels take (they read a layer's keys as a column block in place)."""
+        from .. import attention as A
+        if not FUSE_CROSS_KEYS or EAGER_ATTENTION or len(self.layers) < 2 or not enc.is_cuda or enc.dtype != torch.bfloat16:
+            return False
+        a0 = self.layers[0].encoder_attn
+        if enc.shape[1] > A.MAX_LEN or a0.head_dim != A.HEAD_DIM:
+            return False
+        if enc_mask is not None and not (enc_mask.dtype == torch.bool and enc_mask.dim() == 4 and enc_mask.shape[1] == 1 and enc_mask.shape[2] == 1):
+            return False
+        return all((not l.encoder_attn.use_lora) and _frozen(l.encoder_attn.k_proj, l.encoder_attn.v_proj) for l in self.layers)
+
+    def _cross_keys(self, enc):
+        from .. import functional as VF
+        mods = [l.encoder_attn.k_proj for l in self.layers]
+        key = (enc.dtype, VF.FROZEN_EPOCH) + tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in mods)
+        c = getattr(self, "_ck_cache", None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                w = torch.cat([m.weight.to(enc.dtype) for m in mods], 0).contiguous()
+                b = torch.cat([m.bias.to(enc.dtype) for m in mods], 0).contiguous()
+            c = self._ck_cache = (key, w, b)
+        return VF.cross_key_blocks(enc, c[1], c[2], len(mods))
 
 
 class VLBartModel(nn.Module):
