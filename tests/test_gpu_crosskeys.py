@@ -146,3 +146,39 @@ def test_trainer_with_fused_cross_keys_equals_per_layer_projections(graph, monke
         assert abs(a - b) <= 2e-2 * abs(b), (res[True][0], res[False][0])
     worst = max(float((res[True][1][n] - res[False][1][n]).abs().max() / (res[False][1][n].abs().max() + 1e-12)) for n in res[True][1])
     assert worst <= 5e-2, worst
+
+
+def test_t5_trainer_with_fused_cross_keys_equals_per_block_projections(monkeypatch):
+    """The same for the T5 host (bias-free projections, relative-position bias in the attention kernels, RMS norms)."""
+    import vlpet_amd.functional as VF
+    import vlpet_amd.host.t5 as HT
+    import vlpet_amd.train as TR
+    from vlpet_amd import _lib
+    cfg = HT.vlt5_config(d_model=128, d_kv=64, d_ff=256, num_layers=2, num_decoder_layers=3, num_heads=2, vocab_size=500, feat_dim=128,
+                         adapter_down_dim=16, adapter_gating_down_dim=16, decoder_enc_attn_value_parallel_adapter_down_dim=8, dropout_rate=0.0)
+    torch.manual_seed(0)
+    model = HT.VLT5(cfg)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    TR.trainable_names(model, cfg)
+    model.cuda()
+    TR.cast_frozen(model, torch.bfloat16)
+    model.train()
+    gen = torch.Generator().manual_seed(4)
+    b = TR.synthetic_batch("vqa", 6, cfg, "cpu", gen)
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    batch["vis_inputs"] = tuple(x.cuda() for x in b["vis_inputs"])
+    used = []
+    orig = VF.cross_key_blocks
+    monkeypatch.setattr(VF, "cross_key_blocks", lambda *a: (used.append(1), orig(*a))[1])
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(HT, "FUSE_CROSS_KEYS", fused)
+        m = copy.deepcopy(model)
+        tr = TR.Trainer(m, cfg, lr=1e-2, total_steps=20, warmup_ratio=0.1)
+        res[fused] = [float(tr.step(batch)) for _ in range(4)]
+        _lib.load().vlpet_set_seed_counter(None)
+    assert used, "the fused key projection did not run"
+    for a, c in zip(res[True], res[False]):
+        assert abs(a - c) <= 2e-2 * abs(c), res

@@ -32,7 +32,7 @@ def apply():
     put(HB, "EAGER_ATTENTION", on("VLPET_EAGER_ATTENTION"))
     put(HT, "EAGER_ATTENTION", on("VLPET_EAGER_ATTENTION"))
     put(HB, "FUSE_QKV", not on("VLPET_NO_FUSED_QKV"))
-    put(HB, "FUSE_CROSS_KEYS", not on("VLPET_NO_FUSED_CROSS_KEYS"))        # the decoder layers' cross-attention key projections as one GEMM each way
+    put(HB, "FUSE_CROSS_KEYS", not on("VLPET_NO_FUSED_CROSS_KEYS")); put(HT, "FUSE_CROSS_KEYS", not on("VLPET_NO_FUSED_CROSS_KEYS"))        # the decoder layers' cross-attention key projections as one GEMM each way
     put(HT, "FUSE_QKV", not on("VLPET_NO_FUSED_QKV"))
     put(HB, "SDPA_BACKEND", os.environ.get("VLPET_SDPA") or None)
     put(LC, "LINK_DELTA_GRAD", not on("VLPET_NO_LORA_LINK"))

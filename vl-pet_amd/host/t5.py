@@ -178,6 +178,7 @@ def relative_position_bucket(relative_position, bidirectional, num_buckets=32, m
 
 EAGER_ATTENTION = False   # A/B switch (tools/ab_switches.py): True = torch SDPA with a dense additive mask for every T5 attention
 FUSE_QKV = True           # A/B switch: False = separate q / k / v projections in self-attention
+FUSE_CROSS_KEYS = True    # A/B switch: False = every decoder block projects its own cross-attention keys (host/bart.py: the same fusion)
 
 
 class AttnSpec:
@@ -272,10 +273,12 @@ class T5Attention(nn.Module):
             self._qkv_cache = c
         return c[1]
 
-    def forward(self, hidden, bias, kv=None, task=None):
+    def forward(self, hidden, bias, kv=None, task=None, k_pre=None):
+        """``k_pre`` = (k, k_slot): this block's cross-attention keys, a column block of the decoder's fused key projection (T5Stack._cross_keys)"""
         B, Lq, _ = hidden.shape
         src = hidden if kv is None else kv
         from .. import attention as A
+        k_slot = None
         spec = bias if isinstance(bias, AttnSpec) else None
         if (kv is None and FUSE_QKV and spec is not None and not EAGER_ATTENTION and hidden.is_cuda and hidden.dtype == torch.bfloat16
                 and self.d_kv == A.HEAD_DIM and Lq <= A.MAX_LEN and not any(m.weight.requires_grad for m in (self.q, self.k, self.v))):
@@ -303,7 +306,10 @@ class T5Attention(nn.Module):
             else:
                 q = _linear(self.q, hidden)
                 kv_link = ResidualLink() if self.attn_value_parallel_adapter is not None else None
-                k, v = linear_acc(src, kv_link, self.k, self.v)
+                if k_pre is not None:
+                    (k, k_slot), v = k_pre, linear_acc(src, kv_link, self.v)
+                else:
+                    k, v = linear_acc(src, kv_link, self.k, self.v)
                 if self.attn_value_parallel_adapter is not None:
                     v = self.attn_value_parallel_adapter(src, task, y=v, link=kv_link)    # K2
         else:
@@ -313,10 +319,11 @@ class T5Attention(nn.Module):
         if spec is not None and not EAGER_ATTENTION and self.d_kv == A.HEAD_DIM and A.supported(q, k, self.n_heads):
             fast = spec.fast()
             if fast is not None:        # on-chip kernels: bias shared by the batch + boolean key mask + causal flag; T5 has no 1/sqrt(d)
-                out = A.short_attention(q, k, v, self.n_heads, fast[1], spec.causal, self.dropout, self.training, scale=1.0, bias=fast[0])
+                out = A.short_attention(q, k, v, self.n_heads, fast[1], spec.causal, self.dropout, self.training, scale=1.0, bias=fast[0],
+                                        k_slot=k_slot)
                 return _linear(self.o, out)
         mask = spec.dense(q.dtype) if spec is not None else (None if bias is None else bias.to(q.dtype))
-        out = F.scaled_dot_product_attention(self._shape(q, B), self._shape(k, B), self._shape(v, B), attn_mask=mask,
+        out = F.scaled_dot_product_attention(self._shape(q, B), self._shape(k.contiguous(), B), self._shape(v, B), attn_mask=mask,
                                              dropout_p=self.dropout if self.training else 0.0, scale=1.0)
         return _linear(self.o, out.transpose(1, 2).reshape(B, Lq, self.inner))
 
@@ -358,9 +365,9 @@ class T5LayerCrossAttention(nn.Module):
                                            value_adapter=bool(config.use_decoder_enc_attn_value_parallel_adapter_down_dim))
         self.layer_norm = T5LayerNorm(config.d_model, eps=config.layer_norm_epsilon)
 
-    def forward(self, hidden, enc, bias, task=None):
+    def forward(self, hidden, enc, bias, task=None, k_pre=None):
         nl = _new_norm_link(hidden)
-        y = self.EncDecAttention(_normed(self.layer_norm, hidden, nl), bias, kv=enc, task=task)
+        y = self.EncDecAttention(_normed(self.layer_norm, hidden, nl), bias, kv=enc, task=task, k_pre=k_pre)
         return _tail_linked(hidden, y, self.p, self.training, nl, layer=self)
 
 
@@ -391,10 +398,10 @@ class T5Block(nn.Module):
         layers.append(T5LayerFF(config, is_decoder))
         self.layer = nn.ModuleList(layers)
 
-    def forward(self, hidden, self_bias, enc=None, cross_bias=None, task=None):
+    def forward(self, hidden, self_bias, enc=None, cross_bias=None, task=None, k_pre=None):
         hidden = self.layer[0](hidden, self_bias, task)
         if self.is_decoder:
-            hidden = self.layer[1](hidden, enc, cross_bias, task)
+            hidden = self.layer[1](hidden, enc, cross_bias, task, k_pre=k_pre)
         return self.layer[-1](hidden, task)
 
 
@@ -458,6 +465,28 @@ class T5Decoder(nn.Module):
         _wire_next_norms(self.block, self.final_layer_norm)
         self.p = config.dropout_rate
 
+    def _cross_keys_ok(self, enc, cross_bias) -> bool:
+        """The blocks' cross-attention key projections as ONE GEMM (functional.cross_key_blocks; host/bart.py BartDecoder._cross_keys_ok)"""
+        from .. import attention as A
+        if not FUSE_CROSS_KEYS or EAGER_ATTENTION or len(self.block) < 2 or not enc.is_cuda or enc.dtype != torch.bfloat16:
+            return False
+        if not (FUSE_RESIDUAL_GRAD and FUSE_NORM_GRAD and torch.is_grad_enabled() and enc.requires_grad):
+            return False
+        atts = [blk.layer[1].EncDecAttention for blk in self.block]
+        if enc.shape[1] > A.MAX_LEN or atts[0].d_kv != A.HEAD_DIM or cross_bias.fast() is None:
+            return False
+        return not any(m.weight.requires_grad or m.bias is not None for a in atts for m in (a.q, a.k, a.v))
+
+    def _cross_keys(self, enc):
+        mods = [blk.layer[1].EncDecAttention.k for blk in self.block]
+        key = (enc.dtype, VF.FROZEN_EPOCH) + tuple((m.weight.data_ptr(), m.weight._version) for m in mods)
+        c = getattr(self, "_ck_cache", None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                w = torch.cat([m.weight.to(enc.dtype) for m in mods], 0).contiguous()
+            c = self._ck_cache = (key, w)
+        return VF.cross_key_blocks(enc, c[1], None, len(mods))
+
     def forward(self, input_ids, enc, enc_keep, task=None):
         B, L = input_ids.shape
         x = F.dropout(self.embed_tokens(input_ids), p=self.p, training=self.training)
@@ -466,9 +495,12 @@ class T5Decoder(nn.Module):
                              rel_trainable=sa0.relative_attention_bias.weight.requires_grad and torch.is_grad_enabled())
         cross_bias = AttnSpec(None, enc_keep, causal=False)      # (dense form: invert_attention_mask, (1 - keep) * -1e9 in fp32)
         from ..functional import fanout
-        encs = fanout(enc, len(self.block))         # one gradient sum for the encoder output instead of autograd's pairwise adds
-        for blk, e in zip(self.block, encs):
-            x = blk(x, self_bias, e, cross_bias, task)
+        n = len(self.block)
+        fused_keys = self._cross_keys_ok(enc, cross_bias)
+        encs = fanout(enc, n + (1 if fused_keys else 0))         # one gradient sum for the encoder output instead of autograd's pairwise adds
+        ks = self._cross_keys(encs[n]) if fused_keys else None
+        for i, (blk, e) in enumerate(zip(self.block, encs)):
+            x = blk(x, self_bias, e, cross_bias, task, k_pre=None if ks is None else (ks[0][i], None if ks[1] is None else (ks[1], i)))
         return F.dropout(self.final_layer_norm(x), p=self.p, training=self.training)
 
 
