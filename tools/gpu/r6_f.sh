@@ -1,29 +1,27 @@
 #!/bin/bash
-# round 6, GPU pass f: pass 2 of the K1 backward with the down side's dx1 / dx2 rows staged through LDS (64-byte runs of 16 rows per store
-# instruction) vs lane-per-row 16-byte stores (libvlpet_hip_ab.so = the same sources with -DVLPET_COLS_STAGED=0): parity, then ABBA
+# round 6, GPU pass f: final validation (fanout sum, fused cross-attention keys on top of pass r):
+# whole GPU suite, smoke, bench lines of every config (LoRA r = 64 / 8 replayed, BART replayed at the full batch, emulated ranks)
 O=gpurun_out/r6f; mkdir -p $O
 export HIP_FORCE_DEV_KERNARG=1
-timeout 900 python -m pytest tests/test_gpu_cols.py tests/test_gpu_fullsize.py -x -q 2>&1 | grep -v amdgpu.ids | tail -5 | tee $O/pytest.txt
-AB=$PWD/vl-pet_amd/lib/libvlpet_hip_ab.so
-for arm in ab new new ab; do
-  if [ $arm = ab ]; then export VLPET_LIB=$AB; else unset VLPET_LIB; fi
-  python tools/k1red.py 15272 28000 31616 46648 2>&1 | grep -v amdgpu.ids | sed "s/^/$arm /" | tee -a $O/k1red.txt
-done
-unset VLPET_LIB
-for arm in ab new new ab; do
-  if [ $arm = ab ]; then export VLPET_LIB=$AB; else unset VLPET_LIB; fi
-  timeout 600 python bench.py --steps 24 --warmup 4 --no-cpu-baseline > $O/bench_${arm}_$RANDOM.json.log 2>&1
-done
-unset VLPET_LIB
+timeout 2700 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids | tail -12 | tee $O/pytest_gpu.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3 | tee $O/smoke.txt
+timeout 600 python bench.py --steps 20 --warmup 4 > $O/bench_bart.json.log 2>&1
+timeout 600 python bench.py --graph off --steps 20 --warmup 4 --no-cpu-baseline > $O/bench_bart_eager.json.log 2>&1
+timeout 600 python bench.py --model t5 --steps 12 --warmup 4 --no-cpu-baseline > $O/bench_t5.json.log 2>&1
+timeout 600 python bench.py --model lora --steps 20 --warmup 4 --no-cpu-baseline > $O/bench_lora.json.log 2>&1
+timeout 600 python bench.py --model lora --lora-r 8 --steps 12 --warmup 4 --no-cpu-baseline > $O/bench_lora_r8.json.log 2>&1
+timeout 600 python bench.py --model video --steps 8 --warmup 3 --no-cpu-baseline > $O/bench_video.json.log 2>&1
+timeout 600 python bench.py --emulate-ranks 8 --steps 20 --warmup 6 --no-cpu-baseline > $O/bench_bart_rank1of8.json.log 2>&1
+timeout 600 python bench.py --model t5 --emulate-ranks 8 --steps 20 --warmup 6 --no-cpu-baseline > $O/bench_t5_rank1of8.json.log 2>&1
 python - <<'P' | tee $O/summary.txt
 import json, glob
-for f in sorted(glob.glob("gpurun_out/r6f/bench_*.json.log")):
+for f in sorted(glob.glob("gpurun_out/r6f/bench_*.log")):
     ok = False
     for l in open(f):
         if l.startswith("{"):
             ok = True
             j = json.loads(l); k = j["kernels"]
-            print(f.split("/")[-1], j["value"], "steady", j["steady_state"]["value"], "op_us", j["roofline"].get("op_avg_us"), "frac", j["roofline"]["frac"],
-                  {n: k[n]["avg_us"] for n in ("k1_bwd_rows", "k1_bwd_wgrad", "k1_bwd_fin") if n in k}, {t: v["median"] for t, v in j["step_ms_by_task"].items()})
-    if not ok: print(f, "NO JSON", open(f).read()[-800:])
+            print(f.split("/")[-1], j["value"], j["ms_per_step"], "median", j["step_ms_median"], "steady", j["steady_state"]["value"], "peak GB", j.get("peak_memory_GB"), "frac", j["roofline"]["frac"], "op_us", j["roofline"].get("op_avg_us"),
+                  {n: k[n]["avg_us"] for n in ("k1_fwd", "k1_bwd_rows", "k1_bwd_wgrad", "k1_bwd_fin", "k5_fwd", "k5_bwd", "k4_fwd", "k4_wgrad", "k2_fwd", "k2_bwd", "k3_fwd", "k3_bwd") if n in k})
+    if not ok: print(f, "NO JSON"); print(open(f).read()[-1200:])
 P
