@@ -496,6 +496,14 @@ int vlpet_act_dropout_fwd(const void* x, void* out, uint8_t* keep_out, int64_t n
                           int io_dtype, vlpet_stream_t stream);
 int vlpet_act_dropout_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, float p, uint64_t seed,
                           int io_dtype, vlpet_stream_t stream);
+/* The joint encoder's input assembly: x [B, La + Lv, d] = dropout(cat([a [B, La, d], v [B, Lv, d]], dim = 1), p) in one pass, and its
+ * backward dx -> da, dv (either NULL: not wanted) with the mask regenerated from (p, seed) -- instead of a concatenation pass, a dropout
+ * pass that also writes a byte mask, a masked-scale pass and one copy per slice of the gradient.
+ * replaces: src/modeling_bart.py:804-820 (inputs_embeds = torch.cat([inputs_embeds, vis_embeds], dim=1); F.dropout), T5: src/modeling_t5.py:263, 300. */
+int vlpet_concat_dropout_fwd(const void* a, const void* v, void* x, int64_t B, int La, int Lv, int d, float p, uint64_t seed,
+                             int io_dtype, vlpet_stream_t stream);
+int vlpet_concat_dropout_bwd(const void* dx, void* da, void* dv, int64_t B, int La, int Lv, int d, float p, uint64_t seed,
+                             int io_dtype, vlpet_stream_t stream);
 
 /* ---- LM-head cross entropy (the loss of the training step; src/modeling_bart.py:1574-1586, src/modeling_t5.py:680-694) --
  * CrossEntropyLoss(ignore_index=-100, reduction='none') on logits [N, V] stored with a row stride of ld elements

@@ -86,3 +86,39 @@ def test_host_encoder_layer_uses_the_fused_activation(monkeypatch):
     monkeypatch.setattr(HB, "ffn_activation", lambda x, act, p, tr: F.dropout(F.gelu(x), p=p, training=tr))
     y_ref = layer(x)
     assert rel_err(y, y_ref) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,La,Lv,d,p", [(5, 20, 36, 768, 0.1), (3, 7, 72, 64, 0.3), (4, 40, 36, 768, 0.0), (500, 20, 36, 768, 0.1)])
+def test_concat_dropout_is_cat_then_dropout_with_the_regenerated_mask(B, La, Lv, d, p, dtype):
+    """act.concat_dropout (src/modeling_bart.py:804-820): x = dropout(cat([a, v], 1)); every element is either 0 or its source / (1 - p),
+    the kept fraction is 1 - p, and the backward applies the SAME mask to the two slices of the gradient."""
+    from vlpet_amd.act import concat_dropout
+    torch.manual_seed(0)
+    a = (torch.randn(B, La, d) + 3.0).cuda().to(dtype).requires_grad_(True)       # (bounded away from 0: a zero output is a dropped element)
+    v = (torch.randn(B, Lv, d) - 3.0).cuda().to(dtype).requires_grad_(True)
+    x = concat_dropout(a, v, p, training=True, seed=11)
+    ref = torch.cat([a, v], 1).detach().float()
+    keep = x.detach().float() != 0
+    if p == 0.0:
+        assert torch.equal(x.detach(), torch.cat([a, v], 1).detach())
+    else:
+        frac = float(keep.float().mean())
+        assert abs(frac - (1 - p)) < 0.02, frac
+        scaled = (ref / (1 - p)).to(dtype).float()
+        assert float(((x.detach().float() - scaled) * keep).abs().max()) <= 2.0 ** -7 * float(scaled.abs().max())
+    dx = torch.randn(B, La + Lv, d).cuda().to(dtype)
+    x.backward(dx)
+    want = (dx.float() * keep / (1 - p)).to(dtype).float()
+    assert float((a.grad.float() - want[:, :La]).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
+    assert float((v.grad.float() - want[:, La:]).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
+    # the same seed gives the same mask; eval mode is the plain concatenation
+    x2 = concat_dropout(a, v, p, training=True, seed=11)
+    assert torch.equal(x2, x)
+    assert torch.equal(concat_dropout(a, v, p, training=False), torch.cat([a, v], 1))
+    # only one side wants a gradient
+    v2 = v.detach()
+    x3 = concat_dropout(a, v2, p, training=True, seed=11)
+    a.grad = None
+    x3.backward(dx)
+    assert float((a.grad.float() - want[:, :La]).abs().max()) <= 2.0 ** -7 * float(want.abs().max())

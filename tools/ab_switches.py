@@ -3,7 +3,7 @@ VLPET_AB=1): the product package itself reads nothing from the environment at im
     VLPET_NO_LINK=1, VLPET_NO_GEMM_LINK=1, VLPET_NO_NORM_LINK=1, VLPET_NO_LORA_LINK=1, VLPET_NO_BIAS_GRAD_KERNEL=1, VLPET_NO_FUSED_QKV=1,
     VLPET_EAGER_FFN_ACT=1, VLPET_EAGER_LM_LOSS=1, VLPET_EAGER_ATTENTION=1, VLPET_EAGER_RMS_NORM=1, VLPET_SPLIT_WIDE=1, VLPET_SDPA=flash|efficient|math, VLPET_NO_DEFER_REDUCES=1,
     VLPET_K4_FORM=gemm|library|fused, VLPET_SAVE_PRENORM=auto|0|1, VLPET_NO_TAIL_NORM_FUSION=1, VLPET_NO_ALIAS_RESIDUAL_GRAD=1,
-    VLPET_K1_BWD_FROM_X2=1, VLPET_DEFER_FINALIZE=1, VLPET_FINALIZE_SIDE_STREAM=1, VLPET_FINALIZE_LAUNCH=1, VLPET_NO_POS_KERNEL=1, VLPET_NO_FANOUT_SUM=1, VLPET_NO_FUSED_CROSS_KEYS=1"""
+    VLPET_K1_BWD_FROM_X2=1, VLPET_DEFER_FINALIZE=1, VLPET_FINALIZE_SIDE_STREAM=1, VLPET_FINALIZE_LAUNCH=1, VLPET_NO_POS_KERNEL=1, VLPET_NO_FANOUT_SUM=1, VLPET_NO_FUSED_CROSS_KEYS=1, VLPET_NO_CONCAT_DROPOUT=1"""
 import os
 
 
@@ -50,6 +50,8 @@ def apply():
     put(VF, "DEFER_FINALIZE", on("VLPET_DEFER_FINALIZE"))                       # weight-gradient finalize launches queued and issued 16 per launch at the end of the backward (default off: no gain)
     put(VF, "FINALIZE_SIDE_STREAM", on("VLPET_FINALIZE_SIDE_STREAM"))          # captured steps: K1's finalize launch as a parallel branch of the graph (default off: slower)
     put(VF, "K1_BWD_FROM_OUTPUT", not on("VLPET_K1_BWD_FROM_X2"))               # gated K1 backward from the forward's output y (default) | from x2
+    import vlpet_amd.act as ACT
+    put(ACT, "FUSE_CONCAT_DROPOUT", not on("VLPET_NO_CONCAT_DROPOUT"))          # the joint encoder's cat + dropout as one pass each way | torch.cat + F.dropout
     put(VF, "FANOUT_SUM", not on("VLPET_NO_FANOUT_SUM"))                        # the encoder output's gradient summed in one launch (vlpet_sum_n) | autograd's pairwise adds
     put(TR, "IN_LAUNCH_REDUCE", not on("VLPET_FINALIZE_LAUNCH"))               # VLPET_FINALIZE_LAUNCH=1: the K1 / K2 / K3 backward passes end in a finalize launch (round 3) instead of the in-launch reduce-scatter
     return changed

@@ -137,6 +137,8 @@ SIGNATURES = {
     "vlpet_attn_bwd_ld": (c_int, [c_void_p] * 10 + [c_int] * 7 + [c_float, c_float, c_uint64, c_void_p]),
     "vlpet_attn_fwd_bias": (c_int, [c_void_p] * 8 + [c_int] * 7 + [c_float, c_float, c_uint64, c_void_p]),
     "vlpet_attn_bwd_bias": (c_int, [c_void_p] * 12 + [c_int] * 7 + [c_float, c_float, c_uint64, c_void_p]),
+    "vlpet_concat_dropout_fwd": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_int, c_int, c_float, c_uint64, c_int, c_void_p]),
+    "vlpet_concat_dropout_bwd": (c_int, [c_void_p] * 3 + [c_int64, c_int, c_int, c_int, c_float, c_uint64, c_int, c_void_p]),
     "vlpet_attn_fwd_kv": (c_int, [c_void_p] * 8 + [c_int] * 8 + [c_float, c_float, c_uint64, c_void_p]),
     "vlpet_attn_bwd_kv": (c_int, [c_void_p] * 12 + [c_int] * 8 + [c_float, c_float, c_uint64, c_void_p]),
     "vlpet_ce_loss_fwd": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_void_p]),

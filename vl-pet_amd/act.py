@@ -64,3 +64,55 @@ def act_dropout(x: torch.Tensor, act: str = "gelu", p: float = 0.0, training: bo
     if seed is None:
         seed = _draw_seed() if pe > 0.0 else 0
     return _ActDropFn.apply(x, ACTS[act], pe, int(seed), bool(return_mask))
+
+
+# ------------------------------------------------------------------------------------------------ joint-encoder input assembly
+FUSE_CONCAT_DROPOUT = True      # A/B switch (tools/ab_switches.py: VLPET_NO_CONCAT_DROPOUT=1): torch.cat + F.dropout instead
+
+
+class _ConcatDropFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, v, p, seed):
+        lib = _lib.load()
+        _need_cuda(a, v)
+        ac, vc = a.contiguous(), v.contiguous()
+        B, La, d = ac.shape
+        Lv = vc.shape[1]
+        io = _io_dtype(ac)
+        x = torch.empty(B, La + Lv, d, dtype=ac.dtype, device=ac.device)
+        rc = _timed("concat_drop_fwd", B * (La + Lv), lambda: lib.vlpet_concat_dropout_fwd(
+            ac.data_ptr(), vc.data_ptr(), x.data_ptr(), B, La, Lv, d, float(p), seed, io, _stream()))
+        _lib.check(rc, "vlpet_concat_dropout_fwd")
+        ctx.cfg = (B, La, Lv, d, float(p), seed, io, ac.dtype)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        lib = _lib.load()
+        B, La, Lv, d, p, seed, io, dtype = ctx.cfg
+        dxc = dx.contiguous()
+        if dxc.dtype != dtype:
+            dxc = dxc.to(dtype)
+        da = torch.empty(B, La, d, dtype=dtype, device=dx.device) if ctx.needs_input_grad[0] else None
+        dv = torch.empty(B, Lv, d, dtype=dtype, device=dx.device) if ctx.needs_input_grad[1] else None
+        if da is None and dv is None:
+            return None, None, None, None
+        rc = _timed("concat_drop_bwd", B * (La + Lv), lambda: lib.vlpet_concat_dropout_bwd(
+            dxc.data_ptr(), _ptr(da), _ptr(dv), B, La, Lv, d, p, seed, io, _stream()))
+        _lib.check(rc, "vlpet_concat_dropout_bwd")
+        return da, dv, None, None
+
+
+def concat_dropout(a: torch.Tensor, v: torch.Tensor, p: float = 0.0, training: bool = False, seed=None) -> torch.Tensor:
+    """``F.dropout(torch.cat([a, v], dim=1), p, training)`` for ``a [B, La, d]``, ``v [B, Lv, d]`` in one HIP pass each way
+    (src/modeling_bart.py:804-820: the joint encoder's text | visual concatenation and the dropout behind it); plain torch ops where
+    the kernel does not apply (CPU tensors, other dtypes, widths not a multiple of 8)."""
+    pe = float(p) if training else 0.0
+    ok = (FUSE_CONCAT_DROPOUT and a.is_cuda and v.is_cuda and a.dim() == 3 and v.dim() == 3 and a.dtype == v.dtype
+          and a.dtype in (torch.bfloat16, torch.float32) and a.shape[0] == v.shape[0] and a.shape[2] == v.shape[2] and a.shape[2] % 8 == 0
+          and a.shape[0] > 0 and a.shape[1] > 0 and v.shape[1] > 0)
+    if not ok:
+        return torch.nn.functional.dropout(torch.cat([a, v], dim=1), p=p, training=training)
+    if seed is None:
+        seed = _draw_seed() if pe > 0.0 else 0
+    return _ConcatDropFn.apply(a, v, pe, int(seed))

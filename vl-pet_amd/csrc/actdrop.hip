@@ -125,3 +125,59 @@ static hipError_t launch_act_io(const ActDropArgs& a, bool bwd, hipStream_t stre
 hipError_t launch_act_dropout(const ActDropArgs& a, bool bwd, int io_fp32, hipStream_t stream) {
     return io_fp32 ? launch_act_io<float>(a, bwd, stream) : launch_act_io<__bf16>(a, bwd, stream);
 }
+
+// ------------------------------------------------------------------------------------------------ joint-encoder input assembly
+// x = dropout(cat([a, v], dim = 1), p): a [B, La, d] (the embedded, layer-normed text), v [B, Lv, d] (the visual embedding, K4's output),
+// x [B, La + Lv, d] -- src/modeling_bart.py:804-820 (JointEncoder.forward: inputs_embeds = cat([inputs_embeds, vis_embeds], dim=1), then
+// F.dropout); T5: src/modeling_t5.py:263, 300.  The library chain is a concatenation pass, a dropout pass that also writes a byte mask,
+// and in the backward a masked-scale pass plus one copy per slice of the gradient; here one pass each way, the mask regenerated
+// (rng.h, keyed by the element index of x).  BWD: dx -> da, dv (either may be nullptr: no gradient wanted).
+struct CatDropArgs {
+    const void* a; const void* v; void* x;      // forward: a, v in, x out.  backward: x = dx in, a / v = da / dv out
+    int64_t B; int La, Lv, d;
+    uint32_t thr; float keep_scale; uint64_t seed; const uint64_t* seed_ctr;
+};
+template <typename IO, bool DROP, bool BWD>
+__global__ __launch_bounds__(256) void cat_dropout_kernel(CatDropArgs c) {
+    const int gpr = c.d >> 3, L = c.La + c.Lv;                     // groups of 8 elements per row
+    const int64_t groups = c.B * (int64_t)L * gpr;
+    const uint64_t seed = DROP ? vlpet_eff_seed(c.seed, c.seed_ctr) : 0;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = g / gpr;
+        const int col = (int)(g - row * gpr);
+        const int64_t b = row / L;
+        const int t = (int)(row - b * L);
+        const bool text = t < c.La;
+        const int64_t sg = text ? (b * c.La + t) * (int64_t)gpr + col : (b * c.Lv + (t - c.La)) * (int64_t)gpr + col;     // group index inside a / v
+        void* side = const_cast<void*>(text ? c.a : c.v);
+        uint32_t bits = 0xffu;
+        if constexpr (DROP) bits = keep8(g, seed, c.thr);
+        Vec8<IO> in, o;
+        if constexpr (BWD) {
+            if (side == nullptr) continue;
+            in.load(c.x, g);
+        } else in.load(side, sg);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.set(j, ((bits >> j) & 1u) ? in.get(j) * c.keep_scale : 0.f);
+        if constexpr (BWD) o.store(side, sg);
+        else o.store(c.x, g);
+    }
+}
+hipError_t launch_cat_dropout(const void* a, const void* v, void* x, int64_t B, int La, int Lv, int d, uint32_t thr, float keep_scale,
+                              uint64_t seed, const uint64_t* seed_ctr, bool bwd, int io_fp32, hipStream_t stream) {
+    CatDropArgs c{a, v, x, B, La, Lv, d, thr, keep_scale, seed, seed_ctr};
+    const int64_t groups = B * (int64_t)(La + Lv) * (d >> 3);
+    if (groups == 0) return hipSuccess;
+    int64_t blocks = (groups + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const dim3 grid((unsigned)blocks), blk(256);
+    const bool drop = thr != 0;
+#define VLPET_CD(IO) \
+    if (bwd) { if (drop) hipLaunchKernelGGL((cat_dropout_kernel<IO, true, true>), grid, blk, 0, stream, c); \
+               else hipLaunchKernelGGL((cat_dropout_kernel<IO, false, true>), grid, blk, 0, stream, c); } \
+    else { if (drop) hipLaunchKernelGGL((cat_dropout_kernel<IO, true, false>), grid, blk, 0, stream, c); \
+           else hipLaunchKernelGGL((cat_dropout_kernel<IO, false, false>), grid, blk, 0, stream, c); }
+    if (io_fp32) { VLPET_CD(float) } else { VLPET_CD(__bf16) }
+#undef VLPET_CD
+    return hipGetLastError();
+}

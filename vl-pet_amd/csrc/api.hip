@@ -1482,6 +1482,29 @@ extern "C" int vlpet_act_dropout_fwd(const void* x, void* out, uint8_t* keep_out
     return herr(launch_act_dropout(a, false, io_dtype == VLPET_F32, (hipStream_t)stream));
 }
 
+// x [B, La + Lv, d] = dropout(cat([a [B, La, d], v [B, Lv, d]], dim = 1), p): the joint encoder's input assembly (src/modeling_bart.py:804-820)
+extern "C" int vlpet_concat_dropout_fwd(const void* a, const void* v, void* x, int64_t B, int La, int Lv, int d, float p, uint64_t seed,
+                                        int io_dtype, vlpet_stream_t stream) {
+    if (!a || !v || !x) return VLPET_E_NULL;
+    if (B <= 0 || La <= 0 || Lv <= 0 || d <= 0 || d % 8 != 0 || !(p >= 0.f && p < 1.f)) return VLPET_E_SHAPE;
+    if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    if (!aligned16(a) || !aligned16(v) || !aligned16(x)) return VLPET_E_ALIGN;
+    const uint32_t thr = tail_thr(p);
+    return herr(launch_cat_dropout(a, v, x, B, La, Lv, d, thr, thr ? 1.0f / (1.0f - p) : 1.0f, seed, g_seed_ctr.load(), false,
+                                   io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+// ... backward: dx [B, La + Lv, d] -> da [B, La, d], dv [B, Lv, d] (either NULL: not wanted), the mask regenerated from (p, seed)
+extern "C" int vlpet_concat_dropout_bwd(const void* dx, void* da, void* dv, int64_t B, int La, int Lv, int d, float p, uint64_t seed,
+                                        int io_dtype, vlpet_stream_t stream) {
+    if (!dx || (!da && !dv)) return VLPET_E_NULL;
+    if (B <= 0 || La <= 0 || Lv <= 0 || d <= 0 || d % 8 != 0 || !(p >= 0.f && p < 1.f)) return VLPET_E_SHAPE;
+    if (!dtype_ok(io_dtype)) return VLPET_E_DTYPE;
+    if (!aligned16(dx) || (da && !aligned16(da)) || (dv && !aligned16(dv))) return VLPET_E_ALIGN;
+    const uint32_t thr = tail_thr(p);
+    return herr(launch_cat_dropout(da, dv, const_cast<void*>(dx), B, La, Lv, d, thr, thr ? 1.0f / (1.0f - p) : 1.0f, seed, g_seed_ctr.load(), true,
+                                   io_dtype == VLPET_F32, (hipStream_t)stream));
+}
+
 extern "C" int vlpet_act_dropout_bwd(const void* dy, const void* x, void* dx, int64_t n, int act, float p, uint64_t seed,
                                      int io_dtype, vlpet_stream_t stream) {
     int rc = act_common(n, act, p, io_dtype);

@@ -414,6 +414,9 @@ struct ActDropArgs {
     const uint64_t* seed_ctr;   // optional device step counter mixed into the seed (rng.h vlpet_eff_seed)
 };
 hipError_t launch_act_dropout(const ActDropArgs& a, bool bwd, int io_fp32, hipStream_t stream);
+// x = dropout(cat([a, v], dim = 1), p) over [B, La | Lv, d] (actdrop.hip); bwd: x = dx in, a / v = da / dv out (nullptr: not wanted)
+hipError_t launch_cat_dropout(const void* a, const void* v, void* x, int64_t B, int La, int Lv, int d, uint32_t thr, float keep_scale,
+                              uint64_t seed, const uint64_t* seed_ctr, bool bwd, int io_fp32, hipStream_t stream);
 
 // token-level cross entropy over the LM-head logits (celoss.hip)
 struct CeArgs {

@@ -461,9 +461,10 @@ class JointEncoder(nn.Module):
         vis = self.visual_embedding(feats, boxes, img_ids, obj_ids).to(x.dtype)   # K4
         if self.config.share_vis_lang_layer_norm:
             x = self.layernorm_embedding(torch.cat([x, vis], dim=1))
+            x = F.dropout(x, p=self.dropout, training=self.training)
         else:
-            x = torch.cat([self.layernorm_embedding(x), vis], dim=1)
-        x = F.dropout(x, p=self.dropout, training=self.training)
+            from ..act import concat_dropout
+            x = concat_dropout(self.layernorm_embedding(x), vis, self.dropout, self.training)      # cat + dropout: one pass each way
         mask = None
         if attention_mask is not None:      # [B, L] text padding mask; visual tokens always attended
             full = torch.cat([attention_mask.bool(), torch.ones(B, vis.shape[1], dtype=torch.bool,

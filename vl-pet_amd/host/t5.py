@@ -438,7 +438,8 @@ class JointEncoder(nn.Module):
         obj_ids = vis_inputs[3] if len(vis_inputs) == 4 else None
         vis = self.visual_embedding(feats, boxes, img_ids, obj_ids).to(x.dtype)             # K4
         V = vis.shape[1]
-        x = torch.cat([x, vis], dim=1)
+        from ..act import concat_dropout
+        x = concat_dropout(x, vis, self.p, self.training)      # cat + dropout (src/modeling_t5.py:263, 300): one pass each way
         if attention_mask is None:
             attention_mask = input_ids.ne(self.config.pad_token_id)
         full = torch.cat([attention_mask.to(torch.float32), torch.ones(B, V, device=x.device)], dim=1)
@@ -448,7 +449,6 @@ class JointEncoder(nn.Module):
         rel = text_bias.new_zeros(1, text_bias.shape[1], L + V, L + V)
         rel[:, :, :L, :L] = text_bias
         bias = AttnSpec(rel, full, causal=False, rel_trainable=sa0.relative_attention_bias.weight.requires_grad and torch.is_grad_enabled())
-        x = F.dropout(x, p=self.p, training=self.training)
         for blk in self.block:
             x = blk(x, bias, task=task)
         x = F.dropout(self.final_layer_norm(x), p=self.p, training=self.training)
