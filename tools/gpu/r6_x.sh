@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 6, GPU pass x2 (after fanout / vlpet_sum_n and the d = 1024 position-kernel change): the whole GPU suite + smoke + the default bench line at HEAD (after the diagnosis build was rebuilt)
-O=gpurun_out/r6x2; mkdir -p $O
+# round 6, GPU pass x3 (after the fused cross-attention keys and concat_dropout): the whole GPU suite + smoke + the default bench line at HEAD (after the diagnosis build was rebuilt)
+O=gpurun_out/r6x3; mkdir -p $O
 export HIP_FORCE_DEV_KERNARG=1
 timeout 2700 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids | tail -6 | tee $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3 | tee $O/smoke.txt
